@@ -1,0 +1,218 @@
+// TEST INFRASTRUCTURE ONLY -- drives the REAL reference (ITBE-Lab/ma, compiled from /root/reference into
+// oracle/_ref/libma_ref.so by Makefile.ref) and dumps per-stage results in the text format that
+// oracle_dump (our CPU restatement) also emits, so the two can be diffed byte-for-byte.
+// This file is our own harness; it includes the reference's public headers where they lie and
+// never travels to the GPU box in compiled-from-reference form other than oracle/_ref/.
+//
+// usage:
+//   ref_dump index <case> <out_prefix>                 -> <prefix>.pac/.ann/.amb/.bwt/.sa (reference writers)
+//   ref_dump pipe  <case> <preset> <srand_seed> <out>   -> per-read stage dump
+//   ref_dump ext   <case> <out>                        -> extend_backward traces
+//   ref_dump ksw   <kswcase> <out> [dirty]             -> kswcpp_dispatch results
+#include "ma/container/fMIndex.h"
+#include "ma/container/pack.h"
+#include "ma/module/binarySeeding.h"
+#include "ma/module/harmonization.h"
+#include "ma/module/mappingQuality.h"
+#include "ma/module/needlemanWunsch.h"
+#include "ma/module/stripOfConsideration.h"
+#include "kswcpp.h"
+#include "dump_format.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+using namespace libMA;
+using namespace libMS;
+
+static std::shared_ptr<NucSeq> mkSeq( const std::vector<uint8_t>& v )
+{
+    auto p = std::make_shared<NucSeq>( );
+    if( !v.empty( ) )
+        p->vAppend( v.data( ), v.size( ) );
+    return p;
+}
+
+struct RefIndex
+{
+    std::shared_ptr<Pack> pPack;
+    std::shared_ptr<FMIndex> pFM;
+};
+
+static RefIndex buildIndex( const CaseFile& c )
+{
+    RefIndex r;
+    r.pPack = std::make_shared<Pack>( );
+    for( size_t i = 0; i < c.contigs.size( ); i++ )
+        r.pPack->vAppendSequence( c.names[ i ], "", *mkSeq( c.contigs[ i ] ) );
+    r.pFM = std::make_shared<FMIndex>( r.pPack );
+    return r;
+}
+
+static int cmdIndex( const char* sCase, const char* sPrefix )
+{
+    CaseFile c = readCase( sCase );
+    RefIndex idx = buildIndex( c );
+    idx.pPack->vStoreCollection( sPrefix );
+    idx.pFM->vStoreFMIndex( sPrefix );
+    return 0;
+}
+
+static void dumpSeeds( FILE* f, const char* tag, Seeds& s )
+{
+    for( auto& x : s )
+        fprintf( f, "%s %llu %llu %llu %u %d %llu\n", tag, (unsigned long long)x.start( ), (unsigned long long)x.size( ),
+                 (unsigned long long)x.start_ref( ), x.uiAmbiguity, (int)x.bOnForwStrand,
+                 (unsigned long long)x.uiDelta );
+}
+
+static int cmdPipe( const char* sCase, const char* sPreset, unsigned uiSeed, const char* sOut )
+{
+    CaseFile c = readCase( sCase );
+    RefIndex idx = buildIndex( c );
+    ParameterSetManager xParams;
+    xParams.setSelected( sPreset );
+    BinarySeeding xSeeding( xParams );
+    StripOfConsideration xSoc( xParams );
+    Harmonization xHarm( xParams );
+    NeedlemanWunsch xDp( xParams );
+    MappingQuality xMq( xParams );
+    FILE* f = fopen( sOut, "w" );
+    for( size_t i = 0; i < c.reads.size( ); i++ )
+    {
+        auto pQ = mkSeq( c.reads[ i ] );
+        pQ->sName = "r" + std::to_string( i );
+        fprintf( f, "R %zu %zu\n", i, c.reads[ i ].size( ) );
+        auto pSegs = xSeeding.execute( idx.pFM, pQ );
+        fprintf( f, "SEG %zu\n", pSegs->size( ) );
+        for( auto& s : *pSegs )
+            fprintf( f, "s %llu %llu %lld %lld %lld\n", (unsigned long long)s.start( ), (unsigned long long)s.size( ),
+                     (long long)s.saInterval( ).start( ), (long long)s.saInterval( ).startRevComp( ),
+                     (long long)s.saInterval( ).size( ) );
+        {
+            auto pSeeds = xSoc.xExtractHelper.execute( pSegs, idx.pFM, pQ, idx.pPack );
+            fprintf( f, "SEED %zu\n", pSeeds->size( ) );
+            dumpSeeds( f, "d", *pSeeds );
+            // SoC pop order on a private queue
+            auto pSocs = xSoc.xHelper.execute( pSeeds, pQ, idx.pPack );
+            fprintf( f, "SOC %zu\n", pSocs->size( ) );
+            while( !pSocs->empty( ) )
+            {
+                auto uiScore = std::get<0>( pSocs->vMaxima.front( ) ).uiAccumulativeLength;
+                auto uiAmb = std::get<0>( pSocs->vMaxima.front( ) ).uiSeedAmbiguity;
+                auto p = pSocs->pop( );
+                fprintf( f, "c %u %llu %u %zu\n", p->xStats.index_of_strip, (unsigned long long)uiScore, uiAmb,
+                         p->size( ) );
+                dumpSeeds( f, "e", *p );
+            }
+        }
+        auto pSocs = xSoc.execute( pSegs, pQ, idx.pPack, idx.pFM );
+        srand( uiSeed );
+        auto pHarm = xHarm.execute( pSocs, pQ, idx.pFM );
+        fprintf( f, "HARM %zu\n", pHarm->size( ) );
+        for( auto& pS : *pHarm )
+        {
+            fprintf( f, "h %u %zu\n", pS->xStats.index_of_strip, pS->size( ) );
+            dumpSeeds( f, "g", *pS );
+        }
+        auto pAlns = xDp.execute( pHarm, pQ, idx.pPack );
+        fprintf( f, "ALN %zu\n", pAlns->size( ) );
+        for( auto& pA : *pAlns )
+        {
+            fprintf( f, "a %llu %llu %llu %llu %lld %u %zu", (unsigned long long)pA->uiBeginOnRef,
+                     (unsigned long long)pA->uiEndOnRef, (unsigned long long)pA->uiBeginOnQuery,
+                     (unsigned long long)pA->uiEndOnQuery, (long long)pA->iScore, pA->xStats.index_of_strip,
+                     pA->data.size( ) );
+            for( auto& d : pA->data )
+                fprintf( f, " %d:%llu", (int)d.first, (unsigned long long)d.second );
+            fprintf( f, "\n" );
+        }
+        auto pMq = xMq.execute( pQ, pAlns );
+        fprintf( f, "MQ %zu\n", pMq->size( ) );
+        for( auto& pA : *pMq )
+            fprintf( f, "m %llu %llu %llu %llu %lld %d %d %.17g\n", (unsigned long long)pA->uiBeginOnRef,
+                     (unsigned long long)pA->uiEndOnRef, (unsigned long long)pA->uiBeginOnQuery,
+                     (unsigned long long)pA->uiEndOnQuery, (long long)pA->iScore, (int)pA->bSecondary,
+                     (int)pA->bSupplementary, pA->fMappingQuality );
+    }
+    fclose( f );
+    return 0;
+}
+
+static int cmdExt( const char* sCase, const char* sOut )
+{
+    CaseFile c = readCase( sCase );
+    RefIndex idx = buildIndex( c );
+    FILE* f = fopen( sOut, "w" );
+    for( size_t i = 0; i < c.reads.size( ); i++ )
+    {
+        auto& q = c.reads[ i ];
+        fprintf( f, "R %zu %zu\n", i, q.size( ) );
+        if( q.empty( ) || q.back( ) >= 4 )
+            continue;
+        SAInterval ik = idx.pFM->init_interval( q.back( ) );
+        fprintf( f, "i %lld %lld %lld\n", (long long)ik.start( ), (long long)ik.startRevComp( ), (long long)ik.size( ) );
+        for( size_t j = q.size( ) - 1; j-- > 0 && ik.size( ) > 0; )
+        {
+            for( uint8_t cc = 0; cc < 5; cc++ )
+            {
+                SAInterval ok = idx.pFM->extend_backward( ik, cc );
+                fprintf( f, "x %d %lld %lld %lld\n", (int)cc, (long long)ok.start( ), (long long)ok.startRevComp( ),
+                         (long long)ok.size( ) );
+            }
+            ik = idx.pFM->extend_backward( ik, q[ j ] );
+        }
+        // SA lookups over the final (small) interval
+        if( ik.size( ) > 0 && ik.size( ) <= 64 )
+            for( auto p = ik.start( ); p < ik.end( ); p++ )
+                fprintf( f, "p %lld %lld\n", (long long)p, (long long)idx.pFM->bwt_sa( p ) );
+    }
+    fclose( f );
+    return 0;
+}
+
+static int cmdKsw( const char* sCase, const char* sOut, bool bDirty )
+{
+    std::vector<KswCase> v = readKswCases( sCase );
+    FILE* f = fopen( sOut, "w" );
+    KswCppParam<5> xP( 2, 4, 4, 2, 24, 1 );
+    AlignedMemoryManager xShared;
+    for( size_t i = 0; i < v.size( ); i++ )
+    {
+        auto& k = v[ i ];
+        kswcpp_extz_t ez{ };
+        if( bDirty )
+            kswcpp_dispatch( (int)k.q.size( ), k.q.data( ), (int)k.t.size( ), k.t.data( ), xP, k.w, k.zdrop, k.flag, &ez,
+                             xShared );
+        else
+        {
+            AlignedMemoryManager xMem;
+            kswcpp_dispatch( (int)k.q.size( ), k.q.data( ), (int)k.t.size( ), k.t.data( ), xP, k.w, k.zdrop, k.flag, &ez,
+                             xMem );
+        }
+        fprintf( f, "k %zu %u %u %d %d %d %d %d %d %d %d %d", i, (unsigned)ez.max, (unsigned)ez.zdropped, ez.max_q,
+                 ez.max_t, ez.mqe, ez.mqe_t, ez.mte, ez.mte_q, ez.score, ez.reach_end, ez.n_cigar );
+        for( int j = 0; j < ez.n_cigar; j++ )
+            fprintf( f, " %u", ez.cigar[ j ] );
+        fprintf( f, "\n" );
+        free( ez.cigar );
+    }
+    fclose( f );
+    return 0;
+}
+
+int main( int argc, char** argv )
+{
+    if( argc >= 4 && !strcmp( argv[ 1 ], "index" ) )
+        return cmdIndex( argv[ 2 ], argv[ 3 ] );
+    if( argc >= 6 && !strcmp( argv[ 1 ], "pipe" ) )
+        return cmdPipe( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ] );
+    if( argc >= 4 && !strcmp( argv[ 1 ], "ext" ) )
+        return cmdExt( argv[ 2 ], argv[ 3 ] );
+    if( argc >= 4 && !strcmp( argv[ 1 ], "ksw" ) )
+        return cmdKsw( argv[ 2 ], argv[ 3 ], argc >= 5 );
+    fprintf( stderr, "usage: ref_dump index|pipe|ext|ksw ...\n" );
+    return 2;
+}
