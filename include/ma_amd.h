@@ -1,0 +1,177 @@
+/* ma_amd.h -- C ABI of the MI355X-native seed-and-extend engine (libma_amd.so).
+ *
+ * This is the drop-in boundary for MA's hot path.  Every entry point is plain C (pointers + sizes,
+ * no C++/torch types) so the reference's host code (C++ via a thin wrapper, or Python via ctypes)
+ * can bind it.  Each function cites the reference interface it replaces (paths relative to the
+ * ITBE-Lab/ma source tree).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; ma_last_error() gives the message
+ *     (the C++ module wrappers in ma_amd/host turn that into std::runtime_error, mirroring
+ *     libs/ms/inc/ms/module/module.h:339-377).
+ *   - nothing here falls back to a CPU path: without a HIP device every compute call fails.
+ *   - all positions follow the reference: reference positions r in [0, 2F) on T.revcomp(T),
+ *     query positions q in [0,|Q|), bases A0 C1 G2 T3, N = 4 (nucSeq.cpp:17-28).
+ */
+#ifndef MA_AMD_H
+#define MA_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MA_AMD_ABI_VERSION 1
+
+typedef struct ma_index ma_index; /* device-resident FMD-index + pack (FMIndex fMIndex.h:195-230, Pack pack.h:39-176) */
+typedef struct ma_batch ma_batch; /* device-resident batch of reads + all stage outputs */
+
+/* Parameters the path reads (parameter.h:521-1060); same fields/meaning as the reference's
+ * Presetting/GlobalParameter members named in the comments of ma_params_default(). */
+typedef struct
+{
+    int32_t seeding_technique; /* 0 maxSpan, 1 SMEMs            xSeedingTechnique  (binarySeeding.h:560) */
+    int32_t min_seed_len; /* 16                                  xMinSeedLength */
+    int32_t min_ambiguity; /* 0                                  xMinimalSeedAmbiguity */
+    int32_t max_ambiguity; /* 100                                xMaximalSeedAmbiguity */
+    int32_t min_seed_size_drop; /* 15                            xMinimalSeedSizeDrop */
+    int32_t max_num_soc, min_num_soc; /* 30 / 1                  xMaxNumSoC / xMinNumSoC */
+    int32_t harm_score_min; /* 18                                xHarmScoreMin */
+    int32_t max_score_lookahead; /* 3                            xMaxScoreLookahead */
+    int32_t switch_qlen; /* 800                                  xSwitchQlen */
+    int32_t min_delta_dist; /* 16                                xMinDeltaDist */
+    int32_t max_gap_area; /* 20                                  xMaxGapArea */
+    int32_t padding; /* 1000                                     xPadding */
+    int32_t bandwidth_ext; /* 512                                xBandwidthDPExtension */
+    int32_t min_bandwidth_gap; /* 20                             xMinBandwidthGapFilling */
+    int32_t zdrop; /* 200                                        xZDrop */
+    int32_t sv_penalty; /* 100                                   pGlobalParams->uiSVPenalty */
+    int32_t match, mismatch, gap, extend, gap2, extend2; /* 2 4 4 2 24 1 (pGlobalParams) */
+    int32_t disable_heuristics; /* 0                             xDisableHeuristics */
+    int32_t soc_width; /* 0                                      xSoCWidth */
+    uint32_t srand_seed; /* RANSAC draws: glibc srand(seed) state at the start of each read's Harmonization */
+    uint64_t genome_size_disable; /* 10 000 000                  xGenomeSizeDisable */
+    double rel_min_seed_size_amount; /* 0.005                    xRelMinSeedSizeAmount */
+    double harm_score_min_rel; /* 0.002                          xHarmScoreMinRel */
+    double soc_score_decrease_tol; /* 0.1                        xSoCScoreDecreaseTolerance */
+    double score_diff_tol; /* 0.0001                             xScoreDiffTolerance */
+    double max_delta_dist; /* 0.1                                xMaxDeltaDist */
+    int32_t min_alignment_score; /* 75                           xMinAlignmentScore */
+    int32_t report_n_best; /* 0                                  xReportN */
+    int32_t max_supplementary; /* 1                              xMaxSupplementaryPerPrim */
+    double max_overlap_supplementary; /* 0.1                     xMaxOverlapSupplementary */
+} ma_params;
+
+/* ParameterSetManager presets (parameter.h:1079-1087) */
+void ma_params_default( ma_params* p );
+void ma_params_illumina( ma_params* p );
+
+/* Records (same layout as the oracle's records so parity tests compare raw arrays) */
+typedef struct
+{
+    int64_t q_start, q_size, sa_start, sa_start_rc, sa_size; /* Segment (segment.h:31-113): size = length-1 */
+} ma_segment;
+typedef struct
+{
+    int64_t q_start, len, r_start, delta; /* Seed (seed.h:34-46) */
+    uint32_t ambiguity, on_forward;
+} ma_seed;
+typedef struct
+{
+    int32_t max, zdropped, max_q, max_t, mqe, mqe_t, mte, mte_q, score, reach_end, n_cigar; /* kswcpp_extz_t (kswcpp.h:31-41) */
+} ma_ez;
+typedef struct
+{
+    int64_t begin_ref, end_ref, begin_q, end_q, score; /* Alignment (alignment.h:55-84) */
+    uint32_t soc_index, n_ops;
+    uint64_t ops_off; /* first (type,len) pair of this alignment in the ops array */
+    uint32_t secondary, supplementary;
+    double mapq;
+} ma_alignment;
+typedef struct
+{
+    int32_t qlen, tlen, w, zdrop, flag; /* kswcpp_dispatch arguments (kswcpp.h:165-190) */
+    uint32_t reserved;
+    uint64_t q_off, t_off; /* offsets into the query / target byte arrays handed to ma_ksw_batch */
+} ma_ksw_job;
+
+/* ---- runtime ---- */
+const char* ma_last_error( void ); /* thread-local message of the last failing call */
+int ma_abi_version( void );
+int ma_device_count( int* n );
+int ma_set_device( int device );
+
+/* ---- index: replaces FMIndex(std::string) / Pack(std::string) loading (fMIndex.h:952-955, pack.h:513-525) ---- */
+/* Upload an index whose arrays were read from the reference's own .bwt/.sa/.pac files. */
+int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t* sa, uint64_t n_sa,
+                     const uint64_t L2[ 5 ], int64_t primary, uint64_t ref_len_fwd_rev, const uint8_t* pac,
+                     int32_t n_contigs, const uint64_t* contig_starts, const uint64_t* contig_lens, ma_index** out );
+/* Build pack + FMD-index on the GPU from N-free contigs (host codes 0..3); replaces
+ * FMIndex::build_FMIndex (fMIndex.cpp:316-391) + Pack::vAppendSequence (pack.h:586-698). Produces
+ * byte-identical .bwt/.sa/.pac content. */
+int ma_index_build( int32_t n_contigs, const uint64_t* contig_lens, const uint8_t* codes_concat, ma_index** out );
+/* Same, for a genome that already lives in device memory as 1 byte/base codes. */
+int ma_index_build_device( int32_t n_contigs, const uint64_t* contig_lens, const void* d_codes, ma_index** out );
+int ma_index_destroy( ma_index* );
+int ma_index_sizes( const ma_index*, uint64_t* n_words, uint64_t* n_sa, uint64_t* ref_len, int32_t* n_contigs );
+/* Download (for FMIndex::vStoreFMIndex-compatible files and for tests); any pointer may be NULL. */
+int ma_index_download( const ma_index*, uint32_t* bwt_words, int64_t* sa, uint64_t L2[ 5 ], int64_t* primary,
+                       uint8_t* pac, uint64_t* contig_starts, uint64_t* contig_lens );
+
+/* ---- primitive ops (tests / SuffixArrayInterface seam, fMIndex.h:155-175) ---- */
+/* n independent FMIndex::extend_backward calls (fMIndex.cpp:21-101): ik[3n] -> ok[3n] (host arrays) */
+int ma_extend_backward_batch( const ma_index*, const int64_t* ik, const uint8_t* c, uint64_t n, int64_t* ok );
+/* n independent FMIndex::bwt_sa calls (fMIndex.h:788-814) */
+int ma_bwt_sa_batch( const ma_index*, const int64_t* rows, uint64_t n, int64_t* pos );
+/* n independent kswcpp_dispatch calls (kswcpp.h:165-190). ez[n]; cigars concatenated into cigar[]
+ * with cigar_off[n+1]; returns error if cigar_cap is too small. */
+int ma_ksw_batch( const ma_params*, const ma_ksw_job* jobs, uint64_t n, const uint8_t* q_bytes, uint64_t q_len,
+                  const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off, uint32_t* cigar,
+                  uint64_t cigar_cap );
+
+/* ---- batch pipeline: BinarySeeding -> StripOfConsideration -> Harmonization -> NeedlemanWunsch -> MappingQuality
+ *      as wired in libMA::setUpCompGraph (libs/ma/src/util/export.cpp:104-108) ---- */
+int ma_batch_create( const ma_index*, const ma_params*, uint64_t max_reads, uint64_t max_bases, ma_batch** out );
+int ma_batch_destroy( ma_batch* );
+/* stream: a hipStream_t (as void*) all stage kernels of this batch are launched on; NULL = default stream */
+int ma_batch_set_stream( ma_batch*, void* hip_stream );
+/* reads as 1 byte/base codes, CSR offsets[n+1]; host or device pointers */
+int ma_batch_set_reads( ma_batch*, const uint8_t* codes, const uint64_t* offsets, uint64_t n_reads );
+int ma_batch_set_reads_device( ma_batch*, const void* d_codes, const void* d_offsets, uint64_t n_reads,
+                               uint64_t n_bases );
+/* stages (asynchronous on the batch stream; each requires the previous one) */
+int ma_seed_batch( ma_batch* ); /* BinarySeeding::execute (binarySeeding.cpp:86-178) */
+int ma_extract_seeds_batch( ma_batch* ); /* ExtractSeeds::execute (stripOfConsideration.h:138-157) */
+int ma_chain_batch( ma_batch* ); /* StripOfConsiderationSeeds::execute + Harmonization::execute */
+int ma_dp_batch( ma_batch* ); /* NeedlemanWunsch::execute + MappingQuality::execute */
+int ma_align_batch( ma_batch* ); /* all four */
+int ma_batch_sync( ma_batch* ); /* wait for the stream; surfaces asynchronous kernel errors / capacity overflows */
+
+/* results: counts first, then download into caller-allocated arrays (any pointer may be NULL) */
+int ma_batch_counts( ma_batch*, uint64_t* n_segments, uint64_t* n_seeds, uint64_t* n_hsets, uint64_t* n_hseeds,
+                     uint64_t* n_alignments, uint64_t* n_ops, uint64_t* n_aligned_reads );
+int ma_batch_get_segments( ma_batch*, uint64_t* seg_off /*n+1*/, ma_segment* segs );
+int ma_batch_get_seeds( ma_batch*, uint64_t* seed_off /*n+1*/, ma_seed* seeds );
+int ma_batch_get_hsets( ma_batch*, uint64_t* hset_off /*n+1*/, uint64_t* hseed_off /*n_hsets+1*/, uint32_t* hset_soc,
+                        ma_seed* hseeds );
+int ma_batch_get_alignments( ma_batch*, uint64_t* aln_off /*n+1*/, ma_alignment* alns, uint64_t* ops /*2*n_ops*/ );
+int ma_batch_get_mapq_alignments( ma_batch*, uint64_t* aln_off /*n+1*/, ma_alignment* alns, uint64_t* ops );
+/* work counters for the roofline model (same meaning as the oracle's): [0] extend_backward steps,
+ * [1] distinct occ blocks touched, [2] bwt_sa LF steps, [3] SA rows, [4] DP band cells, [5] ksw jobs */
+int ma_batch_counters( ma_batch*, uint64_t out[ 8 ] );
+/* per-kernel HIP-event times of the last stage calls in ms: [0] seeding [1] sa-lookup [2] chaining
+ * [3] dp-jobs [4] ksw [5] stitch; requires ma_batch_enable_timing(b,1) */
+int ma_batch_enable_timing( ma_batch*, int on );
+int ma_batch_kernel_ms( ma_batch*, float out[ 8 ] );
+
+/* ---- synthetic workloads (BASELINE.json configs; deterministic counter-based generators) ---- */
+/* genome: d_codes[total] (device, 1 byte/base). reads sampled from it: device CSR. */
+int ma_synth_genome_device( uint64_t seed, uint64_t total_len, int32_t with_repeats, void* d_codes );
+int ma_synth_reads_device( const ma_index*, uint64_t seed, uint64_t n_reads, uint32_t read_len, double sub_rate,
+                           double ins_rate, double del_rate, uint64_t first_read_index, void* d_codes,
+                           void* d_offsets, uint64_t codes_cap, uint64_t* n_bases );
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MA_AMD_H */

@@ -1,0 +1,299 @@
+"""ctypes binding of include/ma_amd.h (the drop-in C ABI)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libma_amd.so")
+
+
+class MaError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("seeding_technique", C.c_int32), ("min_seed_len", C.c_int32), ("min_ambiguity", C.c_int32),
+        ("max_ambiguity", C.c_int32), ("min_seed_size_drop", C.c_int32), ("max_num_soc", C.c_int32),
+        ("min_num_soc", C.c_int32), ("harm_score_min", C.c_int32), ("max_score_lookahead", C.c_int32),
+        ("switch_qlen", C.c_int32), ("min_delta_dist", C.c_int32), ("max_gap_area", C.c_int32),
+        ("padding", C.c_int32), ("bandwidth_ext", C.c_int32), ("min_bandwidth_gap", C.c_int32),
+        ("zdrop", C.c_int32), ("sv_penalty", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
+        ("gap", C.c_int32), ("extend", C.c_int32), ("gap2", C.c_int32), ("extend2", C.c_int32),
+        ("disable_heuristics", C.c_int32), ("soc_width", C.c_int32), ("srand_seed", C.c_uint32),
+        ("genome_size_disable", C.c_uint64), ("rel_min_seed_size_amount", C.c_double),
+        ("harm_score_min_rel", C.c_double), ("soc_score_decrease_tol", C.c_double),
+        ("score_diff_tol", C.c_double), ("max_delta_dist", C.c_double), ("min_alignment_score", C.c_int32),
+        ("report_n_best", C.c_int32), ("max_supplementary", C.c_int32), ("max_overlap_supplementary", C.c_double),
+    ]
+
+    @staticmethod
+    def preset(name="default"):
+        p = Params()
+        if name.lower() == "illumina":
+            lib().ma_params_illumina(C.byref(p))
+        else:
+            lib().ma_params_default(C.byref(p))
+        return p
+
+
+SEGMENT_DT = np.dtype([("q_start", "<i8"), ("q_size", "<i8"), ("sa_start", "<i8"), ("sa_start_rc", "<i8"),
+                       ("sa_size", "<i8")])
+SEED_DT = np.dtype([("q_start", "<i8"), ("len", "<i8"), ("r_start", "<i8"), ("delta", "<i8"), ("ambiguity", "<u4"),
+                    ("on_forward", "<u4")])
+EZ_DT = np.dtype([(k, "<i4") for k in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score",
+                                       "reach_end", "n_cigar")])
+ALIGNMENT_DT = np.dtype([("begin_ref", "<i8"), ("end_ref", "<i8"), ("begin_q", "<i8"), ("end_q", "<i8"),
+                         ("score", "<i8"), ("soc_index", "<u4"), ("n_ops", "<u4"), ("ops_off", "<u8"),
+                         ("secondary", "<u4"), ("supplementary", "<u4"), ("mapq", "<f8")])
+KSW_JOB_DT = np.dtype([("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("zdrop", "<i4"), ("flag", "<i4"),
+                       ("reserved", "<u4"), ("q_off", "<u8"), ("t_off", "<u8")])
+
+_lib = None
+
+
+def lib():
+    """Loads libma_amd.so; fails loudly when the HIP extension was not built."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise MaError("libma_amd.so is missing (%s): run __graft_entry__.build(); there is no CPU fallback" % p)
+        _lib = C.CDLL(p)
+        _lib.ma_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise MaError(lib().ma_last_error().decode(errors="replace"))
+
+
+def _ptr(a, t=C.c_void_p):
+    if a is None:
+        return None
+    return a.ctypes.data_as(t)
+
+
+def device_count():
+    n = C.c_int(0)
+    _chk(lib().ma_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(d):
+    _chk(lib().ma_set_device(C.c_int(d)))
+
+
+class Index:
+    """Device-resident FMD-index + pack (ma_index*)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @staticmethod
+    def from_arrays(bwt, sa, L2, primary, ref_len, pac, contig_starts, contig_lens):
+        bwt = np.ascontiguousarray(bwt, dtype=np.uint32)
+        sa = np.ascontiguousarray(sa, dtype=np.int64)
+        L2 = np.ascontiguousarray(L2, dtype=np.uint64)
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        cs = np.ascontiguousarray(contig_starts, dtype=np.uint64)
+        cl = np.ascontiguousarray(contig_lens, dtype=np.uint64)
+        h = C.c_void_p()
+        _chk(lib().ma_index_create(_ptr(bwt), C.c_uint64(len(bwt)), _ptr(sa), C.c_uint64(len(sa)), _ptr(L2),
+                                   C.c_int64(int(primary)), C.c_uint64(int(ref_len)), _ptr(pac), C.c_int32(len(cs)),
+                                   _ptr(cs), _ptr(cl), C.byref(h)))
+        return Index(h)
+
+    @staticmethod
+    def build(contigs):
+        """GPU index construction from N-free contigs (list of uint8 code arrays)."""
+        lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+        cat = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint8) for c in contigs]))
+        h = C.c_void_p()
+        _chk(lib().ma_index_build(C.c_int32(len(lens)), _ptr(lens), _ptr(cat), C.byref(h)))
+        return Index(h)
+
+    @staticmethod
+    def build_device(contig_lens, d_codes_ptr):
+        lens = np.ascontiguousarray(contig_lens, dtype=np.uint64)
+        h = C.c_void_p()
+        _chk(lib().ma_index_build_device(C.c_int32(len(lens)), _ptr(lens), C.c_void_p(int(d_codes_ptr)), C.byref(h)))
+        return Index(h)
+
+    def sizes(self):
+        nw, ns, rl, nc = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_int32()
+        _chk(lib().ma_index_sizes(self.h, C.byref(nw), C.byref(ns), C.byref(rl), C.byref(nc)))
+        return nw.value, ns.value, rl.value, nc.value
+
+    def download(self):
+        nw, ns, rl, nc = self.sizes()
+        bwt = np.empty(nw, dtype=np.uint32)
+        sa = np.empty(ns, dtype=np.int64)
+        L2 = np.zeros(5, dtype=np.uint64)
+        primary = C.c_int64()
+        pac = np.empty((rl // 2 + 3) // 4, dtype=np.uint8)
+        cs = np.empty(nc, dtype=np.uint64)
+        cl = np.empty(nc, dtype=np.uint64)
+        _chk(lib().ma_index_download(self.h, _ptr(bwt), _ptr(sa), _ptr(L2), C.byref(primary), _ptr(pac), _ptr(cs),
+                                     _ptr(cl)))
+        return dict(bwt=bwt, sa=sa, L2=L2, primary=primary.value, ref_len=rl, pac=pac, contig_starts=cs,
+                    contig_lens=cl)
+
+    def extend_backward(self, ik, c):
+        ik = np.ascontiguousarray(ik, dtype=np.int64).reshape(-1, 3)
+        c = np.ascontiguousarray(c, dtype=np.uint8)
+        ok = np.empty_like(ik)
+        _chk(lib().ma_extend_backward_batch(self.h, _ptr(ik), _ptr(c), C.c_uint64(len(c)), _ptr(ok)))
+        return ok
+
+    def bwt_sa(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        pos = np.empty_like(rows)
+        _chk(lib().ma_bwt_sa_batch(self.h, _ptr(rows), C.c_uint64(len(rows)), _ptr(pos)))
+        return pos
+
+    def close(self):
+        if self.h:
+            lib().ma_index_destroy(self.h)
+            self.h = None
+
+
+def ksw_batch(params, cases, cigar_cap=None):
+    """cases: list of (q, t, w, zdrop, flag) -> (ez structured array, list of cigar arrays)"""
+    n = len(cases)
+    jobs = np.zeros(n, dtype=KSW_JOB_DT)
+    qs, ts = [], []
+    qo = to = 0
+    for i, (q, t, w, zd, fl) in enumerate(cases):
+        jobs[i] = (len(q), len(t), w, zd, fl, 0, qo, to)
+        qs.append(np.asarray(q, dtype=np.uint8))
+        ts.append(np.asarray(t, dtype=np.uint8))
+        qo += len(q)
+        to += len(t)
+    qb = np.ascontiguousarray(np.concatenate(qs + [np.zeros(1, dtype=np.uint8)]))
+    tb = np.ascontiguousarray(np.concatenate(ts + [np.zeros(1, dtype=np.uint8)]))
+    if cigar_cap is None:
+        cigar_cap = qo + to + 2 * n + 16
+    ez = np.zeros(n, dtype=EZ_DT)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    cig = np.zeros(cigar_cap, dtype=np.uint32)
+    _chk(lib().ma_ksw_batch(C.byref(params), _ptr(jobs), C.c_uint64(n), _ptr(qb), C.c_uint64(len(qb)), _ptr(tb),
+                            C.c_uint64(len(tb)), _ptr(ez), _ptr(off), _ptr(cig), C.c_uint64(cigar_cap)))
+    cigs = [cig[int(off[i]):int(off[i]) + int(ez["n_cigar"][i])].copy() for i in range(n)]
+    return ez, cigs
+
+
+class Batch:
+    """Device-resident batch of reads and stage outputs (ma_batch*)."""
+
+    def __init__(self, index, params, max_reads, max_bases):
+        self.index = index
+        self.params = params
+        self.h = C.c_void_p()
+        _chk(lib().ma_batch_create(index.h, C.byref(params), C.c_uint64(max_reads), C.c_uint64(max_bases),
+                                   C.byref(self.h)))
+        self.n = 0
+
+    def set_stream(self, stream_ptr):
+        _chk(lib().ma_batch_set_stream(self.h, C.c_void_p(int(stream_ptr))))
+
+    def enable_timing(self, on=True):
+        _chk(lib().ma_batch_enable_timing(self.h, C.c_int(1 if on else 0)))
+
+    def set_reads(self, reads):
+        """reads: list of uint8 code arrays"""
+        off = np.zeros(len(reads) + 1, dtype=np.uint64)
+        if len(reads):
+            off[1:] = np.cumsum([len(r) for r in reads])
+            cat = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint8) for r in reads]
+                                                      + [np.zeros(1, dtype=np.uint8)]))
+        else:
+            cat = np.zeros(1, dtype=np.uint8)
+        _chk(lib().ma_batch_set_reads(self.h, _ptr(cat), _ptr(off), C.c_uint64(len(reads))))
+        self.n = len(reads)
+
+    def set_reads_device(self, d_codes_ptr, d_offsets_ptr, n_reads, n_bases):
+        _chk(lib().ma_batch_set_reads_device(self.h, C.c_void_p(int(d_codes_ptr)), C.c_void_p(int(d_offsets_ptr)),
+                                             C.c_uint64(n_reads), C.c_uint64(n_bases)))
+        self.n = n_reads
+
+    def seed(self):
+        _chk(lib().ma_seed_batch(self.h))
+
+    def extract(self):
+        _chk(lib().ma_extract_seeds_batch(self.h))
+
+    def chain(self):
+        _chk(lib().ma_chain_batch(self.h))
+
+    def dp(self):
+        _chk(lib().ma_dp_batch(self.h))
+
+    def align(self):
+        _chk(lib().ma_align_batch(self.h))
+
+    def sync(self):
+        _chk(lib().ma_batch_sync(self.h))
+
+    def counts(self):
+        v = [C.c_uint64() for _ in range(7)]
+        _chk(lib().ma_batch_counts(self.h, *[C.byref(x) for x in v]))
+        keys = ("segments", "seeds", "hsets", "hseeds", "alignments", "ops_cap", "aligned_reads")
+        return dict(zip(keys, [x.value for x in v]))
+
+    def counters(self):
+        out = np.zeros(8, dtype=np.uint64)
+        _chk(lib().ma_batch_counters(self.h, _ptr(out)))
+        return out
+
+    def kernel_ms(self):
+        out = np.zeros(8, dtype=np.float32)
+        _chk(lib().ma_batch_kernel_ms(self.h, _ptr(out)))
+        return out
+
+    def segments(self):
+        c = self.counts()
+        off = np.zeros(self.n + 1, dtype=np.uint64)
+        segs = np.zeros(c["segments"], dtype=SEGMENT_DT)
+        _chk(lib().ma_batch_get_segments(self.h, _ptr(off), _ptr(segs)))
+        return off, segs
+
+    def seeds(self):
+        c = self.counts()
+        off = np.zeros(self.n + 1, dtype=np.uint64)
+        seeds = np.zeros(c["seeds"], dtype=SEED_DT)
+        _chk(lib().ma_batch_get_seeds(self.h, _ptr(off), _ptr(seeds)))
+        return off, seeds
+
+    def hsets(self):
+        c = self.counts()
+        hoff = np.zeros(self.n + 1, dtype=np.uint64)
+        soff = np.zeros(c["hsets"] + 1, dtype=np.uint64)
+        soc = np.zeros(c["hsets"], dtype=np.uint32)
+        seeds = np.zeros(c["hseeds"], dtype=SEED_DT)
+        _chk(lib().ma_batch_get_hsets(self.h, _ptr(hoff), _ptr(soff), _ptr(soc), _ptr(seeds)))
+        return hoff, soff, soc, seeds[: int(soff[-1])]
+
+    def _alns(self, fn):
+        c = self.counts()
+        off = np.zeros(self.n + 1, dtype=np.uint64)
+        alns = np.zeros(c["alignments"], dtype=ALIGNMENT_DT)
+        ops = np.zeros(2 * c["ops_cap"] + 2, dtype=np.uint64)
+        _chk(fn(self.h, _ptr(off), _ptr(alns), _ptr(ops)))
+        return off, alns[: int(off[-1])], ops
+
+    def alignments(self):
+        return self._alns(lib().ma_batch_get_alignments)
+
+    def mapq_alignments(self):
+        return self._alns(lib().ma_batch_get_mapq_alignments)
+
+    def close(self):
+        if self.h:
+            lib().ma_batch_destroy(self.h)
+            self.h = None

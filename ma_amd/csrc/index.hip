@@ -1,0 +1,210 @@
+// index.hip -- index handle: upload / download of the FMD-index + pack (FMIndex::vLoadFMIndex
+// fMIndex.h:555-663, Pack::vLoadCollection pack.h:271-470 replaced by ma_index_create), runtime helpers.
+#include "internal.h"
+#include <cstring>
+
+namespace ma
+{
+static thread_local std::string g_err;
+void set_error( const std::string& s )
+{
+    g_err = s;
+}
+int fail( const std::string& s )
+{
+    g_err = s;
+    return 1;
+}
+int DevBuf::reserve( size_t bytes )
+{
+    if( bytes <= cap && p )
+        return 0;
+    if( p )
+    {
+        (void)hipFree( p );
+        p = nullptr;
+        cap = 0;
+    }
+    if( bytes == 0 )
+        bytes = 16;
+    hipError_t e = hipMalloc( &p, bytes );
+    if( e != hipSuccess )
+    {
+        p = nullptr;
+        return fail( std::string( "hipMalloc(" ) + std::to_string( bytes ) + "): " + hipGetErrorString( e ) );
+    }
+    cap = bytes;
+    return 0;
+}
+void DevBuf::release( )
+{
+    if( p )
+        (void)hipFree( p );
+    p = nullptr;
+    cap = 0;
+}
+} // namespace ma
+
+using namespace ma;
+
+extern "C" {
+
+const char* ma_last_error( void )
+{
+    return g_err.c_str( );
+}
+int ma_abi_version( void )
+{
+    return MA_AMD_ABI_VERSION;
+}
+int ma_device_count( int* n )
+{
+    MA_HIP( hipGetDeviceCount( n ) );
+    return 0;
+}
+int ma_set_device( int device )
+{
+    MA_HIP( hipSetDevice( device ) );
+    return 0;
+}
+
+void ma_params_default( ma_params* p )
+{
+    memset( p, 0, sizeof( *p ) );
+    p->seeding_technique = 0;
+    p->min_seed_len = 16;
+    p->min_ambiguity = 0;
+    p->max_ambiguity = 100;
+    p->min_seed_size_drop = 15;
+    p->max_num_soc = 30;
+    p->min_num_soc = 1;
+    p->harm_score_min = 18;
+    p->max_score_lookahead = 3;
+    p->switch_qlen = 800;
+    p->min_delta_dist = 16;
+    p->max_gap_area = 20;
+    p->padding = 1000;
+    p->bandwidth_ext = 512;
+    p->min_bandwidth_gap = 20;
+    p->zdrop = 200;
+    p->sv_penalty = 100;
+    p->match = 2;
+    p->mismatch = 4;
+    p->gap = 4;
+    p->extend = 2;
+    p->gap2 = 24;
+    p->extend2 = 1;
+    p->disable_heuristics = 0;
+    p->soc_width = 0;
+    p->srand_seed = 1;
+    p->genome_size_disable = 10000000;
+    p->rel_min_seed_size_amount = 0.005;
+    p->harm_score_min_rel = 0.002;
+    p->soc_score_decrease_tol = 0.1;
+    p->score_diff_tol = 0.0001;
+    p->max_delta_dist = 0.1;
+    p->min_alignment_score = 75;
+    p->report_n_best = 0;
+    p->max_supplementary = 1;
+    p->max_overlap_supplementary = 0.1;
+}
+void ma_params_illumina( ma_params* p )
+{
+    ma_params_default( p );
+    p->seeding_technique = 1;
+    p->max_ambiguity = 500;
+    p->min_num_soc = 10;
+    p->max_num_soc = 20;
+}
+
+int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t* sa, uint64_t n_sa,
+                     const uint64_t L2[ 5 ], int64_t primary, uint64_t ref_len, const uint8_t* pac, int32_t n_contigs,
+                     const uint64_t* contig_starts, const uint64_t* contig_lens, ma_index** out )
+{
+    if( !bwt_words || !sa || !pac || !out || n_contigs <= 0 )
+        return fail( "ma_index_create: null argument" );
+    ma_index* x = new ma_index( );
+    MA_HIP( hipGetDevice( &x->device ) );
+    x->n_words = n_words;
+    x->n_sa = n_sa;
+    const uint64_t F = ref_len / 2;
+    if( x->bwt.reserve( n_words * 4 + 64 ) || x->sa.reserve( n_sa * 8 ) || x->pac.reserve( ( F + 3 ) / 4 + 16 ) ||
+        x->cstart.reserve( n_contigs * 8 ) || x->clen.reserve( n_contigs * 8 ) )
+    {
+        delete x;
+        return 1;
+    }
+    MA_HIP( hipMemcpy( x->bwt.p, bwt_words, n_words * 4, hipMemcpyHostToDevice ) );
+    MA_HIP( hipMemcpy( x->sa.p, sa, n_sa * 8, hipMemcpyHostToDevice ) );
+    MA_HIP( hipMemcpy( x->pac.p, pac, ( F + 3 ) / 4, hipMemcpyHostToDevice ) );
+    MA_HIP( hipMemcpy( x->cstart.p, contig_starts, n_contigs * 8, hipMemcpyHostToDevice ) );
+    MA_HIP( hipMemcpy( x->clen.p, contig_lens, n_contigs * 8, hipMemcpyHostToDevice ) );
+    x->h_cstart.assign( contig_starts, contig_starts + n_contigs );
+    x->h_clen.assign( contig_lens, contig_lens + n_contigs );
+    x->v.bwt = x->bwt.as<u32>( );
+    x->v.sa = x->sa.as<i64>( );
+    x->v.pac = x->pac.as<uint8_t>( );
+    x->v.cstart = x->cstart.as<u64>( );
+    x->v.clen = x->clen.as<u64>( );
+    x->v.n = ref_len;
+    x->v.F = F;
+    x->v.primary = primary;
+    for( int i = 0; i < 5; i++ )
+        x->v.L2[ i ] = L2[ i ];
+    x->v.n_contigs = n_contigs;
+    *out = x;
+    return 0;
+}
+
+int ma_index_destroy( ma_index* x )
+{
+    if( !x )
+        return 0;
+    x->bwt.release( );
+    x->sa.release( );
+    x->pac.release( );
+    x->cstart.release( );
+    x->clen.release( );
+    delete x;
+    return 0;
+}
+
+int ma_index_sizes( const ma_index* x, uint64_t* n_words, uint64_t* n_sa, uint64_t* ref_len, int32_t* n_contigs )
+{
+    if( !x )
+        return fail( "ma_index_sizes: null index" );
+    if( n_words )
+        *n_words = x->n_words;
+    if( n_sa )
+        *n_sa = x->n_sa;
+    if( ref_len )
+        *ref_len = x->v.n;
+    if( n_contigs )
+        *n_contigs = x->v.n_contigs;
+    return 0;
+}
+
+int ma_index_download( const ma_index* x, uint32_t* bwt_words, int64_t* sa, uint64_t L2[ 5 ], int64_t* primary,
+                       uint8_t* pac, uint64_t* contig_starts, uint64_t* contig_lens )
+{
+    if( !x )
+        return fail( "ma_index_download: null index" );
+    if( bwt_words )
+        MA_HIP( hipMemcpy( bwt_words, x->bwt.p, x->n_words * 4, hipMemcpyDeviceToHost ) );
+    if( sa )
+        MA_HIP( hipMemcpy( sa, x->sa.p, x->n_sa * 8, hipMemcpyDeviceToHost ) );
+    if( L2 )
+        for( int i = 0; i < 5; i++ )
+            L2[ i ] = x->v.L2[ i ];
+    if( primary )
+        *primary = x->v.primary;
+    if( pac )
+        MA_HIP( hipMemcpy( pac, x->pac.p, ( x->v.F + 3 ) / 4, hipMemcpyDeviceToHost ) );
+    if( contig_starts )
+        memcpy( contig_starts, x->h_cstart.data( ), x->h_cstart.size( ) * 8 );
+    if( contig_lens )
+        memcpy( contig_lens, x->h_clen.data( ), x->h_clen.size( ) * 8 );
+    return 0;
+}
+
+} // extern "C"

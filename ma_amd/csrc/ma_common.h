@@ -1,0 +1,88 @@
+// ma_common.h -- shared host/device definitions of the MI355X seed-and-extend engine.
+// All stage logic lives in MA_HD functions so that the very same code can be exercised on the CPU
+// by tests/host_emul (logic tests, "-m 'not gpu'") while the shipped path runs it inside HIP kernels.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/ma_amd.h"
+
+#if defined( __HIPCC__ )
+#include <hip/hip_runtime.h>
+#define MA_HD __host__ __device__ __forceinline__
+#define MA_HD_NOINLINE __host__ __device__
+#else
+#define MA_HD inline
+#define MA_HD_NOINLINE
+#endif
+
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef int32_t i32;
+
+namespace ma
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+MA_HD int popc32( u32 x )
+{
+    return __popc( x );
+}
+MA_HD int popc64( u64 x )
+{
+    return __popcll( x );
+}
+#else
+MA_HD int popc32( u32 x )
+{
+    return __builtin_popcount( x );
+}
+MA_HD int popc64( u64 x )
+{
+    return __builtin_popcountll( x );
+}
+#endif
+
+template <typename T> MA_HD T mmin( T a, T b )
+{
+    return a < b ? a : b;
+}
+template <typename T> MA_HD T mmax( T a, T b )
+{
+    return a > b ? a : b;
+}
+template <typename T> MA_HD void mswap( T& a, T& b )
+{
+    T t = a;
+    a = b;
+    b = t;
+}
+
+// Device-resident index view (FMIndex fMIndex.h:195-230 + Pack pack.h:39-176).
+// HBM layout: bwt = the reference's occ-injected word array, one 64-byte block per 128 nt:
+// 4 x u64 cumulative A/C/G/T counts followed by 8 x u32 words of 16 nt (2 bit each, MSB first).
+struct IndexView
+{
+    const u32* bwt; // 64-B aligned
+    const i64* sa; // every 32nd SA row, sa[0] = -1
+    const uint8_t* pac; // forward strand, 2 bit/base, MSB first
+    const u64* cstart; // contig start offsets (forward strand)
+    const u64* clen;
+    u64 n; // forward + reverse length
+    u64 F; // forward length
+    i64 primary;
+    u64 L2[ 5 ];
+    i32 n_contigs;
+};
+
+// error / overflow flags raised by kernels (checked in ma_batch_sync)
+enum : u32
+{
+    MA_ERR_SEG_OVERFLOW = 1u,
+    MA_ERR_SEED_OVERFLOW = 2u,
+    MA_ERR_STACK_OVERFLOW = 4u,
+    MA_ERR_CIGAR_OVERFLOW = 8u,
+    MA_ERR_OPS_OVERFLOW = 16u,
+    MA_ERR_SCRATCH_OVERFLOW = 32u,
+    MA_ERR_SMEM_OVERFLOW = 64u,
+};
+} // namespace ma

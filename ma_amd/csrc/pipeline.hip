@@ -1,0 +1,1365 @@
+// pipeline.hip -- the batch pipeline behind the C ABI: BinarySeeding -> ExtractSeeds -> SoC sweep +
+// Harmonization -> NeedlemanWunsch (job enumeration, batched ksw, stitch) -> MappingQuality, wired as in
+// libMA::setUpCompGraph (libs/ma/src/util/export.cpp:104-108) but over a whole batch of reads resident
+// in HBM.  Every stage is a HIP kernel; there is no host fallback.
+#include "chain.h"
+#include "ksw_launch.h"
+#include "nw.h"
+#include "seeding.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cstring>
+
+using namespace ma;
+
+// ------------------------------------------------------------------------------------------------
+// device-side counters of a batch
+// ------------------------------------------------------------------------------------------------
+enum : int
+{
+    CTR_SEG_USED = 0, // segment pool bump pointer
+    CTR_NEXT_READ = 1, // seeding read queue
+    CTR_STEPS = 2, // extend_backward steps
+    CTR_BLOCKS = 3, // distinct occ blocks touched
+    CTR_LF_STEPS = 4,
+    CTR_SA_ROWS = 5,
+    CTR_HSEED_USED = 6, // harmonized seed pool bump pointer
+    CTR_ERR = 7,
+    CTR_CIG_USED = 8,
+    CTR_CELLS = 9,
+    CTR_KSW_JOBS = 10,
+    CTR_NEXT_SLOT = 11,
+    CTR_MAX_STATE = 12, // ksw sizing (atomicMax)
+    CTR_MAX_H = 13,
+    CTR_MAX_P = 14,
+    CTR_MAX_CIG = 15,
+    CTR_N_JOBS = 16,
+    CTR_N_ALIGNED = 17,
+    CTR_COUNT = 32
+};
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+struct SeedKernelArgs
+{
+    IndexView X;
+    SeedParams P;
+    const uint8_t* reads;
+    const u64* roff;
+    u32 n_reads;
+    ma_segment* stage; // lanes * seg_cap
+    u32 seg_cap;
+    ma_segment* smem_a; // lanes * smem_cap
+    ma_segment* smem_b;
+    u32 smem_cap;
+    ma_segment* pool;
+    u32* pool_read; // read id per pooled segment
+    u64 pool_cap;
+    u64* seg_off; // per read
+    u32* seg_cnt; // per read
+    unsigned long long* ctr;
+};
+
+// One read per lane at a time; lanes refill from a global queue, so a wavefront keeps stepping 64
+// reads in lockstep through extend_backward until the batch is exhausted.
+__global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
+{
+    const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
+    SeedScratch S;
+    S.stage = A.stage + (u64)lane * A.seg_cap;
+    S.seg_cap = A.seg_cap;
+    S.smem_a = A.smem_a ? A.smem_a + (u64)lane * A.smem_cap : nullptr;
+    S.smem_b = A.smem_b ? A.smem_b + (u64)lane * A.smem_cap : nullptr;
+    S.smem_cap = A.smem_cap;
+    SeedLane L;
+    L.phase = PH_DONE;
+    u32 read = 0xffffffffu;
+    u64 steps = 0, blocks = 0;
+    while( true )
+    {
+        if( L.phase == PH_DONE )
+        {
+            if( read != 0xffffffffu )
+            {
+                // flush the finished read: staged segments -> pool
+                const u32 n = seed_finish( L, A.P, S, A.X );
+                const u64 off = atomicAdd( &A.ctr[ CTR_SEG_USED ], (unsigned long long)n );
+                if( off + n <= A.pool_cap )
+                {
+                    for( u32 k = 0; k < n; k++ )
+                    {
+                        A.pool[ off + k ] = S.stage[ k ];
+                        A.pool_read[ off + k ] = read;
+                    }
+                }
+                else
+                    L.err |= MA_ERR_SEG_OVERFLOW;
+                A.seg_off[ read ] = off;
+                A.seg_cnt[ read ] = off + n <= A.pool_cap ? n : 0;
+                if( L.err )
+                    atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)L.err );
+                steps += L.steps;
+                blocks += L.blocks;
+            }
+            read = (u32)atomicAdd( &A.ctr[ CTR_NEXT_READ ], 1ull );
+            if( read >= A.n_reads )
+                break;
+            seed_begin_read( L, A.reads + A.roff[ read ], (u32)( A.roff[ read + 1 ] - A.roff[ read ] ) );
+            continue;
+        }
+        u32 c;
+        if( seed_prepare( L, A.P, S, A.X, c ) )
+        {
+            i64 ok[ 3 ];
+            u32 nb;
+            extend_backward( A.X, L.ik, c, ok, nb );
+            L.steps++;
+            L.blocks += nb;
+            seed_apply( L, A.P, S, ok );
+        }
+    }
+    atomicAdd( &A.ctr[ CTR_STEPS ], (unsigned long long)steps );
+    atomicAdd( &A.ctr[ CTR_BLOCKS ], (unsigned long long)blocks );
+}
+
+// per pooled segment: number of seeds it yields (segment.h:316-349 filters)
+__global__ void k_seg_seed_counts( const ma_segment* pool, u64 n, u32 min_len, u32 max_amb, u64* cnt )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    const ma_segment s = pool[ i ];
+    u64 c = (u64)s.sa_size;
+    if( (u64)s.q_size < (u64)min_len )
+        c = 0;
+    if( s.sa_size > (i64)max_amb && max_amb != 0 )
+        c = 0; // bSkip == true (segment.h:365)
+    cnt[ i ] = c;
+}
+
+// per read: seed range = ranges of its segments (contiguous in the pool)
+__global__ void k_read_seed_ranges( const u64* seg_off, const u32* seg_cnt, const u64* seg_seed_off, u64 n_pool,
+                                    u64 total_seeds, u32 n_reads, u64* seed_off, u32* seed_cnt )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    const u64 b = seg_off[ r ], e = b + seg_cnt[ r ];
+    const u64 sb = seg_cnt[ r ] ? seg_seed_off[ b ] : 0;
+    const u64 se = seg_cnt[ r ] ? ( e < n_pool ? seg_seed_off[ e ] : total_seeds ) : 0;
+    seed_off[ r ] = sb;
+    seed_cnt[ r ] = (u32)( se - sb );
+}
+
+// one lane per seed: SA row -> reference position (Segment::forEachSeed segment.h:89-113, setDeltaOfSeed
+// stripOfConsideration.h:97-112 in rectangular mode)
+__global__ void k_extract( IndexView X, const ma_segment* pool, const u32* pool_read, const u64* seg_seed_off,
+                           u64 n_pool, u64 total_seeds, const u64* roff, ma_seed* seeds, unsigned long long* ctr )
+{
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 steps = 0;
+    if( j < total_seeds )
+    {
+        // last segment i with seg_seed_off[i] <= j (segments with zero seeds share offsets -> upper bound - 1)
+        u64 lo = 0, hi = n_pool;
+        while( lo < hi )
+        {
+            const u64 mid = ( lo + hi ) / 2;
+            if( seg_seed_off[ mid ] <= j )
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        const u64 i = lo - 1;
+        const ma_segment s = pool[ i ];
+        const i64 row = s.sa_start + (i64)( j - seg_seed_off[ i ] );
+        u64 r = (u64)bwt_sa( X, row, steps );
+        const bool fwd = r < X.n / 2;
+        if( !fwd )
+            r = X.n - r - 1;
+        const u32 rd = pool_read[ i ];
+        const u64 qlen = roff[ rd + 1 ] - roff[ rd ];
+        ma_seed sd;
+        sd.q_start = s.q_start;
+        sd.len = s.q_size + 1;
+        sd.r_start = (i64)r;
+        sd.ambiguity = (u32)s.sa_size;
+        sd.on_forward = fwd ? 1 : 0;
+        u64 delta = r + ( qlen - (u64)s.q_start );
+        delta += ( qlen + 1 ) * (u64)seq_id_for_position( X, r );
+        sd.delta = (i64)delta;
+        seeds[ j ] = sd;
+    }
+    // wave-aggregated counters
+    u64 st = steps;
+    for( int m = 32; m >= 1; m >>= 1 )
+        st += __shfl_xor( st, m, 64 );
+    if( ( threadIdx.x & 63 ) == 0 && st )
+        atomicAdd( &ctr[ CTR_LF_STEPS ], (unsigned long long)st );
+}
+
+struct ChainKernelArgs
+{
+    IndexView X;
+    ChainParams P;
+    u32 n_reads;
+    const u64* roff;
+    const u64* seed_off;
+    const u32* seed_cnt;
+    const ma_seed* seeds;
+    // scratch carved by seed offset
+    ma_seed* work;
+    SoCEntry* maxima;
+    RefMinMax* mm;
+    ma_seed* setA;
+    ma_seed* setB;
+    ma_seed* outA;
+    Shadow* sh1;
+    Shadow* sh2;
+    double* vX;
+    double* vY;
+    double* med;
+    i32* inl;
+    i32* best;
+    // output
+    ma_seed* hpool;
+    u64 hpool_cap;
+    HSet* sets; // n_reads * set_cap
+    u32 set_cap;
+    u32* nsets; // per read
+    unsigned long long* ctr;
+};
+
+__global__ void __launch_bounds__( 64 ) k_chain( ChainKernelArgs A )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= A.n_reads )
+        return;
+    const u64 off = A.seed_off[ r ];
+    const u32 n = A.seed_cnt[ r ];
+    ChainScratch C;
+    C.work = A.work + off;
+    C.maxima = A.maxima + off;
+    C.mm = A.mm + off;
+    C.setA = A.setA + off;
+    C.setB = A.setB + off;
+    C.outA = A.outA + off;
+    C.sh1 = A.sh1 + off;
+    C.sh2 = A.sh2 + off;
+    C.vX = A.vX + 3 * off;
+    C.vY = A.vY + 3 * off;
+    C.med = A.med + 6 * off;
+    C.inl = A.inl + 3 * off;
+    C.best = A.best + 3 * off;
+    for( u32 i = 0; i < n; i++ )
+        C.work[ i ] = A.seeds[ off + i ];
+    ChainOut O;
+    O.pool = A.hpool;
+    O.pool_cap = A.hpool_cap;
+    O.pool_used = &A.ctr[ CTR_HSEED_USED ];
+    O.sets = A.sets + (u64)r * A.set_cap;
+    O.set_cap = A.set_cap;
+    u32 err = 0;
+    const u32 qlen = (u32)( A.roff[ r + 1 ] - A.roff[ r ] );
+    const u32 ns = chain_read( A.X, A.P, C, n, qlen, O, err );
+    A.nsets[ r ] = ns < A.set_cap ? ns : A.set_cap;
+    if( err )
+        atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
+}
+
+// flatten the per-read set tables into CSR order (hset_off from an exclusive scan of nsets)
+__global__ void k_hset_flatten( const HSet* sets, u32 set_cap, const u32* nsets, const u64* hset_off, u32 n_reads,
+                                HSet* flat, u32* flat_read )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    const u64 o = hset_off[ r ];
+    for( u32 k = 0; k < nsets[ r ]; k++ )
+    {
+        flat[ o + k ] = sets[ (u64)r * set_cap + k ];
+        flat_read[ o + k ] = r;
+    }
+}
+
+struct SetInfo // per harmonized set, filled by the enumeration pass
+{
+    u64 win_begin, win_end;
+    u32 valid;
+    u32 n_jobs;
+};
+
+struct EnumSink
+{
+    static const bool STITCH = false;
+    DpJob* jobs; // slots of this set
+    u32 n;
+    u32 cap;
+    u64 win_begin, read_off;
+    unsigned long long* ctr;
+    MA_HD void job( u32 qf, u32 qt, u32 rf, u32 rt, i32 w, i32 zdrop, i32 flag, u32 rev )
+    {
+        if( n < cap )
+        {
+            DpJob j;
+            j.win_begin = win_begin;
+            j.read_off = read_off;
+            j.q_from = qf, j.q_to = qt, j.r_from = rf, j.r_to = rt;
+            j.w = w, j.zdrop = zdrop, j.flag = flag, j.rev = rev;
+            jobs[ n ] = j;
+#if defined( __HIP_DEVICE_COMPILE__ )
+            const i32 ql = (i32)( qt - qf ), tl = (i32)( rt - rf );
+            const u64 st = ksw_state_bytes( ql, tl );
+            const u64 L = (u64)( ( tl + 15 ) / 16 ) * 16;
+            const u64 p = (u64)( (i64)ql + tl - 1 ) * (u64)( ksw_ncol( ql, tl, w ) * 16 ) + 16;
+            atomicMax( &ctr[ CTR_MAX_STATE ], (unsigned long long)st );
+            atomicMax( &ctr[ CTR_MAX_H ], (unsigned long long)( L * 4 ) );
+            atomicMax( &ctr[ CTR_MAX_P ], (unsigned long long)p );
+            atomicMax( &ctr[ CTR_MAX_CIG ], (unsigned long long)( (u64)ql + tl + 2 ) );
+            atomicAdd( &ctr[ CTR_N_JOBS ], 1ull );
+#endif
+        }
+        n++;
+    }
+    MA_HD KswResult next( )
+    {
+        return KswResult{ -1, -1, nullptr, 0 };
+    }
+};
+
+struct DpKernelArgs
+{
+    IndexView X;
+    NwParams P;
+    u32 n_sets;
+    const HSet* sets;
+    const u32* set_read;
+    const ma_seed* hpool;
+    const uint8_t* reads;
+    const u64* roff;
+    DpJob* jobs; // 2 slots per pooled harmonized seed: slots of set s start at 2*sets[s].off
+    SetInfo* info;
+    unsigned long long* ctr;
+};
+
+__global__ void k_dp_enum( DpKernelArgs A )
+{
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if( s >= A.n_sets )
+        return;
+    const HSet hs = A.sets[ s ];
+    const ma_seed* S = A.hpool + hs.off;
+    const u32 rd = A.set_read[ s ];
+    const u64 qlen = A.roff[ rd + 1 ] - A.roff[ rd ];
+    SetInfo I;
+    const NwWindow W = nw_window( A.X, A.P, S, hs.cnt );
+    I.win_begin = W.begin_ref;
+    I.win_end = W.end_ref;
+    I.valid = W.valid ? 1 : 0;
+    I.n_jobs = 0;
+    DpJob* slots = A.jobs + 2 * hs.off;
+    if( W.valid )
+    {
+        EnumSink sink;
+        sink.jobs = slots;
+        sink.n = 0;
+        sink.cap = 2 * hs.cnt;
+        sink.win_begin = W.begin_ref;
+        sink.read_off = A.roff[ rd ];
+        sink.ctr = A.ctr;
+        NwWalk<EnumSink> walk{ A.X, A.P, sink, A.reads + A.roff[ rd ], W.begin_ref, AlnBuilder{ nullptr, nullptr, nullptr } };
+        walk.run( S, hs.cnt, qlen, W );
+        I.n_jobs = sink.n < sink.cap ? sink.n : sink.cap;
+        if( sink.n > sink.cap )
+            atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)MA_ERR_SCRATCH_OVERFLOW );
+    }
+    A.info[ s ] = I;
+}
+
+namespace
+{
+struct PipeFetch
+{
+    IndexView X;
+    const DpJob* jobs;
+    const uint8_t* reads;
+    __device__ bool valid( u32 s ) const
+    {
+        return jobs[ s ].q_to > jobs[ s ].q_from; // slots are zero-filled before enumeration
+    }
+    __device__ KswJobView view( u32 s ) const
+    {
+        const DpJob& j = jobs[ s ];
+        KswJobView v;
+        v.qlen = (i32)( j.q_to - j.q_from );
+        v.tlen = (i32)( j.r_to - j.r_from );
+        v.w = j.w;
+        v.zdrop = j.zdrop;
+        v.flag = j.flag;
+        return v;
+    }
+    struct Q
+    {
+        const uint8_t* q;
+        u32 from, to, rev;
+        __device__ u32 operator( )( i32 i ) const
+        {
+            return rev ? q[ to - 1 - (u32)i ] : q[ from + (u32)i ];
+        }
+    };
+    struct T
+    {
+        IndexView X;
+        u64 base;
+        u32 from, to, rev;
+        __device__ u32 operator( )( i32 i ) const
+        {
+            return text_base( X, base + ( rev ? to - 1 - (u32)i : from + (u32)i ) );
+        }
+    };
+    __device__ Q qfetch( u32 s ) const
+    {
+        const DpJob& j = jobs[ s ];
+        return Q{ reads + j.read_off, j.q_from, j.q_to, j.rev };
+    }
+    __device__ T tfetch( u32 s ) const
+    {
+        const DpJob& j = jobs[ s ];
+        return T{ X, j.win_begin, j.r_from, j.r_to, j.rev };
+    }
+};
+} // namespace
+
+// ops capacity of a set: |Q| + sum of its jobs' cigar lengths + 8 * seeds + 16 (see nw.h)
+__global__ void k_ops_caps( const HSet* sets, const SetInfo* info, const u32* set_read, const u64* roff,
+                            const ma_ez* ez, u32 n_sets, u64* caps )
+{
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if( s >= n_sets )
+        return;
+    const HSet hs = sets[ s ];
+    const u32 rd = set_read[ s ];
+    u64 c = ( roff[ rd + 1 ] - roff[ rd ] ) + 8ull * hs.cnt + 16;
+    for( u32 k = 0; k < info[ s ].n_jobs; k++ )
+        c += (u64)ez[ 2 * hs.off + k ].n_cigar;
+    caps[ s ] = info[ s ].valid ? c : 0;
+}
+
+struct StitchSink
+{
+    static const bool STITCH = true;
+    const ma_ez* ez;
+    const u64* cig_off;
+    const u32* cig_pool;
+    u32 k;
+    MA_HD void job( u32, u32, u32, u32, i32, i32, i32, u32 )
+    {}
+    MA_HD KswResult next( )
+    {
+        KswResult R;
+        R.max_q = ez[ k ].max_q;
+        R.max_t = ez[ k ].max_t;
+        R.n_cigar = (u32)ez[ k ].n_cigar;
+        R.cigar = cig_pool + cig_off[ k ];
+        k++;
+        return R;
+    }
+};
+
+struct StitchKernelArgs
+{
+    IndexView X;
+    NwParams P;
+    u32 n_sets;
+    const HSet* sets;
+    const u32* set_read;
+    const SetInfo* info;
+    const ma_seed* hpool;
+    const uint8_t* reads;
+    const u64* roff;
+    const ma_ez* ez;
+    const u64* cig_off;
+    const u32* cig_pool;
+    const u64* ops_off; // exclusive scan of caps
+    const u64* ops_cap;
+    u64* ops;
+    AlnHeader* hdr;
+    unsigned long long* ctr;
+};
+
+__global__ void k_stitch( StitchKernelArgs A )
+{
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if( s >= A.n_sets )
+        return;
+    const HSet hs = A.sets[ s ];
+    const u32 rd = A.set_read[ s ];
+    const SetInfo I = A.info[ s ];
+    AlnHeader h;
+    h.begin_ref = h.end_ref = 0;
+    h.begin_q = h.end_q = 0;
+    h.score = 0;
+    h.length = 0;
+    h.ops_off = A.ops_off[ s ];
+    h.n_ops = 0;
+    h.ops_cap = (u32)A.ops_cap[ s ];
+    h.soc_index = hs.soc;
+    h.secondary = h.supplementary = 0;
+    h.mapq = NAN;
+    u32 err = 0;
+    if( I.valid )
+    {
+        h.begin_ref = h.end_ref = I.win_begin;
+        NwWindow W;
+        W.begin_ref = I.win_begin;
+        W.end_ref = I.win_end;
+        W.valid = true;
+        StitchSink sink{ A.ez + 2 * hs.off, A.cig_off + 2 * hs.off, A.cig_pool, 0 };
+        NwWalk<StitchSink> walk{ A.X, A.P, sink, A.reads + A.roff[ rd ], I.win_begin,
+                                 AlnBuilder{ &h, A.ops + h.ops_off, &err } };
+        walk.run( A.hpool + hs.off, hs.cnt, A.roff[ rd + 1 ] - A.roff[ rd ], W );
+    }
+    A.hdr[ s ] = h;
+    if( err )
+        atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
+}
+
+// per read: NeedlemanWunsch::execute's final sort + MappingQuality::execute
+__global__ void k_finish( NwParams P, u32 n_reads, const u64* hset_off, const u64* roff, AlnHeader* hdr, const u64* ops,
+                          u32* order, u32* mq_order, u32* mq_cnt, unsigned long long* ctr )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    const u64 b = hset_off[ r ];
+    const u32 n = (u32)( hset_off[ r + 1 ] - b );
+    const u32 m = finish_read( P, hdr + b, ops, n, roff[ r + 1 ] - roff[ r ], order + b, mq_order + b );
+    mq_cnt[ r ] = m;
+    if( m )
+        atomicAdd( &ctr[ CTR_N_ALIGNED ], 1ull );
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch object
+// ------------------------------------------------------------------------------------------------
+struct ma_batch
+{
+    const ma_index* idx = nullptr;
+    ma_params P;
+    hipStream_t stream = nullptr;
+    u64 max_reads = 0, max_bases = 0;
+    u64 n_reads = 0, n_bases = 0;
+    u32 max_qlen = 0;
+    bool reads_external = false;
+    const uint8_t* d_reads = nullptr;
+    const u64* d_roff = nullptr;
+    DevBuf reads, roff, ctr;
+    // seeding
+    DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt;
+    u64 segPoolCap = 0;
+    // extraction
+    DevBuf segSeedCnt, segSeedOff, seedOff, seedCnt, seeds, cubTmp;
+    u64 nSegs = 0, nSeeds = 0;
+    // chaining
+    DevBuf cWork, cMax, cMm, cA, cB, cOut, cSh1, cSh2, cVx, cVy, cMed, cInl, cBest, hpool, setTab, nsets, hsetOff,
+        hsetFlat, hsetRead;
+    u64 hpoolCap = 0, nHsets = 0, nHseeds = 0;
+    // dp
+    DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
+    u64 cigPoolCap = 0, nOpsCap = 0;
+    int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
+    bool timing = false;
+    hipEvent_t ev[ 16 ];
+    bool evInit = false;
+    float kms[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long hctr[ CTR_COUNT ];
+};
+
+static int read_ctr( ma_batch* b )
+{
+    MA_HIP( hipMemcpyAsync( b->hctr, b->ctr.p, sizeof( b->hctr ), hipMemcpyDeviceToHost, b->stream ) );
+    MA_HIP( hipStreamSynchronize( b->stream ) );
+    return 0;
+}
+
+static int check_err( ma_batch* b, const char* where )
+{
+    const u32 e = (u32)b->hctr[ CTR_ERR ];
+    if( !e )
+        return 0;
+    std::string s = std::string( where ) + ": device capacity overflow:";
+    if( e & MA_ERR_SEG_OVERFLOW )
+        s += " segments";
+    if( e & MA_ERR_SEED_OVERFLOW )
+        s += " seeds";
+    if( e & MA_ERR_STACK_OVERFLOW )
+        s += " interval-stack";
+    if( e & MA_ERR_CIGAR_OVERFLOW )
+        s += " cigar";
+    if( e & MA_ERR_OPS_OVERFLOW )
+        s += " alignment-ops";
+    if( e & MA_ERR_SCRATCH_OVERFLOW )
+        s += " scratch";
+    if( e & MA_ERR_SMEM_OVERFLOW )
+        s += " smem-lists";
+    return fail( s );
+}
+
+template <typename T> static int scan_exclusive( ma_batch* b, const T* in, T* out, u64 n )
+{
+    size_t tb = 0;
+    MA_HIP( hipcub::DeviceScan::ExclusiveSum( nullptr, tb, in, out, (int)n, b->stream ) );
+    if( b->cubTmp.reserve( tb + 256 ) )
+        return 1;
+    MA_HIP( hipcub::DeviceScan::ExclusiveSum( b->cubTmp.p, tb, in, out, (int)n, b->stream ) );
+    return 0;
+}
+
+struct EvTimer
+{
+    ma_batch* b;
+    int slot;
+    EvTimer( ma_batch* b_, int s ) : b( b_ ), slot( s )
+    {
+        if( b->timing )
+            (void)hipEventRecord( b->ev[ 2 * slot ], b->stream );
+    }
+    ~EvTimer( )
+    {
+        if( b->timing )
+            (void)hipEventRecord( b->ev[ 2 * slot + 1 ], b->stream );
+    }
+};
+
+extern "C" {
+
+int ma_batch_create( const ma_index* idx, const ma_params* P, uint64_t max_reads, uint64_t max_bases, ma_batch** out )
+{
+    if( !idx || !P || !out )
+        return fail( "ma_batch_create: null argument" );
+    ma_batch* b = new ma_batch( );
+    b->idx = idx;
+    b->P = *P;
+    b->max_reads = max_reads;
+    b->max_bases = max_bases;
+    if( b->ctr.reserve( CTR_COUNT * 8 ) || b->reads.reserve( max_bases + 64 ) || b->roff.reserve( ( max_reads + 1 ) * 8 ) )
+    {
+        delete b;
+        return 1;
+    }
+    *out = b;
+    return 0;
+}
+
+int ma_batch_destroy( ma_batch* b )
+{
+    if( !b )
+        return 0;
+    DevBuf* all[] = { &b->reads,   &b->roff,    &b->ctr,      &b->stage,   &b->smemA,  &b->smemB,      &b->segPool,
+                      &b->segRead, &b->segOff,  &b->segCnt,   &b->segSeedCnt, &b->segSeedOff, &b->seedOff, &b->seedCnt,
+                      &b->seeds,   &b->cubTmp,  &b->cWork,    &b->cMax,    &b->cMm,    &b->cA,         &b->cB,
+                      &b->cOut,    &b->cSh1,    &b->cSh2,     &b->cVx,     &b->cVy,    &b->cMed,       &b->cInl,
+                      &b->cBest,   &b->hpool,   &b->setTab,   &b->nsets,   &b->hsetOff, &b->hsetFlat,  &b->hsetRead,
+                      &b->jobs,    &b->info,    &b->ez,       &b->cigOff,  &b->cigPool, &b->kswScratch, &b->opsCap,
+                      &b->opsOff,  &b->ops,     &b->hdr,      &b->order,   &b->mqOrder, &b->mqCnt };
+    for( DevBuf* d : all )
+        d->release( );
+    if( b->evInit )
+        for( int i = 0; i < 16; i++ )
+            (void)hipEventDestroy( b->ev[ i ] );
+    delete b;
+    return 0;
+}
+
+int ma_batch_set_stream( ma_batch* b, void* s )
+{
+    if( !b )
+        return fail( "ma_batch_set_stream: null batch" );
+    b->stream = (hipStream_t)s;
+    return 0;
+}
+
+int ma_batch_enable_timing( ma_batch* b, int on )
+{
+    if( !b )
+        return fail( "null batch" );
+    if( on && !b->evInit )
+    {
+        for( int i = 0; i < 16; i++ )
+            MA_HIP( hipEventCreate( &b->ev[ i ] ) );
+        b->evInit = true;
+    }
+    b->timing = on != 0;
+    return 0;
+}
+
+int ma_batch_set_reads( ma_batch* b, const uint8_t* codes, const uint64_t* offsets, uint64_t n )
+{
+    if( !b || !offsets || ( n && !codes ) )
+        return fail( "ma_batch_set_reads: null argument" );
+    if( n > b->max_reads || offsets[ n ] > b->max_bases )
+        return fail( "ma_batch_set_reads: batch capacity exceeded" );
+    b->n_reads = n;
+    b->n_bases = offsets[ n ];
+    u32 mq = 0;
+    for( u64 i = 0; i < n; i++ )
+        mq = std::max<u32>( mq, (u32)( offsets[ i + 1 ] - offsets[ i ] ) );
+    b->max_qlen = mq;
+    if( b->n_bases )
+        MA_HIP( hipMemcpyAsync( b->reads.p, codes, b->n_bases, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipMemcpyAsync( b->roff.p, offsets, ( n + 1 ) * 8, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipStreamSynchronize( b->stream ) );
+    b->d_reads = b->reads.as<uint8_t>( );
+    b->d_roff = b->roff.as<u64>( );
+    b->reads_external = false;
+    b->stage_done = 0;
+    return 0;
+}
+
+__global__ void k_max_qlen( const u64* roff, u64 n, unsigned long long* out )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i < n )
+        atomicMax( out, (unsigned long long)( roff[ i + 1 ] - roff[ i ] ) );
+}
+
+int ma_batch_set_reads_device( ma_batch* b, const void* d_codes, const void* d_offsets, uint64_t n, uint64_t n_bases )
+{
+    if( !b || !d_offsets || ( n && !d_codes ) )
+        return fail( "ma_batch_set_reads_device: null argument" );
+    b->n_reads = n;
+    b->n_bases = n_bases;
+    b->d_reads = (const uint8_t*)d_codes;
+    b->d_roff = (const u64*)d_offsets;
+    b->reads_external = true;
+    MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
+    if( n )
+        hipLaunchKernelGGL( k_max_qlen, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->d_roff, n,
+                            b->ctr.as<unsigned long long>( ) );
+    if( read_ctr( b ) )
+        return 1;
+    b->max_qlen = (u32)b->hctr[ 0 ];
+    b->stage_done = 0;
+    return 0;
+}
+
+static SeedParams seed_params( const ma_params& P )
+{
+    SeedParams S;
+    S.technique = (u32)P.seeding_technique;
+    S.min_amb = (u32)P.min_ambiguity;
+    S.max_amb = (u32)P.max_ambiguity;
+    S.min_seed_size_drop = (u32)P.min_seed_size_drop;
+    S.disable_heuristics = (u32)P.disable_heuristics;
+    S.rel_min_seed_size_amount = P.rel_min_seed_size_amount;
+    S.genome_size_disable = P.genome_size_disable;
+    return S;
+}
+
+int ma_seed_batch( ma_batch* b )
+{
+    if( !b || !b->d_roff )
+        return fail( "ma_seed_batch: no reads set" );
+    const u64 n = b->n_reads;
+    MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
+    b->nSegs = b->nSeeds = b->nHsets = b->nHseeds = 0;
+    if( n == 0 )
+    {
+        b->stage_done = 1;
+        return 0;
+    }
+    const bool smem = b->P.seeding_technique == 1;
+    const u32 seg_cap = ( smem ? 6 : 2 ) * b->max_qlen + 8;
+    const u32 smem_cap = smem ? b->max_qlen + 2 : 0;
+    const u64 lane_bytes = (u64)seg_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment );
+    // resident lanes: up to 8 waves per SIMD on 256 CUs, bounded by the reads and an 8 GiB staging budget
+    u64 lanes = 256ull * 2048;
+    lanes = std::min<u64>( lanes, ( n + 255 ) / 256 * 256 );
+    lanes = std::min<u64>( lanes, std::max<u64>( 256, ( ( 8ull << 30 ) / lane_bytes ) / 256 * 256 ) );
+    b->segPoolCap = std::max<u64>( b->n_bases / 2 + 64 * n, 1024 );
+    if( smem )
+        b->segPoolCap *= 2;
+    if( b->stage.reserve( lanes * seg_cap * sizeof( ma_segment ) ) ||
+        ( smem && ( b->smemA.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ||
+                    b->smemB.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ) ) ||
+        b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
+        b->segOff.reserve( n * 8 ) || b->segCnt.reserve( n * 4 ) )
+        return 1;
+    SeedKernelArgs A;
+    A.X = b->idx->v;
+    A.P = seed_params( b->P );
+    A.reads = b->d_reads;
+    A.roff = b->d_roff;
+    A.n_reads = (u32)n;
+    A.stage = b->stage.as<ma_segment>( );
+    A.seg_cap = seg_cap;
+    A.smem_a = smem ? b->smemA.as<ma_segment>( ) : nullptr;
+    A.smem_b = smem ? b->smemB.as<ma_segment>( ) : nullptr;
+    A.smem_cap = smem_cap;
+    A.pool = b->segPool.as<ma_segment>( );
+    A.pool_read = b->segRead.as<u32>( );
+    A.pool_cap = b->segPoolCap;
+    A.seg_off = b->segOff.as<u64>( );
+    A.seg_cnt = b->segCnt.as<u32>( );
+    A.ctr = b->ctr.as<unsigned long long>( );
+    {
+        EvTimer t( b, 0 );
+        hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), 0, b->stream, A );
+    }
+    MA_HIP( hipGetLastError( ) );
+    b->stage_done = 1;
+    return 0;
+}
+
+int ma_extract_seeds_batch( ma_batch* b )
+{
+    if( !b || b->stage_done < 1 )
+        return fail( "ma_extract_seeds_batch: run ma_seed_batch first" );
+    const u64 n = b->n_reads;
+    if( n == 0 )
+    {
+        b->stage_done = 2;
+        return 0;
+    }
+    if( read_ctr( b ) || check_err( b, "ma_seed_batch" ) )
+        return 1;
+    b->nSegs = b->hctr[ CTR_SEG_USED ];
+    const u64 ns = b->nSegs;
+    if( b->segSeedCnt.reserve( ( ns + 1 ) * 8 ) || b->segSeedOff.reserve( ( ns + 2 ) * 8 ) ||
+        b->seedOff.reserve( n * 8 ) || b->seedCnt.reserve( n * 4 ) )
+        return 1;
+    EvTimer t( b, 1 );
+    u64 total = 0;
+    if( ns )
+    {
+        hipLaunchKernelGGL( k_seg_seed_counts, dim3( (unsigned)( ( ns + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream,
+                            b->segPool.as<ma_segment>( ), ns, (u32)b->P.min_seed_len, (u32)b->P.max_ambiguity,
+                            b->segSeedCnt.as<u64>( ) );
+        MA_HIP( hipMemsetAsync( (char*)b->segSeedCnt.p + ns * 8, 0, 8, b->stream ) );
+        if( scan_exclusive<u64>( b, b->segSeedCnt.as<u64>( ), b->segSeedOff.as<u64>( ), ns + 1 ) )
+            return 1;
+        MA_HIP( hipMemcpyAsync( &total, (char*)b->segSeedOff.p + ns * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
+        MA_HIP( hipStreamSynchronize( b->stream ) );
+    }
+    b->nSeeds = total;
+    if( b->seeds.reserve( ( total + 1 ) * sizeof( ma_seed ) ) )
+        return 1;
+    hipLaunchKernelGGL( k_read_seed_ranges, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream,
+                        b->segOff.as<u64>( ), b->segCnt.as<u32>( ), b->segSeedOff.as<u64>( ), ns, total, (u32)n,
+                        b->seedOff.as<u64>( ), b->seedCnt.as<u32>( ) );
+    if( total )
+        hipLaunchKernelGGL( k_extract, dim3( (unsigned)( ( total + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->idx->v,
+                            b->segPool.as<ma_segment>( ), b->segRead.as<u32>( ), b->segSeedOff.as<u64>( ), ns, total,
+                            b->d_roff, b->seeds.as<ma_seed>( ), b->ctr.as<unsigned long long>( ) );
+    MA_HIP( hipGetLastError( ) );
+    b->stage_done = 2;
+    return 0;
+}
+
+// glibc srandom_r + 310 discards (stdlib/random_r.c): state after srand(seed)
+static void glibc_srand_ring( u32 seed, u32 ring[ 31 ] )
+{
+    if( seed == 0 )
+        seed = 1;
+    i32 word = (i32)seed;
+    ring[ 0 ] = (u32)word;
+    for( int i = 1; i < 31; i++ )
+    {
+        const long hi = word / 127773, lo = word % 127773;
+        word = (i32)( 16807 * lo - 2836 * hi );
+        if( word < 0 )
+            word += 2147483647;
+        ring[ i ] = (u32)word;
+    }
+    int f = 3, r = 0;
+    for( int i = 0; i < 310; i++ )
+    {
+        ring[ f ] += ring[ r ];
+        if( ++f >= 31 )
+            f = 0;
+        if( ++r >= 31 )
+            r = 0;
+    }
+    // after 310 = 10*31 steps f and r are back at 3 and 0
+}
+
+int ma_chain_batch( ma_batch* b )
+{
+    if( !b || b->stage_done < 2 )
+        return fail( "ma_chain_batch: run ma_extract_seeds_batch first" );
+    const u64 n = b->n_reads;
+    if( n == 0 )
+    {
+        b->stage_done = 3;
+        return 0;
+    }
+    const u64 ts = b->nSeeds + 1;
+    const u32 set_cap = 2 * (u32)b->P.max_num_soc;
+    b->hpoolCap = 3 * ts + 1024;
+    if( b->cWork.reserve( ts * sizeof( ma_seed ) ) || b->cMax.reserve( ts * sizeof( SoCEntry ) ) ||
+        b->cMm.reserve( ts * sizeof( RefMinMax ) ) || b->cA.reserve( ts * sizeof( ma_seed ) ) ||
+        b->cB.reserve( ts * sizeof( ma_seed ) ) || b->cOut.reserve( ts * sizeof( ma_seed ) ) ||
+        b->cSh1.reserve( ts * sizeof( Shadow ) ) || b->cSh2.reserve( ts * sizeof( Shadow ) ) ||
+        b->cVx.reserve( 3 * ts * 8 ) || b->cVy.reserve( 3 * ts * 8 ) || b->cMed.reserve( 6 * ts * 8 ) ||
+        b->cInl.reserve( 3 * ts * 4 ) || b->cBest.reserve( 3 * ts * 4 ) ||
+        b->hpool.reserve( b->hpoolCap * sizeof( ma_seed ) ) || b->setTab.reserve( n * set_cap * sizeof( HSet ) ) ||
+        b->nsets.reserve( ( n + 1 ) * 4 ) || b->hsetOff.reserve( ( n + 2 ) * 8 ) )
+        return 1;
+    ChainKernelArgs A;
+    A.X = b->idx->v;
+    A.P.max_num_soc = (u32)b->P.max_num_soc;
+    A.P.min_num_soc = (u32)b->P.min_num_soc;
+    A.P.harm_score_min = (u32)b->P.harm_score_min;
+    A.P.max_score_lookahead = (u32)b->P.max_score_lookahead;
+    A.P.switch_qlen = (u32)b->P.switch_qlen;
+    A.P.min_delta_dist = (u32)b->P.min_delta_dist;
+    A.P.sv_penalty = (u32)b->P.sv_penalty;
+    A.P.match = (u32)b->P.match;
+    A.P.gap = (u32)b->P.gap;
+    A.P.extend = (u32)b->P.extend;
+    A.P.disable_heuristics = (u32)b->P.disable_heuristics;
+    A.P.soc_width = (u32)b->P.soc_width;
+    A.P.genome_size_disable = b->P.genome_size_disable;
+    A.P.harm_score_min_rel = b->P.harm_score_min_rel;
+    A.P.soc_score_decrease_tol = b->P.soc_score_decrease_tol;
+    A.P.score_diff_tol = b->P.score_diff_tol;
+    A.P.max_delta_dist = b->P.max_delta_dist;
+    glibc_srand_ring( b->P.srand_seed, A.P.rng_ring );
+    A.n_reads = (u32)n;
+    A.roff = b->d_roff;
+    A.seed_off = b->seedOff.as<u64>( );
+    A.seed_cnt = b->seedCnt.as<u32>( );
+    A.seeds = b->seeds.as<ma_seed>( );
+    A.work = b->cWork.as<ma_seed>( );
+    A.maxima = b->cMax.as<SoCEntry>( );
+    A.mm = b->cMm.as<RefMinMax>( );
+    A.setA = b->cA.as<ma_seed>( );
+    A.setB = b->cB.as<ma_seed>( );
+    A.outA = b->cOut.as<ma_seed>( );
+    A.sh1 = b->cSh1.as<Shadow>( );
+    A.sh2 = b->cSh2.as<Shadow>( );
+    A.vX = b->cVx.as<double>( );
+    A.vY = b->cVy.as<double>( );
+    A.med = b->cMed.as<double>( );
+    A.inl = b->cInl.as<i32>( );
+    A.best = b->cBest.as<i32>( );
+    A.hpool = b->hpool.as<ma_seed>( );
+    A.hpool_cap = b->hpoolCap;
+    A.sets = b->setTab.as<HSet>( );
+    A.set_cap = set_cap;
+    A.nsets = b->nsets.as<u32>( );
+    A.ctr = b->ctr.as<unsigned long long>( );
+    {
+        EvTimer t( b, 2 );
+        hipLaunchKernelGGL( k_chain, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, A );
+    }
+    MA_HIP( hipGetLastError( ) );
+    // CSR of sets per read: widen counts to u64 via a scan over u32->u64 transform
+    {
+        size_t tb = 0;
+        auto in = hipcub::TransformInputIterator<u64, hipcub::CastOp<u64>, const u32*>( b->nsets.as<u32>( ),
+                                                                                      hipcub::CastOp<u64>( ) );
+        MA_HIP( hipMemsetAsync( (char*)b->nsets.p + n * 4, 0, 4, b->stream ) );
+        MA_HIP( hipcub::DeviceScan::ExclusiveSum( nullptr, tb, in, b->hsetOff.as<u64>( ), (int)( n + 1 ), b->stream ) );
+        if( b->cubTmp.reserve( tb + 256 ) )
+            return 1;
+        MA_HIP( hipcub::DeviceScan::ExclusiveSum( b->cubTmp.p, tb, in, b->hsetOff.as<u64>( ), (int)( n + 1 ),
+                                                  b->stream ) );
+    }
+    u64 nh = 0;
+    MA_HIP( hipMemcpyAsync( &nh, (char*)b->hsetOff.p + n * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
+    if( read_ctr( b ) || check_err( b, "ma_chain_batch" ) )
+        return 1;
+    b->nHsets = nh;
+    b->nHseeds = b->hctr[ CTR_HSEED_USED ];
+    if( b->hsetFlat.reserve( ( nh + 1 ) * sizeof( HSet ) ) || b->hsetRead.reserve( ( nh + 1 ) * 4 ) )
+        return 1;
+    hipLaunchKernelGGL( k_hset_flatten, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream,
+                        b->setTab.as<HSet>( ), set_cap, b->nsets.as<u32>( ), b->hsetOff.as<u64>( ), (u32)n,
+                        b->hsetFlat.as<HSet>( ), b->hsetRead.as<u32>( ) );
+    MA_HIP( hipGetLastError( ) );
+    b->stage_done = 3;
+    return 0;
+}
+
+static NwParams nw_params( const ma_params& P )
+{
+    NwParams N;
+    N.max_gap_area = (u32)P.max_gap_area;
+    N.padding = (u32)P.padding;
+    N.bandwidth_ext = (u32)P.bandwidth_ext;
+    N.min_bandwidth_gap = (u32)P.min_bandwidth_gap;
+    N.zdrop = (u32)P.zdrop;
+    N.sv_penalty = (u32)P.sv_penalty;
+    N.match = (u32)P.match;
+    N.mismatch = (u32)P.mismatch;
+    N.gap = (u32)P.gap;
+    N.extend = (u32)P.extend;
+    N.kq = (i32)(int8_t)P.gap;
+    N.ke = (i32)(int8_t)P.extend;
+    N.min_alignment_score = (u32)P.min_alignment_score;
+    N.report_n_best = (u32)P.report_n_best;
+    N.max_supplementary = (u32)P.max_supplementary;
+    N.max_overlap_supplementary = P.max_overlap_supplementary;
+    return N;
+}
+
+int ma_dp_batch( ma_batch* b )
+{
+    if( !b || b->stage_done < 3 )
+        return fail( "ma_dp_batch: run ma_chain_batch first" );
+    const u64 n = b->n_reads, nh = b->nHsets, nhs = b->nHseeds;
+    if( b->mqCnt.reserve( ( n + 1 ) * 4 ) )
+        return 1;
+    MA_HIP( hipMemsetAsync( b->mqCnt.p, 0, ( n + 1 ) * 4, b->stream ) );
+    if( n == 0 || nh == 0 )
+    {
+        b->stage_done = 4;
+        return 0;
+    }
+    const u64 nSlots = 2 * nhs;
+    if( b->jobs.reserve( ( nSlots + 2 ) * sizeof( DpJob ) ) || b->info.reserve( nh * sizeof( SetInfo ) ) ||
+        b->ez.reserve( ( nSlots + 2 ) * sizeof( ma_ez ) ) || b->cigOff.reserve( ( nSlots + 2 ) * 8 ) ||
+        b->opsCap.reserve( ( nh + 1 ) * 8 ) || b->opsOff.reserve( ( nh + 2 ) * 8 ) ||
+        b->hdr.reserve( nh * sizeof( AlnHeader ) ) || b->order.reserve( nh * 4 ) || b->mqOrder.reserve( nh * 4 ) )
+        return 1;
+    const NwParams NP = nw_params( b->P );
+    DpKernelArgs D;
+    D.X = b->idx->v;
+    D.P = NP;
+    D.n_sets = (u32)nh;
+    D.sets = b->hsetFlat.as<HSet>( );
+    D.set_read = b->hsetRead.as<u32>( );
+    D.hpool = b->hpool.as<ma_seed>( );
+    D.reads = b->d_reads;
+    D.roff = b->d_roff;
+    D.jobs = b->jobs.as<DpJob>( );
+    D.info = b->info.as<SetInfo>( );
+    D.ctr = b->ctr.as<unsigned long long>( );
+    {
+        EvTimer t( b, 3 );
+        // zero-fill: a slot is a job iff q_to > q_from (pool regions of dropped sets stay empty)
+        MA_HIP( hipMemsetAsync( b->ez.p, 0, ( nSlots + 2 ) * sizeof( ma_ez ), b->stream ) );
+        MA_HIP( hipMemsetAsync( b->jobs.p, 0, ( nSlots + 2 ) * sizeof( DpJob ), b->stream ) );
+        hipLaunchKernelGGL( k_dp_enum, dim3( (unsigned)( ( nh + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, D );
+    }
+    MA_HIP( hipGetLastError( ) );
+    if( read_ctr( b ) || check_err( b, "ma_dp_batch(enumerate)" ) )
+        return 1;
+    const u64 nJobs = b->hctr[ CTR_N_JOBS ];
+    if( nJobs )
+    {
+        KswSizing S;
+        S.state = b->hctr[ CTR_MAX_STATE ];
+        S.h = b->hctr[ CTR_MAX_H ];
+        S.p = b->hctr[ CTR_MAX_P ];
+        S.cig = b->hctr[ CTR_MAX_CIG ];
+        KswPlan plan = ksw_plan( S, nJobs, 24ull << 30 );
+        b->cigPoolCap = std::max<u64>( 64 * nJobs + ( 1 << 20 ), b->n_bases / 2 );
+        if( b->kswScratch.reserve( plan.ws.stride * plan.waves ) || b->cigPool.reserve( b->cigPoolCap * 4 ) )
+            return 1;
+        plan.ws.base = b->kswScratch.as<uint8_t>( );
+        KswScoring SC{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
+        unsigned long long* c = b->ctr.as<unsigned long long>( );
+        KswOut O;
+        O.ez = b->ez.as<ma_ez>( );
+        O.cig_off = b->cigOff.as<u64>( );
+        O.cig_pool = b->cigPool.as<u32>( );
+        O.cig_pool_cap = b->cigPoolCap;
+        O.cig_used = c + CTR_CIG_USED;
+        O.cells = c + CTR_CELLS;
+        O.njobs = c + CTR_KSW_JOBS;
+        O.err = (u32*)( c + CTR_ERR );
+        PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
+        if( plan.lds_bytes > 48 * 1024 )
+            MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<PipeFetch>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)plan.lds_bytes ) );
+        EvTimer t( b, 4 );
+        hipLaunchKernelGGL( k_ksw<PipeFetch>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, b->stream, F, SC,
+                            (u32)nSlots, (unsigned int*)( c + CTR_NEXT_SLOT ), plan.ws, O );
+        MA_HIP( hipGetLastError( ) );
+    }
+    {
+        EvTimer t( b, 5 );
+        hipLaunchKernelGGL( k_ops_caps, dim3( (unsigned)( ( nh + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream,
+                            b->hsetFlat.as<HSet>( ), b->info.as<SetInfo>( ), b->hsetRead.as<u32>( ), b->d_roff,
+                            b->ez.as<ma_ez>( ), (u32)nh, b->opsCap.as<u64>( ) );
+        MA_HIP( hipMemsetAsync( (char*)b->opsCap.p + nh * 8, 0, 8, b->stream ) );
+        if( scan_exclusive<u64>( b, b->opsCap.as<u64>( ), b->opsOff.as<u64>( ), nh + 1 ) )
+            return 1;
+        u64 totalOps = 0;
+        MA_HIP( hipMemcpyAsync( &totalOps, (char*)b->opsOff.p + nh * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
+        MA_HIP( hipStreamSynchronize( b->stream ) );
+        b->nOpsCap = totalOps;
+        if( b->ops.reserve( ( totalOps + 2 ) * 8 ) )
+            return 1;
+        StitchKernelArgs T;
+        T.X = b->idx->v;
+        T.P = NP;
+        T.n_sets = (u32)nh;
+        T.sets = b->hsetFlat.as<HSet>( );
+        T.set_read = b->hsetRead.as<u32>( );
+        T.info = b->info.as<SetInfo>( );
+        T.hpool = b->hpool.as<ma_seed>( );
+        T.reads = b->d_reads;
+        T.roff = b->d_roff;
+        T.ez = b->ez.as<ma_ez>( );
+        T.cig_off = b->cigOff.as<u64>( );
+        T.cig_pool = b->cigPool.as<u32>( );
+        T.ops_off = b->opsOff.as<u64>( );
+        T.ops_cap = b->opsCap.as<u64>( );
+        T.ops = b->ops.as<u64>( );
+        T.hdr = b->hdr.as<AlnHeader>( );
+        T.ctr = b->ctr.as<unsigned long long>( );
+        hipLaunchKernelGGL( k_stitch, dim3( (unsigned)( ( nh + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, T );
+        hipLaunchKernelGGL( k_finish, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, NP, (u32)n,
+                            b->hsetOff.as<u64>( ), b->d_roff, b->hdr.as<AlnHeader>( ), b->ops.as<u64>( ),
+                            b->order.as<u32>( ), b->mqOrder.as<u32>( ), b->mqCnt.as<u32>( ),
+                            b->ctr.as<unsigned long long>( ) );
+    }
+    MA_HIP( hipGetLastError( ) );
+    b->stage_done = 4;
+    return 0;
+}
+
+int ma_align_batch( ma_batch* b )
+{
+    if( ma_seed_batch( b ) || ma_extract_seeds_batch( b ) || ma_chain_batch( b ) || ma_dp_batch( b ) )
+        return 1;
+    return 0;
+}
+
+int ma_batch_sync( ma_batch* b )
+{
+    if( !b )
+        return fail( "ma_batch_sync: null batch" );
+    if( read_ctr( b ) )
+        return 1;
+    if( b->timing && b->evInit )
+        for( int i = 0; i < 6; i++ )
+        {
+            float ms = 0;
+            if( hipEventElapsedTime( &ms, b->ev[ 2 * i ], b->ev[ 2 * i + 1 ] ) == hipSuccess )
+                b->kms[ i ] = ms;
+        }
+    return check_err( b, "ma_batch_sync" );
+}
+
+int ma_batch_kernel_ms( ma_batch* b, float out[ 8 ] )
+{
+    if( !b )
+        return fail( "null batch" );
+    for( int i = 0; i < 8; i++ )
+        out[ i ] = b->kms[ i ];
+    return 0;
+}
+
+int ma_batch_counters( ma_batch* b, uint64_t out[ 8 ] )
+{
+    if( ma_batch_sync( b ) )
+        return 1;
+    out[ 0 ] = b->hctr[ CTR_STEPS ];
+    out[ 1 ] = b->hctr[ CTR_BLOCKS ];
+    out[ 2 ] = b->hctr[ CTR_LF_STEPS ];
+    out[ 3 ] = b->nSeeds;
+    out[ 4 ] = b->hctr[ CTR_CELLS ];
+    out[ 5 ] = b->hctr[ CTR_KSW_JOBS ];
+    out[ 6 ] = out[ 7 ] = 0;
+    return 0;
+}
+
+int ma_batch_counts( ma_batch* b, uint64_t* n_segments, uint64_t* n_seeds, uint64_t* n_hsets, uint64_t* n_hseeds,
+                     uint64_t* n_alignments, uint64_t* n_ops, uint64_t* n_aligned_reads )
+{
+    if( ma_batch_sync( b ) )
+        return 1;
+    if( b->stage_done >= 1 && b->nSegs == 0 )
+        b->nSegs = b->hctr[ CTR_SEG_USED ];
+    if( n_segments )
+        *n_segments = b->nSegs;
+    if( n_seeds )
+        *n_seeds = b->nSeeds;
+    if( n_hsets )
+        *n_hsets = b->nHsets;
+    if( n_hseeds )
+        *n_hseeds = b->nHseeds;
+    if( n_alignments )
+        *n_alignments = b->stage_done >= 4 ? b->nHsets : 0;
+    if( n_ops )
+        *n_ops = b->stage_done >= 4 ? b->nOpsCap : 0;
+    if( n_aligned_reads )
+        *n_aligned_reads = b->hctr[ CTR_N_ALIGNED ];
+    return 0;
+}
+
+// Downloads gather the per-read ranges (pools are in completion order) into read-order CSR arrays.
+int ma_batch_get_segments( ma_batch* b, uint64_t* seg_off, ma_segment* segs )
+{
+    if( !b || b->stage_done < 1 )
+        return fail( "ma_batch_get_segments: stage not run" );
+    if( ma_batch_sync( b ) )
+        return 1;
+    const u64 n = b->n_reads, ns = b->hctr[ CTR_SEG_USED ];
+    std::vector<u64> off( n );
+    std::vector<u32> cnt( n );
+    std::vector<ma_segment> pool( ns );
+    if( n )
+    {
+        MA_HIP( hipMemcpy( off.data( ), b->segOff.p, n * 8, hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( cnt.data( ), b->segCnt.p, n * 4, hipMemcpyDeviceToHost ) );
+    }
+    if( ns )
+        MA_HIP( hipMemcpy( pool.data( ), b->segPool.p, ns * sizeof( ma_segment ), hipMemcpyDeviceToHost ) );
+    u64 o = 0;
+    for( u64 r = 0; r < n; r++ )
+    {
+        if( seg_off )
+            seg_off[ r ] = o;
+        if( segs )
+            for( u32 k = 0; k < cnt[ r ]; k++ )
+                segs[ o + k ] = pool[ off[ r ] + k ];
+        o += cnt[ r ];
+    }
+    if( seg_off )
+        seg_off[ n ] = o;
+    return 0;
+}
+
+int ma_batch_get_seeds( ma_batch* b, uint64_t* seed_off, ma_seed* seeds )
+{
+    if( !b || b->stage_done < 2 )
+        return fail( "ma_batch_get_seeds: stage not run" );
+    if( ma_batch_sync( b ) )
+        return 1;
+    const u64 n = b->n_reads;
+    std::vector<u64> off( n );
+    std::vector<u32> cnt( n );
+    std::vector<ma_seed> pool( b->nSeeds );
+    if( n )
+    {
+        MA_HIP( hipMemcpy( off.data( ), b->seedOff.p, n * 8, hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( cnt.data( ), b->seedCnt.p, n * 4, hipMemcpyDeviceToHost ) );
+    }
+    if( b->nSeeds )
+        MA_HIP( hipMemcpy( pool.data( ), b->seeds.p, b->nSeeds * sizeof( ma_seed ), hipMemcpyDeviceToHost ) );
+    u64 o = 0;
+    for( u64 r = 0; r < n; r++ )
+    {
+        if( seed_off )
+            seed_off[ r ] = o;
+        if( seeds )
+            for( u32 k = 0; k < cnt[ r ]; k++ )
+                seeds[ o + k ] = pool[ off[ r ] + k ];
+        o += cnt[ r ];
+    }
+    if( seed_off )
+        seed_off[ n ] = o;
+    return 0;
+}
+
+int ma_batch_get_hsets( ma_batch* b, uint64_t* hset_off, uint64_t* hseed_off, uint32_t* hset_soc, ma_seed* hseeds )
+{
+    if( !b || b->stage_done < 3 )
+        return fail( "ma_batch_get_hsets: stage not run" );
+    if( ma_batch_sync( b ) )
+        return 1;
+    const u64 n = b->n_reads, nh = b->nHsets;
+    if( hset_off && n )
+        MA_HIP( hipMemcpy( hset_off, b->hsetOff.p, ( n + 1 ) * 8, hipMemcpyDeviceToHost ) );
+    if( hset_off && !n )
+        hset_off[ 0 ] = 0;
+    std::vector<HSet> flat( nh );
+    std::vector<ma_seed> pool( b->nHseeds );
+    if( nh )
+        MA_HIP( hipMemcpy( flat.data( ), b->hsetFlat.p, nh * sizeof( HSet ), hipMemcpyDeviceToHost ) );
+    if( b->nHseeds )
+        MA_HIP( hipMemcpy( pool.data( ), b->hpool.p, b->nHseeds * sizeof( ma_seed ), hipMemcpyDeviceToHost ) );
+    u64 o = 0;
+    for( u64 s = 0; s < nh; s++ )
+    {
+        if( hseed_off )
+            hseed_off[ s ] = o;
+        if( hset_soc )
+            hset_soc[ s ] = flat[ s ].soc;
+        if( hseeds )
+            for( u32 k = 0; k < flat[ s ].cnt; k++ )
+                hseeds[ o + k ] = pool[ flat[ s ].off + k ];
+        o += flat[ s ].cnt;
+    }
+    if( hseed_off )
+        hseed_off[ nh ] = o;
+    return 0;
+}
+
+static int get_alns( ma_batch* b, bool mq, uint64_t* aln_off, ma_alignment* alns, uint64_t* ops )
+{
+    if( !b || b->stage_done < 4 )
+        return fail( "ma_batch_get_alignments: stage not run" );
+    if( ma_batch_sync( b ) )
+        return 1;
+    const u64 n = b->n_reads, nh = b->nHsets;
+    std::vector<u64> hoff( n + 1, 0 );
+    std::vector<AlnHeader> hdr( nh );
+    std::vector<u32> ord( nh ), mqc( n + 1, 0 );
+    std::vector<u64> pool( b->nOpsCap + 1 );
+    if( n && nh )
+    {
+        MA_HIP( hipMemcpy( hoff.data( ), b->hsetOff.p, ( n + 1 ) * 8, hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( hdr.data( ), b->hdr.p, nh * sizeof( AlnHeader ), hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( ord.data( ), mq ? b->mqOrder.p : b->order.p, nh * 4, hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( mqc.data( ), b->mqCnt.p, n * 4, hipMemcpyDeviceToHost ) );
+        if( b->nOpsCap )
+            MA_HIP( hipMemcpy( pool.data( ), b->ops.p, b->nOpsCap * 8, hipMemcpyDeviceToHost ) );
+    }
+    u64 o = 0, po = 0;
+    for( u64 r = 0; r < n; r++ )
+    {
+        if( aln_off )
+            aln_off[ r ] = o;
+        const u64 base = hoff[ r ];
+        const u32 cnt = mq ? mqc[ r ] : (u32)( hoff[ r + 1 ] - hoff[ r ] );
+        for( u32 k = 0; k < cnt; k++ )
+        {
+            const AlnHeader& h = hdr[ base + ord[ base + k ] ];
+            if( alns )
+            {
+                ma_alignment a;
+                a.begin_ref = (i64)h.begin_ref;
+                a.end_ref = (i64)h.end_ref;
+                a.begin_q = (i64)h.begin_q;
+                a.end_q = (i64)h.end_q;
+                a.score = h.score;
+                a.soc_index = h.soc_index;
+                a.n_ops = h.n_ops;
+                a.ops_off = po;
+                a.secondary = mq ? h.secondary : 0;
+                a.supplementary = mq ? h.supplementary : 0;
+                a.mapq = mq ? h.mapq : 0.0;
+                alns[ o + k ] = a;
+            }
+            if( ops )
+                for( u32 j = 0; j < h.n_ops; j++ )
+                {
+                    ops[ 2 * ( po + j ) ] = op_type( pool[ h.ops_off + j ] );
+                    ops[ 2 * ( po + j ) + 1 ] = op_len( pool[ h.ops_off + j ] );
+                }
+            po += h.n_ops;
+        }
+        o += cnt;
+    }
+    if( aln_off )
+        aln_off[ n ] = o;
+    return 0;
+}
+
+int ma_batch_get_alignments( ma_batch* b, uint64_t* aln_off, ma_alignment* alns, uint64_t* ops )
+{
+    return get_alns( b, false, aln_off, alns, ops );
+}
+int ma_batch_get_mapq_alignments( ma_batch* b, uint64_t* aln_off, ma_alignment* alns, uint64_t* ops )
+{
+    return get_alns( b, true, aln_off, alns, ops );
+}
+
+} // extern "C"

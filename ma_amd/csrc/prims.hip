@@ -1,0 +1,178 @@
+// prims.hip -- batched primitive operations behind the C ABI (kernel-level parity seams):
+// FMIndex::extend_backward (fMIndex.cpp:21-101), FMIndex::bwt_sa (fMIndex.h:788-814) and
+// kswcpp_dispatch (kswcpp.h:165-190).
+#include "ksw_launch.h"
+#include "fm_device.h"
+#include <cstring>
+
+using namespace ma;
+
+__global__ void k_extend( IndexView X, const i64* ik, const uint8_t* c, u64 n, i64* ok )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    i64 a[ 3 ] = { ik[ 3 * i ], ik[ 3 * i + 1 ], ik[ 3 * i + 2 ] }, o[ 3 ];
+    u32 nb;
+    extend_backward( X, a, c[ i ], o, nb );
+    ok[ 3 * i ] = o[ 0 ];
+    ok[ 3 * i + 1 ] = o[ 1 ];
+    ok[ 3 * i + 2 ] = o[ 2 ];
+}
+
+__global__ void k_bwt_sa( IndexView X, const i64* rows, u64 n, i64* pos )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    u32 steps;
+    pos[ i ] = bwt_sa( X, rows[ i ], steps );
+}
+
+extern "C" int ma_extend_backward_batch( const ma_index* x, const int64_t* ik, const uint8_t* c, uint64_t n, int64_t* ok )
+{
+    if( !x )
+        return fail( "ma_extend_backward_batch: null index" );
+    if( n == 0 )
+        return 0;
+    DevBuf dik, dc, dok;
+    if( dik.reserve( n * 24 ) || dc.reserve( n ) || dok.reserve( n * 24 ) )
+        return 1;
+    MA_HIP( hipMemcpy( dik.p, ik, n * 24, hipMemcpyHostToDevice ) );
+    MA_HIP( hipMemcpy( dc.p, c, n, hipMemcpyHostToDevice ) );
+    hipLaunchKernelGGL( k_extend, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, 0, x->v, dik.as<i64>( ),
+                        dc.as<uint8_t>( ), n, dok.as<i64>( ) );
+    MA_HIP( hipGetLastError( ) );
+    MA_HIP( hipMemcpy( ok, dok.p, n * 24, hipMemcpyDeviceToHost ) );
+    dik.release( );
+    dc.release( );
+    dok.release( );
+    return 0;
+}
+
+extern "C" int ma_bwt_sa_batch( const ma_index* x, const int64_t* rows, uint64_t n, int64_t* pos )
+{
+    if( !x )
+        return fail( "ma_bwt_sa_batch: null index" );
+    if( n == 0 )
+        return 0;
+    DevBuf dr, dp;
+    if( dr.reserve( n * 8 ) || dp.reserve( n * 8 ) )
+        return 1;
+    MA_HIP( hipMemcpy( dr.p, rows, n * 8, hipMemcpyHostToDevice ) );
+    hipLaunchKernelGGL( k_bwt_sa, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, 0, x->v, dr.as<i64>( ), n,
+                        dp.as<i64>( ) );
+    MA_HIP( hipGetLastError( ) );
+    MA_HIP( hipMemcpy( pos, dp.p, n * 8, hipMemcpyDeviceToHost ) );
+    dr.release( );
+    dp.release( );
+    return 0;
+}
+
+namespace
+{
+struct ByteFetch
+{
+    const ma_ksw_job* jobs;
+    const uint8_t* qb;
+    const uint8_t* tb;
+    __device__ bool valid( u32 ) const
+    {
+        return true;
+    }
+    __device__ KswJobView view( u32 s ) const
+    {
+        KswJobView v;
+        v.qlen = jobs[ s ].qlen;
+        v.tlen = jobs[ s ].tlen;
+        v.w = jobs[ s ].w;
+        v.zdrop = jobs[ s ].zdrop;
+        v.flag = jobs[ s ].flag;
+        return v;
+    }
+    struct Q
+    {
+        const uint8_t* p;
+        __device__ u32 operator( )( i32 i ) const
+        {
+            return p[ i ];
+        }
+    };
+    __device__ Q qfetch( u32 s ) const
+    {
+        return Q{ qb + jobs[ s ].q_off };
+    }
+    __device__ Q tfetch( u32 s ) const
+    {
+        return Q{ tb + jobs[ s ].t_off };
+    }
+};
+} // namespace
+
+extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_t n, const uint8_t* q_bytes,
+                             uint64_t q_len, const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off,
+                             uint32_t* cigar, uint64_t cigar_cap )
+{
+    if( !P || !jobs || !ez || !cigar_off )
+        return fail( "ma_ksw_batch: null argument" );
+    if( n == 0 )
+        return 0;
+    KswSizing S;
+    for( uint64_t i = 0; i < n; i++ )
+        ksw_size_job( S, jobs[ i ].qlen, jobs[ i ].tlen, jobs[ i ].w );
+    KswPlan plan = ksw_plan( S, n, 8ull << 30 );
+    DevBuf dj, dq, dt, dez, doff, dpool, dscr, dctr;
+    if( dj.reserve( n * sizeof( ma_ksw_job ) ) || dq.reserve( q_len + 16 ) || dt.reserve( t_len + 16 ) ||
+        dez.reserve( n * sizeof( ma_ez ) ) || doff.reserve( ( n + 1 ) * 8 ) || dpool.reserve( cigar_cap * 4 + 16 ) ||
+        dscr.reserve( plan.ws.stride * plan.waves ) || dctr.reserve( 64 ) )
+        return 1;
+    MA_HIP( hipMemcpy( dj.p, jobs, n * sizeof( ma_ksw_job ), hipMemcpyHostToDevice ) );
+    MA_HIP( hipMemcpy( dq.p, q_bytes, q_len, hipMemcpyHostToDevice ) );
+    MA_HIP( hipMemcpy( dt.p, t_bytes, t_len, hipMemcpyHostToDevice ) );
+    MA_HIP( hipMemset( dctr.p, 0, 64 ) );
+    MA_HIP( hipMemset( dez.p, 0, n * sizeof( ma_ez ) ) );
+    MA_HIP( hipMemset( doff.p, 0, ( n + 1 ) * 8 ) );
+    plan.ws.base = dscr.as<uint8_t>( );
+    KswScoring SC{ P->match, P->mismatch, P->gap, P->extend, P->gap2, P->extend2 };
+    KswOut O;
+    unsigned long long* ctr = dctr.as<unsigned long long>( );
+    O.ez = dez.as<ma_ez>( );
+    O.cig_off = doff.as<u64>( );
+    O.cig_pool = dpool.as<u32>( );
+    O.cig_pool_cap = cigar_cap;
+    O.cig_used = ctr + 0;
+    O.cells = ctr + 1;
+    O.njobs = ctr + 2;
+    O.err = (u32*)( ctr + 3 );
+    unsigned int* next = (unsigned int*)( ctr + 4 );
+    ByteFetch F{ dj.as<ma_ksw_job>( ), dq.as<uint8_t>( ), dt.as<uint8_t>( ) };
+    if( plan.lds_bytes > 48 * 1024 )
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<ByteFetch>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)plan.lds_bytes ) );
+    hipLaunchKernelGGL( k_ksw<ByteFetch>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, 0, F, SC, (u32)n, next,
+                        plan.ws, O );
+    MA_HIP( hipGetLastError( ) );
+    MA_HIP( hipDeviceSynchronize( ) );
+    unsigned long long h[ 8 ];
+    MA_HIP( hipMemcpy( h, dctr.p, 64, hipMemcpyDeviceToHost ) );
+    int rc = 0;
+    if( ( (u32)h[ 3 ] ) & MA_ERR_CIGAR_OVERFLOW )
+        rc = fail( "ma_ksw_batch: cigar capacity too small" );
+    else
+    {
+        MA_HIP( hipMemcpy( ez, dez.p, n * sizeof( ma_ez ), hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( cigar_off, doff.p, n * 8, hipMemcpyDeviceToHost ) );
+        cigar_off[ n ] = h[ 0 ];
+        if( cigar && h[ 0 ] )
+            MA_HIP( hipMemcpy( cigar, dpool.p, h[ 0 ] * 4, hipMemcpyDeviceToHost ) );
+    }
+    dj.release( );
+    dq.release( );
+    dt.release( );
+    dez.release( );
+    doff.release( );
+    dpool.release( );
+    dscr.release( );
+    dctr.release( );
+    return rc;
+}

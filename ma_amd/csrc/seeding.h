@@ -1,0 +1,453 @@
+// seeding.h -- BinarySeeding (binarySeeding.h:55-452, binarySeeding.cpp:32-178) as a per-read state
+// machine that performs exactly one FMIndex::extend_backward per step, so that the 64 reads of a
+// wavefront advance in lockstep through one shared "load two occ blocks + popcount" code path
+// regardless of which extension phase each read is in.
+#pragma once
+#include "fm_device.h"
+
+namespace ma
+{
+struct SeedParams
+{
+    u32 technique; // 0 maxSpan, 1 SMEMs
+    u32 min_amb, max_amb;
+    u32 min_seed_size_drop;
+    u32 disable_heuristics;
+    double rel_min_seed_size_amount;
+    u64 genome_size_disable;
+};
+
+// Scratch a read needs while it is being seeded (lives in HBM, one slot per resident lane).
+struct SeedScratch
+{
+    ma_segment* stage; // staged output segments of the read in flight (capacity seg_cap)
+    u32 seg_cap;
+    ma_segment* smem_a; // SMEM pending lists (capacity smem_cap each)
+    ma_segment* smem_b;
+    u32 smem_cap;
+};
+
+enum SeedPhase : u32
+{
+    PH_NEW_CENTER = 0,
+    PH_P1_RIGHT = 1,
+    PH_P1_LEFT = 2,
+    PH_P2_LEFT = 3,
+    PH_P2_RIGHT = 4,
+    PH_SMEM_FWD = 5,
+    PH_SMEM_BWD = 6,
+    PH_DONE = 7
+};
+
+#define MA_SEED_STACK 40
+
+struct SeedLane
+{
+    // read
+    const uint8_t* q;
+    u32 qlen;
+    // interval stack of procesInterval (binarySeeding.cpp:32-84): left parts recurse, right parts iterate
+    u32 stS[ MA_SEED_STACK ], stN[ MA_SEED_STACK ];
+    u32 sp;
+    u32 aS, aN; // area currently processed
+    // extension state
+    u32 phase;
+    u32 center, i, start, end;
+    u32 s1_start, s1_end; // first (right-then-left) segment of the center, for the duplicate test
+    i64 ik[ 3 ];
+    // SMEM state
+    u32 nPrev, nCurr, jPrev; // list sizes / cursor
+    u32 bHaveOne, retS, retE;
+    u32 flip; // which of smem_a/smem_b is "prev"
+    // output
+    u32 nseg;
+    u32 err;
+    // counters
+    u32 steps, blocks;
+};
+
+MA_HD u32 comp_base( u32 c ) // NucSeq::nucleotideComplement (nucSeq.h:524-532)
+{
+    return c < 4 ? 3 - c : 5;
+}
+
+MA_HD void seed_emit( SeedLane& L, const SeedScratch& S, u32 start, u32 size, i64 a, i64 b, i64 c )
+{
+    if( L.nseg < S.seg_cap )
+    {
+        ma_segment s;
+        s.q_start = start;
+        s.q_size = size;
+        s.sa_start = a;
+        s.sa_start_rc = b;
+        s.sa_size = c;
+        S.stage[ L.nseg ] = s;
+    }
+    else
+        L.err |= MA_ERR_SEG_OVERFLOW;
+    L.nseg++;
+}
+
+MA_HD void seed_begin_read( SeedLane& L, const uint8_t* q, u32 qlen )
+{
+    L.q = q;
+    L.qlen = qlen;
+    L.sp = 0;
+    L.aS = 0;
+    L.aN = qlen;
+    L.nseg = 0;
+    L.err = 0;
+    L.steps = L.blocks = 0;
+    L.phase = qlen == 0 ? PH_DONE : PH_NEW_CENTER;
+}
+
+// After an extension around `center` covered [cS, cS+cN] (reference convention), split the area
+// (binarySeeding.cpp:58-82): recurse left first, continue right afterwards.
+MA_HD void seed_after_center( SeedLane& L, u32 cS, u32 cN )
+{
+    const u32 cE = cS + cN, aE = L.aS + L.aN;
+    const bool hasLeft = cS != 0 && L.aS + 1 < cS;
+    const bool hasRight = aE > cE + 1;
+    if( hasLeft )
+    {
+        if( hasRight )
+        {
+            if( L.sp < MA_SEED_STACK )
+            {
+                L.stS[ L.sp ] = cE;
+                L.stN[ L.sp ] = aE - cE;
+                L.sp++;
+            }
+            else
+                L.err |= MA_ERR_STACK_OVERFLOW;
+        }
+        L.aN = cS - L.aS; // [aS, cS)
+        L.phase = PH_NEW_CENTER;
+    }
+    else if( hasRight )
+    {
+        L.aS = cE;
+        L.aN = aE - cE;
+        L.phase = PH_NEW_CENTER;
+    }
+    else if( L.sp > 0 )
+    {
+        L.sp--;
+        L.aS = L.stS[ L.sp ];
+        L.aN = L.stN[ L.sp ];
+        L.phase = PH_NEW_CENTER;
+    }
+    else
+        L.phase = PH_DONE;
+}
+
+MA_HD bool seed_stop( const SeedParams& P, const i64 ok[ 3 ], const i64 ik[ 3 ] ) // binarySeeding.h:109-112
+{
+    if( ok[ 2 ] <= 0 )
+        return true;
+    return ok[ 2 ] <= (i64)P.min_amb && ik[ 2 ] <= (i64)P.max_amb;
+}
+
+// ---- transitions (no index access) ----------------------------------------------------------
+// Runs cheap bookkeeping until the lane either needs an extension (returns true and sets c) or is done.
+MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
+{
+    while( true )
+    {
+        switch( L.phase )
+        {
+            case PH_DONE:
+                return false;
+            case PH_NEW_CENTER:
+            {
+                L.center = L.aS + L.aN / 2;
+                const u32 qc = L.q[ L.center ];
+                if( qc >= 4 )
+                { // N covers one position (binarySeeding.h:70-72 / 275-277)
+                    seed_after_center( L, L.center, 1 );
+                    break;
+                }
+                init_interval( X, 3 - qc, L.ik );
+                if( P.technique == 0 )
+                {
+                    if( L.ik[ 2 ] == 0 )
+                    {
+                        seed_after_center( L, L.center, 1 );
+                        break;
+                    }
+                    L.end = L.center;
+                    L.i = L.center + 1;
+                    L.phase = PH_P1_RIGHT;
+                }
+                else
+                {
+                    L.nCurr = 0;
+                    L.retS = L.retE = L.center;
+                    L.i = L.center + 1;
+                    L.flip = 0;
+                    L.phase = PH_SMEM_FWD;
+                }
+                break;
+            }
+            case PH_P1_RIGHT:
+                if( L.i < L.qlen )
+                {
+                    c = comp_base( L.q[ L.i ] );
+                    return true;
+                }
+                // end of query: switch direction (binarySeeding.h:118-120)
+                mswap( L.ik[ 0 ], L.ik[ 1 ] );
+                L.start = L.center;
+                if( L.center > 0 )
+                {
+                    L.i = L.center - 1;
+                    L.phase = PH_P1_LEFT;
+                    break;
+                }
+                L.phase = PH_P1_LEFT;
+                L.i = 0xffffffffu; // sentinel: left loop skipped
+                break;
+            case PH_P1_LEFT:
+                if( L.i != 0xffffffffu )
+                {
+                    c = L.q[ L.i ];
+                    return true;
+                }
+                // record first segment and start the second pass (binarySeeding.h:152-163)
+                seed_emit( L, S, L.start, L.end - L.start, L.ik[ 0 ], L.ik[ 1 ], L.ik[ 2 ] );
+                L.s1_start = L.start;
+                L.s1_end = L.end;
+                init_interval( X, L.q[ L.center ], L.ik );
+                L.start = L.center;
+                L.phase = PH_P2_LEFT;
+                L.i = L.center > 0 ? L.center - 1 : 0xffffffffu;
+                break;
+            case PH_P2_LEFT:
+                if( L.i != 0xffffffffu )
+                {
+                    c = L.q[ L.i ];
+                    return true;
+                }
+                mswap( L.ik[ 0 ], L.ik[ 1 ] );
+                L.end = L.center;
+                L.i = L.center + 1;
+                L.phase = PH_P2_RIGHT;
+                break;
+            case PH_P2_RIGHT:
+                if( L.i < L.qlen )
+                {
+                    c = comp_base( L.q[ L.i ] );
+                    return true;
+                }
+                {
+                    // finish the center (binarySeeding.h:226-251)
+                    if( L.s1_start == L.start && L.s1_end == L.end )
+                        seed_after_center( L, L.s1_start, L.s1_end - L.s1_start );
+                    else
+                    {
+                        seed_emit( L, S, L.start, L.end - L.start, L.ik[ 1 ], L.ik[ 0 ], L.ik[ 2 ] );
+                        const u32 s = L.start < L.s1_start ? L.start : L.s1_start;
+                        const u32 e = L.end > L.s1_end ? L.end : L.s1_end;
+                        seed_after_center( L, s, e - s );
+                    }
+                }
+                break;
+            case PH_SMEM_FWD:
+                if( L.i < L.qlen )
+                {
+                    c = comp_base( L.q[ L.i ] );
+                    return true;
+                }
+                // forward phase over: reverse the list (binarySeeding.h:343) and go backwards
+                {
+                    ma_segment* cur = S.smem_a;
+                    for( u32 a = 0, b = L.nCurr; a + 1 < b; a++, b-- )
+                    {
+                        ma_segment t = cur[ a ];
+                        cur[ a ] = cur[ b - 1 ];
+                        cur[ b - 1 ] = t;
+                    }
+                    L.nPrev = L.nCurr;
+                    L.nCurr = 0;
+                    L.flip = 0; // prev = smem_a, curr = smem_b
+                    L.jPrev = 0;
+                    L.bHaveOne = 0;
+                    if( L.center != 0 && L.nPrev > 0 )
+                    {
+                        L.i = L.center - 1;
+                        L.phase = PH_SMEM_BWD;
+                    }
+                    else
+                    {
+                        // cannot extend backwards at all (binarySeeding.h:354, 437-448)
+                        if( L.nPrev > 0 )
+                        {
+                            const ma_segment& f = S.smem_a[ 0 ];
+                            seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
+                        }
+                        seed_after_center( L, L.retS, L.retE - L.retS );
+                    }
+                }
+                break;
+            case PH_SMEM_BWD:
+            {
+                ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
+                if( L.jPrev < L.nPrev )
+                {
+                    L.ik[ 0 ] = prev[ L.jPrev ].sa_start;
+                    L.ik[ 1 ] = prev[ L.jPrev ].sa_start_rc;
+                    L.ik[ 2 ] = prev[ L.jPrev ].sa_size;
+                    c = L.q[ L.i ];
+                    return true;
+                }
+                // end of one backward position: swap lists (binarySeeding.h:416-433)
+                L.flip ^= 1;
+                L.nPrev = L.nCurr;
+                L.nCurr = 0;
+                L.jPrev = 0;
+                L.bHaveOne = 0;
+                bool fin = false;
+                if( L.nPrev == 0 )
+                    fin = true;
+                else
+                {
+                    L.retS = L.i;
+                    if( L.i == 0 )
+                        fin = true;
+                    else
+                        L.i--;
+                }
+                if( fin )
+                {
+                    if( L.nPrev > 0 )
+                    {
+                        const ma_segment& f = ( L.flip ? S.smem_b : S.smem_a )[ 0 ];
+                        seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
+                    }
+                    seed_after_center( L, L.retS, L.retE - L.retS );
+                }
+                break;
+            }
+            default:
+                return false;
+        }
+    }
+}
+
+// ---- apply the result of the extension requested by seed_prepare --------------------------------
+MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, const i64 ok[ 3 ] )
+{
+    switch( L.phase )
+    {
+        case PH_P1_RIGHT:
+        case PH_P2_RIGHT:
+            if( seed_stop( P, ok, L.ik ) )
+                L.i = L.qlen; // leave the loop; seed_prepare performs the transition
+            else
+            {
+                L.end = L.i;
+                L.ik[ 0 ] = ok[ 0 ], L.ik[ 1 ] = ok[ 1 ], L.ik[ 2 ] = ok[ 2 ];
+                L.i++;
+            }
+            break;
+        case PH_P1_LEFT:
+        case PH_P2_LEFT:
+            if( seed_stop( P, ok, L.ik ) )
+                L.i = 0xffffffffu;
+            else
+            {
+                L.start = L.i;
+                L.ik[ 0 ] = ok[ 0 ], L.ik[ 1 ] = ok[ 1 ], L.ik[ 2 ] = ok[ 2 ];
+                L.i = L.i == 0 ? 0xffffffffu : L.i - 1;
+            }
+            break;
+        case PH_SMEM_FWD:
+        { // binarySeeding.h:296-337
+            ma_segment* cur = S.smem_a;
+            auto push = [ & ]( u32 st, u32 sz, i64 a, i64 b, i64 c ) {
+                if( L.nCurr < S.smem_cap )
+                {
+                    ma_segment s;
+                    s.q_start = st, s.q_size = sz, s.sa_start = a, s.sa_start_rc = b, s.sa_size = c;
+                    cur[ L.nCurr ] = s;
+                }
+                else
+                    L.err |= MA_ERR_SMEM_OVERFLOW;
+                L.nCurr++;
+            };
+            if( ok[ 2 ] != L.ik[ 2 ] )
+                push( L.center, L.i - L.center - 1, L.ik[ 1 ], L.ik[ 0 ], L.ik[ 2 ] );
+            if( L.i == L.qlen - 1 && ok[ 2 ] != 0 )
+                push( L.center, L.i - L.center, ok[ 1 ], ok[ 0 ], ok[ 2 ] );
+            if( ok[ 2 ] == 0 || ( ok[ 2 ] <= (i64)P.min_amb && L.ik[ 2 ] <= (i64)P.max_amb ) )
+                L.i = L.qlen; // break
+            else
+            {
+                L.ik[ 0 ] = ok[ 0 ], L.ik[ 1 ] = ok[ 1 ], L.ik[ 2 ] = ok[ 2 ];
+                L.retE = L.i;
+                L.i++;
+            }
+            break;
+        }
+        case PH_SMEM_BWD:
+        { // binarySeeding.h:380-413
+            ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
+            ma_segment* curr = L.flip ? S.smem_a : S.smem_b;
+            const ma_segment s = prev[ L.jPrev ];
+            if( ok[ 2 ] <= (i64)P.min_amb && !L.bHaveOne )
+            {
+                seed_emit( L, S, (u32)s.q_start, (u32)s.q_size, s.sa_start, s.sa_start_rc, s.sa_size );
+                L.bHaveOne = 1;
+            }
+            else if( ok[ 2 ] > (i64)P.min_amb || ( ok[ 2 ] > 0 && (u64)s.q_size >= (u64)P.max_amb ) )
+            {
+                if( L.nCurr < S.smem_cap )
+                {
+                    ma_segment t;
+                    t.q_start = L.i, t.q_size = s.q_size + 1, t.sa_start = ok[ 0 ], t.sa_start_rc = ok[ 1 ],
+                    t.sa_size = ok[ 2 ];
+                    curr[ L.nCurr ] = t;
+                }
+                else
+                    L.err |= MA_ERR_SMEM_OVERFLOW;
+                L.nCurr++;
+            }
+            L.jPrev++;
+            break;
+        }
+        default:
+            break;
+    }
+}
+
+// BinarySeeding::execute's post filter (binarySeeding.cpp:172-175, numSeedsLarger segment.h:278-289):
+// returns the number of segments to keep (0 = drop all)
+MA_HD u32 seed_finish( const SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X )
+{
+    u32 n = L.nseg < S.seg_cap ? L.nseg : S.seg_cap;
+    if( !P.disable_heuristics && P.min_seed_size_drop != 0 )
+    {
+        u64 sum = 0;
+        for( u32 k = 0; k < n; k++ )
+            sum += (u64)S.stage[ k ].q_size / (u64)P.min_seed_size_drop;
+        if( (double)sum < P.rel_min_seed_size_amount * (double)L.qlen && P.genome_size_disable < X.n )
+            n = 0;
+    }
+    return n;
+}
+
+// Whole read on one lane (used by the host emulation and as the loop body of the kernel).
+MA_HD void seed_read_serial( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X )
+{
+    u32 c;
+    while( seed_prepare( L, P, S, X, c ) )
+    {
+        i64 ok[ 3 ];
+        u32 nb;
+        extend_backward( X, L.ik, c, ok, nb );
+        L.steps++;
+        L.blocks += nb;
+        seed_apply( L, P, S, ok );
+    }
+}
+} // namespace ma

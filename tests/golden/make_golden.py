@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors in this directory from the REAL reference.
+
+Needs oracle/_ref/ref_dump (built by `make -C oracle ref` from /root/reference; only possible in the
+build container).  The outputs are data only: synthetic inputs (case files) and the reference's
+results on them (text dumps / index files).  Run:  python tests/golden/make_golden.py
+"""
+import gzip
+import os
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from ma_testlib import (rand_genome, sample_reads, write_case, write_ksw_cases, rand_ksw_cases, run_ref, have_ref)  # noqa
+
+
+def gz(path):
+    with open(path, "rb") as f, gzip.open(path + ".gz", "wb", compresslevel=9) as g:
+        shutil.copyfileobj(f, g)
+    os.remove(path)
+
+
+def main():
+    if not have_ref():
+        sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle ref` where /root/reference exists")
+    os.chdir(HERE)
+    # G1/G2/G3..G8: small multi-contig genome with a planted repeat family
+    g = rand_genome(101, [30000, 22000, 9000], repeat_unit=200, repeat_copies=25, repeat_div=0.06)
+    reads = (sample_reads(g, 90, 150, 201, sub=0.01) + sample_reads(g, 20, 150, 202, sub=0.06, n_rate=0.01)
+             + sample_reads(g, 6, 2500, 203, sub=0.01, ins=0.005, dele=0.005)
+             + sample_reads(g, 4, 150, 204, random_frac=1.0) + sample_reads(g, 4, 14, 205) + sample_reads(g, 4, 17, 206))
+    write_case("small.case", g, reads)
+    run_ref("index", "small.case", "small_ref")
+    for ext in ("ann", "amb"):
+        if os.path.exists("small_ref." + ext):
+            os.remove("small_ref." + ext)
+    run_ref("ext", "small.case", "small_ref.ext")
+    for preset in ("default", "illumina"):
+        run_ref("pipe", "small.case", preset, 1, "small_ref.%s.pipe" % preset)
+    run_ref("pipe", "small.case", "default", 7, "small_ref.default.seed7.pipe")
+    # G7: kswcpp cases (all three flag modes, N bases, narrow bands, int16/int32 boundary)
+    cases = rand_ksw_cases(600, 301, max_len=120) + rand_ksw_cases(12, 302, long_frac=1.0)
+    write_ksw_cases("ksw.case", cases)
+    run_ref("ksw", "ksw.case", "ksw_ref.out")
+    for f in ("small_ref.ext", "small_ref.default.pipe", "small_ref.illumina.pipe", "small_ref.default.seed7.pipe",
+              "ksw_ref.out", "small.case", "ksw.case", "small_ref.bwt", "small_ref.sa", "small_ref.pac"):
+        gz(f)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

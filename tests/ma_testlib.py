@@ -211,3 +211,232 @@ def first_diff(a_path, b_path, context=3):
     if len(la) != len(lb):
         return "length differs: %d vs %d" % (len(la), len(lb))
     return None
+
+
+# ---------------------------------------------------------------------------------------------
+# dump parsing (the text format written by ref_dump / oracle_dump / host_emul)
+# ---------------------------------------------------------------------------------------------
+def _open(path):
+    import gzip
+    return gzip.open(path, "rt") if str(path).endswith(".gz") else open(path)
+
+
+def parse_pipe_dump(path):
+    reads = []
+    cur = None
+    with _open(path) as f:
+        for line in f:
+            t = line.split()
+            k = t[0]
+            if k == "R":
+                cur = dict(len=int(t[2]), segs=[], seeds=[], socs=[], hsets=[], alns=[], mq=[])
+                reads.append(cur)
+            elif k == "s":
+                cur["segs"].append(tuple(int(x) for x in t[1:6]))
+            elif k == "d":
+                cur["seeds"].append(tuple(int(x) for x in t[1:7]))
+            elif k == "c":
+                cur["socs"].append(dict(idx=int(t[1]), score=int(t[2]), amb=int(t[3]), seeds=[]))
+            elif k == "e":
+                cur["socs"][-1]["seeds"].append(tuple(int(x) for x in t[1:7]))
+            elif k == "h":
+                cur["hsets"].append(dict(soc=int(t[1]), seeds=[]))
+            elif k == "g":
+                cur["hsets"][-1]["seeds"].append(tuple(int(x) for x in t[1:7]))
+            elif k == "a":
+                ops = [tuple(int(y) for y in x.split(":")) for x in t[8:]]
+                cur["alns"].append(dict(bref=int(t[1]), eref=int(t[2]), bq=int(t[3]), eq=int(t[4]), score=int(t[5]),
+                                        soc=int(t[6]), ops=ops))
+            elif k == "m":
+                cur["mq"].append(dict(bref=int(t[1]), eref=int(t[2]), bq=int(t[3]), eq=int(t[4]), score=int(t[5]),
+                                      secondary=int(t[6]), supplementary=int(t[7]), mapq=float(t[8])))
+    return reads
+
+
+def parse_ksw_dump(path):
+    out = []
+    with _open(path) as f:
+        for line in f:
+            t = line.split()
+            v = [int(x) for x in t[2:13]]
+            out.append(dict(max=v[0], zdropped=v[1], max_q=v[2], max_t=v[3], mqe=v[4], mqe_t=v[5], mte=v[6],
+                            mte_q=v[7], score=v[8], reach_end=v[9], n_cigar=v[10],
+                            cigar=[int(x) for x in t[13:]]))
+    return out
+
+
+def gunzip_to(src_gz, dst):
+    import gzip
+    import shutil
+    with gzip.open(src_gz, "rb") as f, open(dst, "wb") as g:
+        shutil.copyfileobj(f, g)
+    return dst
+
+
+# ---------------------------------------------------------------------------------------------
+# ctypes binding of the oracle (TEST INFRASTRUCTURE)
+# ---------------------------------------------------------------------------------------------
+class OrParams(C.Structure):
+    _fields_ = [
+        ("seeding_technique", C.c_int32), ("min_seed_len", C.c_int32), ("min_ambiguity", C.c_int32),
+        ("max_ambiguity", C.c_int32), ("min_seed_size_drop", C.c_int32), ("max_num_soc", C.c_int32),
+        ("min_num_soc", C.c_int32), ("harm_score_min", C.c_int32), ("max_score_lookahead", C.c_int32),
+        ("switch_qlen", C.c_int32), ("min_delta_dist", C.c_int32), ("max_gap_area", C.c_int32),
+        ("padding", C.c_int32), ("bandwidth_ext", C.c_int32), ("min_bandwidth_gap", C.c_int32),
+        ("zdrop", C.c_int32), ("sv_penalty", C.c_int32), ("match", C.c_int32), ("mismatch", C.c_int32),
+        ("gap", C.c_int32), ("extend", C.c_int32), ("gap2", C.c_int32), ("extend2", C.c_int32),
+        ("disable_heuristics", C.c_int32), ("soc_width", C.c_int32), ("srand_seed", C.c_uint32),
+        ("genome_size_disable", C.c_uint64), ("rel_min_seed_size_amount", C.c_double),
+        ("harm_score_min_rel", C.c_double), ("soc_score_decrease_tol", C.c_double),
+        ("score_diff_tol", C.c_double), ("max_delta_dist", C.c_double), ("min_alignment_score", C.c_int32),
+        ("report_n_best", C.c_int32), ("max_supplementary", C.c_int32), ("max_overlap_supplementary", C.c_double),
+    ]
+
+
+OR_SEGMENT_DT = np.dtype([("q_start", "<i8"), ("q_size", "<i8"), ("sa_start", "<i8"), ("sa_start_rc", "<i8"),
+                          ("sa_size", "<i8")])
+OR_SEED_DT = np.dtype([("q_start", "<i8"), ("len", "<i8"), ("r_start", "<i8"), ("delta", "<i8"), ("ambiguity", "<u4"),
+                       ("on_forward", "<u4")])
+OR_EZ_DT = np.dtype([(k, "<i4") for k in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score",
+                                          "reach_end", "n_cigar")])
+OR_ALN_DT = np.dtype([("begin_ref", "<i8"), ("end_ref", "<i8"), ("begin_q", "<i8"), ("end_q", "<i8"), ("score", "<i8"),
+                      ("soc_index", "<u4"), ("n_ops", "<u4"), ("ops_off", "<u8"), ("secondary", "<u4"),
+                      ("supplementary", "<u4"), ("mapq", "<f8")])
+
+_orlib = None
+
+
+def orlib():
+    global _orlib
+    if _orlib is None:
+        build_oracle()
+        L = C.CDLL(os.path.join(ORACLE_DIR, "libma_oracle.so"))
+        L.ma_or_index_build.restype = C.c_void_p
+        L.ma_or_index_from_parts.restype = C.c_void_p
+        L.ma_or_align_batch.restype = C.c_void_p
+        for fn in ("ma_or_index_n_words", "ma_or_index_n_sa", "ma_or_res_n_ops", "ma_or_res_n_aligned"):
+            getattr(L, fn).restype = C.c_uint64
+        for fn in ("ma_or_index_bwt", "ma_or_index_sa", "ma_or_index_pac", "ma_or_res_seg_off", "ma_or_res_segs",
+                   "ma_or_res_seed_off", "ma_or_res_seeds", "ma_or_res_hset_off", "ma_or_res_hseed_off",
+                   "ma_or_res_hset_soc", "ma_or_res_hseeds", "ma_or_res_aln_off", "ma_or_res_alns", "ma_or_res_ops"):
+            getattr(L, fn).restype = C.c_void_p
+        L.ma_or_bwt_sa.restype = C.c_int64
+        _orlib = L
+    return _orlib
+
+
+def or_params(preset="default", seed=1):
+    p = OrParams()
+    if preset == "illumina":
+        orlib().ma_or_params_illumina(C.byref(p))
+    else:
+        orlib().ma_or_params_default(C.byref(p))
+    p.srand_seed = seed
+    return p
+
+
+def _np_from(ptr, n, dt):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dt)
+    buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt).copy()
+
+
+class OrIndex:
+    def __init__(self, h, contig_lens):
+        self.h = C.c_void_p(h)
+        self.contig_lens = np.asarray(contig_lens, dtype=np.uint64)
+        self.contig_starts = np.concatenate([[0], np.cumsum(self.contig_lens)[:-1]]).astype(np.uint64)
+
+    @staticmethod
+    def build(contigs):
+        lens = np.array([len(c) for c in contigs], dtype=np.uint64)
+        cat = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint8) for c in contigs]))
+        h = orlib().ma_or_index_build(C.c_int32(len(lens)), lens.ctypes.data_as(C.c_void_p),
+                                      cat.ctypes.data_as(C.c_void_p))
+        return OrIndex(h, lens)
+
+    @staticmethod
+    def from_parts(d):
+        bwt = np.ascontiguousarray(d["bwt"], dtype=np.uint32)
+        sa = np.ascontiguousarray(d["sa"], dtype=np.int64)
+        L2 = np.ascontiguousarray(d["L2"], dtype=np.uint64)
+        pac = np.ascontiguousarray(d["pac"], dtype=np.uint8)
+        cs = np.ascontiguousarray(d["contig_starts"], dtype=np.uint64)
+        cl = np.ascontiguousarray(d["contig_lens"], dtype=np.uint64)
+        h = orlib().ma_or_index_from_parts(bwt.ctypes.data_as(C.c_void_p), C.c_uint64(len(bwt)),
+                                           sa.ctypes.data_as(C.c_void_p), C.c_uint64(len(sa)),
+                                           L2.ctypes.data_as(C.c_void_p), C.c_int64(int(d["primary"])),
+                                           C.c_uint64(int(d["ref_len"])), pac.ctypes.data_as(C.c_void_p),
+                                           C.c_int32(len(cs)), cs.ctypes.data_as(C.c_void_p),
+                                           cl.ctypes.data_as(C.c_void_p))
+        return OrIndex(h, cl)
+
+    def arrays(self):
+        L = orlib()
+        nw = L.ma_or_index_n_words(self.h)
+        ns = L.ma_or_index_n_sa(self.h)
+        L2 = np.zeros(5, dtype=np.uint64)
+        primary = C.c_int64()
+        ref_len = C.c_uint64()
+        L.ma_or_index_meta(self.h, L2.ctypes.data_as(C.c_void_p), C.byref(primary), C.byref(ref_len))
+        F = ref_len.value // 2
+        return dict(bwt=_np_from(L.ma_or_index_bwt(self.h), nw, np.uint32),
+                    sa=_np_from(L.ma_or_index_sa(self.h), ns, np.int64), L2=L2, primary=primary.value,
+                    ref_len=ref_len.value, pac=_np_from(L.ma_or_index_pac(self.h), (F + 3) // 4, np.uint8),
+                    contig_starts=self.contig_starts, contig_lens=self.contig_lens)
+
+    def extend_backward(self, ik, c):
+        ik = np.ascontiguousarray(ik, dtype=np.int64).reshape(-1, 3)
+        ok = np.zeros_like(ik)
+        for i in range(len(ik)):
+            a = ik[i].copy()
+            o = np.zeros(3, dtype=np.int64)
+            orlib().ma_or_extend_backward(self.h, a.ctypes.data_as(C.c_void_p), C.c_uint8(int(c[i])),
+                                          o.ctypes.data_as(C.c_void_p))
+            ok[i] = o
+        return ok
+
+    def bwt_sa(self, rows):
+        return np.array([orlib().ma_or_bwt_sa(self.h, C.c_int64(int(r))) for r in rows], dtype=np.int64)
+
+    def align(self, reads, params, threads=1):
+        off = np.zeros(len(reads) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(r) for r in reads])
+        cat = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.uint8) for r in reads]
+                                                  + [np.zeros(1, dtype=np.uint8)]))
+        L = orlib()
+        r = C.c_void_p(L.ma_or_align_batch(self.h, C.byref(params), cat.ctypes.data_as(C.c_void_p),
+                                           off.ctypes.data_as(C.c_void_p), C.c_uint64(len(reads)), C.c_int32(threads)))
+        n = len(reads)
+        res = {}
+        res["seg_off"] = _np_from(L.ma_or_res_seg_off(r), n + 1, np.uint64)
+        res["segs"] = _np_from(L.ma_or_res_segs(r), int(res["seg_off"][-1]), OR_SEGMENT_DT)
+        res["seed_off"] = _np_from(L.ma_or_res_seed_off(r), n + 1, np.uint64)
+        res["seeds"] = _np_from(L.ma_or_res_seeds(r), int(res["seed_off"][-1]), OR_SEED_DT)
+        res["hset_off"] = _np_from(L.ma_or_res_hset_off(r), n + 1, np.uint64)
+        nh = int(res["hset_off"][-1])
+        res["hseed_off"] = _np_from(L.ma_or_res_hseed_off(r), nh + 1, np.uint64)
+        res["hset_soc"] = _np_from(L.ma_or_res_hset_soc(r), nh, np.uint32)
+        res["hseeds"] = _np_from(L.ma_or_res_hseeds(r), int(res["hseed_off"][-1]), OR_SEED_DT)
+        res["aln_off"] = _np_from(L.ma_or_res_aln_off(r), n + 1, np.uint64)
+        res["alns"] = _np_from(L.ma_or_res_alns(r), int(res["aln_off"][-1]), OR_ALN_DT)
+        res["ops"] = _np_from(L.ma_or_res_ops(r), 2 * int(L.ma_or_res_n_ops(r)), np.uint64)
+        ctr = np.zeros(8, dtype=np.uint64)
+        L.ma_or_res_counters(r, ctr.ctypes.data_as(C.c_void_p))
+        res["counters"] = ctr
+        res["n_aligned"] = int(L.ma_or_res_n_aligned(r))
+        L.ma_or_result_free(r)
+        return res
+
+
+def or_ksw(params, q, t, w, zdrop, flag):
+    q = np.ascontiguousarray(q, dtype=np.uint8)
+    t = np.ascontiguousarray(t, dtype=np.uint8)
+    ez = np.zeros(1, dtype=OR_EZ_DT)
+    cap = len(q) + len(t) + 8
+    cig = np.zeros(cap, dtype=np.uint32)
+    n = orlib().ma_or_ksw(C.c_int32(len(q)), q.ctypes.data_as(C.c_void_p), C.c_int32(len(t)),
+                          t.ctypes.data_as(C.c_void_p), C.c_int32(w), C.c_int32(zdrop), C.c_int32(flag),
+                          C.byref(params), ez.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p), C.c_int32(cap))
+    return ez[0], cig[:max(n, 0)].copy()

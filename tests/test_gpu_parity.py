@@ -1,0 +1,257 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the oracle and against the golden
+vectors produced by the real reference.  Bit-exact on every integer output."""
+import os
+
+import numpy as np
+import pytest
+
+from ma_testlib import (ROOT, gunzip_to, read_case, read_ksw_cases, parse_pipe_dump, parse_ksw_dump, OrIndex, or_params,
+                        rand_genome, sample_reads, rand_ksw_cases, or_ksw)
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def gpu_pipeline(index, preset, seed, reads, stages=True):
+    import ma_amd
+    P = ma_amd.Params.preset(preset)
+    P.srand_seed = seed
+    b = ma_amd.Batch(index, P, max(len(reads), 1), sum(len(r) for r in reads) + 64)
+    b.set_reads(reads)
+    b.seed()
+    b.extract()
+    b.chain()
+    b.dp()
+    b.sync()
+    out = []
+    soff, segs = b.segments()
+    doff, seeds = b.seeds()
+    hoff, hsoff, hsoc, hseeds = b.hsets()
+    aoff, alns, ops = b.alignments()
+    moff, malns, mops = b.mapq_alignments()
+
+    def seedt(s):
+        return (int(s["q_start"]), int(s["len"]), int(s["r_start"]), int(s["ambiguity"]), int(s["on_forward"]),
+                int(s["delta"]))
+
+    for r in range(len(reads)):
+        d = dict(len=len(reads[r]))
+        d["segs"] = [tuple(int(x) for x in s) for s in segs[int(soff[r]):int(soff[r + 1])]]
+        d["seeds"] = [seedt(s) for s in seeds[int(doff[r]):int(doff[r + 1])]]
+        d["hsets"] = []
+        for h in range(int(hoff[r]), int(hoff[r + 1])):
+            d["hsets"].append(dict(soc=int(hsoc[h]), seeds=[seedt(s) for s in hseeds[int(hsoff[h]):int(hsoff[h + 1])]]))
+        d["alns"] = []
+        for a in alns[int(aoff[r]):int(aoff[r + 1])]:
+            o = int(a["ops_off"])
+            d["alns"].append(dict(bref=int(a["begin_ref"]), eref=int(a["end_ref"]), bq=int(a["begin_q"]),
+                                  eq=int(a["end_q"]), score=int(a["score"]), soc=int(a["soc_index"]),
+                                  ops=[(int(ops[2 * (o + k)]), int(ops[2 * (o + k) + 1])) for k in range(int(a["n_ops"]))]))
+        d["mq"] = []
+        for a in malns[int(moff[r]):int(moff[r + 1])]:
+            d["mq"].append(dict(bref=int(a["begin_ref"]), eref=int(a["end_ref"]), bq=int(a["begin_q"]), eq=int(a["end_q"]),
+                                score=int(a["score"]), secondary=int(a["secondary"]),
+                                supplementary=int(a["supplementary"]), mapq=float(a["mapq"])))
+        out.append(d)
+    counters = b.counters()
+    counts = b.counts()
+    b.close()
+    return out, counters, counts
+
+
+def compare_reads(got, want, what=("segs", "seeds", "hsets", "alns", "mq")):
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        for k in what:
+            if k == "mq":
+                assert len(g[k]) == len(w[k]), "read %d: mq count %d vs %d" % (i, len(g[k]), len(w[k]))
+                for a, b in zip(g[k], w[k]):
+                    for f in ("bref", "eref", "bq", "eq", "score", "secondary", "supplementary"):
+                        assert a[f] == b[f], "read %d mq field %s: %s vs %s" % (i, f, a, b)
+                    assert float("%.17g" % a["mapq"]) == b["mapq"], "read %d mapq %r vs %r" % (i, a["mapq"], b["mapq"])
+            else:
+                assert g[k] == w[k], "read %d stage %s differs:\n got  %s\n want %s" % (i, k, g[k][:6], w[k][:6])
+
+
+@pytest.fixture(scope="module")
+def small(tmp_path_factory, gpu_device):
+    import ma_amd
+    d = tmp_path_factory.mktemp("gpu")
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(d / "small.case"))
+    contigs, reads, _ = read_case(case)
+    oidx = OrIndex.build(contigs)
+    gidx = ma_amd.Index.from_arrays(**oidx.arrays())
+    return dict(contigs=contigs, reads=reads, oidx=oidx, gidx=gidx, dir=d)
+
+
+def test_extend_backward_and_bwt_sa(small):
+    oidx, gidx = small["oidx"], small["gidx"]
+    A = oidx.arrays()
+    n, L2 = A["ref_len"], A["L2"]
+    rng = np.random.default_rng(5)
+    iks, cs = [], []
+    # intervals reached by backward search of random reads (covers primary / block boundaries) + raw ones
+    for r in small["reads"][:60]:
+        q = r[r < 4]
+        if len(q) < 2:
+            continue
+        c0 = int(q[-1])
+        ik = np.array([L2[c0] + 1, L2[3 - c0] + 1, L2[c0 + 1] - L2[c0]], dtype=np.int64)
+        for j in range(len(q) - 2, max(len(q) - 14, -1), -1):
+            for c in range(5):
+                iks.append(ik.copy())
+                cs.append(c)
+            ik = oidx.extend_backward(ik.reshape(1, 3), [int(q[j])])[0]
+            if ik[2] <= 0:
+                break
+    for _ in range(500):
+        s = int(rng.integers(1, n))
+        sz = int(rng.integers(1, min(2000, n + 1 - s) + 1))
+        iks.append(np.array([s, int(rng.integers(1, n)), sz], dtype=np.int64))
+        cs.append(int(rng.integers(0, 5)))
+    iks.append(np.array([1, 1, n], dtype=np.int64))  # whole range incl. primary
+    cs.append(2)
+    iks = np.array(iks, dtype=np.int64)
+    cs = np.array(cs, dtype=np.uint8)
+    want = oidx.extend_backward(iks, cs)
+    got = gidx.extend_backward(iks, cs)
+    assert np.array_equal(got, want)
+    rows = np.concatenate([rng.integers(1, n + 1, size=3000), [1, n, A["primary"], 32, 31, 33]]).astype(np.int64)
+    assert np.array_equal(gidx.bwt_sa(rows), oidx.bwt_sa(rows))
+
+
+def test_ksw_golden_cases(gpu_device, tmp_path):
+    import ma_amd
+    case = gunzip_to(os.path.join(G, "ksw.case.gz"), str(tmp_path / "ksw.case"))
+    ref = parse_ksw_dump(os.path.join(G, "ksw_ref.out.gz"))
+    cases = read_ksw_cases(case)
+    ez, cigs = ma_amd.ksw_batch(ma_amd.Params.preset("default"), cases)
+    for i, w in enumerate(ref):
+        for f in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "reach_end", "n_cigar"):
+            assert int(ez[f][i]) == w[f], "case %d field %s: %d vs %d (qlen %d tlen %d w %d zdrop %d flag %d)" % (
+                i, f, int(ez[f][i]), w[f], len(cases[i][0]), len(cases[i][1]), cases[i][2], cases[i][3], cases[i][4])
+        assert list(cigs[i]) == w["cigar"], "case %d cigar" % i
+
+
+def test_ksw_random_vs_oracle(gpu_device):
+    import ma_amd
+    cases = rand_ksw_cases(1500, 4242, max_len=260) + rand_ksw_cases(20, 4243, long_frac=1.0)
+    # degenerate shapes
+    cases += [(np.array([1], dtype=np.uint8), np.array([1, 2, 3] * 30, dtype=np.uint8), 512, 200, 0x40),
+              (np.array([0, 1, 2, 3] * 10, dtype=np.uint8), np.array([2], dtype=np.uint8), 20, -1, 0),
+              (np.array([4] * 20, dtype=np.uint8), np.array([4] * 17, dtype=np.uint8), 20, -1, 0)]
+    P = ma_amd.Params.preset("default")
+    ez, cigs = ma_amd.ksw_batch(P, cases)
+    op = or_params()
+    for i, (q, t, w, zd, fl) in enumerate(cases):
+        oez, ocig = or_ksw(op, q, t, w, zd, fl)
+        for f in oez.dtype.names:
+            assert int(ez[f][i]) == int(oez[f]), "case %d field %s (qlen %d tlen %d w %d zdrop %d flag %d)" % (
+                i, f, len(q), len(t), w, zd, fl)
+        assert np.array_equal(cigs[i], ocig), "case %d cigar" % i
+
+
+@pytest.mark.parametrize("preset,seed,name", [("default", 1, "small_ref.default.pipe"),
+                                              ("illumina", 1, "small_ref.illumina.pipe"),
+                                              ("default", 7, "small_ref.default.seed7.pipe")])
+def test_pipeline_vs_reference_golden(small, preset, seed, name):
+    want = parse_pipe_dump(os.path.join(G, name + ".gz"))
+    got, counters, counts = gpu_pipeline(small["gidx"], preset, seed, small["reads"])
+    compare_reads(got, want)
+    assert counts["aligned_reads"] == sum(1 for w in want if w["mq"])
+
+
+def test_pipeline_counters_match_oracle(small):
+    res = small["oidx"].align(small["reads"], or_params("default", 1))
+    got, counters, counts = gpu_pipeline(small["gidx"], "default", 1, small["reads"])
+    c = res["counters"]
+    assert int(counters[0]) == int(c[0])  # extend_backward steps
+    assert int(counters[1]) == int(c[1])  # distinct occ blocks
+    assert int(counters[2]) == int(c[2])  # LF steps
+    assert int(counters[3]) == int(c[3])  # SA rows
+    assert int(counters[4]) == int(c[4])  # DP band cells
+    assert int(counters[5]) == int(c[5])  # ksw calls
+
+
+def test_empty_and_ragged_batches(small):
+    import ma_amd
+    got, _, counts = gpu_pipeline(small["gidx"], "default", 1, [])
+    assert got == [] and counts["alignments"] == 0
+    reads = [np.zeros(0, dtype=np.uint8), np.array([1], dtype=np.uint8), np.full(40, 4, dtype=np.uint8),
+             small["reads"][0], small["reads"][0][:20]]
+    oreads = [r for r in reads]
+    res = small["oidx"].align([r if len(r) else np.zeros(0, dtype=np.uint8) for r in oreads], or_params())
+    got, _, _ = gpu_pipeline(small["gidx"], "default", 1, reads)
+    for r in range(len(reads)):
+        want_segs = [tuple(int(x) for x in s) for s in res["segs"][int(res["seg_off"][r]):int(res["seg_off"][r + 1])]]
+        assert got[r]["segs"] == want_segs
+        assert len(got[r]["alns"]) == int(res["aln_off"][r + 1] - res["aln_off"][r])
+
+
+def test_index_build_on_gpu_matches_reference_files(small, tmp_path):
+    import ma_amd
+    gidx = ma_amd.Index.build(small["contigs"])
+    d = gidx.download()
+    ref_bwt = np.fromfile(gunzip_to(os.path.join(G, "small_ref.bwt.gz"), str(tmp_path / "r.bwt")), dtype=np.uint8)
+    ref_sa = np.fromfile(gunzip_to(os.path.join(G, "small_ref.sa.gz"), str(tmp_path / "r.sa")), dtype=np.uint8)
+    ref_pac = np.fromfile(gunzip_to(os.path.join(G, "small_ref.pac.gz"), str(tmp_path / "r.pac")), dtype=np.uint8)
+    # .bwt = primary(8) L2[1..4](32) words ; .sa = primary(8) L2(32) intv(4) seq_len(8) sa[1..]
+    hdr = np.concatenate([np.array([d["primary"]], dtype=np.int64).view(np.uint8), d["L2"][1:5].view(np.uint8)])
+    assert np.array_equal(np.concatenate([hdr, d["bwt"].view(np.uint8)]), ref_bwt)
+    sa_hdr = np.concatenate([hdr, np.array([32], dtype=np.int32).view(np.uint8),
+                             np.array([d["ref_len"]], dtype=np.uint64).view(np.uint8)])
+    assert np.array_equal(np.concatenate([sa_hdr, d["sa"][1:].view(np.uint8)]), ref_sa)
+    F = d["ref_len"] // 2
+    assert np.array_equal(d["pac"][:(F + 3) // 4], ref_pac[:(F + 3) // 4])
+    gidx.close()
+
+
+def test_index_build_repeats_and_odd_lengths(gpu_device):
+    import ma_amd
+    for lens, kw in (([1000, 37, 128, 5000], {}), ([50000, 50001], dict(repeat_unit=700, repeat_copies=60, repeat_div=0.01)),
+                     ([64], {}), ([4000], dict(repeat_unit=3000, repeat_copies=3, repeat_div=0.0))):
+        g = rand_genome(int(sum(lens)), lens, **kw)
+        want = OrIndex.build(g).arrays()
+        gidx = ma_amd.Index.build(g)
+        got = gidx.download()
+        assert got["primary"] == want["primary"] and np.array_equal(got["L2"], want["L2"])
+        assert np.array_equal(got["bwt"], want["bwt"]), lens
+        assert np.array_equal(got["sa"], want["sa"]), lens
+        assert np.array_equal(got["pac"][:len(want["pac"])], want["pac"]), lens
+        gidx.close()
+
+
+@pytest.mark.parametrize("preset", ["default", "illumina"])
+def test_pipeline_vs_oracle_heuristics_long_reads(gpu_device, preset):
+    import ma_amd
+    g = rand_genome(9, [2600000, 1500000, 1000000], repeat_unit=300, repeat_copies=200, repeat_div=0.08)
+    reads = (sample_reads(g, 600, 150, 31, sub=0.01) + sample_reads(g, 100, 150, 32, sub=0.06, n_rate=0.01)
+             + sample_reads(g, 12, 6000, 33, sub=0.005, ins=0.003, dele=0.003)
+             + sample_reads(g, 2, 30000, 34, sub=0.03, ins=0.03, dele=0.04) + sample_reads(g, 20, 150, 35, random_frac=1.0))
+    gidx = ma_amd.Index.build(g)
+    oidx = OrIndex.from_parts(gidx.download())
+    res = oidx.align(reads, or_params(preset, 3), threads=8)
+    got, counters, counts = gpu_pipeline(gidx, preset, 3, reads)
+    want = []
+    for r in range(len(reads)):
+        d = dict(len=len(reads[r]))
+        d["segs"] = [tuple(int(x) for x in s) for s in res["segs"][int(res["seg_off"][r]):int(res["seg_off"][r + 1])]]
+        d["seeds"] = [(int(s["q_start"]), int(s["len"]), int(s["r_start"]), int(s["ambiguity"]), int(s["on_forward"]),
+                       int(s["delta"])) for s in res["seeds"][int(res["seed_off"][r]):int(res["seed_off"][r + 1])]]
+        d["hsets"] = []
+        for h in range(int(res["hset_off"][r]), int(res["hset_off"][r + 1])):
+            ss = res["hseeds"][int(res["hseed_off"][h]):int(res["hseed_off"][h + 1])]
+            d["hsets"].append(dict(soc=int(res["hset_soc"][h]),
+                                   seeds=[(int(s["q_start"]), int(s["len"]), int(s["r_start"]), int(s["ambiguity"]),
+                                           int(s["on_forward"]), int(s["delta"])) for s in ss]))
+        d["alns"] = []
+        for a in res["alns"][int(res["aln_off"][r]):int(res["aln_off"][r + 1])]:
+            o = int(a["ops_off"])
+            d["alns"].append(dict(bref=int(a["begin_ref"]), eref=int(a["end_ref"]), bq=int(a["begin_q"]),
+                                  eq=int(a["end_q"]), score=int(a["score"]), soc=int(a["soc_index"]),
+                                  ops=[(int(res["ops"][2 * (o + k)]), int(res["ops"][2 * (o + k) + 1]))
+                                       for k in range(int(a["n_ops"]))]))
+        want.append(d)
+    compare_reads(got, want, what=("segs", "seeds", "hsets", "alns"))
+    assert counts["aligned_reads"] == res["n_aligned"]
+    gidx.close()

@@ -1,0 +1,51 @@
+"""Product stage logic (ma_amd/csrc/{seeding,chain,nw,stdsort,fm_device}.h) compiled for the CPU by
+tests/emul/host_emul.cpp and diffed against the oracle and the reference's golden dumps.  The shipped
+path runs the same functions inside HIP kernels; this is the 'host logic' part of the CPU suite."""
+import os
+import subprocess
+
+import pytest
+
+from ma_testlib import ROOT, build_oracle, gunzip_to, first_diff, rand_genome, sample_reads, write_case, run_oracle
+
+EMUL = os.path.join(ROOT, "tests", "emul", "host_emul")
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    build_oracle()
+    src = os.path.join(ROOT, "tests", "emul", "host_emul.cpp")
+    deps = [src] + [os.path.join(ROOT, "ma_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "ma_amd", "csrc"))
+                    if f.endswith(".h")]
+    if not os.path.exists(EMUL) or any(os.path.getmtime(d) > os.path.getmtime(EMUL) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-w", "-I" + os.path.join(ROOT, "include"),
+                               src, "-o", EMUL, "-L" + os.path.join(ROOT, "oracle"), "-lma_oracle",
+                               "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+    return EMUL
+
+
+def test_stdsort_matches_libstdcxx(emul):
+    out = subprocess.check_output([emul, "x", "default", "3", "/dev/null", "sortcheck"]).decode()
+    assert "sortcheck ok" in out
+
+
+@pytest.mark.parametrize("preset,name", [("default", "small_ref.default.pipe"), ("illumina", "small_ref.illumina.pipe")])
+def test_stage_logic_vs_reference_golden(emul, tmp_path, preset, name):
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    ref = gunzip_to(os.path.join(G, name + ".gz"), str(tmp_path / name))
+    out = str(tmp_path / "emul.pipe")
+    subprocess.check_call([emul, case, preset, "1", out, "all"])
+    assert first_diff(ref, out) is None
+
+
+def test_stage_logic_vs_oracle_long_reads(emul, tmp_path):
+    g = rand_genome(77, [400000, 250000], repeat_unit=250, repeat_copies=60, repeat_div=0.05)
+    reads = (sample_reads(g, 120, 150, 1, sub=0.02) + sample_reads(g, 6, 5000, 2, sub=0.01, ins=0.005, dele=0.005)
+             + sample_reads(g, 1, 20000, 3, sub=0.03, ins=0.03, dele=0.03))
+    case = str(tmp_path / "c.case")
+    write_case(case, g, reads)
+    for preset in ("default", "illumina"):
+        run_oracle("pipe", case, preset, 5, str(tmp_path / "or.pipe"))
+        subprocess.check_call([emul, case, preset, "5", str(tmp_path / "em.pipe"), "all"])
+        assert first_diff(str(tmp_path / "or.pipe"), str(tmp_path / "em.pipe")) is None

@@ -1,0 +1,85 @@
+"""The oracle (oracle/, CPU restatement) against the golden vectors the REAL reference produced
+(tests/golden/make_golden.py).  Bit-exact on every integer; mapq compared as printed (%.17g)."""
+import filecmp
+import os
+
+import numpy as np
+import pytest
+
+from ma_testlib import (ROOT, gunzip_to, run_oracle, first_diff, orlib, or_params, OrIndex, read_case,
+                        read_ksw_cases, parse_ksw_dump, or_ksw)
+
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def small_case(tmp_path_factory):
+    d = tmp_path_factory.mktemp("golden")
+    return gunzip_to(os.path.join(G, "small.case.gz"), str(d / "small.case")), d
+
+
+def test_index_files_identical(small_case):
+    case, d = small_case
+    run_oracle("index", case, str(d / "or"))
+    for ext in ("bwt", "sa", "pac"):
+        ref = gunzip_to(os.path.join(G, "small_ref.%s.gz" % ext), str(d / ("ref." + ext)))
+        assert filecmp.cmp(ref, str(d / ("or." + ext)), shallow=False), ext
+
+
+def test_extend_backward_traces_identical(small_case):
+    case, d = small_case
+    run_oracle("ext", case, str(d / "or.ext"))
+    ref = gunzip_to(os.path.join(G, "small_ref.ext.gz"), str(d / "ref.ext"))
+    assert first_diff(ref, str(d / "or.ext")) is None
+
+
+@pytest.mark.parametrize("preset,seed,name", [("default", 1, "small_ref.default.pipe"),
+                                              ("illumina", 1, "small_ref.illumina.pipe"),
+                                              ("default", 7, "small_ref.default.seed7.pipe")])
+def test_pipeline_dump_identical(small_case, preset, seed, name):
+    case, d = small_case
+    out = str(d / (name + ".or"))
+    run_oracle("pipe", case, preset, seed, out)
+    ref = gunzip_to(os.path.join(G, name + ".gz"), str(d / name))
+    assert first_diff(ref, out) is None
+
+
+def test_ksw_golden(tmp_path):
+    case = gunzip_to(os.path.join(G, "ksw.case.gz"), str(tmp_path / "ksw.case"))
+    run_oracle("ksw", case, str(tmp_path / "or.out"))
+    ref = gunzip_to(os.path.join(G, "ksw_ref.out.gz"), str(tmp_path / "ref.out"))
+    assert first_diff(ref, str(tmp_path / "or.out")) is None
+
+
+def test_ksw_edge_cases_via_ctypes():
+    p = or_params()
+    # empty inputs reset ez only (kswcpp_core.h:362-364)
+    ez, cig = or_ksw(p, [], [0, 1, 2], 10, -1, 0)
+    assert ez["n_cigar"] == 0 and ez["max"] == 0 and ez["score"] == -2**31 and ez["max_q"] == -1
+    # 1x1 match
+    ez, cig = or_ksw(p, [2], [2], 10, -1, 0)
+    assert ez["score"] == 2 and list(cig) == [1 << 4 | 0]
+
+
+def test_glibc_rand_restatement_matches_libc():
+    import ctypes as C
+    libc = C.CDLL("libc.so.6")
+    L = orlib()
+    L.ma_or_rand.restype = C.c_int32
+    for seed in (0, 1, 7, 12345, 2**31 - 1):
+        libc.srand(C.c_uint(seed))
+        st = (C.c_uint32 * 35)()
+        L.ma_or_srand(C.c_uint32(seed), st)
+        for _ in range(1000):
+            assert libc.rand() == L.ma_or_rand(st)
+
+
+def test_counters_are_consistent(small_case):
+    case, d = small_case
+    contigs, reads, _ = read_case(case)
+    idx = OrIndex.build(contigs)
+    res = idx.align(reads[:40], or_params(), threads=2)
+    c = res["counters"]
+    assert c[0] > 0 and c[0] <= c[1] <= 2 * c[0]  # blocks per extend_backward in [1,2]
+    assert c[3] == len(res["seeds"])
+    assert c[5] > 0 and c[4] > 0

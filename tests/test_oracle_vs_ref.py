@@ -1,0 +1,49 @@
+"""Differential tests of the oracle against the real reference compiled into oracle/_ref (only where
+/root/reference was available to build it; skipped otherwise -- the committed golden vectors in
+tests/golden cover that case)."""
+import os
+
+import pytest
+
+from ma_testlib import (have_ref, rand_genome, sample_reads, write_case, write_ksw_cases, rand_ksw_cases, run_ref,
+                        run_oracle, first_diff)
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (no /root/reference here)")
+
+
+def test_ksw_random_cases(tmp_path):
+    cases = rand_ksw_cases(4000, 991, max_len=150) + rand_ksw_cases(40, 992, long_frac=1.0)
+    p = str(tmp_path / "k.case")
+    write_ksw_cases(p, cases)
+    run_ref("ksw", p, str(tmp_path / "ref.out"))
+    run_oracle("ksw", p, str(tmp_path / "or.out"))
+    assert first_diff(str(tmp_path / "ref.out"), str(tmp_path / "or.out")) is None
+
+
+@pytest.mark.parametrize("preset", ["default", "illumina"])
+def test_pipeline_with_heuristics_and_repeats(tmp_path, preset):
+    # doubled length > 10 Mnt so that the genome-size gated heuristics are active
+    g = rand_genome(5, [2600000, 1500000, 1000000], repeat_unit=300, repeat_copies=200, repeat_div=0.08)
+    reads = (sample_reads(g, 250, 150, 31, sub=0.01) + sample_reads(g, 60, 150, 32, sub=0.06, n_rate=0.01)
+             + sample_reads(g, 8, 6000, 33, sub=0.005, ins=0.003, dele=0.003)
+             + sample_reads(g, 2, 30000, 34, sub=0.03, ins=0.03, dele=0.04) + sample_reads(g, 10, 150, 35, random_frac=1.0))
+    p = str(tmp_path / "c.case")
+    write_case(p, g, reads)
+    run_ref("pipe", p, preset, 3, str(tmp_path / "ref.pipe"))
+    run_oracle("pipe", p, preset, 3, str(tmp_path / "or.pipe"))
+    assert first_diff(str(tmp_path / "ref.pipe"), str(tmp_path / "or.pipe")) is None
+
+
+def test_index_and_traces(tmp_path):
+    import filecmp
+    g = rand_genome(8, [70000, 1, 129, 40000])
+    reads = sample_reads(g[:1], 80, 120, 41, sub=0.02)
+    p = str(tmp_path / "c.case")
+    write_case(p, g, reads)
+    run_ref("index", p, str(tmp_path / "ref"))
+    run_oracle("index", p, str(tmp_path / "or"))
+    for ext in ("bwt", "sa", "pac"):
+        assert filecmp.cmp(str(tmp_path / ("ref." + ext)), str(tmp_path / ("or." + ext)), shallow=False)
+    run_ref("ext", p, str(tmp_path / "ref.ext"))
+    run_oracle("ext", p, str(tmp_path / "or.ext"))
+    assert first_diff(str(tmp_path / "ref.ext"), str(tmp_path / "or.ext")) is None
