@@ -255,6 +255,7 @@ inline void occ4( const ma_or_index& x, i64 k, u64 cntv[ 4 ] )
 // FMIndex::extend_backward (fMIndex.cpp:21-101) with bwt_2occ4's forced two-call branch (fMIndex.h:671-690)
 inline void extendBackward( const ma_or_index& x, const i64 ik[ 3 ], uint8_t c, i64 ok[ 3 ] )
 {
+    cnt( 0 ); // every call counts, also the c >= 4 early-out that touches no block
     if( c >= 4 )
     {
         ok[ 0 ] = ok[ 1 ] = ok[ 2 ] = 0;
@@ -264,7 +265,6 @@ inline void extendBackward( const ma_or_index& x, const i64 ik[ 3 ], uint8_t c, 
     u64 cntk[ 4 ], cntl[ 4 ], cnts[ 4 ];
     occ4( x, start - 1, cntk );
     occ4( x, end - 1, cntl );
-    cnt( 0 );
     {
         i64 k = start - 1, l = end - 1;
         i64 kb = k == -1 ? -1 : ( ( k - ( k >= x.primary ) ) >> 7 );
