@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned reads/s of the MI355X seed-and-extend path on BASELINE.json's workload.
+
+A "step" is one pass of the whole hot path (FMD seeding -> seed extraction -> SoC/harmonization ->
+banded-DP gap fill/extension -> mapping quality) over one batch of synthetic reads that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: 150 bp Illumina-like reads (0.5 %
+substitutions) against a GRCh38-sized synthetic genome (24 contigs, 3.09 Gnt, planted repeat
+families), Default preset, 10 steps x 1 M reads = 10 M reads on one MI355X.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used only for the barrier and the
+max-over-ranks time); reads are partitioned by index, the index is replicated, there is no data-path
+collective.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+          133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616,
+          64444167, 46709983, 50818468, 156040895, 57227415]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads-per-step", type=int, default=1000000)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--sub", type=float, default=0.005)
+    ap.add_argument("--ins", type=float, default=0.0)
+    ap.add_argument("--dele", type=float, default=0.0)
+    ap.add_argument("--genome-scale", type=float, default=1.0, help="fraction of GRCh38 contig lengths (tests only)")
+    ap.add_argument("--preset", default="default")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 off)")
+    ap.add_argument("--no-repeats", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import ma_amd
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    ma_amd.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    L = ma_amd.lib()
+
+    def chk(rc):
+        if rc != 0:
+            raise RuntimeError(L.ma_last_error().decode())
+
+    # ---- synthetic genome + index (not timed: one-off preprocessing) -----------------
+    lens = np.array([max(1000, int(x * args.genome_scale)) for x in GRCH38], dtype=np.uint64)
+    F = int(lens.sum())
+    t0 = time.perf_counter()
+    g = torch.empty(F, dtype=torch.uint8, device=dev)
+    chk(L.ma_synth_genome_device(C.c_uint64(2), C.c_uint64(F), C.c_int32(0 if args.no_repeats else 1),
+                                 C.c_void_p(g.data_ptr())))
+    idx = ma_amd.Index.build_device(lens, g.data_ptr())
+    del g
+    torch.cuda.empty_cache()
+    torch.cuda.synchronize()
+    t_index = time.perf_counter() - t0
+
+    # ---- reads: every rank owns steps x reads_per_step reads (weak scaling), resident in HBM ---------
+    B, K, W = args.reads_per_step, args.steps, args.warmup
+    n_reads = B * K
+    cap = int(n_reads * (args.read_len * (1.0 + 2 * args.ins) + 8)) + 1024
+    codes = torch.empty(cap, dtype=torch.uint8, device=dev)
+    offs = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
+    nb = C.c_uint64()
+    seed = 11 if args.read_len <= 1000 else (12 if args.read_len <= 20000 else 13)
+    chk(L.ma_synth_reads_device(idx.h, C.c_uint64(seed), C.c_uint64(n_reads), C.c_uint32(args.read_len),
+                                C.c_double(args.sub), C.c_double(args.ins), C.c_double(args.dele),
+                                C.c_uint64(rank * n_reads), C.c_void_p(codes.data_ptr()), C.c_void_p(offs.data_ptr()),
+                                C.c_uint64(cap), C.byref(nb)))
+    offs_h = offs.cpu().numpy().astype(np.uint64)
+
+    P = ma_amd.Params.preset(args.preset)
+    max_bases = int((offs_h[B::B] - offs_h[:-1:B]).max()) if K > 0 else 0
+    batch = ma_amd.Batch(idx, P, B, max_bases + 64)
+    batch.set_stream(torch.cuda.current_stream().cuda_stream)
+    batch.enable_timing(True)
+
+    def step(k):
+        lo = k * B
+        nbases = int(offs_h[lo + B] - offs_h[lo])
+        batch.set_reads_device(codes.data_ptr(), offs.data_ptr() + 8 * lo, B, nbases)
+        batch.align()
+        batch.sync()
+
+    for w in range(W):
+        step(w % K)
+
+    kms = np.zeros(8, dtype=np.float64)
+    ctr = np.zeros(8, dtype=np.float64)
+    segs = 0
+    aligned = 0
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(k)
+        kms += batch.kernel_ms().astype(np.float64)
+        ctr += batch.counters().astype(np.float64)
+        c = batch.counts()
+        aligned += c["aligned_reads"]
+        segs += c["segments"]
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        a = torch.tensor([float(aligned)], dtype=torch.float64, device=dev)
+        dist.all_reduce(a, op=dist.ReduceOp.SUM)
+        aligned_all = float(a.item())
+    else:
+        aligned_all = float(aligned)
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the K launches) --
+    names = ["k_seed", "k_extract", "k_chain", "k_dp_enum", "k_ksw", "k_stitch+k_finish"]
+    total_bases = float(offs_h[n_reads] - offs_h[0])
+    alg = [64.0 * ctr[1] + total_bases + 40.0 * segs,  # seeding: occ blocks + read bases + segments out
+           64.0 * ctr[2] + 8.0 * ctr[3] + 48.0 * ctr[3],  # SA lookup: LF blocks + SA sample + seed out
+           0.0, 0.0,
+           ctr[6] + ctr[4] + ctr[7],  # DP: sequences in + 1 B per band cell + back-trace reads + cigar out
+           0.0]
+    dom = int(np.argmax(kms[:6]))
+    avg_s = kms[dom] / 1e3 / max(K, 1)
+    ach = (alg[dom] / max(K, 1)) / avg_s / 1e9 if avg_s > 0 else 0.0
+    roofline = {"kernel": names[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "avg_launch_ms": round(kms[dom] / max(K, 1), 3),
+                "algorithmic_bytes_per_launch": int(alg[dom] / max(K, 1)),
+                "kernel_ms_per_step": {names[i]: round(kms[i] / max(K, 1), 3) for i in range(6)},
+                "seeding_GBps": round((alg[0] / max(K, 1)) / (kms[0] / 1e3 / max(K, 1)) / 1e9, 2) if kms[0] > 0 else 0.0,
+                "dp_GCUPS": round(ctr[4] / (kms[4] / 1e3) / 1e9, 3) if kms[4] > 0 else 0.0}
+
+    # ---- CPU baseline: the oracle (bit-exact restatement of the reference) on this host's cores -----------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_sample != 0:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from ma_testlib import OrIndex, or_params
+        ncores = os.cpu_count() or 1
+        S = args.cpu_sample if args.cpu_sample > 0 else min(n_reads, max(2000, int(4000 * ncores * 150 / max(args.read_len, 1))))
+        oidx = OrIndex.from_parts(idx.download())
+        hb = int(offs_h[S])
+        rc = codes[:hb].cpu().numpy()
+        reads = [rc[int(offs_h[i]):int(offs_h[i + 1])] for i in range(S)]
+        op = or_params(args.preset, 1)
+        t1 = time.perf_counter()
+        res = oidx.align(reads, op, threads=ncores)
+        tc = time.perf_counter() - t1
+        cpu = {"value": round(res["n_aligned"] / tc, 1), "unit": "aligned reads/s", "cores": ncores, "kind": "port",
+               "sample": "first %d reads of the same workload, oracle with %d threads, %.1f s" % (S, ncores, tc)}
+
+    if rank == 0:
+        out = {
+            "metric": "aligned reads/sec (whole node), 150bp & 10kb synthetic vs GRCh38",
+            "value": round(aligned_all / dt, 1), "unit": "aligned reads/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / max(K, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/int8 (2-bit BWT ranks, int8 DP differences, int16/32 scores)",
+            "data": "synthetic",
+            "config": {"workload": "%d x %d bp reads (%.2f%% sub, %.2f%% ins, %.2f%% del) vs GRCh38-like synthetic genome "
+                       "(%d contigs, %d nt%s), %s preset, %d reads/step per GPU" % (
+                           n_reads * world, args.read_len, 100 * args.sub, 100 * args.ins, 100 * args.dele, len(lens), F,
+                           "" if args.no_repeats else ", planted repeats", args.preset, B),
+                       "reads_per_s_total": round(n_reads * world / dt, 1), "index_build_s": round(t_index, 2),
+                       "parallelism": "reads partitioned over %d GPU(s), index replicated, no collective" % world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

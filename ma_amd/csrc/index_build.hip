@@ -90,6 +90,28 @@ struct InBucket // suffixes whose first K bases spell `code` (bases past the end
     }
 };
 
+// one pass: how many suffixes fall into each first-K-bases bucket
+__global__ void k_bucket_hist( TextView T, u32 K, unsigned long long* hist /* 4^K */ )
+{
+    __shared__ unsigned int sh[ 256 ];
+    sh[ threadIdx.x ] = 0;
+    __syncthreads( );
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for( u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < T.n; p += stride )
+    {
+        u32 c = 0;
+        for( u32 i = 0; i < K; i++ )
+        {
+            const u64 q = p + i;
+            c = ( c << 2 ) | ( q < T.n ? T.at( q ) : 0u );
+        }
+        atomicAdd( &sh[ c ], 1u );
+    }
+    __syncthreads( );
+    if( threadIdx.x < ( 1u << ( 2 * K ) ) && sh[ threadIdx.x ] )
+        atomicAdd( &hist[ threadIdx.x ], (unsigned long long)sh[ threadIdx.x ] );
+}
+
 __global__ void k_keys( TextView T, const u64* pos, u64 m, u64 depth, u64* keys )
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -388,9 +410,20 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
     if( cnt.reserve( 16 ) || tPos.reserve( 1 << 20 ) || tGid.reserve( 1 << 20 ) )
         return 1;
     u64 nTied = 0, base = 0;
+    std::vector<unsigned long long> bucketCount( nb, n );
+    if( K > 0 )
+    {
+        DevBuf bh;
+        if( bh.reserve( nb * 8 ) )
+            return 1;
+        MA_HIP( hipMemset( bh.p, 0, nb * 8 ) );
+        hipLaunchKernelGGL( k_bucket_hist, dim3( 256 * 8 ), dim3( 256 ), 0, 0, T, K, bh.as<unsigned long long>( ) );
+        MA_HIP( hipMemcpy( bucketCount.data( ), bh.p, nb * 8, hipMemcpyDeviceToHost ) );
+        bh.release( );
+    }
     for( u32 b = 0; b < nb; b++ )
     {
-        u64 m = n;
+        u64 m = bucketCount[ b ];
         if( K == 0 )
         {
             if( bPos.reserve( n * 8 ) )
@@ -401,17 +434,19 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
         {
             rocprim::counting_iterator<u64> it( 0 );
             InBucket pred{ T, K, b };
-            size_t tb = 0;
-            MA_HIP( rocprim::select( nullptr, tb, it, rocprim::make_discard_iterator( ), cnt.as<u64>( ), n, pred ) );
-            if( B.ensure_tmp( tb ) )
-                return 1;
-            // count first, then materialise the bucket's suffix positions
-            MA_HIP( rocprim::select( B.tmp.p, tb, it, rocprim::make_discard_iterator( ), cnt.as<u64>( ), n, pred ) );
-            MA_HIP( hipMemcpy( &m, cnt.p, 8, hipMemcpyDeviceToHost ) );
+            if( m == 0 )
+                continue;
             if( bPos.reserve( ( m + 1 ) * 8 ) )
                 return 1;
+            size_t tb = 0;
+            MA_HIP( rocprim::select( nullptr, tb, it, bPos.as<u64>( ), cnt.as<u64>( ), n, pred ) );
+            if( B.ensure_tmp( tb ) )
+                return 1;
             MA_HIP( rocprim::select( B.tmp.p, tb, it, bPos.as<u64>( ), cnt.as<u64>( ), n, pred ) );
-            MA_HIP( hipMemcpy( &m, cnt.p, 8, hipMemcpyDeviceToHost ) );
+            u64 got = 0;
+            MA_HIP( hipMemcpy( &got, cnt.p, 8, hipMemcpyDeviceToHost ) );
+            if( got != m )
+                return fail( "ma_index_build: bucket histogram / selection mismatch" );
         }
         if( m == 0 )
             continue;

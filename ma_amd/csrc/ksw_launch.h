@@ -27,6 +27,7 @@ struct KswOut
     unsigned long long* cig_used;
     unsigned long long* cells; // sum of band cells
     unsigned long long* njobs;
+    unsigned long long* path; // back-trace steps
     u32* err;
 };
 
@@ -67,13 +68,13 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlot
         M.L = ( ( J.tlen + 15 ) / 16 ) * 16;
         KswEz ez;
         u32 nCig = 0;
-        u64 cells = 0;
+        u64 cells = 0, path = 0;
         auto qf = F.qfetch( slot );
         auto tf = F.tfetch( slot );
         if( ksw_h16( SC, J.qlen, J.tlen ) )
-            ksw_wave_core<int16_t, 8>( SC, J, qf, tf, M, ez, nCig, cells );
+            ksw_wave_core<int16_t, 8>( SC, J, qf, tf, M, ez, nCig, cells, path );
         else
-            ksw_wave_core<int32_t, 4>( SC, J, qf, tf, M, ez, nCig, cells );
+            ksw_wave_core<int32_t, 4>( SC, J, qf, tf, M, ez, nCig, cells, path );
         // publish
         __shared__ unsigned long long sOff;
         if( threadIdx.x == 0 )
@@ -97,6 +98,8 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlot
                 atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
             atomicAdd( O.cells, (unsigned long long)cells );
             atomicAdd( O.njobs, 1ull );
+            if( O.path )
+                atomicAdd( O.path, (unsigned long long)path );
         }
         __syncthreads( );
         const u64 off = sOff;

@@ -111,7 +111,7 @@ __device__ __forceinline__ void ksw_red_pair( i32& h, i32& c, int laneMask )
 // decides where bases come from (plain byte arrays for ma_ksw_batch, read + 2-bit pack for the pipeline).
 template <typename TH, int HL, typename QF, typename TF>
 __device__ void ksw_wave_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, const KswMem& M, KswEz& ez,
-                               u32& nCigar, u64& cells )
+                               u32& nCigar, u64& cells, u64& pathSteps )
 {
     const int lane = threadIdx.x & 63;
     const i32 qlen = J.qlen, tlen = J.tlen;
@@ -123,6 +123,7 @@ __device__ void ksw_wave_core( const KswScoring& SC, const KswJobView& J, QF qba
     ez.reach_end = 0;
     nCigar = 0;
     cells = 0;
+    pathSteps = 0;
     if( qlen <= 0 || tlen <= 0 )
         return;
     int8_t q = (int8_t)SC.q, e = (int8_t)SC.e, q2 = (int8_t)SC.q2, e2 = (int8_t)SC.e2;
@@ -451,6 +452,7 @@ __device__ void ksw_wave_core( const KswScoring& SC, const KswJobView& J, QF qba
                 state = tmp & 7;
             if( force_state >= 0 )
                 state = force_state;
+            pathSteps++;
             if( state == 0 )
                 push( 0, 1 ), --i, --j;
             else if( state == 1 || state == 3 )

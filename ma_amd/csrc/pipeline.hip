@@ -35,6 +35,8 @@ enum : int
     CTR_MAX_CIG = 15,
     CTR_N_JOBS = 16,
     CTR_N_ALIGNED = 17,
+    CTR_SEQ_BYTES = 18, // sum of qlen+tlen over DP jobs
+    CTR_PATH_BYTES = 19, // back-trace steps (direction bytes read back)
     CTR_COUNT = 32
 };
 
@@ -318,6 +320,7 @@ struct EnumSink
             atomicMax( &ctr[ CTR_MAX_P ], (unsigned long long)p );
             atomicMax( &ctr[ CTR_MAX_CIG ], (unsigned long long)( (u64)ql + tl + 2 ) );
             atomicAdd( &ctr[ CTR_N_JOBS ], 1ull );
+            atomicAdd( &ctr[ CTR_SEQ_BYTES ], (unsigned long long)( ql + tl ) );
 #endif
         }
         n++;
@@ -1071,6 +1074,7 @@ int ma_dp_batch( ma_batch* b )
         O.cells = c + CTR_CELLS;
         O.njobs = c + CTR_KSW_JOBS;
         O.err = (u32*)( c + CTR_ERR );
+        O.path = c + CTR_PATH_BYTES;
         PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
         if( plan.lds_bytes > 48 * 1024 )
             MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<PipeFetch>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1165,7 +1169,8 @@ int ma_batch_counters( ma_batch* b, uint64_t out[ 8 ] )
     out[ 3 ] = b->nSeeds;
     out[ 4 ] = b->hctr[ CTR_CELLS ];
     out[ 5 ] = b->hctr[ CTR_KSW_JOBS ];
-    out[ 6 ] = out[ 7 ] = 0;
+    out[ 6 ] = b->hctr[ CTR_SEQ_BYTES ];
+    out[ 7 ] = b->hctr[ CTR_PATH_BYTES ] + 4 * b->hctr[ CTR_CIG_USED ];
     return 0;
 }
 

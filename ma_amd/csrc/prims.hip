@@ -144,6 +144,7 @@ extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_
     O.cells = ctr + 1;
     O.njobs = ctr + 2;
     O.err = (u32*)( ctr + 3 );
+    O.path = nullptr;
     unsigned int* next = (unsigned int*)( ctr + 4 );
     ByteFetch F{ dj.as<ma_ksw_job>( ), dq.as<uint8_t>( ), dt.as<uint8_t>( ) };
     if( plan.lds_bytes > 48 * 1024 )
