@@ -232,7 +232,24 @@ void buildFromText( ma_or_index& x, const std::vector<uint8_t>& t )
 }
 
 // ---- FM-index primitives ----
-// bwt_occ4 (fMIndex.h:446-510)
+// counts of the four symbols among the first nsym symbols (MSB first) of a 16-symbol word
+inline void wordCounts( uint32_t w, unsigned nsym, u64 add[ 4 ] )
+{
+    if( nsym == 0 )
+        return;
+    const uint32_t mask = nsym >= 16 ? 0xffffffffu : ~( ( 1u << ( ( 16 - nsym ) << 1 ) ) - 1u );
+    const uint32_t x = w & mask;
+    const uint32_t hi = ( x >> 1 ) & 0x55555555u, lo = x & 0x55555555u;
+    const unsigned t = __builtin_popcount( hi & lo ), g = __builtin_popcount( hi & ~lo ),
+                   c = __builtin_popcount( ~hi & lo );
+    add[ 3 ] += t;
+    add[ 2 ] += g;
+    add[ 1 ] += c;
+    add[ 0 ] += ( nsym >= 16 ? 16 : nsym ) - t - g - c; // masked-off positions read as A and are not counted
+}
+
+// bwt_occ4 (fMIndex.h:446-510): the reference sums byte-table look-ups of whole words plus a masked
+// partial word; popcounts on the 2-bit fields give the same integers
 inline void occ4( const ma_or_index& x, i64 k, u64 cntv[ 4 ] )
 {
     if( k == (i64)-1 )
@@ -244,10 +261,10 @@ inline void occ4( const ma_or_index& x, i64 k, u64 cntv[ 4 ] )
     const uint32_t* p = &x.bwt[ ( (u64)k >> 7 ) << 4 ];
     memcpy( cntv, p, 32 );
     p += 8;
-    u64 within = (u64)k & 127; // number of symbols [block start .. k] is within+1
+    const unsigned within = (unsigned)( (u64)k & 127 ) + 1; // symbols [block start .. k]
     u64 add[ 4 ] = { 0, 0, 0, 0 };
-    for( u64 i = 0; i <= within; i++ )
-        add[ ( p[ i >> 4 ] >> ( ( ~i & 15 ) << 1 ) ) & 3 ]++;
+    for( unsigned w = 0; w * 16 < within; w++ )
+        wordCounts( p[ w ], within - w * 16, add );
     for( int c = 0; c < 4; c++ )
         cntv[ c ] += add[ c ];
 }
@@ -305,14 +322,9 @@ inline i64 bwtOcc( const ma_or_index& x, i64 k, uint8_t c )
         return (i64)( x.L2[ c + 1 ] - x.L2[ c ] );
     if( k == (i64)-1 )
         return 0;
-    k -= ( k >= x.primary );
-    const uint32_t* p = &x.bwt[ ( (u64)k >> 7 ) << 4 ];
-    i64 nn = (i64)( (const u64*)p )[ c ];
-    p += 8;
-    u64 within = (u64)k & 127;
-    for( u64 i = 0; i <= within; i++ )
-        nn += ( ( p[ i >> 4 ] >> ( ( ~i & 15 ) << 1 ) ) & 3 ) == c;
-    return nn;
+    u64 cntv[ 4 ];
+    occ4( x, k, cntv ); // same block, same masking; only the c-th counter is used
+    return (i64)cntv[ c ];
 }
 
 // bwt_invPsi (fMIndex.h:329-343)
