@@ -47,6 +47,7 @@ def main():
 
     import torch
     import ma_amd
+    from ma_amd.shard import weak_shard_first_index, reduce_timing_and_counts
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -87,7 +88,7 @@ def main():
     seed = 11 if args.read_len <= 1000 else (12 if args.read_len <= 20000 else 13)
     chk(L.ma_synth_reads_device(idx.h, C.c_uint64(seed), C.c_uint64(n_reads), C.c_uint32(args.read_len),
                                 C.c_double(args.sub), C.c_double(args.ins), C.c_double(args.dele),
-                                C.c_uint64(rank * n_reads), C.c_void_p(codes.data_ptr()), C.c_void_p(offs.data_ptr()),
+                                C.c_uint64(weak_shard_first_index(n_reads, rank)), C.c_void_p(codes.data_ptr()), C.c_void_p(offs.data_ptr()),
                                 C.c_uint64(cap), C.byref(nb)))
     offs_h = offs.cpu().numpy().astype(np.uint64)
 
@@ -126,15 +127,7 @@ def main():
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        a = torch.tensor([float(aligned)], dtype=torch.float64, device=dev)
-        dist.all_reduce(a, op=dist.ReduceOp.SUM)
-        aligned_all = float(a.item())
-    else:
-        aligned_all = float(aligned)
+    dt, (aligned_all,) = reduce_timing_and_counts(dist, dev, dt, [aligned])
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the K launches) --
     names = ["k_seed", "k_extract", "k_chain", "k_dp_enum", "k_ksw", "k_stitch+k_finish"]
