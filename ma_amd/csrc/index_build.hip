@@ -14,6 +14,7 @@
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 using namespace ma;
@@ -64,14 +65,21 @@ __global__ void k_pack( const uint8_t* codes, u64 F, uint8_t* pac, unsigned long
         }
         pac[ byte ] = (uint8_t)v;
     }
+    __shared__ unsigned int sh[ 4 ];
+    if( threadIdx.x < 4 )
+        sh[ threadIdx.x ] = 0;
+    __syncthreads( );
     for( int b = 0; b < 4; b++ )
     {
         u32 x = c[ b ];
         for( int m = 32; m >= 1; m >>= 1 )
             x += __shfl_xor( x, m, 64 );
         if( ( threadIdx.x & 63 ) == 0 && x )
-            atomicAdd( &hist[ b ], (unsigned long long)x );
+            atomicAdd( &sh[ b ], x );
     }
+    __syncthreads( );
+    if( threadIdx.x < 4 && sh[ threadIdx.x ] )
+        atomicAdd( &hist[ threadIdx.x ], (unsigned long long)sh[ threadIdx.x ] );
 }
 
 struct InBucket // suffixes whose first K bases spell `code` (bases past the end read as A)
@@ -404,7 +412,9 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
         return 1;
     Builder B;
     // ---- round 0: bucketed sort
-    const u32 K = n > ( 400ull << 20 ) ? 2 : 0;
+    u32 K = n > ( 400ull << 20 ) ? 2 : 0;
+    if( const char* e = getenv( "MA_INDEX_BUCKET_K" ) ) // test hook: force the bucketed round 0 on small genomes
+        K = (u32)atoi( e ) & 3;
     const u32 nb = 1u << ( 2 * K );
     DevBuf tPos, tGid, bPos, bGid, cnt;
     if( cnt.reserve( 16 ) || tPos.reserve( 1 << 20 ) || tGid.reserve( 1 << 20 ) )

@@ -255,3 +255,62 @@ def test_pipeline_vs_oracle_heuristics_long_reads(gpu_device, preset):
     compare_reads(got, want, what=("segs", "seeds", "hsets", "alns"))
     assert counts["aligned_reads"] == res["n_aligned"]
     gidx.close()
+
+
+def test_index_build_bucketed_round0_path(gpu_device, monkeypatch):
+    """GRCh38-sized genomes take the bucketed (first-2-bases) round 0; force it on a small genome."""
+    import ma_amd
+    g = rand_genome(77, [30000, 999, 20001], repeat_unit=500, repeat_copies=20, repeat_div=0.02)
+    want = OrIndex.build(g).arrays()
+    for k in ("1", "2"):
+        monkeypatch.setenv("MA_INDEX_BUCKET_K", k)
+        gidx = ma_amd.Index.build(g)
+        got = gidx.download()
+        assert got["primary"] == want["primary"]
+        assert np.array_equal(got["bwt"], want["bwt"]) and np.array_equal(got["sa"], want["sa"]), k
+        gidx.close()
+    monkeypatch.delenv("MA_INDEX_BUCKET_K")
+
+
+def test_full_size_property_reads_map_back_to_origin(gpu_device):
+    """Size-independent property at a large scale: on a 300 Mnt synthetic genome (bucketed index build,
+    heuristics on) error-free reads must align end-to-end at the position they were sampled from."""
+    import ctypes as C
+    import torch
+    import ma_amd
+    L = ma_amd.lib()
+    lens = np.array([120000000, 100000000, 80000000], dtype=np.uint64)
+    F = int(lens.sum())
+    g = torch.empty(F, dtype=torch.uint8, device="cuda")
+    assert L.ma_synth_genome_device(C.c_uint64(2), C.c_uint64(F), C.c_int32(0), C.c_void_p(g.data_ptr())) == 0
+    idx = ma_amd.Index.build_device(lens, g.data_ptr())
+    n, rl = 200000, 150
+    codes = torch.empty(n * rl + 64, dtype=torch.uint8, device="cuda")
+    offs = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    nb = C.c_uint64()
+    assert L.ma_synth_reads_device(idx.h, C.c_uint64(11), C.c_uint64(n), C.c_uint32(rl), C.c_double(0.0), C.c_double(0.0),
+                                   C.c_double(0.0), C.c_uint64(0), C.c_void_p(codes.data_ptr()),
+                                   C.c_void_p(offs.data_ptr()), C.c_uint64(n * rl + 64), C.byref(nb)) == 0
+    b = ma_amd.Batch(idx, ma_amd.Params.preset("default"), n, n * rl + 64)
+    b.set_reads_device(codes.data_ptr(), offs.data_ptr(), n, int(nb.value))
+    b.align()
+    b.sync()
+    moff, alns, ops = b.mapq_alignments()
+    assert b.counts()["aligned_reads"] == n
+    first = alns[moff[:-1].astype(np.int64)]
+    # error-free 150-mers: one seed, score 2*150, whole query, reference span 150
+    assert np.all(first["score"] == 2 * rl)
+    assert np.all(first["begin_q"] == 0) and np.all(first["end_q"] == rl)
+    assert np.all(first["end_ref"] - first["begin_ref"] == rl)
+    # reads come from their true origin: re-extract the reference window and compare with the read
+    gh = g.cpu().numpy()
+    rc = codes[: n * rl].cpu().numpy().reshape(n, rl)
+    for i in range(0, n, 997):
+        br = int(first["begin_ref"][i])
+        if br < F:
+            ref = gh[br:br + rl]
+        else:
+            ref = 3 - gh[2 * F - (br + rl):2 * F - br][::-1]
+        assert np.array_equal(ref, rc[i]), i
+    b.close()
+    idx.close()
