@@ -60,6 +60,12 @@ def lib():
     """Loads libma_amd.so; fails loudly when the HIP extension was not built."""
     global _lib
     if _lib is None:
+        try:
+            # PyTorch-ROCm bundles its own HIP runtime; load it first so that libma_amd.so binds to the same
+            # one (two runtimes in one process cannot both own the device)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         p = lib_path()
         if not os.path.exists(p):
             raise MaError("libma_amd.so is missing (%s): run __graft_entry__.build(); there is no CPU fallback" % p)

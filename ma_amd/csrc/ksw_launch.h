@@ -3,6 +3,8 @@
 #pragma once
 #include "internal.h"
 #include "ksw_wave.h"
+#include "ksw_reg.h"
+#include <algorithm>
 #include <cstring>
 
 namespace ma
@@ -30,6 +32,82 @@ struct KswOut
     unsigned long long* path; // back-trace steps
     u32* err;
 };
+
+// job classes by the number of register slots they need (ksw_need_slots): <=3, <=5, <=11, else LDS kernel
+#define KSW_S0 3
+#define KSW_S1 5
+#define KSW_S2 11
+MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
+{
+    const i32 n = ksw_need_slots( qlen, tlen, w );
+    return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : 3 ) );
+}
+
+template <typename FETCH, int S>
+__global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, u32 nSlots, unsigned int* nextSlot, int cls,
+                                                  uint8_t* scratch, u64 stride, u64 p_cap, KswOut O )
+{
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
+    __shared__ u32 sSlot;
+    __shared__ unsigned long long sOff;
+    uint8_t* my = scratch + (u64)blockIdx.x * stride;
+    uint8_t* P = my;
+    u32* cig = (u32*)( my + p_cap );
+    while( true )
+    {
+        if( threadIdx.x == 0 )
+            sSlot = atomicAdd( nextSlot, 1u );
+        __syncthreads( );
+        const u32 slot = sSlot;
+        __syncthreads( );
+        if( slot >= nSlots )
+            break;
+        if( !F.valid( slot ) )
+            continue;
+        const KswJobView J = F.view( slot );
+        if( ksw_job_class( J.qlen, J.tlen, J.w ) != cls )
+            continue;
+        KswEz ez;
+        u32 nCig = 0;
+        u64 cells = 0, path = 0;
+        auto qf = F.qfetch( slot );
+        auto tf = F.tfetch( slot );
+        if( ksw_h16( SC, J.qlen, J.tlen ) )
+            ksw_reg_core<S, int16_t, 8>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path );
+        else
+            ksw_reg_core<S, int32_t, 4>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path );
+        if( threadIdx.x == 0 )
+        {
+            ma_ez r;
+            r.max = (i32)ez.max;
+            r.zdropped = ez.zdropped;
+            r.max_q = ez.max_q;
+            r.max_t = ez.max_t;
+            r.mqe = ez.mqe;
+            r.mqe_t = ez.mqe_t;
+            r.mte = ez.mte;
+            r.mte_q = ez.mte_q;
+            r.score = ez.score;
+            r.reach_end = ez.reach_end;
+            r.n_cigar = (i32)nCig;
+            O.ez[ slot ] = r;
+            sOff = atomicAdd( O.cig_used, (unsigned long long)nCig );
+            O.cig_off[ slot ] = sOff;
+            if( sOff + nCig > O.cig_pool_cap )
+                atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
+            atomicAdd( O.cells, (unsigned long long)cells );
+            atomicAdd( O.njobs, 1ull );
+            if( O.path )
+                atomicAdd( O.path, (unsigned long long)path );
+        }
+        __syncthreads( );
+        const u64 off = sOff;
+        if( off + nCig <= O.cig_pool_cap )
+            for( u32 i = threadIdx.x; i < nCig; i += 64 )
+                O.cig_pool[ off + i ] = cig[ i ];
+        __syncthreads( );
+    }
+}
 
 template <typename FETCH>
 __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlots, unsigned int* nextSlot,
@@ -65,6 +143,8 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlot
         if( !F.valid( slot ) )
             continue;
         const KswJobView J = F.view( slot );
+        if( ksw_job_class( J.qlen, J.tlen, J.w ) != 3 )
+            continue; // handled by a register-resident launch
         M.L = ( ( J.tlen + 15 ) / 16 ) * 16;
         KswEz ez;
         u32 nCig = 0;
@@ -114,11 +194,15 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlot
 struct KswSizing
 {
     u64 state = 0, h = 0, p = 0, cig = 0;
+    u64 qlen = 0; // longest query (LDS bytes of the register kernels)
+    u64 cls[ 4 ] = { 0, 0, 0, 0 }; // jobs per class
 };
 inline void ksw_size_job( KswSizing& S, i32 qlen, i32 tlen, i32 w )
 {
     if( qlen <= 0 || tlen <= 0 )
         return;
+    S.cls[ ksw_job_class( qlen, tlen, w ) ]++;
+    S.qlen = S.qlen > (u64)qlen ? S.qlen : (u64)qlen;
     const u64 st = ksw_state_bytes( qlen, tlen );
     const u64 L = (u64)( ( tlen + 15 ) / 16 ) * 16;
     const u64 p = (u64)( (i64)qlen + tlen - 1 ) * (u64)( ksw_ncol( qlen, tlen, w ) * 16 ) + 16;
@@ -163,5 +247,48 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
         waves = 1;
     P.waves = (u32)waves;
     return P;
+}
+
+// Launches every class that has jobs. `next` = 4 zeroed counters (one per launch).
+template <typename FETCH>
+int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
+                 unsigned int* next, KswOut O, hipStream_t stream )
+{
+    auto al = []( u64 x ) { return ( x + 255 ) / 256 * 256; };
+    const u64 nJobs = SZ.cls[ 0 ] + SZ.cls[ 1 ] + SZ.cls[ 2 ] + SZ.cls[ 3 ];
+    if( nJobs == 0 )
+        return 0;
+    const u64 p_cap = al( SZ.p );
+    const u64 regStride = al( p_cap + al( SZ.cig * 4 ) );
+    KswPlan plan = ksw_plan( SZ, SZ.cls[ 3 ] ? SZ.cls[ 3 ] : 1, 24ull << 30 );
+    u64 regWaves = std::min<u64>( 256ull * 24, nJobs );
+    if( regStride * regWaves > ( 24ull << 30 ) )
+        regWaves = std::max<u64>( 1, ( 24ull << 30 ) / regStride );
+    const u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 3 ] ? plan.ws.stride * plan.waves : 0 );
+    if( scratch.reserve( need ) )
+        return 1;
+    const u32 ldsReg = (u32)( ( ( SZ.qlen + 15 ) / 16 ) * 16 + 64 );
+    uint8_t* base = scratch.as<uint8_t>( );
+    // the launches run back to back on one stream, so they can share the scratch
+    if( SZ.cls[ 0 ] )
+        hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S0> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 0 ] ) ), dim3( 64 ),
+                            ldsReg, stream, F, SC, nSlots, next + 0, 0, base, regStride, p_cap, O );
+    if( SZ.cls[ 1 ] )
+        hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S1> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 1 ] ) ), dim3( 64 ),
+                            ldsReg, stream, F, SC, nSlots, next + 1, 1, base, regStride, p_cap, O );
+    if( SZ.cls[ 2 ] )
+        hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S2> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 2 ] ) ), dim3( 64 ),
+                            ldsReg, stream, F, SC, nSlots, next + 2, 2, base, regStride, p_cap, O );
+    if( SZ.cls[ 3 ] )
+    {
+        plan.ws.base = base;
+        if( plan.lds_bytes > 48 * 1024 )
+            MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)plan.lds_bytes ) );
+        hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, nSlots, next + 3,
+                            plan.ws, O );
+    }
+    MA_HIP( hipGetLastError( ) );
+    return 0;
 }
 } // namespace ma

@@ -107,6 +107,65 @@ __device__ __forceinline__ void ksw_red_pair( i32& h, i32& c, int laneMask )
     }
 }
 
+// ksw_backtrack__ (kswcpp_core.h:76-150) by lane 0 of the wave; off[r] / off_end[r] are recomputed from r.
+// Leaves the CIGAR in cig[0..nCigar) and broadcasts nCigar to the wave.
+__device__ __forceinline__ void ksw_backtrack_lane0( const uint8_t* P, u32* cig, i64 n_col, i32 qlen, i32 tlen, i32 w,
+                                                     i32 flag, i32 i0, i32 j0, u32& nCigar, u64& pathSteps )
+{
+    const int lane = threadIdx.x & 63;
+    if( lane == 0 )
+    {
+        u32 n = 0;
+        auto push = [ & ]( u32 op, u32 len ) {
+            if( n == 0 || op != ( cig[ n - 1 ] & 0xf ) )
+                cig[ n++ ] = len << 4 | op;
+            else
+                cig[ n - 1 ] += len << 4;
+        };
+        i64 i = i0, j = j0, state = 0;
+        while( i >= 0 && j >= 0 )
+        {
+            int force_state = -1;
+            const i64 r = i + j;
+            const KswBounds B = ksw_bounds( r, qlen, tlen, w );
+            if( i < B.st )
+                force_state = 2;
+            if( i > B.en )
+                force_state = 1;
+            const u32 tmp = force_state < 0 ? (u32)P[ r * n_col + i - B.st ] : 0u;
+            if( state == 0 )
+                state = tmp & 7;
+            else if( !( tmp >> ( state + 2 ) & 1 ) )
+                state = 0;
+            if( state == 0 )
+                state = tmp & 7;
+            if( force_state >= 0 )
+                state = force_state;
+            pathSteps++;
+            if( state == 0 )
+                push( 0, 1 ), --i, --j;
+            else if( state == 1 || state == 3 )
+                push( 2, 1 ), --i;
+            else
+                push( 1, 1 ), --j;
+        }
+        if( i >= 0 )
+            push( 2, (u32)( i + 1 ) );
+        if( j >= 0 )
+            push( 1, (u32)( j + 1 ) );
+        if( !( flag & KSW_EZ_REV_CIGAR ) )
+            for( u32 a = 0; a < ( n >> 1 ); a++ )
+            {
+                const u32 t = cig[ a ];
+                cig[ a ] = cig[ n - 1 - a ];
+                cig[ n - 1 - a ] = t;
+            }
+        nCigar = n;
+    }
+    nCigar = (u32)__shfl( (int)nCigar, 0, 64 );
+    __syncthreads( );
+}
+
 // One job on one wave (blockDim.x == 64). query/target are fetched through functors so the caller
 // decides where bases come from (plain byte arrays for ma_ksw_batch, read + 2-bit pack for the pipeline).
 template <typename TH, int HL, typename QF, typename TF>
@@ -422,59 +481,7 @@ __device__ void ksw_wave_core( const KswScoring& SC, const KswJobView& J, QF qba
         i0 = ez.max_t, j0 = ez.max_q;
     else
         return;
-    // ksw_backtrack__ (kswcpp_core.h:76-150) by lane 0; off/off_end are recomputed from r
-    if( lane == 0 )
-    {
-        u32 n = 0;
-        u32* cig = M.cig;
-        auto push = [ & ]( u32 op, u32 len ) {
-            if( n == 0 || op != ( cig[ n - 1 ] & 0xf ) )
-                cig[ n++ ] = len << 4 | op;
-            else
-                cig[ n - 1 ] += len << 4;
-        };
-        i64 i = i0, j = j0, state = 0;
-        while( i >= 0 && j >= 0 )
-        {
-            int force_state = -1;
-            const i64 r = i + j;
-            const KswBounds B = ksw_bounds( r, qlen, tlen, w );
-            if( i < B.st )
-                force_state = 2;
-            if( i > B.en )
-                force_state = 1;
-            const u32 tmp = force_state < 0 ? (u32)M.p[ r * n_col + i - B.st ] : 0u;
-            if( state == 0 )
-                state = tmp & 7;
-            else if( !( tmp >> ( state + 2 ) & 1 ) )
-                state = 0;
-            if( state == 0 )
-                state = tmp & 7;
-            if( force_state >= 0 )
-                state = force_state;
-            pathSteps++;
-            if( state == 0 )
-                push( 0, 1 ), --i, --j;
-            else if( state == 1 || state == 3 )
-                push( 2, 1 ), --i;
-            else
-                push( 1, 1 ), --j;
-        }
-        if( i >= 0 )
-            push( 2, (u32)( i + 1 ) );
-        if( j >= 0 )
-            push( 1, (u32)( j + 1 ) );
-        if( !( J.flag & KSW_EZ_REV_CIGAR ) )
-            for( u32 a = 0; a < ( n >> 1 ); a++ )
-            {
-                const u32 t = cig[ a ];
-                cig[ a ] = cig[ n - 1 - a ];
-                cig[ n - 1 - a ] = t;
-            }
-        nCigar = n;
-    }
-    nCigar = (u32)__shfl( (int)nCigar, 0, 64 );
-    __syncthreads( );
+    ksw_backtrack_lane0( M.p, M.cig, n_col, qlen, tlen, w, J.flag, i0, j0, nCigar, pathSteps );
 }
 } // namespace ma
 #endif

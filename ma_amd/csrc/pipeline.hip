@@ -37,6 +37,9 @@ enum : int
     CTR_N_ALIGNED = 17,
     CTR_SEQ_BYTES = 18, // sum of qlen+tlen over DP jobs
     CTR_PATH_BYTES = 19, // back-trace steps (direction bytes read back)
+    CTR_CLS0 = 20, // DP jobs per register-slot class (4 consecutive words)
+    CTR_MAX_QLEN = 24,
+    CTR_NEXT_SLOTS = 26, // 4 x u32 job queues of the ksw launches (2 words)
     CTR_COUNT = 32
 };
 
@@ -321,6 +324,8 @@ struct EnumSink
             atomicMax( &ctr[ CTR_MAX_CIG ], (unsigned long long)( (u64)ql + tl + 2 ) );
             atomicAdd( &ctr[ CTR_N_JOBS ], 1ull );
             atomicAdd( &ctr[ CTR_SEQ_BYTES ], (unsigned long long)( ql + tl ) );
+            atomicAdd( &ctr[ CTR_CLS0 + ksw_job_class( ql, tl, w ) ], 1ull );
+            atomicMax( &ctr[ CTR_MAX_QLEN ], (unsigned long long)ql );
 #endif
         }
         n++;
@@ -1058,11 +1063,12 @@ int ma_dp_batch( ma_batch* b )
         S.h = b->hctr[ CTR_MAX_H ];
         S.p = b->hctr[ CTR_MAX_P ];
         S.cig = b->hctr[ CTR_MAX_CIG ];
-        KswPlan plan = ksw_plan( S, nJobs, 24ull << 30 );
+        S.qlen = b->hctr[ CTR_MAX_QLEN ];
+        for( int k = 0; k < 4; k++ )
+            S.cls[ k ] = b->hctr[ CTR_CLS0 + k ];
         b->cigPoolCap = std::max<u64>( 64 * nJobs + ( 1 << 20 ), b->n_bases / 2 );
-        if( b->kswScratch.reserve( plan.ws.stride * plan.waves ) || b->cigPool.reserve( b->cigPoolCap * 4 ) )
+        if( b->cigPool.reserve( b->cigPoolCap * 4 ) )
             return 1;
-        plan.ws.base = b->kswScratch.as<uint8_t>( );
         KswScoring SC{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
         unsigned long long* c = b->ctr.as<unsigned long long>( );
         KswOut O;
@@ -1076,12 +1082,9 @@ int ma_dp_batch( ma_batch* b )
         O.err = (u32*)( c + CTR_ERR );
         O.path = c + CTR_PATH_BYTES;
         PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
-        if( plan.lds_bytes > 48 * 1024 )
-            MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<PipeFetch>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)plan.lds_bytes ) );
         EvTimer t( b, 4 );
-        hipLaunchKernelGGL( k_ksw<PipeFetch>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, b->stream, F, SC,
-                            (u32)nSlots, (unsigned int*)( c + CTR_NEXT_SLOT ), plan.ws, O );
+        if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream ) )
+            return 1;
         MA_HIP( hipGetLastError( ) );
     }
     {

@@ -120,19 +120,17 @@ extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_
     KswSizing S;
     for( uint64_t i = 0; i < n; i++ )
         ksw_size_job( S, jobs[ i ].qlen, jobs[ i ].tlen, jobs[ i ].w );
-    KswPlan plan = ksw_plan( S, n, 8ull << 30 );
     DevBuf dj, dq, dt, dez, doff, dpool, dscr, dctr;
     if( dj.reserve( n * sizeof( ma_ksw_job ) ) || dq.reserve( q_len + 16 ) || dt.reserve( t_len + 16 ) ||
         dez.reserve( n * sizeof( ma_ez ) ) || doff.reserve( ( n + 1 ) * 8 ) || dpool.reserve( cigar_cap * 4 + 16 ) ||
-        dscr.reserve( plan.ws.stride * plan.waves ) || dctr.reserve( 64 ) )
+        dctr.reserve( 128 ) )
         return 1;
     MA_HIP( hipMemcpy( dj.p, jobs, n * sizeof( ma_ksw_job ), hipMemcpyHostToDevice ) );
     MA_HIP( hipMemcpy( dq.p, q_bytes, q_len, hipMemcpyHostToDevice ) );
     MA_HIP( hipMemcpy( dt.p, t_bytes, t_len, hipMemcpyHostToDevice ) );
-    MA_HIP( hipMemset( dctr.p, 0, 64 ) );
+    MA_HIP( hipMemset( dctr.p, 0, 128 ) );
     MA_HIP( hipMemset( dez.p, 0, n * sizeof( ma_ez ) ) );
     MA_HIP( hipMemset( doff.p, 0, ( n + 1 ) * 8 ) );
-    plan.ws.base = dscr.as<uint8_t>( );
     KswScoring SC{ P->match, P->mismatch, P->gap, P->extend, P->gap2, P->extend2 };
     KswOut O;
     unsigned long long* ctr = dctr.as<unsigned long long>( );
@@ -145,14 +143,10 @@ extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_
     O.njobs = ctr + 2;
     O.err = (u32*)( ctr + 3 );
     O.path = nullptr;
-    unsigned int* next = (unsigned int*)( ctr + 4 );
+    unsigned int* next = (unsigned int*)( ctr + 4 ); // 4 x u32 launch queues
     ByteFetch F{ dj.as<ma_ksw_job>( ), dq.as<uint8_t>( ), dt.as<uint8_t>( ) };
-    if( plan.lds_bytes > 48 * 1024 )
-        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<ByteFetch>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)plan.lds_bytes ) );
-    hipLaunchKernelGGL( k_ksw<ByteFetch>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, 0, F, SC, (u32)n, next,
-                        plan.ws, O );
-    MA_HIP( hipGetLastError( ) );
+    if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0 ) )
+        return 1;
     MA_HIP( hipDeviceSynchronize( ) );
     unsigned long long h[ 8 ];
     MA_HIP( hipMemcpy( h, dctr.p, 64, hipMemcpyDeviceToHost ) );
