@@ -33,14 +33,16 @@ struct KswOut
     u32* err;
 };
 
-// job classes by the number of register slots they need (ksw_need_slots): <=3, <=5, <=11, else LDS kernel
-#define KSW_S0 3
-#define KSW_S1 5
-#define KSW_S2 11
+// job classes by the number of ring slots they need (ksw_need_slots): 1, 2, <=4, <=9, else LDS kernel (class 3
+// shares the launch slot of the widest ring; class 4 = ksw_wave.h)
+#define KSW_S0 1
+#define KSW_S1 2
+#define KSW_S2 3
+#define KSW_S3 9
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
     const i32 n = ksw_need_slots( qlen, tlen, w );
-    return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : 3 ) );
+    return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : ( n <= KSW_S3 ? 3 : 4 ) ) );
 }
 
 template <typename FETCH, int S>
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlot
         if( !F.valid( slot ) )
             continue;
         const KswJobView J = F.view( slot );
-        if( ksw_job_class( J.qlen, J.tlen, J.w ) != 3 )
+        if( ksw_job_class( J.qlen, J.tlen, J.w ) != 4 )
             continue; // handled by a register-resident launch
         M.L = ( ( J.tlen + 15 ) / 16 ) * 16;
         KswEz ez;
@@ -195,7 +197,7 @@ struct KswSizing
 {
     u64 state = 0, h = 0, p = 0, cig = 0;
     u64 qlen = 0; // longest query (LDS bytes of the register kernels)
-    u64 cls[ 4 ] = { 0, 0, 0, 0 }; // jobs per class
+    u64 cls[ 5 ] = { 0, 0, 0, 0, 0 }; // jobs per class
 };
 inline void ksw_size_job( KswSizing& S, i32 qlen, i32 tlen, i32 w )
 {
@@ -249,22 +251,22 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
     return P;
 }
 
-// Launches every class that has jobs. `next` = 4 zeroed counters (one per launch).
+// Launches every class that has jobs. `next` = 5 zeroed counters (one per launch).
 template <typename FETCH>
 int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
                  unsigned int* next, KswOut O, hipStream_t stream )
 {
     auto al = []( u64 x ) { return ( x + 255 ) / 256 * 256; };
-    const u64 nJobs = SZ.cls[ 0 ] + SZ.cls[ 1 ] + SZ.cls[ 2 ] + SZ.cls[ 3 ];
+    const u64 nJobs = SZ.cls[ 0 ] + SZ.cls[ 1 ] + SZ.cls[ 2 ] + SZ.cls[ 3 ] + SZ.cls[ 4 ];
     if( nJobs == 0 )
         return 0;
     const u64 p_cap = al( SZ.p );
     const u64 regStride = al( p_cap + al( SZ.cig * 4 ) );
-    KswPlan plan = ksw_plan( SZ, SZ.cls[ 3 ] ? SZ.cls[ 3 ] : 1, 24ull << 30 );
+    KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, 24ull << 30 );
     u64 regWaves = std::min<u64>( 256ull * 24, nJobs );
     if( regStride * regWaves > ( 24ull << 30 ) )
         regWaves = std::max<u64>( 1, ( 24ull << 30 ) / regStride );
-    const u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 3 ] ? plan.ws.stride * plan.waves : 0 );
+    const u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0 );
     if( scratch.reserve( need ) )
         return 1;
     const u32 ldsReg = (u32)( ( ( SZ.qlen + 15 ) / 16 ) * 16 + 64 );
@@ -280,12 +282,15 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S2> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 2 ] ) ), dim3( 64 ),
                             ldsReg, stream, F, SC, nSlots, next + 2, 2, base, regStride, p_cap, O );
     if( SZ.cls[ 3 ] )
+        hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S3> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 3 ] ) ), dim3( 64 ),
+                            ldsReg, stream, F, SC, nSlots, next + 3, 3, base, regStride, p_cap, O );
+    if( SZ.cls[ 4 ] )
     {
         plan.ws.base = base;
         if( plan.lds_bytes > 48 * 1024 )
             MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)plan.lds_bytes ) );
-        hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, nSlots, next + 3,
+        hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, nSlots, next + 4,
                             plan.ws, O );
     }
     MA_HIP( hipGetLastError( ) );

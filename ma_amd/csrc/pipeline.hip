@@ -37,9 +37,9 @@ enum : int
     CTR_N_ALIGNED = 17,
     CTR_SEQ_BYTES = 18, // sum of qlen+tlen over DP jobs
     CTR_PATH_BYTES = 19, // back-trace steps (direction bytes read back)
-    CTR_CLS0 = 20, // DP jobs per register-slot class (4 consecutive words)
-    CTR_MAX_QLEN = 24,
-    CTR_NEXT_SLOTS = 26, // 4 x u32 job queues of the ksw launches (2 words)
+    CTR_CLS0 = 20, // DP jobs per ring-slot class (5 consecutive words)
+    CTR_MAX_QLEN = 25,
+    CTR_NEXT_SLOTS = 26, // 5 x u32 job queues of the ksw launches (3 words)
     CTR_COUNT = 32
 };
 
@@ -1064,7 +1064,7 @@ int ma_dp_batch( ma_batch* b )
         S.p = b->hctr[ CTR_MAX_P ];
         S.cig = b->hctr[ CTR_MAX_CIG ];
         S.qlen = b->hctr[ CTR_MAX_QLEN ];
-        for( int k = 0; k < 4; k++ )
+        for( int k = 0; k < 5; k++ )
             S.cls[ k ] = b->hctr[ CTR_CLS0 + k ];
         b->cigPoolCap = std::max<u64>( 64 * nJobs + ( 1 << 20 ), b->n_bases / 2 );
         if( b->cigPool.reserve( b->cigPoolCap * 4 ) )
