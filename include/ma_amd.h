@@ -159,6 +159,9 @@ int ma_batch_get_mapq_alignments( ma_batch*, uint64_t* aln_off /*n+1*/, ma_align
 /* work counters for the roofline model (same meaning as the oracle's): [0] extend_backward steps,
  * [1] distinct occ blocks touched, [2] bwt_sa LF steps, [3] SA rows, [4] DP band cells, [5] ksw jobs */
 int ma_batch_counters( ma_batch*, uint64_t out[ 8 ] );
+/* diagnostics: the kswcpp calls of the last ma_dp_batch, 8 x int32 per call:
+ * qlen, tlen, w, zdrop, flag, ez.zdropped, ez.max_q, ez.max_t (shapes may be NULL to only count) */
+int ma_batch_get_dp_jobs( ma_batch*, uint64_t* n_jobs, int32_t* shapes, uint64_t cap );
 /* per-kernel HIP-event times of the last stage calls in ms: [0] seeding [1] sa-lookup [2] chaining
  * [3] dp-jobs [4] ksw [5] stitch; requires ma_batch_enable_timing(b,1) */
 int ma_batch_enable_timing( ma_batch*, int on );

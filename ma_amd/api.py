@@ -257,6 +257,15 @@ class Batch:
         _chk(lib().ma_batch_counters(self.h, _ptr(out)))
         return out
 
+    def dp_jobs(self):
+        """(n, 8) int32: qlen, tlen, w, zdrop, flag, zdropped, max_q, max_t of every kswcpp call of the last dp stage."""
+        n = C.c_uint64()
+        _chk(lib().ma_batch_get_dp_jobs(self.h, C.byref(n), None, C.c_uint64(0)))
+        out = np.zeros((int(n.value), 8), dtype=np.int32)
+        if n.value:
+            _chk(lib().ma_batch_get_dp_jobs(self.h, C.byref(n), _ptr(out), C.c_uint64(n.value)))
+        return out
+
     def kernel_ms(self):
         out = np.zeros(8, dtype=np.float32)
         _chk(lib().ma_batch_kernel_ms(self.h, _ptr(out)))

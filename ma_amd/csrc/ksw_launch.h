@@ -75,9 +75,9 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, u32 n
         auto qf = F.qfetch( slot );
         auto tf = F.tfetch( slot );
         if( ksw_h16( SC, J.qlen, J.tlen ) )
-            ksw_reg_core<S, int16_t, 8>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path );
+            ksw_reg_core<S, int16_t, 8, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path );
         else
-            ksw_reg_core<S, int32_t, 4>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path );
+            ksw_reg_core<S, int32_t, 4, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path );
         if( threadIdx.x == 0 )
         {
             ma_ez r;

@@ -58,7 +58,27 @@ __device__ __forceinline__ void best_pair( i32& h, i32& k, i32 oh, i32 ok )
     }
 }
 
-template <int R, typename TH, int HL, typename QF, typename TF>
+__device__ __forceinline__ i32 wave_max_i32( i32 v )
+{
+    v = max( v, dpp_ctrl<0x121>( v ) ); // row_ror:1
+    v = max( v, dpp_ctrl<0x122>( v ) ); // row_ror:2
+    v = max( v, dpp_ctrl<0x124>( v ) ); // row_ror:4
+    v = max( v, dpp_ctrl<0x128>( v ) ); // row_ror:8
+    return max( max( lane_bcast( v, 0 ), lane_bcast( v, 16 ) ), max( lane_bcast( v, 32 ), lane_bcast( v, 48 ) ) );
+}
+
+// EARLY (pipeline mode, extension jobs only): stop as soon as no later diagonal can raise ez.max.
+// The callers of the extension (NeedlemanWunsch::dynPrg / ksw_dual_ext, needlemanWunsch.cpp:499-622,
+// 392-497) read only max_q, max_t and the cigar traced back from (max_t, max_q), and kswcpp moves that
+// cell only when a diagonal's maximum is strictly greater than ez.max (kswcpp_core.h:22-44).  Every cell
+// obeys H(i,j) = H(i-1,j-1) + z with z <= match (kswcpp_core.h:703, the min with sc_mch_), and with
+// qlen <= w+1 the lower band edge is the last query row, so the diagonal predecessor chain of any later
+// cell stays inside the band until it reaches diagonal r or r-1 or the first-row boundary H(i,-1).
+// Hence for r >= qlen:  later H <= max( B_r, B_{r-1}, H(r-1,-1) + match*qlen ),
+// B_d = max over cells (t, d-t) of diagonal d of  H + match * min(qlen-1-(d-t), tlen-1-t).
+// When that bound is <= ez.max the remaining diagonals cannot change max/max_q/max_t; the other ez
+// fields (mqe, mte, score, zdropped) are then unspecified, which is why ma_ksw_batch never uses EARLY.
+template <int R, typename TH, int HL, bool EARLY, typename QF, typename TF>
 __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, uint8_t* qr /*LDS*/,
                               uint8_t* P /*HBM direction bytes*/, u32* cig, KswEz& ez, u32& nCigar, u64& cells,
                               u64& pathSteps )
@@ -137,6 +157,8 @@ __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbas
     i32 hBelow = NEG; // H[st-1]: the only recycled lane that is read again (as H[en0-1] when en0 == st)
     const i32 nDiag = qlen + tlen - 1;
     bool stop = false;
+    const bool early = EARLY && ( J.flag & KSW_EZ_EXTZ_ONLY ) && qlen <= w + 1;
+    i32 topH = 0, boundPrev = 0x7fffffff; // H(r-1,-1) of the first-row boundary; B_{r-1}
     for( i32 r = 0; r < nDiag && !stop; ++r )
     {
         // ---- bounds (kswcpp_core.h:541-559); 32 bit is enough since r < 2^31
@@ -411,6 +433,22 @@ __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbas
         }
         if( !stop && r == qlen + tlen - 2 && en0 == tlen - 1 )
             ez.score = hEnd;
+        if( EARLY && early && r >= qlen - 1 )
+        {
+            i32 bnd = (i32)0x80000000;
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+            {
+                const i32 tt = TT[ s ];
+                if( tt >= st0 && tt <= en0 )
+                    bnd = max( bnd, H[ s ] + sc_mch * min( qoff + tt, tlen - 1 - tt ) );
+            }
+            bnd = wave_max_i32( bnd );
+            if( r >= qlen && max( max( bnd, boundPrev ), topH + sc_mch * qlen ) <= (i32)ez.max )
+                stop = true;
+            boundPrev = bnd;
+        }
+        topH += uInit; // H(r,-1)
         last_st = st;
         last_en = en;
     }

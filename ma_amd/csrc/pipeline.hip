@@ -389,6 +389,7 @@ namespace
 {
 struct PipeFetch
 {
+    static const bool EARLY = true; // the stitch pass reads only max_q, max_t and the cigar (ksw_reg.h)
     IndexView X;
     const DpJob* jobs;
     const uint8_t* reads;
@@ -575,7 +576,7 @@ struct ma_batch
     u64 hpoolCap = 0, nHsets = 0, nHseeds = 0;
     // dp
     DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
-    u64 cigPoolCap = 0, nOpsCap = 0;
+    u64 cigPoolCap = 0, nOpsCap = 0, nJobSlots = 0;
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
     bool timing = false;
     hipEvent_t ev[ 16 ];
@@ -1023,10 +1024,12 @@ int ma_dp_batch( ma_batch* b )
     MA_HIP( hipMemsetAsync( b->mqCnt.p, 0, ( n + 1 ) * 4, b->stream ) );
     if( n == 0 || nh == 0 )
     {
+        b->nJobSlots = 0;
         b->stage_done = 4;
         return 0;
     }
     const u64 nSlots = 2 * nhs;
+    b->nJobSlots = nSlots;
     if( b->jobs.reserve( ( nSlots + 2 ) * sizeof( DpJob ) ) || b->info.reserve( nh * sizeof( SetInfo ) ) ||
         b->ez.reserve( ( nSlots + 2 ) * sizeof( ma_ez ) ) || b->cigOff.reserve( ( nSlots + 2 ) * 8 ) ||
         b->opsCap.reserve( ( nh + 1 ) * 8 ) || b->opsOff.reserve( ( nh + 2 ) * 8 ) ||
@@ -1368,6 +1371,45 @@ int ma_batch_get_alignments( ma_batch* b, uint64_t* aln_off, ma_alignment* alns,
 int ma_batch_get_mapq_alignments( ma_batch* b, uint64_t* aln_off, ma_alignment* alns, uint64_t* ops )
 {
     return get_alns( b, true, aln_off, alns, ops );
+}
+
+int ma_batch_get_dp_jobs( ma_batch* b, uint64_t* n_jobs, int32_t* shapes /* 8 x i32 per job */, uint64_t cap )
+{
+    if( !b || b->stage_done < 4 )
+        return fail( "ma_batch_get_dp_jobs: stage not run" );
+    if( ma_batch_sync( b ) )
+        return 1;
+    const u64 nSlots = b->nJobSlots;
+    std::vector<DpJob> jobs( nSlots + 1 );
+    std::vector<ma_ez> ez( nSlots + 1 );
+    if( nSlots )
+    {
+        MA_HIP( hipMemcpy( jobs.data( ), b->jobs.p, nSlots * sizeof( DpJob ), hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( ez.data( ), b->ez.p, nSlots * sizeof( ma_ez ), hipMemcpyDeviceToHost ) );
+    }
+    u64 n = 0;
+    for( u64 i = 0; i < nSlots; i++ )
+    {
+        const DpJob& j = jobs[ i ];
+        if( j.q_to <= j.q_from )
+            continue;
+        if( shapes && n < cap )
+        {
+            int32_t* o = shapes + 8 * n;
+            o[ 0 ] = (int32_t)( j.q_to - j.q_from );
+            o[ 1 ] = (int32_t)( j.r_to - j.r_from );
+            o[ 2 ] = j.w;
+            o[ 3 ] = j.zdrop;
+            o[ 4 ] = j.flag;
+            o[ 5 ] = ez[ i ].zdropped;
+            o[ 6 ] = ez[ i ].max_q;
+            o[ 7 ] = ez[ i ].max_t;
+        }
+        n++;
+    }
+    if( n_jobs )
+        *n_jobs = n;
+    return 0;
 }
 
 } // extern "C"

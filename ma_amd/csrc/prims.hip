@@ -73,6 +73,7 @@ namespace
 {
 struct ByteFetch
 {
+    static const bool EARLY = false; // ma_ksw_batch returns every ez field of kswcpp_dispatch
     const ma_ksw_job* jobs;
     const uint8_t* qb;
     const uint8_t* tb;
