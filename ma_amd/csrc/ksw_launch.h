@@ -45,9 +45,10 @@ MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
     return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : ( n <= KSW_S3 ? 3 : 4 ) ) );
 }
 
+// `list` = the job slots of this class (n entries), or null: scan all n slots and skip other classes
 template <typename FETCH, int S>
-__global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, u32 nSlots, unsigned int* nextSlot, int cls,
-                                                  uint8_t* scratch, u64 stride, u64 p_cap, KswOut O )
+__global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
+                                                  int cls, uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
     __shared__ u32 sSlot;
@@ -60,14 +61,15 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, u32 n
         if( threadIdx.x == 0 )
             sSlot = atomicAdd( nextSlot, 1u );
         __syncthreads( );
-        const u32 slot = sSlot;
+        const u32 at = sSlot;
         __syncthreads( );
-        if( slot >= nSlots )
+        if( at >= n )
             break;
-        if( !F.valid( slot ) )
+        const u32 slot = list ? list[ at ] : at;
+        if( !list && !F.valid( slot ) )
             continue;
         const KswJobView J = F.view( slot );
-        if( ksw_job_class( J.qlen, J.tlen, J.w ) != cls )
+        if( !list && ksw_job_class( J.qlen, J.tlen, J.w ) != cls )
             continue;
         KswEz ez;
         u32 nCig = 0;
@@ -75,9 +77,9 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, u32 n
         auto qf = F.qfetch( slot );
         auto tf = F.tfetch( slot );
         if( ksw_h16( SC, J.qlen, J.tlen ) )
-            ksw_reg_core<S, int16_t, 8, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path );
+            ksw_reg_core<S, int16_t, 8, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
         else
-            ksw_reg_core<S, int32_t, 4, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path );
+            ksw_reg_core<S, int32_t, 4, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
         if( threadIdx.x == 0 )
         {
             ma_ez r;
@@ -112,8 +114,8 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, u32 n
 }
 
 template <typename FETCH>
-__global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlots, unsigned int* nextSlot,
-                                              KswWaveScratch WS, KswOut O )
+__global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
+                                              KswWaveScratch WS, u32 ldsBytes, KswOut O )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
     __shared__ u32 sSlot;
@@ -125,6 +127,8 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlot
         M.H = (void*)( lds + WS.state_cap );
         M.p = my;
         M.cig = (u32*)( my + WS.p_cap );
+        M.stage = (uint8_t*)lds;
+        M.stageBytes = ldsBytes;
     }
     else
     {
@@ -132,20 +136,23 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, u32 nSlot
         M.H = (void*)( my + WS.state_cap );
         M.p = my + WS.state_cap + WS.h_cap;
         M.cig = (u32*)( my + WS.state_cap + WS.h_cap + WS.p_cap );
+        M.stage = nullptr;
+        M.stageBytes = 0;
     }
     while( true )
     {
         if( threadIdx.x == 0 )
             sSlot = atomicAdd( nextSlot, 1u );
         __syncthreads( );
-        const u32 slot = sSlot;
+        const u32 at = sSlot;
         __syncthreads( );
-        if( slot >= nSlots )
+        if( at >= n )
             break;
-        if( !F.valid( slot ) )
+        const u32 slot = list ? list[ at ] : at;
+        if( !list && !F.valid( slot ) )
             continue;
         const KswJobView J = F.view( slot );
-        if( ksw_job_class( J.qlen, J.tlen, J.w ) != 4 )
+        if( !list && ksw_job_class( J.qlen, J.tlen, J.w ) != 4 )
             continue; // handled by a register-resident launch
         M.L = ( ( J.tlen + 15 ) / 16 ) * 16;
         KswEz ez;
@@ -251,10 +258,12 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
     return P;
 }
 
-// Launches every class that has jobs. `next` = 5 zeroed counters (one per launch).
+// Launches every class that has jobs. `next` = 5 zeroed counters (one per launch).  `lists` (device, or null) holds
+// the job slots of class k at lists + k * list_stride, SZ.cls[k] entries; without it every launch scans nSlots.
+#define KSW_REG_LDS 6144u // per-wave LDS of the ring kernels: reversed query, later the back-trace staging block
 template <typename FETCH>
 int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
-                 unsigned int* next, KswOut O, hipStream_t stream )
+                 unsigned int* next, KswOut O, hipStream_t stream, const u32* lists = nullptr, u64 list_stride = 0 )
 {
     auto al = []( u64 x ) { return ( x + 255 ) / 256 * 256; };
     const u64 nJobs = SZ.cls[ 0 ] + SZ.cls[ 1 ] + SZ.cls[ 2 ] + SZ.cls[ 3 ] + SZ.cls[ 4 ];
@@ -269,29 +278,31 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     const u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0 );
     if( scratch.reserve( need ) )
         return 1;
-    const u32 ldsReg = (u32)( ( ( SZ.qlen + 15 ) / 16 ) * 16 + 64 );
+    const u32 ldsReg = std::max<u32>( (u32)( ( ( SZ.qlen + 15 ) / 16 ) * 16 + 64 ), KSW_REG_LDS );
     uint8_t* base = scratch.as<uint8_t>( );
+    auto lst = [ & ]( int k ) { return lists ? lists + (u64)k * list_stride : (const u32*)nullptr; };
+    auto cnt = [ & ]( int k ) { return lists ? (u32)SZ.cls[ k ] : nSlots; };
     // the launches run back to back on one stream, so they can share the scratch
     if( SZ.cls[ 0 ] )
         hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S0> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 0 ] ) ), dim3( 64 ),
-                            ldsReg, stream, F, SC, nSlots, next + 0, 0, base, regStride, p_cap, O );
+                            ldsReg, stream, F, SC, lst( 0 ), cnt( 0 ), next + 0, 0, base, regStride, p_cap, ldsReg, O );
     if( SZ.cls[ 1 ] )
         hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S1> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 1 ] ) ), dim3( 64 ),
-                            ldsReg, stream, F, SC, nSlots, next + 1, 1, base, regStride, p_cap, O );
+                            ldsReg, stream, F, SC, lst( 1 ), cnt( 1 ), next + 1, 1, base, regStride, p_cap, ldsReg, O );
     if( SZ.cls[ 2 ] )
         hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S2> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 2 ] ) ), dim3( 64 ),
-                            ldsReg, stream, F, SC, nSlots, next + 2, 2, base, regStride, p_cap, O );
+                            ldsReg, stream, F, SC, lst( 2 ), cnt( 2 ), next + 2, 2, base, regStride, p_cap, ldsReg, O );
     if( SZ.cls[ 3 ] )
         hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S3> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 3 ] ) ), dim3( 64 ),
-                            ldsReg, stream, F, SC, nSlots, next + 3, 3, base, regStride, p_cap, O );
+                            ldsReg, stream, F, SC, lst( 3 ), cnt( 3 ), next + 3, 3, base, regStride, p_cap, ldsReg, O );
     if( SZ.cls[ 4 ] )
     {
         plan.ws.base = base;
         if( plan.lds_bytes > 48 * 1024 )
             MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)plan.lds_bytes ) );
-        hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, nSlots, next + 4,
-                            plan.ws, O );
+        hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, lst( 4 ), cnt( 4 ),
+                            next + 4, plan.ws, plan.lds_bytes, O );
     }
     MA_HIP( hipGetLastError( ) );
     return 0;

@@ -81,7 +81,7 @@ __device__ __forceinline__ i32 wave_max_i32( i32 v )
 template <int R, typename TH, int HL, bool EARLY, typename QF, typename TF>
 __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, uint8_t* qr /*LDS*/,
                               uint8_t* P /*HBM direction bytes*/, u32* cig, KswEz& ez, u32& nCigar, u64& cells,
-                              u64& pathSteps )
+                              u64& pathSteps, u32 ldsBytes )
 {
     const int lane = threadIdx.x & 63;
     const i32 qlen = J.qlen, tlen = J.tlen;
@@ -465,7 +465,7 @@ __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbas
         i0 = ez.max_t, j0b = ez.max_q;
     else
         return;
-    ksw_backtrack_lane0( P, cig, (i64)n_col, qlen, tlen, w, J.flag, i0, j0b, nCigar, pathSteps );
+    ksw_backtrack_lane0( P, cig, (i64)n_col, qlen, tlen, w, J.flag, i0, j0b, nCigar, pathSteps, qr, ldsBytes );
 }
 } // namespace ma
 #endif

@@ -33,6 +33,8 @@ struct KswMem
     void* H; // L entries of int16 or int32
     uint8_t* p; // direction bytes: (qlen+tlen-1) * ncol
     u32* cig; // qlen + tlen + 2 entries
+    uint8_t* stage; // LDS the back-trace may stage direction rows in once the diagonal loop is done (or null)
+    u32 stageBytes;
 };
 
 struct KswJobView // what the kernel needs to fetch the sequences of one job
@@ -107,63 +109,99 @@ __device__ __forceinline__ void ksw_red_pair( i32& h, i32& c, int laneMask )
     }
 }
 
-// ksw_backtrack__ (kswcpp_core.h:76-150) by lane 0 of the wave; off[r] / off_end[r] are recomputed from r.
-// Leaves the CIGAR in cig[0..nCigar) and broadcasts nCigar to the wave.
+// ksw_backtrack__ (kswcpp_core.h:76-150); off[r] / off_end[r] are recomputed from r.  The walk is
+// wave-uniform (every value is made scalar with v_readfirstlane, so it runs on the scalar unit); the
+// direction rows it is about to cross are staged from HBM into `stage` (LDS, stageBytes, may be 0) by all
+// 64 lanes, a block of rows at a time, so a step costs an LDS read instead of an HBM round trip.  The
+// current cigar run is kept in registers and written once per run.  Leaves the CIGAR in cig[0..nCigar).
 __device__ __forceinline__ void ksw_backtrack_lane0( const uint8_t* P, u32* cig, i64 n_col, i32 qlen, i32 tlen, i32 w,
-                                                     i32 flag, i32 i0, i32 j0, u32& nCigar, u64& pathSteps )
+                                                     i32 flag, i32 i0, i32 j0, u32& nCigar, u64& pathSteps,
+                                                     uint8_t* stage = nullptr, u32 stageBytes = 0 )
 {
     const int lane = threadIdx.x & 63;
-    if( lane == 0 )
-    {
-        u32 n = 0;
-        auto push = [ & ]( u32 op, u32 len ) {
-            if( n == 0 || op != ( cig[ n - 1 ] & 0xf ) )
-                cig[ n++ ] = len << 4 | op;
-            else
-                cig[ n - 1 ] += len << 4;
-        };
-        i64 i = i0, j = j0, state = 0;
-        while( i >= 0 && j >= 0 )
+    const i32 rowsCap = ( stage && n_col * 2 <= (i64)stageBytes ) ? (i32)( (i64)stageBytes / n_col ) : 0;
+    i32 rlo = 1, rhi = 0; // staged rows [rlo, rhi]
+    u32 n = 0, curOp = 0xffffffffu, curLen = 0, steps = 0;
+    auto push = [ & ]( u32 op, u32 len ) {
+        if( op == curOp )
+            curLen += len;
+        else
         {
-            int force_state = -1;
-            const i64 r = i + j;
-            const KswBounds B = ksw_bounds( r, qlen, tlen, w );
-            if( i < B.st )
-                force_state = 2;
-            if( i > B.en )
-                force_state = 1;
-            const u32 tmp = force_state < 0 ? (u32)P[ r * n_col + i - B.st ] : 0u;
-            if( state == 0 )
-                state = tmp & 7;
-            else if( !( tmp >> ( state + 2 ) & 1 ) )
-                state = 0;
-            if( state == 0 )
-                state = tmp & 7;
-            if( force_state >= 0 )
-                state = force_state;
-            pathSteps++;
-            if( state == 0 )
-                push( 0, 1 ), --i, --j;
-            else if( state == 1 || state == 3 )
-                push( 2, 1 ), --i;
-            else
-                push( 1, 1 ), --j;
-        }
-        if( i >= 0 )
-            push( 2, (u32)( i + 1 ) );
-        if( j >= 0 )
-            push( 1, (u32)( j + 1 ) );
-        if( !( flag & KSW_EZ_REV_CIGAR ) )
-            for( u32 a = 0; a < ( n >> 1 ); a++ )
+            if( curOp != 0xffffffffu )
             {
-                const u32 t = cig[ a ];
-                cig[ a ] = cig[ n - 1 - a ];
-                cig[ n - 1 - a ] = t;
+                if( lane == 0 )
+                    cig[ n ] = curLen << 4 | curOp;
+                n++;
             }
-        nCigar = n;
+            curOp = op;
+            curLen = len;
+        }
+    };
+    i32 i = __builtin_amdgcn_readfirstlane( i0 ), j = __builtin_amdgcn_readfirstlane( j0 ), state = 0;
+    while( i >= 0 && j >= 0 )
+    {
+        int force_state = -1;
+        const i32 r = i + j;
+        const KswBounds B = ksw_bounds( r, qlen, tlen, w );
+        if( i < B.st )
+            force_state = 2;
+        if( i > B.en )
+            force_state = 1;
+        u32 tmp = 0;
+        if( force_state < 0 )
+        {
+            if( rowsCap )
+            {
+                if( r < rlo || r > rhi )
+                {
+                    __syncthreads( );
+                    rhi = r;
+                    rlo = r - rowsCap + 1 > 0 ? r - rowsCap + 1 : 0;
+                    const i64 bytes = (i64)( rhi - rlo + 1 ) * n_col;
+                    const uint8_t* src = P + (i64)rlo * n_col;
+                    for( i64 k = (i64)lane * 16; k < bytes; k += 1024 )
+                        *(uint4*)( stage + k ) = *(const uint4*)( src + k );
+                    __syncthreads( );
+                }
+                tmp = (u32)__builtin_amdgcn_readfirstlane( (i32)stage[ (i64)( r - rlo ) * n_col + i - B.st ] );
+            }
+            else
+                tmp = (u32)__builtin_amdgcn_readfirstlane( (i32)P[ (i64)r * n_col + i - B.st ] );
+        }
+        if( state == 0 )
+            state = tmp & 7;
+        else if( !( tmp >> ( state + 2 ) & 1 ) )
+            state = 0;
+        if( state == 0 )
+            state = tmp & 7;
+        if( force_state >= 0 )
+            state = force_state;
+        steps++;
+        if( state == 0 )
+            push( 0, 1 ), --i, --j;
+        else if( state == 1 || state == 3 )
+            push( 2, 1 ), --i;
+        else
+            push( 1, 1 ), --j;
     }
-    nCigar = (u32)__shfl( (int)nCigar, 0, 64 );
+    if( i >= 0 )
+        push( 2, (u32)( i + 1 ) );
+    if( j >= 0 )
+        push( 1, (u32)( j + 1 ) );
+    push( 0xfffffffeu, 0 ); // flush the last run
+    pathSteps += steps;
     __syncthreads( );
+    if( !( flag & KSW_EZ_REV_CIGAR ) )
+    {
+        for( u32 a = (u32)lane; a < ( n >> 1 ); a += 64 )
+        {
+            const u32 t = cig[ a ];
+            cig[ a ] = cig[ n - 1 - a ];
+            cig[ n - 1 - a ] = t;
+        }
+        __syncthreads( );
+    }
+    nCigar = n;
 }
 
 // One job on one wave (blockDim.x == 64). query/target are fetched through functors so the caller
@@ -481,7 +519,7 @@ __device__ void ksw_wave_core( const KswScoring& SC, const KswJobView& J, QF qba
         i0 = ez.max_t, j0 = ez.max_q;
     else
         return;
-    ksw_backtrack_lane0( M.p, M.cig, n_col, qlen, tlen, w, J.flag, i0, j0, nCigar, pathSteps );
+    ksw_backtrack_lane0( M.p, M.cig, n_col, qlen, tlen, w, J.flag, i0, j0, nCigar, pathSteps, M.stage, M.stageBytes );
 }
 } // namespace ma
 #endif

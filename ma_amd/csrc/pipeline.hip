@@ -301,8 +301,13 @@ struct EnumSink
     DpJob* jobs; // slots of this set
     u32 n;
     u32 cap;
+    u32 slot0; // global index of jobs[0]
     u64 win_begin, read_off;
     unsigned long long* ctr;
+    u32* lists; // job slots by ring class (5 x list_stride)
+    u64 list_stride;
+    // sizing of the ksw launches, accumulated per lane and reduced once per wave by the kernel
+    u64 mx_state = 0, mx_h = 0, mx_p = 0, mx_cig = 0, mx_qlen = 0, n_jobs = 0, seq_bytes = 0;
     MA_HD void job( u32 qf, u32 qt, u32 rf, u32 rt, i32 w, i32 zdrop, i32 flag, u32 rev )
     {
         if( n < cap )
@@ -315,17 +320,18 @@ struct EnumSink
             jobs[ n ] = j;
 #if defined( __HIP_DEVICE_COMPILE__ )
             const i32 ql = (i32)( qt - qf ), tl = (i32)( rt - rf );
-            const u64 st = ksw_state_bytes( ql, tl );
             const u64 L = (u64)( ( tl + 15 ) / 16 ) * 16;
             const u64 p = (u64)( (i64)ql + tl - 1 ) * (u64)( ksw_ncol( ql, tl, w ) * 16 ) + 16;
-            atomicMax( &ctr[ CTR_MAX_STATE ], (unsigned long long)st );
-            atomicMax( &ctr[ CTR_MAX_H ], (unsigned long long)( L * 4 ) );
-            atomicMax( &ctr[ CTR_MAX_P ], (unsigned long long)p );
-            atomicMax( &ctr[ CTR_MAX_CIG ], (unsigned long long)( (u64)ql + tl + 2 ) );
-            atomicAdd( &ctr[ CTR_N_JOBS ], 1ull );
-            atomicAdd( &ctr[ CTR_SEQ_BYTES ], (unsigned long long)( ql + tl ) );
-            atomicAdd( &ctr[ CTR_CLS0 + ksw_job_class( ql, tl, w ) ], 1ull );
-            atomicMax( &ctr[ CTR_MAX_QLEN ], (unsigned long long)ql );
+            mx_state = mmax( mx_state, ksw_state_bytes( ql, tl ) );
+            mx_h = mmax( mx_h, L * 4 );
+            mx_p = mmax( mx_p, p );
+            mx_cig = mmax( mx_cig, (u64)ql + tl + 2 );
+            mx_qlen = mmax( mx_qlen, (u64)ql );
+            n_jobs++;
+            seq_bytes += (u64)( ql + tl );
+            const int cls = ksw_job_class( ql, tl, w );
+            const u64 at = atomicAdd( &ctr[ CTR_CLS0 + cls ], 1ull );
+            lists[ (u64)cls * list_stride + at ] = slot0 + n;
 #endif
         }
         n++;
@@ -349,13 +355,30 @@ struct DpKernelArgs
     DpJob* jobs; // 2 slots per pooled harmonized seed: slots of set s start at 2*sets[s].off
     SetInfo* info;
     unsigned long long* ctr;
+    u32* lists;
+    u64 list_stride;
 };
 
-__global__ void k_dp_enum( DpKernelArgs A )
+#if defined( __HIPCC__ )
+__device__ __forceinline__ u64 wave_max_u64( u64 v )
 {
-    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-    if( s >= A.n_sets )
-        return;
+    for( int m = 32; m; m >>= 1 )
+    {
+        const u64 o = ( (u64)(u32)__shfl_xor( (int)( v >> 32 ), m, 64 ) << 32 ) | (u32)__shfl_xor( (int)(u32)v, m, 64 );
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum_u64( u64 v )
+{
+    for( int m = 32; m; m >>= 1 )
+        v += ( (u64)(u32)__shfl_xor( (int)( v >> 32 ), m, 64 ) << 32 ) | (u32)__shfl_xor( (int)(u32)v, m, 64 );
+    return v;
+}
+#endif
+
+__device__ void dp_enum_one( const DpKernelArgs& A, u32 s, EnumSink& sink )
+{
     const HSet hs = A.sets[ s ];
     const ma_seed* S = A.hpool + hs.off;
     const u32 rd = A.set_read[ s ];
@@ -366,16 +389,14 @@ __global__ void k_dp_enum( DpKernelArgs A )
     I.win_end = W.end_ref;
     I.valid = W.valid ? 1 : 0;
     I.n_jobs = 0;
-    DpJob* slots = A.jobs + 2 * hs.off;
     if( W.valid )
     {
-        EnumSink sink;
-        sink.jobs = slots;
+        sink.jobs = A.jobs + 2 * hs.off;
+        sink.slot0 = (u32)( 2 * hs.off );
         sink.n = 0;
         sink.cap = 2 * hs.cnt;
         sink.win_begin = W.begin_ref;
         sink.read_off = A.roff[ rd ];
-        sink.ctr = A.ctr;
         NwWalk<EnumSink> walk{ A.X, A.P, sink, A.reads + A.roff[ rd ], W.begin_ref, AlnBuilder{ nullptr, nullptr, nullptr } };
         walk.run( S, hs.cnt, qlen, W );
         I.n_jobs = sink.n < sink.cap ? sink.n : sink.cap;
@@ -383,6 +404,31 @@ __global__ void k_dp_enum( DpKernelArgs A )
             atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)MA_ERR_SCRATCH_OVERFLOW );
     }
     A.info[ s ] = I;
+}
+
+__global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
+{
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    EnumSink sink;
+    sink.ctr = A.ctr;
+    sink.lists = A.lists;
+    sink.list_stride = A.list_stride;
+    if( s < A.n_sets )
+        dp_enum_one( A, s, sink );
+    // one atomic per wave and quantity instead of eight per job
+    const u64 st = wave_max_u64( sink.mx_state ), h = wave_max_u64( sink.mx_h ), p = wave_max_u64( sink.mx_p );
+    const u64 cg = wave_max_u64( sink.mx_cig ), ql = wave_max_u64( sink.mx_qlen );
+    const u64 nj = wave_sum_u64( sink.n_jobs ), sb = wave_sum_u64( sink.seq_bytes );
+    if( ( threadIdx.x & 63 ) == 0 && nj )
+    {
+        atomicMax( &A.ctr[ CTR_MAX_STATE ], (unsigned long long)st );
+        atomicMax( &A.ctr[ CTR_MAX_H ], (unsigned long long)h );
+        atomicMax( &A.ctr[ CTR_MAX_P ], (unsigned long long)p );
+        atomicMax( &A.ctr[ CTR_MAX_CIG ], (unsigned long long)cg );
+        atomicMax( &A.ctr[ CTR_MAX_QLEN ], (unsigned long long)ql );
+        atomicAdd( &A.ctr[ CTR_N_JOBS ], (unsigned long long)nj );
+        atomicAdd( &A.ctr[ CTR_SEQ_BYTES ], (unsigned long long)sb );
+    }
 }
 
 namespace
@@ -575,7 +621,7 @@ struct ma_batch
         hsetFlat, hsetRead;
     u64 hpoolCap = 0, nHsets = 0, nHseeds = 0;
     // dp
-    DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
+    DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, clsLists, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
     u64 cigPoolCap = 0, nOpsCap = 0, nJobSlots = 0;
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
     bool timing = false;
@@ -1031,7 +1077,7 @@ int ma_dp_batch( ma_batch* b )
     const u64 nSlots = 2 * nhs;
     b->nJobSlots = nSlots;
     if( b->jobs.reserve( ( nSlots + 2 ) * sizeof( DpJob ) ) || b->info.reserve( nh * sizeof( SetInfo ) ) ||
-        b->ez.reserve( ( nSlots + 2 ) * sizeof( ma_ez ) ) || b->cigOff.reserve( ( nSlots + 2 ) * 8 ) ||
+        b->ez.reserve( ( nSlots + 2 ) * sizeof( ma_ez ) ) || b->clsLists.reserve( ( 5 * nSlots + 2 ) * 4 ) || b->cigOff.reserve( ( nSlots + 2 ) * 8 ) ||
         b->opsCap.reserve( ( nh + 1 ) * 8 ) || b->opsOff.reserve( ( nh + 2 ) * 8 ) ||
         b->hdr.reserve( nh * sizeof( AlnHeader ) ) || b->order.reserve( nh * 4 ) || b->mqOrder.reserve( nh * 4 ) )
         return 1;
@@ -1048,6 +1094,8 @@ int ma_dp_batch( ma_batch* b )
     D.jobs = b->jobs.as<DpJob>( );
     D.info = b->info.as<SetInfo>( );
     D.ctr = b->ctr.as<unsigned long long>( );
+    D.lists = b->clsLists.as<u32>( );
+    D.list_stride = nSlots;
     {
         EvTimer t( b, 3 );
         // zero-fill: a slot is a job iff q_to > q_from (pool regions of dropped sets stay empty)
@@ -1086,7 +1134,8 @@ int ma_dp_batch( ma_batch* b )
         O.path = c + CTR_PATH_BYTES;
         PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
         EvTimer t( b, 4 );
-        if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream ) )
+        if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
+                         b->clsLists.as<u32>( ), nSlots ) )
             return 1;
         MA_HIP( hipGetLastError( ) );
     }
