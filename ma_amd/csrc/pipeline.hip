@@ -303,9 +303,6 @@ struct EnumSink
     u32 cap;
     u32 slot0; // global index of jobs[0]
     u64 win_begin, read_off;
-    unsigned long long* ctr;
-    u32* lists; // job slots by ring class (5 x list_stride)
-    u64 list_stride;
     // sizing of the ksw launches, accumulated per lane and reduced once per wave by the kernel
     u64 mx_state = 0, mx_h = 0, mx_p = 0, mx_cig = 0, mx_qlen = 0, n_jobs = 0, seq_bytes = 0;
     MA_HD void job( u32 qf, u32 qt, u32 rf, u32 rt, i32 w, i32 zdrop, i32 flag, u32 rev )
@@ -329,9 +326,6 @@ struct EnumSink
             mx_qlen = mmax( mx_qlen, (u64)ql );
             n_jobs++;
             seq_bytes += (u64)( ql + tl );
-            const int cls = ksw_job_class( ql, tl, w );
-            const u64 at = atomicAdd( &ctr[ CTR_CLS0 + cls ], 1ull );
-            lists[ (u64)cls * list_stride + at ] = slot0 + n;
 #endif
         }
         n++;
@@ -410,11 +404,39 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
 {
     const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
     EnumSink sink;
-    sink.ctr = A.ctr;
-    sink.lists = A.lists;
-    sink.list_stride = A.list_stride;
+    sink.n = 0;
+    sink.cap = 0;
+    sink.slot0 = 0;
     if( s < A.n_sets )
         dp_enum_one( A, s, sink );
+    // append the jobs to the per-class lists: one atomic per wave, class and round instead of one per job
+    {
+        const u32 mine = sink.n < sink.cap ? sink.n : sink.cap;
+        const u32 rounds = (u32)wave_max_u64( mine );
+        const int lane = threadIdx.x & 63;
+        for( u32 k = 0; k < rounds; k++ )
+        {
+            int cls = -1;
+            if( k < mine )
+            {
+                const DpJob& j = A.jobs[ sink.slot0 + k ];
+                cls = ksw_job_class( (i32)( j.q_to - j.q_from ), (i32)( j.r_to - j.r_from ), j.w );
+            }
+            for( int c = 0; c < 5; c++ )
+            {
+                const unsigned long long m = __ballot( cls == c );
+                if( m == 0 )
+                    continue;
+                const int leader = __ffsll( (long long)m ) - 1;
+                unsigned long long base = 0;
+                if( lane == leader )
+                    base = atomicAdd( &A.ctr[ CTR_CLS0 + c ], (unsigned long long)__popcll( m ) );
+                base = ( (u64)(u32)__shfl( (int)( base >> 32 ), leader, 64 ) << 32 ) | (u32)__shfl( (int)(u32)base, leader, 64 );
+                if( cls == c )
+                    A.lists[ (u64)c * A.list_stride + base + __popcll( m & ( ( 1ull << lane ) - 1 ) ) ] = sink.slot0 + k;
+            }
+        }
+    }
     // one atomic per wave and quantity instead of eight per job
     const u64 st = wave_max_u64( sink.mx_state ), h = wave_max_u64( sink.mx_h ), p = wave_max_u64( sink.mx_p );
     const u64 cg = wave_max_u64( sink.mx_cig ), ql = wave_max_u64( sink.mx_qlen );
