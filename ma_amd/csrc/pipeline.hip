@@ -81,15 +81,36 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
     L.phase = PH_DONE;
     u32 read = 0xffffffffu;
     u64 steps = 0, blocks = 0;
+    const u32 wl = threadIdx.x & 63;
+    bool alive = true;
     while( true )
     {
-        if( L.phase == PH_DONE )
+        // Flush finished reads and fetch new ones wave-wide: one atomic per wave on the segment pool pointer and on
+        // the read queue instead of one per read (same-address atomics serialise in L2).
+        const bool done = alive && L.phase == PH_DONE;
+        const unsigned long long dm = __ballot( done );
+        if( dm )
         {
-            if( read != 0xffffffffu )
+            const bool flush = done && read != 0xffffffffu;
+            const u32 n = flush ? seed_finish( L, A.P, S, A.X ) : 0u;
+            u32 inc = n;
+            for( int d = 1; d < 64; d <<= 1 )
             {
-                // flush the finished read: staged segments -> pool
-                const u32 n = seed_finish( L, A.P, S, A.X );
-                const u64 off = atomicAdd( &A.ctr[ CTR_SEG_USED ], (unsigned long long)n );
+                const u32 o = (u32)__shfl_up( (int)inc, d, 64 );
+                if( wl >= (u32)d )
+                    inc += o;
+            }
+            const u32 total = (u32)__shfl( (int)inc, 63, 64 );
+            unsigned long long base = 0;
+            if( total )
+            {
+                if( wl == 0 )
+                    base = atomicAdd( &A.ctr[ CTR_SEG_USED ], (unsigned long long)total );
+                base = ( (u64)(u32)__shfl( (int)( base >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)base, 0, 64 );
+            }
+            if( flush )
+            {
+                const u64 off = base + inc - n;
                 if( off + n <= A.pool_cap )
                 {
                     for( u32 k = 0; k < n; k++ )
@@ -107,14 +128,26 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
                 steps += L.steps;
                 blocks += L.blocks;
             }
-            read = (u32)atomicAdd( &A.ctr[ CTR_NEXT_READ ], 1ull );
-            if( read >= A.n_reads )
-                break;
-            seed_begin_read( L, A.reads + A.roff[ read ], (u32)( A.roff[ read + 1 ] - A.roff[ read ] ) );
-            continue;
+            unsigned long long rb = 0;
+            if( wl == 0 )
+                rb = atomicAdd( &A.ctr[ CTR_NEXT_READ ], (unsigned long long)__popcll( dm ) );
+            rb = ( (u64)(u32)__shfl( (int)( rb >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)rb, 0, 64 );
+            if( done )
+            {
+                const u64 mine = rb + (u64)__popcll( dm & ( ( 1ull << wl ) - 1 ) );
+                if( mine >= A.n_reads )
+                    alive = false;
+                else
+                {
+                    read = (u32)mine;
+                    seed_begin_read( L, A.reads + A.roff[ read ], (u32)( A.roff[ read + 1 ] - A.roff[ read ] ) );
+                }
+            }
         }
+        if( __ballot( alive ) == 0 )
+            break;
         u32 c;
-        if( seed_prepare( L, A.P, S, A.X, c ) )
+        if( alive && L.phase != PH_DONE && seed_prepare( L, A.P, S, A.X, c ) )
         {
             i64 ok[ 3 ];
             u32 nb;
