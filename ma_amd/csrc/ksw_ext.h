@@ -1,0 +1,434 @@
+// ksw_ext.h -- the pipeline's extension DP (NeedlemanWunsch::dynPrg with bLocalBeginning / bLocalEnd and
+// ksw_dual_ext, needlemanWunsch.cpp:239-622): kswcpp_dispatch with KSW_EZ_EXTZ_ONLY, of which the callers read
+// only ez.max_q, ez.max_t and the cigar traced back from that cell.
+//
+// Regime.  With qlen <= w+1 and r <= w the band never cuts the DP rectangle: on diagonal r the reference's
+// [st0, en0] is [max(0, r-qlen+1), min(r, tlen-1)], every cell of it is a true cell of the rectangle, and the
+// cells the 16-lane blocks compute outside of it (the aligned overshoot) are never read by a true cell: the
+// lower neighbour of cell st0 was cell st0-1 of the previous diagonal, a first-row cell is initialised before it
+// is used (kswcpp_core.h:580-585), and the back-trace cannot leave the rectangle.  So only true cells are
+// computed here.  A job that gets to r > w without having stopped is handed back (return false) and re-run by
+// the exact ring kernel (ksw_reg.h); with the early stop below that does not happen for short reads.
+//
+// Layout.  One wavefront per job, TWO cells per lane: cell t lives in half (t & 1) of lane ((t mod RING) >> 1)
+// of register slot ((t mod RING) >> 7), RING = 128 * R cells.  The int8 difference vectors are kept as
+// value << 8 in a 16-bit half, so packed 16-bit adds / subs wrap exactly like the reference's epi8 arithmetic
+// and v_pk_max/min_i16 order them correctly; the low byte of a half carries a small tag that makes ONE max
+// chain deliver both z and the direction state d (first maximum wins for the left-aligned variant, last for the
+// right-aligned one, kswcpp_core.h:653-699).  The query flows through the lanes (one cell per diagonal), the
+// target base, the exact score H (int16: riskOfOverflow<int16_t> must hold) and the cell index stay put; cells
+// that fell out of the band are recycled 16 at a time for cells RING further up.  H is tracked as
+// H(t-1, r-1) + u(t, r), which equals the reference's H(t, r-1) + v(t, r) wherever both exist.
+// Per diagonal the wave needs max H; the reference's max_t (8-lane classes with independent horizontal maxima,
+// kswcpp_core.h:156-299) is only evaluated on diagonals that raise ez.max or could z-drop.
+// Early stop: see ksw_reg.h (same bound, same proof; here the regime makes every cell exact DP).
+#pragma once
+#include "ksw_wave.h"
+#include "ksw_reg.h"
+
+#if defined( __HIPCC__ )
+namespace ma
+{
+typedef short ksw_s2 __attribute__( ( ext_vector_type( 2 ) ) );
+typedef unsigned short ksw_u2 __attribute__( ( ext_vector_type( 2 ) ) );
+#define KS2( x ) __builtin_bit_cast( ksw_s2, (u32)( x ) )
+#define KU2( x ) __builtin_bit_cast( ksw_u2, (u32)( x ) )
+#define KR( x ) __builtin_bit_cast( u32, ( x ) )
+__device__ __forceinline__ u32 pk_add( u32 a, u32 b ) { return KR( KU2( a ) + KU2( b ) ); }
+__device__ __forceinline__ u32 pk_sub( u32 a, u32 b ) { return KR( KU2( a ) - KU2( b ) ); }
+__device__ __forceinline__ u32 pk_max( u32 a, u32 b ) { return KR( __builtin_elementwise_max( KS2( a ), KS2( b ) ) ); }
+__device__ __forceinline__ u32 pk_min( u32 a, u32 b ) { return KR( __builtin_elementwise_min( KS2( a ), KS2( b ) ) ); }
+__device__ __forceinline__ u32 pk_minu( u32 a, u32 b ) { return KR( __builtin_elementwise_min( KU2( a ), KU2( b ) ) ); }
+__device__ __forceinline__ u32 pk_subsat( u32 a, u32 b ) { return KR( __builtin_elementwise_sub_sat( KS2( a ), KS2( b ) ) ); }
+__device__ __forceinline__ u32 pk_subsatu( u32 a, u32 b ) { return KR( __builtin_elementwise_sub_sat( KU2( a ), KU2( b ) ) ); }
+__device__ __forceinline__ u32 pk_ashr8( u32 a ) { return KR( KS2( a ) >> (short)8 ); }
+__device__ __forceinline__ u32 pk_lshr( u32 a, int n ) { return KR( KU2( a ) >> (unsigned short)n ); }
+__device__ __forceinline__ u32 pk_lshr15( u32 a ) { return KR( KU2( a ) >> (unsigned short)15 ); }
+__device__ __forceinline__ u32 pk_mad( u32 a, u32 b, u32 c ) { return KR( KU2( a ) * KU2( b ) + KU2( c ) ); }
+__device__ __forceinline__ u32 pk_bfi( u32 mask, u32 a, u32 b ) // mask ? a : b, bitwise
+{
+    return ( a & mask ) | ( b & ~mask );
+}
+__device__ __forceinline__ u32 pk_bcast( i32 v ) // both halves = v (16 bit)
+{
+    return ( (u32)v & 0xffffu ) * 0x00010001u;
+}
+__device__ __forceinline__ u32 pk_val( i32 v8, u32 tag ) // int8 value in the high byte, tag in the low byte
+{
+    return pk_bcast( (i32)( ( ( (u32)v8 & 0xffu ) << 8 ) | tag ) );
+}
+// lane i <- lane i-1 with lane 0 <- lane 63 (one register = a ring of 64 lanes)
+__device__ __forceinline__ u32 lanes_ror1( u32 x ) { return (u32)dpp_wave_ror1( (i32)x ); }
+// per-cell shift by one: half lo <- previous lane's hi, half hi <- own lo
+__device__ __forceinline__ u32 cells_shift1( u32 cur, u32 prevLanes ) { return __builtin_amdgcn_alignbit( cur, prevLanes, 16 ); }
+
+// registers slots a job needs in this kernel, 0 = not eligible (see the regime above)
+MA_HD int ksw_ext_slots( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 flag )
+{
+    if( !( flag & 0x40 ) || qlen < 1 || tlen < 1 || w < 0 || qlen > w + 1 || !ksw_h16( SC, qlen, tlen ) )
+        return 0;
+    // the difference vectors must stay inside int8 (they do in kswcpp for such scores; here H tracking relies on it)
+    const i32 a = SC.q + SC.e, b = SC.q2 + SC.e2, mch = SC.match < 0 ? -SC.match : SC.match;
+    const i32 mis = SC.mismatch < 0 ? -SC.mismatch : SC.mismatch;
+    if( SC.q < 0 || SC.e < 1 || SC.q2 < 0 || SC.e2 < 1 || 2 * ( a > b ? a : b ) + mch + mis > 120 )
+        return 0;
+    if( qlen > 256 )
+        return 0; // the query is held four bases per lane
+    if( qlen + 15 <= 128 || tlen <= 128 )
+        return 1;
+    if( qlen + 15 <= 256 || tlen <= 256 )
+        return 2;
+    return 0;
+}
+
+template <int R, bool LEFT, typename QF, typename TF>
+__device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, uint8_t* lds, u32 ldsBytes,
+                              uint8_t* P /*HBM direction rows, RING bytes each*/, u32* cig, KswEz& ez, u32& nCigar,
+                              u64& cells, u64& pathSteps )
+{
+    constexpr i32 RING = 128 * R;
+    const int lane = threadIdx.x & 63;
+    const i32 qlen = J.qlen, tlen = J.tlen, w = J.w;
+    ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
+    ez.max = 0;
+    ez.score = ez.mqe = ez.mte = (i32)0x80000000;
+    ez.zdropped = 0;
+    ez.reach_end = 0;
+    nCigar = 0;
+    int8_t q = (int8_t)SC.q, e = (int8_t)SC.e, q2 = (int8_t)SC.q2, e2 = (int8_t)SC.e2;
+    const i32 sc_mch = (int8_t)( SC.match < 0 ? -SC.match : SC.match );
+    const i32 sc_mis = (int8_t)( SC.mismatch > 0 ? -SC.mismatch : SC.mismatch );
+    if( q2 + e2 < q + e )
+    {
+        int8_t t = q;
+        q = q2;
+        q2 = t;
+        t = e;
+        e = e2;
+        e2 = t;
+    }
+    {
+        const i32 min_sc = sc_mis < 0 ? sc_mis : 0;
+        if( -min_sc > 2 * ( q + e ) )
+            return true; // kswcpp returns an untouched ez (kswcpp_core.h:340-341)
+    }
+    i32 long_thres = e != e2 ? ( q2 - q ) / ( e - e2 ) - 1 : 0;
+    if( q2 + e2 + long_thres * e2 > q + e + long_thres * e )
+        ++long_thres;
+    const i32 long_diff = long_thres * ( e - e2 ) - ( q2 - q ) - e2;
+    // first-row / first-column boundary differences (kswcpp_core.h:562-585): value for diagonal / cell r
+    auto initOf = [ & ]( i32 r ) -> i32 {
+        return (int8_t)( r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2 );
+    };
+    // tags: LEFT keeps the first maximum of (s, a, b, a2, b2): d = 4 - tag; RIGHT the last of (s, a, b, a2): d = tag
+    constexpr u32 tS = LEFT ? 4 : 0, tX = LEFT ? 3 : 1, tY = 2, tX2 = LEFT ? 1 : 3, tY2 = 0;
+    const u32 K_X0 = pk_val( -q - e, tX ), K_Y0 = pk_val( -q - e, tY ), K_X20 = pk_val( -q2 - e2, tX2 ),
+              K_Y20 = pk_val( -q2 - e2, tY2 ), K_V0 = pk_val( -q - e, 0 );
+    const u32 K_TX = pk_val( 0, tX ), K_TY = pk_val( 0, tY ), K_TX2 = pk_val( 0, tX2 ), K_TY2 = pk_val( 0, tY2 );
+    const u32 K_Q = pk_val( q, 0 ), K_Q2 = pk_val( q2, 0 ), K_QE = pk_val( q + e, 0 ), K_QE2 = pk_val( q2 + e2, 0 );
+    const u32 K_MCH = pk_val( sc_mch, tS ), K_NDIFF = pk_val( sc_mis - sc_mch, 0 ), K_NADJ = pk_val( -e2 - sc_mis, 0 );
+    const u32 K_CLIP = pk_val( sc_mch, 0xff ), K_NEG = 0x80008000u, K_MATCH = pk_bcast( sc_mch );
+    const u32 M_LANE0LO = lane == 0 ? 0x0000ffffu : 0u;
+
+    // the query, four bases per lane (qlen <= 256)
+    u32 Qall = 0;
+    for( int k = 0; k < 4; k++ )
+    {
+        const i32 i = 4 * lane + k;
+        Qall |= ( i < qlen ? (u32)qbase( i ) & 0xffu : 4u ) << ( 8 * k );
+    }
+    auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t+1
+        const u32 a = t < tlen ? (u32)tbase( t ) & 0xffu : 0u;
+        const u32 b = t + 1 < tlen ? (u32)tbase( t + 1 ) & 0xffu : 0u;
+        return a | b << 16;
+    };
+    auto uInit2 = [ & ]( i32 t ) -> u32 { // first-row u of cells t, t+1
+        return ( ( (u32)initOf( t ) & 0xffu ) << 8 ) | ( ( (u32)initOf( t + 1 ) & 0xffu ) << 24 );
+    };
+    u32 U[ R ], V[ R ], X[ R ], Y[ R ], X2[ R ], Y2[ R ], T[ R ], H[ R ], Qf[ R ], TTpk[ R ], PB[ R ];
+    i32 TT[ R ];
+#pragma unroll
+    for( int s = 0; s < R; s++ )
+    {
+        TT[ s ] = 128 * s + 2 * lane;
+        TTpk[ s ] = (u32)TT[ s ] | (u32)( TT[ s ] + 1 ) << 16;
+        PB[ s ] = pk_sub( pk_bcast( tlen - 1 ), TTpk[ s ] );
+        U[ s ] = uInit2( TT[ s ] );
+        V[ s ] = K_V0;
+        X[ s ] = K_X0;
+        Y[ s ] = K_Y0;
+        X2[ s ] = K_X20;
+        Y2[ s ] = K_Y20;
+        T[ s ] = tgt2( TT[ s ] );
+        H[ s ] = 0;
+        Qf[ s ] = 0x00040004u;
+    }
+    i32 recycled = 0; // cells below this index have been handed to cells RING further up
+    i32 hLeft = 0, hTop = 0; // H(-1, r-1) of the first column, H(r-1, -1) of the first row
+    i32 boundPrev = 0x7fffffff;
+    const i32 nDiag = qlen + tlen - 1;
+    bool stop = false;
+    u64 nCells = 0;
+    for( i32 r = 0; r < nDiag && !stop; ++r )
+    {
+        if( r > w )
+            return false; // the band starts to cut the rectangle: not this kernel's regime
+        const i32 st0 = max( 0, r - qlen + 1 ), en0 = min( r, tlen - 1 );
+        const i32 ini = initOf( r );
+        // ---- recycle the 16-cell block that left the band
+        if( ( st0 & ~15 ) > recycled )
+        {
+            const i32 lim = recycled + 16;
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+                if( TT[ s ] < lim )
+                {
+                    TT[ s ] += RING;
+                    TTpk[ s ] = (u32)TT[ s ] | (u32)( TT[ s ] + 1 ) << 16;
+                    PB[ s ] = pk_sub( pk_bcast( tlen - 1 ), TTpk[ s ] );
+                    U[ s ] = uInit2( TT[ s ] );
+                    Y[ s ] = K_Y0;
+                    Y2[ s ] = K_Y20;
+                    T[ s ] = tgt2( TT[ s ] );
+                }
+            recycled = lim;
+        }
+        // ---- neighbours t-1 of the previous diagonal; the query moves one cell up
+        u32 xt1[ R ], vt1[ R ], x2t1[ R ], hup[ R ];
+        {
+            u32 px[ R ], pv[ R ], px2[ R ], ph[ R ], pq[ R ];
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+            {
+                px[ s ] = lanes_ror1( X[ s ] );
+                pv[ s ] = lanes_ror1( V[ s ] );
+                px2[ s ] = lanes_ror1( X2[ s ] );
+                ph[ s ] = lanes_ror1( H[ s ] );
+                pq[ s ] = lanes_ror1( Qf[ s ] );
+            }
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+            {
+                const int sp = s == 0 ? R - 1 : s - 1; // lane 0 continues lane 63 of the previous slot of the ring
+                const u32 ax = R == 1 ? px[ s ] : ( lane == 0 ? px[ sp ] : px[ s ] );
+                const u32 av = R == 1 ? pv[ s ] : ( lane == 0 ? pv[ sp ] : pv[ s ] );
+                const u32 ax2 = R == 1 ? px2[ s ] : ( lane == 0 ? px2[ sp ] : px2[ s ] );
+                const u32 ah = R == 1 ? ph[ s ] : ( lane == 0 ? ph[ sp ] : ph[ s ] );
+                const u32 aq = R == 1 ? pq[ s ] : ( lane == 0 ? pq[ sp ] : pq[ s ] );
+                xt1[ s ] = cells_shift1( X[ s ], ax );
+                vt1[ s ] = cells_shift1( V[ s ], av );
+                x2t1[ s ] = cells_shift1( X2[ s ], ax2 );
+                hup[ s ] = cells_shift1( H[ s ], ah );
+                Qf[ s ] = cells_shift1( Qf[ s ], aq );
+            }
+        }
+        if( st0 == 0 )
+        {
+            // cell 0 (slot 0, lane 0, low half until it is recycled at r >= qlen + 15): first-column carry-in
+            // (kswcpp_core.h:562-579) and the query base that enters the band
+            const u32 qb = ( (u32)lane_bcast( (i32)Qall, r >> 2 ) >> ( 8 * ( r & 3 ) ) ) & 0xffu;
+            xt1[ 0 ] = pk_bfi( M_LANE0LO, K_X0, xt1[ 0 ] );
+            x2t1[ 0 ] = pk_bfi( M_LANE0LO, K_X20, x2t1[ 0 ] );
+            vt1[ 0 ] = pk_bfi( M_LANE0LO, ( (u32)ini & 0xffu ) << 8, vt1[ 0 ] );
+            hLeft += ini; // H(-1, r)
+            hup[ 0 ] = pk_bfi( M_LANE0LO, (u32)hLeft & 0xffffu, hup[ 0 ] );
+            Qf[ 0 ] = pk_bfi( M_LANE0LO, qb, Qf[ 0 ] );
+        }
+        const u32 st0pk = pk_bcast( st0 ), wpk = pk_bcast( en0 - st0 + 1 );
+        uint8_t* prow = P + (size_t)r * RING;
+        u32 Hm[ R ], DD[ R ], LMs[ R ];
+#pragma unroll
+        for( int s = 0; s < R; s++ )
+        {
+            // ---- live cells of this slot: st0 <= t <= en0
+            const u32 dd = pk_sub( TTpk[ s ], st0pk ); // t - st0 (mod 2^16)
+            const u32 lm1 = pk_minu( pk_subsatu( wpk, dd ), 0x00010001u ); // 1 where live
+            const u32 LM = pk_sub( 0u, lm1 ); // 0xffff where live
+            DD[ s ] = dd;
+            LMs[ s ] = LM;
+            // ---- score: match / mismatch, -e2 when either base is N (kswcpp_core.h:598-615)
+            const u32 isN = pk_lshr( T[ s ] | Qf[ s ], 2 );
+            const u32 differ = pk_minu( ( T[ s ] ^ Qf[ s ] ) | isN, 0x00010001u );
+            u32 z = pk_mad( differ, K_NDIFF, K_MCH );
+            z = pk_mad( isN, K_NADJ, z );
+            // ---- DP cell (kswcpp_core.h:653-766)
+            const u32 ut = U[ s ];
+            u32 a = pk_add( xt1[ s ], vt1[ s ] );
+            u32 b = pk_add( Y[ s ], ut );
+            u32 a2 = pk_add( x2t1[ s ], vt1[ s ] );
+            u32 b2 = pk_add( Y2[ s ], ut );
+            u32 d;
+            if( LEFT )
+            {
+                z = pk_max( pk_max( z, a ), pk_max( pk_max( b, a2 ), b2 ) );
+                d = pk_sub( 0x00040004u, z & 0x00070007u );
+            }
+            else
+            {
+                z = pk_max( pk_max( z, a ), pk_max( b, a2 ) );
+                d = z & 0x00070007u;
+                z = pk_max( z, b2 ); // state 4 is never recorded (kswcpp_core.h:693-699)
+            }
+            const u32 zc = pk_min( z, K_CLIP ) & 0xff00ff00u;
+            const u32 nu = pk_sub( zc, vt1[ s ] ), nv = pk_sub( zc, ut );
+            u32 tmp = pk_sub( zc, K_Q );
+            a = pk_sub( a, tmp );
+            b = pk_sub( b, tmp );
+            tmp = pk_sub( zc, K_Q2 );
+            a2 = pk_sub( a2, tmp );
+            b2 = pk_sub( b2, tmp );
+            const u32 nx = pk_sub( pk_max( a, K_TX ), K_QE ), ny = pk_sub( pk_max( b, K_TY ), K_QE );
+            const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), K_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), K_QE2 );
+            u32 fa, fb, fa2, fb2; // bit 15 of a half = continuation flag
+            if( LEFT )
+            {
+                fa = pk_subsat( K_TX, a ); // a > 0
+                fb = pk_subsat( K_TY, b );
+                fa2 = pk_subsat( K_TX2, a2 );
+                fb2 = pk_subsat( K_TY2, b2 );
+            }
+            else
+            {
+                fa = ~pk_subsat( a, K_TX ); // !(a < 0)
+                fb = ~pk_subsat( b, K_TY );
+                fa2 = ~pk_subsat( a2, K_TX2 );
+                fb2 = ~pk_subsat( b2, K_TY2 );
+            }
+            d |= ( ( fa >> 12 ) & 0x00080008u ) | ( ( fb >> 11 ) & 0x00100010u ) | ( ( fa2 >> 10 ) & 0x00200020u ) |
+                 ( ( fb2 >> 9 ) & 0x00400040u );
+            // ---- commit: u, y, y2 of cells that are not born yet keep their first-row initialisation
+            U[ s ] = pk_bfi( LM, nu, ut );
+            Y[ s ] = pk_bfi( LM, ny, Y[ s ] );
+            Y2[ s ] = pk_bfi( LM, ny2, Y2[ s ] );
+            V[ s ] = nv;
+            X[ s ] = nx;
+            X2[ s ] = nx2;
+            *(uint16_t*)( prow + 128 * s + 2 * lane ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
+            // ---- H(t, r) = H(t-1, r-1) + u(t, r)
+            const u32 hn = pk_add( hup[ s ], pk_ashr8( nu ) );
+            H[ s ] = hn;
+            Hm[ s ] = pk_bfi( LM, hn, K_NEG );
+        }
+        nCells += (u64)( en0 - st0 + 1 );
+        // ---- the diagonal's maximum
+        u32 hm = Hm[ 0 ];
+#pragma unroll
+        for( int s = 1; s < R; s++ )
+            hm = pk_max( hm, Hm[ s ] );
+        const i32 max_H = wave_max_i32( max( (i32)( hm << 16 ) >> 16, (i32)hm >> 16 ) );
+        const bool newMax = max_H > (i32)ez.max;
+        if( newMax || ( J.zdrop >= 0 && (i32)ez.max - max_H > J.zdrop ) )
+        {
+            // ---- the reference's max_t (kswcpp_core.h:156-299): 8 classes (t - st0) mod 8 over the chunks
+            // [st0, en1), each class keeps its first maximum and the chunk base it came from, the initial
+            // (H[en0], en0) wins ties, max_t is the largest of the classes' values; then [en1, en0) one by one
+            const i32 pe = en0 & ( RING - 1 );
+            u32 hreg = H[ 0 ];
+#pragma unroll
+            for( int s = 1; s < R; s++ )
+                if( ( pe >> 7 ) == s )
+                    hreg = H[ s ];
+            const i32 hEn0 = (i32)( (u32)lane_bcast( (i32)hreg, ( pe & 127 ) >> 1 ) << ( pe & 1 ? 0 : 16 ) ) >> 16;
+            const i32 nS = ( ( en0 - st0 ) / 8 ) * 8; // cells of the 8-lane part
+            i32 kLo = (i32)0x80000000, kHi = (i32)0x80000000;
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+            {
+                const u32 inv = pk_sub( 0xffffffffu, DD[ s ] ); // 0xffff - (t - st0): earlier chunks win ties
+                const i32 lo = (i32)__builtin_amdgcn_perm( H[ s ], inv, 0x05040100u );
+                const i32 hi = (i32)__builtin_amdgcn_perm( H[ s ], inv, 0x07060302u );
+                if( ( DD[ s ] & 0xffffu ) < (u32)nS )
+                    kLo = max( kLo, lo );
+                if( ( DD[ s ] >> 16 ) < (u32)nS )
+                    kHi = max( kHi, hi );
+            }
+            // lanes with equal (lane mod 4) hold the same two classes
+            kLo = max( kLo, dpp_ctrl<0x124>( kLo ) );
+            kHi = max( kHi, dpp_ctrl<0x124>( kHi ) );
+            kLo = max( kLo, dpp_ctrl<0x128>( kLo ) );
+            kHi = max( kHi, dpp_ctrl<0x128>( kHi ) );
+            {
+                auto a16 = __builtin_amdgcn_permlane16_swap( (u32)kLo, (u32)kLo, false, false );
+                kLo = max( (i32)a16[ 0 ], (i32)a16[ 1 ] );
+                auto b16 = __builtin_amdgcn_permlane16_swap( (u32)kHi, (u32)kHi, false, false );
+                kHi = max( (i32)b16[ 0 ], (i32)b16[ 1 ] );
+                auto a32 = __builtin_amdgcn_permlane32_swap( (u32)kLo, (u32)kLo, false, false );
+                kLo = max( (i32)a32[ 0 ], (i32)a32[ 1 ] );
+                auto b32 = __builtin_amdgcn_permlane32_swap( (u32)kHi, (u32)kHi, false, false );
+                kHi = max( (i32)b32[ 0 ], (i32)b32[ 1 ] );
+            }
+            i32 mH = hEn0, mT = en0;
+            if( nS > 0 )
+            {
+                const i32 hl = kLo >> 16, hh = kHi >> 16;
+                const i32 tl = hl > hEn0 ? st0 + ( ( 0xffff - ( kLo & 0xffff ) ) & ~7 ) : en0;
+                const i32 th = hh > hEn0 ? st0 + ( ( 0xffff - ( kHi & 0xffff ) ) & ~7 ) : en0;
+                i32 vh = max( max( hl, hh ), hEn0 ), vt = max( tl, th );
+                vh = max( vh, dpp_ctrl<0xB1>( vh ) ); // the four lanes of a quad hold the eight classes
+                vt = max( vt, dpp_ctrl<0xB1>( vt ) );
+                vh = max( vh, dpp_ctrl<0x4E>( vh ) );
+                vt = max( vt, dpp_ctrl<0x4E>( vt ) );
+                mH = __builtin_amdgcn_readfirstlane( vh );
+                mT = __builtin_amdgcn_readfirstlane( vt );
+            }
+            for( i32 t = st0 + nS; t < en0; ++t )
+            {
+                const i32 p = t & ( RING - 1 );
+                u32 hr = H[ 0 ];
+#pragma unroll
+                for( int s = 1; s < R; s++ )
+                    if( ( p >> 7 ) == s )
+                        hr = H[ s ];
+                const i32 h = (i32)( (u32)lane_bcast( (i32)hr, ( p & 127 ) >> 1 ) << ( p & 1 ? 0 : 16 ) ) >> 16;
+                if( h > mH )
+                    mH = h, mT = t;
+            }
+            // ksw_apply_zdrop (kswcpp_core.h:22-44), is_rot = 1; mH == max_H
+            if( mH > (i32)ez.max )
+            {
+                ez.max = (u32)mH & 0x7fffffffu;
+                ez.max_t = mT;
+                ez.max_q = r - mT;
+            }
+            else if( mT >= ez.max_t && r - mT >= ez.max_q )
+            {
+                const i32 tl = mT - ez.max_t, ql = ( r - mT ) - ez.max_q;
+                const i32 l = tl > ql ? tl - ql : ql - tl;
+                if( J.zdrop >= 0 && (i32)( ez.max - (u32)mH ) > J.zdrop + l * e2 )
+                {
+                    ez.zdropped = 1;
+                    stop = true;
+                }
+            }
+        }
+        // ---- early stop (ksw_reg.h): no later cell can exceed ez.max
+        if( !newMax && !stop && r >= qlen - 1 )
+        {
+            const u32 qo = pk_bcast( qlen - 1 - r );
+            u32 bm = K_NEG;
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+            {
+                const u32 pot = pk_min( pk_add( TTpk[ s ], qo ), PB[ s ] );
+                const u32 bnd = pk_mad( pot, K_MATCH, H[ s ] );
+                bm = pk_max( bm, pk_bfi( LMs[ s ], bnd, K_NEG ) );
+            }
+            const i32 bound = wave_max_i32( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
+            if( r >= qlen && max( max( bound, boundPrev ), hTop + sc_mch * qlen ) <= (i32)ez.max )
+                stop = true;
+            boundPrev = bound;
+        }
+        else
+            boundPrev = 0x7fffffff;
+        hTop += ini; // H(r, -1)
+    }
+    cells += nCells;
+    __syncthreads( ); // direction bytes visible to the back-trace
+    if( ez.max_t < 0 || ez.max_q < 0 )
+        return true;
+    ksw_backtrack_lane0<true>( P, cig, (i64)RING, qlen, tlen, w, J.flag, ez.max_t, ez.max_q, nCigar, pathSteps, lds,
+                               ldsBytes );
+    return true;
+}
+} // namespace ma
+#endif

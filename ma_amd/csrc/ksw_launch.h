@@ -4,6 +4,7 @@
 #include "internal.h"
 #include "ksw_wave.h"
 #include "ksw_reg.h"
+#include "ksw_ext.h"
 #include <algorithm>
 #include <cstring>
 
@@ -39,22 +40,74 @@ struct KswOut
 #define KSW_S1 2
 #define KSW_S2 3
 #define KSW_S3 9
+#define KSW_N_CLASSES 7 // 0..3 ring kernels, 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
     const i32 n = ksw_need_slots( qlen, tlen, w );
     return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : ( n <= KSW_S3 ? 3 : 4 ) ) );
 }
+// pipeline mode: extensions whose callers read only max_q / max_t / cigar go to the extension kernel
+MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 flag )
+{
+    const int e = ksw_ext_slots( SC, qlen, tlen, w, flag );
+    return e ? 4 + e : ksw_job_class( qlen, tlen, w );
+}
 
-// `list` = the job slots of this class (n entries), or null: scan all n slots and skip other classes
-template <typename FETCH, int S>
-__global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
-                                                  int cls, uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O )
+// result record + cigar of one finished job -> output arrays (all 64 lanes call this)
+__device__ __forceinline__ void ksw_publish( const KswOut& O, u32 slot, const KswEz& ez, u32 nCig, u64 cells, u64 path,
+                                             const u32* cig, unsigned long long* sOff )
+{
+    if( threadIdx.x == 0 )
+    {
+        ma_ez r;
+        r.max = (i32)ez.max;
+        r.zdropped = ez.zdropped;
+        r.max_q = ez.max_q;
+        r.max_t = ez.max_t;
+        r.mqe = ez.mqe;
+        r.mqe_t = ez.mqe_t;
+        r.mte = ez.mte;
+        r.mte_q = ez.mte_q;
+        r.score = ez.score;
+        r.reach_end = ez.reach_end;
+        r.n_cigar = (i32)nCig;
+        O.ez[ slot ] = r;
+        *sOff = atomicAdd( O.cig_used, (unsigned long long)nCig );
+        O.cig_off[ slot ] = *sOff;
+        if( *sOff + nCig > O.cig_pool_cap )
+            atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
+        atomicAdd( O.cells, (unsigned long long)cells );
+        atomicAdd( O.njobs, 1ull );
+        if( O.path )
+            atomicAdd( O.path, (unsigned long long)path );
+    }
+    __syncthreads( );
+    const u64 off = *sOff;
+    if( off + nCig <= O.cig_pool_cap )
+        for( u32 i = threadIdx.x; i < nCig; i += 64 )
+            O.cig_pool[ off + i ] = cig[ i ];
+    __syncthreads( );
+}
+
+// job source of a launch: mode 0 = list[0..n), 1 = every slot 0..n that is valid and of class cls,
+// 2 = list[0..*nDev) filtered by class cls (the jobs the extension kernel handed back)
+struct KswJobs
+{
+    const u32* list;
+    u32 n;
+    const unsigned int* nDev;
+    int mode, cls;
+};
+
+template <typename FETCH, int R>
+__global__ void __launch_bounds__( 64 ) k_ksw_ext( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
+                                                  uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O,
+                                                  u32* redo, unsigned int* nRedo )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
     __shared__ u32 sSlot;
     __shared__ unsigned long long sOff;
     uint8_t* my = scratch + (u64)blockIdx.x * stride;
-    uint8_t* P = my;
     u32* cig = (u32*)( my + p_cap );
     while( true )
     {
@@ -65,11 +118,53 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, const
         __syncthreads( );
         if( at >= n )
             break;
-        const u32 slot = list ? list[ at ] : at;
-        if( !list && !F.valid( slot ) )
+        const u32 slot = list[ at ];
+        const KswJobView J = F.view( slot );
+        KswEz ez;
+        u32 nCig = 0;
+        u64 cells = 0, path = 0;
+        auto qf = F.qfetch( slot );
+        auto tf = F.tfetch( slot );
+        bool ok;
+        if( J.flag & KSW_EZ_RIGHT )
+            ok = ksw_ext_core<R, false>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path );
+        else
+            ok = ksw_ext_core<R, true>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path );
+        if( !ok )
+        {
+            if( threadIdx.x == 0 )
+                redo[ atomicAdd( nRedo, 1u ) ] = slot;
+            continue;
+        }
+        ksw_publish( O, slot, ez, nCig, cells, path, cig, &sOff );
+    }
+}
+
+template <typename FETCH, int S>
+__global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, KswJobs JB, unsigned int* nextSlot,
+                                                  uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O )
+{
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
+    __shared__ u32 sSlot;
+    __shared__ unsigned long long sOff;
+    uint8_t* my = scratch + (u64)blockIdx.x * stride;
+    uint8_t* P = my;
+    u32* cig = (u32*)( my + p_cap );
+    const u32 n = JB.mode == 2 ? *JB.nDev : JB.n;
+    while( true )
+    {
+        if( threadIdx.x == 0 )
+            sSlot = atomicAdd( nextSlot, 1u );
+        __syncthreads( );
+        const u32 at = sSlot;
+        __syncthreads( );
+        if( at >= n )
+            break;
+        const u32 slot = JB.mode == 1 ? at : JB.list[ at ];
+        if( JB.mode == 1 && !F.valid( slot ) )
             continue;
         const KswJobView J = F.view( slot );
-        if( !list && ksw_job_class( J.qlen, J.tlen, J.w ) != cls )
+        if( JB.mode != 0 && ksw_job_class( J.qlen, J.tlen, J.w ) != JB.cls )
             continue;
         KswEz ez;
         u32 nCig = 0;
@@ -80,41 +175,12 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, const
             ksw_reg_core<S, int16_t, 8, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
         else
             ksw_reg_core<S, int32_t, 4, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
-        if( threadIdx.x == 0 )
-        {
-            ma_ez r;
-            r.max = (i32)ez.max;
-            r.zdropped = ez.zdropped;
-            r.max_q = ez.max_q;
-            r.max_t = ez.max_t;
-            r.mqe = ez.mqe;
-            r.mqe_t = ez.mqe_t;
-            r.mte = ez.mte;
-            r.mte_q = ez.mte_q;
-            r.score = ez.score;
-            r.reach_end = ez.reach_end;
-            r.n_cigar = (i32)nCig;
-            O.ez[ slot ] = r;
-            sOff = atomicAdd( O.cig_used, (unsigned long long)nCig );
-            O.cig_off[ slot ] = sOff;
-            if( sOff + nCig > O.cig_pool_cap )
-                atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
-            atomicAdd( O.cells, (unsigned long long)cells );
-            atomicAdd( O.njobs, 1ull );
-            if( O.path )
-                atomicAdd( O.path, (unsigned long long)path );
-        }
-        __syncthreads( );
-        const u64 off = sOff;
-        if( off + nCig <= O.cig_pool_cap )
-            for( u32 i = threadIdx.x; i < nCig; i += 64 )
-                O.cig_pool[ off + i ] = cig[ i ];
-        __syncthreads( );
+        ksw_publish( O, slot, ez, nCig, cells, path, cig, &sOff );
     }
 }
 
 template <typename FETCH>
-__global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
+__global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, KswJobs JB, unsigned int* nextSlot,
                                               KswWaveScratch WS, u32 ldsBytes, KswOut O )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
@@ -139,6 +205,8 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, const u32
         M.stage = nullptr;
         M.stageBytes = 0;
     }
+    __shared__ unsigned long long sOff;
+    const u32 n = JB.mode == 2 ? *JB.nDev : JB.n;
     while( true )
     {
         if( threadIdx.x == 0 )
@@ -148,11 +216,11 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, const u32
         __syncthreads( );
         if( at >= n )
             break;
-        const u32 slot = list ? list[ at ] : at;
-        if( !list && !F.valid( slot ) )
+        const u32 slot = JB.mode == 1 ? at : JB.list[ at ];
+        if( JB.mode == 1 && !F.valid( slot ) )
             continue;
         const KswJobView J = F.view( slot );
-        if( !list && ksw_job_class( J.qlen, J.tlen, J.w ) != 4 )
+        if( JB.mode != 0 && ksw_job_class( J.qlen, J.tlen, J.w ) != 4 )
             continue; // handled by a register-resident launch
         M.L = ( ( J.tlen + 15 ) / 16 ) * 16;
         KswEz ez;
@@ -164,38 +232,7 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, const u32
             ksw_wave_core<int16_t, 8>( SC, J, qf, tf, M, ez, nCig, cells, path );
         else
             ksw_wave_core<int32_t, 4>( SC, J, qf, tf, M, ez, nCig, cells, path );
-        // publish
-        __shared__ unsigned long long sOff;
-        if( threadIdx.x == 0 )
-        {
-            ma_ez r;
-            r.max = (i32)ez.max;
-            r.zdropped = ez.zdropped;
-            r.max_q = ez.max_q;
-            r.max_t = ez.max_t;
-            r.mqe = ez.mqe;
-            r.mqe_t = ez.mqe_t;
-            r.mte = ez.mte;
-            r.mte_q = ez.mte_q;
-            r.score = ez.score;
-            r.reach_end = ez.reach_end;
-            r.n_cigar = (i32)nCig;
-            O.ez[ slot ] = r;
-            sOff = atomicAdd( O.cig_used, (unsigned long long)nCig );
-            O.cig_off[ slot ] = sOff;
-            if( sOff + nCig > O.cig_pool_cap )
-                atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
-            atomicAdd( O.cells, (unsigned long long)cells );
-            atomicAdd( O.njobs, 1ull );
-            if( O.path )
-                atomicAdd( O.path, (unsigned long long)path );
-        }
-        __syncthreads( );
-        const u64 off = sOff;
-        if( off + nCig <= O.cig_pool_cap )
-            for( u32 i = threadIdx.x; i < nCig; i += 64 )
-                O.cig_pool[ off + i ] = M.cig[ i ];
-        __syncthreads( );
+        ksw_publish( O, slot, ez, nCig, cells, path, M.cig, &sOff );
     }
 }
 
@@ -204,7 +241,7 @@ struct KswSizing
 {
     u64 state = 0, h = 0, p = 0, cig = 0;
     u64 qlen = 0; // longest query (LDS bytes of the register kernels)
-    u64 cls[ 5 ] = { 0, 0, 0, 0, 0 }; // jobs per class
+    u64 cls[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0 }; // jobs per class
 };
 inline void ksw_size_job( KswSizing& S, i32 qlen, i32 tlen, i32 w )
 {
@@ -258,17 +295,23 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
     return P;
 }
 
-// Launches every class that has jobs. `next` = 5 zeroed counters (one per launch).  `lists` (device, or null) holds
-// the job slots of class k at lists + k * list_stride, SZ.cls[k] entries; without it every launch scans nSlots.
+// Launches every class that has jobs.  `next` = 12 zeroed counters (one per launch).  `lists` (device, or null) holds
+// the job slots of class k at lists + k * list_stride, SZ.cls[k] entries, and room for the jobs the extension
+// kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every launch scans
+// nSlots and there are no extension-kernel classes.
 #define KSW_REG_LDS 6144u // per-wave LDS of the ring kernels: reversed query, later the back-trace staging block
 template <typename FETCH>
 int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
-                 unsigned int* next, KswOut O, hipStream_t stream, const u32* lists = nullptr, u64 list_stride = 0 )
+                 unsigned int* next, KswOut O, hipStream_t stream, u32* lists = nullptr, u64 list_stride = 0,
+                 unsigned int* nRedo = nullptr )
 {
     auto al = []( u64 x ) { return ( x + 255 ) / 256 * 256; };
-    const u64 nJobs = SZ.cls[ 0 ] + SZ.cls[ 1 ] + SZ.cls[ 2 ] + SZ.cls[ 3 ] + SZ.cls[ 4 ];
+    u64 nJobs = 0;
+    for( int k = 0; k < KSW_N_CLASSES; k++ )
+        nJobs += SZ.cls[ k ];
     if( nJobs == 0 )
         return 0;
+    const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ];
     const u64 p_cap = al( SZ.p );
     const u64 regStride = al( p_cap + al( SZ.cig * 4 ) );
     KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, 24ull << 30 );
@@ -280,29 +323,52 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         return 1;
     const u32 ldsReg = std::max<u32>( (u32)( ( ( SZ.qlen + 15 ) / 16 ) * 16 + 64 ), KSW_REG_LDS );
     uint8_t* base = scratch.as<uint8_t>( );
-    auto lst = [ & ]( int k ) { return lists ? lists + (u64)k * list_stride : (const u32*)nullptr; };
-    auto cnt = [ & ]( int k ) { return lists ? (u32)SZ.cls[ k ] : nSlots; };
+    u32* redo = lists ? lists + (u64)KSW_N_CLASSES * list_stride : nullptr;
+    auto grid = [ & ]( u64 jobs ) { return dim3( (unsigned)std::max<u64>( 1, std::min<u64>( regWaves, jobs ) ) ); };
     // the launches run back to back on one stream, so they can share the scratch
-    if( SZ.cls[ 0 ] )
-        hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S0> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 0 ] ) ), dim3( 64 ),
-                            ldsReg, stream, F, SC, lst( 0 ), cnt( 0 ), next + 0, 0, base, regStride, p_cap, ldsReg, O );
-    if( SZ.cls[ 1 ] )
-        hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S1> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 1 ] ) ), dim3( 64 ),
-                            ldsReg, stream, F, SC, lst( 1 ), cnt( 1 ), next + 1, 1, base, regStride, p_cap, ldsReg, O );
-    if( SZ.cls[ 2 ] )
-        hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S2> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 2 ] ) ), dim3( 64 ),
-                            ldsReg, stream, F, SC, lst( 2 ), cnt( 2 ), next + 2, 2, base, regStride, p_cap, ldsReg, O );
-    if( SZ.cls[ 3 ] )
-        hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S3> ), dim3( (unsigned)std::min<u64>( regWaves, SZ.cls[ 3 ] ) ), dim3( 64 ),
-                            ldsReg, stream, F, SC, lst( 3 ), cnt( 3 ), next + 3, 3, base, regStride, p_cap, ldsReg, O );
-    if( SZ.cls[ 4 ] )
+    if( SZ.cls[ 5 ] )
+        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), grid( SZ.cls[ 5 ] ), dim3( 64 ), KSW_REG_LDS, stream, F, SC,
+                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base, regStride, p_cap, KSW_REG_LDS, O, redo,
+                            nRedo );
+    if( SZ.cls[ 6 ] )
+        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), grid( SZ.cls[ 6 ] ), dim3( 64 ), KSW_REG_LDS, stream, F, SC,
+                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base, regStride, p_cap, KSW_REG_LDS, O, redo,
+                            nRedo );
+    for( int pass = 0; pass < ( nExt ? 2 : 1 ); pass++ )
     {
-        plan.ws.base = base;
-        if( plan.lds_bytes > 48 * 1024 )
-            MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)plan.lds_bytes ) );
-        hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, lst( 4 ), cnt( 4 ),
-                            next + 4, plan.ws, plan.lds_bytes, O );
+        // pass 0: the classes' own jobs; pass 1: whatever the extension kernel handed back (usually nothing)
+        auto jobs = [ & ]( int k ) {
+            KswJobs JB;
+            JB.list = pass ? redo : ( lists ? lists + (u64)k * list_stride : nullptr );
+            JB.n = lists ? (u32)SZ.cls[ k ] : nSlots;
+            JB.nDev = nRedo;
+            JB.mode = pass ? 2 : ( lists ? 0 : 1 );
+            JB.cls = k;
+            return JB;
+        };
+        auto cnt = [ & ]( int k ) { return pass ? std::min<u64>( nExt, 256 * 4 ) : SZ.cls[ k ]; };
+        unsigned int* nx = next + ( pass ? 7 : 0 );
+        if( cnt( 0 ) )
+            hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S0> ), grid( cnt( 0 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 0 ),
+                                nx + 0, base, regStride, p_cap, ldsReg, O );
+        if( cnt( 1 ) )
+            hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S1> ), grid( cnt( 1 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 1 ),
+                                nx + 1, base, regStride, p_cap, ldsReg, O );
+        if( cnt( 2 ) )
+            hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S2> ), grid( cnt( 2 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 2 ),
+                                nx + 2, base, regStride, p_cap, ldsReg, O );
+        if( cnt( 3 ) )
+            hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S3> ), grid( cnt( 3 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 3 ),
+                                nx + 3, base, regStride, p_cap, ldsReg, O );
+        if( !pass && cnt( 4 ) ) // a handed-back job always fits a ring kernel
+        {
+            plan.ws.base = base;
+            if( plan.lds_bytes > 48 * 1024 )
+                MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)plan.lds_bytes ) );
+            hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC,
+                                jobs( 4 ), nx + 4, plan.ws, plan.lds_bytes, O );
+        }
     }
     MA_HIP( hipGetLastError( ) );
     return 0;

@@ -114,6 +114,8 @@ __device__ __forceinline__ void ksw_red_pair( i32& h, i32& c, int laneMask )
 // direction rows it is about to cross are staged from HBM into `stage` (LDS, stageBytes, may be 0) by all
 // 64 lanes, a block of rows at a time, so a step costs an LDS read instead of an HBM round trip.  The
 // current cigar run is kept in registers and written once per run.  Leaves the CIGAR in cig[0..nCigar).
+// RINGROWS: rows are n_col (a power of two) bytes and cell (r, i) sits at column i mod n_col (ksw_ext.h).
+template <bool RINGROWS = false>
 __device__ __forceinline__ void ksw_backtrack_lane0( const uint8_t* P, u32* cig, i64 n_col, i32 qlen, i32 tlen, i32 w,
                                                      i32 flag, i32 i0, i32 j0, u32& nCigar, u64& pathSteps,
                                                      uint8_t* stage = nullptr, u32 stageBytes = 0 )
@@ -163,10 +165,14 @@ __device__ __forceinline__ void ksw_backtrack_lane0( const uint8_t* P, u32* cig,
                         *(uint4*)( stage + k ) = *(const uint4*)( src + k );
                     __syncthreads( );
                 }
-                tmp = (u32)__builtin_amdgcn_readfirstlane( (i32)stage[ (i64)( r - rlo ) * n_col + i - B.st ] );
+                const i64 col = RINGROWS ? (i64)( i & (i32)( n_col - 1 ) ) : (i64)( i - B.st );
+                tmp = (u32)__builtin_amdgcn_readfirstlane( (i32)stage[ (i64)( r - rlo ) * n_col + col ] );
             }
             else
-                tmp = (u32)__builtin_amdgcn_readfirstlane( (i32)P[ (i64)r * n_col + i - B.st ] );
+            {
+                const i64 col = RINGROWS ? (i64)( i & (i32)( n_col - 1 ) ) : (i64)( i - B.st );
+                tmp = (u32)__builtin_amdgcn_readfirstlane( (i32)P[ (i64)r * n_col + col ] );
+            }
         }
         if( state == 0 )
             state = tmp & 7;

@@ -37,10 +37,11 @@ enum : int
     CTR_N_ALIGNED = 17,
     CTR_SEQ_BYTES = 18, // sum of qlen+tlen over DP jobs
     CTR_PATH_BYTES = 19, // back-trace steps (direction bytes read back)
-    CTR_CLS0 = 20, // DP jobs per ring-slot class (5 consecutive words)
-    CTR_MAX_QLEN = 25,
-    CTR_NEXT_SLOTS = 26, // 5 x u32 job queues of the ksw launches (3 words)
-    CTR_COUNT = 32
+    CTR_CLS0 = 20, // DP jobs per kernel class (KSW_N_CLASSES = 7 consecutive words)
+    CTR_MAX_QLEN = 27,
+    CTR_NEXT_SLOTS = 28, // 12 x u32 job queues of the ksw launches (6 words)
+    CTR_N_REDO = 34, // u32: jobs the extension kernel handed back
+    CTR_COUNT = 40
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -384,6 +385,7 @@ struct DpKernelArgs
     unsigned long long* ctr;
     u32* lists;
     u64 list_stride;
+    KswScoring SC;
 };
 
 #if defined( __HIPCC__ )
@@ -453,9 +455,9 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
             if( k < mine )
             {
                 const DpJob& j = A.jobs[ sink.slot0 + k ];
-                cls = ksw_job_class( (i32)( j.q_to - j.q_from ), (i32)( j.r_to - j.r_from ), j.w );
+                cls = ksw_job_class_pipe( A.SC, (i32)( j.q_to - j.q_from ), (i32)( j.r_to - j.r_from ), j.w, j.flag );
             }
-            for( int c = 0; c < 5; c++ )
+            for( int c = 0; c < KSW_N_CLASSES; c++ )
             {
                 const unsigned long long m = __ballot( cls == c );
                 if( m == 0 )
@@ -1132,7 +1134,7 @@ int ma_dp_batch( ma_batch* b )
     const u64 nSlots = 2 * nhs;
     b->nJobSlots = nSlots;
     if( b->jobs.reserve( ( nSlots + 2 ) * sizeof( DpJob ) ) || b->info.reserve( nh * sizeof( SetInfo ) ) ||
-        b->ez.reserve( ( nSlots + 2 ) * sizeof( ma_ez ) ) || b->clsLists.reserve( ( 5 * nSlots + 2 ) * 4 ) || b->cigOff.reserve( ( nSlots + 2 ) * 8 ) ||
+        b->ez.reserve( ( nSlots + 2 ) * sizeof( ma_ez ) ) || b->clsLists.reserve( ( ( KSW_N_CLASSES + 1 ) * nSlots + 2 ) * 4 ) || b->cigOff.reserve( ( nSlots + 2 ) * 8 ) ||
         b->opsCap.reserve( ( nh + 1 ) * 8 ) || b->opsOff.reserve( ( nh + 2 ) * 8 ) ||
         b->hdr.reserve( nh * sizeof( AlnHeader ) ) || b->order.reserve( nh * 4 ) || b->mqOrder.reserve( nh * 4 ) )
         return 1;
@@ -1151,6 +1153,7 @@ int ma_dp_batch( ma_batch* b )
     D.ctr = b->ctr.as<unsigned long long>( );
     D.lists = b->clsLists.as<u32>( );
     D.list_stride = nSlots;
+    D.SC = KswScoring{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
     {
         EvTimer t( b, 3 );
         // zero-fill: a slot is a job iff q_to > q_from (pool regions of dropped sets stay empty)
@@ -1170,7 +1173,7 @@ int ma_dp_batch( ma_batch* b )
         S.p = b->hctr[ CTR_MAX_P ];
         S.cig = b->hctr[ CTR_MAX_CIG ];
         S.qlen = b->hctr[ CTR_MAX_QLEN ];
-        for( int k = 0; k < 5; k++ )
+        for( int k = 0; k < KSW_N_CLASSES; k++ )
             S.cls[ k ] = b->hctr[ CTR_CLS0 + k ];
         b->cigPoolCap = std::max<u64>( 64 * nJobs + ( 1 << 20 ), b->n_bases / 2 );
         if( b->cigPool.reserve( b->cigPoolCap * 4 ) )
@@ -1190,7 +1193,7 @@ int ma_dp_batch( ma_batch* b )
         PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
         EvTimer t( b, 4 );
         if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
-                         b->clsLists.as<u32>( ), nSlots ) )
+                         b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ) ) )
             return 1;
         MA_HIP( hipGetLastError( ) );
     }
