@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libma_amd.so")
+    # MA_AMD_LIB: an alternative build of the same library (e.g. the -DMA_KSW_PROF diagnostics build)
+    return os.environ.get("MA_AMD_LIB") or os.path.join(_HERE, "libma_amd.so")
 
 
 class MaError(RuntimeError):

@@ -63,9 +63,13 @@ __device__ __forceinline__ u32 lanes_ror1( u32 x ) { return (u32)dpp_wave_ror1( 
 __device__ __forceinline__ u32 cells_shift1( u32 cur, u32 prevLanes ) { return __builtin_amdgcn_alignbit( cur, prevLanes, 16 ); }
 
 // registers slots a job needs in this kernel, 0 = not eligible (see the regime above)
-MA_HD int ksw_ext_slots( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 flag )
+MA_HD int ksw_ext_slots( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag )
 {
-    if( !( flag & 0x40 ) || qlen < 1 || tlen < 1 || w < 0 || qlen > w + 1 || !ksw_h16( SC, qlen, tlen ) )
+    if( qlen < 1 || tlen < 1 || w < 0 || qlen > w + 1 || !ksw_h16( SC, qlen, tlen ) )
+        return 0;
+    // global jobs (NeedlemanWunsch::ksw, needlemanWunsch.cpp:82-169: only the cigar is read): all diagonals must be
+    // inside the regime and nothing may depend on the running maximum
+    if( !( flag & 0x40 ) && ( zdrop >= 0 || (i64)qlen + tlen - 2 > (i64)w ) )
         return 0;
     // the difference vectors must stay inside int8 (they do in kswcpp for such scores; here H tracking relies on it)
     const i32 a = SC.q + SC.e, b = SC.q2 + SC.e2, mch = SC.match < 0 ? -SC.match : SC.match;
@@ -81,10 +85,94 @@ MA_HD int ksw_ext_slots( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 fl
     return 0;
 }
 
-template <int R, bool LEFT, typename QF, typename TF>
+// GLOBAL: no KSW_EZ_EXTZ_ONLY, zdrop < 0: every diagonal is computed, no score is tracked, the back-trace starts
+// at (tlen-1, qlen-1) (kswcpp_core.h:796-835) and ez keeps its initial values apart from the cigar.
+// ksw_backtrack__ (kswcpp_core.h:76-150) over ring rows (RING bytes per diagonal, cell (r, i) at column i mod RING).
+// Inside the regime the path never leaves the DP rectangle, so the force_state cases cannot occur.  Everything is
+// wave-uniform and kept on the scalar unit; rows are staged into LDS `rows` at a time by all 64 lanes.
+template <int RING>
+__device__ __forceinline__ void ksw_backtrack_ring( const uint8_t* P, u32* cig, i32 flag, i32 i0, i32 j0, u32& nCigar,
+                                                    u64& pathSteps, uint8_t* stage, u32 stageBytes )
+{
+    const int lane = threadIdx.x & 63;
+    const i32 rows = (i32)( stageBytes / RING ); // >= 1
+    i32 rlo = 1 << 30;
+    u32 n = 0, curOp = 3, curLen = 0, steps = 0;
+    i32 i = __builtin_amdgcn_readfirstlane( i0 ), j = __builtin_amdgcn_readfirstlane( j0 ), state = 0;
+    while( i >= 0 && j >= 0 )
+    {
+        const i32 r = i + j;
+        if( r < rlo )
+        {
+            __syncthreads( );
+            rlo = r - rows + 1 > 0 ? r - rows + 1 : 0;
+            const i32 bytes = ( r - rlo + 1 ) * RING;
+            const uint8_t* src = P + (size_t)rlo * RING;
+            for( i32 k = lane * 16; k < bytes; k += 1024 )
+                *(uint4*)( stage + k ) = *(const uint4*)( src + k );
+            __syncthreads( );
+        }
+        const i32 tmp = __builtin_amdgcn_readfirstlane( (i32)stage[ ( r - rlo ) * RING + ( i & ( RING - 1 ) ) ] );
+        if( state != 0 && !( ( tmp >> ( state + 2 ) ) & 1 ) )
+            state = 0;
+        if( state == 0 )
+            state = tmp & 7;
+        const u32 op = state == 0 ? 0u : ( ( state == 1 || state == 3 ) ? 2u : 1u );
+        steps++;
+        if( op == curOp )
+            curLen++;
+        else
+        {
+            if( curLen )
+                cig[ n++ ] = curLen << 4 | curOp; // uniform store
+            curOp = op;
+            curLen = 1;
+        }
+        i -= op != 1u ? 1 : 0;
+        j -= op != 2u ? 1 : 0;
+    }
+    // leftovers: deletions for target, insertions for query (kswcpp_core.h:139-144)
+    auto push = [ & ]( u32 op, u32 len ) {
+        if( op == curOp )
+            curLen += len;
+        else
+        {
+            if( curLen )
+                cig[ n++ ] = curLen << 4 | curOp;
+            curOp = op;
+            curLen = len;
+        }
+    };
+    if( i >= 0 )
+        push( 2, (u32)( i + 1 ) );
+    if( j >= 0 )
+        push( 1, (u32)( j + 1 ) );
+    if( curLen )
+        cig[ n++ ] = curLen << 4 | curOp;
+    pathSteps += steps;
+    __syncthreads( );
+    if( !( flag & KSW_EZ_REV_CIGAR ) )
+    {
+        for( u32 a = (u32)lane; a < ( n >> 1 ); a += 64 )
+        {
+            const u32 t = cig[ a ];
+            cig[ a ] = cig[ n - 1 - a ];
+            cig[ n - 1 - a ] = t;
+        }
+        __syncthreads( );
+    }
+    nCigar = n;
+}
+
+template <int R, bool LEFT, bool GLOBAL, typename QF, typename TF>
 __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, uint8_t* lds, u32 ldsBytes,
                               uint8_t* P /*HBM direction rows, RING bytes each*/, u32* cig, KswEz& ez, u32& nCigar,
-                              u64& cells, u64& pathSteps )
+                              u64& cells, u64& pathSteps
+#if defined( MA_KSW_PROF )
+                              ,
+                              unsigned long long* prof
+#endif
+)
 {
     constexpr i32 RING = 128 * R;
     const int lane = threadIdx.x & 63;
@@ -163,6 +251,9 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         H[ s ] = 0;
         Qf[ s ] = 0x00040004u;
     }
+#if defined( MA_KSW_PROF )
+    const unsigned long long tp0 = clock64( );
+#endif
     i32 recycled = 0; // cells below this index have been handed to cells RING further up
     i32 hLeft = 0, hTop = 0; // H(-1, r-1) of the first column, H(r-1, -1) of the first row
     i32 boundPrev = 0x7fffffff;
@@ -203,7 +294,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                 px[ s ] = lanes_ror1( X[ s ] );
                 pv[ s ] = lanes_ror1( V[ s ] );
                 px2[ s ] = lanes_ror1( X2[ s ] );
-                ph[ s ] = lanes_ror1( H[ s ] );
+                ph[ s ] = GLOBAL ? 0u : lanes_ror1( H[ s ] );
                 pq[ s ] = lanes_ror1( Qf[ s ] );
             }
 #pragma unroll
@@ -218,7 +309,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                 xt1[ s ] = cells_shift1( X[ s ], ax );
                 vt1[ s ] = cells_shift1( V[ s ], av );
                 x2t1[ s ] = cells_shift1( X2[ s ], ax2 );
-                hup[ s ] = cells_shift1( H[ s ], ah );
+                hup[ s ] = GLOBAL ? 0u : cells_shift1( H[ s ], ah );
                 Qf[ s ] = cells_shift1( Qf[ s ], aq );
             }
         }
@@ -231,7 +322,8 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             x2t1[ 0 ] = pk_bfi( M_LANE0LO, K_X20, x2t1[ 0 ] );
             vt1[ 0 ] = pk_bfi( M_LANE0LO, ( (u32)ini & 0xffu ) << 8, vt1[ 0 ] );
             hLeft += ini; // H(-1, r)
-            hup[ 0 ] = pk_bfi( M_LANE0LO, (u32)hLeft & 0xffffu, hup[ 0 ] );
+            if( !GLOBAL )
+                hup[ 0 ] = pk_bfi( M_LANE0LO, (u32)hLeft & 0xffffu, hup[ 0 ] );
             Qf[ 0 ] = pk_bfi( M_LANE0LO, qb, Qf[ 0 ] );
         }
         const u32 st0pk = pk_bcast( st0 ), wpk = pk_bcast( en0 - st0 + 1 );
@@ -305,11 +397,16 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             X2[ s ] = nx2;
             *(uint16_t*)( prow + 128 * s + 2 * lane ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
             // ---- H(t, r) = H(t-1, r-1) + u(t, r)
-            const u32 hn = pk_add( hup[ s ], pk_ashr8( nu ) );
-            H[ s ] = hn;
-            Hm[ s ] = pk_bfi( LM, hn, K_NEG );
+            if( !GLOBAL )
+            {
+                const u32 hn = pk_add( hup[ s ], pk_ashr8( nu ) );
+                H[ s ] = hn;
+                Hm[ s ] = pk_bfi( LM, hn, K_NEG );
+            }
         }
         nCells += (u64)( en0 - st0 + 1 );
+        if( GLOBAL )
+            continue;
         // ---- the diagonal's maximum
         u32 hm = Hm[ 0 ];
 #pragma unroll
@@ -423,11 +520,20 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         hTop += ini; // H(r, -1)
     }
     cells += nCells;
+#if defined( MA_KSW_PROF )
+    const unsigned long long tp1 = clock64( );
+#endif
     __syncthreads( ); // direction bytes visible to the back-trace
-    if( ez.max_t < 0 || ez.max_q < 0 )
+    if( !GLOBAL && ( ez.max_t < 0 || ez.max_q < 0 ) )
         return true;
-    ksw_backtrack_lane0<true>( P, cig, (i64)RING, qlen, tlen, w, J.flag, ez.max_t, ez.max_q, nCigar, pathSteps, lds,
-                               ldsBytes );
+    ksw_backtrack_ring<RING>( P, cig, J.flag, GLOBAL ? tlen - 1 : ez.max_t, GLOBAL ? qlen - 1 : ez.max_q, nCigar,
+                              pathSteps, lds, ldsBytes );
+#if defined( MA_KSW_PROF )
+    prof[ GLOBAL ? 8 : 4 ] += tp1 - tp0; // diagonal loop
+    prof[ GLOBAL ? 9 : 5 ] += clock64( ) - tp1; // back-trace
+    prof[ GLOBAL ? 10 : 6 ] += (unsigned long long)nCells;
+    prof[ GLOBAL ? 11 : 7 ] += 1ull;
+#endif
     return true;
 }
 } // namespace ma

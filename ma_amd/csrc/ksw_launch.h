@@ -31,8 +31,20 @@ struct KswOut
     unsigned long long* cells; // sum of band cells
     unsigned long long* njobs;
     unsigned long long* path; // back-trace steps
+    unsigned long long* cig_words; // cigar words written (may be null)
     u32* err;
+    u32 cig_chunk; // 0: one pool atomic per job (dense pool); else each wave reserves pool space this many words at a time
 };
+
+// Per-wave running totals and the wave's current cigar-pool reservation: the device-wide counters sit in one cache
+// line, and same-line atomics serialise in L2 (~9 ns each), so they are touched once per wave, not once per job.
+struct KswWaveAcc
+{
+    u64 cells = 0, njobs = 0, path = 0, cig_words = 0;
+    u64 chunk_off = 0;
+    u32 chunk_left = 0;
+};
+#define KSW_JOBS_PER_FETCH 8u // queue entries a wave takes per atomic
 
 // job classes by the number of ring slots they need (ksw_need_slots): 1, 2, <=4, <=9, else LDS kernel (class 3
 // shares the launch slot of the widest ring; class 4 = ksw_wave.h)
@@ -47,16 +59,45 @@ MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
     return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : ( n <= KSW_S3 ? 3 : 4 ) ) );
 }
 // pipeline mode: extensions whose callers read only max_q / max_t / cigar go to the extension kernel
-MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 flag )
+MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag )
 {
-    const int e = ksw_ext_slots( SC, qlen, tlen, w, flag );
+    const int e = ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag );
     return e ? 4 + e : ksw_job_class( qlen, tlen, w );
 }
 
 // result record + cigar of one finished job -> output arrays (all 64 lanes call this)
-__device__ __forceinline__ void ksw_publish( const KswOut& O, u32 slot, const KswEz& ez, u32 nCig, u64 cells, u64 path,
-                                             const u32* cig, unsigned long long* sOff )
+__device__ __forceinline__ void ksw_publish( const KswOut& O, KswWaveAcc& A, u32 slot, const KswEz& ez, u32 nCig, u64 cells,
+                                             u64 path, const u32* cig, unsigned long long* sOff )
 {
+    A.cells += cells;
+    A.njobs += 1;
+    A.path += path;
+    A.cig_words += nCig;
+    u64 off;
+    if( O.cig_chunk == 0 || nCig > O.cig_chunk )
+    {
+        if( threadIdx.x == 0 )
+            *sOff = atomicAdd( O.cig_used, (unsigned long long)nCig );
+        __syncthreads( );
+        off = *sOff;
+        __syncthreads( );
+    }
+    else
+    {
+        if( nCig > A.chunk_left )
+        {
+            if( threadIdx.x == 0 )
+                *sOff = atomicAdd( O.cig_used, (unsigned long long)O.cig_chunk );
+            __syncthreads( );
+            A.chunk_off = *sOff;
+            A.chunk_left = O.cig_chunk;
+            __syncthreads( );
+        }
+        off = A.chunk_off;
+        A.chunk_off += nCig;
+        A.chunk_left -= nCig;
+    }
+    const bool fits = off + nCig <= O.cig_pool_cap;
     if( threadIdx.x == 0 )
     {
         ma_ez r;
@@ -72,21 +113,43 @@ __device__ __forceinline__ void ksw_publish( const KswOut& O, u32 slot, const Ks
         r.reach_end = ez.reach_end;
         r.n_cigar = (i32)nCig;
         O.ez[ slot ] = r;
-        *sOff = atomicAdd( O.cig_used, (unsigned long long)nCig );
-        O.cig_off[ slot ] = *sOff;
-        if( *sOff + nCig > O.cig_pool_cap )
+        O.cig_off[ slot ] = off;
+        if( !fits )
             atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
-        atomicAdd( O.cells, (unsigned long long)cells );
-        atomicAdd( O.njobs, 1ull );
-        if( O.path )
-            atomicAdd( O.path, (unsigned long long)path );
     }
-    __syncthreads( );
-    const u64 off = *sOff;
-    if( off + nCig <= O.cig_pool_cap )
+    if( fits )
         for( u32 i = threadIdx.x; i < nCig; i += 64 )
             O.cig_pool[ off + i ] = cig[ i ];
-    __syncthreads( );
+    __syncthreads( ); // the scratch cigar may be overwritten by the next job
+}
+__device__ __forceinline__ void ksw_flush( const KswOut& O, const KswWaveAcc& A )
+{
+    if( threadIdx.x == 0 && A.njobs )
+    {
+        atomicAdd( O.cells, (unsigned long long)A.cells );
+        atomicAdd( O.njobs, (unsigned long long)A.njobs );
+        if( O.path )
+            atomicAdd( O.path, (unsigned long long)A.path );
+        if( O.cig_words )
+            atomicAdd( O.cig_words, (unsigned long long)A.cig_words );
+    }
+}
+// next queue position of this wave: KSW_JOBS_PER_FETCH entries per atomic
+__device__ __forceinline__ bool ksw_next( unsigned int* nextSlot, u32 n, u32& cur, u32& end, u32* sSlot, u32& at )
+{
+    if( cur == end )
+    {
+        if( threadIdx.x == 0 )
+            *sSlot = atomicAdd( nextSlot, KSW_JOBS_PER_FETCH );
+        __syncthreads( );
+        cur = *sSlot;
+        __syncthreads( );
+        end = cur + KSW_JOBS_PER_FETCH < n ? cur + KSW_JOBS_PER_FETCH : n;
+        if( cur >= n )
+            return false;
+    }
+    at = cur++;
+    return true;
 }
 
 // job source of a launch: mode 0 = list[0..n), 1 = every slot 0..n that is valid and of class cls,
@@ -99,8 +162,18 @@ struct KswJobs
     int mode, cls;
 };
 
+#if defined( MA_KSW_PROF )
+#define KSW_PROF_T( v ) const unsigned long long v = clock64( )
+#define KSW_PROF_ADD( i, a, b ) prof[ i ] += ( b ) - ( a )
+#define KSW_PROF_ARG , prof
+#else
+#define KSW_PROF_ARG
+#define KSW_PROF_T( v )
+#define KSW_PROF_ADD( i, a, b )
+#endif
+
 template <typename FETCH, int R>
-__global__ void __launch_bounds__( 64 ) k_ksw_ext( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 8, 8 ) ) ) k_ksw_ext( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
                                                   uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O,
                                                   u32* redo, unsigned int* nRedo )
 {
@@ -109,14 +182,16 @@ __global__ void __launch_bounds__( 64 ) k_ksw_ext( FETCH F, KswScoring SC, const
     __shared__ unsigned long long sOff;
     uint8_t* my = scratch + (u64)blockIdx.x * stride;
     u32* cig = (u32*)( my + p_cap );
+#if defined( MA_KSW_PROF )
+    unsigned long long prof[ 12 ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
+    KswWaveAcc acc;
+    u32 qCur = 0, qEnd = 0;
     while( true )
     {
-        if( threadIdx.x == 0 )
-            sSlot = atomicAdd( nextSlot, 1u );
-        __syncthreads( );
-        const u32 at = sSlot;
-        __syncthreads( );
-        if( at >= n )
+        KSW_PROF_T( t0 );
+        u32 at;
+        if( !ksw_next( nextSlot, n, qCur, qEnd, &sSlot, at ) )
             break;
         const u32 slot = list[ at ];
         const KswJobView J = F.view( slot );
@@ -126,18 +201,38 @@ __global__ void __launch_bounds__( 64 ) k_ksw_ext( FETCH F, KswScoring SC, const
         auto qf = F.qfetch( slot );
         auto tf = F.tfetch( slot );
         bool ok;
-        if( J.flag & KSW_EZ_RIGHT )
-            ok = ksw_ext_core<R, false>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path );
+        KSW_PROF_T( t1 );
+        if( !( J.flag & KSW_EZ_EXTZ_ONLY ) )
+        {
+            if( J.flag & KSW_EZ_RIGHT )
+                ok = ksw_ext_core<R, false, true>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path KSW_PROF_ARG );
+            else
+                ok = ksw_ext_core<R, true, true>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path KSW_PROF_ARG );
+        }
+        else if( J.flag & KSW_EZ_RIGHT )
+            ok = ksw_ext_core<R, false, false>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path KSW_PROF_ARG );
         else
-            ok = ksw_ext_core<R, true>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path );
+            ok = ksw_ext_core<R, true, false>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path KSW_PROF_ARG );
         if( !ok )
         {
             if( threadIdx.x == 0 )
                 redo[ atomicAdd( nRedo, 1u ) ] = slot;
             continue;
         }
-        ksw_publish( O, slot, ez, nCig, cells, path, cig, &sOff );
+        KSW_PROF_T( t2 );
+        ksw_publish( O, acc, slot, ez, nCig, cells, path, cig, &sOff );
+        KSW_PROF_T( t3 );
+        KSW_PROF_ADD( 0, t0, t1 );
+        KSW_PROF_ADD( 1, t1, t2 );
+        KSW_PROF_ADD( 2, t2, t3 );
+        KSW_PROF_ADD( 3, 0ull, 1ull );
     }
+    ksw_flush( O, acc );
+#if defined( MA_KSW_PROF )
+    if( threadIdx.x == 0 )
+        for( int i = 0; i < 12; i++ )
+            atomicAdd( &g_ksw_prof[ i ], prof[ i ] );
+#endif
 }
 
 template <typename FETCH, int S>
@@ -151,14 +246,12 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, KswJo
     uint8_t* P = my;
     u32* cig = (u32*)( my + p_cap );
     const u32 n = JB.mode == 2 ? *JB.nDev : JB.n;
+    KswWaveAcc acc;
+    u32 qCur = 0, qEnd = 0;
     while( true )
     {
-        if( threadIdx.x == 0 )
-            sSlot = atomicAdd( nextSlot, 1u );
-        __syncthreads( );
-        const u32 at = sSlot;
-        __syncthreads( );
-        if( at >= n )
+        u32 at;
+        if( !ksw_next( nextSlot, n, qCur, qEnd, &sSlot, at ) )
             break;
         const u32 slot = JB.mode == 1 ? at : JB.list[ at ];
         if( JB.mode == 1 && !F.valid( slot ) )
@@ -175,8 +268,9 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, KswJo
             ksw_reg_core<S, int16_t, 8, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
         else
             ksw_reg_core<S, int32_t, 4, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
-        ksw_publish( O, slot, ez, nCig, cells, path, cig, &sOff );
+        ksw_publish( O, acc, slot, ez, nCig, cells, path, cig, &sOff );
     }
+    ksw_flush( O, acc );
 }
 
 template <typename FETCH>
@@ -207,14 +301,12 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, KswJobs J
     }
     __shared__ unsigned long long sOff;
     const u32 n = JB.mode == 2 ? *JB.nDev : JB.n;
+    KswWaveAcc acc;
+    u32 qCur = 0, qEnd = 0;
     while( true )
     {
-        if( threadIdx.x == 0 )
-            sSlot = atomicAdd( nextSlot, 1u );
-        __syncthreads( );
-        const u32 at = sSlot;
-        __syncthreads( );
-        if( at >= n )
+        u32 at;
+        if( !ksw_next( nextSlot, n, qCur, qEnd, &sSlot, at ) )
             break;
         const u32 slot = JB.mode == 1 ? at : JB.list[ at ];
         if( JB.mode == 1 && !F.valid( slot ) )
@@ -232,8 +324,9 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, KswJobs J
             ksw_wave_core<int16_t, 8>( SC, J, qf, tf, M, ez, nCig, cells, path );
         else
             ksw_wave_core<int32_t, 4>( SC, J, qf, tf, M, ez, nCig, cells, path );
-        ksw_publish( O, slot, ez, nCig, cells, path, M.cig, &sOff );
+        ksw_publish( O, acc, slot, ez, nCig, cells, path, M.cig, &sOff );
     }
+    ksw_flush( O, acc );
 }
 
 // sizes for a job population (host side)
@@ -300,6 +393,7 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
 // kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every launch scans
 // nSlots and there are no extension-kernel classes.
 #define KSW_REG_LDS 6144u // per-wave LDS of the ring kernels: reversed query, later the back-trace staging block
+#define KSW_EXT_LDS 4096u // extension kernel: back-trace staging only (8 waves per SIMD fit)
 template <typename FETCH>
 int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
                  unsigned int* next, KswOut O, hipStream_t stream, u32* lists = nullptr, u64 list_stride = 0,
@@ -315,7 +409,7 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     const u64 p_cap = al( SZ.p );
     const u64 regStride = al( p_cap + al( SZ.cig * 4 ) );
     KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, 24ull << 30 );
-    u64 regWaves = std::min<u64>( 256ull * 24, nJobs );
+    u64 regWaves = std::min<u64>( 256ull * 32, nJobs );
     if( regStride * regWaves > ( 24ull << 30 ) )
         regWaves = std::max<u64>( 1, ( 24ull << 30 ) / regStride );
     const u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0 );
@@ -327,12 +421,12 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     auto grid = [ & ]( u64 jobs ) { return dim3( (unsigned)std::max<u64>( 1, std::min<u64>( regWaves, jobs ) ) ); };
     // the launches run back to back on one stream, so they can share the scratch
     if( SZ.cls[ 5 ] )
-        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), grid( SZ.cls[ 5 ] ), dim3( 64 ), KSW_REG_LDS, stream, F, SC,
-                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base, regStride, p_cap, KSW_REG_LDS, O, redo,
+        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), grid( SZ.cls[ 5 ] ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
+                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base, regStride, p_cap, KSW_EXT_LDS, O, redo,
                             nRedo );
     if( SZ.cls[ 6 ] )
-        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), grid( SZ.cls[ 6 ] ), dim3( 64 ), KSW_REG_LDS, stream, F, SC,
-                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base, regStride, p_cap, KSW_REG_LDS, O, redo,
+        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), grid( SZ.cls[ 6 ] ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
+                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base, regStride, p_cap, KSW_EXT_LDS, O, redo,
                             nRedo );
     for( int pass = 0; pass < ( nExt ? 2 : 1 ); pass++ )
     {

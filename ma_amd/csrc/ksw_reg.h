@@ -42,7 +42,7 @@ __device__ __forceinline__ i32 dpp_wave_ror1( i32 x ) // lane i <- lane i-1, lan
 }
 template <int CTRL> __device__ __forceinline__ i32 dpp_ctrl( i32 x )
 {
-    return __builtin_amdgcn_update_dpp( x, x, CTRL, 0xf, 0xf, false );
+    return __builtin_amdgcn_update_dpp( 0, x, CTRL, 0xf, 0xf, true ); // folds into the consuming VALU op
 }
 __device__ __forceinline__ i32 lane_bcast( i32 x, int srcLane ) // wave-uniform source lane
 {

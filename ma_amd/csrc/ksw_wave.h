@@ -16,6 +16,9 @@
 #if defined( __HIPCC__ )
 namespace ma
 {
+#if defined( MA_KSW_PROF )
+static __device__ unsigned long long g_ksw_prof[ 16 ]; // phase cycle counters (diagnostics build only)
+#endif
 #define KSW_EZ_RIGHT 0x02
 #define KSW_EZ_EXTZ_ONLY 0x40
 #define KSW_EZ_REV_CIGAR 0x80

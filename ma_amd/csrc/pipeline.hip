@@ -41,6 +41,7 @@ enum : int
     CTR_MAX_QLEN = 27,
     CTR_NEXT_SLOTS = 28, // 12 x u32 job queues of the ksw launches (6 words)
     CTR_N_REDO = 34, // u32: jobs the extension kernel handed back
+    CTR_CIG_WORDS = 35, // cigar words written (CTR_CIG_USED counts pool words reserved)
     CTR_COUNT = 40
 };
 
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
             if( k < mine )
             {
                 const DpJob& j = A.jobs[ sink.slot0 + k ];
-                cls = ksw_job_class_pipe( A.SC, (i32)( j.q_to - j.q_from ), (i32)( j.r_to - j.r_from ), j.w, j.flag );
+                cls = ksw_job_class_pipe( A.SC, (i32)( j.q_to - j.q_from ), (i32)( j.r_to - j.r_from ), j.w, j.zdrop, j.flag );
             }
             for( int c = 0; c < KSW_N_CLASSES; c++ )
             {
@@ -1175,7 +1176,8 @@ int ma_dp_batch( ma_batch* b )
         S.qlen = b->hctr[ CTR_MAX_QLEN ];
         for( int k = 0; k < KSW_N_CLASSES; k++ )
             S.cls[ k ] = b->hctr[ CTR_CLS0 + k ];
-        b->cigPoolCap = std::max<u64>( 64 * nJobs + ( 1 << 20 ), b->n_bases / 2 );
+        // every wave of the ksw launches may leave one partly used 4096-word reservation per class launch
+        b->cigPoolCap = std::max<u64>( 64 * nJobs + ( 1 << 20 ), b->n_bases / 2 ) + 4096ull * 256 * 32 * 4;
         if( b->cigPool.reserve( b->cigPoolCap * 4 ) )
             return 1;
         KswScoring SC{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
@@ -1190,6 +1192,8 @@ int ma_dp_batch( ma_batch* b )
         O.njobs = c + CTR_KSW_JOBS;
         O.err = (u32*)( c + CTR_ERR );
         O.path = c + CTR_PATH_BYTES;
+        O.cig_chunk = 4096;
+        O.cig_words = c + CTR_CIG_WORDS;
         PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
         EvTimer t( b, 4 );
         if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
@@ -1283,7 +1287,7 @@ int ma_batch_counters( ma_batch* b, uint64_t out[ 8 ] )
     out[ 4 ] = b->hctr[ CTR_CELLS ];
     out[ 5 ] = b->hctr[ CTR_KSW_JOBS ];
     out[ 6 ] = b->hctr[ CTR_SEQ_BYTES ];
-    out[ 7 ] = b->hctr[ CTR_PATH_BYTES ] + 4 * b->hctr[ CTR_CIG_USED ];
+    out[ 7 ] = b->hctr[ CTR_PATH_BYTES ] + 4 * b->hctr[ CTR_CIG_WORDS ];
     return 0;
 }
 
@@ -1518,5 +1522,13 @@ int ma_batch_get_dp_jobs( ma_batch* b, uint64_t* n_jobs, int32_t* shapes /* 8 x 
         *n_jobs = n;
     return 0;
 }
+
+#if defined( MA_KSW_PROF )
+int ma_debug_ksw_prof( unsigned long long* out )
+{
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_ksw_prof ), 16 * 8 ) );
+    return 0;
+}
+#endif
 
 } // extern "C"

@@ -144,6 +144,8 @@ extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_
     O.njobs = ctr + 2;
     O.err = (u32*)( ctr + 3 );
     O.path = nullptr;
+    O.cig_words = nullptr;
+    O.cig_chunk = 0; // dense pool: cigar_off[n] is the total
     unsigned int* next = (unsigned int*)( ctr + 4 ); // 4 x u32 launch queues
     ByteFetch F{ dj.as<ma_ksw_job>( ), dq.as<uint8_t>( ), dt.as<uint8_t>( ) };
     if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0 ) )

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Phase cycle counters of the extension kernel (needs the -DMA_KSW_PROF build, see tools/_prof)."""
+import ctypes as C, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["MA_AMD_LIB"] = os.path.join(ROOT, "tools", "_prof", "libma_amd_prof.so")
+sys.path.insert(0, ROOT)
+sys.argv = ["bench.py", "--steps", "2", "--warmup", "0", "--cpu-sample", "0"] + sys.argv[1:]
+import runpy
+import ma_amd
+try:
+    runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
+finally:
+    out = (C.c_ulonglong * 16)()
+    ma_amd.lib().ma_debug_ksw_prof(out)
+    v = list(out)
+    names = ["fetch+setup", "core(total)", "publish", "jobs", "ext:loop", "ext:backtrace", "ext:cells", "ext:jobs",
+             "glob:loop", "glob:backtrace", "glob:cells", "glob:jobs"]
+    for n, x in zip(names, v):
+        print("%-16s %d" % (n, x))
+    j = max(v[3], 1)
+    print("per job cycles: fetch %.0f core %.0f publish %.0f" % (v[0] / j, v[1] / j, v[2] / j))
+    if v[7]:
+        print("ext  per job: loop %.0f backtrace %.0f cells %.0f" % (v[4] / v[7], v[5] / v[7], v[6] / v[7]))
+    if v[11]:
+        print("glob per job: loop %.0f backtrace %.0f cells %.0f" % (v[8] / v[11], v[9] / v[11], v[10] / v[11]))
