@@ -63,9 +63,12 @@ MA_HD void occ4_in_block( const Block64& b, u32 within, u64 cnt[ 4 ] )
 
 MA_HD void init_interval( const IndexView& x, u32 c, i64 ik[ 3 ] ) // fMIndex.h:768-775
 {
-    ik[ 0 ] = (i64)x.L2[ c ] + 1;
-    ik[ 1 ] = (i64)x.L2[ 3 - c ] + 1;
-    ik[ 2 ] = (i64)( x.L2[ c + 1 ] - x.L2[ c ] );
+    const u64 lo = c == 0 ? x.L2[ 0 ] : ( c == 1 ? x.L2[ 1 ] : ( c == 2 ? x.L2[ 2 ] : x.L2[ 3 ] ) );
+    const u64 hi = c == 0 ? x.L2[ 1 ] : ( c == 1 ? x.L2[ 2 ] : ( c == 2 ? x.L2[ 3 ] : x.L2[ 4 ] ) );
+    const u64 rc = c == 0 ? x.L2[ 3 ] : ( c == 1 ? x.L2[ 2 ] : ( c == 2 ? x.L2[ 1 ] : x.L2[ 0 ] ) );
+    ik[ 0 ] = (i64)lo + 1;
+    ik[ 1 ] = (i64)rc + 1;
+    ik[ 2 ] = (i64)( hi - lo );
 }
 
 // One FMD backward step. Reads the block of row k-1 and of row l-1 (one 64-B line each; the second
@@ -104,22 +107,18 @@ MA_HD void extend_backward( const IndexView& x, const i64 ik[ 3 ], u32 c, i64 ok
         occ4_in_block( bk, (u32)( (u64)kk & 127 ), cntk );
     if( hasL )
         occ4_in_block( bl, (u32)( (u64)ll & 127 ), cntl );
-    u64 cnts[ 4 ];
-#pragma unroll
-    for( int i = 0; i < 4; i++ )
-        cnts[ i ] = cntl[ i ] - cntk[ i ];
+    // selects instead of c-indexed arrays: a dynamically indexed local array would live in scratch memory
+    const u64 s0 = cntl[ 0 ] - cntk[ 0 ], s1 = cntl[ 1 ] - cntk[ 1 ], s2 = cntl[ 2 ] - cntk[ 2 ], s3 = cntl[ 3 ] - cntk[ 3 ];
     u64 c2 = (u64)ik[ 1 ];
     if( start <= x.primary && end > x.primary )
         c2++;
     // cntk_2[i] = cntk_2[i-1] + cnts[3-(i-1)]; result uses cntk_2[3-c]
-    u64 acc[ 4 ];
-    acc[ 0 ] = c2;
-    acc[ 1 ] = acc[ 0 ] + cnts[ 3 ];
-    acc[ 2 ] = acc[ 1 ] + cnts[ 2 ];
-    acc[ 3 ] = acc[ 2 ] + cnts[ 1 ];
-    ok[ 0 ] = (i64)( x.L2[ c ] + cntk[ c ] + 1 );
-    ok[ 1 ] = (i64)acc[ 3 - c ];
-    ok[ 2 ] = (i64)cnts[ c ];
+    const u64 a0 = c2, a1 = a0 + s3, a2 = a1 + s2, a3 = a2 + s1;
+    const u64 l2c = c == 0 ? x.L2[ 0 ] : ( c == 1 ? x.L2[ 1 ] : ( c == 2 ? x.L2[ 2 ] : x.L2[ 3 ] ) );
+    const u64 ckc = c == 0 ? cntk[ 0 ] : ( c == 1 ? cntk[ 1 ] : ( c == 2 ? cntk[ 2 ] : cntk[ 3 ] ) );
+    ok[ 0 ] = (i64)( l2c + ckc + 1 );
+    ok[ 1 ] = (i64)( c == 0 ? a3 : ( c == 1 ? a2 : ( c == 2 ? a1 : a0 ) ) );
+    ok[ 2 ] = (i64)( c == 0 ? s0 : ( c == 1 ? s1 : ( c == 2 ? s2 : s3 ) ) );
 }
 
 // bwt_invPsi (fMIndex.h:329-343): one 64-B block per LF step (B0 and occ hit the same block)
@@ -136,7 +135,9 @@ MA_HD i64 inv_psi( const IndexView& x, i64 k )
     // equals xx for k != primary
     u64 cnt[ 4 ];
     occ4_in_block( b, within, cnt );
-    return (i64)( x.L2[ c ] + cnt[ c ] );
+    const u64 l2c = c == 0 ? x.L2[ 0 ] : ( c == 1 ? x.L2[ 1 ] : ( c == 2 ? x.L2[ 2 ] : x.L2[ 3 ] ) );
+    const u64 cc = c == 0 ? cnt[ 0 ] : ( c == 1 ? cnt[ 1 ] : ( c == 2 ? cnt[ 2 ] : cnt[ 3 ] ) );
+    return (i64)( l2c + cc );
 }
 
 // bwt_sa (fMIndex.h:788-814)

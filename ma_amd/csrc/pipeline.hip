@@ -60,6 +60,7 @@ struct SeedKernelArgs
     ma_segment* smem_a; // lanes * smem_cap
     ma_segment* smem_b;
     u32 smem_cap;
+    u32* stack; // lanes * 2 * MA_SEED_STACK
     ma_segment* pool;
     u32* pool_read; // read id per pooled segment
     u64 pool_cap;
@@ -79,6 +80,7 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
     S.smem_a = A.smem_a ? A.smem_a + (u64)lane * A.smem_cap : nullptr;
     S.smem_b = A.smem_b ? A.smem_b + (u64)lane * A.smem_cap : nullptr;
     S.smem_cap = A.smem_cap;
+    S.stack = A.stack + (u64)lane * ( 2 * MA_SEED_STACK );
     SeedLane L;
     L.phase = PH_DONE;
     u32 read = 0xffffffffu;
@@ -667,7 +669,7 @@ struct ma_batch
     bool reads_external = false;
     const uint8_t* d_reads = nullptr;
     const u64* d_roff = nullptr;
-    DevBuf reads, roff, ctr;
+    DevBuf reads, roff, ctr, seedStack;
     // seeding
     DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt;
     u64 segPoolCap = 0;
@@ -897,7 +899,7 @@ int ma_seed_batch( ma_batch* b )
         ( smem && ( b->smemA.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ||
                     b->smemB.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ) ) ||
         b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
-        b->segOff.reserve( n * 8 ) || b->segCnt.reserve( n * 4 ) )
+        b->segOff.reserve( n * 8 ) || b->segCnt.reserve( n * 4 ) || b->seedStack.reserve( lanes * 2 * MA_SEED_STACK * 4 ) )
         return 1;
     SeedKernelArgs A;
     A.X = b->idx->v;
@@ -910,6 +912,7 @@ int ma_seed_batch( ma_batch* b )
     A.smem_a = smem ? b->smemA.as<ma_segment>( ) : nullptr;
     A.smem_b = smem ? b->smemB.as<ma_segment>( ) : nullptr;
     A.smem_cap = smem_cap;
+    A.stack = b->seedStack.as<u32>( );
     A.pool = b->segPool.as<ma_segment>( );
     A.pool_read = b->segRead.as<u32>( );
     A.pool_cap = b->segPoolCap;

@@ -25,6 +25,8 @@ struct SeedScratch
     ma_segment* smem_a; // SMEM pending lists (capacity smem_cap each)
     ma_segment* smem_b;
     u32 smem_cap;
+    u32* stack; // 2 * MA_SEED_STACK words: interval stack of procesInterval (kept out of SeedLane so that the lane
+                // state stays in registers; a dynamically indexed member would put the whole struct in scratch memory)
 };
 
 enum SeedPhase : u32
@@ -47,7 +49,7 @@ struct SeedLane
     const uint8_t* q;
     u32 qlen;
     // interval stack of procesInterval (binarySeeding.cpp:32-84): left parts recurse, right parts iterate
-    u32 stS[ MA_SEED_STACK ], stN[ MA_SEED_STACK ];
+    // (entries live in SeedScratch::stack)
     u32 sp;
     u32 aS, aN; // area currently processed
     // extension state
@@ -103,7 +105,7 @@ MA_HD void seed_begin_read( SeedLane& L, const uint8_t* q, u32 qlen )
 
 // After an extension around `center` covered [cS, cS+cN] (reference convention), split the area
 // (binarySeeding.cpp:58-82): recurse left first, continue right afterwards.
-MA_HD void seed_after_center( SeedLane& L, u32 cS, u32 cN )
+MA_HD void seed_after_center( SeedLane& L, const SeedScratch& S, u32 cS, u32 cN )
 {
     const u32 cE = cS + cN, aE = L.aS + L.aN;
     const bool hasLeft = cS != 0 && L.aS + 1 < cS;
@@ -114,8 +116,8 @@ MA_HD void seed_after_center( SeedLane& L, u32 cS, u32 cN )
         {
             if( L.sp < MA_SEED_STACK )
             {
-                L.stS[ L.sp ] = cE;
-                L.stN[ L.sp ] = aE - cE;
+                S.stack[ 2 * L.sp ] = cE;
+                S.stack[ 2 * L.sp + 1 ] = aE - cE;
                 L.sp++;
             }
             else
@@ -133,8 +135,8 @@ MA_HD void seed_after_center( SeedLane& L, u32 cS, u32 cN )
     else if( L.sp > 0 )
     {
         L.sp--;
-        L.aS = L.stS[ L.sp ];
-        L.aN = L.stN[ L.sp ];
+        L.aS = S.stack[ 2 * L.sp ];
+        L.aN = S.stack[ 2 * L.sp + 1 ];
         L.phase = PH_NEW_CENTER;
     }
     else
@@ -164,7 +166,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
                 const u32 qc = L.q[ L.center ];
                 if( qc >= 4 )
                 { // N covers one position (binarySeeding.h:70-72 / 275-277)
-                    seed_after_center( L, L.center, 1 );
+                    seed_after_center( L, S, L.center, 1 );
                     break;
                 }
                 init_interval( X, 3 - qc, L.ik );
@@ -172,7 +174,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
                 {
                     if( L.ik[ 2 ] == 0 )
                     {
-                        seed_after_center( L, L.center, 1 );
+                        seed_after_center( L, S, L.center, 1 );
                         break;
                     }
                     L.end = L.center;
@@ -242,13 +244,13 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
                 {
                     // finish the center (binarySeeding.h:226-251)
                     if( L.s1_start == L.start && L.s1_end == L.end )
-                        seed_after_center( L, L.s1_start, L.s1_end - L.s1_start );
+                        seed_after_center( L, S, L.s1_start, L.s1_end - L.s1_start );
                     else
                     {
                         seed_emit( L, S, L.start, L.end - L.start, L.ik[ 1 ], L.ik[ 0 ], L.ik[ 2 ] );
                         const u32 s = L.start < L.s1_start ? L.start : L.s1_start;
                         const u32 e = L.end > L.s1_end ? L.end : L.s1_end;
-                        seed_after_center( L, s, e - s );
+                        seed_after_center( L, S, s, e - s );
                     }
                 }
                 break;
@@ -285,7 +287,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
                             const ma_segment& f = S.smem_a[ 0 ];
                             seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
                         }
-                        seed_after_center( L, L.retS, L.retE - L.retS );
+                        seed_after_center( L, S, L.retS, L.retE - L.retS );
                     }
                 }
                 break;
@@ -324,7 +326,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
                         const ma_segment& f = ( L.flip ? S.smem_b : S.smem_a )[ 0 ];
                         seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
                     }
-                    seed_after_center( L, L.retS, L.retE - L.retS );
+                    seed_after_center( L, S, L.retS, L.retE - L.retS );
                 }
                 break;
             }
