@@ -61,6 +61,7 @@ struct SeedKernelArgs
     ma_segment* smem_b;
     u32 smem_cap;
     u32* stack; // lanes * 2 * MA_SEED_STACK
+    u32 q_lds; // LDS bytes per lane for the read in flight (0: reads stay in HBM)
     ma_segment* pool;
     u32* pool_read; // read id per pooled segment
     u64 pool_cap;
@@ -69,6 +70,9 @@ struct SeedKernelArgs
     unsigned long long* ctr;
 };
 
+#if defined( MA_KSW_PROF )
+static __device__ unsigned long long g_seed_prof[ 8 ];
+#endif
 // One read per lane at a time; lanes refill from a global queue, so a wavefront keeps stepping 64
 // reads in lockstep through extend_backward until the batch is exhausted.
 __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
@@ -81,11 +85,19 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
     S.smem_b = A.smem_b ? A.smem_b + (u64)lane * A.smem_cap : nullptr;
     S.smem_cap = A.smem_cap;
     S.stack = A.stack + (u64)lane * ( 2 * MA_SEED_STACK );
+    S.drop_div = A.P.min_seed_size_drop;
     SeedLane L;
     L.phase = PH_DONE;
     u32 read = 0xffffffffu;
     u64 steps = 0, blocks = 0;
     const u32 wl = threadIdx.x & 63;
+#if defined( MA_KSW_PROF )
+    unsigned long long pf[ 6 ] = { 0, 0, 0, 0, 0, 0 };
+#endif
+    // the read in flight is staged in LDS (stride = odd number of words: conflict-free): every step of the state
+    // machine starts with a query base, and an LDS read is ~20x closer than an HBM one
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t q_lds[];
+    uint8_t* myq = q_lds + (size_t)threadIdx.x * A.q_lds;
     bool alive = true;
     while( true )
     {
@@ -93,7 +105,12 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
         // the read queue instead of one per read (same-address atomics serialise in L2).
         const bool done = alive && L.phase == PH_DONE;
         const unsigned long long dm = __ballot( done );
-        if( dm )
+#if defined( MA_KSW_PROF )
+        const unsigned long long tA = clock64( );
+#endif
+        // refill when at least 8 lanes wait (a refill stalls the whole wave for several memory round trips) or when
+        // nothing else is left to do
+        if( dm && ( __popcll( dm ) >= 8 || dm == __ballot( alive ) ) )
         {
             const bool flush = done && read != 0xffffffffu;
             const u32 n = flush ? seed_finish( L, A.P, S, A.X ) : 0u;
@@ -105,22 +122,28 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
                     inc += o;
             }
             const u32 total = (u32)__shfl( (int)inc, 63, 64 );
-            unsigned long long base = 0;
-            if( total )
+            unsigned long long base = 0, rb = 0;
+            if( wl == 0 )
             {
-                if( wl == 0 )
-                    base = atomicAdd( &A.ctr[ CTR_SEG_USED ], (unsigned long long)total );
-                base = ( (u64)(u32)__shfl( (int)( base >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)base, 0, 64 );
+                // both in flight before either result is needed
+                rb = atomicAdd( &A.ctr[ CTR_NEXT_READ ], (unsigned long long)__popcll( dm ) );
+                base = atomicAdd( &A.ctr[ CTR_SEG_USED ], (unsigned long long)total );
             }
+            base = ( (u64)(u32)__shfl( (int)( base >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)base, 0, 64 );
+            rb = ( (u64)(u32)__shfl( (int)( rb >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)rb, 0, 64 );
             if( flush )
             {
                 const u64 off = base + inc - n;
                 if( off + n <= A.pool_cap )
                 {
+                    const ma_segment* __restrict__ src = S.stage;
+                    ma_segment* __restrict__ dst = A.pool + off;
+                    u32* __restrict__ dr = A.pool_read + off;
+#pragma unroll 4
                     for( u32 k = 0; k < n; k++ )
                     {
-                        A.pool[ off + k ] = S.stage[ k ];
-                        A.pool_read[ off + k ] = read;
+                        dst[ k ] = src[ k ];
+                        dr[ k ] = read;
                     }
                 }
                 else
@@ -132,10 +155,6 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
                 steps += L.steps;
                 blocks += L.blocks;
             }
-            unsigned long long rb = 0;
-            if( wl == 0 )
-                rb = atomicAdd( &A.ctr[ CTR_NEXT_READ ], (unsigned long long)__popcll( dm ) );
-            rb = ( (u64)(u32)__shfl( (int)( rb >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)rb, 0, 64 );
             if( done )
             {
                 const u64 mine = rb + (u64)__popcll( dm & ( ( 1ull << wl ) - 1 ) );
@@ -144,14 +163,38 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
                 else
                 {
                     read = (u32)mine;
-                    seed_begin_read( L, A.reads + A.roff[ read ], (u32)( A.roff[ read + 1 ] - A.roff[ read ] ) );
+                    const uint8_t* src = A.reads + A.roff[ read ];
+                    const u32 ql = (u32)( A.roff[ read + 1 ] - A.roff[ read ] );
+                    if( A.q_lds )
+                    {
+                        u32 k = 0;
+                        for( ; k + 16 <= ql; k += 16 )
+                        {
+                            uint4 v;
+                            __builtin_memcpy( &v, src + k, 16 );
+                            u32* d = (u32*)( myq + k ); // 4-byte aligned (stride and k are multiples of 4)
+                            d[ 0 ] = v.x, d[ 1 ] = v.y, d[ 2 ] = v.z, d[ 3 ] = v.w;
+                        }
+                        for( ; k < ql; k++ )
+                            myq[ k ] = src[ k ];
+                        src = myq;
+                    }
+                    seed_begin_read( L, src, ql );
                 }
             }
         }
         if( __ballot( alive ) == 0 )
             break;
+#if defined( MA_KSW_PROF )
+        const unsigned long long tB = clock64( );
+#endif
         u32 c;
-        if( alive && L.phase != PH_DONE && seed_prepare( L, A.P, S, A.X, c ) )
+        const bool ext = alive && L.phase != PH_DONE && seed_prepare( L, A.P, S, A.X, c );
+#if defined( MA_KSW_PROF )
+        const unsigned long long tC = clock64( );
+        pf[ 4 ] += __popcll( __ballot( ext ) );
+#endif
+        if( ext )
         {
             i64 ok[ 3 ];
             u32 nb;
@@ -160,7 +203,20 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
             L.blocks += nb;
             seed_apply( L, A.P, S, ok );
         }
+#if defined( MA_KSW_PROF )
+        const unsigned long long tD = clock64( );
+        pf[ 0 ] += tB - tA;
+        pf[ 1 ] += tC - tB;
+        pf[ 2 ] += tD - tC;
+        pf[ 3 ] += 1;
+        pf[ 5 ] += dm ? 1 : 0;
+#endif
     }
+#if defined( MA_KSW_PROF )
+    if( wl == 0 )
+        for( int i = 0; i < 6; i++ )
+            atomicAdd( &g_seed_prof[ i ], pf[ i ] );
+#endif
     atomicAdd( &A.ctr[ CTR_STEPS ], (unsigned long long)steps );
     atomicAdd( &A.ctr[ CTR_BLOCKS ], (unsigned long long)blocks );
 }
@@ -921,7 +977,10 @@ int ma_seed_batch( ma_batch* b )
     A.ctr = b->ctr.as<unsigned long long>( );
     {
         EvTimer t( b, 0 );
-        hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), 0, b->stream, A );
+        // reads up to 240 bases are staged in LDS (256 lanes x q_lds bytes <= 64 KB)
+        const u32 qb = (u32)( ( b->max_qlen + 7 ) / 8 * 8 + 4 );
+        A.q_lds = qb * 256 <= 64 * 1024 ? qb : 0;
+        hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
     }
     MA_HIP( hipGetLastError( ) );
     b->stage_done = 1;
@@ -1530,6 +1589,11 @@ int ma_batch_get_dp_jobs( ma_batch* b, uint64_t* n_jobs, int32_t* shapes /* 8 x 
 int ma_debug_ksw_prof( unsigned long long* out )
 {
     MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_ksw_prof ), 16 * 8 ) );
+    return 0;
+}
+int ma_debug_seed_prof( unsigned long long* out )
+{
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( g_seed_prof ), 8 * 8 ) );
     return 0;
 }
 #endif

@@ -25,6 +25,7 @@ struct SeedScratch
     ma_segment* smem_a; // SMEM pending lists (capacity smem_cap each)
     ma_segment* smem_b;
     u32 smem_cap;
+    u32 drop_div; // SeedParams::min_seed_size_drop (seed_emit keeps the running sum seed_finish needs)
     u32* stack; // 2 * MA_SEED_STACK words: interval stack of procesInterval (kept out of SeedLane so that the lane
                 // state stays in registers; a dynamically indexed member would put the whole struct in scratch memory)
 };
@@ -64,6 +65,7 @@ struct SeedLane
     // output
     u32 nseg;
     u32 err;
+    u64 drop_sum; // sum over emitted segments of q_size / min_seed_size_drop (numSeedsLarger, segment.h:278-289)
     // counters
     u32 steps, blocks;
 };
@@ -84,6 +86,8 @@ MA_HD void seed_emit( SeedLane& L, const SeedScratch& S, u32 start, u32 size, i6
         s.sa_start_rc = b;
         s.sa_size = c;
         S.stage[ L.nseg ] = s;
+        if( S.drop_div )
+            L.drop_sum += (u64)size / (u64)S.drop_div;
     }
     else
         L.err |= MA_ERR_SEG_OVERFLOW;
@@ -98,6 +102,7 @@ MA_HD void seed_begin_read( SeedLane& L, const uint8_t* q, u32 qlen )
     L.aS = 0;
     L.aN = qlen;
     L.nseg = 0;
+    L.drop_sum = 0;
     L.err = 0;
     L.steps = L.blocks = 0;
     L.phase = qlen == 0 ? PH_DONE : PH_NEW_CENTER;
@@ -429,9 +434,7 @@ MA_HD u32 seed_finish( const SeedLane& L, const SeedParams& P, const SeedScratch
     u32 n = L.nseg < S.seg_cap ? L.nseg : S.seg_cap;
     if( !P.disable_heuristics && P.min_seed_size_drop != 0 )
     {
-        u64 sum = 0;
-        for( u32 k = 0; k < n; k++ )
-            sum += (u64)S.stage[ k ].q_size / (u64)P.min_seed_size_drop;
+        const u64 sum = L.drop_sum; // == sum of stage[k].q_size / min_seed_size_drop over the n kept segments
         if( (double)sum < P.rel_min_seed_size_amount * (double)L.qlen && P.genome_size_disable < X.n )
             n = 0;
     }

@@ -232,7 +232,7 @@ int main( int argc, char** argv )
         const u32 seg_cap = 6 * qlen + 8;
         std::vector<ma_segment> stage( seg_cap ), sa( qlen + 2 ), sb( qlen + 2 );
         std::vector<u32> seedStack( 2 * MA_SEED_STACK );
-        SeedScratch SS{ stage.data( ), seg_cap, sa.data( ), sb.data( ), qlen + 2, seedStack.data( ) };
+        SeedScratch SS{ stage.data( ), seg_cap, sa.data( ), sb.data( ), qlen + 2, SP.min_seed_size_drop, seedStack.data( ) };
         SeedLane L;
         seed_begin_read( L, q.data( ), qlen );
         seed_read_serial( L, SP, SS, X );

@@ -17,6 +17,12 @@ finally:
              "glob:loop", "glob:backtrace", "glob:cells", "glob:jobs"]
     for n, x in zip(names, v):
         print("%-16s %d" % (n, x))
+    sp = (C.c_ulonglong * 8)()
+    ma_amd.lib().ma_debug_seed_prof(sp)
+    sp = list(sp)
+    print("k_seed: refill cycles %d, prepare %d, extend+apply %d, wave trips %d, active lanes/trip %.1f, refill trips %d" % (
+        sp[0], sp[1], sp[2], sp[3], sp[4] / max(sp[3], 1), sp[5]))
+    print("k_seed per trip: refill %.0f prepare %.0f extend %.0f" % (sp[0] / max(sp[3], 1), sp[1] / max(sp[3], 1), sp[2] / max(sp[3], 1)))
     j = max(v[3], 1)
     print("per job cycles: fetch %.0f core %.0f publish %.0f" % (v[0] / j, v[1] / j, v[2] / j))
     if v[7]:
