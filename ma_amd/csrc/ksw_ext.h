@@ -329,9 +329,19 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         const u32 st0pk = pk_bcast( st0 ), wpk = pk_bcast( en0 - st0 + 1 );
         uint8_t* prow = P + (size_t)r * RING;
         u32 Hm[ R ], DD[ R ], LMs[ R ];
+        const int sLo = ( st0 & ( RING - 1 ) ) >> 7, sHi = ( en0 & ( RING - 1 ) ) >> 7;
+        const bool allSlots = en0 - st0 >= 128;
 #pragma unroll
         for( int s = 0; s < R; s++ )
         {
+            if( R > 1 && !allSlots && s != sLo && s != sHi )
+            {
+                // no live cell in this slot: nothing to update (its registers are only read by the other slot)
+                Hm[ s ] = K_NEG;
+                DD[ s ] = 0xffffffffu;
+                LMs[ s ] = 0;
+                continue;
+            }
             // ---- live cells of this slot: st0 <= t <= en0
             const u32 dd = pk_sub( TTpk[ s ], st0pk ); // t - st0 (mod 2^16)
             const u32 lm1 = pk_minu( pk_subsatu( wpk, dd ), 0x00010001u ); // 1 where live
@@ -412,9 +422,17 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
 #pragma unroll
         for( int s = 1; s < R; s++ )
             hm = pk_max( hm, Hm[ s ] );
-        const i32 max_H = wave_max_i32( max( (i32)( hm << 16 ) >> 16, (i32)hm >> 16 ) );
-        const bool newMax = max_H > (i32)ez.max;
-        if( newMax || ( J.zdrop >= 0 && (i32)ez.max - max_H > J.zdrop ) )
+        // cheap wave-uniform tests instead of a full reduction: does any cell exceed ez.max, and (z-drop candidate)
+        // are all cells below ez.max - zdrop?  Only then the exact (max_H, max_t) of the diagonal is needed.
+        const u32 ezpk = pk_bcast( (i32)ez.max );
+        const bool newMax = __any( pk_max( hm, ezpk ) != ezpk ) != 0;
+        bool need = newMax;
+        if( !need && J.zdrop >= 0 && (i32)ez.max - J.zdrop - 1 >= -32768 )
+        {
+            const u32 tpk = pk_bcast( (i32)ez.max - J.zdrop - 1 );
+            need = __any( pk_max( hm, tpk ) != tpk ) == 0;
+        }
+        if( need )
         {
             // ---- the reference's max_t (kswcpp_core.h:156-299): 8 classes (t - st0) mod 8 over the chunks
             // [st0, en1), each class keeps its first maximum and the chunk base it came from, the initial
@@ -499,7 +517,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             }
         }
         // ---- early stop (ksw_reg.h): no later cell can exceed ez.max
-        if( !newMax && !stop && r >= qlen - 1 )
+        if( !newMax && !stop && r >= qlen - 1 && ( r & 2 ) ) // on two of every four diagonals
         {
             const u32 qo = pk_bcast( qlen - 1 - r );
             u32 bm = K_NEG;
