@@ -61,11 +61,23 @@ MA_HD void occ4_in_block( const Block64& b, u32 within, u64 cnt[ 4 ] )
     cnt[ 3 ] = b.c[ 3 ] + t;
 }
 
+// x.L2[i] as a register value.  IndexView is a kernel argument; without the (empty) asm the compiler turns a
+// select between L2 entries into ONE vector load from a selected kernarg address, i.e. a memory round trip that
+// depends on the base just read -- on the critical path of every FM step.
+MA_HD u64 l2v( const IndexView& x, int i )
+{
+    u64 v = x.L2[ i ];
+#if defined( __HIP_DEVICE_COMPILE__ )
+    asm( "" : "+s"( v ) );
+#endif
+    return v;
+}
+
 MA_HD void init_interval( const IndexView& x, u32 c, i64 ik[ 3 ] ) // fMIndex.h:768-775
 {
-    const u64 lo = c == 0 ? x.L2[ 0 ] : ( c == 1 ? x.L2[ 1 ] : ( c == 2 ? x.L2[ 2 ] : x.L2[ 3 ] ) );
-    const u64 hi = c == 0 ? x.L2[ 1 ] : ( c == 1 ? x.L2[ 2 ] : ( c == 2 ? x.L2[ 3 ] : x.L2[ 4 ] ) );
-    const u64 rc = c == 0 ? x.L2[ 3 ] : ( c == 1 ? x.L2[ 2 ] : ( c == 2 ? x.L2[ 1 ] : x.L2[ 0 ] ) );
+    const u64 lo = c == 0 ? l2v( x, 0 ) : ( c == 1 ? l2v( x, 1 ) : ( c == 2 ? l2v( x, 2 ) : l2v( x, 3 ) ) );
+    const u64 hi = c == 0 ? l2v( x, 1 ) : ( c == 1 ? l2v( x, 2 ) : ( c == 2 ? l2v( x, 3 ) : l2v( x, 4 ) ) );
+    const u64 rc = c == 0 ? l2v( x, 3 ) : ( c == 1 ? l2v( x, 2 ) : ( c == 2 ? l2v( x, 1 ) : l2v( x, 0 ) ) );
     ik[ 0 ] = (i64)lo + 1;
     ik[ 1 ] = (i64)rc + 1;
     ik[ 2 ] = (i64)( hi - lo );
@@ -114,7 +126,7 @@ MA_HD void extend_backward( const IndexView& x, const i64 ik[ 3 ], u32 c, i64 ok
         c2++;
     // cntk_2[i] = cntk_2[i-1] + cnts[3-(i-1)]; result uses cntk_2[3-c]
     const u64 a0 = c2, a1 = a0 + s3, a2 = a1 + s2, a3 = a2 + s1;
-    const u64 l2c = c == 0 ? x.L2[ 0 ] : ( c == 1 ? x.L2[ 1 ] : ( c == 2 ? x.L2[ 2 ] : x.L2[ 3 ] ) );
+    const u64 l2c = c == 0 ? l2v( x, 0 ) : ( c == 1 ? l2v( x, 1 ) : ( c == 2 ? l2v( x, 2 ) : l2v( x, 3 ) ) );
     const u64 ckc = c == 0 ? cntk[ 0 ] : ( c == 1 ? cntk[ 1 ] : ( c == 2 ? cntk[ 2 ] : cntk[ 3 ] ) );
     ok[ 0 ] = (i64)( l2c + ckc + 1 );
     ok[ 1 ] = (i64)( c == 0 ? a3 : ( c == 1 ? a2 : ( c == 2 ? a1 : a0 ) ) );
@@ -135,7 +147,7 @@ MA_HD i64 inv_psi( const IndexView& x, i64 k )
     // equals xx for k != primary
     u64 cnt[ 4 ];
     occ4_in_block( b, within, cnt );
-    const u64 l2c = c == 0 ? x.L2[ 0 ] : ( c == 1 ? x.L2[ 1 ] : ( c == 2 ? x.L2[ 2 ] : x.L2[ 3 ] ) );
+    const u64 l2c = c == 0 ? l2v( x, 0 ) : ( c == 1 ? l2v( x, 1 ) : ( c == 2 ? l2v( x, 2 ) : l2v( x, 3 ) ) );
     const u64 cc = c == 0 ? cnt[ 0 ] : ( c == 1 ? cnt[ 1 ] : ( c == 2 ? cnt[ 2 ] : cnt[ 3 ] ) );
     return (i64)( l2c + cc );
 }

@@ -42,6 +42,7 @@ enum : int
     CTR_NEXT_SLOTS = 28, // 12 x u32 job queues of the ksw launches (6 words)
     CTR_N_REDO = 34, // u32: jobs the extension kernel handed back
     CTR_CIG_WORDS = 35, // cigar words written (CTR_CIG_USED counts pool words reserved)
+    CTR_NEXT_SEED = 36, // queue of k_lf_walk
     CTR_COUNT = 40
 };
 
@@ -250,29 +251,98 @@ __global__ void k_read_seed_ranges( const u64* seg_off, const u32* seg_cnt, cons
     seed_cnt[ r ] = (u32)( se - sb );
 }
 
-// one lane per seed: SA row -> reference position (Segment::forEachSeed segment.h:89-113, setDeltaOfSeed
-// stripOfConsideration.h:97-112 in rectangular mode)
-__global__ void k_extract( IndexView X, const ma_segment* pool, const u32* pool_read, const u64* seg_seed_off,
-                           u64 n_pool, u64 total_seeds, const u64* roff, ma_seed* seeds, unsigned long long* ctr )
+// ---- seed extraction (Segment::forEachSeed segment.h:89-113, setDeltaOfSeed stripOfConsideration.h:97-112 in
+// rectangular mode) in three passes:
+//  k_seed_rows   one lane per pooled segment: SA row and segment index of each of its seeds
+//  k_lf_walk     persistent lanes, ONE LF step (one random 64-B block) per lane and trip, a finished lane takes
+//                the next seed from a wave-aggregated queue: no divergence over the (unbounded, mean 16) steps a
+//                row needs until it hits a sampled row
+//  k_seed_final  one lane per seed: sampled SA value, strand, contig, delta
+__global__ void k_seed_rows( const ma_segment* pool, const u64* seg_seed_off, u64 n_pool, i64* row, u32* seg_of )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n_pool )
+        return;
+    const u64 o = seg_seed_off[ i ], cnt = seg_seed_off[ i + 1 ] - o;
+    if( cnt == 0 )
+        return;
+    const i64 r0 = pool[ i ].sa_start;
+    for( u64 t = 0; t < cnt; t++ )
+    {
+        row[ o + t ] = r0 + (i64)t;
+        seg_of[ o + t ] = (u32)i;
+    }
+}
+
+__global__ void __launch_bounds__( 256 ) k_lf_walk( IndexView X, i64* row /* in: SA row, out: sampled row reached */,
+                                                   u32* nsteps, u64 total, unsigned long long* next )
+{
+    const u32 wl = threadIdx.x & 63;
+    bool alive = true, have = false;
+    i64 k = 0;
+    u64 j = 0;
+    u32 st = 0;
+    u64 qCur = 0, qEnd = 0; // this wave's slice of the seed queue: one device atomic per 256 seeds
+    while( true )
+    {
+        if( have && ( k & 31 ) == 0 )
+        {
+            row[ j ] = k;
+            nsteps[ j ] = st; // not bounded by the sampling interval: the walk ends when it HITS a sampled row
+            have = false;
+        }
+        const bool need = alive && !have;
+        const unsigned long long dm = __ballot( need ), am = __ballot( alive );
+        if( dm && ( __popcll( dm ) >= 8 || dm == am ) )
+        {
+            if( qCur == qEnd )
+            {
+                unsigned long long base = 0;
+                if( wl == 0 )
+                    base = atomicAdd( next, 256ull );
+                base = ( (u64)(u32)__shfl( (int)( base >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)base, 0, 64 );
+                qCur = base < total ? base : total;
+                qEnd = base + 256 < total ? base + 256 : total;
+            }
+            const u64 avail = qEnd - qCur;
+            const u64 rank = (u64)__popcll( dm & ( ( 1ull << wl ) - 1 ) );
+            if( need )
+            {
+                if( rank < avail )
+                {
+                    j = qCur + rank;
+                    k = row[ j ];
+                    st = 0;
+                    have = true;
+                }
+                else if( qEnd == total )
+                    alive = false; // the queue is exhausted
+            }
+            const u64 want = (u64)__popcll( dm );
+            qCur += want < avail ? want : avail;
+        }
+        if( __ballot( alive ) == 0 )
+            break;
+        if( have && ( k & 31 ) )
+        {
+            k = inv_psi( X, k );
+            st++;
+        }
+    }
+}
+
+__global__ void k_seed_final( IndexView X, const ma_segment* pool, const u32* pool_read, const u64* seg_seed_off,
+                              const i64* row, const u32* nsteps, const u32* seg_of, u64 total_seeds, const u64* roff,
+                              ma_seed* seeds, unsigned long long* ctr )
 {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u32 steps = 0;
     if( j < total_seeds )
     {
-        // last segment i with seg_seed_off[i] <= j (segments with zero seeds share offsets -> upper bound - 1)
-        u64 lo = 0, hi = n_pool;
-        while( lo < hi )
-        {
-            const u64 mid = ( lo + hi ) / 2;
-            if( seg_seed_off[ mid ] <= j )
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        const u64 i = lo - 1;
+        const u64 i = seg_of[ j ];
         const ma_segment s = pool[ i ];
-        const i64 row = s.sa_start + (i64)( j - seg_seed_off[ i ] );
-        u64 r = (u64)bwt_sa( X, row, steps );
+        steps = nsteps[ j ];
+        u64 r = (u64)( (i64)steps + X.sa[ row[ j ] >> 5 ] ); // bwt_sa (fMIndex.h:788-814)
         const bool fwd = r < X.n / 2;
         if( !fwd )
             r = X.n - r - 1;
@@ -725,7 +795,7 @@ struct ma_batch
     bool reads_external = false;
     const uint8_t* d_reads = nullptr;
     const u64* d_roff = nullptr;
-    DevBuf reads, roff, ctr, seedStack;
+    DevBuf reads, roff, ctr, seedStack, seedRow, seedSteps, seedSeg;
     // seeding
     DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt;
     u64 segPoolCap = 0;
@@ -1024,9 +1094,21 @@ int ma_extract_seeds_batch( ma_batch* b )
                         b->segOff.as<u64>( ), b->segCnt.as<u32>( ), b->segSeedOff.as<u64>( ), ns, total, (u32)n,
                         b->seedOff.as<u64>( ), b->seedCnt.as<u32>( ) );
     if( total )
-        hipLaunchKernelGGL( k_extract, dim3( (unsigned)( ( total + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->idx->v,
-                            b->segPool.as<ma_segment>( ), b->segRead.as<u32>( ), b->segSeedOff.as<u64>( ), ns, total,
-                            b->d_roff, b->seeds.as<ma_seed>( ), b->ctr.as<unsigned long long>( ) );
+    {
+        if( b->seedRow.reserve( ( total + 1 ) * 8 ) || b->seedSteps.reserve( ( total + 4 ) * 4 ) || b->seedSeg.reserve( ( total + 1 ) * 4 ) )
+            return 1;
+        unsigned long long* c = b->ctr.as<unsigned long long>( );
+        hipLaunchKernelGGL( k_seed_rows, dim3( (unsigned)( ( ns + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream,
+                            b->segPool.as<ma_segment>( ), b->segSeedOff.as<u64>( ), ns, b->seedRow.as<i64>( ),
+                            b->seedSeg.as<u32>( ) );
+        const u64 lanes = std::min<u64>( 256ull * 2048, ( total + 255 ) / 256 * 256 );
+        hipLaunchKernelGGL( k_lf_walk, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), 0, b->stream, b->idx->v,
+                            b->seedRow.as<i64>( ), b->seedSteps.as<u32>( ), total, c + CTR_NEXT_SEED );
+        hipLaunchKernelGGL( k_seed_final, dim3( (unsigned)( ( total + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->idx->v,
+                            b->segPool.as<ma_segment>( ), b->segRead.as<u32>( ), b->segSeedOff.as<u64>( ),
+                            b->seedRow.as<i64>( ), b->seedSteps.as<u32>( ), b->seedSeg.as<u32>( ), total, b->d_roff,
+                            b->seeds.as<ma_seed>( ), c );
+    }
     MA_HIP( hipGetLastError( ) );
     b->stage_done = 2;
     return 0;

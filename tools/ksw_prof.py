@@ -23,6 +23,7 @@ finally:
     print("k_seed: refill cycles %d, prepare %d, extend+apply %d, wave trips %d, active lanes/trip %.1f, refill trips %d" % (
         sp[0], sp[1], sp[2], sp[3], sp[4] / max(sp[3], 1), sp[5]))
     print("k_seed per trip: refill %.0f prepare %.0f extend %.0f" % (sp[0] / max(sp[3], 1), sp[1] / max(sp[3], 1), sp[2] / max(sp[3], 1)))
+    print("k_extract: wave cycles in segment search %d, in bwt_sa %d" % (sp[6], sp[7]))
     j = max(v[3], 1)
     print("per job cycles: fetch %.0f core %.0f publish %.0f" % (v[0] / j, v[1] / j, v[2] / j))
     if v[7]:
