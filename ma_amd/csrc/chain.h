@@ -603,7 +603,13 @@ struct ChainOut
     unsigned long long* pool_used; // atomic bump pointer
     HSet* sets; // this read's table (capacity set_cap)
     u32 set_cap;
+    // optional private region of this read: sets go there first (HSet::off = MA_HSET_LOCAL | offset in the region) and
+    // the shared pool only takes what does not fit, so the common case needs no device-wide atomic; a later pass
+    // compacts everything into a dense pool in read order (k_hset_flatten)
+    ma_seed* local = nullptr;
+    u32 local_cap = 0;
 };
+#define MA_HSET_LOCAL ( 1ull << 63 )
 
 #if defined( __HIP_DEVICE_COMPILE__ )
 MA_HD u64 bump_alloc( unsigned long long* ctr, u64 n )
@@ -630,17 +636,29 @@ MA_HD u32 chain_read( const IndexView& X, const ChainParams& P, const ChainScrat
     u64 lastHarm = 0, bestSoC = 0;
     const bool heur = !P.disable_heuristics;
     const u64 switchQ = (u64)P.switch_qlen;
+    u32 localUsed = 0;
     auto emit = [ & ]( ma_seed* S, u32 n, u32 soc ) {
         u32 b, m;
         apply_filters( P, S, n, b, m );
         if( nsets < O.set_cap )
         {
-            const u64 off = bump_alloc( O.pool_used, m );
-            if( off + m <= O.pool_cap )
+            u64 off;
+            if( O.local && localUsed + m <= O.local_cap )
+            {
+                off = MA_HSET_LOCAL | (u64)localUsed;
                 for( u32 i = 0; i < m; i++ )
-                    O.pool[ off + i ] = S[ b + i ];
+                    O.local[ localUsed + i ] = S[ b + i ];
+                localUsed += m;
+            }
             else
-                err |= MA_ERR_SEED_OVERFLOW;
+            {
+                off = bump_alloc( O.pool_used, m );
+                if( off + m <= O.pool_cap )
+                    for( u32 i = 0; i < m; i++ )
+                        O.pool[ off + i ] = S[ b + i ];
+                else
+                    err |= MA_ERR_SEED_OVERFLOW;
+            }
             O.sets[ nsets ].off = off;
             O.sets[ nsets ].cnt = m;
             O.sets[ nsets ].soc = soc;

@@ -391,8 +391,9 @@ struct ChainKernelArgs
     i32* inl;
     i32* best;
     // output
-    ma_seed* hpool;
+    ma_seed* hpool; // shared overflow pool (atomic bump pointer CTR_HSEED_USED)
     u64 hpool_cap;
+    ma_seed* hlocal; // private regions: read r owns [3 * seed_off[r], + 3 * seed_cnt[r])
     HSet* sets; // n_reads * set_cap
     u32 set_cap;
     u32* nsets; // per read
@@ -428,6 +429,8 @@ __global__ void __launch_bounds__( 64 ) k_chain( ChainKernelArgs A )
     O.pool_used = &A.ctr[ CTR_HSEED_USED ];
     O.sets = A.sets + (u64)r * A.set_cap;
     O.set_cap = A.set_cap;
+    O.local = A.hlocal + 3 * off; // seed ranges of different reads are disjoint (but not ordered by read)
+    O.local_cap = 3 * n;
     u32 err = 0;
     const u32 qlen = (u32)( A.roff[ r + 1 ] - A.roff[ r ] );
     const u32 ns = chain_read( A.X, A.P, C, n, qlen, O, err );
@@ -436,17 +439,39 @@ __global__ void __launch_bounds__( 64 ) k_chain( ChainKernelArgs A )
         atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
 }
 
-// flatten the per-read set tables into CSR order (hset_off from an exclusive scan of nsets)
+// harmonized seeds of a read (sum of its sets' sizes), input of the scan that lays out the dense pool
+__global__ void k_hseed_counts( const HSet* sets, u32 set_cap, const u32* nsets, u32 n_reads, u64* cnt )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    u64 c = 0;
+    for( u32 k = 0; k < nsets[ r ]; k++ )
+        c += sets[ (u64)r * set_cap + k ].cnt;
+    cnt[ r ] = c;
+}
+
+// flatten the per-read set tables into CSR order (hset_off from an exclusive scan of nsets) and compact the seeds of
+// the sets (private regions / overflow pool) into one dense pool in read order (hseed_off from a scan of the counts)
 __global__ void k_hset_flatten( const HSet* sets, u32 set_cap, const u32* nsets, const u64* hset_off, u32 n_reads,
-                                HSet* flat, u32* flat_read )
+                                const u64* hseed_off, const u64* seed_off, const ma_seed* hlocal, const ma_seed* hovf,
+                                ma_seed* dense, HSet* flat, u32* flat_read )
 {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if( r >= n_reads )
         return;
     const u64 o = hset_off[ r ];
+    u64 d = hseed_off[ r ];
+    const ma_seed* mine = hlocal + 3 * seed_off[ r ];
     for( u32 k = 0; k < nsets[ r ]; k++ )
     {
-        flat[ o + k ] = sets[ (u64)r * set_cap + k ];
+        HSet h = sets[ (u64)r * set_cap + k ];
+        const ma_seed* src = ( h.off & MA_HSET_LOCAL ) ? mine + ( h.off & ~MA_HSET_LOCAL ) : hovf + h.off;
+        for( u32 i = 0; i < h.cnt; i++ )
+            dense[ d + i ] = src[ i ];
+        h.off = d;
+        d += h.cnt;
+        flat[ o + k ] = h;
         flat_read[ o + k ] = r;
     }
 }
@@ -795,7 +820,7 @@ struct ma_batch
     bool reads_external = false;
     const uint8_t* d_reads = nullptr;
     const u64* d_roff = nullptr;
-    DevBuf reads, roff, ctr, seedStack, seedRow, seedSteps, seedSeg;
+    DevBuf reads, roff, ctr, seedStack, seedRow, seedSteps, seedSeg, hlocal, hdense, hseedCnt, hseedOff;
     // seeding
     DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt;
     u64 segPoolCap = 0;
@@ -903,7 +928,9 @@ int ma_batch_destroy( ma_batch* b )
                       &b->cOut,    &b->cSh1,    &b->cSh2,     &b->cVx,     &b->cVy,    &b->cMed,       &b->cInl,
                       &b->cBest,   &b->hpool,   &b->setTab,   &b->nsets,   &b->hsetOff, &b->hsetFlat,  &b->hsetRead,
                       &b->jobs,    &b->info,    &b->ez,       &b->cigOff,  &b->cigPool, &b->kswScratch, &b->opsCap,
-                      &b->opsOff,  &b->ops,     &b->hdr,      &b->order,   &b->mqOrder, &b->mqCnt };
+                      &b->opsOff,  &b->ops,     &b->hdr,      &b->order,   &b->mqOrder, &b->mqCnt,     &b->clsLists,
+                      &b->seedStack, &b->seedRow, &b->seedSteps, &b->seedSeg, &b->hlocal, &b->hdense,  &b->hseedCnt,
+                      &b->hseedOff };
     for( DevBuf* d : all )
         d->release( );
     if( b->evInit )
@@ -1160,7 +1187,9 @@ int ma_chain_batch( ma_batch* b )
         b->cSh1.reserve( ts * sizeof( Shadow ) ) || b->cSh2.reserve( ts * sizeof( Shadow ) ) ||
         b->cVx.reserve( 3 * ts * 8 ) || b->cVy.reserve( 3 * ts * 8 ) || b->cMed.reserve( 6 * ts * 8 ) ||
         b->cInl.reserve( 3 * ts * 4 ) || b->cBest.reserve( 3 * ts * 4 ) ||
-        b->hpool.reserve( b->hpoolCap * sizeof( ma_seed ) ) || b->setTab.reserve( n * set_cap * sizeof( HSet ) ) ||
+        b->hpool.reserve( b->hpoolCap * sizeof( ma_seed ) ) || b->hlocal.reserve( ( 3 * ts + 16 ) * sizeof( ma_seed ) ) ||
+        b->hseedCnt.reserve( ( n + 2 ) * 8 ) || b->hseedOff.reserve( ( n + 2 ) * 8 ) ||
+        b->setTab.reserve( n * set_cap * sizeof( HSet ) ) ||
         b->nsets.reserve( ( n + 1 ) * 4 ) || b->hsetOff.reserve( ( n + 2 ) * 8 ) )
         return 1;
     ChainKernelArgs A;
@@ -1203,6 +1232,7 @@ int ma_chain_batch( ma_batch* b )
     A.best = b->cBest.as<i32>( );
     A.hpool = b->hpool.as<ma_seed>( );
     A.hpool_cap = b->hpoolCap;
+    A.hlocal = b->hlocal.as<ma_seed>( );
     A.sets = b->setTab.as<HSet>( );
     A.set_cap = set_cap;
     A.nsets = b->nsets.as<u32>( );
@@ -1224,17 +1254,25 @@ int ma_chain_batch( ma_batch* b )
         MA_HIP( hipcub::DeviceScan::ExclusiveSum( b->cubTmp.p, tb, in, b->hsetOff.as<u64>( ), (int)( n + 1 ),
                                                   b->stream ) );
     }
-    u64 nh = 0;
+    hipLaunchKernelGGL( k_hseed_counts, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream,
+                        b->setTab.as<HSet>( ), set_cap, b->nsets.as<u32>( ), (u32)n, b->hseedCnt.as<u64>( ) );
+    MA_HIP( hipMemsetAsync( (char*)b->hseedCnt.p + n * 8, 0, 8, b->stream ) );
+    if( scan_exclusive<u64>( b, b->hseedCnt.as<u64>( ), b->hseedOff.as<u64>( ), n + 1 ) )
+        return 1;
+    u64 nh = 0, nhs = 0;
     MA_HIP( hipMemcpyAsync( &nh, (char*)b->hsetOff.p + n * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
+    MA_HIP( hipMemcpyAsync( &nhs, (char*)b->hseedOff.p + n * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
     if( read_ctr( b ) || check_err( b, "ma_chain_batch" ) )
         return 1;
     b->nHsets = nh;
-    b->nHseeds = b->hctr[ CTR_HSEED_USED ];
-    if( b->hsetFlat.reserve( ( nh + 1 ) * sizeof( HSet ) ) || b->hsetRead.reserve( ( nh + 1 ) * 4 ) )
+    b->nHseeds = nhs;
+    if( b->hsetFlat.reserve( ( nh + 1 ) * sizeof( HSet ) ) || b->hsetRead.reserve( ( nh + 1 ) * 4 ) ||
+        b->hdense.reserve( ( nhs + 1 ) * sizeof( ma_seed ) ) )
         return 1;
     hipLaunchKernelGGL( k_hset_flatten, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream,
                         b->setTab.as<HSet>( ), set_cap, b->nsets.as<u32>( ), b->hsetOff.as<u64>( ), (u32)n,
-                        b->hsetFlat.as<HSet>( ), b->hsetRead.as<u32>( ) );
+                        b->hseedOff.as<u64>( ), b->seedOff.as<u64>( ), b->hlocal.as<ma_seed>( ), b->hpool.as<ma_seed>( ),
+                        b->hdense.as<ma_seed>( ), b->hsetFlat.as<HSet>( ), b->hsetRead.as<u32>( ) );
     MA_HIP( hipGetLastError( ) );
     b->stage_done = 3;
     return 0;
@@ -1290,7 +1328,7 @@ int ma_dp_batch( ma_batch* b )
     D.n_sets = (u32)nh;
     D.sets = b->hsetFlat.as<HSet>( );
     D.set_read = b->hsetRead.as<u32>( );
-    D.hpool = b->hpool.as<ma_seed>( );
+    D.hpool = b->hdense.as<ma_seed>( );
     D.reads = b->d_reads;
     D.roff = b->d_roff;
     D.jobs = b->jobs.as<DpJob>( );
@@ -1366,7 +1404,7 @@ int ma_dp_batch( ma_batch* b )
         T.sets = b->hsetFlat.as<HSet>( );
         T.set_read = b->hsetRead.as<u32>( );
         T.info = b->info.as<SetInfo>( );
-        T.hpool = b->hpool.as<ma_seed>( );
+        T.hpool = b->hdense.as<ma_seed>( );
         T.reads = b->d_reads;
         T.roff = b->d_roff;
         T.ez = b->ez.as<ma_ez>( );
@@ -1540,7 +1578,7 @@ int ma_batch_get_hsets( ma_batch* b, uint64_t* hset_off, uint64_t* hseed_off, ui
     if( nh )
         MA_HIP( hipMemcpy( flat.data( ), b->hsetFlat.p, nh * sizeof( HSet ), hipMemcpyDeviceToHost ) );
     if( b->nHseeds )
-        MA_HIP( hipMemcpy( pool.data( ), b->hpool.p, b->nHseeds * sizeof( ma_seed ), hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( pool.data( ), b->hdense.p, b->nHseeds * sizeof( ma_seed ), hipMemcpyDeviceToHost ) );
     u64 o = 0;
     for( u64 s = 0; s < nh; s++ )
     {
