@@ -27,6 +27,7 @@ GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1593
           133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616,
           64444167, 46709983, 50818468, 156040895, 57227415]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+GATHER_CEILING_GBLOCKS = 51.8  # measured on MI355X by tools/gups.hip: random 64-B blocks/s, all CUs (profiles/r01_gups.txt)
 
 
 def main():
@@ -130,7 +131,7 @@ def main():
     dt, (aligned_all,) = reduce_timing_and_counts(dist, dev, dt, [aligned])
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the K launches) --
-    names = ["k_seed", "k_extract", "k_chain", "k_dp_enum", "k_ksw", "k_stitch+k_finish"]
+    names = ["k_seed", "k_seed_rows+k_lf_walk+k_seed_final", "k_chain", "k_dp_enum", "k_ksw", "k_stitch+k_finish"]
     total_bases = float(offs_h[n_reads] - offs_h[0])
     alg = [64.0 * ctr[1] + total_bases + 40.0 * segs,  # seeding: occ blocks + read bases + segments out
            64.0 * ctr[2] + 8.0 * ctr[3] + 48.0 * ctr[3],  # SA lookup: LF blocks + SA sample + seed out
@@ -140,12 +141,23 @@ def main():
     dom = int(np.argmax(kms[:6]))
     avg_s = kms[dom] / 1e3 / max(K, 1)
     ach = (alg[dom] / max(K, 1)) / avg_s / 1e9 if avg_s > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
+    # DESIGN.md 3.4); only meaningful for the workload those passes were taken on
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pt = json.load(f)
+        if pt.get("workload_key") == [args.read_len, B, args.preset, args.genome_scale]:
+            traffic = pt["bytes_per_launch"].get(names[dom])
+    except (OSError, ValueError, KeyError):
+        traffic = None
     roofline = {"kernel": names[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "avg_launch_ms": round(kms[dom] / max(K, 1), 3),
                 "algorithmic_bytes_per_launch": int(alg[dom] / max(K, 1)),
                 "kernel_ms_per_step": {names[i]: round(kms[i] / max(K, 1), 3) for i in range(6)},
                 "seeding_GBps": round((alg[0] / max(K, 1)) / (kms[0] / 1e3 / max(K, 1)) / 1e9, 2) if kms[0] > 0 else 0.0,
+                "seeding_frac_of_gather_ceiling": round(ctr[1] / (kms[0] / 1e3) / 1e9 / GATHER_CEILING_GBLOCKS, 4) if kms[0] > 0 else 0.0,
                 "dp_GCUPS": round(ctr[4] / (kms[4] / 1e3) / 1e9, 3) if kms[4] > 0 else 0.0}
 
     # ---- CPU baseline: the oracle (bit-exact restatement of the reference) on this host's cores -----------
@@ -164,7 +176,10 @@ def main():
         res = oidx.align(reads, op, threads=ncores)
         tc = time.perf_counter() - t1
         cpu = {"value": round(res["n_aligned"] / tc, 1), "unit": "aligned reads/s", "cores": ncores, "kind": "port",
-               "sample": "first %d reads of the same workload, oracle with %d threads, %.1f s" % (S, ncores, tc)}
+               "sample": "first %d reads of the same workload, oracle with %d threads, %.1f s" % (S, ncores, tc),
+               # the reference computes every diagonal of an extension; the GPU path stops once ez.max is final
+               "dp_band_cells_per_read": round(float(res["counters"][4]) / S, 1)}
+        roofline["dp_band_cells_per_read_executed"] = round(ctr[4] / max(n_reads, 1), 1)
 
     if rank == 0:
         out = {

@@ -405,7 +405,8 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             V[ s ] = nv;
             X[ s ] = nx;
             X2[ s ] = nx2;
-            *(uint16_t*)( prow + 128 * s + 2 * lane ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
+            if( LM ) // only lanes with a live cell write their two direction bytes (keeps HBM traffic at the live band)
+                *(uint16_t*)( prow + 128 * s + 2 * lane ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
             // ---- H(t, r) = H(t-1, r-1) + u(t, r)
             if( !GLOBAL )
             {

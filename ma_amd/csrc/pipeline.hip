@@ -400,7 +400,7 @@ struct ChainKernelArgs
     unsigned long long* ctr;
 };
 
-__global__ void __launch_bounds__( 64 ) k_chain( ChainKernelArgs A )
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4, 4 ) ) ) k_chain( ChainKernelArgs A )
 {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if( r >= A.n_reads )
