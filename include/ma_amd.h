@@ -129,6 +129,14 @@ int ma_ksw_batch( const ma_params*, const ma_ksw_job* jobs, uint64_t n, const ui
                   const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off, uint32_t* cigar,
                   uint64_t cigar_cap );
 
+/* Same call with the semantics the pipeline uses for its extension / small-gap DP (NeedlemanWunsch::dynPrg,
+ * ksw_dual_ext, ksw; needlemanWunsch.cpp:82-622 read only these): ez.max, ez.max_q, ez.max_t, n_cigar and the
+ * cigar are those of kswcpp_dispatch, the other ez fields are unspecified.  Runs the packed extension kernel with
+ * the exact early stop where a job qualifies (ma_amd/csrc/ksw_ext.h) and the exact kernels otherwise. */
+int ma_ksw_ext_batch( const ma_params*, const ma_ksw_job* jobs, uint64_t n, const uint8_t* q_bytes, uint64_t q_len,
+                      const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off, uint32_t* cigar,
+                      uint64_t cigar_cap );
+
 /* ---- batch pipeline: BinarySeeding -> StripOfConsideration -> Harmonization -> NeedlemanWunsch -> MappingQuality
  *      as wired in libMA::setUpCompGraph (libs/ma/src/util/export.cpp:104-108) ---- */
 int ma_batch_create( const ma_index*, const ma_params*, uint64_t max_reads, uint64_t max_bases, ma_batch** out );

@@ -170,8 +170,9 @@ class Index:
             self.h = None
 
 
-def ksw_batch(params, cases, cigar_cap=None):
-    """cases: list of (q, t, w, zdrop, flag) -> (ez structured array, list of cigar arrays)"""
+def ksw_batch(params, cases, cigar_cap=None, pipeline_semantics=False):
+    """cases: list of (q, t, w, zdrop, flag) -> (ez structured array, list of cigar arrays).
+    pipeline_semantics: ma_ksw_ext_batch (only max, max_q, max_t, cigar defined)."""
     n = len(cases)
     jobs = np.zeros(n, dtype=KSW_JOB_DT)
     qs, ts = [], []
@@ -189,8 +190,9 @@ def ksw_batch(params, cases, cigar_cap=None):
     ez = np.zeros(n, dtype=EZ_DT)
     off = np.zeros(n + 1, dtype=np.uint64)
     cig = np.zeros(cigar_cap, dtype=np.uint32)
-    _chk(lib().ma_ksw_batch(C.byref(params), _ptr(jobs), C.c_uint64(n), _ptr(qb), C.c_uint64(len(qb)), _ptr(tb),
-                            C.c_uint64(len(tb)), _ptr(ez), _ptr(off), _ptr(cig), C.c_uint64(cigar_cap)))
+    fn = lib().ma_ksw_ext_batch if pipeline_semantics else lib().ma_ksw_batch
+    _chk(fn(C.byref(params), _ptr(jobs), C.c_uint64(n), _ptr(qb), C.c_uint64(len(qb)), _ptr(tb),
+            C.c_uint64(len(tb)), _ptr(ez), _ptr(off), _ptr(cig), C.c_uint64(cigar_cap)))
     cigs = [cig[int(off[i]):int(off[i]) + int(ez["n_cigar"][i])].copy() for i in range(n)]
     return ez, cigs
 

@@ -108,19 +108,45 @@ struct ByteFetch
         return Q{ tb + jobs[ s ].t_off };
     }
 };
+struct ByteFetchPipe : ByteFetch
+{
+    static const bool EARLY = true; // what NeedlemanWunsch reads: max, max_q, max_t, cigar
+};
 } // namespace
 
-extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_t n, const uint8_t* q_bytes,
-                             uint64_t q_len, const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off,
-                             uint32_t* cigar, uint64_t cigar_cap )
+// FETCH::EARLY selects the pipeline semantics (extension kernel + early stop, see ksw_ext.h)
+template <typename FETCH>
+static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t n, const uint8_t* q_bytes, uint64_t q_len,
+                           const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off, uint32_t* cigar,
+                           uint64_t cigar_cap )
 {
     if( !P || !jobs || !ez || !cigar_off )
         return fail( "ma_ksw_batch: null argument" );
     if( n == 0 )
         return 0;
+    KswScoring SC{ P->match, P->mismatch, P->gap, P->extend, P->gap2, P->extend2 };
     KswSizing S;
     for( uint64_t i = 0; i < n; i++ )
         ksw_size_job( S, jobs[ i ].qlen, jobs[ i ].tlen, jobs[ i ].w );
+    // pipeline semantics: per-class job lists as k_dp_enum builds them on the device
+    std::vector<u32> lists;
+    DevBuf dlists;
+    if( FETCH::EARLY )
+    {
+        for( int k = 0; k < KSW_N_CLASSES; k++ )
+            S.cls[ k ] = 0;
+        lists.assign( (size_t)( KSW_N_CLASSES + 1 ) * n, 0u );
+        for( uint64_t i = 0; i < n; i++ )
+        {
+            if( jobs[ i ].qlen <= 0 || jobs[ i ].tlen <= 0 )
+                continue;
+            const int c = ksw_job_class_pipe( SC, jobs[ i ].qlen, jobs[ i ].tlen, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
+            lists[ (size_t)c * n + S.cls[ c ]++ ] = (u32)i;
+        }
+        if( dlists.reserve( lists.size( ) * 4 + 16 ) )
+            return 1;
+        MA_HIP( hipMemcpy( dlists.p, lists.data( ), lists.size( ) * 4, hipMemcpyHostToDevice ) );
+    }
     DevBuf dj, dq, dt, dez, doff, dpool, dscr, dctr;
     if( dj.reserve( n * sizeof( ma_ksw_job ) ) || dq.reserve( q_len + 16 ) || dt.reserve( t_len + 16 ) ||
         dez.reserve( n * sizeof( ma_ez ) ) || doff.reserve( ( n + 1 ) * 8 ) || dpool.reserve( cigar_cap * 4 + 16 ) ||
@@ -132,7 +158,6 @@ extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_
     MA_HIP( hipMemset( dctr.p, 0, 128 ) );
     MA_HIP( hipMemset( dez.p, 0, n * sizeof( ma_ez ) ) );
     MA_HIP( hipMemset( doff.p, 0, ( n + 1 ) * 8 ) );
-    KswScoring SC{ P->match, P->mismatch, P->gap, P->extend, P->gap2, P->extend2 };
     KswOut O;
     unsigned long long* ctr = dctr.as<unsigned long long>( );
     O.ez = dez.as<ma_ez>( );
@@ -147,8 +172,12 @@ extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_
     O.cig_words = nullptr;
     O.cig_chunk = 0; // dense pool: cigar_off[n] is the total
     unsigned int* next = (unsigned int*)( ctr + 4 ); // 4 x u32 launch queues
-    ByteFetch F{ dj.as<ma_ksw_job>( ), dq.as<uint8_t>( ), dt.as<uint8_t>( ) };
-    if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0 ) )
+    FETCH F;
+    F.jobs = dj.as<ma_ksw_job>( );
+    F.qb = dq.as<uint8_t>( );
+    F.tb = dt.as<uint8_t>( );
+    if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0, FETCH::EARLY ? dlists.as<u32>( ) : nullptr, n,
+                     (unsigned int*)( ctr + 11 ) ) )
         return 1;
     MA_HIP( hipDeviceSynchronize( ) );
     unsigned long long h[ 8 ];
@@ -164,6 +193,7 @@ extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_
         if( cigar && h[ 0 ] )
             MA_HIP( hipMemcpy( cigar, dpool.p, h[ 0 ] * 4, hipMemcpyDeviceToHost ) );
     }
+    dlists.release( );
     dj.release( );
     dq.release( );
     dt.release( );
@@ -173,4 +203,18 @@ extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_
     dscr.release( );
     dctr.release( );
     return rc;
+}
+
+extern "C" int ma_ksw_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_t n, const uint8_t* q_bytes,
+                             uint64_t q_len, const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off,
+                             uint32_t* cigar, uint64_t cigar_cap )
+{
+    return ksw_batch_impl<ByteFetch>( P, jobs, n, q_bytes, q_len, t_bytes, t_len, ez, cigar_off, cigar, cigar_cap );
+}
+
+extern "C" int ma_ksw_ext_batch( const ma_params* P, const ma_ksw_job* jobs, uint64_t n, const uint8_t* q_bytes,
+                                 uint64_t q_len, const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off,
+                                 uint32_t* cigar, uint64_t cigar_cap )
+{
+    return ksw_batch_impl<ByteFetchPipe>( P, jobs, n, q_bytes, q_len, t_bytes, t_len, ez, cigar_off, cigar, cigar_cap );
 }

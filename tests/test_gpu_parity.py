@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from ma_testlib import (ROOT, gunzip_to, read_case, read_ksw_cases, parse_pipe_dump, parse_ksw_dump, OrIndex, or_params,
-                        rand_genome, sample_reads, rand_ksw_cases, or_ksw, revcomp)
+                        rand_genome, sample_reads, rand_ksw_cases, or_ksw, revcomp, KSW_EXTZ, KSW_RIGHT, KSW_REV)
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(ROOT, "tests", "golden")
@@ -149,6 +149,62 @@ def test_ksw_random_vs_oracle(gpu_device):
             assert int(ez[f][i]) == int(oez[f]), "case %d field %s (qlen %d tlen %d w %d zdrop %d flag %d)" % (
                 i, f, len(q), len(t), w, zd, fl)
         assert np.array_equal(cigs[i], ocig), "case %d cigar" % i
+
+
+def ext_shaped_cases(n, seed):
+    """Jobs shaped like NeedlemanWunsch's extensions: short query, long padded target, w = 512, zdrop = 200; plus
+    the small global gap fills (w >= qlen + tlen) that the extension kernel also takes."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for _ in range(n):
+        kind = rng.random()
+        ql = int(rng.integers(1, 250)) if kind < 0.85 else int(rng.integers(1, 7))
+        if kind < 0.85:
+            tl = int(rng.integers(max(1, ql - 20), ql + 1100))
+            t = rng.integers(0, 4, size=tl, dtype=np.uint8)
+            if rng.random() < 0.3:  # low complexity target: late maxima are plausible
+                unit = rng.integers(0, 4, size=int(rng.integers(1, 6)), dtype=np.uint8)
+                t = np.tile(unit, tl // len(unit) + 1)[:tl].copy()
+            q = t[:min(ql, tl)].copy()
+            if len(q) < ql:
+                q = np.concatenate([q, rng.integers(0, 4, size=ql - len(q), dtype=np.uint8)])
+            er = rng.choice([0.0, 0.02, 0.08, 0.25, 0.75])
+            mut = rng.random(ql) < er
+            q[mut] = (q[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) % 4
+            if rng.random() < 0.3 and ql > 8:  # an indel
+                k = int(rng.integers(1, ql - 1))
+                q = np.concatenate([q[:k], q[k + int(rng.integers(1, 4)):], rng.integers(0, 4, size=3, dtype=np.uint8)])[:ql]
+            if rng.random() < 0.1:
+                q[int(rng.integers(0, len(q)))] = 4
+            flag = KSW_EXTZ if rng.random() < 0.5 else (KSW_EXTZ | KSW_RIGHT | KSW_REV)
+            cases.append((q, t, int(rng.choice([512, 512, 300, 260])), int(rng.choice([200, 200, 40, -1])), flag))
+        else:
+            tl = int(rng.integers(1, 120))
+            t = rng.integers(0, 4, size=tl, dtype=np.uint8)
+            q = rng.integers(0, 4, size=ql, dtype=np.uint8)
+            cases.append((q, t, max(20, abs(tl - ql) + 10), -1, 0))
+    return cases
+
+
+def test_ksw_pipeline_semantics_vs_oracle(gpu_device):
+    """ma_ksw_ext_batch (packed extension kernel, early stop) against kswcpp as restated by the oracle, on what the
+    pipeline reads: max, max_q, max_t and the cigar."""
+    import ma_amd
+    cases = ext_shaped_cases(3000, 99) + rand_ksw_cases(600, 777, max_len=200)
+    P = ma_amd.Params.preset("default")
+    ez, cigs = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
+    op = or_params()
+    n_ext = 0
+    for i, (q, t, w, zd, fl) in enumerate(cases):
+        oez, ocig = or_ksw(op, q, t, w, zd, fl)
+        what = ("max", "max_q", "max_t") if fl & KSW_EXTZ else ()
+        for f in what:
+            assert int(ez[f][i]) == int(oez[f]), "case %d field %s: %d vs %d (qlen %d tlen %d w %d zdrop %d flag %d)" % (
+                i, f, int(ez[f][i]), int(oez[f]), len(q), len(t), w, zd, fl)
+        assert np.array_equal(cigs[i], ocig), "case %d cigar (qlen %d tlen %d w %d zdrop %d flag %d)" % (
+            i, len(q), len(t), w, zd, fl)
+        n_ext += 1 if fl & KSW_EXTZ else 0
+    assert n_ext > 2000
 
 
 @pytest.mark.parametrize("preset,seed,name", [("default", 1, "small_ref.default.pipe"),
