@@ -1041,10 +1041,18 @@ int ma_seed_batch( ma_batch* b )
     const u32 seg_cap = ( smem ? 6 : 2 ) * b->max_qlen + 8;
     const u32 smem_cap = smem ? b->max_qlen + 2 : 0;
     const u64 lane_bytes = (u64)seg_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment );
-    // resident lanes: up to 8 waves per SIMD on 256 CUs, bounded by the reads and an 8 GiB staging budget
+    // resident lanes: up to 8 waves per SIMD on 256 CUs, bounded by the reads and by a staging budget of a third of
+    // the free HBM (a 10 kb read needs 0.8 MB of worst-case staging; with 288 GB that still keeps >100 k reads in
+    // flight, and a lane walks its read serially, so lanes in flight are what hides the gather latency)
     u64 lanes = 256ull * 2048;
     lanes = std::min<u64>( lanes, ( n + 255 ) / 256 * 256 );
-    lanes = std::min<u64>( lanes, std::max<u64>( 256, ( ( 8ull << 30 ) / lane_bytes ) / 256 * 256 ) );
+    {
+        size_t freeB = 0, totalB = 0;
+        MA_HIP( hipMemGetInfo( &freeB, &totalB ) );
+        const u64 have = b->stage.cap + b->smemA.cap + b->smemB.cap; // already ours
+        const u64 budget = std::max<u64>( 8ull << 30, ( (u64)freeB + have ) / 3 );
+        lanes = std::min<u64>( lanes, std::max<u64>( 256, ( budget / lane_bytes ) / 256 * 256 ) );
+    }
     b->segPoolCap = std::max<u64>( b->n_bases / 2 + 64 * n, 1024 );
     if( smem )
         b->segPoolCap *= 2;

@@ -13,6 +13,9 @@ def main():
     ap.add_argument("--reads", type=int, default=200000)
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--preset", default="default")
+    ap.add_argument("--sub", type=float, default=0.005)
+    ap.add_argument("--ins", type=float, default=0.0)
+    ap.add_argument("--dele", type=float, default=0.0)
     a = ap.parse_args()
     import torch, ma_amd
     dev = torch.device("cuda", 0)
@@ -24,12 +27,12 @@ def main():
     idx = ma_amd.Index.build_device(lens, g.data_ptr())
     del g
     n = a.reads
-    cap = n * (a.read_len + 8) + 1024
+    cap = int(n * (a.read_len * (1 + 2 * a.ins) + 8)) + 1024
     codes = torch.empty(cap, dtype=torch.uint8, device=dev)
     offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
     nb = C.c_uint64()
-    assert L.ma_synth_reads_device(idx.h, C.c_uint64(11), C.c_uint64(n), C.c_uint32(a.read_len), C.c_double(0.005),
-                                   C.c_double(0.0), C.c_double(0.0), C.c_uint64(0), C.c_void_p(codes.data_ptr()),
+    assert L.ma_synth_reads_device(idx.h, C.c_uint64(11), C.c_uint64(n), C.c_uint32(a.read_len), C.c_double(a.sub),
+                                   C.c_double(a.ins), C.c_double(a.dele), C.c_uint64(0), C.c_void_p(codes.data_ptr()),
                                    C.c_void_p(offs.data_ptr()), C.c_uint64(cap), C.byref(nb)) == 0
     P = ma_amd.Params.preset(a.preset)
     b = ma_amd.Batch(idx, P, n, int(nb.value) + 64)
@@ -64,6 +67,13 @@ def main():
     print("diag share by qlen//16 (rows) x tlen//16 (cols)")
     for r in range(13):
         print(" ".join("%5.1f" % x for x in H[r]))
+    for nm, k in (("global", (fl & 0x40) == 0), ("ext", (fl & 0x40) != 0)):
+        if k.any():
+            print(nm, "jobs", int(k.sum()), "qlen pct", np.percentile(ql[k], [10, 50, 90, 99, 100]).tolist(), "tlen pct",
+                  np.percentile(tl[k], [10, 50, 90, 99, 100]).tolist(), "w pct", np.percentile(w[k], [10, 50, 90, 100]).tolist(),
+                  "diag share %.3f" % (diags[k].sum() / diags.sum()))
+            elig = k & (ql <= weff + 1) & (ql <= 256) & ((ql + 15 <= 256) | (tl <= 256)) & (((fl & 0x40) != 0) | (ql + tl - 2 <= weff))
+            print("   eligible for the extension kernel: %.3f of jobs, %.3f of their diagonals" % (elig.sum() / k.sum(), diags[elig].sum() / max(1, diags[k].sum())))
     ext = (fl & 0x40) != 0
     print("extension jobs (EXTZ_ONLY)", ext.mean(), "diag share", diags[ext].sum() / diags.sum())
     e = zdr == 1
