@@ -32,11 +32,23 @@ inline void maCheck( int rc )
         throw std::runtime_error( ma_last_error( ) );
 }
 
+// SAM options of the selected parameter set (parameter.h:557-564, defaults 726-754); read by FileWriter (ma_sam.h)
+struct SamOptions
+{
+    bool bNoSecondary = false; // "Omit Secondary Alignments"
+    bool bNoSupplementary = false; // "Omit Supplementary Alignments"
+    bool bEmulateNgmlrTags = false; // "Emulate NGMLR's tag output"
+    bool bOutputMCigar = true; // "Use M in CIGAR"
+    bool bCGTag = true; // "Output long cigars in CG tag"
+    bool bSoftClip = false; // "Soft clip"
+};
+
 // ParameterSetManager (parameter.h:1067-1201) reduced to the preset selection the path reads
 class ParameterSetManager
 {
   public:
     ma_params xSelected;
+    SamOptions xSam;
     ParameterSetManager( )
     {
         ma_params_default( &xSelected );

@@ -12,6 +12,7 @@
 #include "ma/container/fMIndex.h"
 #include "ma/container/pack.h"
 #include "ma/module/binarySeeding.h"
+#include "ma/module/fileWriter.h"
 #include "ma/module/harmonization.h"
 #include "ma/module/mappingQuality.h"
 #include "ma/module/needlemanWunsch.h"
@@ -141,6 +142,51 @@ static int cmdPipe( const char* sCase, const char* sPreset, unsigned uiSeed, con
     return 0;
 }
 
+// SAM records of the reference's FileWriter (fileWriter.cpp:11-158) for the reads of a case, written through its
+// OutStream constructor (fileWriter.h:407-422); options: bit 0 = soft clip, bit 1 = =/X cigars instead of M
+struct CaptureStream : public OutStream
+{
+    FILE* f;
+    CaptureStream( FILE* f_ ) : f( f_ )
+    {}
+    OutStream& operator<<( std::string s )
+    {
+        fputs( s.c_str( ), f );
+        return *this;
+    }
+};
+static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, const char* sOut, int iOptions )
+{
+    CaseFile c = readCase( sCase );
+    RefIndex idx = buildIndex( c );
+    ParameterSetManager xParams;
+    xParams.setSelected( sPreset );
+    xParams.getSelected( )->xSoftClip->set( ( iOptions & 1 ) != 0 );
+    xParams.getSelected( )->xOutputMCigar->set( ( iOptions & 2 ) == 0 );
+    BinarySeeding xSeeding( xParams );
+    StripOfConsideration xSoc( xParams );
+    Harmonization xHarm( xParams );
+    NeedlemanWunsch xDp( xParams );
+    MappingQuality xMq( xParams );
+    FILE* f = fopen( sOut, "w" );
+    auto pStream = std::make_shared<CaptureStream>( f );
+    FileWriter xWriter( xParams, pStream, idx.pPack );
+    for( size_t i = 0; i < c.reads.size( ); i++ )
+    {
+        auto pQ = mkSeq( c.reads[ i ] );
+        pQ->sName = "r" + std::to_string( i );
+        auto pSegs = xSeeding.execute( idx.pFM, pQ );
+        auto pSocs = xSoc.execute( pSegs, pQ, idx.pPack, idx.pFM );
+        srand( uiSeed );
+        auto pHarm = xHarm.execute( pSocs, pQ, idx.pFM );
+        auto pAlns = xDp.execute( pHarm, pQ, idx.pPack );
+        auto pMq = xMq.execute( pQ, pAlns );
+        xWriter.execute( pQ, pMq, idx.pPack );
+    }
+    fclose( f );
+    return 0;
+}
+
 static int cmdExt( const char* sCase, const char* sOut )
 {
     CaseFile c = readCase( sCase );
@@ -209,10 +255,12 @@ int main( int argc, char** argv )
         return cmdIndex( argv[ 2 ], argv[ 3 ] );
     if( argc >= 6 && !strcmp( argv[ 1 ], "pipe" ) )
         return cmdPipe( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ] );
+    if( argc >= 6 && !strcmp( argv[ 1 ], "sam" ) )
+        return cmdSam( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ], argc >= 7 ? atoi( argv[ 6 ] ) : 0 );
     if( argc >= 4 && !strcmp( argv[ 1 ], "ext" ) )
         return cmdExt( argv[ 2 ], argv[ 3 ] );
     if( argc >= 4 && !strcmp( argv[ 1 ], "ksw" ) )
         return cmdKsw( argv[ 2 ], argv[ 3 ], argc >= 5 );
-    fprintf( stderr, "usage: ref_dump index|pipe|ext|ksw ...\n" );
+    fprintf( stderr, "usage: ref_dump index|pipe|sam|ext|ksw ...\n" );
     return 2;
 }

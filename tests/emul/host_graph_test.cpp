@@ -3,7 +3,7 @@
 // (volatile reader -> seeding -> SoC -> harmonization -> DP -> mapping quality) and writes the
 // ALN / MQ records in the common dump format.  Without a GPU the first module must throw
 // std::runtime_error (mode "nogpu").
-#include "../../ma_amd/host/ma_modules.h"
+#include "../../ma_amd/host/ma_sam.h"
 #include "../../oracle/dump_format.h"
 #include <cstdio>
 
@@ -61,6 +61,15 @@ class Writer : public Module<Container, false, NucSeq, ContainerVector<std::shar
                      (unsigned long long)a->uiEndOnRef, (unsigned long long)a->uiBeginOnQuery,
                      (unsigned long long)a->uiEndOnQuery, (long long)a->iScore, (int)a->bSecondary, (int)a->bSupplementary,
                      a->fMappingQuality );
+        return std::make_shared<Container>( );
+    }
+};
+
+// both writers must have seen the read before it is unlocked
+struct Join2 : public Module<Container, false, Container, Container>
+{
+    std::shared_ptr<Container> execute( std::shared_ptr<Container>, std::shared_ptr<Container> ) override
+    {
         return std::make_shared<Container>( );
     }
 };
@@ -127,8 +136,18 @@ int main( int argc, char** argv )
     auto pAlignments = promiseMe( pDP, pHarmonized, pQuery, pPack );
     auto pAlignmentsWQuality = promiseMe( pMappingQual, pQuery, pAlignments );
     auto pWritten = promiseMe( pWriter, pQuery, pAlignments, pAlignmentsWQuality );
-    auto pSink = promiseMe( std::make_shared<UnLock<Container>>( pQuery ), pWritten ); // export.cpp:122-124
+    // the SAM writer of export.cpp:109-117 on an in-memory stream (argv[3] + ".sam")
+    auto pSamStream = std::make_shared<StringOutStream>( );
+    auto pSamWriter = std::make_shared<FileWriter>( xParams, std::static_pointer_cast<OutStream>( pSamStream ), pPackC );
+    auto pSamWritten = promiseMe( pSamWriter, pQuery, pAlignmentsWQuality, pPack );
+    auto pBoth = promiseMe( std::make_shared<Join2>( ), pWritten, pSamWritten );
+    auto pSink = promiseMe( std::make_shared<UnLock<Container>>( pQuery ), pBoth ); // export.cpp:122-124
     BasePledge::simultaneousGet( { pSink } );
     fclose( f );
+    {
+        FILE* fs = fopen( ( std::string( argv[ 3 ] ) + ".sam" ).c_str( ), "w" );
+        fputs( pSamStream->sText.c_str( ), fs );
+        fclose( fs );
+    }
     return 0;
 }

@@ -21,6 +21,18 @@ def gz(path):
     os.remove(path)
 
 
+SAM_GOLDENS = [("default", 0), ("default", 1), ("default", 2), ("default", 3), ("illumina", 0)]
+
+
+def sam_goldens():
+    """SAM text of the reference's FileWriter (fileWriter.cpp:11-158) for small.case; options: bit 0 = soft clip,
+    bit 1 = '='/'X' cigars instead of 'M'."""
+    for preset, opt in SAM_GOLDENS:
+        name = "small_ref.%s.opt%d.sam" % (preset, opt)
+        run_ref("sam", "small.case", preset, 1, name, opt)
+        gz(name)
+
+
 def main():
     if not have_ref():
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle ref` where /root/reference exists")
@@ -39,6 +51,7 @@ def main():
     for preset in ("default", "illumina"):
         run_ref("pipe", "small.case", preset, 1, "small_ref.%s.pipe" % preset)
     run_ref("pipe", "small.case", "default", 7, "small_ref.default.seed7.pipe")
+    sam_goldens()
     # G7: kswcpp cases (all three flag modes, N bases, narrow bands, int16/int32 boundary)
     cases = rand_ksw_cases(600, 301, max_len=120) + rand_ksw_cases(12, 302, long_frac=1.0)
     write_ksw_cases("ksw.case", cases)

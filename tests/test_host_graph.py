@@ -5,6 +5,8 @@ import subprocess
 
 import pytest
 
+import gzip
+
 from ma_testlib import ROOT, gunzip_to, parse_pipe_dump
 
 EXE = os.path.join(ROOT, "tests", "emul", "host_graph_test")
@@ -14,9 +16,10 @@ G = os.path.join(ROOT, "tests", "golden")
 def build_exe():
     src = os.path.join(ROOT, "tests", "emul", "host_graph_test.cpp")
     deps = [src, os.path.join(ROOT, "ma_amd", "host", "ms_graph.h"), os.path.join(ROOT, "ma_amd", "host", "ma_modules.h"),
-            os.path.join(ROOT, "include", "ma_amd.h")]
+            os.path.join(ROOT, "ma_amd", "host", "ma_sam.h"), os.path.join(ROOT, "include", "ma_amd.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", EXE,
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", EXE,
                                "-L" + os.path.join(ROOT, "ma_amd"), "-lma_amd",
                                "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"), "-lpthread"])
     return EXE
@@ -51,3 +54,6 @@ def test_graph_of_dropin_modules_matches_reference(tmp_path, gpu_device, preset,
         assert len(g["mq"]) == len(w["mq"])
         for a, b in zip(g["mq"], w["mq"]):
             assert a == b, "read %d mapq record" % i
+    # the FileWriter node of the same graph: SAM text identical to the reference's
+    sam_want = gzip.open(os.path.join(G, "small_ref.%s.opt0.sam.gz" % preset), "rt").read()
+    assert open(out + ".sam").read() == sam_want

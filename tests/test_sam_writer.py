@@ -1,0 +1,37 @@
+"""SAM emission of the host layer (ma_amd/host/ma_sam.h) against the text the reference's FileWriter
+printed for the same reads (tests/golden/small_ref.*.sam.gz, made by make_golden.py from oracle/_ref)."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+from ma_testlib import ROOT, gunzip_to
+
+G = os.path.join(ROOT, "tests", "golden")
+EXE = os.path.join(ROOT, "tests", "emul", "sam_test")
+
+
+def build_exe():
+    src = os.path.join(ROOT, "tests", "emul", "sam_test.cpp")
+    deps = [src] + [os.path.join(ROOT, "ma_amd", "host", h) for h in ("ma_sam.h", "ma_modules.h", "ms_graph.h")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", EXE,
+                               "-L" + os.path.join(ROOT, "ma_amd"), "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"),
+                               "-lpthread"])
+    return EXE
+
+
+@pytest.mark.parametrize("preset,opt", [("default", 0), ("default", 1), ("default", 2), ("default", 3), ("illumina", 0)])
+def test_sam_text_matches_reference_filewriter(tmp_path, preset, opt):
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    pipe = gunzip_to(os.path.join(G, "small_ref.%s.pipe.gz" % preset), str(tmp_path / "p.pipe"))
+    out = str(tmp_path / "o.sam")
+    subprocess.check_call([exe, case, pipe, out, str(opt)])
+    want = gzip.open(os.path.join(G, "small_ref.%s.opt%d.sam.gz" % (preset, opt)), "rt").read()
+    got = open(out).read()
+    assert got.count("\n") == want.count("\n")
+    for i, (a, b) in enumerate(zip(got.split("\n"), want.split("\n"))):
+        assert a == b, "SAM line %d differs" % i
