@@ -44,6 +44,9 @@ def main():
     ap.add_argument("--preset", default="default")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 off)")
     ap.add_argument("--no-repeats", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight per GPU (own stream + host thread each): while one batch is in its "
+                         "VALU-bound DP kernels another runs its memory-bound seeding / chaining")
     args = ap.parse_args()
 
     import torch
@@ -96,39 +99,69 @@ def main():
 
     P = ma_amd.Params.preset(args.preset)
     max_bases = int((offs_h[B::B] - offs_h[:-1:B]).max()) if K > 0 else 0
-    batch = ma_amd.Batch(idx, P, B, max_bases + 64)
-    batch.set_stream(torch.cuda.current_stream().cuda_stream)
-    batch.enable_timing(True)
+    NB = max(1, min(args.inflight, K))
+    batches = []
+    for i in range(NB):
+        bt = ma_amd.Batch(idx, P, B, max_bases + 64)
+        st = torch.cuda.current_stream() if NB == 1 else torch.cuda.Stream()
+        bt.set_stream(st.cuda_stream)
+        bt.enable_timing(True)
+        batches.append((bt, st))
 
-    def step(k):
+    def step(i, k):
+        bt = batches[i][0]
         lo = k * B
         nbases = int(offs_h[lo + B] - offs_h[lo])
-        batch.set_reads_device(codes.data_ptr(), offs.data_ptr() + 8 * lo, B, nbases)
-        batch.align()
-        batch.sync()
+        bt.set_reads_device(codes.data_ptr(), offs.data_ptr() + 8 * lo, B, nbases)
+        bt.align()
+        bt.sync()
 
+    # warm-up: W steps on every batch object (each sizes its own buffers); untimed
     for w in range(W):
-        step(w % K)
+        for i in range(NB):
+            step(i, (w + i) % K)
 
-    kms = np.zeros(8, dtype=np.float64)
-    ctr = np.zeros(8, dtype=np.float64)
-    segs = 0
-    aligned = 0
+    import threading
+    acc = [dict(kms=np.zeros(8), ctr=np.zeros(8), segs=0, aligned=0, err=None) for _ in range(NB)]
+
+    def worker(i):
+        try:
+            torch.cuda.set_device(local_rank)
+            a = acc[i]
+            for k in range(i, K, NB):
+                step(i, k)
+                bt = batches[i][0]
+                a["kms"] += bt.kernel_ms().astype(np.float64)
+                a["ctr"] += bt.counters().astype(np.float64)
+                c = bt.counts()
+                a["aligned"] += c["aligned_reads"]
+                a["segs"] += c["segments"]
+        except Exception as e:  # surfaced after the join
+            acc[i]["err"] = e
+
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for k in range(K):
-        step(k)
-        kms += batch.kernel_ms().astype(np.float64)
-        ctr += batch.counters().astype(np.float64)
-        c = batch.counts()
-        aligned += c["aligned_reads"]
-        segs += c["segments"]
+    if NB == 1:
+        worker(0)
+    else:
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(NB)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    for a in acc:
+        if a["err"] is not None:
+            raise a["err"]
+    kms = sum(a["kms"] for a in acc)
+    ctr = sum(a["ctr"] for a in acc)
+    segs = sum(a["segs"] for a in acc)
+    aligned = sum(a["aligned"] for a in acc)
     dt, (aligned_all,) = reduce_timing_and_counts(dist, dev, dt, [aligned])
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the K launches) --
@@ -194,7 +227,8 @@ def main():
                            n_reads * world, args.read_len, 100 * args.sub, 100 * args.ins, 100 * args.dele, len(lens), F,
                            "" if args.no_repeats else ", planted repeats", args.preset, B),
                        "reads_per_s_total": round(n_reads * world / dt, 1), "index_build_s": round(t_index, 2),
-                       "parallelism": "reads partitioned over %d GPU(s), index replicated, no collective" % world},
+                       "parallelism": "reads partitioned over %d GPU(s), index replicated, no collective; %d batches in "
+                                      "flight per GPU" % (world, NB)},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -6,6 +6,7 @@
 #include "ksw_reg.h"
 #include "ksw_ext.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace ma
@@ -409,7 +410,10 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     const u64 p_cap = al( SZ.p );
     const u64 regStride = al( p_cap + al( SZ.cig * 4 ) );
     KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, 24ull << 30 );
-    u64 regWaves = std::min<u64>( 256ull * 32, nJobs );
+    u64 perCu = 32; // waves per CU of the persistent ksw launches (MA_KSW_WAVES_PER_CU: tuning hook)
+    if( const char* e = getenv( "MA_KSW_WAVES_PER_CU" ) )
+        perCu = (u64)std::max( 1, atoi( e ) );
+    u64 regWaves = std::min<u64>( 256ull * perCu, nJobs );
     if( regStride * regWaves > ( 24ull << 30 ) )
         regWaves = std::max<u64>( 1, ( 24ull << 30 ) / regStride );
     const u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0 );
