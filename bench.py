@@ -178,15 +178,22 @@ def main():
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
     # DESIGN.md 3.4); only meaningful for the workload those passes were taken on
     traffic = None
+    valu_issue = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             pt = json.load(f)
         if pt.get("workload_key") == [args.read_len, B, args.preset, args.genome_scale]:
             traffic = pt["bytes_per_launch"].get(names[dom])
+            vi = pt.get("valu_wave_insts_per_launch", {}).get(names[dom])
+            if vi and avg_s > 0:
+                # the DP kernels are VALU-issue bound, not HBM bound: instructions from the committed PMC pass over
+                # the live launch time, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
+                valu_issue = {"wave_insts_per_launch": vi, "achieved_Ginst_s": round(vi / avg_s / 1e9, 1),
+                              "peak_Ginst_s": 614.4, "frac": round(vi / avg_s / 1e9 / 614.4, 3)}
     except (OSError, ValueError, KeyError):
         traffic = None
     roofline = {"kernel": names[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_issue": valu_issue,
                 "avg_launch_ms": round(kms[dom] / max(K, 1), 3),
                 "algorithmic_bytes_per_launch": int(alg[dom] / max(K, 1)),
                 "kernel_ms_per_step": {names[i]: round(kms[i] / max(K, 1), 3) for i in range(6)},
