@@ -75,6 +75,7 @@ class NucSeq : public libMS::Container // nucSeq.h:61-160: codes A0 C1 G2 T3 N4
 {
   public:
     std::vector<uint8_t> xCodes;
+    std::vector<uint8_t> xQuality; // FASTQ quality characters (empty = none, nucSeq.h:105-108)
     std::string sName = "unknown";
     NucSeq( )
     {}

@@ -1,4 +1,5 @@
-// ma_sam.h -- SAM emission of the drop-in host layer: FileWriter with the reference's name,
+// ma_sam.h -- SAM emission and FASTA/FASTQ reading of the drop-in host layer: FileWriter /
+// FileReader with the reference's name,
 // Module signature, constructors, options and output bytes (libs/ma/inc/ma/module/fileWriter.h:21-78,364-440,
 // libs/ma/src/module/fileWriter.cpp:11-158), plus the Alignment / Pack / NucSeq string helpers it calls
 // (alignment.h:367-467,576-623; pack.h:900-997,1063-1067; nucSeq.h:558-713).  Pure host code: SAM text is
@@ -8,8 +9,10 @@
 #include "ma_modules.h"
 
 #include <algorithm>
+#include <cctype>
 #include <iostream>
 #include <mutex>
+#include <sstream>
 
 namespace libMA
 {
@@ -100,6 +103,15 @@ inline std::string fromToComplement( const NucSeq& rQ, nucSeqIndex uiStart, nucS
 inline std::string toString( const NucSeq& rQ )
 {
     return fromTo( rQ, 0, rQ.length( ) );
+}
+inline std::string fromToQual( const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd ) // nucSeq.h:697-709
+{
+    if( rQ.xQuality.empty( ) )
+        return "*";
+    std::string ret;
+    for( nucSeqIndex i = uiStart; i < uiEnd && i < rQ.length( ); i++ )
+        ret += (char)rQ.xQuality[ i ];
+    return ret;
 }
 
 // ---- Alignment (alignment.h:367-467,576-623)
@@ -321,7 +333,8 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
                                : sam::toString( *pQuery );
             else
                 sSegment = sam::getQuerySequence( *pAlignment, *pQuery, *pPack );
-            const std::string sQual = "*"; // reads carry no qualities here (nucSeq.h:697-709 without WITH_QUALITY data)
+            // (sic) not reversed for reverse-strand alignments (alignment.h:611-614)
+            const std::string sQual = sam::fromToQual( *pQuery, pAlignment->uiBeginOnQuery, pAlignment->uiEndOnQuery );
             const std::string sRefName = sam::nameOfSequenceForPosition( *pPack, pAlignment->uiBeginOnRef );
             const nucSeqIndex uiRefPos = sam::getSamPosition( *pAlignment, *pPack );
             std::string sTag;
@@ -362,10 +375,10 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
         }
         if( pAlignments->size( ) == 0 )
             sCombined += pQuery->sName + "\t" + std::to_string( MA_SAM_SEGMENT_UNMAPPED ) + "\t*\t0\t255\t*\t*\t0\t0\t" +
-                         sam::toString( *pQuery ) + "\t*\n";
+                         sam::toString( *pQuery ) + "\t" + sam::fromToQual( *pQuery, 0, pQuery->length( ) ) + "\n";
         if( sCombined.size( ) == 0 )
             sCombined += pQuery->sName + "\t" + std::to_string( MA_SAM_SEGMENT_UNMAPPED ) + "\t*\t0\t0\t*\t*\t0\t0\t" +
-                         sam::toString( *pQuery ) + "\t*\n";
+                         sam::toString( *pQuery ) + "\t" + sam::fromToQual( *pQuery, 0, pQuery->length( ) ) + "\n";
         {
             std::lock_guard<std::mutex> xGuard( *pLock );
             *pOut << sCombined;
@@ -375,6 +388,202 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
     virtual bool requiresLock( ) const
     {
         return false; // the writer serialises its own output
+    }
+};
+// ---- FASTA / FASTQ reading (fileReader.h:28-200,475-496; fileReader.cpp:12-196 with WITH_QUALITY == 1) --------
+class FileStream : public libMS::Container
+{
+  public:
+    std::mutex xMutex;
+    virtual bool eof( ) const = 0;
+    virtual char peek( ) = 0;
+    virtual char pop( ) = 0;
+    virtual std::string fileName( ) = 0;
+    virtual void safeGetLine( std::string& t ) = 0;
+};
+namespace detail
+{
+// fileReader.h:152-186: \n, \r\n and \r line ends; a last line without line end is still a line
+inline void safeGetLine( std::istream& xStream, std::string& t )
+{
+    t.clear( );
+    std::istream::sentry se( xStream, true );
+    std::streambuf* sb = xStream.rdbuf( );
+    while( true )
+    {
+        int c = sb->sbumpc( );
+        switch( c )
+        {
+            case '\n':
+                return;
+            case '\r':
+                if( sb->sgetc( ) == '\n' )
+                    sb->sbumpc( );
+                return;
+            case std::streambuf::traits_type::eof( ):
+                if( t.empty( ) )
+                    xStream.setstate( std::ios::eofbit );
+                return;
+            default:
+                t += (char)c;
+        }
+    }
+}
+} // namespace detail
+class StdFileStream : public FileStream
+{
+    std::ifstream xStream;
+    const std::string sFileName;
+
+  public:
+    StdFileStream( const std::string& sFilename ) : xStream( sFilename ), sFileName( sFilename )
+    {
+        if( !xStream.is_open( ) )
+            throw std::runtime_error( "Unable to open file " + sFilename );
+    }
+    bool eof( ) const override
+    {
+        return !xStream.good( ) || xStream.eof( );
+    }
+    char peek( ) override
+    {
+        return (char)xStream.peek( );
+    }
+    char pop( ) override
+    {
+        return (char)xStream.get( );
+    }
+    std::string fileName( ) override
+    {
+        return sFileName;
+    }
+    void safeGetLine( std::string& t ) override
+    {
+        detail::safeGetLine( xStream, t );
+    }
+};
+class StringStream : public FileStream
+{
+    std::stringstream xStream;
+
+  public:
+    StringStream( const std::string& sString ) : xStream( sString )
+    {}
+    bool eof( ) const override
+    {
+        return !xStream.good( ) || xStream.eof( );
+    }
+    char peek( ) override
+    {
+        return (char)xStream.peek( );
+    }
+    char pop( ) override
+    {
+        return (char)xStream.get( );
+    }
+    std::string fileName( ) override
+    {
+        return "StringStream";
+    }
+    void safeGetLine( std::string& t ) override
+    {
+        detail::safeGetLine( xStream, t );
+    }
+};
+
+class FileReader : public libMS::Module<NucSeq, true, FileStream>
+{
+    static bool validNuc( char c ) // fileReader.cpp:12-18
+    {
+        for( char c2 : { 'A', 'C', 'G', 'T', 'N', 'U', 'R', 'Y', 'K', 'K', 'M', 'S', 'W', 'B', 'D', 'H', 'V' } )
+            if( c2 == toupper( c ) )
+                return true;
+        return false;
+    }
+    static size_t len( const std::string& sLine ) // trailing non-nucleotide characters are dropped (20-27)
+    {
+        size_t n = sLine.length( );
+        while( n > 0 && !validNuc( sLine[ n - 1 ] ) )
+            n--;
+        return n;
+    }
+    static size_t lenq( const std::string& sLine ) // 29-35
+    {
+        size_t n = sLine.length( );
+        while( n > 0 && ( sLine[ n - 1 ] == '\n' || sLine[ n - 1 ] == '\r' ) )
+            n--;
+        return n;
+    }
+    static uint8_t code( char c ) // NucSeq::xNucleotideTranslationTable (nucSeq.cpp:17-28)
+    {
+        return c == 'A' || c == 'a' ? 0 : c == 'C' || c == 'c' ? 1 : c == 'G' || c == 'g' ? 2 : c == 'T' || c == 't' ? 3 : 4;
+    }
+    static void advanceTillNext( FileStream& rS ) // fileReader.h:477-485
+    {
+        rS.peek( );
+        while( !( rS.eof( ) || rS.peek( ) == '>' || rS.peek( ) == '@' ) )
+        {
+            rS.pop( );
+            rS.peek( );
+        }
+    }
+
+  public:
+    FileReader( const ParameterSetManager& )
+    {}
+    // nullptr = end of file (volatile source, module.h:688-695)
+    virtual std::shared_ptr<NucSeq> execute( std::shared_ptr<FileStream> pStream ) override
+    {
+        std::lock_guard<std::mutex> xLock( pStream->xMutex );
+        pStream->peek( );
+        if( pStream->eof( ) )
+            return nullptr;
+        auto pRet = std::make_shared<NucSeq>( );
+        const char cFirst = pStream->peek( );
+        if( cFirst == '>' || cFirst == '@' )
+        {
+            const bool bFastq = cFirst == '@';
+            std::string sLine;
+            pStream->safeGetLine( sLine );
+            if( sLine.size( ) == 0 )
+                throw std::runtime_error( "Invalid line in fasta" );
+            pRet->sName = sLine.substr( 1, sLine.find( ' ' ) - 1 ); // everything past the first blank is description
+            while( !pStream->eof( ) && pStream->peek( ) != ( bFastq ? '+' : '>' ) && pStream->peek( ) != ' ' )
+            {
+                sLine = "";
+                pStream->safeGetLine( sLine );
+                if( sLine.size( ) == 0 )
+                    continue;
+                const size_t n = len( sLine );
+                for( size_t i = 0; i < n; i++ )
+                    pRet->xCodes.push_back( code( sLine[ i ] ) );
+            }
+            if( bFastq )
+            {
+                pRet->xQuality.assign( pRet->xCodes.size( ), 0 );
+                pStream->safeGetLine( sLine );
+                if( sLine[ 0 ] == '+' )
+                {
+                    size_t uiPos = 0;
+                    while( !pStream->eof( ) && ( pStream->peek( ) != '@' || uiPos == 0 ) )
+                    {
+                        pStream->safeGetLine( sLine );
+                        if( sLine.size( ) == 0 )
+                            continue;
+                        const size_t n = lenq( sLine );
+                        for( size_t i = 0; i < n && i + uiPos < pRet->xQuality.size( ); i++ )
+                            pRet->xQuality[ i + uiPos ] = (uint8_t)sLine[ i ];
+                        uiPos += n;
+                    }
+                }
+            }
+            if( pRet->length( ) == 0 )
+                throw std::runtime_error( "found empty read: " + pRet->sName );
+            advanceTillNext( *pStream );
+            return pRet;
+        }
+        throw std::runtime_error( "Error while reading file.\nIs your input really in FASTA/Q format?\nError occurred in file: " +
+                                  pStream->fileName( ) + "\npeek was:" + pStream->peek( ) );
     }
 };
 } // namespace libMA

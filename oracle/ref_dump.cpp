@@ -12,6 +12,7 @@
 #include "ma/container/fMIndex.h"
 #include "ma/container/pack.h"
 #include "ma/module/binarySeeding.h"
+#include "ma/module/fileReader.h"
 #include "ma/module/fileWriter.h"
 #include "ma/module/harmonization.h"
 #include "ma/module/mappingQuality.h"
@@ -155,7 +156,8 @@ struct CaptureStream : public OutStream
         return *this;
     }
 };
-static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, const char* sOut, int iOptions )
+static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, const char* sOut, int iOptions,
+                   const char* sReadsFile )
 {
     CaseFile c = readCase( sCase );
     RefIndex idx = buildIndex( c );
@@ -171,10 +173,24 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     FILE* f = fopen( sOut, "w" );
     auto pStream = std::make_shared<CaptureStream>( f );
     FileWriter xWriter( xParams, pStream, idx.pPack );
-    for( size_t i = 0; i < c.reads.size( ); i++ )
+    // reads: the case's own, or (sReadsFile) whatever the reference's FileReader returns for a FASTA/FASTQ file
+    std::vector<std::shared_ptr<NucSeq>> vReads;
+    if( sReadsFile )
     {
-        auto pQ = mkSeq( c.reads[ i ] );
-        pQ->sName = "r" + std::to_string( i );
+        FileReader xReader( xParams );
+        auto pIn = std::make_shared<StdFileStream>( fs::path( sReadsFile ) );
+        while( auto pQ = xReader.execute( pIn ) )
+            vReads.push_back( pQ );
+    }
+    else
+        for( size_t i = 0; i < c.reads.size( ); i++ )
+        {
+            vReads.push_back( mkSeq( c.reads[ i ] ) );
+            vReads.back( )->sName = "r" + std::to_string( i );
+        }
+    for( size_t i = 0; i < vReads.size( ); i++ )
+    {
+        auto pQ = vReads[ i ];
         auto pSegs = xSeeding.execute( idx.pFM, pQ );
         auto pSocs = xSoc.execute( pSegs, pQ, idx.pPack, idx.pFM );
         srand( uiSeed );
@@ -182,6 +198,36 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
         auto pAlns = xDp.execute( pHarm, pQ, idx.pPack );
         auto pMq = xMq.execute( pQ, pAlns );
         xWriter.execute( pQ, pMq, idx.pPack );
+    }
+    fclose( f );
+    return 0;
+}
+
+// reads of a FASTA / FASTQ file as the reference's FileReader (fileReader.cpp:37-196) returns them
+static int cmdRead( const char* sIn, const char* sOut )
+{
+    ParameterSetManager xParams;
+    FileReader xReader( xParams );
+    auto pStream = std::make_shared<StdFileStream>( fs::path( sIn ) );
+    FILE* f = fopen( sOut, "w" );
+    while( true )
+    {
+        std::shared_ptr<NucSeq> pQ;
+        try
+        {
+            pQ = xReader.execute( pStream );
+        }
+        catch( const std::runtime_error& e )
+        {
+            fprintf( f, "ERROR %s\n", e.what( ) );
+            break;
+        }
+        if( pQ == nullptr )
+            break;
+        fprintf( f, "%s %llu ", pQ->sName.c_str( ), (unsigned long long)pQ->length( ) );
+        for( size_t i = 0; i < pQ->length( ); i++ )
+            fputc( '0' + ( *pQ )[ i ], f );
+        fputc( '\n', f );
     }
     fclose( f );
     return 0;
@@ -256,11 +302,14 @@ int main( int argc, char** argv )
     if( argc >= 6 && !strcmp( argv[ 1 ], "pipe" ) )
         return cmdPipe( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ] );
     if( argc >= 6 && !strcmp( argv[ 1 ], "sam" ) )
-        return cmdSam( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ], argc >= 7 ? atoi( argv[ 6 ] ) : 0 );
+        return cmdSam( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ], argc >= 7 ? atoi( argv[ 6 ] ) : 0,
+                       argc >= 8 ? argv[ 7 ] : nullptr );
+    if( argc >= 4 && !strcmp( argv[ 1 ], "read" ) )
+        return cmdRead( argv[ 2 ], argv[ 3 ] );
     if( argc >= 4 && !strcmp( argv[ 1 ], "ext" ) )
         return cmdExt( argv[ 2 ], argv[ 3 ] );
     if( argc >= 4 && !strcmp( argv[ 1 ], "ksw" ) )
         return cmdKsw( argv[ 2 ], argv[ 3 ], argc >= 5 );
-    fprintf( stderr, "usage: ref_dump index|pipe|sam|ext|ksw ...\n" );
+    fprintf( stderr, "usage: ref_dump index|pipe|sam|read|ext|ksw ...\n" );
     return 2;
 }

@@ -1,0 +1,37 @@
+// CPU-only check of the FASTA/FASTQ reader of the host layer (ma_amd/host/ma_sam.h): dumps name, length and codes of
+// every read exactly like `ref_dump read` does for the reference's FileReader.
+// usage: reader_test <in.fa|fq> <out>
+#include "ma_sam.h"
+
+#include <cstdio>
+
+using namespace libMA;
+
+int main( int argc, char** argv )
+{
+    if( argc < 3 )
+        return 2;
+    ParameterSetManager xParams;
+    FileReader xReader( xParams );
+    FILE* f = fopen( argv[ 2 ], "w" );
+    try
+    {
+        auto pStream = std::make_shared<StdFileStream>( argv[ 1 ] );
+        while( true )
+        {
+            auto pQ = xReader.execute( pStream );
+            if( pQ == nullptr )
+                break;
+            fprintf( f, "%s %llu ", pQ->sName.c_str( ), (unsigned long long)pQ->length( ) );
+            for( uint8_t c : pQ->xCodes )
+                fputc( '0' + c, f );
+            fputc( '\n', f );
+        }
+    }
+    catch( const std::runtime_error& e )
+    {
+        fprintf( f, "ERROR %s\n", e.what( ) );
+    }
+    fclose( f );
+    return 0;
+}

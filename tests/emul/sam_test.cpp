@@ -1,7 +1,9 @@
 // CPU-only check of the SAM writer of the host layer (ma_amd/host/ma_sam.h): alignments are taken from a pipeline
 // dump (golden of the compiled reference, MQ + ALN records), the reads and contigs from the case file, and the SAM
 // text must equal what the reference's FileWriter printed for the same reads (tests/golden/*.sam.gz).
-// usage: sam_test <case> <pipe dump> <out.sam> <options: bit0 soft clip, bit1 =/X cigar>
+// usage: sam_test <case> <pipe dump> <out.sam> <options: bit0 soft clip, bit1 =/X cigar> [reads.fastq]
+// with a FASTA/FASTQ file the reads (names, qualities) come from the host layer's FileReader; they must be the first
+// reads of the case in order, because the alignments are looked up in the dump by read index
 #include "../../oracle/dump_format.h"
 #include "ma_sam.h"
 
@@ -31,6 +33,14 @@ int main( int argc, char** argv )
     xParams.xSam.bOutputMCigar = ( iOptions & 2 ) == 0;
     auto pStream = std::make_shared<StringOutStream>( );
     FileWriter xWriter( xParams, std::static_pointer_cast<OutStream>( pStream ), pPack );
+    std::vector<std::shared_ptr<NucSeq>> vFileReads;
+    if( argc >= 6 )
+    {
+        FileReader xReader( xParams );
+        auto pIn = std::make_shared<StdFileStream>( argv[ 5 ] );
+        while( auto pQ = xReader.execute( pIn ) )
+            vFileReads.push_back( pQ );
+    }
     // parse the dump: per read the "a" records (with ops) and the "m" records (MappingQuality order + flags)
     std::ifstream f( argv[ 2 ] );
     std::string line;
@@ -46,9 +56,17 @@ int main( int argc, char** argv )
     auto flush = [ & ]( ) {
         if( read < 0 )
             return;
+        if( argc >= 6 && (size_t)read >= vFileReads.size( ) )
+            return;
         auto pQ = std::make_shared<NucSeq>( );
         pQ->xCodes = c.reads[ (size_t)read ];
         pQ->sName = "r" + std::to_string( read );
+        if( argc >= 6 )
+        {
+            if( vFileReads[ (size_t)read ]->xCodes != pQ->xCodes )
+                throw std::runtime_error( "reads file does not match the case" );
+            pQ = vFileReads[ (size_t)read ];
+        }
         auto pV = std::make_shared<libMS::ContainerVector<std::shared_ptr<Alignment>>>( );
         for( auto& p : mq )
             pV->push_back( p );

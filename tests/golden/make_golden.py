@@ -33,6 +33,35 @@ def sam_goldens():
         gz(name)
 
 
+READER_INPUTS = {
+    "reader_multi.fa": ">r1 some description here\nACGTACGTNNacgt\nGGGTTT\n\n>r2\nAC\r\nGT\r\n>r3_iupac extra\nRYKMSWACGT*\n ACGT\n>r4\nTTTT",
+    "reader_multi.fq": "@q1 desc\nACGTN\nACG\n+\nIIIII\nIII\n@q2\nGGGG\n+\n@@@@\n@q3\nACGTACGT\n+\nIIIIIIII",
+    "reader_empty.fa": ">e1\n\n>e2\nACGT\n",
+    "reader_notfasta.txt": "hello\n>x\nACGT\n",
+    "reader_plusname.fq": "@a\nACGT\n+a\nIIII\n",
+}
+
+
+def reader_goldens():
+    """What the reference's FileReader (fileReader.cpp:37-196) returns for small FASTA/FASTQ inputs, and the SAM text of
+    its FileWriter when the reads (names, qualities) come from a FASTQ file."""
+    os.makedirs("reader", exist_ok=True)
+    for name, text in READER_INPUTS.items():
+        with open(os.path.join("reader", name), "w", newline="") as f:
+            f.write(text)
+        run_ref("read", os.path.join("reader", name), os.path.join("reader", name + ".ref"))
+    # FASTQ with qualities for the first 24 reads of small.case
+    from ma_testlib import read_case
+    _, reads, _ = read_case("small.case")
+    with open(os.path.join("reader", "small24.fq"), "w") as f:
+        for i, r in enumerate(reads[:24]):
+            seq = "".join("ACGTN"[int(c)] for c in r)
+            qual = "".join(chr(33 + (7 * i + 3 * k) % 40) for k in range(len(seq)))
+            f.write("@fq%d sample=%d\n%s\n+\n%s\n" % (i, i, seq, qual))
+    run_ref("sam", "small.case", "default", 1, os.path.join("reader", "small24.fq.sam"), 0, os.path.join("reader", "small24.fq"))
+    gz(os.path.join("reader", "small24.fq.sam"))
+
+
 def main():
     if not have_ref():
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle ref` where /root/reference exists")
@@ -52,6 +81,7 @@ def main():
         run_ref("pipe", "small.case", preset, 1, "small_ref.%s.pipe" % preset)
     run_ref("pipe", "small.case", "default", 7, "small_ref.default.seed7.pipe")
     sam_goldens()
+    reader_goldens()
     # G7: kswcpp cases (all three flag modes, N bases, narrow bands, int16/int32 boundary)
     cases = rand_ksw_cases(600, 301, max_len=120) + rand_ksw_cases(12, 302, long_frac=1.0)
     write_ksw_cases("ksw.case", cases)

@@ -35,3 +35,39 @@ def test_sam_text_matches_reference_filewriter(tmp_path, preset, opt):
     assert got.count("\n") == want.count("\n")
     for i, (a, b) in enumerate(zip(got.split("\n"), want.split("\n"))):
         assert a == b, "SAM line %d differs" % i
+
+
+READER_EXE = os.path.join(ROOT, "tests", "emul", "reader_test")
+
+
+def build_reader_exe():
+    src = os.path.join(ROOT, "tests", "emul", "reader_test.cpp")
+    deps = [src] + [os.path.join(ROOT, "ma_amd", "host", h) for h in ("ma_sam.h", "ma_modules.h", "ms_graph.h")]
+    if not os.path.exists(READER_EXE) or any(os.path.getmtime(d) > os.path.getmtime(READER_EXE) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", READER_EXE,
+                               "-L" + os.path.join(ROOT, "ma_amd"), "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"),
+                               "-lpthread"])
+    return READER_EXE
+
+
+@pytest.mark.parametrize("name", ["reader_multi.fa", "reader_multi.fq", "reader_empty.fa", "reader_notfasta.txt",
+                                  "reader_plusname.fq"])
+def test_fasta_fastq_reader_matches_reference(tmp_path, name):
+    """Multi-line records, CRLF, lower case, IUPAC codes, trailing junk, descriptions, empty reads, non-FASTA input:
+    same reads / same error text as the reference's FileReader (tests/golden/reader/*.ref from oracle/_ref)."""
+    exe = build_reader_exe()
+    out = str(tmp_path / "o.txt")
+    # the error text quotes the path as given: use the one the golden was made with
+    subprocess.check_call([exe, os.path.join("reader", name), out], cwd=G)
+    assert open(out).read() == open(os.path.join(G, "reader", name + ".ref")).read()
+
+
+def test_sam_with_fastq_names_and_qualities(tmp_path):
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    pipe = gunzip_to(os.path.join(G, "small_ref.default.pipe.gz"), str(tmp_path / "p.pipe"))
+    out = str(tmp_path / "o.sam")
+    subprocess.check_call([exe, case, pipe, out, "0", os.path.join(G, "reader", "small24.fq")])
+    want = gzip.open(os.path.join(G, "reader", "small24.fq.sam.gz"), "rt").read()
+    assert open(out).read() == want
