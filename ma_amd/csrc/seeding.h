@@ -60,6 +60,7 @@ struct SeedLane
     i64 ik[ 3 ];
     // SMEM state
     u32 nPrev, nCurr, jPrev; // list sizes / cursor
+    u32 curQStart, curQSize; // prev[jPrev] of the extension in flight (its interval is in ik): read once, in seed_prepare
     u32 bHaveOne, retS, retE;
     u32 flip; // which of smem_a/smem_b is "prev"
     // output
@@ -301,9 +302,12 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
                 ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
                 if( L.jPrev < L.nPrev )
                 {
-                    L.ik[ 0 ] = prev[ L.jPrev ].sa_start;
-                    L.ik[ 1 ] = prev[ L.jPrev ].sa_start_rc;
-                    L.ik[ 2 ] = prev[ L.jPrev ].sa_size;
+                    const ma_segment s = prev[ L.jPrev ];
+                    L.ik[ 0 ] = s.sa_start;
+                    L.ik[ 1 ] = s.sa_start_rc;
+                    L.ik[ 2 ] = s.sa_size;
+                    L.curQStart = (u32)s.q_start;
+                    L.curQSize = (u32)s.q_size;
                     c = L.q[ L.i ];
                     return true;
                 }
@@ -398,9 +402,9 @@ MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, c
         }
         case PH_SMEM_BWD:
         { // binarySeeding.h:380-413
-            ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
             ma_segment* curr = L.flip ? S.smem_a : S.smem_b;
-            const ma_segment s = prev[ L.jPrev ];
+            ma_segment s; // = prev[ L.jPrev ], kept in the lane state by seed_prepare (saves a memory round trip per step)
+            s.q_start = L.curQStart, s.q_size = L.curQSize, s.sa_start = L.ik[ 0 ], s.sa_start_rc = L.ik[ 1 ], s.sa_size = L.ik[ 2 ];
             if( ok[ 2 ] <= (i64)P.min_amb && !L.bHaveOne )
             {
                 seed_emit( L, S, (u32)s.q_start, (u32)s.q_size, s.sa_start, s.sa_start_rc, s.sa_size );
