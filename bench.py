@@ -221,6 +221,42 @@ def main():
                # the reference computes every diagonal of an extension; the GPU path stops once ez.max is final
                "dp_band_cells_per_read": round(float(res["counters"][4]) / S, 1)}
         roofline["dp_band_cells_per_read_executed"] = round(ctr[4] / max(n_reads, 1), 1)
+        # ---- parity at full scale: the GPU results of the sampled reads of step 0 against the oracle's, bit for bit
+        # (NeedlemanWunsch output incl. every alignment op, and the MappingQuality records incl. mapq doubles)
+        Pn = min(S, B)
+        step(0, 0)
+        bt = batches[0][0]
+        goff, galn, gops = bt.alignments()
+        moff, mq, _ = bt.mapq_alignments()
+        na, nm = int(res["aln_off"][Pn]), int(res["mq_off"][Pn])
+        nops = int(res["alns"]["ops_off"][na - 1] + res["alns"]["n_ops"][na - 1]) if na else 0
+        same = (np.array_equal(goff[:Pn + 1], res["aln_off"][:Pn + 1]) and int(goff[Pn]) == na
+                and galn[:na].tobytes() == res["alns"][:na].tobytes()
+                and np.array_equal(gops[:2 * nops], res["ops"][:2 * nops])
+                and np.array_equal(moff[:Pn + 1], res["mq_off"][:Pn + 1]))
+        if same:
+            for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops", "secondary", "supplementary"):
+                same = same and np.array_equal(mq[f][:nm], res["mq"][f][:nm])
+            same = same and mq["mapq"][:nm].tobytes() == res["mq"]["mapq"][:nm].tobytes()
+        bad = 0
+        if not same:  # count the reads that differ
+            for r in range(Pn):
+                a0, a1 = int(res["aln_off"][r]), int(res["aln_off"][r + 1])
+                g0, g1 = int(goff[r]), int(goff[r + 1])
+                ok = (a1 - a0) == (g1 - g0)
+                if ok:
+                    for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops"):
+                        ok = ok and np.array_equal(galn[f][g0:g1], res["alns"][f][a0:a1])
+                    for k in range(a1 - a0):
+                        oa, ga = res["alns"][a0 + k], galn[g0 + k]
+                        ok = ok and np.array_equal(gops[2 * int(ga["ops_off"]):2 * int(ga["ops_off"] + ga["n_ops"])],
+                                                   res["ops"][2 * int(oa["ops_off"]):2 * int(oa["ops_off"] + oa["n_ops"])])
+                bad += 0 if ok else 1
+            bad = max(bad, 1)
+        cpu["parity_check"] = {"reads": Pn, "alignments": na, "alignment_ops": nops, "mapq_records": nm,
+                               "mismatching_reads": bad,
+                               "what": "GPU vs oracle on the first reads of step 0: every NeedlemanWunsch alignment (positions, score, "
+                                       "ops) and MappingQuality record (flags, mapq bits)"}
 
     if rank == 0:
         out = {

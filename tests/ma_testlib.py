@@ -318,7 +318,8 @@ def orlib():
             getattr(L, fn).restype = C.c_uint64
         for fn in ("ma_or_index_bwt", "ma_or_index_sa", "ma_or_index_pac", "ma_or_res_seg_off", "ma_or_res_segs",
                    "ma_or_res_seed_off", "ma_or_res_seeds", "ma_or_res_hset_off", "ma_or_res_hseed_off",
-                   "ma_or_res_hset_soc", "ma_or_res_hseeds", "ma_or_res_aln_off", "ma_or_res_alns", "ma_or_res_ops"):
+                   "ma_or_res_hset_soc", "ma_or_res_hseeds", "ma_or_res_aln_off", "ma_or_res_alns", "ma_or_res_ops",
+                   "ma_or_res_mq_off", "ma_or_res_mq"):
             getattr(L, fn).restype = C.c_void_p
         L.ma_or_bwt_sa.restype = C.c_int64
         _orlib = L
@@ -422,6 +423,8 @@ class OrIndex:
         res["aln_off"] = _np_from(L.ma_or_res_aln_off(r), n + 1, np.uint64)
         res["alns"] = _np_from(L.ma_or_res_alns(r), int(res["aln_off"][-1]), OR_ALN_DT)
         res["ops"] = _np_from(L.ma_or_res_ops(r), 2 * int(L.ma_or_res_n_ops(r)), np.uint64)
+        res["mq_off"] = _np_from(L.ma_or_res_mq_off(r), n + 1, np.uint64)
+        res["mq"] = _np_from(L.ma_or_res_mq(r), int(res["mq_off"][-1]), OR_ALN_DT)
         ctr = np.zeros(8, dtype=np.uint64)
         L.ma_or_res_counters(r, ctr.ctypes.data_as(C.c_void_p))
         res["counters"] = ctr
