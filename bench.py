@@ -131,7 +131,10 @@ def main():
             for k in range(i, K, NB):
                 step(i, k)
                 bt = batches[i][0]
-                a["kms"] += bt.kernel_ms().astype(np.float64)
+                km = bt.kernel_ms().astype(np.float64)
+                if os.environ.get("MA_BENCH_VERBOSE"):
+                    print("step %d stage ms %s" % (k, np.round(km[:6], 2).tolist()), file=sys.stderr, flush=True)
+                a["kms"] += km
                 a["ctr"] += bt.counters().astype(np.float64)
                 c = bt.counts()
                 a["aligned"] += c["aligned_reads"]

@@ -19,6 +19,10 @@ int DevBuf::reserve( size_t bytes )
 {
     if( bytes <= cap && p )
         return 0;
+    // growing an existing buffer: leave headroom, batch sizes of successive steps differ by a few per cent and a
+    // multi-GB hipFree + hipMalloc in the middle of a step costs far more than the memory
+    if( p )
+        bytes += bytes / 4;
     if( p )
     {
         (void)hipFree( p );

@@ -229,8 +229,7 @@ __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbas
             }
         }
         i32 hEn0c = 0, hSt0c = 0; // owner-lane candidates
-        i32 bh = (i32)0x80000000, bk = 0x7fffffff; // SIMD part of calcMaxScore: (h desc, chunk asc)
-        i32 tailH = (i32)0x80000000; // scalar remainder [en1, en0): one lane per cell
+        i32 laneMax = (i32)0x80000000; // largest new H of this lane's cells in [st0, en0)
 #pragma unroll
         for( int s = 0; s < R; s++ )
         {
@@ -351,10 +350,7 @@ __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbas
             {
                 const i32 h = (TH)( H[ s ] + V[ s ] );
                 H[ s ] = h;
-                if( tt < en1 )
-                    best_pair( bh, bk, h, ( tt - st0 ) / HL );
-                else
-                    tailH = h;
+                laneMax = max( laneMax, h );
             }
             if( tt == st0 )
                 hSt0c = H[ s ];
@@ -369,34 +365,59 @@ __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbas
                     H[ s ] = hEn0;
             hEnd = hEn0;
             hS = st0 == en0 ? hEn0 : lane_bcast( hSt0c, st0 & 63 );
-            // all-reduce over the lanes of one SIMD class (equal lane mod HL)
-            if( HL == 4 )
-                best_pair( bh, bk, dpp_ctrl<0x124>( bh ), dpp_ctrl<0x124>( bk ) ); // row_ror:4
-            best_pair( bh, bk, dpp_ctrl<0x128>( bh ), dpp_ctrl<0x128>( bk ) ); // row_ror:8
-            best_pair( bh, bk, __shfl_xor( bh, 16, 64 ), __shfl_xor( bk, 16, 64 ) );
-            best_pair( bh, bk, __shfl_xor( bh, 32, 64 ), __shfl_xor( bk, 32, 64 ) );
-            i32 vH = hEn0, vT = en0; // the initial (H[en0], en0) wins ties
-            if( bh > vH )
-                vH = bh, vT = st0 + bk * HL;
-            // independent horizontal maxima over the HL classes (values repeat with period HL lanes)
-            i32 mh = vH, mt = vT;
-            mh = max( mh, dpp_ctrl<0xB1>( mh ) ); // quad_perm [1,0,3,2]
-            mt = max( mt, dpp_ctrl<0xB1>( mt ) );
-            mh = max( mh, dpp_ctrl<0x4E>( mh ) ); // quad_perm [2,3,0,1]
-            mt = max( mt, dpp_ctrl<0x4E>( mt ) );
-            if( HL == 8 )
+            // The exact (max_H, max_t) of calcMaxScore is only consumed when the diagonal raises ez.max or could
+            // z-drop (ksw_apply_zdrop needs nothing else); two ballot tests decide that, the reduction below runs
+            // only then.  max_H = -inf otherwise makes the update code a no-op.
+            max_H = (i32)0x80000000;
+            max_t = 0;
+            bool need = hEn0 > (i32)ez.max || __any( laneMax > (i32)ez.max ) != 0;
+            if( !need && J.zdrop >= 0 )
+                need = hEn0 < (i32)ez.max - J.zdrop && __any( laneMax >= (i32)ez.max - J.zdrop ) == 0;
+            if( need )
             {
-                mh = max( mh, dpp_ctrl<0x124>( mh ) ); // row_ror:4 (period-8 values: quad q-1 == quad q+1)
-                mt = max( mt, dpp_ctrl<0x124>( mt ) );
-            }
-            max_H = __builtin_amdgcn_readfirstlane( mh );
-            max_t = __builtin_amdgcn_readfirstlane( mt );
-            // scalar remainder [en1, en0): ascending t, strict >
-            for( i32 t = en1; t < en0; ++t )
-            {
-                const i32 h = lane_bcast( tailH, t & 63 );
-                if( h > max_H )
-                    max_H = h, max_t = t;
+                i32 bh = (i32)0x80000000, bk = 0x7fffffff; // SIMD part: (h desc, chunk asc)
+                i32 tailH = (i32)0x80000000; // scalar remainder [en1, en0): one lane per cell
+#pragma unroll
+                for( int s = 0; s < R; s++ )
+                {
+                    const i32 tt = TT[ s ];
+                    if( tt >= st0 && tt < en0 )
+                    {
+                        if( tt < en1 )
+                            best_pair( bh, bk, H[ s ], ( tt - st0 ) / HL );
+                        else
+                            tailH = H[ s ];
+                    }
+                }
+                // all-reduce over the lanes of one SIMD class (equal lane mod HL)
+                if( HL == 4 )
+                    best_pair( bh, bk, dpp_ctrl<0x124>( bh ), dpp_ctrl<0x124>( bk ) ); // row_ror:4
+                best_pair( bh, bk, dpp_ctrl<0x128>( bh ), dpp_ctrl<0x128>( bk ) ); // row_ror:8
+                best_pair( bh, bk, __shfl_xor( bh, 16, 64 ), __shfl_xor( bk, 16, 64 ) );
+                best_pair( bh, bk, __shfl_xor( bh, 32, 64 ), __shfl_xor( bk, 32, 64 ) );
+                i32 vH = hEn0, vT = en0; // the initial (H[en0], en0) wins ties
+                if( bh > vH )
+                    vH = bh, vT = st0 + bk * HL;
+                // independent horizontal maxima over the HL classes (values repeat with period HL lanes)
+                i32 mh = vH, mt = vT;
+                mh = max( mh, dpp_ctrl<0xB1>( mh ) ); // quad_perm [1,0,3,2]
+                mt = max( mt, dpp_ctrl<0xB1>( mt ) );
+                mh = max( mh, dpp_ctrl<0x4E>( mh ) ); // quad_perm [2,3,0,1]
+                mt = max( mt, dpp_ctrl<0x4E>( mt ) );
+                if( HL == 8 )
+                {
+                    mh = max( mh, dpp_ctrl<0x124>( mh ) ); // row_ror:4 (period-8 values: quad q-1 == quad q+1)
+                    mt = max( mt, dpp_ctrl<0x124>( mt ) );
+                }
+                max_H = __builtin_amdgcn_readfirstlane( mh );
+                max_t = __builtin_amdgcn_readfirstlane( mt );
+                // scalar remainder [en1, en0): ascending t, strict >
+                for( i32 t = en1; t < en0; ++t )
+                {
+                    const i32 h = lane_bcast( tailH, t & 63 );
+                    if( h > max_H )
+                        max_H = h, max_t = t;
+                }
             }
         }
         else
@@ -421,7 +442,7 @@ __device__ void ksw_reg_core( const KswScoring& SC, const KswJobView& J, QF qbas
             ez.max_t = max_t;
             ez.max_q = r - max_t;
         }
-        else if( max_t >= ez.max_t && r - max_t >= ez.max_q )
+        else if( max_H != (i32)0x80000000 && max_t >= ez.max_t && r - max_t >= ez.max_q )
         {
             const i32 tl = max_t - ez.max_t, ql = ( r - max_t ) - ez.max_q;
             const i32 l = tl > ql ? tl - ql : ql - tl;
