@@ -5,6 +5,7 @@
 #include "ksw_wave.h"
 #include "ksw_reg.h"
 #include "ksw_ext.h"
+#include "ksw_pk.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -52,11 +53,11 @@ struct KswWaveAcc
 #define KSW_S0 1
 #define KSW_S1 2
 #define KSW_S2 3
-#define KSW_S3 9
+#define KSW_S3 5
 #define KSW_N_CLASSES 7 // 0..3 ring kernels, 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
-    const i32 n = ksw_need_slots( qlen, tlen, w );
+    const i32 n = ksw_pk_slots( qlen, tlen, w ); // 128-cell slots of the two-cells-per-lane kernel (ksw_pk.h)
     return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : ( n <= KSW_S3 ? 3 : 4 ) ) );
 }
 // pipeline mode: extensions whose callers read only max_q / max_t / cigar go to the extension kernel
@@ -265,10 +266,18 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, KswJo
         u64 cells = 0, path = 0;
         auto qf = F.qfetch( slot );
         auto tf = F.tfetch( slot );
-        if( ksw_h16( SC, J.qlen, J.tlen ) )
-            ksw_reg_core<S, int16_t, 8, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
+        const bool h16 = ksw_h16( SC, J.qlen, J.tlen );
+        if( J.flag & KSW_EZ_RIGHT )
+        {
+            if( h16 )
+                ksw_pk_core<S, int16_t, 8, FETCH::EARLY, false>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
+            else
+                ksw_pk_core<S, int32_t, 4, FETCH::EARLY, false>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
+        }
+        else if( h16 )
+            ksw_pk_core<S, int16_t, 8, FETCH::EARLY, true>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
         else
-            ksw_reg_core<S, int32_t, 4, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
+            ksw_pk_core<S, int32_t, 4, FETCH::EARLY, true>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
         ksw_publish( O, acc, slot, ez, nCig, cells, path, cig, &sOff );
     }
     ksw_flush( O, acc );

@@ -1,0 +1,494 @@
+// ksw_pk.h -- the exact kswcpp wavefront kernel (every ez field, every 16-aligned lane block of the SSE code with
+// its overshoot lanes; contract and bit-exactness rules in ksw_wave.h / ksw_reg.h) with TWO diagonal cells per lane:
+// cell t lives in half (t & 1) of lane ((t >> 1) & 63) of ring slot ((t >> 7) mod R), a slot holds 128 cells.
+// The int8 difference vectors u,v,x,y,x2,y2 and the score profile are packed as value << 8 (+ a tie-break tag in
+// the low byte) in the two 16-bit halves of a VGPR, so one v_pk_* instruction advances two cells and ONE max chain
+// yields both z and the direction state (ksw_ext.h explains the encoding).  The exact score H stays 32 bit (two
+// registers per lane), so both the int16 and the int32 flavour of kswcpp (riskOfOverflow, kswcpp.h:101-115) run
+// here.  Everything else -- ring rotation with the 16-aligned window start, carry-in, first-row initialisation,
+// unaligned score-profile stride, calcMaxScore classes, z-drop, direction rows, back-trace -- is ksw_reg.h's logic.
+// This is the kernel for wide bands (long reads: band 512, thousands of diagonals): per diagonal it issues roughly
+// half the VALU instructions of the one-cell-per-lane ring kernel.
+#pragma once
+#include "ksw_ext.h"
+
+#if defined( __HIPCC__ )
+namespace ma
+{
+// ring slots (128 cells each) a job needs here: the touched range of a diagonal is [st, st + m + 29]
+MA_HD i32 ksw_pk_slots( i32 qlen, i32 tlen, i32 w )
+{
+    if( w < 0 )
+        w = tlen > qlen ? tlen : qlen;
+    i64 m = qlen < tlen ? qlen : tlen;
+    if( (i64)w + 1 < m )
+        m = (i64)w + 1;
+    return (i32)( ( m + 30 + 127 ) / 128 );
+}
+
+__device__ __forceinline__ i32 pk_lo8( u32 x ) // int8 value of the low half
+{
+    return (i32)( x << 16 ) >> 24;
+}
+__device__ __forceinline__ i32 pk_hi8( u32 x ) // int8 value of the high half
+{
+    return (i32)x >> 24;
+}
+
+template <int R, typename TH, int HL, bool EARLY, bool LEFT, typename QF, typename TF>
+__device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, uint8_t* qr /*LDS*/,
+                             uint8_t* P /*HBM direction bytes*/, u32* cig, KswEz& ez, u32& nCigar, u64& cells,
+                             u64& pathSteps, u32 ldsBytes )
+{
+    constexpr i32 RING = 128 * R;
+    const int lane = threadIdx.x & 63;
+    const i32 qlen = J.qlen, tlen = J.tlen;
+    ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
+    ez.max = 0;
+    ez.score = ez.mqe = ez.mte = (i32)0x80000000;
+    ez.zdropped = 0;
+    ez.reach_end = 0;
+    nCigar = 0;
+    cells = 0;
+    pathSteps = 0;
+    if( qlen <= 0 || tlen <= 0 )
+        return;
+    int8_t q = (int8_t)SC.q, e = (int8_t)SC.e, q2 = (int8_t)SC.q2, e2 = (int8_t)SC.e2;
+    const i32 sc_mch = (int8_t)( SC.match < 0 ? -SC.match : SC.match );
+    const i32 sc_mis = (int8_t)( SC.mismatch > 0 ? -SC.mismatch : SC.mismatch );
+    const i32 qe0 = q + e; // q+e before the swap (H[0] on the first diagonal)
+    if( q2 + e2 < q + e )
+    {
+        int8_t t = q;
+        q = q2;
+        q2 = t;
+        t = e;
+        e = e2;
+        e2 = t;
+    }
+    i32 w = J.w;
+    if( w < 0 )
+        w = tlen > qlen ? tlen : qlen;
+    {
+        const i32 min_sc = sc_mis < 0 ? sc_mis : 0;
+        if( -min_sc > 2 * ( q + e ) )
+            return;
+    }
+    const i32 n_col = (i32)ksw_ncol( qlen, tlen, J.w ) * 16;
+    i32 long_thres = e != e2 ? ( q2 - q ) / ( e - e2 ) - 1 : 0;
+    if( q2 + e2 + long_thres * e2 > q + e + long_thres * e )
+        ++long_thres;
+    const i32 long_diff = long_thres * ( e - e2 ) - ( q2 - q ) - e2;
+    const i32 L = ( ( tlen + 15 ) / 16 ) * 16;
+    const i32 qrBytes = ( ( qlen + 15 ) / 16 ) * 16 + 32;
+    const i32 NEG = sizeof( TH ) == 2 ? -32768 : (i32)0x80000000;
+    auto initOf = [ & ]( i32 r ) -> i32 {
+        return (int8_t)( r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2 );
+    };
+    // tags (ksw_ext.h): LEFT keeps the first maximum of (s, a, b, a2, b2): d = 4 - tag; RIGHT the last of (s, a, b, a2)
+    constexpr u32 tS = LEFT ? 4 : 0, tX = LEFT ? 3 : 1, tY = 2, tX2 = LEFT ? 1 : 3, tY2 = 0;
+    const u32 K_X0 = pk_val( -q - e, tX ), K_Y0 = pk_val( -q - e, tY ), K_X20 = pk_val( -q2 - e2, tX2 ),
+              K_Y20 = pk_val( -q2 - e2, tY2 ), K_V0 = pk_val( -q - e, 0 ), K_S0 = pk_val( 0, tS );
+    const u32 K_TX = pk_val( 0, tX ), K_TY = pk_val( 0, tY ), K_TX2 = pk_val( 0, tX2 ), K_TY2 = pk_val( 0, tY2 );
+    const u32 K_Q = pk_val( q, 0 ), K_Q2 = pk_val( q2, 0 ), K_QE = pk_val( q + e, 0 ), K_QE2 = pk_val( q2 + e2, 0 );
+    const u32 K_MCH = pk_val( sc_mch, tS ), K_NDIFF = pk_val( sc_mis - sc_mch, 0 ), K_NADJ = pk_val( -e2 - sc_mis, 0 );
+    const u32 K_CLIP = pk_val( sc_mch, 0xff );
+
+    for( i32 t = lane; t < qrBytes; t += 64 )
+        qr[ t ] = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
+    __syncthreads( );
+
+    // target byte as the reference's contiguous scratch sees it: sf[t] for t < L, then the qr region
+    auto tgtAt = [ & ]( i32 tt ) -> u32 {
+        if( tt < tlen )
+            return (u32)tbase( tt ) & 0xffu;
+        if( tt < L )
+            return 0u;
+        const i32 k = tt - L;
+        return k < qrBytes ? (u32)qr[ k ] : 0u;
+    };
+
+    u32 U[ R ], V[ R ], X[ R ], Y[ R ], X2[ R ], Y2[ R ], Sp[ R ], T[ R ];
+    i32 Hlo[ R ], Hhi[ R ], TT[ R ];
+#pragma unroll
+    for( int s = 0; s < R; s++ )
+    {
+        TT[ s ] = 128 * s + 2 * lane;
+        U[ s ] = V[ s ] = K_V0;
+        X[ s ] = K_X0;
+        Y[ s ] = K_Y0;
+        X2[ s ] = K_X20;
+        Y2[ s ] = K_Y20;
+        Sp[ s ] = K_S0;
+        T[ s ] = tgtAt( TT[ s ] ) | tgtAt( TT[ s ] + 1 ) << 16;
+        Hlo[ s ] = Hhi[ s ] = NEG;
+    }
+    i32 last_st = -1, last_en = -1, cur_st = 0;
+    i32 hBelow = NEG; // H[st-1]: the only recycled cell that is read again (as H[en0-1] when en0 == st)
+    const i32 nDiag = qlen + tlen - 1;
+    bool stop = false;
+    const bool early = EARLY && ( J.flag & KSW_EZ_EXTZ_ONLY ) && qlen <= w + 1;
+    i32 topH = 0, boundPrev = 0x7fffffff; // H(r-1,-1) of the first-row boundary; B_{r-1} (ksw_reg.h)
+    for( i32 r = 0; r < nDiag && !stop; ++r )
+    {
+        // ---- bounds (kswcpp_core.h:541-559)
+        i32 st0 = 0, en0 = tlen - 1;
+        st0 = max( st0, r - qlen + 1 );
+        en0 = min( en0, r );
+        st0 = max( st0, ( r - w + 1 ) >> 1 );
+        en0 = min( en0, ( r + w ) >> 1 );
+        if( st0 > en0 )
+        {
+            ez.zdropped = 1;
+            break;
+        }
+        const i32 st = st0 & ~15, en = en0 | 15;
+        // ---- carry-in (kswcpp_core.h:562-579) and ring rotation; st advances by 16 at most
+        u32 x1 = K_X0 & 0xffffu, x21 = K_X20 & 0xffffu, v1 = K_V0 & 0xffffu; // one 16-bit half each
+        if( st == 0 )
+            v1 = ( (u32)initOf( r ) & 0xffu ) << 8;
+        if( st != cur_st )
+        {
+            const int jOld = ( cur_st >> 7 ) % R; // slot that holds [cur_st, cur_st + 16)
+            const int src = ( ( st - 1 ) >> 1 ) & 63; // cell st-1 is the HIGH half of this lane
+            const bool useOld = st - 1 >= last_st && st - 1 <= last_en;
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+                if( s == jOld )
+                {
+                    if( useOld )
+                    {
+                        x1 = (u32)lane_bcast( (i32)X[ s ], src ) >> 16;
+                        x21 = (u32)lane_bcast( (i32)X2[ s ], src ) >> 16;
+                        v1 = (u32)lane_bcast( (i32)V[ s ], src ) >> 16;
+                    }
+                    hBelow = lane_bcast( Hhi[ s ], src );
+                    // recycle the 16 cells (8 lanes) that left the window for the 16 cells entering at the top
+                    if( TT[ s ] < st )
+                    {
+                        TT[ s ] += RING;
+                        U[ s ] = V[ s ] = K_V0;
+                        X[ s ] = K_X0;
+                        Y[ s ] = K_Y0;
+                        X2[ s ] = K_X20;
+                        Y2[ s ] = K_Y20;
+                        Sp[ s ] = K_S0;
+                        Hlo[ s ] = Hhi[ s ] = NEG;
+                        T[ s ] = tgtAt( TT[ s ] ) | tgtAt( TT[ s ] + 1 ) << 16;
+                    }
+                }
+            cur_st = st;
+        }
+        const i32 uInit = initOf( r );
+        const bool initRow = en >= r; // kswcpp_core.h:580-585
+        const i32 pEnd = st0 + ( ( en0 - st0 ) / 16 + 1 ) * 16; // score profile refreshes [st0, pEnd)
+        const i32 qoff = qlen - 1 - r;
+        uint8_t* pr = P + (size_t)r * (size_t)n_col - st;
+        cells += (u64)( en - st + 1 );
+        const i32 hi = max( en, pEnd - 1 );
+        const i32 en1 = st0 + ( ( en0 - st0 ) / HL ) * HL;
+        const int b0 = st >> 7, j0 = b0 % R;
+        const int stLane = ( st >> 1 ) & 63; // cell st = low half of this lane of slot j0
+        // previous-lane views (lane i <- lane i-1; lane 0 continues lane 63 of the previous slot of the ring)
+        u32 px[ R ], pv[ R ], px2[ R ];
+        i32 ph[ R ];
+#pragma unroll
+        for( int s = 0; s < R; s++ )
+        {
+            px[ s ] = lanes_ror1( X[ s ] );
+            pv[ s ] = lanes_ror1( V[ s ] );
+            px2[ s ] = lanes_ror1( X2[ s ] );
+            ph[ s ] = dpp_wave_ror1( Hhi[ s ] );
+        }
+        i32 hEn0c = 0, hSt0c = 0; // owner-lane candidates
+        i32 laneMax = (i32)0x80000000; // largest new H of this lane's cells in [st0, en0)
+#pragma unroll
+        for( int s = 0; s < R; s++ )
+        {
+            // wave-uniform skip of slots whose cells are all above the touched range
+            int dj = s - j0;
+            if( dj < 0 )
+                dj += R;
+            if( dj != 0 && ( ( b0 + dj ) << 7 ) > hi )
+                continue;
+            const int sp = s == 0 ? R - 1 : s - 1;
+            const i32 tt = TT[ s ]; // low cell; the high half is cell tt + 1
+            // neighbours t-1 (values of the previous diagonal)
+            u32 xt1 = cells_shift1( X[ s ], R == 1 ? px[ s ] : ( lane == 0 ? px[ sp ] : px[ s ] ) );
+            u32 vt1 = cells_shift1( V[ s ], R == 1 ? pv[ s ] : ( lane == 0 ? pv[ sp ] : pv[ s ] ) );
+            u32 x2t1 = cells_shift1( X2[ s ], R == 1 ? px2[ s ] : ( lane == 0 ? px2[ sp ] : px2[ s ] ) );
+            i32 hupLo = R == 1 ? ph[ s ] : ( lane == 0 ? ph[ sp ] : ph[ s ] );
+            const i32 hupHi = Hlo[ s ];
+            if( s == j0 )
+            {
+                // cell st takes the carry-in
+                const u32 m = lane == stLane ? 0x0000ffffu : 0u;
+                xt1 = pk_bfi( m, x1, xt1 );
+                vt1 = pk_bfi( m, v1, vt1 );
+                x2t1 = pk_bfi( m, x21, x2t1 );
+                if( lane == stLane )
+                    hupLo = hBelow;
+            }
+            // first row / column initialisation of cell r
+            if( initRow && tt <= r && r <= tt + 1 )
+            {
+                const u32 m = tt == r ? 0x0000ffffu : 0xffff0000u;
+                Y[ s ] = pk_bfi( m, K_Y0, Y[ s ] );
+                Y2[ s ] = pk_bfi( m, K_Y20, Y2[ s ] );
+                U[ s ] = pk_bfi( m, pk_val( uInit, 0 ), U[ s ] );
+            }
+            // score profile of the cells in [st0, pEnd): match / mismatch, -e2 when either base is N
+            {
+                const u32 b = (u32)qr[ qoff + tt ] | (u32)qr[ qoff + tt + 1 ] << 16;
+                const u32 isN = pk_lshr( T[ s ] | b, 2 );
+                const u32 differ = pk_minu( ( T[ s ] ^ b ) | isN, 0x00010001u );
+                u32 val = pk_mad( differ, K_NDIFF, K_MCH );
+                val = pk_mad( isN, K_NADJ, val );
+                const u32 mlo = ( tt >= st0 && tt < pEnd ) ? 0x0000ffffu : 0u;
+                const u32 mhi = ( tt + 1 >= st0 && tt + 1 < pEnd ) ? 0xffff0000u : 0u;
+                Sp[ s ] = pk_bfi( mlo | mhi, val, Sp[ s ] );
+            }
+            // DP cell (kswcpp_core.h:653-766)
+            u32 nu, nv;
+            {
+                u32 z = Sp[ s ];
+                const u32 ut = U[ s ];
+                u32 a = pk_add( xt1, vt1 );
+                u32 b = pk_add( Y[ s ], ut );
+                u32 a2 = pk_add( x2t1, vt1 );
+                u32 b2 = pk_add( Y2[ s ], ut );
+                u32 d;
+                if( LEFT )
+                {
+                    z = pk_max( pk_max( z, a ), pk_max( pk_max( b, a2 ), b2 ) );
+                    d = pk_sub( 0x00040004u, z & 0x00070007u );
+                }
+                else
+                {
+                    z = pk_max( pk_max( z, a ), pk_max( b, a2 ) );
+                    d = z & 0x00070007u;
+                    z = pk_max( z, b2 ); // state 4 is never recorded (kswcpp_core.h:693-699)
+                }
+                const u32 zc = pk_min( z, K_CLIP ) & 0xff00ff00u;
+                nu = pk_sub( zc, vt1 );
+                nv = pk_sub( zc, ut );
+                u32 tmp = pk_sub( zc, K_Q );
+                a = pk_sub( a, tmp );
+                b = pk_sub( b, tmp );
+                tmp = pk_sub( zc, K_Q2 );
+                a2 = pk_sub( a2, tmp );
+                b2 = pk_sub( b2, tmp );
+                const u32 nx = pk_sub( pk_max( a, K_TX ), K_QE ), ny = pk_sub( pk_max( b, K_TY ), K_QE );
+                const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), K_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), K_QE2 );
+                u32 fa, fb, fa2, fb2; // bit 15 of a half = continuation flag
+                if( LEFT )
+                {
+                    fa = pk_subsat( K_TX, a ); // a > 0
+                    fb = pk_subsat( K_TY, b );
+                    fa2 = pk_subsat( K_TX2, a2 );
+                    fb2 = pk_subsat( K_TY2, b2 );
+                }
+                else
+                {
+                    fa = ~pk_subsat( a, K_TX ); // !(a < 0)
+                    fb = ~pk_subsat( b, K_TY );
+                    fa2 = ~pk_subsat( a2, K_TX2 );
+                    fb2 = ~pk_subsat( b2, K_TY2 );
+                }
+                d |= ( ( fa >> 12 ) & 0x00080008u ) | ( ( fb >> 11 ) & 0x00100010u ) | ( ( fa2 >> 10 ) & 0x00200020u ) |
+                     ( ( fb2 >> 9 ) & 0x00400040u );
+                if( tt >= st && tt <= en ) // st is even, en odd: a lane is inside with both cells or not at all
+                {
+                    U[ s ] = nu;
+                    V[ s ] = nv;
+                    X[ s ] = nx;
+                    Y[ s ] = ny;
+                    X2[ s ] = nx2;
+                    Y2[ s ] = ny2;
+                    *(uint16_t*)( pr + tt ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
+                }
+            }
+            // ---- calcMaxScore pieces (kswcpp_core.h:156-299) with this diagonal's u / v
+            // (cells of [st0, en0] lie inside [st, en], so nu / nv are the committed values there)
+            const i32 ulo = pk_lo8( nu ), uhi = pk_hi8( nu ), vlo = pk_lo8( nv ), vhi = pk_hi8( nv );
+            // H[en0] = en0 > 0 ? Hold[en0-1] + u[en0] : Hold[en0] + v[en0]
+            if( tt == en0 )
+                hEn0c = (TH)( en0 > 0 ? hupLo + ulo : Hlo[ s ] + vlo );
+            if( tt + 1 == en0 )
+                hEn0c = (TH)( hupHi + uhi );
+            if( r > 0 )
+            {
+                if( tt >= st0 && tt < en0 )
+                {
+                    Hlo[ s ] = (TH)( Hlo[ s ] + vlo );
+                    laneMax = max( laneMax, Hlo[ s ] );
+                }
+                if( tt + 1 >= st0 && tt + 1 < en0 )
+                {
+                    Hhi[ s ] = (TH)( Hhi[ s ] + vhi );
+                    laneMax = max( laneMax, Hhi[ s ] );
+                }
+            }
+            if( tt == st0 )
+                hSt0c = Hlo[ s ];
+            if( tt + 1 == st0 )
+                hSt0c = Hhi[ s ];
+        }
+        i32 max_H, max_t, hEnd, hS;
+        if( r > 0 )
+        {
+            const i32 hEn0 = lane_bcast( hEn0c, ( en0 >> 1 ) & 63 );
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+            {
+                if( TT[ s ] == en0 )
+                    Hlo[ s ] = hEn0;
+                if( TT[ s ] + 1 == en0 )
+                    Hhi[ s ] = hEn0;
+            }
+            hEnd = hEn0;
+            hS = st0 == en0 ? hEn0 : lane_bcast( hSt0c, ( st0 >> 1 ) & 63 );
+            // the exact (max_H, max_t) is only consumed when the diagonal raises ez.max or could z-drop (ksw_reg.h)
+            max_H = (i32)0x80000000;
+            max_t = 0;
+            bool need = hEn0 > (i32)ez.max || __any( laneMax > (i32)ez.max ) != 0;
+            if( !need && J.zdrop >= 0 )
+                need = hEn0 < (i32)ez.max - J.zdrop && __any( laneMax >= (i32)ez.max - J.zdrop ) == 0;
+            if( need )
+            {
+                // classes (t - st0) mod HL: a lane's low cells all share one class, its high cells the next one
+                i32 bhL = (i32)0x80000000, bkL = 0x7fffffff, bhH = (i32)0x80000000, bkH = 0x7fffffff;
+                i32 tailL = (i32)0x80000000, tailH = (i32)0x80000000; // scalar remainder [en1, en0)
+#pragma unroll
+                for( int s = 0; s < R; s++ )
+                {
+                    const i32 tt = TT[ s ];
+                    if( tt >= st0 && tt < en0 )
+                    {
+                        if( tt < en1 )
+                            best_pair( bhL, bkL, Hlo[ s ], ( tt - st0 ) / HL );
+                        else
+                            tailL = Hlo[ s ];
+                    }
+                    if( tt + 1 >= st0 && tt + 1 < en0 )
+                    {
+                        if( tt + 1 < en1 )
+                            best_pair( bhH, bkH, Hhi[ s ], ( tt + 1 - st0 ) / HL );
+                        else
+                            tailH = Hhi[ s ];
+                    }
+                }
+                // all-reduce over the lanes of one class: lanes with equal (lane mod HL/2)
+                if( HL == 4 )
+                {
+                    best_pair( bhL, bkL, dpp_ctrl<0x122>( bhL ), dpp_ctrl<0x122>( bkL ) ); // row_ror:2
+                    best_pair( bhH, bkH, dpp_ctrl<0x122>( bhH ), dpp_ctrl<0x122>( bkH ) );
+                }
+                best_pair( bhL, bkL, dpp_ctrl<0x124>( bhL ), dpp_ctrl<0x124>( bkL ) ); // row_ror:4
+                best_pair( bhH, bkH, dpp_ctrl<0x124>( bhH ), dpp_ctrl<0x124>( bkH ) );
+                best_pair( bhL, bkL, dpp_ctrl<0x128>( bhL ), dpp_ctrl<0x128>( bkL ) ); // row_ror:8
+                best_pair( bhH, bkH, dpp_ctrl<0x128>( bhH ), dpp_ctrl<0x128>( bkH ) );
+                best_pair( bhL, bkL, __shfl_xor( bhL, 16, 64 ), __shfl_xor( bkL, 16, 64 ) );
+                best_pair( bhH, bkH, __shfl_xor( bhH, 16, 64 ), __shfl_xor( bkH, 16, 64 ) );
+                best_pair( bhL, bkL, __shfl_xor( bhL, 32, 64 ), __shfl_xor( bkL, 32, 64 ) );
+                best_pair( bhH, bkH, __shfl_xor( bhH, 32, 64 ), __shfl_xor( bkH, 32, 64 ) );
+                // per class: the initial (H[en0], en0) wins ties; then independent horizontal maxima over the classes
+                i32 mh = hEn0, mt = en0;
+                if( bhL > hEn0 )
+                    mh = bhL, mt = st0 + bkL * HL;
+                {
+                    const i32 vh = bhH > hEn0 ? bhH : hEn0, vt = bhH > hEn0 ? st0 + bkH * HL : en0;
+                    mh = max( mh, vh );
+                    mt = max( mt, vt );
+                }
+                mh = max( mh, dpp_ctrl<0xB1>( mh ) ); // quad_perm [1,0,3,2]: the neighbouring lane's two classes
+                mt = max( mt, dpp_ctrl<0xB1>( mt ) );
+                if( HL == 8 )
+                {
+                    mh = max( mh, dpp_ctrl<0x4E>( mh ) ); // quad_perm [2,3,0,1]
+                    mt = max( mt, dpp_ctrl<0x4E>( mt ) );
+                }
+                max_H = __builtin_amdgcn_readfirstlane( mh );
+                max_t = __builtin_amdgcn_readfirstlane( mt );
+                // scalar remainder [en1, en0): ascending t, strict >
+                for( i32 t = en1; t < en0; ++t )
+                {
+                    const i32 h = lane_bcast( ( t & 1 ) ? tailH : tailL, ( t >> 1 ) & 63 );
+                    if( h > max_H )
+                        max_H = h, max_t = t;
+                }
+            }
+        }
+        else
+        {
+            // r == 0: H[0] = v[0] - (q+e) (kswcpp_core.h:244-249); cell 0 = low half of lane 0 of slot 0
+            const i32 h0 = (TH)( pk_lo8( (u32)lane_bcast( (i32)V[ 0 ], 0 ) ) - qe0 );
+            if( lane == 0 )
+                Hlo[ 0 ] = h0;
+            max_H = h0;
+            max_t = 0;
+            hEnd = h0;
+            hS = h0;
+        }
+        if( en0 == tlen - 1 && hEnd > ez.mte )
+            ez.mte = hEnd, ez.mte_q = r - en;
+        if( r - st0 == qlen - 1 && hS > ez.mqe )
+            ez.mqe = hS, ez.mqe_t = st0;
+        // ksw_apply_zdrop (kswcpp_core.h:22-44), is_rot = 1
+        if( max_H > (i32)ez.max )
+        {
+            ez.max = (u32)max_H & 0x7fffffffu;
+            ez.max_t = max_t;
+            ez.max_q = r - max_t;
+        }
+        else if( max_H != (i32)0x80000000 && max_t >= ez.max_t && r - max_t >= ez.max_q )
+        {
+            const i32 tl = max_t - ez.max_t, ql = ( r - max_t ) - ez.max_q;
+            const i32 l = tl > ql ? tl - ql : ql - tl;
+            if( J.zdrop >= 0 && (i32)( ez.max - (u32)max_H ) > J.zdrop + l * e2 )
+            {
+                ez.zdropped = 1;
+                stop = true;
+            }
+        }
+        if( !stop && r == qlen + tlen - 2 && en0 == tlen - 1 )
+            ez.score = hEnd;
+        if( EARLY && early && r >= qlen - 1 )
+        {
+            // early stop of pipeline extensions (proof in ksw_reg.h)
+            i32 bnd = (i32)0x80000000;
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+            {
+                const i32 tt = TT[ s ];
+                if( tt >= st0 && tt <= en0 )
+                    bnd = max( bnd, Hlo[ s ] + sc_mch * min( qoff + tt, tlen - 1 - tt ) );
+                if( tt + 1 >= st0 && tt + 1 <= en0 )
+                    bnd = max( bnd, Hhi[ s ] + sc_mch * min( qoff + tt + 1, tlen - 2 - tt ) );
+            }
+            bnd = wave_max_i32( bnd );
+            if( r >= qlen && max( max( bnd, boundPrev ), topH + sc_mch * qlen ) <= (i32)ez.max )
+                stop = true;
+            boundPrev = bnd;
+        }
+        topH += uInit; // H(r,-1)
+        last_st = st;
+        last_en = en;
+    }
+    __syncthreads( ); // direction bytes of all lanes visible to the back-trace
+    i32 i0 = -1, j0b = -1;
+    if( !ez.zdropped && !( J.flag & KSW_EZ_EXTZ_ONLY ) )
+        i0 = tlen - 1, j0b = qlen - 1;
+    else if( !ez.zdropped && ( J.flag & KSW_EZ_EXTZ_ONLY ) && ez.mqe > (i32)ez.max )
+    {
+        ez.reach_end = 1;
+        i0 = ez.mqe_t, j0b = qlen - 1;
+    }
+    else if( ez.max_t >= 0 && ez.max_q >= 0 )
+        i0 = ez.max_t, j0b = ez.max_q;
+    else
+        return;
+    ksw_backtrack_lane0( P, cig, (i64)n_col, qlen, tlen, w, J.flag, i0, j0b, nCigar, pathSteps, qr, ldsBytes );
+}
+} // namespace ma
+#endif
