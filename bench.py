@@ -129,11 +129,13 @@ def main():
             torch.cuda.set_device(local_rank)
             a = acc[i]
             for k in range(i, K, NB):
+                tk = time.perf_counter()
                 step(i, k)
                 bt = batches[i][0]
                 km = bt.kernel_ms().astype(np.float64)
                 if os.environ.get("MA_BENCH_VERBOSE"):
-                    print("step %d stage ms %s" % (k, np.round(km[:6], 2).tolist()), file=sys.stderr, flush=True)
+                    print("step %d wall %.1f ms, stage ms %s" % (k, (time.perf_counter() - tk) * 1e3, np.round(km[:6], 2).tolist()),
+                          file=sys.stderr, flush=True)
                 a["kms"] += km
                 a["ctr"] += bt.counters().astype(np.float64)
                 c = bt.counts()

@@ -266,18 +266,7 @@ __global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, KswJo
         u64 cells = 0, path = 0;
         auto qf = F.qfetch( slot );
         auto tf = F.tfetch( slot );
-        const bool h16 = ksw_h16( SC, J.qlen, J.tlen );
-        if( J.flag & KSW_EZ_RIGHT )
-        {
-            if( h16 )
-                ksw_pk_core<S, int16_t, 8, FETCH::EARLY, false>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
-            else
-                ksw_pk_core<S, int32_t, 4, FETCH::EARLY, false>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
-        }
-        else if( h16 )
-            ksw_pk_core<S, int16_t, 8, FETCH::EARLY, true>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
-        else
-            ksw_pk_core<S, int32_t, 4, FETCH::EARLY, true>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
+        ksw_pk_core<S, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
         ksw_publish( O, acc, slot, ez, nCig, cells, path, cig, &sOff );
     }
     ksw_flush( O, acc );
@@ -425,7 +414,11 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     u64 regWaves = std::min<u64>( 256ull * perCu, nJobs );
     if( regStride * regWaves > ( 24ull << 30 ) )
         regWaves = std::max<u64>( 1, ( 24ull << 30 ) / regStride );
-    const u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0 );
+    u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0 );
+    // the per-wave scratch follows the LARGEST job of the batch, which varies a lot from batch to batch for long
+    // reads: once it is in the GB range take the whole budget so that later batches never re-allocate mid-step
+    if( need > ( 2ull << 30 ) )
+        need = 24ull << 30;
     if( scratch.reserve( need ) )
         return 1;
     const u32 ldsReg = std::max<u32>( (u32)( ( ( SZ.qlen + 15 ) / 16 ) * 16 + 64 ), KSW_REG_LDS );

@@ -35,7 +35,10 @@ __device__ __forceinline__ i32 pk_hi8( u32 x ) // int8 value of the high half
     return (i32)x >> 24;
 }
 
-template <int R, typename TH, int HL, bool EARLY, bool LEFT, typename QF, typename TF>
+// The int16 / int32 flavour of H (riskOfOverflow) and the left / right aligned variant are run-time (wave-uniform)
+// switches, not template parameters: four instantiations inlined into one launch kernel pushed the register
+// allocator from ~110 to 248 VGPRs plus scratch.
+template <int R, bool EARLY, typename QF, typename TF>
 __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, uint8_t* qr /*LDS*/,
                              uint8_t* P /*HBM direction bytes*/, u32* cig, KswEz& ez, u32& nCigar, u64& cells,
                              u64& pathSteps, u32 ldsBytes )
@@ -81,12 +84,16 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     const i32 long_diff = long_thres * ( e - e2 ) - ( q2 - q ) - e2;
     const i32 L = ( ( tlen + 15 ) / 16 ) * 16;
     const i32 qrBytes = ( ( qlen + 15 ) / 16 ) * 16 + 32;
-    const i32 NEG = sizeof( TH ) == 2 ? -32768 : (i32)0x80000000;
+    const bool h16 = ksw_h16( SC, qlen, tlen );
+    const i32 HL = h16 ? 8 : 4, HLs = h16 ? 3 : 2; // lanes of one SSE register of H, log2
+    const bool LEFT = !( J.flag & KSW_EZ_RIGHT );
+    auto TH = [ & ]( i32 x ) -> i32 { return h16 ? (i32)(int16_t)x : x; };
+    const i32 NEG = h16 ? -32768 : (i32)0x80000000;
     auto initOf = [ & ]( i32 r ) -> i32 {
         return (int8_t)( r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2 );
     };
     // tags (ksw_ext.h): LEFT keeps the first maximum of (s, a, b, a2, b2): d = 4 - tag; RIGHT the last of (s, a, b, a2)
-    constexpr u32 tS = LEFT ? 4 : 0, tX = LEFT ? 3 : 1, tY = 2, tX2 = LEFT ? 1 : 3, tY2 = 0;
+    const u32 tS = LEFT ? 4 : 0, tX = LEFT ? 3 : 1, tY = 2, tX2 = LEFT ? 1 : 3, tY2 = 0;
     const u32 K_X0 = pk_val( -q - e, tX ), K_Y0 = pk_val( -q - e, tY ), K_X20 = pk_val( -q2 - e2, tX2 ),
               K_Y20 = pk_val( -q2 - e2, tY2 ), K_V0 = pk_val( -q - e, 0 ), K_S0 = pk_val( 0, tS );
     const u32 K_TX = pk_val( 0, tX ), K_TY = pk_val( 0, tY ), K_TX2 = pk_val( 0, tX2 ), K_TY2 = pk_val( 0, tY2 );
@@ -186,7 +193,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         uint8_t* pr = P + (size_t)r * (size_t)n_col - st;
         cells += (u64)( en - st + 1 );
         const i32 hi = max( en, pEnd - 1 );
-        const i32 en1 = st0 + ( ( en0 - st0 ) / HL ) * HL;
+        const i32 en1 = st0 + ( ( ( en0 - st0 ) >> HLs ) << HLs );
         const int b0 = st >> 7, j0 = b0 % R;
         const int stLane = ( st >> 1 ) & 63; // cell st = low half of this lane of slot j0
         // previous-lane views (lane i <- lane i-1; lane 0 continues lane 63 of the previous slot of the ring)
@@ -313,19 +320,19 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             const i32 ulo = pk_lo8( nu ), uhi = pk_hi8( nu ), vlo = pk_lo8( nv ), vhi = pk_hi8( nv );
             // H[en0] = en0 > 0 ? Hold[en0-1] + u[en0] : Hold[en0] + v[en0]
             if( tt == en0 )
-                hEn0c = (TH)( en0 > 0 ? hupLo + ulo : Hlo[ s ] + vlo );
+                hEn0c = TH( en0 > 0 ? hupLo + ulo : Hlo[ s ] + vlo );
             if( tt + 1 == en0 )
-                hEn0c = (TH)( hupHi + uhi );
+                hEn0c = TH( hupHi + uhi );
             if( r > 0 )
             {
                 if( tt >= st0 && tt < en0 )
                 {
-                    Hlo[ s ] = (TH)( Hlo[ s ] + vlo );
+                    Hlo[ s ] = TH( Hlo[ s ] + vlo );
                     laneMax = max( laneMax, Hlo[ s ] );
                 }
                 if( tt + 1 >= st0 && tt + 1 < en0 )
                 {
-                    Hhi[ s ] = (TH)( Hhi[ s ] + vhi );
+                    Hhi[ s ] = TH( Hhi[ s ] + vhi );
                     laneMax = max( laneMax, Hhi[ s ] );
                 }
             }
@@ -333,6 +340,8 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                 hSt0c = Hlo[ s ];
             if( tt + 1 == st0 )
                 hSt0c = Hhi[ s ];
+            // keep the slots' instruction streams apart: interleaving them multiplies the live temporaries by R
+            __builtin_amdgcn_sched_barrier( 0 );
         }
         i32 max_H, max_t, hEnd, hS;
         if( r > 0 )
@@ -366,14 +375,14 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                     if( tt >= st0 && tt < en0 )
                     {
                         if( tt < en1 )
-                            best_pair( bhL, bkL, Hlo[ s ], ( tt - st0 ) / HL );
+                            best_pair( bhL, bkL, Hlo[ s ], ( tt - st0 ) >> HLs );
                         else
                             tailL = Hlo[ s ];
                     }
                     if( tt + 1 >= st0 && tt + 1 < en0 )
                     {
                         if( tt + 1 < en1 )
-                            best_pair( bhH, bkH, Hhi[ s ], ( tt + 1 - st0 ) / HL );
+                            best_pair( bhH, bkH, Hhi[ s ], ( tt + 1 - st0 ) >> HLs );
                         else
                             tailH = Hhi[ s ];
                     }
@@ -395,9 +404,9 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                 // per class: the initial (H[en0], en0) wins ties; then independent horizontal maxima over the classes
                 i32 mh = hEn0, mt = en0;
                 if( bhL > hEn0 )
-                    mh = bhL, mt = st0 + bkL * HL;
+                    mh = bhL, mt = st0 + ( bkL << HLs );
                 {
-                    const i32 vh = bhH > hEn0 ? bhH : hEn0, vt = bhH > hEn0 ? st0 + bkH * HL : en0;
+                    const i32 vh = bhH > hEn0 ? bhH : hEn0, vt = bhH > hEn0 ? st0 + ( bkH << HLs ) : en0;
                     mh = max( mh, vh );
                     mt = max( mt, vt );
                 }
@@ -422,7 +431,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         else
         {
             // r == 0: H[0] = v[0] - (q+e) (kswcpp_core.h:244-249); cell 0 = low half of lane 0 of slot 0
-            const i32 h0 = (TH)( pk_lo8( (u32)lane_bcast( (i32)V[ 0 ], 0 ) ) - qe0 );
+            const i32 h0 = TH( pk_lo8( (u32)lane_bcast( (i32)V[ 0 ], 0 ) ) - qe0 );
             if( lane == 0 )
                 Hlo[ 0 ] = h0;
             max_H = h0;
