@@ -8,7 +8,7 @@
 // lower neighbour of cell st0 was cell st0-1 of the previous diagonal, a first-row cell is initialised before it
 // is used (kswcpp_core.h:580-585), and the back-trace cannot leave the rectangle.  So only true cells are
 // computed here.  A job that gets to r > w without having stopped is handed back (return false) and re-run by
-// the exact ring kernel (ksw_reg.h); with the early stop below that does not happen for short reads.
+// the exact kernel (ksw_pk.h); with the early stop below that does not happen for short reads.
 //
 // Layout.  One wavefront per job, TWO cells per lane: cell t lives in half (t & 1) of lane ((t mod RING) >> 1)
 // of register slot ((t mod RING) >> 7), RING = 128 * R cells.  The int8 difference vectors are kept as

@@ -48,13 +48,13 @@ struct KswWaveAcc
 };
 #define KSW_JOBS_PER_FETCH 8u // queue entries a wave takes per atomic
 
-// job classes by the number of ring slots they need (ksw_need_slots): 1, 2, <=4, <=9, else LDS kernel (class 3
+// job classes by the number of 128-cell ring slots they need (ksw_pk_slots): 1, 2, 3, <=5, else LDS kernel (class 3
 // shares the launch slot of the widest ring; class 4 = ksw_wave.h)
 #define KSW_S0 1
 #define KSW_S1 2
 #define KSW_S2 3
 #define KSW_S3 5
-#define KSW_N_CLASSES 7 // 0..3 ring kernels, 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots
+#define KSW_N_CLASSES 7 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
     const i32 n = ksw_pk_slots( qlen, tlen, w ); // 128-cell slots of the two-cells-per-lane kernel (ksw_pk.h)
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__( 64 ) k_ksw_ext( FETCH F, KswScoring SC, const
 }
 
 template <typename FETCH, int S>
-__global__ void __launch_bounds__( 64 ) k_ksw_reg( FETCH F, KswScoring SC, KswJobs JB, unsigned int* nextSlot,
+__global__ void __launch_bounds__( 64 ) k_ksw_pk( FETCH F, KswScoring SC, KswJobs JB, unsigned int* nextSlot,
                                                   uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
@@ -391,7 +391,7 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
 // the job slots of class k at lists + k * list_stride, SZ.cls[k] entries, and room for the jobs the extension
 // kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every launch scans
 // nSlots and there are no extension-kernel classes.
-#define KSW_REG_LDS 6144u // per-wave LDS of the ring kernels: reversed query, later the back-trace staging block
+#define KSW_REG_LDS 6144u // per-wave LDS of the exact register kernels: reversed query, later the back-trace staging block
 #define KSW_EXT_LDS 4096u // extension kernel: back-trace staging only (8 waves per SIMD fit)
 template <typename FETCH>
 int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
@@ -449,18 +449,18 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         auto cnt = [ & ]( int k ) { return pass ? std::min<u64>( nExt, 256 * 4 ) : SZ.cls[ k ]; };
         unsigned int* nx = next + ( pass ? 7 : 0 );
         if( cnt( 0 ) )
-            hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S0> ), grid( cnt( 0 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 0 ),
+            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S0> ), grid( cnt( 0 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 0 ),
                                 nx + 0, base, regStride, p_cap, ldsReg, O );
         if( cnt( 1 ) )
-            hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S1> ), grid( cnt( 1 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 1 ),
+            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S1> ), grid( cnt( 1 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 1 ),
                                 nx + 1, base, regStride, p_cap, ldsReg, O );
         if( cnt( 2 ) )
-            hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S2> ), grid( cnt( 2 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 2 ),
+            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S2> ), grid( cnt( 2 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 2 ),
                                 nx + 2, base, regStride, p_cap, ldsReg, O );
         if( cnt( 3 ) )
-            hipLaunchKernelGGL( ( k_ksw_reg<FETCH, KSW_S3> ), grid( cnt( 3 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 3 ),
+            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S3> ), grid( cnt( 3 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 3 ),
                                 nx + 3, base, regStride, p_cap, ldsReg, O );
-        if( !pass && cnt( 4 ) ) // a handed-back job always fits a ring kernel
+        if( !pass && cnt( 4 ) ) // a handed-back job always fits a register kernel
         {
             plan.ws.base = base;
             if( plan.lds_bytes > 48 * 1024 )

@@ -1,14 +1,14 @@
 // ksw_pk.h -- the exact kswcpp wavefront kernel (every ez field, every 16-aligned lane block of the SSE code with
-// its overshoot lanes; contract and bit-exactness rules in ksw_wave.h / ksw_reg.h) with TWO diagonal cells per lane:
+// its overshoot lanes; contract and bit-exactness rules in ksw_wave.h) with TWO diagonal cells per lane:
 // cell t lives in half (t & 1) of lane ((t >> 1) & 63) of ring slot ((t >> 7) mod R), a slot holds 128 cells.
 // The int8 difference vectors u,v,x,y,x2,y2 and the score profile are packed as value << 8 (+ a tie-break tag in
 // the low byte) in the two 16-bit halves of a VGPR, so one v_pk_* instruction advances two cells and ONE max chain
 // yields both z and the direction state (ksw_ext.h explains the encoding).  The exact score H stays 32 bit (two
 // registers per lane), so both the int16 and the int32 flavour of kswcpp (riskOfOverflow, kswcpp.h:101-115) run
 // here.  Everything else -- ring rotation with the 16-aligned window start, carry-in, first-row initialisation,
-// unaligned score-profile stride, calcMaxScore classes, z-drop, direction rows, back-trace -- is ksw_reg.h's logic.
+// unaligned score-profile stride, calcMaxScore classes, z-drop, direction rows, back-trace -- follows ksw_wave.h.
 // This is the kernel for wide bands (long reads: band 512, thousands of diagonals): per diagonal it issues roughly
-// half the VALU instructions of the one-cell-per-lane ring kernel.
+// half the VALU instructions of its one-cell-per-lane predecessor (profiles/).
 #pragma once
 #include "ksw_ext.h"
 
