@@ -57,6 +57,8 @@ struct KswWaveAcc
 #define KSW_N_CLASSES 7 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
+    if( qlen > 150000 )
+        return 4; // the register kernels keep the reversed query in LDS (160 KB per CU)
     const i32 n = ksw_pk_slots( qlen, tlen, w ); // 128-cell slots of the two-cells-per-lane kernel (ksw_pk.h)
     return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : ( n <= KSW_S3 ? 3 : 4 ) ) );
 }
@@ -421,7 +423,14 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         need = 24ull << 30;
     if( scratch.reserve( need ) )
         return 1;
-    const u32 ldsReg = std::max<u32>( (u32)( ( ( SZ.qlen + 15 ) / 16 ) * 16 + 64 ), KSW_REG_LDS );
+    const u32 ldsReg = std::max<u32>( (u32)( ( ( std::min<u64>( SZ.qlen, 150000 ) + 15 ) / 16 ) * 16 + 64 ), KSW_REG_LDS );
+    if( ldsReg > 48 * 1024 )
+    {
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReg ) );
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReg ) );
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReg ) );
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReg ) );
+    }
     uint8_t* base = scratch.as<uint8_t>( );
     u32* redo = lists ? lists + (u64)KSW_N_CLASSES * list_stride : nullptr;
     auto grid = [ & ]( u64 jobs ) { return dim3( (unsigned)std::max<u64>( 1, std::min<u64>( regWaves, jobs ) ) ); };

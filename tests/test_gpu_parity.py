@@ -284,7 +284,8 @@ def test_pipeline_vs_oracle_heuristics_long_reads(gpu_device, preset):
     g = rand_genome(9, [2600000, 1500000, 1000000], repeat_unit=300, repeat_copies=200, repeat_div=0.08)
     reads = (sample_reads(g, 600, 150, 31, sub=0.01) + sample_reads(g, 100, 150, 32, sub=0.06, n_rate=0.01)
              + sample_reads(g, 12, 6000, 33, sub=0.005, ins=0.003, dele=0.003)
-             + sample_reads(g, 2, 30000, 34, sub=0.03, ins=0.03, dele=0.04) + sample_reads(g, 20, 150, 35, random_frac=1.0))
+             + sample_reads(g, 2, 30000, 34, sub=0.03, ins=0.03, dele=0.04) + sample_reads(g, 20, 150, 35, random_frac=1.0)
+             + sample_reads(g, 1, 80000, 36, sub=0.01, ins=0.005, dele=0.005))  # > 48 KB of LDS for the reversed query
     gidx = ma_amd.Index.build(g)
     oidx = OrIndex.from_parts(gidx.download())
     res = oidx.align(reads, or_params(preset, 3), threads=8)
