@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=0, help="default: 1 M reads (<= 1 kb) or 100 k reads (long reads)")
+    ap.add_argument("--reads-per-step", type=int, default=0, help="default: 1 M reads (<= 1 kb), else 2 Gbase worth of reads")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--sub", type=float, default=0.005)
     ap.add_argument("--ins", type=float, default=0.0)
@@ -83,7 +83,7 @@ def main():
     t_index = time.perf_counter() - t0
 
     # ---- reads: every rank owns steps x reads_per_step reads (weak scaling), resident in HBM ---------
-    B = args.reads_per_step if args.reads_per_step > 0 else (1000000 if args.read_len <= 1000 else 100000)
+    B = args.reads_per_step if args.reads_per_step > 0 else (1000000 if args.read_len <= 1000 else max(10000, int(2e9 / args.read_len)))
     K, W = args.steps, args.warmup
     n_reads = B * K
     cap = int(n_reads * (args.read_len * (1.0 + 2 * args.ins) + 8)) + 1024

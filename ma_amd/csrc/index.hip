@@ -1,6 +1,7 @@
 // index.hip -- index handle: upload / download of the FMD-index + pack (FMIndex::vLoadFMIndex
 // fMIndex.h:555-663, Pack::vLoadCollection pack.h:271-470 replaced by ma_index_create), runtime helpers.
 #include "internal.h"
+#include <algorithm>
 #include <cstring>
 
 namespace ma
@@ -19,10 +20,10 @@ int DevBuf::reserve( size_t bytes )
 {
     if( bytes <= cap && p )
         return 0;
-    // growing an existing buffer: leave headroom, batch sizes of successive steps differ by a few per cent and a
-    // multi-GB hipFree + hipMalloc in the middle of a step costs far more than the memory
-    if( p )
-        bytes += bytes / 4;
+    // leave headroom: batch sizes of successive steps differ by a few per cent and a multi-GB hipFree + hipMalloc in
+    // the middle of a step costs seconds (an eighth, at most 4 GiB; index arrays are allocated once and pay it too)
+    if( bytes > ( 1u << 20 ) )
+        bytes += std::min<size_t>( bytes / 8, (size_t)4 << 30 );
     if( p )
     {
         (void)hipFree( p );

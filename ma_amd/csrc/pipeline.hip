@@ -1038,56 +1038,72 @@ int ma_seed_batch( ma_batch* b )
         return 0;
     }
     const bool smem = b->P.seeding_technique == 1;
-    const u32 seg_cap = ( smem ? 6 : 2 ) * b->max_qlen + 8;
+    const u32 worst_cap = ( smem ? 6 : 2 ) * b->max_qlen + 8; // segments one read can emit at most
     const u32 smem_cap = smem ? b->max_qlen + 2 : 0;
-    const u64 lane_bytes = (u64)seg_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment );
-    // resident lanes: up to 8 waves per SIMD on 256 CUs, bounded by the reads and by a staging budget of a third of
-    // the free HBM (a 10 kb read needs 0.8 MB of worst-case staging; with 288 GB that still keeps >100 k reads in
-    // flight, and a lane walks its read serially, so lanes in flight are what hides the gather latency)
-    u64 lanes = 256ull * 2048;
-    lanes = std::min<u64>( lanes, ( n + 255 ) / 256 * 256 );
-    {
-        size_t freeB = 0, totalB = 0;
-        MA_HIP( hipMemGetInfo( &freeB, &totalB ) );
-        const u64 have = b->stage.cap + b->smemA.cap + b->smemB.cap; // already ours
-        const u64 budget = std::max<u64>( 8ull << 30, ( (u64)freeB + have ) / 3 );
-        lanes = std::min<u64>( lanes, std::max<u64>( 256, ( budget / lane_bytes ) / 256 * 256 ) );
-    }
     b->segPoolCap = std::max<u64>( b->n_bases / 2 + 64 * n, 1024 );
     if( smem )
         b->segPoolCap *= 2;
-    if( b->stage.reserve( lanes * seg_cap * sizeof( ma_segment ) ) ||
-        ( smem && ( b->smemA.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ||
-                    b->smemB.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ) ) ||
-        b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
-        b->segOff.reserve( n * 8 ) || b->segCnt.reserve( n * 4 ) || b->seedStack.reserve( lanes * 2 * MA_SEED_STACK * 4 ) )
-        return 1;
-    SeedKernelArgs A;
-    A.X = b->idx->v;
-    A.P = seed_params( b->P );
-    A.reads = b->d_reads;
-    A.roff = b->d_roff;
-    A.n_reads = (u32)n;
-    A.stage = b->stage.as<ma_segment>( );
-    A.seg_cap = seg_cap;
-    A.smem_a = smem ? b->smemA.as<ma_segment>( ) : nullptr;
-    A.smem_b = smem ? b->smemB.as<ma_segment>( ) : nullptr;
-    A.smem_cap = smem_cap;
-    A.stack = b->seedStack.as<u32>( );
-    A.pool = b->segPool.as<ma_segment>( );
-    A.pool_read = b->segRead.as<u32>( );
-    A.pool_cap = b->segPoolCap;
-    A.seg_off = b->segOff.as<u64>( );
-    A.seg_cnt = b->segCnt.as<u32>( );
-    A.ctr = b->ctr.as<unsigned long long>( );
+    // Resident lanes: up to 8 waves per SIMD on 256 CUs, bounded by the reads and by a staging budget of a third of
+    // the free HBM.  A lane walks its read serially, so lanes in flight are what hides the gather latency; for long
+    // reads the worst-case staging (0.8 MB per 10 kb read) would leave too few of them, so the first attempt stages
+    // a quarter of a segment per base (>10x what reads produce: 242 segments per 10 kb read) and the
+    // stage is repeated with the worst case if any read overflowed.
+    size_t freeB = 0, totalB = 0;
+    MA_HIP( hipMemGetInfo( &freeB, &totalB ) );
+    const u64 have = b->stage.cap + b->smemA.cap + b->smemB.cap; // already ours
+    const u64 budget = std::max<u64>( 8ull << 30, ( (u64)freeB + have ) / 3 );
+    const u64 want = std::min<u64>( 256ull * 2048, ( n + 255 ) / 256 * 256 );
+    u32 seg_cap = worst_cap;
+    if( want * ( (u64)worst_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment ) ) > budget )
+        seg_cap = std::min<u32>( worst_cap, ( smem ? 3 : 1 ) * ( b->max_qlen / 4 ) + 64 );
+    if( const char* e = getenv( "MA_SEED_STAGE_CAP" ) ) // test hook: force a (too) small first attempt
+        seg_cap = std::min<u32>( worst_cap, (u32)std::max( 1, atoi( e ) ) );
+    for( int attempt = 0; attempt < 2; attempt++ )
     {
-        EvTimer t( b, 0 );
-        // reads up to 240 bases are staged in LDS (256 lanes x q_lds bytes <= 64 KB)
-        const u32 qb = (u32)( ( b->max_qlen + 7 ) / 8 * 8 + 4 );
-        A.q_lds = qb * 256 <= 64 * 1024 ? qb : 0;
-        hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
+        const u64 lane_bytes = (u64)seg_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment );
+        const u64 lanes = std::min<u64>( want, std::max<u64>( 256, ( budget / lane_bytes ) / 256 * 256 ) );
+        if( b->stage.reserve( lanes * seg_cap * sizeof( ma_segment ) ) ||
+            ( smem && ( b->smemA.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ||
+                        b->smemB.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ) ) ||
+            b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
+            b->segOff.reserve( n * 8 ) || b->segCnt.reserve( n * 4 ) || b->seedStack.reserve( lanes * 2 * MA_SEED_STACK * 4 ) )
+            return 1;
+        SeedKernelArgs A;
+        A.X = b->idx->v;
+        A.P = seed_params( b->P );
+        A.reads = b->d_reads;
+        A.roff = b->d_roff;
+        A.n_reads = (u32)n;
+        A.stage = b->stage.as<ma_segment>( );
+        A.seg_cap = seg_cap;
+        A.smem_a = smem ? b->smemA.as<ma_segment>( ) : nullptr;
+        A.smem_b = smem ? b->smemB.as<ma_segment>( ) : nullptr;
+        A.smem_cap = smem_cap;
+        A.stack = b->seedStack.as<u32>( );
+        A.pool = b->segPool.as<ma_segment>( );
+        A.pool_read = b->segRead.as<u32>( );
+        A.pool_cap = b->segPoolCap;
+        A.seg_off = b->segOff.as<u64>( );
+        A.seg_cnt = b->segCnt.as<u32>( );
+        A.ctr = b->ctr.as<unsigned long long>( );
+        {
+            EvTimer t( b, 0 );
+            // reads up to 240 bases are staged in LDS (256 lanes x q_lds bytes <= 64 KB)
+            const u32 qb = (u32)( ( b->max_qlen + 7 ) / 8 * 8 + 4 );
+            A.q_lds = qb * 256 <= 64 * 1024 ? qb : 0;
+            hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
+        }
+        MA_HIP( hipGetLastError( ) );
+        if( seg_cap == worst_cap )
+            break;
+        // reduced staging: did every read fit?
+        if( read_ctr( b ) )
+            return 1;
+        if( !( (u32)b->hctr[ CTR_ERR ] & MA_ERR_SEG_OVERFLOW ) )
+            break;
+        MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
+        seg_cap = worst_cap;
     }
-    MA_HIP( hipGetLastError( ) );
     b->stage_done = 1;
     return 0;
 }

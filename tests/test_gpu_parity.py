@@ -230,6 +230,15 @@ def test_pipeline_counters_match_oracle(small):
     assert int(counters[5]) == int(c[5])  # ksw calls
 
 
+def test_seed_staging_overflow_is_retried_with_full_capacity(small, monkeypatch):
+    """Long reads stage fewer segments per lane than the worst case; a read that overflows makes the stage run again
+    with the worst-case capacity (MA_SEED_STAGE_CAP forces the first attempt to be too small)."""
+    want = parse_pipe_dump(os.path.join(G, "small_ref.default.pipe.gz"))
+    monkeypatch.setenv("MA_SEED_STAGE_CAP", "2")
+    got, counters, counts = gpu_pipeline(small["gidx"], "default", 1, small["reads"])
+    compare_reads(got, want)
+
+
 def test_empty_and_ragged_batches(small):
     import ma_amd
     got, _, counts = gpu_pipeline(small["gidx"], "default", 1, [])
