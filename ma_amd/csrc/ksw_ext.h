@@ -186,6 +186,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     int8_t q = (int8_t)SC.q, e = (int8_t)SC.e, q2 = (int8_t)SC.q2, e2 = (int8_t)SC.e2;
     const i32 sc_mch = (int8_t)( SC.match < 0 ? -SC.match : SC.match );
     const i32 sc_mis = (int8_t)( SC.mismatch > 0 ? -SC.mismatch : SC.mismatch );
+    const i32 qe0 = q + e; // q+e before the swap: kswcpp seeds H[0] with it (kswcpp_core.h:244-249)
     if( q2 + e2 < q + e )
     {
         int8_t t = q;
@@ -255,7 +256,9 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     const unsigned long long tp0 = clock64( );
 #endif
     i32 recycled = 0; // cells below this index have been handed to cells RING further up
-    i32 hLeft = 0, hTop = 0; // H(-1, r-1) of the first column, H(r-1, -1) of the first row
+    // H(-1, r-1) of the first column, H(r-1, -1) of the first row.  (sic) When the two gap models were swapped, kswcpp's
+    // H[0] = v[0] - (q+e) uses the UNswapped sum, which offsets every score of the matrix by (q+e)_swapped - (q+e)_given.
+    i32 hLeft = ( q + e ) - qe0, hTop = ( q + e ) - qe0;
     i32 boundPrev = 0x7fffffff;
     const i32 nDiag = qlen + tlen - 1;
     bool stop = false;

@@ -207,6 +207,30 @@ def test_ksw_pipeline_semantics_vs_oracle(gpu_device):
     assert n_ext > 2000
 
 
+@pytest.mark.parametrize("scoring", [(3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 24, 1, 4, 2), (5, 4, 2, 1, 40, 1)])
+def test_ksw_other_scoring_schemes(gpu_device, scoring):
+    """match, mismatch, gap, extend, gap2, extend2 other than the presets' 2/4/4/2/24/1 (incl. the swapped order of the
+    two gap models, kswcpp_core.h:330-338): every ez field of the exact kernel and the pipeline semantics."""
+    import ma_amd
+    P = ma_amd.Params.preset("default")
+    op = or_params()
+    for prm in (P, op):
+        prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
+    cases = rand_ksw_cases(500, 900 + scoring[0], max_len=220) + rand_ksw_cases(6, 950, long_frac=1.0) + ext_shaped_cases(700, 55)
+    ez, cigs = ma_amd.ksw_batch(P, cases)
+    ez2, cigs2 = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
+    for i, (q, t, w, zd, fl) in enumerate(cases):
+        oez, ocig = or_ksw(op, q, t, w, zd, fl)
+        for f in oez.dtype.names:
+            assert int(ez[f][i]) == int(oez[f]), "case %d field %s (qlen %d tlen %d w %d zdrop %d flag %d)" % (
+                i, f, len(q), len(t), w, zd, fl)
+        assert np.array_equal(cigs[i], ocig), "case %d cigar" % i
+        if fl & KSW_EXTZ:
+            for f in ("max", "max_q", "max_t"):
+                assert int(ez2[f][i]) == int(oez[f]), "pipeline semantics: case %d field %s" % (i, f)
+        assert np.array_equal(cigs2[i], ocig), "pipeline semantics: case %d cigar" % i
+
+
 @pytest.mark.parametrize("preset,seed,name", [("default", 1, "small_ref.default.pipe"),
                                               ("illumina", 1, "small_ref.illumina.pipe"),
                                               ("default", 7, "small_ref.default.seed7.pipe")])
