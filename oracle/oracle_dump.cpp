@@ -89,6 +89,11 @@ int main( int argc, char** argv )
         std::vector<KswCase> v = readKswCases( argv[ 2 ] );
         ma_or_params P;
         ma_or_params_default( &P );
+        if( argc >= 11 ) // ksw <cases> <out> <dirty|clean> match mismatch gap extend gap2 extend2
+        {
+            P.match = atoi( argv[ 5 ] ), P.mismatch = atoi( argv[ 6 ] ), P.gap = atoi( argv[ 7 ] ), P.extend = atoi( argv[ 8 ] );
+            P.gap2 = atoi( argv[ 9 ] ), P.extend2 = atoi( argv[ 10 ] );
+        }
         FILE* f = fopen( argv[ 3 ], "w" );
         std::vector<uint32_t> cig( 1 << 20 );
         for( size_t i = 0; i < v.size( ); i++ )

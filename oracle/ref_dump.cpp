@@ -265,11 +265,11 @@ static int cmdExt( const char* sCase, const char* sOut )
     return 0;
 }
 
-static int cmdKsw( const char* sCase, const char* sOut, bool bDirty )
+static int cmdKsw( const char* sCase, const char* sOut, bool bDirty, const int* aSc )
 {
     std::vector<KswCase> v = readKswCases( sCase );
     FILE* f = fopen( sOut, "w" );
-    KswCppParam<5> xP( 2, 4, 4, 2, 24, 1 );
+    KswCppParam<5> xP( aSc[ 0 ], aSc[ 1 ], aSc[ 2 ], aSc[ 3 ], aSc[ 4 ], aSc[ 5 ] ); // match, mismatch, gap, extend, gap2, extend2
     AlignedMemoryManager xShared;
     for( size_t i = 0; i < v.size( ); i++ )
     {
@@ -309,7 +309,14 @@ int main( int argc, char** argv )
     if( argc >= 4 && !strcmp( argv[ 1 ], "ext" ) )
         return cmdExt( argv[ 2 ], argv[ 3 ] );
     if( argc >= 4 && !strcmp( argv[ 1 ], "ksw" ) )
-        return cmdKsw( argv[ 2 ], argv[ 3 ], argc >= 5 );
+    {
+        // ksw <cases> <out> [dirty|clean [match mismatch gap extend gap2 extend2]]
+        int aSc[ 6 ] = { 2, 4, 4, 2, 24, 1 };
+        if( argc >= 11 )
+            for( int i = 0; i < 6; i++ )
+                aSc[ i ] = atoi( argv[ 5 + i ] );
+        return cmdKsw( argv[ 2 ], argv[ 3 ], argc >= 5 && !strcmp( argv[ 4 ], "dirty" ), aSc );
+    }
     fprintf( stderr, "usage: ref_dump index|pipe|sam|read|ext|ksw ...\n" );
     return 2;
 }

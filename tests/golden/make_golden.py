@@ -62,6 +62,22 @@ def reader_goldens():
     gz(os.path.join("reader", "small24.fq.sam"))
 
 
+KSW_SCORINGS = [(3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 24, 1, 4, 2), (5, 4, 2, 1, 40, 1)]
+
+
+def ksw_scoring_goldens():
+    """G7b: the kswcpp cases of ksw.case under other (match, mismatch, gap, extend, gap2, extend2) than the presets'."""
+    made = not os.path.exists("ksw.case")
+    if made:
+        with gzip.open("ksw.case.gz", "rb") as g, open("ksw.case", "wb") as f:
+            shutil.copyfileobj(g, f)
+    for k, sc in enumerate(KSW_SCORINGS):
+        run_ref("ksw", "ksw.case", "ksw_ref.sc%d.out" % k, "clean", *sc)
+        gz("ksw_ref.sc%d.out" % k)
+    if made:
+        os.remove("ksw.case")
+
+
 def main():
     if not have_ref():
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle ref` where /root/reference exists")
@@ -86,6 +102,7 @@ def main():
     cases = rand_ksw_cases(600, 301, max_len=120) + rand_ksw_cases(12, 302, long_frac=1.0)
     write_ksw_cases("ksw.case", cases)
     run_ref("ksw", "ksw.case", "ksw_ref.out")
+    ksw_scoring_goldens()
     for f in ("small_ref.ext", "small_ref.default.pipe", "small_ref.illumina.pipe", "small_ref.default.seed7.pipe",
               "ksw_ref.out", "small.case", "ksw.case", "small_ref.bwt", "small_ref.sa", "small_ref.pac"):
         gz(f)

@@ -120,12 +120,21 @@ def test_extend_backward_and_bwt_sa(small):
     assert np.array_equal(gidx.bwt_sa(rows), oidx.bwt_sa(rows))
 
 
-def test_ksw_golden_cases(gpu_device, tmp_path):
+# reference outputs for ksw.case under the presets' scoring and under make_golden.py's KSW_SCORINGS
+KSW_GOLDEN = [("ksw_ref.out.gz", None), ("ksw_ref.sc0.out.gz", (3, 5, 6, 3, 30, 2)), ("ksw_ref.sc1.out.gz", (1, 3, 5, 2, 24, 1)),
+              ("ksw_ref.sc2.out.gz", (2, 4, 24, 1, 4, 2)), ("ksw_ref.sc3.out.gz", (5, 4, 2, 1, 40, 1))]
+
+
+@pytest.mark.parametrize("name,scoring", KSW_GOLDEN)
+def test_ksw_golden_cases(gpu_device, tmp_path, name, scoring):
     import ma_amd
     case = gunzip_to(os.path.join(G, "ksw.case.gz"), str(tmp_path / "ksw.case"))
-    ref = parse_ksw_dump(os.path.join(G, "ksw_ref.out.gz"))
+    ref = parse_ksw_dump(os.path.join(G, name))
     cases = read_ksw_cases(case)
-    ez, cigs = ma_amd.ksw_batch(ma_amd.Params.preset("default"), cases)
+    P = ma_amd.Params.preset("default")
+    if scoring:
+        P.match, P.mismatch, P.gap, P.extend, P.gap2, P.extend2 = scoring
+    ez, cigs = ma_amd.ksw_batch(P, cases)
     for i, w in enumerate(ref):
         for f in ("max", "zdropped", "max_q", "max_t", "mqe", "mqe_t", "mte", "mte_q", "score", "reach_end", "n_cigar"):
             assert int(ez[f][i]) == w[f], "case %d field %s: %d vs %d (qlen %d tlen %d w %d zdrop %d flag %d)" % (
@@ -210,7 +219,7 @@ def test_ksw_pipeline_semantics_vs_oracle(gpu_device):
 @pytest.mark.parametrize("scoring", [(3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 24, 1, 4, 2), (5, 4, 2, 1, 40, 1)])
 def test_ksw_other_scoring_schemes(gpu_device, scoring):
     """match, mismatch, gap, extend, gap2, extend2 other than the presets' 2/4/4/2/24/1 (incl. the swapped order of the
-    two gap models, kswcpp_core.h:330-338): every ez field of the exact kernel and the pipeline semantics."""
+    two gap models, kswcpp_core.h:366-376): every ez field of the exact kernel and the pipeline semantics."""
     import ma_amd
     P = ma_amd.Params.preset("default")
     op = or_params()

@@ -44,10 +44,22 @@ def test_pipeline_dump_identical(small_case, preset, seed, name):
     assert first_diff(ref, out) is None
 
 
+# (match, mismatch, gap, extend, gap2, extend2) of tests/golden/ksw_ref.sc<k>.out.gz (make_golden.py KSW_SCORINGS)
+KSW_SCORINGS = [(3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 24, 1, 4, 2), (5, 4, 2, 1, 40, 1)]
+
+
 def test_ksw_golden(tmp_path):
     case = gunzip_to(os.path.join(G, "ksw.case.gz"), str(tmp_path / "ksw.case"))
     run_oracle("ksw", case, str(tmp_path / "or.out"))
     ref = gunzip_to(os.path.join(G, "ksw_ref.out.gz"), str(tmp_path / "ref.out"))
+    assert first_diff(ref, str(tmp_path / "or.out")) is None
+
+
+@pytest.mark.parametrize("k", range(len(KSW_SCORINGS)))
+def test_ksw_golden_other_scorings(tmp_path, k):
+    case = gunzip_to(os.path.join(G, "ksw.case.gz"), str(tmp_path / "ksw.case"))
+    run_oracle("ksw", case, str(tmp_path / "or.out"), "clean", *KSW_SCORINGS[k])
+    ref = gunzip_to(os.path.join(G, "ksw_ref.sc%d.out.gz" % k), str(tmp_path / "ref.out"))
     assert first_diff(ref, str(tmp_path / "or.out")) is None
 
 

@@ -20,6 +20,21 @@ def test_ksw_random_cases(tmp_path):
     assert first_diff(str(tmp_path / "ref.out"), str(tmp_path / "or.out")) is None
 
 
+# match, mismatch, gap, extend, gap2, extend2 -- the third has q2 + e2 < q + e, which makes
+# kswcpp swap the two models internally (kswcpp_core.h:367-377) while still seeding H[0] from the un-swapped one
+OTHER_SCORINGS = [(3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 24, 1, 4, 2), (5, 4, 2, 1, 40, 1)]
+
+
+@pytest.mark.parametrize("sc", OTHER_SCORINGS)
+def test_ksw_other_scoring_schemes(tmp_path, sc):
+    cases = rand_ksw_cases(1500, 993 + sc[0], max_len=150) + rand_ksw_cases(12, 994, long_frac=1.0)
+    p = str(tmp_path / "k.case")
+    write_ksw_cases(p, cases)
+    run_ref("ksw", p, str(tmp_path / "ref.out"), "clean", *sc)
+    run_oracle("ksw", p, str(tmp_path / "or.out"), "clean", *sc)
+    assert first_diff(str(tmp_path / "ref.out"), str(tmp_path / "or.out")) is None
+
+
 @pytest.mark.parametrize("preset", ["default", "illumina"])
 def test_pipeline_with_heuristics_and_repeats(tmp_path, preset):
     # doubled length > 10 Mnt so that the genome-size gated heuristics are active
