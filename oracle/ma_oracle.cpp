@@ -63,6 +63,13 @@ extern "C" void ma_or_params_default( ma_or_params* p )
     p->report_n_best = 0;
     p->max_supplementary = 1;
     p->max_overlap_supplementary = 0.1;
+    p->search_inversions = 0;
+    p->zdrop_inversion = 100;
+    p->use_paired_reads = 0;
+    p->pad_ = 0;
+    p->mean_paired_dist = 400;
+    p->std_paired_dist = 150;
+    p->paired_bonus = 1.25;
 }
 
 extern "C" void ma_or_params_illumina( ma_or_params* p )
@@ -455,6 +462,8 @@ struct Aln // alignment.h:55-84
     uint32_t socIndex = 0;
     bool secondary = false, supplementary = false;
     double mapq = NAN;
+    bool first = false; // AlignmentStatistics::bFirst (seed.h:227)
+    int other = -1; // xStats.pOther: index of the mate's alignment in the PairedReads output
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -926,4 +935,5 @@ extern "C" int32_t ma_or_rand( uint32_t state[ 35 ] )
 #include "ma_oracle_harm.inc"
 #include "ma_oracle_ksw.inc"
 #include "ma_oracle_nw.inc"
+#include "ma_oracle_f4.inc"
 #include "ma_oracle_api.inc"

@@ -47,6 +47,29 @@ int main( int argc, char** argv )
         }
         return ma_or_dump_pipe( x, &P, cat.data( ), off.data( ), c.reads.size( ), argv[ 5 ] );
     }
+    if( argc >= 9 && !strcmp( argv[ 1 ], "f4" ) ) // f4 <case> <preset> <seed> <out> <inversions> <paired> <zdrop_inversion>
+    {
+        CaseFile c = readCase( argv[ 2 ] );
+        ma_or_index* x = build( c );
+        ma_or_params P;
+        if( !strcmp( argv[ 3 ], "illumina" ) )
+            ma_or_params_illumina( &P );
+        else
+            ma_or_params_default( &P );
+        P.srand_seed = (uint32_t)atoi( argv[ 4 ] );
+        P.search_inversions = atoi( argv[ 6 ] );
+        P.use_paired_reads = atoi( argv[ 7 ] );
+        P.zdrop_inversion = atoi( argv[ 8 ] );
+        std::vector<uint8_t> cat;
+        std::vector<uint64_t> off{ 0 };
+        for( auto& r : c.reads )
+        {
+            cat.insert( cat.end( ), r.begin( ), r.end( ) );
+            off.push_back( cat.size( ) );
+        }
+        cat.push_back( 0 );
+        return ma_or_dump_f4( x, &P, cat.data( ), off.data( ), c.reads.size( ), argv[ 5 ] );
+    }
     if( argc >= 4 && !strcmp( argv[ 1 ], "ext" ) )
     {
         CaseFile c = readCase( argv[ 2 ] );

@@ -9,6 +9,8 @@
 //   ref_dump pipe  <case> <preset> <srand_seed> <out>   -> per-read stage dump
 //   ref_dump ext   <case> <out>                        -> extend_backward traces
 //   ref_dump ksw   <kswcase> <out> [dirty]             -> kswcpp_dispatch results
+//   ref_dump f4    <case> <preset> <seed> <out> <inversions 0|1> <paired 0|1> <zdrop_inversion> [<out.sam> [<sam options>]]
+//                                                      -> SmallInversions / PairedReads lists (+ SAM of the (Paired)FileWriter)
 #include "ma/container/fMIndex.h"
 #include "ma/container/pack.h"
 #include "ma/module/binarySeeding.h"
@@ -17,6 +19,8 @@
 #include "ma/module/harmonization.h"
 #include "ma/module/mappingQuality.h"
 #include "ma/module/needlemanWunsch.h"
+#include "ma/module/pairedReads.h"
+#include "ma/module/smallInversions.h"
 #include "ma/module/stripOfConsideration.h"
 #include "kswcpp.h"
 #include "dump_format.h"
@@ -203,6 +207,105 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     return 0;
 }
 
+// MappingQuality -> [SmallInversions] -> [PairedReads] -> (Paired)FileWriter, as wired in
+// setUpCompGraph / setUpCompGraphPaired (export.cpp:72-202); reads 2k and 2k+1 of the case are the mates of pair k
+static void dumpF4Line( FILE* f, const char* tag, const std::shared_ptr<Alignment>& pA, int iOther )
+{
+    fprintf( f, "%s %d %d %llu %llu %llu %llu %lld %u %d %d %.17g %zu", tag, (int)pA->xStats.bFirst, iOther,
+             (unsigned long long)pA->uiBeginOnRef, (unsigned long long)pA->uiEndOnRef, (unsigned long long)pA->uiBeginOnQuery,
+             (unsigned long long)pA->uiEndOnQuery, (long long)pA->iScore, pA->xStats.index_of_strip, (int)pA->bSecondary,
+             (int)pA->bSupplementary, pA->fMappingQuality, pA->data.size( ) );
+    for( auto& d : pA->data )
+        fprintf( f, " %d:%llu", (int)d.first, (unsigned long long)d.second );
+    fprintf( f, "\n" );
+}
+static int cmdF4( const char* sCase, const char* sPreset, unsigned uiSeed, const char* sOut, bool bInv, bool bPaired,
+                  int iZDropInv, const char* sSam, int iOptions )
+{
+    CaseFile c = readCase( sCase );
+    RefIndex idx = buildIndex( c );
+    ParameterSetManager xParams;
+    xParams.setSelected( sPreset );
+    xParams.getSelected( )->xSearchInversions->set( bInv );
+    xParams.getSelected( )->xZDropInversion->set( iZDropInv );
+    xParams.getSelected( )->xSoftClip->set( ( iOptions & 1 ) != 0 );
+    xParams.getSelected( )->xOutputMCigar->set( ( iOptions & 2 ) == 0 );
+    BinarySeeding xSeeding( xParams );
+    StripOfConsideration xSoc( xParams );
+    Harmonization xHarm( xParams );
+    NeedlemanWunsch xDp( xParams );
+    MappingQuality xMq( xParams );
+    SmallInversions xInv( xParams );
+    PairedReads xPair( xParams );
+    FILE* f = fopen( sOut, "w" );
+    FILE* fSam = sSam ? fopen( sSam, "w" ) : nullptr;
+    std::shared_ptr<FileWriter> pWriter;
+    std::shared_ptr<PairedFileWriter> pPairedWriter;
+    if( fSam && bPaired )
+        pPairedWriter = std::make_shared<PairedFileWriter>( xParams, std::make_shared<CaptureStream>( fSam ), idx.pPack );
+    else if( fSam )
+        pWriter = std::make_shared<FileWriter>( xParams, std::make_shared<CaptureStream>( fSam ), idx.pPack );
+    auto fFinal = [ & ]( std::shared_ptr<NucSeq> pQ ) {
+        auto pSegs = xSeeding.execute( idx.pFM, pQ );
+        auto pSocs = xSoc.execute( pSegs, pQ, idx.pPack, idx.pFM );
+        srand( uiSeed );
+        auto pHarm = xHarm.execute( pSocs, pQ, idx.pFM );
+        auto pAlns = xDp.execute( pHarm, pQ, idx.pPack );
+        auto pMq = xMq.execute( pQ, pAlns );
+        return bInv ? xInv.execute( pMq, pQ, idx.pPack ) : pMq;
+    };
+    std::vector<std::shared_ptr<NucSeq>> vReads;
+    for( size_t i = 0; i < c.reads.size( ); i++ )
+    {
+        vReads.push_back( mkSeq( c.reads[ i ] ) );
+        vReads.back( )->sName = "r" + std::to_string( i );
+    }
+    if( !bPaired )
+        for( size_t i = 0; i < vReads.size( ); i++ )
+        {
+            auto pFin = fFinal( vReads[ i ] );
+            fprintf( f, "R %zu %llu\nFIN 0 %zu\n", i, (unsigned long long)vReads[ i ]->length( ), pFin->size( ) );
+            for( auto& pA : *pFin )
+                dumpF4Line( f, "f", pA, -1 );
+            if( pWriter )
+                pWriter->execute( vReads[ i ], pFin, idx.pPack );
+        }
+    else
+        for( size_t k = 0; 2 * k + 1 < vReads.size( ); k++ )
+        {
+            auto pQ1 = vReads[ 2 * k ], pQ2 = vReads[ 2 * k + 1 ];
+            auto pFin1 = fFinal( pQ1 ), pFin2 = fFinal( pQ2 );
+            auto pPair = xPair.execute( pQ1, pQ2, pFin1, pFin2, idx.pPack );
+            fprintf( f, "P %zu %llu %llu\n", k, (unsigned long long)pQ1->length( ), (unsigned long long)pQ2->length( ) );
+            fprintf( f, "FIN 0 %zu\n", pFin1->size( ) );
+            for( auto& pA : *pFin1 )
+                dumpF4Line( f, "f", pA, -1 );
+            fprintf( f, "FIN 1 %zu\n", pFin2->size( ) );
+            for( auto& pA : *pFin2 )
+                dumpF4Line( f, "f", pA, -1 );
+            fprintf( f, "PAIR %zu\n", pPair->size( ) );
+            for( auto& pA : *pPair )
+            {
+                int iOther = -1;
+                auto pO = pA->xStats.pOther.lock( );
+                for( size_t j = 0; pO != nullptr && j < pPair->size( ); j++ )
+                    if( ( *pPair )[ j ] == pO )
+                        iOther = (int)j;
+                dumpF4Line( f, "p", pA, iOther );
+            }
+            if( pPairedWriter )
+                pPairedWriter->execute( pQ1, pQ2, pPair, idx.pPack );
+        }
+    fclose( f );
+    if( fSam )
+    {
+        pWriter.reset( );
+        pPairedWriter.reset( );
+        fclose( fSam );
+    }
+    return 0;
+}
+
 // reads of a FASTA / FASTQ file as the reference's FileReader (fileReader.cpp:37-196) returns them
 static int cmdRead( const char* sIn, const char* sOut )
 {
@@ -304,6 +407,9 @@ int main( int argc, char** argv )
     if( argc >= 6 && !strcmp( argv[ 1 ], "sam" ) )
         return cmdSam( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ], argc >= 7 ? atoi( argv[ 6 ] ) : 0,
                        argc >= 8 ? argv[ 7 ] : nullptr );
+    if( argc >= 9 && !strcmp( argv[ 1 ], "f4" ) )
+        return cmdF4( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ], atoi( argv[ 6 ] ) != 0, atoi( argv[ 7 ] ) != 0,
+                      atoi( argv[ 8 ] ), argc >= 10 ? argv[ 9 ] : nullptr, argc >= 11 ? atoi( argv[ 10 ] ) : 0 );
     if( argc >= 4 && !strcmp( argv[ 1 ], "read" ) )
         return cmdRead( argv[ 2 ], argv[ 3 ] );
     if( argc >= 4 && !strcmp( argv[ 1 ], "ext" ) )
@@ -317,6 +423,6 @@ int main( int argc, char** argv )
                 aSc[ i ] = atoi( argv[ 5 + i ] );
         return cmdKsw( argv[ 2 ], argv[ 3 ], argc >= 5 && !strcmp( argv[ 4 ], "dirty" ), aSc );
     }
-    fprintf( stderr, "usage: ref_dump index|pipe|sam|read|ext|ksw ...\n" );
+    fprintf( stderr, "usage: ref_dump index|pipe|sam|f4|read|ext|ksw ...\n" );
     return 2;
 }

@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from ma_testlib import (rand_genome, sample_reads, write_case, write_ksw_cases, rand_ksw_cases, run_ref, have_ref)  # noqa
+from ma_testlib import (sample_inversion_reads, sample_pairs, rand_genome, sample_reads, write_case, write_ksw_cases, rand_ksw_cases, run_ref, have_ref)  # noqa
 
 
 def gz(path):
@@ -78,6 +78,29 @@ def ksw_scoring_goldens():
         os.remove("ksw.case")
 
 
+# (preset, search inversions, paired, Z Drop Inversions, SAM options) of the f4 goldens
+F4_CONFIGS = [("default", 1, 0, 100, 0), ("default", 1, 1, 100, 0), ("illumina", 0, 1, 100, 3), ("default", 1, 1, 40, 1)]
+
+
+def f4_name(preset, inv, paired, zd, opt):
+    return "f4.%s.inv%d.pair%d.zd%d.opt%d" % (preset, inv, paired, zd, opt)
+
+
+def f4_goldens():
+    """f4: SmallInversions + PairedReads + PairedFileWriter of the reference on mate pairs and reads with small inversions."""
+    g = rand_genome(101, [30000, 22000, 9000], repeat_unit=200, repeat_copies=25, repeat_div=0.06)  # = small.case
+    reads = (sample_pairs(g, 120, 150, 401) + sample_pairs(g, 10, 250, 402, sub=0.04, insert_mean=600, insert_std=200)
+             + sample_inversion_reads(g, 16, 1200, 403))
+    write_case("f4.case", g, reads)
+    for cfg in F4_CONFIGS:
+        preset, inv, paired, zd, opt = cfg
+        nm = f4_name(*cfg)
+        run_ref("f4", "f4.case", preset, 1, nm + ".f4", inv, paired, zd, nm + ".sam", opt)
+        gz(nm + ".f4")
+        gz(nm + ".sam")
+    gz("f4.case")
+
+
 def main():
     if not have_ref():
         sys.exit("oracle/_ref/ref_dump missing: run `make -C oracle ref` where /root/reference exists")
@@ -103,6 +126,7 @@ def main():
     write_ksw_cases("ksw.case", cases)
     run_ref("ksw", "ksw.case", "ksw_ref.out")
     ksw_scoring_goldens()
+    f4_goldens()
     for f in ("small_ref.ext", "small_ref.default.pipe", "small_ref.illumina.pipe", "small_ref.default.seed7.pipe",
               "ksw_ref.out", "small.case", "ksw.case", "small_ref.bwt", "small_ref.sa", "small_ref.pac"):
         gz(f)

@@ -83,6 +83,64 @@ def sample_reads(contigs, n, length, seed, sub=0.01, ins=0.0, dele=0.0, n_rate=0
     return reads
 
 
+def _mutate(src, rng, sub):
+    out = np.array(src, dtype=np.uint8).copy()
+    hit = rng.random(len(out)) < sub
+    out[hit] = (out[hit] + rng.integers(1, 4, size=int(hit.sum()))) % 4
+    return out
+
+
+def sample_inversion_reads(contigs, n, length, seed, inv_min=120, inv_max=400, sub=0.01):
+    """Reads whose inner stretch is reverse-complemented in place (a small inversion without seeds of its own
+    orientation in the chain): what SmallInversions (smallInversions.h) looks for."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for i in range(n):
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        L = min(length, len(c))
+        p = int(rng.integers(0, len(c) - L + 1))
+        rd = _mutate(c[p:p + L], rng, sub)
+        w = int(rng.integers(inv_min, inv_max + 1))
+        a = int(rng.integers(L // 4, max(L // 4 + 1, 3 * L // 4 - w)))
+        rd[a:a + w] = revcomp(rd[a:a + w])
+        if i % 2 == 1:
+            rd = revcomp(rd)
+        reads.append(rd)
+    return reads
+
+
+def sample_pairs(contigs, n, length, seed, insert_mean=400, insert_std=60, sub=0.01, far_frac=0.1, same_strand_frac=0.05,
+                 random_mate_frac=0.08):
+    """Mate pairs (reads 2k, 2k+1) as PairedReads (pairedReads.cpp) expects them after PairedFileReader: opposite
+    strands, outer distance ~ insert_mean; some pairs too far apart, on the same strand, or with a random mate."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for k in range(n):
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        d = max(length + 1, int(rng.normal(insert_mean, insert_std)))
+        if rng.random() < far_frac:
+            d = int(rng.integers(2000, 6000))
+        d = min(d, len(c) - 1)
+        p = int(rng.integers(0, len(c) - d))
+        m1 = _mutate(c[p:p + length], rng, sub)
+        m2 = _mutate(c[p + d - length:p + d], rng, sub)
+        if rng.random() >= same_strand_frac:
+            m2 = revcomp(m2)
+        if k % 2 == 1:  # the pair seen from the other strand
+            m1, m2 = revcomp(m1), revcomp(m2)
+            m1, m2 = m2, m1
+        r = rng.random()
+        if r < random_mate_frac / 2:
+            m1 = rng.integers(0, 4, size=length, dtype=np.uint8)
+        elif r < random_mate_frac:
+            m2 = rng.integers(0, 4, size=length, dtype=np.uint8)
+        elif r < random_mate_frac * 1.25:
+            m1 = rng.integers(0, 4, size=length, dtype=np.uint8)
+            m2 = rng.integers(0, 4, size=length, dtype=np.uint8)
+        reads += [m1, m2]
+    return reads
+
+
 def write_case(path, contigs, reads, names=None):
     with open(path, "wb") as f:
         f.write(b"MACASE01")

@@ -95,3 +95,18 @@ def test_counters_are_consistent(small_case):
     assert c[0] > 0 and c[0] <= c[1] <= 2 * c[0]  # blocks per extend_backward in [1,2]
     assert c[3] == len(res["seeds"])
     assert c[5] > 0 and c[4] > 0
+
+
+# (preset, search inversions, paired, Z Drop Inversions, SAM options) of tests/golden/f4.* (make_golden.py F4_CONFIGS)
+F4_CONFIGS = [("default", 1, 0, 100, 0), ("default", 1, 1, 100, 0), ("illumina", 0, 1, 100, 3), ("default", 1, 1, 40, 1)]
+
+
+@pytest.mark.parametrize("cfg", F4_CONFIGS)
+def test_f4_golden(tmp_path, cfg):
+    """SmallInversions + PairedReads of the oracle against the reference's lists."""
+    preset, inv, paired, zd, opt = cfg
+    nm = "f4.%s.inv%d.pair%d.zd%d.opt%d" % cfg
+    case = gunzip_to(os.path.join(G, "f4.case.gz"), str(tmp_path / "f4.case"))
+    run_oracle("f4", case, preset, 1, str(tmp_path / "or.f4"), inv, paired, zd)
+    ref = gunzip_to(os.path.join(G, nm + ".f4.gz"), str(tmp_path / "ref.f4"))
+    assert first_diff(ref, str(tmp_path / "or.f4")) is None

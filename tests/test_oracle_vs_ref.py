@@ -5,7 +5,7 @@ import os
 
 import pytest
 
-from ma_testlib import (have_ref, rand_genome, sample_reads, write_case, write_ksw_cases, rand_ksw_cases, run_ref,
+from ma_testlib import (sample_inversion_reads, sample_pairs, have_ref, rand_genome, sample_reads, write_case, write_ksw_cases, rand_ksw_cases, run_ref,
                         run_oracle, first_diff)
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (no /root/reference here)")
@@ -47,6 +47,23 @@ def test_pipeline_with_heuristics_and_repeats(tmp_path, preset):
     run_ref("pipe", p, preset, 3, str(tmp_path / "ref.pipe"))
     run_oracle("pipe", p, preset, 3, str(tmp_path / "or.pipe"))
     assert first_diff(str(tmp_path / "ref.pipe"), str(tmp_path / "or.pipe")) is None
+
+
+@pytest.mark.parametrize("preset,inv,paired,zdrop_inv", [("default", 1, 0, 100), ("default", 1, 0, 30), ("default", 0, 1, 100),
+                                                         ("illumina", 1, 1, 100), ("default", 1, 1, 60)])
+def test_f4_small_inversions_and_paired_reads(tmp_path, preset, inv, paired, zdrop_inv):
+    """SmallInversions (smallInversions.h) and PairedReads (pairedReads.cpp) after MappingQuality."""
+    g = rand_genome(21, [60000, 35000, 12000], repeat_unit=250, repeat_copies=30, repeat_div=0.05)
+    reads = (sample_pairs(g, 250, 150, 71) + sample_pairs(g, 30, 250, 72, sub=0.05, insert_mean=600, insert_std=200)
+             + sample_inversion_reads(g, 24, 1400, 73) + sample_inversion_reads(g, 6, 4000, 74, inv_min=300, inv_max=900, sub=0.03))
+    p = str(tmp_path / "c.case")
+    write_case(p, g, reads)
+    run_ref("f4", p, preset, 5, str(tmp_path / "ref.f4"), inv, paired, zdrop_inv)
+    run_oracle("f4", p, preset, 5, str(tmp_path / "or.f4"), inv, paired, zdrop_inv)
+    assert first_diff(str(tmp_path / "ref.f4"), str(tmp_path / "or.f4")) is None
+    if inv:  # the case must actually contain inversions that are found
+        with open(str(tmp_path / "ref.f4")) as f:
+            assert sum(1 for l in f if l.startswith("f ") and " 0:" not in l) >= 10
 
 
 def test_index_and_traces(tmp_path):
