@@ -60,6 +60,14 @@ typedef struct
     int32_t report_n_best; /* 0                                  xReportN */
     int32_t max_supplementary; /* 1                              xMaxSupplementaryPerPrim */
     double max_overlap_supplementary; /* 0.1                     xMaxOverlapSupplementary */
+    /* read by the host modules SmallInversions / PairedReads */
+    int32_t search_inversions; /* 0                              xSearchInversions */
+    int32_t zdrop_inversion; /* 100                              xZDropInversion */
+    int32_t use_paired_reads; /* 0                               xUsePairedReads */
+    int32_t pad_;
+    double mean_paired_dist; /* 400                              xMeanPairedReadDistance */
+    double std_paired_dist; /* 150                               xStdPairedReadDistance */
+    double paired_bonus; /* 1.25                                 xPairedBonus */
 } ma_params;
 
 /* ParameterSetManager presets (parameter.h:1079-1087) */
@@ -117,6 +125,11 @@ int ma_index_sizes( const ma_index*, uint64_t* n_words, uint64_t* n_sa, uint64_t
 /* Download (for FMIndex::vStoreFMIndex-compatible files and for tests); any pointer may be NULL. */
 int ma_index_download( const ma_index*, uint32_t* bwt_words, int64_t* sa, uint64_t L2[ 5 ], int64_t* primary,
                        uint8_t* pac, uint64_t* contig_starts, uint64_t* contig_lens );
+
+/* Pack::vExtract (pack.h:1440-1450, vExtractSubsection 1147-1236) for n ranges [begin[i], end[i]) of the doubled
+ * text; codes 0..3 back to back in out (host). Replaces the reference extraction SmallInversions does
+ * (smallInversions.h:207). */
+int ma_pack_extract( const ma_index*, const uint64_t* begin, const uint64_t* end, uint64_t n, uint8_t* out );
 
 /* ---- primitive ops (tests / SuffixArrayInterface seam, fMIndex.h:155-175) ---- */
 /* n independent FMIndex::extend_backward calls (fMIndex.cpp:21-101): ik[3n] -> ok[3n] (host arrays) */

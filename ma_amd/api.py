@@ -30,6 +30,8 @@ class Params(C.Structure):
         ("harm_score_min_rel", C.c_double), ("soc_score_decrease_tol", C.c_double),
         ("score_diff_tol", C.c_double), ("max_delta_dist", C.c_double), ("min_alignment_score", C.c_int32),
         ("report_n_best", C.c_int32), ("max_supplementary", C.c_int32), ("max_overlap_supplementary", C.c_double),
+        ("search_inversions", C.c_int32), ("zdrop_inversion", C.c_int32), ("use_paired_reads", C.c_int32), ("pad_", C.c_int32),
+        ("mean_paired_dist", C.c_double), ("std_paired_dist", C.c_double), ("paired_bonus", C.c_double),
     ]
 
     @staticmethod
@@ -150,6 +152,15 @@ class Index:
                                      _ptr(cl)))
         return dict(bwt=bwt, sa=sa, L2=L2, primary=primary.value, ref_len=rl, pac=pac, contig_starts=cs,
                     contig_lens=cl)
+
+    def extract(self, begin, end):
+        """Pack::vExtract for ranges [begin[i], end[i]) of the doubled text: list of uint8 code arrays."""
+        b = np.ascontiguousarray(begin, dtype=np.uint64)
+        e = np.ascontiguousarray(end, dtype=np.uint64)
+        out = np.empty(int((e - b).sum()) + 1, dtype=np.uint8)
+        _chk(lib().ma_pack_extract(self.h, _ptr(b), _ptr(e), C.c_uint64(len(b)), _ptr(out)))
+        cuts = np.concatenate([[0], np.cumsum(e - b)]).astype(np.int64)
+        return [out[cuts[i]:cuts[i + 1]] for i in range(len(b))]
 
     def extend_backward(self, ik, c):
         ik = np.ascontiguousarray(ik, dtype=np.int64).reshape(-1, 3)

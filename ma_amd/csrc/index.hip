@@ -112,6 +112,13 @@ void ma_params_default( ma_params* p )
     p->report_n_best = 0;
     p->max_supplementary = 1;
     p->max_overlap_supplementary = 0.1;
+    p->search_inversions = 0;
+    p->zdrop_inversion = 100;
+    p->use_paired_reads = 0;
+    p->pad_ = 0;
+    p->mean_paired_dist = 400;
+    p->std_paired_dist = 150;
+    p->paired_bonus = 1.25;
 }
 void ma_params_illumina( ma_params* p )
 {
@@ -209,6 +216,40 @@ int ma_index_download( const ma_index* x, uint32_t* bwt_words, int64_t* sa, uint
         memcpy( contig_starts, x->h_cstart.data( ), x->h_cstart.size( ) * 8 );
     if( contig_lens )
         memcpy( contig_lens, x->h_clen.data( ), x->h_clen.size( ) * 8 );
+    return 0;
+}
+
+// Pack::vExtract / vExtractSubsection (pack.h:1147-1236, 1440-1450) for n ranges [begin[i], end[i]) of the doubled text
+// (reverse strand = complement of the mirrored forward base); out receives the ranges back to back.
+int ma_pack_extract( const ma_index* x, const uint64_t* begin, const uint64_t* end, uint64_t n, uint8_t* out )
+{
+    if( !x || ( n && ( !begin || !end || !out ) ) )
+        return fail( "ma_pack_extract: null argument" );
+    std::vector<uint8_t> bytes;
+    for( uint64_t i = 0; i < n; i++ )
+    {
+        const uint64_t b = begin[ i ], e = end[ i ];
+        if( b > e )
+            return fail( "(vExtractSubsection) Try to extract with begin greater than end." );
+        if( e > x->v.n || b >= x->v.n )
+            return fail( "(vExtractSubsection) range check failed" );
+        if( b < e && ( b >= x->v.F ) != ( e - 1 >= x->v.F ) )
+            return fail( "(vExtractSubsection) Try to extract bridging sequence. This is impossible." );
+        if( b == e )
+            continue;
+        const bool bRev = b >= x->v.F;
+        // forward-strand positions covered: [lo, hi]
+        const uint64_t lo = bRev ? x->v.n - e : b, hi = bRev ? x->v.n - 1 - b : e - 1;
+        bytes.resize( ( hi >> 2 ) - ( lo >> 2 ) + 1 );
+        MA_HIP( hipMemcpy( bytes.data( ), x->pac.as<uint8_t>( ) + ( lo >> 2 ), bytes.size( ), hipMemcpyDeviceToHost ) );
+        auto base = [ & ]( uint64_t p ) { return (uint8_t)( ( bytes[ ( p >> 2 ) - ( lo >> 2 ) ] >> ( ( ~p & 3 ) << 1 ) ) & 3 ); };
+        if( !bRev )
+            for( uint64_t p = b; p < e; p++ )
+                *out++ = base( p );
+        else
+            for( uint64_t p = b; p < e; p++ )
+                *out++ = (uint8_t)( 3 - base( x->v.n - 1 - p ) );
+    }
     return 0;
 }
 

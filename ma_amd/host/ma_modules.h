@@ -16,6 +16,8 @@
 #include "../../include/ma_amd.h"
 #include "ms_graph.h"
 #include <cmath>
+#include <limits>
+#include <tuple>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -62,6 +64,19 @@ class ParameterSetManager
             ma_params_default( &xSelected );
         else if( k == "illumina" )
             ma_params_illumina( &xSelected );
+        else if( k == "illuminapaired" ) // parameter.h:1089-1094
+        {
+            ma_params_illumina( &xSelected );
+            xSelected.use_paired_reads = 1;
+        }
+        else if( k == "pacbio" || k == "nanopore" ) // parameter.h:1096-1104
+        {
+            ma_params_default( &xSelected );
+            xSelected.max_supplementary = 100;
+            xSelected.min_num_soc = 5;
+            if( k == "nanopore" )
+                xSelected.seeding_technique = 1;
+        }
         else
             throw std::runtime_error( "The presetting '" + sKey + "' can not be found." );
     }
@@ -69,6 +84,11 @@ class ParameterSetManager
     {
         return &xSelected;
     }
+    ma_params* getSelected( )
+    {
+        return &xSelected;
+    }
+    bool bRevCompPairedReadMates = true; // "Paired Mate - Mate Pair" (parameter.h:785-788), read by PairedFileReader
 };
 
 class NucSeq : public libMS::Container // nucSeq.h:61-160: codes A0 C1 G2 T3 N4
@@ -123,8 +143,10 @@ class Pack : public libMS::Container
     std::shared_ptr<DeviceIndex> pDev;
     std::vector<std::string> vNames;
     std::vector<uint64_t> vStarts, vLengths;
-    uint64_t uiUnpackedSizeForwardPlusReverse( ) const
+    uint64_t uiUnpackedSizeForwardPlusReverse( ) const // pack.h:881-884: twice the forward strand
     {
+        if( !vStarts.empty( ) )
+            return 2 * ( vStarts.back( ) + vLengths.back( ) );
         uint64_t n = 0;
         maCheck( ma_index_sizes( pDev->p, nullptr, nullptr, &n, nullptr ) );
         return n;
@@ -295,6 +317,12 @@ enum MatchType // alignment.h:39-46
     insertion,
     deletion
 };
+class Alignment;
+struct AlignmentStatistics // seed.h:219-248 (the members the paired path reads)
+{
+    std::weak_ptr<Alignment> pOther; // the mate's alignment picked by PairedReads
+    bool bFirst = false; // alignment of the first mate?
+};
 class Alignment : public libMS::Container // alignment.h:55-84
 {
   public:
@@ -304,9 +332,70 @@ class Alignment : public libMS::Container // alignment.h:55-84
     double fMappingQuality = NAN;
     unsigned int index_of_strip = 0;
     bool bSecondary = false, bSupplementary = false;
+    AlignmentStatistics xStats;
     int64_t score( ) const
     {
         return iScore;
+    }
+    nucSeqIndex beginOnRef( ) const
+    {
+        return uiBeginOnRef;
+    }
+    nucSeqIndex length( ) const // alignment.h:760-770
+    {
+        nucSeqIndex n = 0;
+        for( auto& x : data )
+            n += x.second;
+        return n;
+    }
+    size_t getNumSeeds( ) const // alignment.h:239-246
+    {
+        size_t uiRet = 0;
+        for( auto& x : data )
+            if( x.first == MatchType::seed )
+                uiRet++;
+        return uiRet;
+    }
+    // Alignment::append (alignment.cpp:10-98): run-length storage; the score follows the global scoring parameters,
+    // an indel run costs at most the SV penalty
+    void append( MatchType type, nucSeqIndex size, const ma_params& rP )
+    {
+        if( size == 0 )
+            return;
+        if( type == MatchType::seed || type == MatchType::match )
+        {
+            iScore += (int64_t)rP.match * (int64_t)size;
+            uiEndOnRef += size;
+            uiEndOnQuery += size;
+        }
+        else if( type == MatchType::missmatch )
+        {
+            iScore -= (int64_t)rP.mismatch * (int64_t)size;
+            uiEndOnRef += size;
+            uiEndOnQuery += size;
+        }
+        else
+        {
+            if( type == MatchType::insertion )
+                uiEndOnQuery += size;
+            else
+                uiEndOnRef += size;
+            auto cost = [ & ]( nucSeqIndex n ) {
+                const nucSeqIndex c = (nucSeqIndex)rP.extend * n + (nucSeqIndex)rP.gap;
+                return c < (nucSeqIndex)rP.sv_penalty ? c : (nucSeqIndex)rP.sv_penalty;
+            };
+            if( data.size( ) != 0 && data.back( ).first == type )
+            {
+                size += data.back( ).second;
+                iScore += (int64_t)cost( data.back( ).second );
+                data.pop_back( );
+            }
+            iScore -= (int64_t)cost( size );
+        }
+        if( data.size( ) != 0 && data.back( ).first == type )
+            data.back( ).second += size;
+        else
+            data.push_back( std::make_pair( type, size ) );
     }
 };
 typedef libMS::ContainerVector<std::shared_ptr<Seeds>> SeedsSetVector;
@@ -492,6 +581,296 @@ class MappingQuality : public libMS::Module<libMS::ContainerVector<std::shared_p
         auto pRet = std::make_shared<AlignmentVector>( );
         pRet->pBatch = detail::requireBatch( pIn ? pIn->pBatch : nullptr, "MappingQuality" );
         detail::fillAlignments( pRet->pBatch->p, true, *pRet );
+        return pRet;
+    }
+};
+
+// SmallInversions (smallInversions.h:22-221): the second consumer of kswcpp.  The scan for z-drops between seeds and the
+// assembly of the inversion alignments are host glue; the DP calls of ALL alignments handed in (one read, or a
+// whole batch through executeBatch) go to the GPU in one ma_ksw_batch launch, their reference windows come from the
+// device-resident pack in one ma_pack_extract call.
+class SmallInversions : public libMS::Module<libMS::ContainerVector<std::shared_ptr<Alignment>>, false,
+                                             libMS::ContainerVector<std::shared_ptr<Alignment>>, NucSeq, Pack>
+{
+    const ma_params xP;
+    struct DropPos
+    {
+        size_t uiRead, uiAlignment;
+        nucSeqIndex uiStartQ, uiStartR, uiEndQ, uiEndR;
+    };
+
+  public:
+    typedef libMS::ContainerVector<std::shared_ptr<Alignment>> TP_ALIGNMENTS;
+    SmallInversions( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) )
+    {}
+
+    // smallInversions.h:54-120
+    template <typename F> void forAllDropPos( F&& fDo, const Alignment& rAlignment ) const
+    {
+        nucSeqIndex uiMaxScorePosQ = rAlignment.uiBeginOnQuery, uiPosQ = uiMaxScorePosQ, uiStartQ = uiMaxScorePosQ;
+        nucSeqIndex uiMaxScorePosR = rAlignment.uiBeginOnRef, uiPosR = uiMaxScorePosR, uiStartR = uiMaxScorePosR;
+        int iMaxScore = std::numeric_limits<int>::min( ), iCurrScore = 0, iMaxDrop = 0;
+        for( const std::pair<MatchType, nucSeqIndex>& section : rAlignment.data )
+        {
+            if( section.first == MatchType::seed )
+            {
+                if( iMaxDrop >= (int)(size_t)xP.zdrop_inversion )
+                    fDo( uiStartQ, uiStartR, uiPosQ, uiPosR );
+                uiStartQ = section.second + uiPosQ;
+                uiStartR = section.second + uiPosR;
+                iMaxDrop = 0;
+                iCurrScore = 0;
+                iMaxScore = std::numeric_limits<int>::min( );
+            }
+            switch( section.first )
+            {
+                case MatchType::seed: // the reference falls through from seed into match
+                case MatchType::match:
+                    iCurrScore += xP.match * (int)section.second;
+                    uiPosQ += section.second;
+                    uiPosR += section.second;
+                    break;
+                case MatchType::missmatch:
+                    iCurrScore -= xP.mismatch * (int)section.second;
+                    uiPosQ += section.second;
+                    uiPosR += section.second;
+                    break;
+                case MatchType::insertion:
+                    iCurrScore -= xP.gap + xP.extend * (int)section.second;
+                    uiPosQ += section.second;
+                    break;
+                case MatchType::deletion:
+                    iCurrScore -= xP.gap + xP.extend * (int)section.second;
+                    uiPosR += section.second;
+                    break;
+            }
+            if( iCurrScore >= iMaxScore )
+            {
+                iMaxScore = iCurrScore;
+                uiMaxScorePosQ = uiPosQ;
+                uiMaxScorePosR = uiPosR;
+            }
+            else
+            {
+                const int uiDiff = (int)std::max( uiPosQ - uiMaxScorePosQ, uiPosR - uiMaxScorePosR );
+                iMaxDrop = std::max( iMaxDrop, iMaxScore - iCurrScore - uiDiff * xP.extend );
+            }
+        }
+    }
+
+    // smallInversions.h:196-218 for many reads at once; vIn[i] belongs to vQueries[i]
+    std::vector<std::shared_ptr<TP_ALIGNMENTS>> executeBatch( const std::vector<std::shared_ptr<TP_ALIGNMENTS>>& vIn,
+                                                               const std::vector<std::shared_ptr<NucSeq>>& vQueries,
+                                                               std::shared_ptr<Pack> pRefPack ) const
+    {
+        // 1. where does the running score drop by more than "Z Drop Inversions" between two seeds?
+        std::vector<DropPos> vPos;
+        for( size_t r = 0; r < vIn.size( ); r++ )
+            for( size_t a = 0; a < vIn[ r ]->size( ); a++ )
+                forAllDropPos(
+                    [ & ]( nucSeqIndex uiStartQ, nucSeqIndex uiStartR, nucSeqIndex uiEndQ, nucSeqIndex uiEndR ) {
+                        vPos.push_back( DropPos{ r, a, uiStartQ, uiStartR, uiEndQ, uiEndR } );
+                    },
+                    *( *vIn[ r ] )[ a ] );
+        // 2. the reverse-strand windows of those stretches (Pack::uiPositionToReverseStrand pack.h:924-927, vExtract)
+        const uint64_t uiN = vPos.empty( ) ? 0 : pRefPack->uiUnpackedSizeForwardPlusReverse( );
+        std::vector<uint64_t> vBegin, vEnd;
+        std::vector<ma_ksw_job> vJobs;
+        std::vector<uint8_t> vQ, vT;
+        std::vector<int64_t> vJobOfPos;
+        std::vector<uint64_t> vTOff;
+        uint64_t uiCigarCap = 16;
+        for( const DropPos& rD : vPos )
+        {
+            vBegin.push_back( uiN - ( rD.uiEndR + 1 ) );
+            vEnd.push_back( uiN - ( rD.uiStartR + 1 ) );
+            ma_ksw_job j;
+            j.qlen = (int)rD.uiEndQ - (int)rD.uiStartQ;
+            j.tlen = (int)( vEnd.back( ) - vBegin.back( ) );
+            j.w = (int)(size_t)xP.bandwidth_ext;
+            j.zdrop = (int)(size_t)xP.zdrop;
+            j.flag = 0;
+            j.reserved = 0;
+            j.q_off = vQ.size( );
+            j.t_off = vT.size( );
+            vTOff.push_back( vT.size( ) );
+            const NucSeq& rQuery = *vQueries[ rD.uiRead ];
+            vQ.insert( vQ.end( ), rQuery.xCodes.begin( ) + rD.uiStartQ, rQuery.xCodes.begin( ) + rD.uiEndQ );
+            vT.resize( vT.size( ) + (size_t)j.tlen );
+            uiCigarCap += (uint64_t)j.qlen + (uint64_t)j.tlen + 2;
+            // kswcpp returns an empty result for an empty side (kswcpp_core.h:362-364): nothing to launch
+            vJobOfPos.push_back( j.qlen > 0 && j.tlen > 0 ? (int64_t)vJobs.size( ) : -1 );
+            if( vJobOfPos.back( ) >= 0 )
+                vJobs.push_back( j );
+        }
+        std::vector<ma_ez> vEz( vJobs.size( ) + 1 );
+        std::vector<uint64_t> vCigOff( vJobs.size( ) + 2, 0 );
+        std::vector<uint32_t> vCigar( uiCigarCap );
+        if( !vPos.empty( ) )
+            maCheck( ma_pack_extract( pRefPack->pDev->p, vBegin.data( ), vEnd.data( ), vBegin.size( ), vT.data( ) ) );
+        vQ.push_back( 0 );
+        vT.push_back( 0 );
+        if( !vJobs.empty( ) )
+        {
+            // 3. kswcpp_dispatch( ..., xKswParameters, uiBandwidth, uiZDrop, 0, ... ) (smallInversions.h:131-133), all at once
+            maCheck( ma_ksw_batch( &xP, vJobs.data( ), vJobs.size( ), vQ.data( ), vQ.size( ), vT.data( ), vT.size( ), vEz.data( ),
+                                   vCigOff.data( ), vCigar.data( ), uiCigarCap ) );
+        }
+        // 4. cigars -> alignments (smallInversions.h:135-175), appended behind the alignment they were found in
+        std::vector<std::shared_ptr<TP_ALIGNMENTS>> vRet;
+        size_t k = 0;
+        for( size_t r = 0; r < vIn.size( ); r++ )
+        {
+            auto pRet = std::make_shared<TP_ALIGNMENTS>( );
+            for( size_t a = 0; a < vIn[ r ]->size( ); a++ )
+            {
+                std::shared_ptr<Alignment> pAlignment = ( *vIn[ r ] )[ a ];
+                pRet->push_back( pAlignment );
+                for( ; k < vPos.size( ) && vPos[ k ].uiRead == r && vPos[ k ].uiAlignment == a; k++ )
+                {
+                    const NucSeq& rQuery = *vQueries[ r ];
+                    const uint8_t* pRef = vT.data( ) + vTOff[ k ];
+                    auto pInv = std::make_shared<Alignment>( );
+                    nucSeqIndex qPos = vPos[ k ].uiStartQ, rPos = 0;
+                    const int64_t iJob = vJobOfPos[ k ];
+                    for( uint64_t c = iJob < 0 ? 0 : vCigOff[ iJob ]; c < ( iJob < 0 ? 0 : vCigOff[ iJob + 1 ] ); c++ )
+                    {
+                        const uint32_t uiSymbol = vCigar[ c ] & 0xf, uiAmount = vCigar[ c ] >> 4;
+                        switch( uiSymbol )
+                        {
+                            case 0:
+                                for( uint32_t uiPos = 0; uiPos < uiAmount; uiPos++ )
+                                    pInv->append( rQuery.xCodes[ uiPos + qPos ] == pRef[ uiPos + rPos ] ? MatchType::match
+                                                                                                     : MatchType::missmatch,
+                                                  1, xP );
+                                qPos += uiAmount;
+                                rPos += uiAmount;
+                                break;
+                            case 1:
+                                pInv->append( MatchType::insertion, uiAmount, xP );
+                                qPos += uiAmount;
+                                break;
+                            case 2:
+                                pInv->append( MatchType::deletion, uiAmount, xP );
+                                rPos += uiAmount;
+                                break;
+                            default:
+                                throw std::runtime_error( "obtained wierd symbol from ksw" );
+                        }
+                    }
+                    if( xP.disable_heuristics || pInv->score( ) > xP.harm_score_min * xP.match )
+                    {
+                        pInv->uiBeginOnQuery += vPos[ k ].uiStartQ;
+                        pInv->uiEndOnQuery += vPos[ k ].uiStartQ;
+                        pInv->uiBeginOnRef += vBegin[ k ];
+                        pInv->uiEndOnRef += vBegin[ k ];
+                        pInv->bSupplementary = true;
+                        pInv->xStats = pAlignment->xStats;
+                        pInv->index_of_strip = pAlignment->index_of_strip;
+                        pInv->fMappingQuality = 0;
+                        pRet->push_back( pInv );
+                    }
+                }
+            }
+            vRet.push_back( pRet );
+        }
+        return vRet;
+    }
+
+    virtual std::shared_ptr<TP_ALIGNMENTS> execute( std::shared_ptr<TP_ALIGNMENTS> pAlignments, std::shared_ptr<NucSeq> pQuery,
+                                                    std::shared_ptr<Pack> pRefPack ) override
+    {
+        return executeBatch( { pAlignments }, { pQuery }, pRefPack )[ 0 ];
+    }
+};
+
+// PairedReads (pairedReads.h:23-63, pairedReads.cpp:14-131): picks the best combination of one alignment per mate
+class PairedReads : public libMS::Module<libMS::ContainerVector<std::shared_ptr<Alignment>>, false, NucSeq, NucSeq,
+                                         libMS::ContainerVector<std::shared_ptr<Alignment>>,
+                                         libMS::ContainerVector<std::shared_ptr<Alignment>>, Pack>
+{
+    const ma_params xP;
+
+  public:
+    typedef libMS::ContainerVector<std::shared_ptr<Alignment>> TP_ALIGNMENTS;
+    double u; // score factor of a proper pair
+    size_t mean; // insert size
+    double std;
+    PairedReads( const ParameterSetManager& rParameters )
+        : xP( *rParameters.getSelected( ) ), u( xP.paired_bonus ), mean( (size_t)xP.mean_paired_dist ), std( xP.std_paired_dist )
+    {}
+    virtual std::shared_ptr<TP_ALIGNMENTS> execute( std::shared_ptr<NucSeq> pQ1, std::shared_ptr<NucSeq> pQ2,
+                                                    std::shared_ptr<TP_ALIGNMENTS> pAlignments1,
+                                                    std::shared_ptr<TP_ALIGNMENTS> pAlignments2, std::shared_ptr<Pack> pPack ) override
+    {
+        for( auto& pA : *pAlignments1 )
+            pA->xStats.bFirst = true;
+        for( auto& pA : *pAlignments2 )
+            pA->xStats.bFirst = false;
+        if( pAlignments1->size( ) == 0 )
+            return pAlignments2;
+        if( pAlignments2->size( ) == 0 )
+            return pAlignments1;
+        const uint64_t uiN = pPack->uiUnpackedSizeForwardPlusReverse( ), uiF = uiN / 2;
+        std::vector<std::tuple<int64_t, bool, size_t, size_t>> vScores;
+        for( size_t i = 0; i < pAlignments1->size( ); i++ )
+        {
+            const Alignment& rA1 = *( *pAlignments1 )[ i ];
+            if( rA1.length( ) == 0 )
+                continue;
+            for( size_t j = 0; j < pAlignments2->size( ); j++ )
+            {
+                const Alignment& rA2 = *( *pAlignments2 )[ j ];
+                if( rA2.length( ) == 0 )
+                    continue;
+                int64_t iScore = rA1.score( ) + rA2.score( );
+                bool bIsPaired = false;
+                // illumina reads must be on opposite strands
+                if( ( rA1.beginOnRef( ) >= uiF ) != ( rA2.beginOnRef( ) >= uiF ) )
+                {
+                    const nucSeqIndex uiP1 = rA1.beginOnRef( ), uiP2 = uiN - ( rA2.beginOnRef( ) + 1 );
+                    const nucSeqIndex d = uiP1 < uiP2 ? uiP2 - uiP1 : uiP1 - uiP2;
+                    if( ( (double)d ) >= ( (double)mean ) - std * 3 && ( (double)d ) <= ( (double)mean ) + std * 3 )
+                    {
+                        iScore = ( int64_t )( iScore * u );
+                        bIsPaired = true;
+                    }
+                }
+                vScores.emplace_back( iScore, bIsPaired, i, j );
+            }
+        }
+        if( vScores.empty( ) )
+            throw std::runtime_error( "PairedReads: no alignment of non-zero length to pair" );
+        // same container, comparator and libstdc++ std::sort as the reference: ties keep its order
+        std::sort( vScores.begin( ), vScores.end( ),
+                   []( const std::tuple<int64_t, bool, size_t, size_t>& rtA, const std::tuple<int64_t, bool, size_t, size_t>& rtB ) {
+                       if( std::get<0>( rtA ) == std::get<0>( rtB ) )
+                           return std::get<1>( rtA ) && !std::get<1>( rtB );
+                       return std::get<0>( rtA ) > std::get<0>( rtB );
+                   } );
+        auto pA = ( *pAlignments1 )[ std::get<2>( vScores[ 0 ] ) ];
+        auto pB = ( *pAlignments2 )[ std::get<3>( vScores[ 0 ] ) ];
+        pA->bSecondary = pB->bSecondary = false;
+        pA->bSupplementary = pB->bSupplementary = false;
+        pA->xStats.pOther = std::weak_ptr<Alignment>( pB );
+        pB->xStats.pOther = std::weak_ptr<Alignment>( pA );
+        if( std::get<1>( vScores[ 0 ] ) && vScores.size( ) > 1 )
+        {
+            float fMapQ = ( (float)( std::get<0>( vScores[ 0 ] ) - std::get<0>( vScores[ 1 ] ) ) ) / std::get<0>( vScores[ 0 ] );
+            if( pA->getNumSeeds( ) <= 1 && pB->getNumSeeds( ) <= 1 )
+                fMapQ /= 2;
+            if( pA->score( ) >= xP.match * pQ1->length( ) * 0.8 && pAlignments1->size( ) >= 3 )
+                fMapQ *= 2;
+            else if( pB->score( ) >= xP.match * pQ2->length( ) * 0.8 && pAlignments2->size( ) >= 3 )
+                fMapQ *= 2;
+            if( fMapQ > 1 )
+                fMapQ = 1;
+            pA->fMappingQuality = fMapQ;
+            pB->fMappingQuality = fMapQ;
+        }
+        auto pRet = std::make_shared<TP_ALIGNMENTS>( );
+        pRet->push_back( pA );
+        pRet->push_back( pB );
         return pRet;
     }
 };

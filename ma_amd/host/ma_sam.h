@@ -16,8 +16,14 @@
 
 namespace libMA
 {
-#define MA_SAM_SEGMENT_UNMAPPED 0x004 // alignment.h:16-25
+#define MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE 0x001 // alignment.h:14-25
+#define MA_SAM_SEGMENT_PROPERLY_ALIGNED 0x002
+#define MA_SAM_SEGMENT_UNMAPPED 0x004
+#define MA_SAM_NEXT_SEGMENT_UNMAPPED 0x008
 #define MA_SAM_REVERSE_COMPLEMENTED 0x010
+#define MA_SAM_NEXT_REVERSE_COMPLEMENTED 0x020
+#define MA_SAM_FIRST_IN_TEMPLATE 0x040
+#define MA_SAM_LAST_IN_TEMPLATE 0x080
 #define MA_SAM_SECONDARY_ALIGNMENT 0x100
 #define MA_SAM_SUPPLEMENTARY_ALIGNMENT 0x800
 
@@ -209,6 +215,39 @@ inline std::string getQuerySequence( const Alignment& rA, const NucSeq& rQuery, 
         throw std::runtime_error( "Query length is off by " + std::to_string( iOff ) + "." );
     return sRet;
 }
+// TagGenerator::computeTag (fileWriter.h:215-357) for the default options: only the CG tag of over-long cigars
+inline std::string computeTag( const Alignment& rA, bool bLong )
+{
+    std::string sTag;
+    if( bLong ) // fileWriter.h:327-357
+    {
+        sTag.append( "\tCG:B:I" );
+        for( auto& rPair : rA.data )
+        {
+            uint32_t uiOperation = 0;
+            switch( rPair.first )
+            {
+                case MatchType::seed:
+                case MatchType::match:
+                    uiOperation = 7;
+                    break;
+                case MatchType::missmatch:
+                    uiOperation = 8;
+                    break;
+                case MatchType::insertion:
+                    uiOperation = 1;
+                    break;
+                case MatchType::deletion:
+                    uiOperation = 2;
+                    break;
+                default:
+                    break;
+            }
+            sTag.append( "," ).append( std::to_string( (uint32_t)( rPair.second << 4 ) | uiOperation ) );
+        }
+    }
+    return sTag;
+}
 } // namespace sam
 
 class OutStream // fileWriter.h:21-34
@@ -337,34 +376,7 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
             const std::string sQual = sam::fromToQual( *pQuery, pAlignment->uiBeginOnQuery, pAlignment->uiEndOnQuery );
             const std::string sRefName = sam::nameOfSequenceForPosition( *pPack, pAlignment->uiBeginOnRef );
             const nucSeqIndex uiRefPos = sam::getSamPosition( *pAlignment, *pPack );
-            std::string sTag;
-            if( bLong ) // fileWriter.h:327-357
-            {
-                sTag.append( "\tCG:B:I" );
-                for( auto& rPair : pAlignment->data )
-                {
-                    uint32_t uiOperation = 0;
-                    switch( rPair.first )
-                    {
-                        case MatchType::seed:
-                        case MatchType::match:
-                            uiOperation = 7;
-                            break;
-                        case MatchType::missmatch:
-                            uiOperation = 8;
-                            break;
-                        case MatchType::insertion:
-                            uiOperation = 1;
-                            break;
-                        case MatchType::deletion:
-                            uiOperation = 2;
-                            break;
-                        default:
-                            break;
-                    }
-                    sTag.append( "," ).append( std::to_string( (uint32_t)( rPair.second << 4 ) | uiOperation ) );
-                }
-            }
+            const std::string sTag = sam::computeTag( *pAlignment, bLong );
             std::string sMapQual;
             if( std::isnan( pAlignment->fMappingQuality ) )
                 sMapQual = "255";
@@ -388,6 +400,151 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
     virtual bool requiresLock( ) const
     {
         return false; // the writer serialises its own output
+    }
+};
+// PairedFileWriter (fileWriter.h:456-545, fileWriter.cpp:158-380): SAM records of a mate pair
+class PairedFileWriter : public libMS::Module<libMS::Container, false, NucSeq, NucSeq,
+                                              libMS::ContainerVector<std::shared_ptr<Alignment>>, Pack>
+{
+    static const size_t uiMaxCigarLen = 0x10000;
+    void init( const SamOptions& rO )
+    {
+        if( rO.bEmulateNgmlrTags )
+            throw std::runtime_error( "PairedFileWriter: the NGMLR tag emulation is not available in the MI355X host layer" );
+    }
+    void header( std::shared_ptr<Pack> pPackContainer, const char* sSep )
+    {
+        for( size_t i = 0; i < pPackContainer->vNames.size( ); i++ )
+            *pOut << "@SQ\tSN:" << pPackContainer->vNames[ i ] << sSep << std::to_string( pPackContainer->vLengths[ i ] ) << "\n";
+        *pOut << "@PG\tID:ma\tPN:ma\tVN:0.1.0\tCL:na\n";
+    }
+
+  public:
+    std::shared_ptr<OutStream> pOut;
+    std::shared_ptr<std::mutex> pLock;
+    const SamOptions xOptions;
+
+    // fileWriter.h:474-491
+    PairedFileWriter( const ParameterSetManager& rParameters, std::string sFileName, std::shared_ptr<Pack> pPackContainer )
+        : pLock( new std::mutex ), xOptions( rParameters.xSam )
+    {
+        init( xOptions );
+        if( sFileName != "stdout" )
+            pOut = std::shared_ptr<OutStream>( new FileOutStream( sFileName ) );
+        else
+            pOut = std::shared_ptr<OutStream>( new StdOutStream( ) );
+        header( pPackContainer, "\tLN:" );
+    }
+    // fileWriter.h:498-511 (sic: a blank, not a tab, before LN)
+    PairedFileWriter( const ParameterSetManager& rParameters, std::shared_ptr<OutStream> pOut_, std::shared_ptr<Pack> pPackContainer )
+        : pOut( pOut_ ), pLock( new std::mutex ), xOptions( rParameters.xSam )
+    {
+        init( xOptions );
+        header( pPackContainer, " LN:" );
+    }
+    // fileWriter.h:520-541: further writers on the same stream
+    PairedFileWriter( const ParameterSetManager& rParameters, std::shared_ptr<FileWriter> pOther )
+        : pOut( pOther->pOut ), pLock( pOther->pLock ), xOptions( rParameters.xSam )
+    {
+        init( xOptions );
+    }
+    PairedFileWriter( const ParameterSetManager& rParameters, std::shared_ptr<PairedFileWriter> pOther )
+        : pOut( pOther->pOut ), pLock( pOther->pLock ), xOptions( rParameters.xSam )
+    {
+        init( xOptions );
+    }
+
+    virtual std::shared_ptr<libMS::Container>
+    execute( std::shared_ptr<NucSeq> pQuery1, std::shared_ptr<NucSeq> pQuery2,
+             std::shared_ptr<libMS::ContainerVector<std::shared_ptr<Alignment>>> pAlignments, std::shared_ptr<Pack> pPack ) override
+    {
+        std::string sCombined;
+        bool bFirstQueryHasAlignment = false, bSecondQueryHasAlignment = false;
+        for( std::shared_ptr<Alignment> pAlignment : *pAlignments )
+        {
+            if( sam::length( *pAlignment ) == 0 )
+                continue;
+            if( xOptions.bNoSecondary && pAlignment->bSecondary )
+                continue;
+            if( xOptions.bNoSupplementary && pAlignment->bSupplementary )
+                continue;
+            const bool bFirst = pAlignment->xStats.bFirst;
+            ( bFirst ? bFirstQueryHasAlignment : bSecondQueryHasAlignment ) = true;
+            const NucSeq& rQuery = bFirst ? *pQuery1 : *pQuery2;
+            const bool bLong = xOptions.bCGTag && pAlignment->data.size( ) >= uiMaxCigarLen;
+            std::string sCigar;
+            if( bLong )
+                sCigar = std::to_string( pAlignment->uiEndOnQuery - pAlignment->uiBeginOnQuery ).append( "S" );
+            else // (sic) clipped against the length of the FIRST mate (fileWriter.cpp:191-193)
+                sCigar = sam::cigarString( *pAlignment, *pPack, pQuery1->length( ), xOptions.bSoftClip, xOptions.bOutputMCigar );
+            uint32_t flag = sam::getSamFlag( *pAlignment, *pPack );
+            std::string sContigOther = "*", sPosOther = "0";
+            std::string sSegment;
+            if( xOptions.bSoftClip )
+                sSegment = sam::bPositionIsOnReversStrand( *pPack, pAlignment->uiBeginOnRef )
+                               ? sam::fromToComplement( rQuery, 0, rQuery.length( ) )
+                               : sam::toString( rQuery );
+            else
+                sSegment = sam::getQuerySequence( *pAlignment, rQuery, *pPack );
+            const std::string sQual = sam::fromToQual( rQuery, pAlignment->uiBeginOnQuery, pAlignment->uiEndOnQuery );
+            flag |= MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE | MA_SAM_SEGMENT_PROPERLY_ALIGNED;
+            flag |= bFirst ? MA_SAM_FIRST_IN_TEMPLATE : MA_SAM_LAST_IN_TEMPLATE;
+            const std::string sRefName = sam::nameOfSequenceForPosition( *pPack, pAlignment->uiBeginOnRef );
+            if( auto pOther = pAlignment->xStats.pOther.lock( ) )
+            {
+                if( sam::bPositionIsOnReversStrand( *pPack, pOther->uiBeginOnRef ) )
+                    flag |= MA_SAM_NEXT_REVERSE_COMPLEMENTED;
+                sContigOther = sam::nameOfSequenceForPosition( *pPack, pOther->uiBeginOnRef );
+                if( sContigOther == sRefName )
+                    sContigOther = "=";
+                sPosOther = std::to_string( sam::getSamPosition( *pOther, *pPack ) );
+            }
+            const nucSeqIndex uiRefPos = sam::getSamPosition( *pAlignment, *pPack );
+            const std::string sTag = sam::computeTag( *pAlignment, bLong );
+            std::string sMapQual;
+            if( std::isnan( pAlignment->fMappingQuality ) )
+                sMapQual = "255";
+            else
+                sMapQual = std::to_string( std::min( static_cast<int>( std::ceil( pAlignment->fMappingQuality * 254 ) ), 255 ) );
+            // the template length is not output by the reference ("0", fileWriter.cpp:317)
+            sCombined += ( bFirst ? pQuery1->sName : pQuery2->sName ) + "\t" + std::to_string( flag ) + "\t" + sRefName + "\t" +
+                         std::to_string( uiRefPos ) + "\t" + sMapQual + "\t" + sCigar + "\t" + sContigOther + "\t" + sPosOther +
+                         "\t0\t" + sSegment + "\t" + sQual + sTag + "\n";
+        }
+        if( !bFirstQueryHasAlignment && !bSecondQueryHasAlignment )
+        {
+            sCombined += pQuery1->sName + "\t" +
+                         std::to_string( MA_SAM_SEGMENT_UNMAPPED | MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE | MA_SAM_FIRST_IN_TEMPLATE |
+                                         MA_SAM_NEXT_SEGMENT_UNMAPPED ) +
+                         "\t*\t0\t0\t*\t*\t0\t0\t" + sam::toString( *pQuery1 ) + "\t" +
+                         sam::fromToQual( *pQuery1, 0, pQuery1->length( ) ) + "\n";
+            sCombined += pQuery2->sName + "\t" +
+                         std::to_string( MA_SAM_SEGMENT_UNMAPPED | MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE | MA_SAM_LAST_IN_TEMPLATE |
+                                         MA_SAM_NEXT_SEGMENT_UNMAPPED ) +
+                         "\t*\t0\t0\t*\t*\t0\t0\t" + sam::toString( *pQuery2 ) + "\t" +
+                         sam::fromToQual( *pQuery2, 0, pQuery2->length( ) ) + "\n";
+        }
+        else if( !bFirstQueryHasAlignment || !bSecondQueryHasAlignment )
+        {
+            // the unaligned mate is placed at the first alignment of the list (fileWriter.cpp:348-366)
+            const std::string sPosOther = std::to_string( sam::getSamPosition( *( *pAlignments )[ 0 ], *pPack ) );
+            const std::string sContigOther = sam::nameOfSequenceForPosition( *pPack, ( *pAlignments )[ 0 ]->uiBeginOnRef );
+            sCombined += ( !bFirstQueryHasAlignment ? pQuery1->sName : pQuery2->sName ) + "\t" +
+                         std::to_string( MA_SAM_SEGMENT_UNMAPPED | MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE |
+                                         ( !bFirstQueryHasAlignment ? MA_SAM_FIRST_IN_TEMPLATE : MA_SAM_LAST_IN_TEMPLATE ) ) +
+                         "\t" + sContigOther + "\t" + sPosOther + "\t0\t*\t=\t" + sPosOther + "\t0\t" +
+                         ( !bFirstQueryHasAlignment ? sam::toString( *pQuery1 ) : sam::toString( *pQuery2 ) ) + "\t*\n";
+        }
+        if( sCombined.size( ) > 0 )
+        {
+            std::lock_guard<std::mutex> xGuard( *pLock );
+            *pOut << sCombined;
+        }
+        return std::make_shared<libMS::Container>( );
+    }
+    virtual bool requiresLock( ) const
+    {
+        return false;
     }
 };
 // ---- FASTA / FASTQ reading (fileReader.h:28-200,475-496; fileReader.cpp:12-196 with WITH_QUALITY == 1) --------
@@ -584,6 +741,60 @@ class FileReader : public libMS::Module<NucSeq, true, FileStream>
         }
         throw std::runtime_error( "Error while reading file.\nIs your input really in FASTA/Q format?\nError occurred in file: " +
                                   pStream->fileName( ) + "\npeek was:" + pStream->peek( ) );
+    }
+};
+// PairedFileStream / PairedFileReader (fileReader.h:499-617): one read from each of two streams per call
+class PairedFileStream : public FileStream, public std::pair<std::shared_ptr<FileStream>, std::shared_ptr<FileStream>>
+{
+  public:
+    using std::pair<std::shared_ptr<FileStream>, std::shared_ptr<FileStream>>::pair;
+    bool eof( ) const override
+    {
+        return first->eof( ) || second->eof( );
+    }
+    char peek( ) override
+    {
+        throw std::runtime_error( "This function should have been overridden" );
+    }
+    char pop( ) override
+    {
+        throw std::runtime_error( "This function should have been overridden" );
+    }
+    std::string fileName( ) override
+    {
+        return first->fileName( ) + std::string( "," ) + second->fileName( );
+    }
+    void safeGetLine( std::string& ) override
+    {
+        throw std::runtime_error( "This function should have been overridden" );
+    }
+};
+typedef libMS::ContainerVector<std::shared_ptr<NucSeq>> PairedReadsContainer;
+class PairedFileReader : public libMS::Module<PairedReadsContainer, true, PairedFileStream>
+{
+  public:
+    FileReader xFileReader;
+    const bool bRevCompMate;
+    PairedFileReader( const ParameterSetManager& rParameters )
+        : xFileReader( rParameters ), bRevCompMate( rParameters.bRevCompPairedReadMates )
+    {}
+    virtual std::shared_ptr<PairedReadsContainer> execute( std::shared_ptr<PairedFileStream> pFileStreamIn ) override
+    {
+        auto pRet = std::make_shared<PairedReadsContainer>( );
+        pRet->push_back( xFileReader.execute( pFileStreamIn->first ) );
+        pRet->push_back( xFileReader.execute( pFileStreamIn->second ) );
+        if( ( *pRet )[ 0 ] == nullptr || ( *pRet )[ 1 ] == nullptr )
+            return nullptr;
+        if( bRevCompMate )
+        {
+            // NucSeq::vReverse (nucSeq.h:373-381, with the qualities) + vSwitchAllBasePairsToComplement (537-543)
+            NucSeq& rMate = *pRet->back( );
+            std::reverse( rMate.xCodes.begin( ), rMate.xCodes.end( ) );
+            std::reverse( rMate.xQuality.begin( ), rMate.xQuality.end( ) );
+            for( uint8_t& c : rMate.xCodes )
+                c = c < 4 ? (uint8_t)( 3 - c ) : (uint8_t)5;
+        }
+        return pRet;
     }
 };
 } // namespace libMA

@@ -241,6 +241,17 @@ template <typename TP_CONTAINER> class UnLock : public Module<TP_CONTAINER, true
     }
 };
 
+// TupleGet (splitter.h:83-94): element IDX of a container of shared pointers (e.g. one mate of a PairedReadsContainer)
+template <typename TP_TUPLE, size_t IDX>
+class TupleGet : public Module<typename TP_TUPLE::value_type::element_type, false, TP_TUPLE>
+{
+  public:
+    typename TP_TUPLE::value_type execute( std::shared_ptr<TP_TUPLE> pIn ) override
+    {
+        return ( *pIn )[ IDX ];
+    }
+};
+
 template <class TP_MODULE, class... TP_PLEDGES>
 std::shared_ptr<Pledge<typename TP_MODULE::TP_RETURN, TP_MODULE::IS_VOLATILE, TP_PLEDGES...>>
 promiseMe( std::shared_ptr<TP_MODULE> pModule, std::shared_ptr<TP_PLEDGES>... pPledges )

@@ -9,6 +9,7 @@
 //   ref_dump pipe  <case> <preset> <srand_seed> <out>   -> per-read stage dump
 //   ref_dump ext   <case> <out>                        -> extend_backward traces
 //   ref_dump ksw   <kswcase> <out> [dirty]             -> kswcpp_dispatch results
+//   ref_dump readpair <in1> <in2> <out> <revcomp mate 0|1> -> mate pairs of the PairedFileReader
 //   ref_dump f4    <case> <preset> <seed> <out> <inversions 0|1> <paired 0|1> <zdrop_inversion> [<out.sam> [<sam options>]]
 //                                                      -> SmallInversions / PairedReads lists (+ SAM of the (Paired)FileWriter)
 #include "ma/container/fMIndex.h"
@@ -336,6 +337,41 @@ static int cmdRead( const char* sIn, const char* sOut )
     return 0;
 }
 
+// mate pairs as the reference's PairedFileReader (fileReader.h:568-617) returns them; bRevComp = "Paired Mate - Mate Pair"
+static int cmdReadPair( const char* sIn1, const char* sIn2, const char* sOut, bool bRevComp )
+{
+    ParameterSetManager xParams;
+    xParams.getSelected( )->xRevCompPairedReadMates->set( bRevComp );
+    PairedFileReader xReader( xParams );
+    auto pStream = std::make_shared<PairedFileStream>( std::make_shared<StdFileStream>( fs::path( sIn1 ) ),
+                                                       std::make_shared<StdFileStream>( fs::path( sIn2 ) ) );
+    FILE* f = fopen( sOut, "w" );
+    while( true )
+    {
+        std::shared_ptr<PairedReadsContainer> pPair;
+        try
+        {
+            pPair = xReader.execute( pStream );
+        }
+        catch( const std::runtime_error& e )
+        {
+            fprintf( f, "ERROR %s\n", e.what( ) );
+            break;
+        }
+        if( pPair == nullptr )
+            break;
+        for( auto pQ : *pPair )
+        {
+            fprintf( f, "%s %llu ", pQ->sName.c_str( ), (unsigned long long)pQ->length( ) );
+            for( size_t i = 0; i < pQ->length( ); i++ )
+                fputc( '0' + ( *pQ )[ i ], f );
+            fprintf( f, " %s\n", pQ->toQualString( ).c_str( ) );
+        }
+    }
+    fclose( f );
+    return 0;
+}
+
 static int cmdExt( const char* sCase, const char* sOut )
 {
     CaseFile c = readCase( sCase );
@@ -410,6 +446,8 @@ int main( int argc, char** argv )
     if( argc >= 9 && !strcmp( argv[ 1 ], "f4" ) )
         return cmdF4( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ], atoi( argv[ 6 ] ) != 0, atoi( argv[ 7 ] ) != 0,
                       atoi( argv[ 8 ] ), argc >= 10 ? argv[ 9 ] : nullptr, argc >= 11 ? atoi( argv[ 10 ] ) : 0 );
+    if( argc >= 6 && !strcmp( argv[ 1 ], "readpair" ) )
+        return cmdReadPair( argv[ 2 ], argv[ 3 ], argv[ 4 ], atoi( argv[ 5 ] ) != 0 );
     if( argc >= 4 && !strcmp( argv[ 1 ], "read" ) )
         return cmdRead( argv[ 2 ], argv[ 3 ] );
     if( argc >= 4 && !strcmp( argv[ 1 ], "ext" ) )

@@ -60,6 +60,14 @@ def reader_goldens():
             f.write("@fq%d sample=%d\n%s\n+\n%s\n" % (i, i, seq, qual))
     run_ref("sam", "small.case", "default", 1, os.path.join("reader", "small24.fq.sam"), 0, os.path.join("reader", "small24.fq"))
     gz(os.path.join("reader", "small24.fq.sam"))
+    # mate files for the PairedFileReader: second file one record shorter (EOF of either ends the pairs), Ns in a mate
+    with open(os.path.join("reader", "mates_1.fq"), "w") as f:
+        f.write("@p0/1\nACGTTGCA\n+\nIIIIHHHH\n@p1/1\nGGGTTTAACC\n+\n0123456789\n@p2/1\nAAAA\n+\n!!!!\n")
+    with open(os.path.join("reader", "mates_2.fq"), "w") as f:
+        f.write("@p0/2 x\nTTGACCNA\n+\nABCDEFGH\n@p1/2\nCATG\n+\n9876\n")
+    for rc in (0, 1):
+        run_ref("readpair", os.path.join("reader", "mates_1.fq"), os.path.join("reader", "mates_2.fq"),
+                os.path.join("reader", "mates.rc%d.ref" % rc), rc)
 
 
 KSW_SCORINGS = [(3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 24, 1, 4, 2), (5, 4, 2, 1, 40, 1)]

@@ -120,6 +120,47 @@ def test_extend_backward_and_bwt_sa(small):
     assert np.array_equal(gidx.bwt_sa(rows), oidx.bwt_sa(rows))
 
 
+def test_pack_extract(small):
+    """ma_pack_extract = Pack::vExtract (pack.h:1147-1236): forward ranges, reverse-strand ranges (complement of the
+    mirrored forward base), empty ranges; bridging and out-of-range requests fail like the reference throws."""
+    import ma_amd
+    gidx = small["gidx"]
+    fwd = np.concatenate(small["contigs"]).astype(np.uint8)
+    F = len(fwd)
+    text = np.concatenate([fwd, (3 - fwd[::-1]).astype(np.uint8)])
+    rng = np.random.default_rng(17)
+    b = np.concatenate([rng.integers(0, F - 700, 40), rng.integers(F, 2 * F - 700, 40), [0, F, 2 * F - 1, 5, F - 1]])
+    e = b + np.concatenate([rng.integers(1, 700, 80), [1, 1, 1, 0, 1]])
+    got = gidx.extract(b, e)
+    for i in range(len(b)):
+        assert np.array_equal(got[i], text[int(b[i]):int(e[i])]), "range %d" % i
+    for bb, ee in ((F - 3, F + 3), (10, 5), (2 * F - 1, 2 * F + 1)):
+        with pytest.raises(ma_amd.MaError, match="vExtractSubsection"):
+            gidx.extract([bb], [ee])
+
+
+def test_pipeline_long_read_presets_vs_oracle(small):
+    """PacBio / Nanopore presets (parameter.h:1096-1104): up to 100 supplementary alignments, at least 5 SoCs, SMEMs."""
+    import ma_amd
+    reads = small["reads"]
+    for technique in (0, 1):
+        P = ma_amd.Params.preset("default")
+        op = or_params("default", 1)
+        for prm in (P, op):
+            prm.max_supplementary, prm.min_num_soc, prm.seeding_technique, prm.srand_seed = 100, 5, technique, 1
+        b = ma_amd.Batch(small["gidx"], P, len(reads), sum(len(r) for r in reads) + 64)
+        b.set_reads(reads)
+        b.align()
+        b.sync()
+        moff, malns, mops = b.mapq_alignments()
+        res = small["oidx"].align(reads, op)
+        assert np.array_equal(moff, res["mq_off"])
+        for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "secondary", "supplementary"):
+            assert np.array_equal(malns[f], res["mq"][f]), f
+        assert np.array_equal(malns["mapq"].view(np.uint64), res["mq"]["mapq"].view(np.uint64))
+        assert int(malns["supplementary"].sum()) > 0
+
+
 # reference outputs for ksw.case under the presets' scoring and under make_golden.py's KSW_SCORINGS
 KSW_GOLDEN = [("ksw_ref.out.gz", None), ("ksw_ref.sc0.out.gz", (3, 5, 6, 3, 30, 2)), ("ksw_ref.sc1.out.gz", (1, 3, 5, 2, 24, 1)),
               ("ksw_ref.sc2.out.gz", (2, 4, 24, 1, 4, 2)), ("ksw_ref.sc3.out.gz", (5, 4, 2, 1, 40, 1))]
