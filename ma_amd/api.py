@@ -157,9 +157,10 @@ class Index:
         """Pack::vExtract for ranges [begin[i], end[i]) of the doubled text: list of uint8 code arrays."""
         b = np.ascontiguousarray(begin, dtype=np.uint64)
         e = np.ascontiguousarray(end, dtype=np.uint64)
-        out = np.empty(int((e - b).sum()) + 1, dtype=np.uint8)
+        n = np.where(e > b, e - b, 0)
+        out = np.empty(int(n.sum()) + 1, dtype=np.uint8)
         _chk(lib().ma_pack_extract(self.h, _ptr(b), _ptr(e), C.c_uint64(len(b)), _ptr(out)))
-        cuts = np.concatenate([[0], np.cumsum(e - b)]).astype(np.int64)
+        cuts = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
         return [out[cuts[i]:cuts[i + 1]] for i in range(len(b))]
 
     def extend_backward(self, ik, c):

@@ -142,7 +142,9 @@ def test_pack_extract(small):
 def test_pipeline_long_read_presets_vs_oracle(small):
     """PacBio / Nanopore presets (parameter.h:1096-1104): up to 100 supplementary alignments, at least 5 SoCs, SMEMs."""
     import ma_amd
-    reads = small["reads"]
+    # f4.case has the genome of small.case; its last reads carry small inversions -> supplementary alignments
+    _, f4reads, _ = read_case(gunzip_to(os.path.join(G, "f4.case.gz"), str(small["dir"] / "f4.case")))
+    reads = small["reads"][:60] + f4reads[-16:]
     for technique in (0, 1):
         P = ma_amd.Params.preset("default")
         op = or_params("default", 1)
