@@ -47,7 +47,18 @@ __device__ __forceinline__ u32 pk_lshr15( u32 a ) { return KR( KU2( a ) >> (unsi
 __device__ __forceinline__ u32 pk_mad( u32 a, u32 b, u32 c ) { return KR( KU2( a ) * KU2( b ) + KU2( c ) ); }
 __device__ __forceinline__ u32 pk_bfi( u32 mask, u32 a, u32 b ) // mask ? a : b, bitwise
 {
-    return ( a & mask ) | ( b & ~mask );
+    return b ^ ( ( a ^ b ) & mask ); // one v_bitop3_b32
+}
+// Opaque to the optimiser: keeps a per-half 0 / 0xffff mask a plain 32-bit value, so that pk_bfi stays ONE v_bfi_b32
+// instead of being rewritten into per-half compares + v_cndmask + v_perm (4-5 instructions per select).
+__device__ __forceinline__ u32 pk_opaque( u32 x )
+{
+    asm( "" : "+v"( x ) );
+    return x;
+}
+__device__ __forceinline__ u32 pk_nonzero15( u32 x ) // per half: 0xffff if 1 <= x <= 0x8000 else 0 (x = 0)
+{
+    return KR( KS2( pk_opaque( KR( KU2( x ) + KU2( 0x7fff7fffu ) ) ) ) >> (short)15 );
 }
 __device__ __forceinline__ u32 pk_bcast( i32 v ) // both halves = v (16 bit)
 {
@@ -214,10 +225,17 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     const u32 K_X0 = pk_val( -q - e, tX ), K_Y0 = pk_val( -q - e, tY ), K_X20 = pk_val( -q2 - e2, tX2 ),
               K_Y20 = pk_val( -q2 - e2, tY2 ), K_V0 = pk_val( -q - e, 0 );
     const u32 K_TX = pk_val( 0, tX ), K_TY = pk_val( 0, tY ), K_TX2 = pk_val( 0, tX2 ), K_TY2 = pk_val( 0, tY2 );
+    // flag thresholds: sign( K - a ) is "a > tag" for LEFT and "a >= tag" for RIGHT
+    const u32 K_FX = pk_sub( K_TX, LEFT ? 0u : 0x00010001u ), K_FY = pk_sub( K_TY, LEFT ? 0u : 0x00010001u ),
+              K_FX2 = pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ), K_FY2 = pk_sub( K_TY2, LEFT ? 0u : 0x00010001u );
     const u32 K_Q = pk_val( q, 0 ), K_Q2 = pk_val( q2, 0 ), K_QE = pk_val( q + e, 0 ), K_QE2 = pk_val( q2 + e2, 0 );
     const u32 K_MCH = pk_val( sc_mch, tS ), K_NDIFF = pk_val( sc_mis - sc_mch, 0 ), K_NADJ = pk_val( -e2 - sc_mis, 0 );
     const u32 K_CLIP = pk_val( sc_mch, 0xff ), K_NEG = 0x80008000u, K_MATCH = pk_bcast( sc_mch );
     const u32 M_LANE0LO = lane == 0 ? 0x0000ffffu : 0u;
+    // the constants of the per-diagonal path live in VGPRs: as SGPRs they overflow the scalar file (spills read back
+    // with v_readlane inside the loop) and a VOP3P instruction takes only one scalar operand anyway
+    const u32 V_NDIFF = pk_opaque( K_NDIFF ), V_MCH = pk_opaque( K_MCH ), V_NADJ = pk_opaque( K_NADJ ), V_CLIP = pk_opaque( K_CLIP );
+    const u32 V_Q = pk_opaque( K_Q ), V_Q2 = pk_opaque( K_Q2 ), V_QE = pk_opaque( K_QE ), V_QE2 = pk_opaque( K_QE2 );
 
     // the query, four bases per lane (qlen <= 256)
     u32 Qall = 0;
@@ -347,15 +365,14 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             }
             // ---- live cells of this slot: st0 <= t <= en0
             const u32 dd = pk_sub( TTpk[ s ], st0pk ); // t - st0 (mod 2^16)
-            const u32 lm1 = pk_minu( pk_subsatu( wpk, dd ), 0x00010001u ); // 1 where live
-            const u32 LM = pk_sub( 0u, lm1 ); // 0xffff where live
+            const u32 LM = pk_opaque( pk_nonzero15( pk_subsatu( wpk, dd ) ) ); // 0xffff where live (width <= 514)
             DD[ s ] = dd;
             LMs[ s ] = LM;
             // ---- score: match / mismatch, -e2 when either base is N (kswcpp_core.h:598-615)
             const u32 isN = pk_lshr( T[ s ] | Qf[ s ], 2 );
-            const u32 differ = pk_minu( ( T[ s ] ^ Qf[ s ] ) | isN, 0x00010001u );
-            u32 z = pk_mad( differ, K_NDIFF, K_MCH );
-            z = pk_mad( isN, K_NADJ, z );
+            const u32 differ = pk_lshr( pk_add( pk_opaque( ( T[ s ] ^ Qf[ s ] ) | isN ), 0x00070007u ), 3 ); // codes <= 7
+            u32 z = pk_mad( differ, V_NDIFF, V_MCH );
+            z = pk_mad( isN, V_NADJ, z );
             // ---- DP cell (kswcpp_core.h:653-766)
             const u32 ut = U[ s ];
             u32 a = pk_add( xt1[ s ], vt1[ s ] );
@@ -374,31 +391,19 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                 d = z & 0x00070007u;
                 z = pk_max( z, b2 ); // state 4 is never recorded (kswcpp_core.h:693-699)
             }
-            const u32 zc = pk_min( z, K_CLIP ) & 0xff00ff00u;
+            const u32 zc = pk_min( z, V_CLIP ) & 0xff00ff00u;
             const u32 nu = pk_sub( zc, vt1[ s ] ), nv = pk_sub( zc, ut );
-            u32 tmp = pk_sub( zc, K_Q );
+            u32 tmp = pk_sub( zc, V_Q );
             a = pk_sub( a, tmp );
             b = pk_sub( b, tmp );
-            tmp = pk_sub( zc, K_Q2 );
+            tmp = pk_sub( zc, V_Q2 );
             a2 = pk_sub( a2, tmp );
             b2 = pk_sub( b2, tmp );
-            const u32 nx = pk_sub( pk_max( a, K_TX ), K_QE ), ny = pk_sub( pk_max( b, K_TY ), K_QE );
-            const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), K_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), K_QE2 );
-            u32 fa, fb, fa2, fb2; // bit 15 of a half = continuation flag
-            if( LEFT )
-            {
-                fa = pk_subsat( K_TX, a ); // a > 0
-                fb = pk_subsat( K_TY, b );
-                fa2 = pk_subsat( K_TX2, a2 );
-                fb2 = pk_subsat( K_TY2, b2 );
-            }
-            else
-            {
-                fa = ~pk_subsat( a, K_TX ); // !(a < 0)
-                fb = ~pk_subsat( b, K_TY );
-                fa2 = ~pk_subsat( a2, K_TX2 );
-                fb2 = ~pk_subsat( b2, K_TY2 );
-            }
+            const u32 nx = pk_sub( pk_max( a, K_TX ), V_QE ), ny = pk_sub( pk_max( b, K_TY ), V_QE );
+            const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), V_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), V_QE2 );
+            // continuation flags = sign bit of a packed difference (no overflow: the scoring guard of ksw_ext_slots keeps
+            // every difference vector far inside int8): LEFT a > 0, RIGHT !(a < 0) (kswcpp_core.h:653-699)
+            const u32 fa = pk_sub( K_FX, a ), fb = pk_sub( K_FY, b ), fa2 = pk_sub( K_FX2, a2 ), fb2 = pk_sub( K_FY2, b2 );
             d |= ( ( fa >> 12 ) & 0x00080008u ) | ( ( fb >> 11 ) & 0x00100010u ) | ( ( fa2 >> 10 ) & 0x00200020u ) |
                  ( ( fb2 >> 9 ) & 0x00400040u );
             // ---- commit: u, y, y2 of cells that are not born yet keep their first-row initialisation

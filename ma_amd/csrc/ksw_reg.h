@@ -15,7 +15,7 @@ __device__ __forceinline__ i32 dpp_wave_shr1( i32 x ) // lane i <- lane i-1 (lan
 }
 __device__ __forceinline__ i32 dpp_wave_ror1( i32 x ) // lane i <- lane i-1, lane 0 <- lane 63
 {
-    return __builtin_amdgcn_update_dpp( 0, x, 0x13C, 0xf, 0xf, false );
+    return __builtin_amdgcn_mov_dpp( x, 0x13C, 0xf, 0xf, false ); // every lane is written: no `old` to initialise
 }
 template <int CTRL> __device__ __forceinline__ i32 dpp_ctrl( i32 x )
 {
