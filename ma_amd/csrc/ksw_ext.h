@@ -68,6 +68,12 @@ __device__ __forceinline__ u32 pk_val( i32 v8, u32 tag ) // int8 value in the hi
 {
     return pk_bcast( (i32)( ( ( (u32)v8 & 0xffu ) << 8 ) | tag ) );
 }
+// x with lane 0 replaced by the wave-uniform value v (v_writelane_b32; the lane select is the constant 0)
+__device__ __forceinline__ u32 lane0_write( u32 x, u32 v )
+{
+    asm( "v_writelane_b32 %0, %1, 0" : "+v"( x ) : "s"( v ) );
+    return x;
+}
 // lane i <- lane i-1 with lane 0 <- lane 63 (one register = a ring of 64 lanes)
 __device__ __forceinline__ u32 lanes_ror1( u32 x ) { return (u32)dpp_wave_ror1( (i32)x ); }
 // per-cell shift by one: half lo <- previous lane's hi, half hi <- own lo
@@ -229,12 +235,14 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     const u32 K_FX = pk_sub( K_TX, LEFT ? 0u : 0x00010001u ), K_FY = pk_sub( K_TY, LEFT ? 0u : 0x00010001u ),
               K_FX2 = pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ), K_FY2 = pk_sub( K_TY2, LEFT ? 0u : 0x00010001u );
     const u32 K_Q = pk_val( q, 0 ), K_Q2 = pk_val( q2, 0 ), K_QE = pk_val( q + e, 0 ), K_QE2 = pk_val( q2 + e2, 0 );
-    const u32 K_MCH = pk_val( sc_mch, tS ), K_NDIFF = pk_val( sc_mis - sc_mch, 0 ), K_NADJ = pk_val( -e2 - sc_mis, 0 );
     const u32 K_CLIP = pk_val( sc_mch, 0xff ), K_NEG = 0x80008000u, K_MATCH = pk_bcast( sc_mch );
     const u32 M_LANE0LO = lane == 0 ? 0x0000ffffu : 0u;
     // the constants of the per-diagonal path live in VGPRs: as SGPRs they overflow the scalar file (spills read back
     // with v_readlane inside the loop) and a VOP3P instruction takes only one scalar operand anyway
-    const u32 V_NDIFF = pk_opaque( K_NDIFF ), V_MCH = pk_opaque( K_MCH ), V_NADJ = pk_opaque( K_NADJ ), V_CLIP = pk_opaque( K_CLIP );
+    const u32 V_CLIP = pk_opaque( K_CLIP );
+    // score table (kswcpp_core.h:598-615): bytes 0 match, 1..3 mismatch, 4 = -e2 (either base is N), 5 = tag of s
+    const u32 V_SCLO = pk_opaque( ( (u32)sc_mch & 0xffu ) | ( ( (u32)sc_mis & 0xffu ) * 0x01010100u ) );
+    const u32 V_SCHI = pk_opaque( ( (u32)( -e2 ) & 0xffu ) | tS << 8 );
     const u32 V_Q = pk_opaque( K_Q ), V_Q2 = pk_opaque( K_Q2 ), V_QE = pk_opaque( K_QE ), V_QE2 = pk_opaque( K_QE2 );
 
     // the query, four bases per lane (qlen <= 256)
@@ -245,8 +253,12 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         Qall |= ( i < qlen ? (u32)qbase( i ) & 0xffu : 4u ) << ( 8 * k );
     }
     auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t+1
-        const u32 a = t < tlen ? (u32)tbase( t ) & 0xffu : 0u;
-        const u32 b = t + 1 < tlen ? (u32)tbase( t + 1 ) & 0xffu : 0u;
+        // an N of the target is coded 12, one of the query 4..5: base ^ base is 0 for a match, 1..3 for a mismatch and
+        // >= 4 as soon as either is N (the score look-up below)
+        u32 a = t < tlen ? (u32)tbase( t ) & 0xffu : 0u;
+        u32 b = t + 1 < tlen ? (u32)tbase( t + 1 ) & 0xffu : 0u;
+        a = a < 4 ? a : 12u;
+        b = b < 4 ? b : 12u;
         return a | b << 16;
     };
     auto uInit2 = [ & ]( i32 t ) -> u32 { // first-row u of cells t, t+1
@@ -322,30 +334,31 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             for( int s = 0; s < R; s++ )
             {
                 const int sp = s == 0 ? R - 1 : s - 1; // lane 0 continues lane 63 of the previous slot of the ring
-                const u32 ax = R == 1 ? px[ s ] : ( lane == 0 ? px[ sp ] : px[ s ] );
-                const u32 av = R == 1 ? pv[ s ] : ( lane == 0 ? pv[ sp ] : pv[ s ] );
-                const u32 ax2 = R == 1 ? px2[ s ] : ( lane == 0 ? px2[ sp ] : px2[ s ] );
-                const u32 ah = R == 1 ? ph[ s ] : ( lane == 0 ? ph[ sp ] : ph[ s ] );
-                const u32 aq = R == 1 ? pq[ s ] : ( lane == 0 ? pq[ sp ] : pq[ s ] );
+                u32 ax = R == 1 ? px[ s ] : ( lane == 0 ? px[ sp ] : px[ s ] );
+                u32 av = R == 1 ? pv[ s ] : ( lane == 0 ? pv[ sp ] : pv[ s ] );
+                u32 ax2 = R == 1 ? px2[ s ] : ( lane == 0 ? px2[ sp ] : px2[ s ] );
+                u32 ah = R == 1 ? ph[ s ] : ( lane == 0 ? ph[ sp ] : ph[ s ] );
+                u32 aq = R == 1 ? pq[ s ] : ( lane == 0 ? pq[ sp ] : pq[ s ] );
+                if( s == 0 && st0 == 0 )
+                {
+                    // cell 0 (slot 0, lane 0, low half until it is recycled at r >= qlen + 15): first-column carry-in
+                    // (kswcpp_core.h:562-579) and the query base that enters the band.  The shift takes the low half of
+                    // lane 0 from the HIGH half of its predecessor: write the boundary values there (v_writelane, scalar).
+                    const u32 qb = ( (u32)lane_bcast( (i32)Qall, r >> 2 ) >> ( 8 * ( r & 3 ) ) ) & 0xffu;
+                    hLeft += ini; // H(-1, r)
+                    ax = lane0_write( ax, K_X0 << 16 );
+                    ax2 = lane0_write( ax2, K_X20 << 16 );
+                    av = lane0_write( av, ( (u32)ini & 0xffu ) << 24 );
+                    if( !GLOBAL )
+                        ah = lane0_write( ah, (u32)hLeft << 16 );
+                    aq = lane0_write( aq, qb << 16 );
+                }
                 xt1[ s ] = cells_shift1( X[ s ], ax );
                 vt1[ s ] = cells_shift1( V[ s ], av );
                 x2t1[ s ] = cells_shift1( X2[ s ], ax2 );
                 hup[ s ] = GLOBAL ? 0u : cells_shift1( H[ s ], ah );
                 Qf[ s ] = cells_shift1( Qf[ s ], aq );
             }
-        }
-        if( st0 == 0 )
-        {
-            // cell 0 (slot 0, lane 0, low half until it is recycled at r >= qlen + 15): first-column carry-in
-            // (kswcpp_core.h:562-579) and the query base that enters the band
-            const u32 qb = ( (u32)lane_bcast( (i32)Qall, r >> 2 ) >> ( 8 * ( r & 3 ) ) ) & 0xffu;
-            xt1[ 0 ] = pk_bfi( M_LANE0LO, K_X0, xt1[ 0 ] );
-            x2t1[ 0 ] = pk_bfi( M_LANE0LO, K_X20, x2t1[ 0 ] );
-            vt1[ 0 ] = pk_bfi( M_LANE0LO, ( (u32)ini & 0xffu ) << 8, vt1[ 0 ] );
-            hLeft += ini; // H(-1, r)
-            if( !GLOBAL )
-                hup[ 0 ] = pk_bfi( M_LANE0LO, (u32)hLeft & 0xffffu, hup[ 0 ] );
-            Qf[ 0 ] = pk_bfi( M_LANE0LO, qb, Qf[ 0 ] );
         }
         const u32 st0pk = pk_bcast( st0 ), wpk = pk_bcast( en0 - st0 + 1 );
         uint8_t* prow = P + (size_t)r * RING;
@@ -369,10 +382,9 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             DD[ s ] = dd;
             LMs[ s ] = LM;
             // ---- score: match / mismatch, -e2 when either base is N (kswcpp_core.h:598-615)
-            const u32 isN = pk_lshr( T[ s ] | Qf[ s ], 2 );
-            const u32 differ = pk_lshr( pk_add( pk_opaque( ( T[ s ] ^ Qf[ s ] ) | isN ), 0x00070007u ), 3 ); // codes <= 7
-            u32 z = pk_mad( differ, V_NDIFF, V_MCH );
-            z = pk_mad( isN, V_NADJ, z );
+            // one byte permute as look-up: index min(q ^ t, 4) -> value byte, index 5 -> the tag of s
+            const u32 sel = ( pk_minu( T[ s ] ^ Qf[ s ], 0x00040004u ) << 8 ) | 0x00050005u;
+            u32 z = __builtin_amdgcn_perm( V_SCHI, V_SCLO, sel );
             // ---- DP cell (kswcpp_core.h:653-766)
             const u32 ut = U[ s ];
             u32 a = pk_add( xt1[ s ], vt1[ s ] );
