@@ -64,6 +64,12 @@ __device__ __forceinline__ u32 pk_bcast( i32 v ) // both halves = v (16 bit)
 {
     return ( (u32)v & 0xffffu ) * 0x00010001u;
 }
+__device__ __forceinline__ u32 pk_bcast_s( i32 v ) // the same for a wave-uniform value: one scalar instruction
+{
+    u32 r;
+    asm( "s_pack_ll_b32_b16 %0, %1, %1" : "=s"( r ) : "s"( v ) );
+    return r;
+}
 __device__ __forceinline__ u32 pk_val( i32 v8, u32 tag ) // int8 value in the high byte, tag in the low byte
 {
     return pk_bcast( (i32)( ( ( (u32)v8 & 0xffu ) << 8 ) | tag ) );
@@ -109,7 +115,7 @@ MA_HD int ksw_ext_slots( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zd
 // wave-uniform and kept on the scalar unit; rows are staged into LDS `rows` at a time by all 64 lanes.
 template <int RING>
 __device__ __forceinline__ void ksw_backtrack_ring( const uint8_t* P, u32* cig, i32 flag, i32 i0, i32 j0, u32& nCigar,
-                                                    u64& pathSteps, uint8_t* stage, u32 stageBytes )
+                                                    u64& pathSteps, uint8_t* stage, u32 stageBytes, i32 qlen, i32 tlen )
 {
     const int lane = threadIdx.x & 63;
     const i32 rows = (i32)( stageBytes / RING ); // >= 1
@@ -125,8 +131,14 @@ __device__ __forceinline__ void ksw_backtrack_ring( const uint8_t* P, u32* cig, 
             rlo = r - rows + 1 > 0 ? r - rows + 1 : 0;
             const i32 bytes = ( r - rlo + 1 ) * RING;
             const uint8_t* src = P + (size_t)rlo * RING;
+            // only the 16-byte chunks that hold live cells [st0, en0] of their row were written; read no others
             for( i32 k = lane * 16; k < bytes; k += 1024 )
-                *(uint4*)( stage + k ) = *(const uint4*)( src + k );
+            {
+                const i32 rr = rlo + k / RING, col = k & ( RING - 1 );
+                const i32 st = ( rr - qlen + 1 > 0 ? rr - qlen + 1 : 0 ) & ~15, en = rr < tlen - 1 ? rr : tlen - 1;
+                if( ( ( col - st ) & ( RING - 1 ) ) <= en - st )
+                    *(uint4*)( stage + k ) = *(const uint4*)( src + k );
+            }
             __syncthreads( );
         }
         const i32 tmp = __builtin_amdgcn_readfirstlane( (i32)stage[ ( r - rlo ) * RING + ( i & ( RING - 1 ) ) ] );
@@ -288,17 +300,23 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     i32 recycled = 0; // cells below this index have been handed to cells RING further up
     // H(-1, r-1) of the first column, H(r-1, -1) of the first row.  (sic) When the two gap models were swapped, kswcpp's
     // H[0] = v[0] - (q+e) uses the UNswapped sum, which offsets every score of the matrix by (q+e)_swapped - (q+e)_given.
-    i32 hLeft = ( q + e ) - qe0, hTop = ( q + e ) - qe0;
+    i32 hLeft = ( q + e ) - qe0;
+    // H(n-1, -1) = hLeft's offset + the sum of initOf(0..n-1) in closed form (only the early stop reads it)
+    auto hTopBefore = [ & ]( i32 n ) -> i32 {
+        const i32 a = max( 0, min( n, long_thres ) - 1 ); // cells 1..n-1 below long_thres
+        const i32 has = long_thres >= 1 && long_thres < n ? 1 : 0;
+        const i32 rest = ( n - 1 ) - a - has;
+        return ( q + e ) - qe0 + ( n < 1 ? 0 : -( q + e ) - e * a + ( has ? long_diff : 0 ) - e2 * rest );
+    };
     i32 boundPrev = 0x7fffffff;
     const i32 nDiag = qlen + tlen - 1;
     bool stop = false;
-    u64 nCells = 0;
+    u32 nCells = 0; // < 2^32: qlen <= 256 cells on at most w + 1 diagonals
     for( i32 r = 0; r < nDiag && !stop; ++r )
     {
         if( r > w )
             return false; // the band starts to cut the rectangle: not this kernel's regime
         const i32 st0 = max( 0, r - qlen + 1 ), en0 = min( r, tlen - 1 );
-        const i32 ini = initOf( r );
         // ---- recycle the 16-cell block that left the band
         if( ( st0 & ~15 ) > recycled )
         {
@@ -345,6 +363,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                     // (kswcpp_core.h:562-579) and the query base that enters the band.  The shift takes the low half of
                     // lane 0 from the HIGH half of its predecessor: write the boundary values there (v_writelane, scalar).
                     const u32 qb = ( (u32)lane_bcast( (i32)Qall, r >> 2 ) >> ( 8 * ( r & 3 ) ) ) & 0xffu;
+                    const i32 ini = initOf( r );
                     hLeft += ini; // H(-1, r)
                     ax = lane0_write( ax, K_X0 << 16 );
                     ax2 = lane0_write( ax2, K_X20 << 16 );
@@ -360,7 +379,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                 Qf[ s ] = cells_shift1( Qf[ s ], aq );
             }
         }
-        const u32 st0pk = pk_bcast( st0 ), wpk = pk_bcast( en0 - st0 + 1 );
+        const u32 st0pk = pk_bcast_s( st0 ), wpk = pk_bcast_s( en0 - st0 + 1 );
         uint8_t* prow = P + (size_t)r * RING;
         u32 Hm[ R ], DD[ R ], LMs[ R ];
         const int sLo = ( st0 & ( RING - 1 ) ) >> 7, sHi = ( en0 & ( RING - 1 ) ) >> 7;
@@ -435,7 +454,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                 Hm[ s ] = pk_bfi( LM, hn, K_NEG );
             }
         }
-        nCells += (u64)( en0 - st0 + 1 );
+        nCells += (u32)( en0 - st0 + 1 );
         if( GLOBAL )
             continue;
         // ---- the diagonal's maximum
@@ -445,12 +464,12 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             hm = pk_max( hm, Hm[ s ] );
         // cheap wave-uniform tests instead of a full reduction: does any cell exceed ez.max, and (z-drop candidate)
         // are all cells below ez.max - zdrop?  Only then the exact (max_H, max_t) of the diagonal is needed.
-        const u32 ezpk = pk_bcast( (i32)ez.max );
+        const u32 ezpk = pk_bcast_s( (i32)ez.max );
         const bool newMax = __any( pk_max( hm, ezpk ) != ezpk ) != 0;
         bool need = newMax;
         if( !need && J.zdrop >= 0 && (i32)ez.max - J.zdrop - 1 >= -32768 )
         {
-            const u32 tpk = pk_bcast( (i32)ez.max - J.zdrop - 1 );
+            const u32 tpk = pk_bcast_s( (i32)ez.max - J.zdrop - 1 );
             need = __any( pk_max( hm, tpk ) != tpk ) == 0;
         }
         if( need )
@@ -540,7 +559,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         // ---- early stop (ksw_reg.h): no later cell can exceed ez.max
         if( !newMax && !stop && r >= qlen - 1 && ( r & 2 ) ) // on two of every four diagonals
         {
-            const u32 qo = pk_bcast( qlen - 1 - r );
+            const u32 qo = pk_bcast_s( qlen - 1 - r );
             u32 bm = K_NEG;
 #pragma unroll
             for( int s = 0; s < R; s++ )
@@ -550,13 +569,12 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                 bm = pk_max( bm, pk_bfi( LMs[ s ], bnd, K_NEG ) );
             }
             const i32 bound = wave_max_i32( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
-            if( r >= qlen && max( max( bound, boundPrev ), hTop + sc_mch * qlen ) <= (i32)ez.max )
+            if( r >= qlen && max( max( bound, boundPrev ), hTopBefore( r ) + sc_mch * qlen ) <= (i32)ez.max )
                 stop = true;
             boundPrev = bound;
         }
         else
             boundPrev = 0x7fffffff;
-        hTop += ini; // H(r, -1)
     }
     cells += nCells;
 #if defined( MA_KSW_PROF )
@@ -566,7 +584,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     if( !GLOBAL && ( ez.max_t < 0 || ez.max_q < 0 ) )
         return true;
     ksw_backtrack_ring<RING>( P, cig, J.flag, GLOBAL ? tlen - 1 : ez.max_t, GLOBAL ? qlen - 1 : ez.max_q, nCigar,
-                              pathSteps, lds, ldsBytes );
+                              pathSteps, lds, ldsBytes, qlen, tlen );
 #if defined( MA_KSW_PROF )
     prof[ GLOBAL ? 8 : 4 ] += tp1 - tp0; // diagonal loop
     prof[ GLOBAL ? 9 : 5 ] += clock64( ) - tp1; // back-trace
