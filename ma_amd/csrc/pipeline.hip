@@ -63,6 +63,7 @@ struct SeedKernelArgs
     u32 smem_cap;
     u32* stack; // lanes * 2 * MA_SEED_STACK
     u32 q_lds; // LDS bytes per lane for the read in flight (0: reads stay in HBM)
+    u32 slow_batch; // lanes of a wave that must wait for a phase transition before the transitions are run
     ma_segment* pool;
     u32* pool_read; // read id per pooled segment
     u64 pool_cap;
@@ -189,8 +190,16 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
 #if defined( MA_KSW_PROF )
         const unsigned long long tB = clock64( );
 #endif
-        u32 c;
-        const bool ext = alive && L.phase != PH_DONE && seed_prepare( L, A.P, S, A.X, c );
+        u32 c = 0;
+        const bool act = alive && L.phase != PH_DONE;
+        bool ext = act && seed_try( L, c );
+        {
+            // phase transitions are batched like the refills: run them when enough lanes wait for one (or nobody can step)
+            const unsigned long long sm = __ballot( act && !ext );
+            if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
+                if( act && !ext )
+                    ext = seed_prepare( L, A.P, S, A.X, c );
+        }
 #if defined( MA_KSW_PROF )
         const unsigned long long tC = clock64( );
         pf[ 4 ] += __popcll( __ballot( ext ) );
@@ -1091,6 +1100,9 @@ int ma_seed_batch( ma_batch* b )
             // reads up to 240 bases are staged in LDS (256 lanes x q_lds bytes <= 64 KB)
             const u32 qb = (u32)( ( b->max_qlen + 7 ) / 8 * 8 + 4 );
             A.q_lds = qb * 256 <= 64 * 1024 ? qb : 0;
+            A.slow_batch = 4; // measured: 8.98 ms (1) -> 8.56 ms (4) -> 8.87 ms (8) per 1 M x 150 bp reads
+            if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook
+                A.slow_batch = (u32)std::max( 1, atoi( e ) );
             hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
         }
         MA_HIP( hipGetLastError( ) );

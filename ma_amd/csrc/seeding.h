@@ -156,6 +156,22 @@ MA_HD bool seed_stop( const SeedParams& P, const i64 ok[ 3 ], const i64 ik[ 3 ] 
     return ok[ 2 ] <= (i64)P.min_amb && ik[ 2 ] <= (i64)P.max_amb;
 }
 
+// Can the lane extend right away, i.e. without any phase transition?  (The kernel batches the transitions of a
+// wavefront: a lane whose transition is due idles for a few steps until enough lanes wait, so that the divergent
+// bookkeeping of seed_prepare is executed once for many lanes instead of on every step for one or two.)
+MA_HD bool seed_try( const SeedLane& L, u32& c )
+{
+    const bool right = L.phase == PH_P1_RIGHT || L.phase == PH_P2_RIGHT || L.phase == PH_SMEM_FWD;
+    const bool left = L.phase == PH_P1_LEFT || L.phase == PH_P2_LEFT;
+    const bool ok = right ? L.i < L.qlen : ( left && L.i != 0xffffffffu );
+    if( ok )
+    {
+        const u32 b = L.q[ L.i ];
+        c = right ? comp_base( b ) : b;
+    }
+    return ok;
+}
+
 // ---- transitions (no index access) ----------------------------------------------------------
 // Runs cheap bookkeeping until the lane either needs an extension (returns true and sets c) or is done.
 MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
