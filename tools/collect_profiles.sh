@@ -12,5 +12,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- p
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_SALU; do
   rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o pmc --output-format csv -- python3 $ARGS > $OUT/pmc_$C.log 2>&1
 done
-python3 tools/pmc_summarize.py $OUT 4 > $OUT/summary.txt 2>&1
+python3 tools/pmc_summarize.py $OUT 4 $OUT/pmc_traffic.json > $OUT/summary.txt 2>&1
+cp $OUT/trace/trace_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv ;
 tail -30 $OUT/summary.txt
