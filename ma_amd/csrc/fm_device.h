@@ -38,27 +38,28 @@ MA_HD void load_block( const u32* bwt, u64 blk, Block64& b )
 // the block's cumulative counters.
 MA_HD void occ4_in_block( const Block64& b, u32 within, u64 cnt[ 4 ] )
 {
-    u32 a = 0, c = 0, g = 0, t = 0;
+    // per word: keep the top nsym symbols (two shifts by nsym <= 16 give the mask for every nsym in 0..16 without
+    // a special case), then three popcounts: H = set high bits, L = set low bits, T = both (the symbol 3);
+    // G = H - T, C = L - T, A = symbols - T - G - C once at the end.
+    u32 H = 0, Lo = 0, T = 0;
     const u32 nsymTotal = within + 1;
 #pragma unroll
     for( int w = 0; w < 8; w++ )
     {
         const i32 rem = (i32)nsymTotal - 16 * w;
-        const u32 nsym = rem <= 0 ? 0u : ( rem >= 16 ? 16u : (u32)rem );
-        // keep the top nsym symbols of the word; masked-off positions read as A (00)
-        const u32 mask = nsym == 0 ? 0u : ( nsym == 16 ? 0xffffffffu : ~( ( 1u << ( ( 16 - nsym ) << 1 ) ) - 1u ) );
-        const u32 x = b.w[ w ] & mask;
+        const u32 nsym = (u32)( rem < 0 ? 0 : ( rem > 16 ? 16 : rem ) );
+        const u32 drop = ( 0xffffffffu >> nsym ) >> nsym; // the low 32 - 2 nsym bits
+        const u32 x = b.w[ w ] & ~drop;
         const u32 hi = ( x >> 1 ) & 0x55555555u, lo = x & 0x55555555u;
-        const u32 nt = (u32)popc32( hi & lo ), ng = (u32)popc32( hi & ~lo ), nc = (u32)popc32( ~hi & lo );
-        t += nt;
-        g += ng;
-        c += nc;
-        a += nsym - nt - ng - nc;
+        H += (u32)popc32( hi );
+        Lo += (u32)popc32( lo );
+        T += (u32)popc32( hi & lo );
     }
+    const u32 g = H - T, c = Lo - T, a = nsymTotal - T - g - c;
     cnt[ 0 ] = b.c[ 0 ] + a;
     cnt[ 1 ] = b.c[ 1 ] + c;
     cnt[ 2 ] = b.c[ 2 ] + g;
-    cnt[ 3 ] = b.c[ 3 ] + t;
+    cnt[ 3 ] = b.c[ 3 ] + T;
 }
 
 // x.L2[i] as a register value.  IndexView is a kernel argument; without the (empty) asm the compiler turns a
