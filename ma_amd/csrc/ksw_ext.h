@@ -67,7 +67,7 @@ __device__ __forceinline__ u32 pk_bcast( i32 v ) // both halves = v (16 bit)
 __device__ __forceinline__ u32 pk_bcast_s( i32 v ) // the same for a wave-uniform value: one scalar instruction
 {
     u32 r;
-    asm( "s_pack_ll_b32_b16 %0, %1, %1" : "=s"( r ) : "s"( v ) );
+    asm( "s_pack_ll_b32_b16 %0, %1, %1" : "=s"( r ) : "s"( __builtin_amdgcn_readfirstlane( v ) ) );
     return r;
 }
 __device__ __forceinline__ u32 pk_val( i32 v8, u32 tag ) // int8 value in the high byte, tag in the low byte
@@ -77,7 +77,7 @@ __device__ __forceinline__ u32 pk_val( i32 v8, u32 tag ) // int8 value in the hi
 // x with lane 0 replaced by the wave-uniform value v (v_writelane_b32; the lane select is the constant 0)
 __device__ __forceinline__ u32 lane0_write( u32 x, u32 v )
 {
-    asm( "v_writelane_b32 %0, %1, 0" : "+v"( x ) : "s"( v ) );
+    asm( "v_writelane_b32 %0, %1, 0" : "+v"( x ) : "s"( __builtin_amdgcn_readfirstlane( (i32)v ) ) );
     return x;
 }
 // lane i <- lane i-1 with lane 0 <- lane 63 (one register = a ring of 64 lanes)
@@ -205,6 +205,9 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
 {
     constexpr i32 RING = 128 * R;
     const int lane = threadIdx.x & 63;
+#if defined( MA_KSW_PROF )
+    const unsigned long long tpA = clock64( );
+#endif
     const i32 qlen = J.qlen, tlen = J.tlen, w = J.w;
     ez.max_q = ez.max_t = ez.mqe_t = ez.mte_q = -1;
     ez.max = 0;
@@ -264,6 +267,12 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         const i32 i = 4 * lane + k;
         Qall |= ( i < qlen ? (u32)qbase( i ) & 0xffu : 4u ) << ( 8 * k );
     }
+#if defined( MA_KSW_PROF )
+    asm volatile( "s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory" );
+    const unsigned long long tpB = clock64( );
+    if( !GLOBAL )
+        prof[ 12 ] += tpB - tpA; // job descriptor + query bytes
+#endif
     auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t+1
         // an N of the target is coded 12, one of the query 4..5: base ^ base is 0 for a match, 1..3 for a mismatch and
         // >= 4 as soon as either is N (the score look-up below)
@@ -295,7 +304,10 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         Qf[ s ] = 0x00040004u;
     }
 #if defined( MA_KSW_PROF )
+    asm volatile( "s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory" );
     const unsigned long long tp0 = clock64( );
+    if( !GLOBAL )
+        prof[ 13 ] += tp0 - tpB; // target bytes + state initialisation
 #endif
     i32 recycled = 0; // cells below this index have been handed to cells RING further up
     // H(-1, r-1) of the first column, H(r-1, -1) of the first row.  (sic) When the two gap models were swapped, kswcpp's

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__( 64 ) k_ksw_ext( FETCH F, KswScoring SC, const
     uint8_t* my = scratch + (u64)blockIdx.x * stride;
     u32* cig = (u32*)( my + p_cap );
 #if defined( MA_KSW_PROF )
-    unsigned long long prof[ 12 ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long prof[ 16 ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     KswWaveAcc acc;
     u32 qCur = 0, qEnd = 0;
@@ -234,7 +234,7 @@ __global__ void __launch_bounds__( 64 ) k_ksw_ext( FETCH F, KswScoring SC, const
     ksw_flush( O, acc );
 #if defined( MA_KSW_PROF )
     if( threadIdx.x == 0 )
-        for( int i = 0; i < 12; i++ )
+        for( int i = 0; i < 16; i++ )
             atomicAdd( &g_ksw_prof[ i ], prof[ i ] );
 #endif
 }

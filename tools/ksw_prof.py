@@ -28,5 +28,7 @@ finally:
     print("per job cycles: fetch %.0f core %.0f publish %.0f" % (v[0] / j, v[1] / j, v[2] / j))
     if v[7]:
         print("ext  per job: loop %.0f backtrace %.0f cells %.0f" % (v[4] / v[7], v[5] / v[7], v[6] / v[7]))
+    if v[7]:
+        print("ext  per job: descriptor+query %.0f target+init %.0f" % (v[12] / v[7], v[13] / v[7]))
     if v[11]:
         print("glob per job: loop %.0f backtrace %.0f cells %.0f" % (v[8] / v[11], v[9] / v[11], v[10] / v[11]))
