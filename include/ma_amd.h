@@ -136,8 +136,9 @@ int ma_pack_extract( const ma_index*, const uint64_t* begin, const uint64_t* end
 int ma_extend_backward_batch( const ma_index*, const int64_t* ik, const uint8_t* c, uint64_t n, int64_t* ok );
 /* n independent FMIndex::bwt_sa calls (fMIndex.h:788-814) */
 int ma_bwt_sa_batch( const ma_index*, const int64_t* rows, uint64_t n, int64_t* pos );
-/* n independent kswcpp_dispatch calls (kswcpp.h:165-190). ez[n]; cigars concatenated into cigar[]
- * with cigar_off[n+1]; returns error if cigar_cap is too small. */
+/* n independent kswcpp_dispatch calls (kswcpp.h:165-190). ez[n]; the cigar of job j is the ez[j].n_cigar words at
+ * cigar[cigar_off[j]] (the cigars are packed densely but NOT in job order); cigar_off[n] = words used in total;
+ * returns an error if cigar_cap is too small. */
 int ma_ksw_batch( const ma_params*, const ma_ksw_job* jobs, uint64_t n, const uint8_t* q_bytes, uint64_t q_len,
                   const uint8_t* t_bytes, uint64_t t_len, ma_ez* ez, uint64_t* cigar_off, uint32_t* cigar,
                   uint64_t cigar_cap );

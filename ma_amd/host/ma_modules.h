@@ -733,7 +733,8 @@ class SmallInversions : public libMS::Module<libMS::ContainerVector<std::shared_
                     auto pInv = std::make_shared<Alignment>( );
                     nucSeqIndex qPos = vPos[ k ].uiStartQ, rPos = 0;
                     const int64_t iJob = vJobOfPos[ k ];
-                    for( uint64_t c = iJob < 0 ? 0 : vCigOff[ iJob ]; c < ( iJob < 0 ? 0 : vCigOff[ iJob + 1 ] ); c++ )
+                    // the cigar of job j is n_cigar words at cigar_off[ j ] (the jobs' cigars are not stored in job order)
+                    for( uint64_t c = iJob < 0 ? 0 : vCigOff[ iJob ]; c < ( iJob < 0 ? 0 : vCigOff[ iJob ] + (uint64_t)vEz[ iJob ].n_cigar ); c++ )
                     {
                         const uint32_t uiSymbol = vCigar[ c ] & 0xf, uiAmount = vCigar[ c ] >> 4;
                         switch( uiSymbol )
@@ -881,9 +882,10 @@ class BatchAligner
                            libMS::ContainerVector<std::shared_ptr<NucSeq>>>
 {
     ma_params xP;
+    ParameterSetManager xParams;
 
   public:
-    BatchAligner( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) )
+    BatchAligner( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) ), xParams( rParameters )
     {}
     virtual std::shared_ptr<libMS::ContainerVector<std::shared_ptr<AlignmentVector>>>
     execute( std::shared_ptr<FMIndex> pFM_index, std::shared_ptr<libMS::ContainerVector<std::shared_ptr<NucSeq>>> pQueries ) override
@@ -922,6 +924,51 @@ class BatchAligner
                                            ops[ 2 * ( alns[ i ].ops_off + k ) + 1 ] );
                 pV->push_back( pA );
             }
+            pRet->push_back( pV );
+        }
+        // "Detect Small Inversions" (export.cpp:118-121): all reads' inversion DP in one more GPU launch
+        if( xP.search_inversions )
+        {
+            auto pPack = std::make_shared<Pack>( );
+            pPack->pDev = pFM_index->pDev;
+            std::vector<std::shared_ptr<SmallInversions::TP_ALIGNMENTS>> vIn;
+            std::vector<std::shared_ptr<NucSeq>> vQ;
+            for( size_t r = 0; r < pQueries->size( ); r++ )
+            {
+                vIn.push_back( ( *pRet )[ r ] );
+                vQ.push_back( ( *pQueries )[ r ] );
+            }
+            auto vOut = SmallInversions( xParams ).executeBatch( vIn, vQ, pPack );
+            for( size_t r = 0; r < pQueries->size( ); r++ )
+            {
+                auto pV = std::make_shared<AlignmentVector>( );
+                for( auto& pA : *vOut[ r ] )
+                    pV->push_back( pA );
+                ( *pRet )[ r ] = pV;
+            }
+        }
+        return pRet;
+    }
+
+    // Paired mode (setUpCompGraphPaired, export.cpp:130-202) for a batch: vMates holds the mates of pair k at 2k and
+    // 2k + 1; both mates of all pairs go through ONE device batch, PairedReads then picks per pair on the host.
+    std::shared_ptr<libMS::ContainerVector<std::shared_ptr<AlignmentVector>>>
+    executePaired( std::shared_ptr<FMIndex> pFM_index, std::shared_ptr<libMS::ContainerVector<std::shared_ptr<NucSeq>>> vMates )
+    {
+        if( vMates->size( ) % 2 )
+            throw std::runtime_error( "BatchAligner::executePaired: odd number of reads" );
+        auto pPerRead = execute( pFM_index, vMates );
+        auto pPack = std::make_shared<Pack>( );
+        pPack->pDev = pFM_index->pDev;
+        PairedReads xPairedReads( xParams );
+        auto pRet = std::make_shared<libMS::ContainerVector<std::shared_ptr<AlignmentVector>>>( );
+        for( size_t k = 0; 2 * k + 1 < vMates->size( ); k++ )
+        {
+            auto pPicked = xPairedReads.execute( ( *vMates )[ 2 * k ], ( *vMates )[ 2 * k + 1 ], ( *pPerRead )[ 2 * k ],
+                                                 ( *pPerRead )[ 2 * k + 1 ], pPack );
+            auto pV = std::make_shared<AlignmentVector>( );
+            for( auto& pA : *pPicked )
+                pV->push_back( pA );
             pRet->push_back( pV );
         }
         return pRet;

@@ -2,10 +2,13 @@
 // (libs/ma/src/util/export.cpp:72-202) with the MI355X modules incl. SmallInversions (DP through ma_ksw_batch),
 // PairedReads and the (Paired)FileWriter, runs the reads of a case through it and writes the f4 dump + SAM text that
 // `ref_dump f4` writes for the reference.  Reads 2k and 2k+1 of the case are the mates of pair k.
-// usage: f4_graph_test <case> <preset> <srand seed> <out.f4> <inversions 0|1> <paired 0|1> <zdrop inversion> <out.sam> <sam options>
+// usage: f4_graph_test <case> <preset> <srand seed> <out.f4> <inversions 0|1> <paired 0|1> <zdrop inversion> <out.sam> <sam options> [batch]
+// with "batch" the reads go through BatchAligner::execute / executePaired (one device batch for all reads, one GPU launch
+// for all inversion DP) instead of the per-read graph; the paired dump then holds the P / PAIR / p records only
 #include "../../ma_amd/host/ma_sam.h"
 #include "../../oracle/dump_format.h"
 #include <cstdio>
+#include <cstring>
 
 using namespace libMA;
 using namespace libMS;
@@ -139,6 +142,59 @@ int main( int argc, char** argv )
         return 1;
     }
     FILE* f = fopen( argv[ 4 ], "w" );
+    if( argc >= 11 && !strcmp( argv[ 10 ], "batch" ) )
+    {
+        auto pAll = std::make_shared<ContainerVector<std::shared_ptr<NucSeq>>>( );
+        for( size_t i = 0; i < c.reads.size( ); i++ )
+        {
+            auto p = std::make_shared<NucSeq>( );
+            p->xCodes = c.reads[ i ];
+            p->sName = "r" + std::to_string( i );
+            pAll->push_back( p );
+        }
+        if( bPaired && pAll->size( ) % 2 )
+            pAll->pop_back( );
+        BatchAligner xBatch( xParams );
+        auto pSamStream = std::make_shared<StringOutStream>( );
+        if( !bPaired )
+        {
+            auto pRes = xBatch.execute( pFmC, pAll );
+            FileWriter xWriter( xParams, std::static_pointer_cast<OutStream>( pSamStream ), pPackC );
+            for( size_t i = 0; i < pAll->size( ); i++ )
+            {
+                fprintf( f, "R %zu %llu\nFIN 0 %zu\n", i, (unsigned long long)( *pAll )[ i ]->length( ), ( *pRes )[ i ]->size( ) );
+                for( auto& a : *( *pRes )[ i ] )
+                    dumpLine( f, "f", *a, -1 );
+                xWriter.execute( ( *pAll )[ i ], ( *pRes )[ i ], pPackC );
+            }
+        }
+        else
+        {
+            auto pRes = xBatch.executePaired( pFmC, pAll );
+            PairedFileWriter xWriter( xParams, std::static_pointer_cast<OutStream>( pSamStream ), pPackC );
+            for( size_t k = 0; k < pRes->size( ); k++ )
+            {
+                auto pPair = ( *pRes )[ k ];
+                fprintf( f, "P %zu %llu %llu\nPAIR %zu\n", k, (unsigned long long)( *pAll )[ 2 * k ]->length( ),
+                         (unsigned long long)( *pAll )[ 2 * k + 1 ]->length( ), pPair->size( ) );
+                for( auto& a : *pPair )
+                {
+                    int iOther = -1;
+                    auto pO = a->xStats.pOther.lock( );
+                    for( size_t j = 0; pO != nullptr && j < pPair->size( ); j++ )
+                        if( ( *pPair )[ j ] == pO )
+                            iOther = (int)j;
+                    dumpLine( f, "p", *a, iOther );
+                }
+                xWriter.execute( ( *pAll )[ 2 * k ], ( *pAll )[ 2 * k + 1 ], pPair, pPackC );
+            }
+        }
+        fclose( f );
+        FILE* fs = fopen( argv[ 8 ], "w" );
+        fputs( pSamStream->sText.c_str( ), fs );
+        fclose( fs );
+        return 0;
+    }
     auto pPack = std::make_shared<Pledge<Pack>>( );
     pPack->set( pPackC );
     auto pFMDIndex = std::make_shared<Pledge<FMIndex>>( );

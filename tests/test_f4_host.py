@@ -89,3 +89,22 @@ def test_graph_with_small_inversions_and_paired_reads_matches_reference(tmp_path
                            str(opt)])
     same_text(str(tmp_path / "o.f4"), os.path.join(G, nm + ".f4.gz"), "f4 dump")
     same_text(str(tmp_path / "o.sam"), os.path.join(G, nm + ".sam.gz"), "SAM")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", F4_CONFIGS)
+def test_batch_aligner_with_small_inversions_and_paired_reads(tmp_path, gpu_device, cfg):
+    """The throughput API: BatchAligner::execute / executePaired put all reads through one device batch and all
+    inversion DP through one ma_ksw_batch launch; same lists and SAM text as the reference's per-read graph."""
+    preset, inv, paired, zd, opt = cfg
+    nm = "f4.%s.inv%d.pair%d.zd%d.opt%d" % cfg
+    exe = build("f4_graph_test")
+    case = gunzip_to(os.path.join(G, "f4.case.gz"), str(tmp_path / "f4.case"))
+    subprocess.check_call([exe, case, preset, "1", str(tmp_path / "o.f4"), str(inv), str(paired), str(zd), str(tmp_path / "o.sam"),
+                           str(opt), "batch"])
+    same_text(str(tmp_path / "o.sam"), os.path.join(G, nm + ".sam.gz"), "SAM")
+    want = gzip.open(os.path.join(G, nm + ".f4.gz"), "rt").read().split("\n")
+    if paired:  # the batch dump holds the pair records only
+        want = [l for l in want if not l.startswith(("f ", "FIN"))]
+    got = open(str(tmp_path / "o.f4")).read().split("\n")
+    assert got == want
