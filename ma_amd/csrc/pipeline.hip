@@ -1100,7 +1100,8 @@ int ma_seed_batch( ma_batch* b )
             // reads up to 240 bases are staged in LDS (256 lanes x q_lds bytes <= 64 KB)
             const u32 qb = (u32)( ( b->max_qlen + 7 ) / 8 * 8 + 4 );
             A.q_lds = qb * 256 <= 64 * 1024 ? qb : 0;
-            A.slow_batch = 4; // measured: 8.98 ms (1) -> 8.56 ms (4) -> 8.87 ms (8) per 1 M x 150 bp reads
+            // measured per 1 M x 150 bp reads: maxSpan 8.98 ms (1) / 8.56 (4) / 8.87 (8); SMEMs 114 ms (4) / 96 (8) / 96 (16) / 101 (32)
+            A.slow_batch = A.P.technique == 0 ? 4 : 8;
             if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook
                 A.slow_batch = (u32)std::max( 1, atoi( e ) );
             hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
