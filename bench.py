@@ -226,6 +226,36 @@ def main():
                # the reference computes every diagonal of an extension; the GPU path stops once ez.max is final
                "dp_band_cells_per_read": round(float(res["counters"][4]) / S, 1)}
         roofline["dp_band_cells_per_read_executed"] = round(ctr[4] / max(n_reads, 1), 1)
+        # ---- the REAL reference (compiled from its own sources into oracle/_ref by oracle/Makefile.ref) on the same
+        # sample: the GPU-built index is written in the reference's file formats, the reference's own loaders read it,
+        # its modules (BinarySeeding .. MappingQuality) run on all host threads (oracle/ref_dump.cpp timeidx)
+        ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+        if os.path.exists(ref_dump) and not os.environ.get("MA_BENCH_NO_REFERENCE"):
+            import shutil
+            import subprocess
+            import tempfile
+            from ma_testlib import write_case
+            td = tempfile.mkdtemp(prefix="ma_ref_")
+            try:
+                t2 = time.perf_counter()
+                idx.store(os.path.join(td, "idx"))
+                write_case(os.path.join(td, "reads.case"), [], reads)
+                out = subprocess.run([ref_dump, "timeidx", os.path.join(td, "idx"), os.path.join(td, "reads.case"), args.preset,
+                                      str(ncores)], capture_output=True, text=True, timeout=1800)
+                m = __import__("re").search(r"(\d+) reads \((\d+) aligned\) in ([0-9.]+) s on (\d+) threads", out.stdout)
+                if out.returncode == 0 and m:
+                    tr = float(m.group(3))
+                    cpu = dict(cpu, value=round(int(m.group(2)) / tr, 1), kind="reference",
+                               sample="first %d reads of the same workload, the reference's own modules on %d threads, %.1f s "
+                                      "(index written by the GPU builder and loaded by the reference's loaders: %.0f s, not "
+                                      "counted)" % (S, ncores, tr, time.perf_counter() - t2 - tr),
+                               port={"value": cpu["value"], "sample": cpu["sample"]})
+                else:
+                    cpu["reference_error"] = (out.stderr or out.stdout)[-300:]
+            except Exception as e:  # the oracle's number stays
+                cpu["reference_error"] = repr(e)[:300]
+            finally:
+                shutil.rmtree(td, ignore_errors=True)
         # ---- parity at full scale: the GPU results of the sampled reads of step 0 against the oracle's, bit for bit
         # (NeedlemanWunsch output incl. every alignment op, and the MappingQuality records incl. mapq doubles)
         Pn = min(S, B)

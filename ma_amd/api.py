@@ -153,6 +153,37 @@ class Index:
         return dict(bwt=bwt, sa=sa, L2=L2, primary=primary.value, ref_len=rl, pac=pac, contig_starts=cs,
                     contig_lens=cl)
 
+    def store(self, prefix, names=None):
+        """Write the index as the reference's <prefix>.bwt/.sa/.pac/.ann/.amb files (FMIndex::vStoreFMIndex
+        fMIndex.h:515-549, Pack::vStoreCollection pack.h:230-269,725-770; same layout as storeIndex of the C++ host
+        layer): maCMD / FMIndex(prefix) load an index that was built on the GPU."""
+        d = self.download()
+        n = int(d["ref_len"])
+        F = n // 2
+        with open(prefix + ".bwt", "wb") as f:
+            f.write(np.int64(d["primary"]).tobytes())
+            f.write(np.ascontiguousarray(d["L2"][1:5], dtype=np.uint64).tobytes())
+            d["bwt"].tofile(f)
+        with open(prefix + ".sa", "wb") as f:
+            f.write(np.int64(d["primary"]).tobytes())
+            f.write(np.ascontiguousarray(d["L2"][1:5], dtype=np.uint64).tobytes())
+            f.write(np.int32(32).tobytes())
+            f.write(np.uint64(n).tobytes())
+            d["sa"][1:].tofile(f)
+        with open(prefix + ".pac", "wb") as f:
+            d["pac"][:(F + 3) // 4].tofile(f)
+            if F % 4 == 0:
+                f.write(b"\0")
+            f.write(bytes([F % 4]))
+        nc = len(d["contig_starts"])
+        with open(prefix + ".ann", "w") as f:
+            f.write("%d %d 0\n" % (F, nc))
+            for i in range(nc):
+                f.write("0 %s none\n%d %d 0\n" % (names[i] if names else "chr%d" % (i + 1), int(d["contig_starts"][i]),
+                                                  int(d["contig_lens"][i])))
+        with open(prefix + ".amb", "w") as f:
+            f.write("%d %d 0\n" % (F, nc))
+
     def extract(self, begin, end):
         """Pack::vExtract for ranges [begin[i], end[i]) of the doubled text: list of uint8 code arrays."""
         b = np.ascontiguousarray(begin, dtype=np.uint64)

@@ -19,6 +19,7 @@
 #include <limits>
 #include <tuple>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <sstream>
@@ -239,6 +240,72 @@ inline void buildIndex( const std::vector<std::shared_ptr<NucSeq>>& vContigs, st
     pPack->pDev = pDev;
     pFM = std::make_shared<FMIndex>( );
     pFM->pDev = pDev;
+}
+
+// Writes the device-resident index as the reference's own files <prefix>.bwt/.sa/.pac/.ann/.amb, i.e. what
+// FMIndex::vStoreFMIndex (fMIndex.h:515-549) and Pack::vStoreCollection (pack.h:230-269, 725-770) write for the same
+// genome: the reference (maCMD -x, FMIndex(prefix), Pack::vLoadCollection) loads an index built on the GPU.  The .bwt,
+// .sa and .pac bytes equal the reference's; .ann carries the reference's time-based seed, here 0.
+inline void storeIndex( const std::string& sPrefix, const std::shared_ptr<Pack>& pPack, const std::shared_ptr<FMIndex>& pFM )
+{
+    uint64_t nWords = 0, nSa = 0, uiN = 0;
+    int32_t nContigs = 0;
+    maCheck( ma_index_sizes( pFM->pDev->p, &nWords, &nSa, &uiN, &nContigs ) );
+    const uint64_t uiF = uiN / 2;
+    std::vector<uint32_t> vBwt( nWords );
+    std::vector<int64_t> vSa( nSa );
+    std::vector<uint8_t> vPac( ( uiF + 3 ) / 4 );
+    std::vector<uint64_t> vStarts( nContigs ), vLens( nContigs );
+    uint64_t L2[ 5 ];
+    int64_t primary = 0;
+    maCheck( ma_index_download( pFM->pDev->p, vBwt.data( ), vSa.data( ), L2, &primary, vPac.data( ), vStarts.data( ), vLens.data( ) ) );
+    auto open = []( const std::string& p ) {
+        FILE* f = fopen( p.c_str( ), "wb" );
+        if( !f )
+            throw std::runtime_error( "File opening error: " + p );
+        return f;
+    };
+    auto put = []( FILE* f, const void* p, size_t n ) {
+        if( n && fwrite( p, 1, n, f ) != n )
+            throw std::runtime_error( "Writing the index failed" );
+    };
+    {
+        FILE* f = open( sPrefix + ".bwt" ); // primary, L2[1..4], words
+        put( f, &primary, 8 );
+        put( f, &L2[ 1 ], 32 );
+        put( f, vBwt.data( ), nWords * 4 );
+        fclose( f );
+    }
+    {
+        FILE* f = open( sPrefix + ".sa" ); // primary, L2[1..4], sampling interval, sequence length, sa[1..]
+        const int32_t iInterval = 32;
+        put( f, &primary, 8 );
+        put( f, &L2[ 1 ], 32 );
+        put( f, &iInterval, 4 );
+        put( f, &uiN, 8 );
+        put( f, vSa.data( ) + 1, ( nSa - 1 ) * 8 );
+        fclose( f );
+    }
+    {
+        FILE* f = open( sPrefix + ".pac" ); // packed bases, a zero byte if the length is a multiple of 4, length % 4
+        put( f, vPac.data( ), vPac.size( ) );
+        const uint8_t zero = 0, check = (uint8_t)( uiF % 4 );
+        if( uiF % 4 == 0 )
+            put( f, &zero, 1 );
+        put( f, &check, 1 );
+        fclose( f );
+    }
+    {
+        std::ofstream f( sPrefix + ".ann" );
+        f << uiF << " " << nContigs << " " << 0 << "\n";
+        for( int32_t i = 0; i < nContigs; i++ )
+            f << 0 << " " << ( (size_t)i < pPack->vNames.size( ) ? pPack->vNames[ i ] : "chr" + std::to_string( i + 1 ) ) << " none\n"
+              << vStarts[ i ] << " " << vLens[ i ] << " " << 0 << "\n";
+    }
+    {
+        std::ofstream f( sPrefix + ".amb" );
+        f << uiF << " " << nContigs << " " << 0 << "\n";
+    }
 }
 
 // Stage outputs keep the device batch alive so the next module continues where this one stopped.

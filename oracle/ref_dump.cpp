@@ -9,6 +9,9 @@
 //   ref_dump pipe  <case> <preset> <srand_seed> <out>   -> per-read stage dump
 //   ref_dump ext   <case> <out>                        -> extend_backward traces
 //   ref_dump ksw   <kswcase> <out> [dirty]             -> kswcpp_dispatch results
+//   ref_dump time  <case> <preset> <threads>           -> reads/s of the reference's modules (seeding .. mapping quality)
+//   ref_dump pipeidx <prefix> <case> <preset> <seed> <out> / timeidx <prefix> <case> <preset> <threads>
+//                                                      -> the same with the index LOADED from <prefix>.* files
 //   ref_dump readpair <in1> <in2> <out> <revcomp mate 0|1> -> mate pairs of the PairedFileReader
 //   ref_dump f4    <case> <preset> <seed> <out> <inversions 0|1> <paired 0|1> <zdrop_inversion> [<out.sam> [<sam options>]]
 //                                                      -> SmallInversions / PairedReads lists (+ SAM of the (Paired)FileWriter)
@@ -48,9 +51,21 @@ struct RefIndex
     std::shared_ptr<FMIndex> pFM;
 };
 
+static const char* g_sIndexPrefix = nullptr; // pipeidx / timeidx: load <prefix>.bwt/.sa/.pac/.ann/.amb instead of building
+
 static RefIndex buildIndex( const CaseFile& c )
 {
     RefIndex r;
+    if( g_sIndexPrefix )
+    {
+        // the reference's own loaders (pack.h:799-812, fMIndex.h:886-900): proves that an index written by the MI355X
+        // host layer (storeIndex) is one the reference accepts
+        r.pPack = std::make_shared<Pack>( );
+        r.pPack->vLoadCollection( g_sIndexPrefix );
+        r.pFM = std::make_shared<FMIndex>( );
+        r.pFM->vLoadFMIndex( g_sIndexPrefix );
+        return r;
+    }
     r.pPack = std::make_shared<Pack>( );
     for( size_t i = 0; i < c.contigs.size( ); i++ )
         r.pPack->vAppendSequence( c.names[ i ], "", *mkSeq( c.contigs[ i ] ) );
@@ -372,6 +387,52 @@ static int cmdReadPair( const char* sIn1, const char* sIn2, const char* sOut, bo
     return 0;
 }
 
+// wall time of the reference's own modules (seeding .. mapping quality) over the reads of a case, T threads each with
+// its own pass over a slice of the reads; prints reads/s (sanity check of the oracle's speed)
+#include <chrono>
+#include <thread>
+static int cmdTime( const char* sCase, const char* sPreset, int iThreads )
+{
+    CaseFile c = readCase( sCase );
+    RefIndex idx = buildIndex( c );
+    ParameterSetManager xParams;
+    xParams.setSelected( sPreset );
+    BinarySeeding xSeeding( xParams );
+    StripOfConsideration xSoc( xParams );
+    Harmonization xHarm( xParams );
+    NeedlemanWunsch xDp( xParams );
+    MappingQuality xMq( xParams );
+    std::vector<std::shared_ptr<NucSeq>> vReads;
+    for( auto& r : c.reads )
+        vReads.push_back( mkSeq( r ) );
+    std::vector<size_t> vAligned( iThreads, 0 );
+    const auto t0 = std::chrono::steady_clock::now( );
+    std::vector<std::thread> vT;
+    for( int t = 0; t < iThreads; t++ )
+        vT.emplace_back( [ &, t ]( ) {
+            for( size_t i = t; i < vReads.size( ); i += iThreads )
+            {
+                auto pQ = vReads[ i ];
+                auto pSegs = xSeeding.execute( idx.pFM, pQ );
+                auto pSocs = xSoc.execute( pSegs, pQ, idx.pPack, idx.pFM );
+                auto pHarm = xHarm.execute( pSocs, pQ, idx.pFM );
+                auto pAlns = xDp.execute( pHarm, pQ, idx.pPack );
+                auto pMq = xMq.execute( pQ, pAlns );
+                if( !pMq->empty( ) )
+                    vAligned[ t ]++;
+            }
+        } );
+    for( auto& t : vT )
+        t.join( );
+    const double dt = std::chrono::duration<double>( std::chrono::steady_clock::now( ) - t0 ).count( );
+    size_t n = 0;
+    for( size_t a : vAligned )
+        n += a;
+    printf( "reference: %zu reads (%zu aligned) in %.3f s on %d threads = %.1f reads/s\n", vReads.size( ), n, dt, iThreads,
+            vReads.size( ) / dt );
+    return 0;
+}
+
 static int cmdExt( const char* sCase, const char* sOut )
 {
     CaseFile c = readCase( sCase );
@@ -448,6 +509,18 @@ int main( int argc, char** argv )
                       atoi( argv[ 8 ] ), argc >= 10 ? argv[ 9 ] : nullptr, argc >= 11 ? atoi( argv[ 10 ] ) : 0 );
     if( argc >= 6 && !strcmp( argv[ 1 ], "readpair" ) )
         return cmdReadPair( argv[ 2 ], argv[ 3 ], argv[ 4 ], atoi( argv[ 5 ] ) != 0 );
+    if( argc >= 7 && !strcmp( argv[ 1 ], "pipeidx" ) ) // pipeidx <prefix> <case> <preset> <seed> <out>
+    {
+        g_sIndexPrefix = argv[ 2 ];
+        return cmdPipe( argv[ 3 ], argv[ 4 ], (unsigned)atoi( argv[ 5 ] ), argv[ 6 ] );
+    }
+    if( argc >= 6 && !strcmp( argv[ 1 ], "timeidx" ) ) // timeidx <prefix> <case (reads only)> <preset> <threads>
+    {
+        g_sIndexPrefix = argv[ 2 ];
+        return cmdTime( argv[ 3 ], argv[ 4 ], atoi( argv[ 5 ] ) );
+    }
+    if( argc >= 5 && !strcmp( argv[ 1 ], "time" ) )
+        return cmdTime( argv[ 2 ], argv[ 3 ], atoi( argv[ 4 ] ) );
     if( argc >= 4 && !strcmp( argv[ 1 ], "read" ) )
         return cmdRead( argv[ 2 ], argv[ 3 ] );
     if( argc >= 4 && !strcmp( argv[ 1 ], "ext" ) )

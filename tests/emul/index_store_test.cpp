@@ -1,0 +1,49 @@
+// SURVEY 8(f) f1, file side: builds the index of a case on the GPU, writes it with storeIndex as the reference's
+// .bwt/.sa/.pac/.ann/.amb files, loads those files again with loadIndex and checks the round trip.
+// usage: index_store_test <case> <prefix>
+#include "../../ma_amd/host/ma_modules.h"
+#include "../../oracle/dump_format.h"
+#include <cstdio>
+
+using namespace libMA;
+
+int main( int argc, char** argv )
+{
+    if( argc < 3 )
+        return 2;
+    CaseFile c = readCase( argv[ 1 ] );
+    std::vector<std::shared_ptr<NucSeq>> vContigs;
+    for( size_t i = 0; i < c.contigs.size( ); i++ )
+    {
+        auto p = std::make_shared<NucSeq>( );
+        p->xCodes = c.contigs[ i ];
+        p->sName = c.names[ i ];
+        vContigs.push_back( p );
+    }
+    try
+    {
+        std::shared_ptr<Pack> pPack, pPack2;
+        std::shared_ptr<FMIndex> pFM, pFM2;
+        buildIndex( vContigs, pPack, pFM );
+        storeIndex( argv[ 2 ], pPack, pFM );
+        loadIndex( argv[ 2 ], pPack2, pFM2 );
+        uint64_t a[ 3 ], b[ 3 ];
+        int32_t na, nb;
+        maCheck( ma_index_sizes( pFM->pDev->p, &a[ 0 ], &a[ 1 ], &a[ 2 ], &na ) );
+        maCheck( ma_index_sizes( pFM2->pDev->p, &b[ 0 ], &b[ 1 ], &b[ 2 ], &nb ) );
+        if( a[ 0 ] != b[ 0 ] || a[ 1 ] != b[ 1 ] || a[ 2 ] != b[ 2 ] || na != nb || pPack->vNames != pPack2->vNames ||
+            pPack->vStarts != pPack2->vStarts || pPack->vLengths != pPack2->vLengths )
+        {
+            fprintf( stderr, "round trip differs\n" );
+            return 1;
+        }
+        printf( "stored and reloaded: %llu bwt words, %llu sa samples, %d contigs\n", (unsigned long long)a[ 0 ],
+                (unsigned long long)a[ 1 ], na );
+    }
+    catch( const std::runtime_error& e )
+    {
+        fprintf( stderr, "error: %s\n", e.what( ) );
+        return 1;
+    }
+    return 0;
+}

@@ -57,3 +57,31 @@ def test_graph_of_dropin_modules_matches_reference(tmp_path, gpu_device, preset,
     # the FileWriter node of the same graph: SAM text identical to the reference's
     sam_want = gzip.open(os.path.join(G, "small_ref.%s.opt0.sam.gz" % preset), "rt").read()
     assert open(out + ".sam").read() == sam_want
+
+
+@pytest.mark.gpu
+def test_gpu_built_index_is_stored_in_the_reference_file_formats(tmp_path, gpu_device):
+    """f1, file side: storeIndex writes .bwt/.sa/.pac byte-identical to the reference's files for the same genome
+    (tests/golden/small_ref.*), .ann/.amb in its text format, and the reference's own loaders accept them
+    (oracle/_ref/ref_dump pipeidx, when that build is present: same pipeline dump as with its own index)."""
+    exe = os.path.join(ROOT, "tests", "emul", "index_store_test")
+    src = exe + ".cpp"
+    deps = [src] + [os.path.join(ROOT, "ma_amd", "host", h) for h in ("ma_modules.h", "ms_graph.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", exe, "-L" + os.path.join(ROOT, "ma_amd"),
+                               "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"), "-lpthread"])
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    prefix = str(tmp_path / "idx")
+    subprocess.check_call([exe, case, prefix])
+    for ext in ("bwt", "sa", "pac"):
+        want = gzip.open(os.path.join(G, "small_ref." + ext + ".gz"), "rb").read()
+        assert open(prefix + "." + ext, "rb").read() == want, ext
+    assert open(prefix + ".ann").read() == ("61000 3 0\n0 chr1 none\n0 30000 0\n0 chr2 none\n30000 22000 0\n"
+                                            "0 chr3 none\n52000 9000 0\n")
+    assert open(prefix + ".amb").read() == "61000 3 0\n"
+    ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if os.path.exists(ref_dump):
+        out = str(tmp_path / "ref.pipe")
+        subprocess.check_call([ref_dump, "pipeidx", prefix, case, "default", "1", out])
+        assert open(out).read() == gzip.open(os.path.join(G, "small_ref.default.pipe.gz"), "rt").read()
