@@ -101,9 +101,11 @@ MA_HD int ksw_ext_slots( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zd
         return 0;
     if( qlen > 256 )
         return 0; // the query is held four bases per lane
-    if( qlen + 15 <= 128 || tlen <= 128 )
+    // one slot of 128 cells: the live window (<= qlen cells) plus the cells that left the band and are not yet handed
+    // on; those are handed on 16 at a time for qlen <= 113 and lane by lane (2 cells) for qlen up to 126
+    if( qlen + 2 <= 128 || tlen <= 128 )
         return 1;
-    if( qlen + 15 <= 256 || tlen <= 256 )
+    if( qlen + 2 <= 256 || tlen <= 256 )
         return 2;
     return 0;
 }
@@ -285,7 +287,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     auto uInit2 = [ & ]( i32 t ) -> u32 { // first-row u of cells t, t+1
         return ( ( (u32)initOf( t ) & 0xffu ) << 8 ) | ( ( (u32)initOf( t + 1 ) & 0xffu ) << 24 );
     };
-    u32 U[ R ], V[ R ], X[ R ], Y[ R ], X2[ R ], Y2[ R ], T[ R ], H[ R ], Qf[ R ], TTpk[ R ], PB[ R ];
+    u32 U[ R ], V[ R ], X[ R ], Y[ R ], X2[ R ], Y2[ R ], T[ R ], Tn[ R ], H[ R ], Qf[ R ], TTpk[ R ], PB[ R ];
     i32 TT[ R ];
 #pragma unroll
     for( int s = 0; s < R; s++ )
@@ -300,6 +302,8 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         X2[ s ] = K_X20;
         Y2[ s ] = K_Y20;
         T[ s ] = tgt2( TT[ s ] );
+        Tn[ s ] = tgt2( TT[ s ] + RING ); // the target of the cells this lane takes over next: requested a ring ahead,
+                                         // so that handing cells on never waits for memory
         H[ s ] = 0;
         Qf[ s ] = 0x00040004u;
     }
@@ -310,6 +314,8 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         prof[ 13 ] += tp0 - tpB; // target bytes + state initialisation
 #endif
     i32 recycled = 0; // cells below this index have been handed to cells RING further up
+    // granularity of that hand-over: 16 cells when the ring has room for 15 dead cells beside the live window, else one lane
+    const i32 gran = ( qlen + 15 <= RING || tlen <= RING ) ? 16 : 2;
     // H(-1, r-1) of the first column, H(r-1, -1) of the first row.  (sic) When the two gap models were swapped, kswcpp's
     // H[0] = v[0] - (q+e) uses the UNswapped sum, which offsets every score of the matrix by (q+e)_swapped - (q+e)_given.
     i32 hLeft = ( q + e ) - qe0;
@@ -330,9 +336,9 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             return false; // the band starts to cut the rectangle: not this kernel's regime
         const i32 st0 = max( 0, r - qlen + 1 ), en0 = min( r, tlen - 1 );
         // ---- recycle the 16-cell block that left the band
-        if( ( st0 & ~15 ) > recycled )
+        if( ( st0 & ~( gran - 1 ) ) > recycled )
         {
-            const i32 lim = recycled + 16;
+            const i32 lim = recycled + gran;
 #pragma unroll
             for( int s = 0; s < R; s++ )
                 if( TT[ s ] < lim )
@@ -343,7 +349,8 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                     U[ s ] = uInit2( TT[ s ] );
                     Y[ s ] = K_Y0;
                     Y2[ s ] = K_Y20;
-                    T[ s ] = tgt2( TT[ s ] );
+                    T[ s ] = Tn[ s ];
+                    Tn[ s ] = tgt2( TT[ s ] + RING );
                 }
             recycled = lim;
         }

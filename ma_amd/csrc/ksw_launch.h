@@ -177,7 +177,7 @@ struct KswJobs
 #endif
 
 template <typename FETCH, int R>
-__global__ void __launch_bounds__( 64 ) k_ksw_ext( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( R == 1 ? 7 : 4 ) ) ) k_ksw_ext( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
                                                   uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O,
                                                   u32* redo, unsigned int* nRedo )
 {

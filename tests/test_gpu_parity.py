@@ -203,14 +203,14 @@ def test_ksw_random_vs_oracle(gpu_device):
         assert np.array_equal(cigs[i], ocig), "case %d cigar" % i
 
 
-def ext_shaped_cases(n, seed):
+def ext_shaped_cases(n, seed, ql_lo=1, ql_hi=250):
     """Jobs shaped like NeedlemanWunsch's extensions: short query, long padded target, w = 512, zdrop = 200; plus
     the small global gap fills (w >= qlen + tlen) that the extension kernel also takes."""
     rng = np.random.default_rng(seed)
     cases = []
     for _ in range(n):
         kind = rng.random()
-        ql = int(rng.integers(1, 250)) if kind < 0.85 else int(rng.integers(1, 7))
+        ql = int(rng.integers(ql_lo, ql_hi)) if kind < 0.85 else int(rng.integers(1, 7))
         if kind < 0.85:
             tl = int(rng.integers(max(1, ql - 20), ql + 1100))
             t = rng.integers(0, 4, size=tl, dtype=np.uint8)
@@ -242,7 +242,9 @@ def test_ksw_pipeline_semantics_vs_oracle(gpu_device):
     """ma_ksw_ext_batch (packed extension kernel, early stop) against kswcpp as restated by the oracle, on what the
     pipeline reads: max, max_q, max_t and the cigar."""
     import ma_amd
-    cases = ext_shaped_cases(3000, 99) + rand_ksw_cases(600, 777, max_len=200)
+    # + the query lengths around the capacity limits of the one- and two-slot rings (113 / 126 / 241 / 254 cells)
+    cases = (ext_shaped_cases(3000, 99) + rand_ksw_cases(600, 777, max_len=200) + ext_shaped_cases(900, 98, 108, 132)
+             + ext_shaped_cases(500, 97, 236, 260))
     P = ma_amd.Params.preset("default")
     ez, cigs = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
     op = or_params()
