@@ -240,7 +240,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( R 
 }
 
 template <typename FETCH, int S>
-__global__ void __launch_bounds__( 64 ) k_ksw_pk( FETCH F, KswScoring SC, KswJobs JB, unsigned int* nextSlot,
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( S >= 5 ? 4 : 3 ) ) ) k_ksw_pk( FETCH F, KswScoring SC, KswJobs JB, unsigned int* nextSlot,
                                                   uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
