@@ -8,6 +8,9 @@
 #pragma once
 #include "ma_modules.h"
 
+#ifdef MA_WITH_ZLIB
+#include <zlib.h>
+#endif
 #include <algorithm>
 #include <cctype>
 #include <iostream>
@@ -619,6 +622,79 @@ class StdFileStream : public FileStream
         detail::safeGetLine( xStream, t );
     }
 };
+#ifdef MA_WITH_ZLIB
+// GzFileStream (fileReader.h:292-403, WITH_ZLIB): a gzip-compressed FASTA / FASTQ file read one byte ahead; a '\r' is
+// dropped and a '\n' ends the line; (sic) pop() does not track the end of the file, safeGetLine does
+class GzFileStream : public FileStream
+{
+    gzFile pFile = nullptr;
+    int lastReadReturn = 0; // 1 == last read was ok; 0 == eof; -1 == error
+    unsigned char cBuff = 0;
+    const std::string sFileName;
+    void open( )
+    {
+        if( pFile == nullptr )
+        {
+            pFile = gzopen( sFileName.c_str( ), "rb" );
+            lastReadReturn = pFile != nullptr ? gzread( pFile, &cBuff, 1 ) : -1;
+        }
+    }
+
+  public:
+    GzFileStream( const std::string& sFilename ) : sFileName( sFilename )
+    {
+        std::ifstream xFileEnd( sFilename, std::ifstream::ate | std::ifstream::binary );
+        if( !xFileEnd.is_open( ) )
+            throw std::runtime_error( "Unable to open file " + sFilename );
+    }
+    ~GzFileStream( )
+    {
+        if( pFile != nullptr )
+            gzclose( pFile );
+    }
+    bool eof( ) const override
+    {
+        return lastReadReturn != 1;
+    }
+    char peek( ) override
+    {
+        open( );
+        return (char)cBuff;
+    }
+    char pop( ) override
+    {
+        open( );
+        const char cRet = (char)cBuff;
+        gzread( pFile, &cBuff, 1 );
+        return cRet;
+    }
+    std::string fileName( ) override // the stem, like fs::path::stem (fileReader.h:373-376)
+    {
+        const size_t uiSlash = sFileName.find_last_of( '/' );
+        std::string sName = uiSlash == std::string::npos ? sFileName : sFileName.substr( uiSlash + 1 );
+        const size_t uiDot = sName.find_last_of( '.' );
+        return uiDot == std::string::npos || uiDot == 0 ? sName : sName.substr( 0, uiDot );
+    }
+    void safeGetLine( std::string& t ) override
+    {
+        open( );
+        t.clear( );
+        while( true )
+        {
+            if( lastReadReturn != 1 )
+                break;
+            if( cBuff == '\r' )
+                lastReadReturn = gzread( pFile, &cBuff, 1 );
+            if( lastReadReturn != 1 || cBuff == '\n' )
+                break;
+            t += (char)cBuff;
+            lastReadReturn = gzread( pFile, &cBuff, 1 );
+        }
+        if( lastReadReturn == 1 )
+            lastReadReturn = gzread( pFile, &cBuff, 1 );
+    }
+};
+#endif
 class StringStream : public FileStream
 {
     std::stringstream xStream;
@@ -648,6 +724,15 @@ class StringStream : public FileStream
     }
 };
 
+// FileStreamFromPath (fileReader.h:407-423): .gz files through zlib when the host layer is built with MA_WITH_ZLIB
+inline std::shared_ptr<FileStream> fileStreamFromPath( const std::string& sFileName )
+{
+#ifdef MA_WITH_ZLIB
+    if( sFileName.size( ) >= 3 && sFileName.compare( sFileName.size( ) - 3, 3, ".gz" ) == 0 )
+        return std::make_shared<GzFileStream>( sFileName );
+#endif
+    return std::make_shared<StdFileStream>( sFileName );
+}
 class FileReader : public libMS::Module<NucSeq, true, FileStream>
 {
     static bool validNuc( char c ) // fileReader.cpp:12-18

@@ -327,7 +327,12 @@ static int cmdRead( const char* sIn, const char* sOut )
 {
     ParameterSetManager xParams;
     FileReader xReader( xParams );
-    auto pStream = std::make_shared<StdFileStream>( fs::path( sIn ) );
+    // .gz files go through the reference's GzFileStream like in FileStreamFromPath (fileReader.h:407-423)
+    std::shared_ptr<FileStream> pStream;
+    if( fs::path( sIn ).extension( ).string( ) == ".gz" )
+        pStream = std::make_shared<GzFileStream>( fs::path( sIn ) );
+    else
+        pStream = std::make_shared<StdFileStream>( fs::path( sIn ) );
     FILE* f = fopen( sOut, "w" );
     while( true )
     {

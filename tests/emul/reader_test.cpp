@@ -41,7 +41,7 @@ int main( int argc, char** argv )
     }
     try
     {
-        auto pStream = std::make_shared<StdFileStream>( argv[ 1 ] );
+        auto pStream = fileStreamFromPath( argv[ 1 ] );
         while( true )
         {
             auto pQ = xReader.execute( pStream );

@@ -60,6 +60,11 @@ def reader_goldens():
             f.write("@fq%d sample=%d\n%s\n+\n%s\n" % (i, i, seq, qual))
     run_ref("sam", "small.case", "default", 1, os.path.join("reader", "small24.fq.sam"), 0, os.path.join("reader", "small24.fq"))
     gz(os.path.join("reader", "small24.fq.sam"))
+    # gzip-compressed inputs (GzFileStream of the reference's WITH_ZLIB build, oracle/Makefile.ref)
+    for name in ("reader_multi.fa", "reader_multi.fq", "reader_plusname.fq"):
+        with open(os.path.join("reader", name), "rb") as f, gzip.open(os.path.join("reader", name + ".gz"), "wb", compresslevel=9) as g:
+            shutil.copyfileobj(f, g)
+        run_ref("read", os.path.join("reader", name + ".gz"), os.path.join("reader", name + ".gz.ref"))
     # mate files for the PairedFileReader: second file one record shorter (EOF of either ends the pairs), Ns in a mate
     with open(os.path.join("reader", "mates_1.fq"), "w") as f:
         f.write("@p0/1\nACGTTGCA\n+\nIIIIHHHH\n@p1/1\nGGGTTTAACC\n+\n0123456789\n@p2/1\nAAAA\n+\n!!!!\n")

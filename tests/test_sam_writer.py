@@ -44,10 +44,11 @@ def build_reader_exe():
     src = os.path.join(ROOT, "tests", "emul", "reader_test.cpp")
     deps = [src] + [os.path.join(ROOT, "ma_amd", "host", h) for h in ("ma_sam.h", "ma_modules.h", "ms_graph.h")]
     if not os.path.exists(READER_EXE) or any(os.path.getmtime(d) > os.path.getmtime(READER_EXE) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+        zl = ["-DMA_WITH_ZLIB"] if os.path.exists("/usr/include/zlib.h") else []
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall"] + zl + ["-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", READER_EXE,
                                "-L" + os.path.join(ROOT, "ma_amd"), "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"),
-                               "-lpthread"])
+                               "-lpthread"] + (["-lz"] if zl else []))
     return READER_EXE
 
 
@@ -61,6 +62,16 @@ def test_fasta_fastq_reader_matches_reference(tmp_path, name):
     # the error text quotes the path as given: use the one the golden was made with
     subprocess.check_call([exe, os.path.join("reader", name), out], cwd=G)
     assert open(out).read() == open(os.path.join(G, "reader", name + ".ref")).read()
+
+
+@pytest.mark.skipif(not os.path.exists("/usr/include/zlib.h"), reason="zlib headers not installed")
+@pytest.mark.parametrize("name", ["reader_multi.fa", "reader_multi.fq", "reader_plusname.fq"])
+def test_gzip_input_matches_reference(tmp_path, name):
+    """GzFileStream (WITH_ZLIB build of the reference): the compressed file yields the same reads."""
+    exe = build_reader_exe()
+    out = str(tmp_path / "o.txt")
+    subprocess.check_call([exe, os.path.join("reader", name + ".gz"), out], cwd=G)
+    assert open(out).read() == open(os.path.join(G, "reader", name + ".gz.ref")).read()
 
 
 def test_sam_with_fastq_names_and_qualities(tmp_path):
