@@ -278,11 +278,13 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t+1
         // an N of the target is coded 12, one of the query 4..5: base ^ base is 0 for a match, 1..3 for a mismatch and
         // >= 4 as soon as either is N (the score look-up below)
-        u32 a = t < tlen ? (u32)tbase( t ) & 0xffu : 0u;
-        u32 b = t + 1 < tlen ? (u32)tbase( t + 1 ) & 0xffu : 0u;
-        a = a < 4 ? a : 12u;
-        b = b < 4 ? b : 12u;
-        return a | b << 16;
+        if( t >= tlen )
+            return 0u;
+        u32 ab = tbase.pair( t ) & ( t + 1 < tlen ? 0x00ff00ffu : 0x000000ffu );
+        if( TF::CLEAN )
+            return ab;
+        const u32 n = pk_lshr( ab, 2 ); // >= 1 where the code is >= 4
+        return pk_bfi( pk_sub( 0u, pk_minu( n, 0x00010001u ) ), 0x000c000cu, ab );
     };
     auto uInit2 = [ & ]( i32 t ) -> u32 { // first-row u of cells t, t+1
         return ( ( (u32)initOf( t ) & 0xffu ) << 8 ) | ( ( (u32)initOf( t + 1 ) & 0xffu ) << 24 );
@@ -316,6 +318,9 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     i32 recycled = 0; // cells below this index have been handed to cells RING further up
     // granularity of that hand-over: 16 cells when the ring has room for 15 dead cells beside the live window, else one lane
     const i32 gran = ( qlen + 15 <= RING || tlen <= RING ) ? 16 : 2;
+    // cells handed on are >= RING: beyond long_thres their first-row difference is the constant -e2 (initOf)
+    const bool uFar = RING > long_thres + 1;
+    const u32 K_UFAR = pk_val( -e2, 0 );
     // H(-1, r-1) of the first column, H(r-1, -1) of the first row.  (sic) When the two gap models were swapped, kswcpp's
     // H[0] = v[0] - (q+e) uses the UNswapped sum, which offsets every score of the matrix by (q+e)_swapped - (q+e)_given.
     i32 hLeft = ( q + e ) - qe0;
@@ -346,7 +351,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                     TT[ s ] += RING;
                     TTpk[ s ] = (u32)TT[ s ] | (u32)( TT[ s ] + 1 ) << 16;
                     PB[ s ] = pk_sub( pk_bcast( tlen - 1 ), TTpk[ s ] );
-                    U[ s ] = uInit2( TT[ s ] );
+                    U[ s ] = uFar ? K_UFAR : uInit2( TT[ s ] );
                     Y[ s ] = K_Y0;
                     Y2[ s ] = K_Y20;
                     T[ s ] = Tn[ s ];

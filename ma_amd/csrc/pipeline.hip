@@ -692,6 +692,24 @@ struct PipeFetch
         {
             return text_base( X, base + ( rev ? to - 1 - (u32)i : from + (u32)i ) );
         }
+        // bases of cells i and i + 1 (low / high half) with one address computation; i < to - from; the high half repeats
+        // cell i when i + 1 is past the window (the caller masks it).  A DP window never bridges the two strands.
+        static const bool CLEAN = true; // codes 0..3 only (2-bit pack): no N to recode
+        __device__ u32 pair( i32 i ) const
+        {
+            // the window lies on one strand, so strand and step direction are wave-uniform: forward position of cell i =
+            // fFirst + sgn * i
+            const u64 pFirst = base + ( rev ? to - 1 : from );
+            const bool comp = pFirst >= X.F;
+            const i32 sgn = ( rev != 0 ) != comp ? -1 : 1;
+            const u64 fFirst = comp ? X.n - 1 - pFirst : pFirst;
+            const u64 f0 = fFirst + (u64)(i64)( sgn * i );
+            const u64 f1 = f0 + (u64)(i64)( (u32)i + 1 < to - from ? sgn : 0 );
+            u32 b0 = ( (u32)X.pac[ f0 >> 2 ] >> ( ( ~(u32)f0 & 3 ) << 1 ) ) & 3;
+            u32 b1 = ( (u32)X.pac[ f1 >> 2 ] >> ( ( ~(u32)f1 & 3 ) << 1 ) ) & 3;
+            const u32 flip = comp ? 0x00030003u : 0u; // complement of a 2-bit code = code ^ 3
+            return ( b0 | b1 << 16 ) ^ flip;
+        }
     };
     __device__ Q qfetch( u32 s ) const
     {

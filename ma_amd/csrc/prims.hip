@@ -98,6 +98,11 @@ struct ByteFetch
         {
             return p[ i ];
         }
+        static const bool CLEAN = false; // bytes as given: 4 (and above) = N
+        __device__ u32 pair( i32 i ) const // cells i, i + 1 (the byte arrays are padded: reading one past the end is safe)
+        {
+            return (u32)p[ i ] | (u32)p[ i + 1 ] << 16;
+        }
     };
     __device__ Q qfetch( u32 s ) const
     {
