@@ -38,6 +38,11 @@ int main( int argc, char** argv )
         else
             ma_or_params_default( &P );
         P.srand_seed = (uint32_t)atoi( argv[ 4 ] );
+        if( argc >= 12 ) // pipe <case> <preset> <seed> <out> match mismatch gap extend gap2 extend2
+        {
+            P.match = atoi( argv[ 6 ] ), P.mismatch = atoi( argv[ 7 ] ), P.gap = atoi( argv[ 8 ] ), P.extend = atoi( argv[ 9 ] );
+            P.gap2 = atoi( argv[ 10 ] ), P.extend2 = atoi( argv[ 11 ] );
+        }
         std::vector<uint8_t> cat;
         std::vector<uint64_t> off{ 0 };
         for( auto& r : c.reads )

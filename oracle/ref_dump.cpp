@@ -504,6 +504,15 @@ int main( int argc, char** argv )
 {
     if( argc >= 4 && !strcmp( argv[ 1 ], "index" ) )
         return cmdIndex( argv[ 2 ], argv[ 3 ] );
+    if( argc >= 12 && !strcmp( argv[ 1 ], "pipe" ) ) // pipe <case> <preset> <seed> <out> match mismatch gap extend gap2 extend2
+    {
+        pGlobalParams->iMatch->set( atoi( argv[ 6 ] ) );
+        pGlobalParams->iMissMatch->set( atoi( argv[ 7 ] ) );
+        pGlobalParams->iGap->set( atoi( argv[ 8 ] ) );
+        pGlobalParams->iExtend->set( atoi( argv[ 9 ] ) );
+        pGlobalParams->iGap2->set( atoi( argv[ 10 ] ) );
+        pGlobalParams->iExtend2->set( atoi( argv[ 11 ] ) );
+    }
     if( argc >= 6 && !strcmp( argv[ 1 ], "pipe" ) )
         return cmdPipe( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ] );
     if( argc >= 6 && !strcmp( argv[ 1 ], "sam" ) )

@@ -163,6 +163,39 @@ def test_pipeline_long_read_presets_vs_oracle(small):
         assert int(malns["supplementary"].sum()) > 0
 
 
+@pytest.mark.parametrize("scoring", [(3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 24, 1, 4, 2)])
+def test_pipeline_other_scoring_schemes_vs_oracle(small, scoring):
+    """The whole path under other global scoring parameters (they enter the SoC thresholds, the gap-cost estimation of
+    Harmonization, every DP call, the alignment scores and MappingQuality): NeedlemanWunsch and MappingQuality
+    records against the oracle.  (The oracle's kswcpp is pinned against the reference for these schemes; the reference's
+    pipeline is not a well-defined function of them, see tests/test_oracle_vs_ref.py: one pGlobalParams per unit.)"""
+    import ma_amd
+    _, f4reads, _ = read_case(gunzip_to(os.path.join(G, "f4.case.gz"), str(small["dir"] / "f4.case")))
+    reads = small["reads"] + f4reads[-8:] + f4reads[:40]
+    P = ma_amd.Params.preset("default")
+    op = or_params("default", 1)
+    for prm in (P, op):
+        prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
+        prm.srand_seed = 1
+    b = ma_amd.Batch(small["gidx"], P, len(reads), sum(len(r) for r in reads) + 64)
+    b.set_reads(reads)
+    b.align()
+    b.sync()
+    res = small["oidx"].align(reads, op)
+    aoff, alns, ops = b.alignments()
+    assert np.array_equal(aoff, res["aln_off"])
+    for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops"):
+        assert np.array_equal(alns[f], res["alns"][f]), f
+    for g, o in zip(alns, res["alns"]):
+        assert np.array_equal(ops[2 * int(g["ops_off"]):2 * int(g["ops_off"] + g["n_ops"])],
+                              res["ops"][2 * int(o["ops_off"]):2 * int(o["ops_off"] + o["n_ops"])])
+    moff, malns, _ = b.mapq_alignments()
+    assert np.array_equal(moff, res["mq_off"])
+    for f in ("begin_ref", "end_ref", "score", "secondary", "supplementary"):
+        assert np.array_equal(malns[f], res["mq"][f]), f
+    assert np.array_equal(malns["mapq"].view(np.uint64), res["mq"]["mapq"].view(np.uint64))
+
+
 # reference outputs for ksw.case under the presets' scoring and under make_golden.py's KSW_SCORINGS
 KSW_GOLDEN = [("ksw_ref.out.gz", None), ("ksw_ref.sc0.out.gz", (3, 5, 6, 3, 30, 2)), ("ksw_ref.sc1.out.gz", (1, 3, 5, 2, 24, 1)),
               ("ksw_ref.sc2.out.gz", (2, 4, 24, 1, 4, 2)), ("ksw_ref.sc3.out.gz", (5, 4, 2, 1, 40, 1))]
