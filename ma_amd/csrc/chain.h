@@ -281,7 +281,7 @@ MA_HD double median_of( double* a, u32 n ) // test_ransac.h:21-40 (sorts its pri
 }
 
 // run_ransac -> (angle, rStart as double); NaNs when no model was found
-MA_HD void run_ransac( const double* X, const double* Y, u32 nPts, double fMAD, GlibcRand& rng, i32* inl, i32* best,
+MA_HD_OUTLINE void run_ransac( const double* X, const double* Y, u32 nPts, double fMAD, GlibcRand& rng, i32* inl, i32* best,
                        double* scratch, double& outAngle, double& outIntercept )
 {
     int iterations = 0;
@@ -396,7 +396,7 @@ MA_HD i64 double_to_i64( double d ) // (int64_t)d with x86 cvttsd2si semantics f
 }
 
 // linesweep (harmonization.cpp:182-249): in = sh (n), out = ends; returns count
-MA_HD u32 linesweep( Shadow* sh, u32 n, Shadow* ends, const ma_seed* seeds, const i64 rStart, const double fAngle )
+MA_HD_OUTLINE u32 linesweep( Shadow* sh, u32 n, Shadow* ends, const ma_seed* seeds, const i64 rStart, const double fAngle )
 {
     ss::sort( sh, (i64)n, ShadowOrder( ) );
     u32 ne = 0;
@@ -436,7 +436,7 @@ MA_HD u32 linesweep( Shadow* sh, u32 n, Shadow* ends, const ma_seed* seeds, cons
 }
 
 // harmonizeOne (harmonization.cpp:251-373): S (n seeds, modified) -> out; returns count
-MA_HD u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScratch& C, GlibcRand& rng )
+MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScratch& C, GlibcRand& rng )
 {
     if( n > 1 )
     {

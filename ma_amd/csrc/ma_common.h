@@ -10,9 +10,11 @@
 #include <hip/hip_runtime.h>
 #define MA_HD __host__ __device__ __forceinline__
 #define MA_HD_NOINLINE __host__ __device__
+#define MA_HD_OUTLINE inline __host__ __device__ __attribute__( ( noinline ) ) // one copy of a big helper per kernel
 #else
 #define MA_HD inline
 #define MA_HD_NOINLINE
+#define MA_HD_OUTLINE inline
 #endif
 
 typedef int64_t i64;

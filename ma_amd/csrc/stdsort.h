@@ -156,7 +156,7 @@ template <typename T, typename C> MA_HD void heap_sort_range( T* a, i64 first, i
 }
 
 // std::sort(a, a+n, comp)
-template <typename T, typename C> MA_HD_NOINLINE void sort( T* a, i64 n, C comp )
+template <typename T, typename C> MA_HD_OUTLINE void sort( T* a, i64 n, C comp )
 {
     if( n <= 0 )
         return;
