@@ -85,3 +85,12 @@ def test_gpu_built_index_is_stored_in_the_reference_file_formats(tmp_path, gpu_d
         out = str(tmp_path / "ref.pipe")
         subprocess.check_call([ref_dump, "pipeidx", prefix, case, "default", "1", out])
         assert open(out).read() == gzip.open(os.path.join(G, "small_ref.default.pipe.gz"), "rt").read()
+        # forward length not a multiple of 4 (no zero byte before the .pac check byte), tiny contig in the middle
+        from ma_testlib import rand_genome, sample_reads, write_case
+        g = rand_genome(77, [70001, 129, 40003])
+        case2 = str(tmp_path / "odd.case")
+        write_case(case2, g, sample_reads(g[:1], 40, 150, 78, sub=0.02) + sample_reads(g[2:], 40, 150, 79, sub=0.02))
+        subprocess.check_call([exe, case2, str(tmp_path / "odd")])
+        subprocess.check_call([ref_dump, "pipeidx", str(tmp_path / "odd"), case2, "default", "1", str(tmp_path / "a.pipe")])
+        subprocess.check_call([ref_dump, "pipe", case2, "default", "1", str(tmp_path / "b.pipe")])
+        assert open(str(tmp_path / "a.pipe")).read() == open(str(tmp_path / "b.pipe")).read()
