@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from ma_testlib import (ROOT, gunzip_to, read_case, read_ksw_cases, parse_pipe_dump, parse_ksw_dump, OrIndex, or_params,
-                        rand_genome, sample_reads, rand_ksw_cases, or_ksw, revcomp, KSW_EXTZ, KSW_RIGHT, KSW_REV)
+                        rand_genome, sample_reads, rand_ksw_cases, or_ksw, revcomp, write_case, KSW_EXTZ, KSW_RIGHT, KSW_REV)
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(ROOT, "tests", "golden")
@@ -316,6 +316,29 @@ def test_ksw_other_scoring_schemes(gpu_device, scoring):
             for f in ("max", "max_q", "max_t"):
                 assert int(ez2[f][i]) == int(oez[f]), "pipeline semantics: case %d field %s" % (i, f)
         assert np.array_equal(cigs2[i], ocig), "pipeline semantics: case %d cigar" % i
+
+
+@pytest.mark.parametrize("preset", ["default", "illumina"])
+def test_pipeline_vs_compiled_reference_direct(gpu_device, tmp_path, preset):
+    """No oracle in the loop: when the compiled reference travelled with the repository (oracle/_ref, built from
+    /root/reference by oracle/Makefile.ref), its own modules and the GPU path align the same reads of a genome large enough
+    for the heuristics (> 10 Mnt doubled), with repeats, N bases, long reads: every stage record must be identical."""
+    import subprocess
+    import ma_amd
+    ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if not os.path.exists(ref_dump):
+        pytest.skip("oracle/_ref not present on this box")
+    g = rand_genome(19, [2700000, 1400000, 1000000], repeat_unit=300, repeat_copies=250, repeat_div=0.08)
+    reads = (sample_reads(g, 2500, 150, 131, sub=0.01) + sample_reads(g, 300, 150, 132, sub=0.06, n_rate=0.01)
+             + sample_reads(g, 20, 5000, 133, sub=0.005, ins=0.003, dele=0.003) + sample_reads(g, 40, 150, 135, random_frac=1.0)
+             + sample_reads(g, 200, 100, 136, sub=0.03) + sample_reads(g, 2, 25000, 134, sub=0.03, ins=0.03, dele=0.04))
+    case = str(tmp_path / "c.case")
+    write_case(case, g, reads)
+    subprocess.check_call([ref_dump, "pipe", case, preset, "3", str(tmp_path / "ref.pipe")], stdout=subprocess.DEVNULL)
+    want = parse_pipe_dump(str(tmp_path / "ref.pipe"))
+    got, counters, counts = gpu_pipeline(ma_amd.Index.build(g), preset, 3, reads)
+    compare_reads(got, want)
+    assert counts["aligned_reads"] == sum(1 for w in want if w["mq"])
 
 
 @pytest.mark.parametrize("preset,seed,name", [("default", 1, "small_ref.default.pipe"),
