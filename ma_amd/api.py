@@ -153,10 +153,16 @@ class Index:
         return dict(bwt=bwt, sa=sa, L2=L2, primary=primary.value, ref_len=rl, pac=pac, contig_starts=cs,
                     contig_lens=cl)
 
-    def store(self, prefix, names=None):
+    def store(self, prefix, names=None, title=None):
         """Write the index as the reference's <prefix>.bwt/.sa/.pac/.ann/.amb files (FMIndex::vStoreFMIndex
         fMIndex.h:515-549, Pack::vStoreCollection pack.h:230-269,725-770; same layout as storeIndex of the C++ host
         layer): maCMD / FMIndex(prefix) load an index that was built on the GPU."""
+        if title:  # the genome file `maCMD -x` takes (execution-context.h:60-136)
+            import json as _json
+            import os as _os
+            with open(_os.path.join(_os.path.dirname(prefix), title + ".json"), "w") as f:
+                f.write(_json.dumps({"name": title, "prefix": _os.path.basename(prefix), "type": "MA Genome",
+                                     "version": {"major": 1, "minor": 0}}, indent=4, sort_keys=True) + "\n")
         d = self.download()
         n = int(d["ref_len"])
         F = n // 2

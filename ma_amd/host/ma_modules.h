@@ -246,8 +246,20 @@ inline void buildIndex( const std::vector<std::shared_ptr<NucSeq>>& vContigs, st
 // FMIndex::vStoreFMIndex (fMIndex.h:515-549) and Pack::vStoreCollection (pack.h:230-269, 725-770) write for the same
 // genome: the reference (maCMD -x, FMIndex(prefix), Pack::vLoadCollection) loads an index built on the GPU.  The .bwt,
 // .sa and .pac bytes equal the reference's; .ann carries the reference's time-based seed, here 0.
-inline void storeIndex( const std::string& sPrefix, const std::shared_ptr<Pack>& pPack, const std::shared_ptr<FMIndex>& pFM )
+// With a genome title also writes <folder of prefix>/<title>.json, the file `maCMD -x` takes (GenomeManager::
+// createGenomeJSON / loadGenome, execution-context.h:60-136; nlohmann layout: keys sorted, 4 blanks).
+inline void storeIndex( const std::string& sPrefix, const std::shared_ptr<Pack>& pPack, const std::shared_ptr<FMIndex>& pFM,
+                        const std::string& sGenomeTitle = "" )
 {
+    if( !sGenomeTitle.empty( ) )
+    {
+        const size_t uiSlash = sPrefix.find_last_of( '/' );
+        const std::string sFolder = uiSlash == std::string::npos ? "" : sPrefix.substr( 0, uiSlash + 1 );
+        const std::string sStem = uiSlash == std::string::npos ? sPrefix : sPrefix.substr( uiSlash + 1 );
+        std::ofstream f( sFolder + sGenomeTitle + ".json" );
+        f << "{\n    \"name\": \"" << sGenomeTitle << "\",\n    \"prefix\": \"" << sStem << "\",\n    \"type\": \"MA Genome\",\n"
+          << "    \"version\": {\n        \"major\": 1,\n        \"minor\": 0\n    }\n}\n";
+    }
     uint64_t nWords = 0, nSa = 0, uiN = 0;
     int32_t nContigs = 0;
     maCheck( ma_index_sizes( pFM->pDev->p, &nWords, &nSa, &uiN, &nContigs ) );

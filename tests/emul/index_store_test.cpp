@@ -1,6 +1,6 @@
 // SURVEY 8(f) f1, file side: builds the index of a case on the GPU, writes it with storeIndex as the reference's
 // .bwt/.sa/.pac/.ann/.amb files, loads those files again with loadIndex and checks the round trip.
-// usage: index_store_test <case> <prefix>
+// usage: index_store_test <case> <prefix> [genome title -> <folder>/<title>.json]
 #include "../../ma_amd/host/ma_modules.h"
 #include "../../oracle/dump_format.h"
 #include <cstdio>
@@ -25,7 +25,7 @@ int main( int argc, char** argv )
         std::shared_ptr<Pack> pPack, pPack2;
         std::shared_ptr<FMIndex> pFM, pFM2;
         buildIndex( vContigs, pPack, pFM );
-        storeIndex( argv[ 2 ], pPack, pFM );
+        storeIndex( argv[ 2 ], pPack, pFM, argc >= 4 ? argv[ 3 ] : "" );
         loadIndex( argv[ 2 ], pPack2, pFM2 );
         uint64_t a[ 3 ], b[ 3 ];
         int32_t na, nb;

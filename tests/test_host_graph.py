@@ -73,7 +73,10 @@ def test_gpu_built_index_is_stored_in_the_reference_file_formats(tmp_path, gpu_d
                                "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"), "-lpthread"])
     case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
     prefix = str(tmp_path / "idx")
-    subprocess.check_call([exe, case, prefix])
+    subprocess.check_call([exe, case, prefix, "small genome"])
+    import json
+    assert json.load(open(str(tmp_path / "small genome.json"))) == {"name": "small genome", "prefix": "idx", "type": "MA Genome",
+                                                                    "version": {"major": 1, "minor": 0}}
     for ext in ("bwt", "sa", "pac"):
         want = gzip.open(os.path.join(G, "small_ref." + ext + ".gz"), "rb").read()
         assert open(prefix + "." + ext, "rb").read() == want, ext
