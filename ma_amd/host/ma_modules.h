@@ -144,6 +144,9 @@ class Pack : public libMS::Container
     std::shared_ptr<DeviceIndex> pDev;
     std::vector<std::string> vNames;
     std::vector<uint64_t> vStarts, vLengths;
+    // runs of N of the input that were replaced by random bases (pack.h:630-666): offset, length; written to .amb
+    std::vector<std::pair<uint64_t, uint64_t>> vHoles;
+    std::vector<uint64_t> vNumHoles; // per contig, for .ann
     uint64_t uiUnpackedSizeForwardPlusReverse( ) const // pack.h:881-884: twice the forward strand
     {
         if( !vStarts.empty( ) )
@@ -228,8 +231,30 @@ inline void buildIndex( const std::vector<std::shared_ptr<NucSeq>>& vContigs, st
     uint64_t off = 0;
     for( auto& c : vContigs )
     {
+        if( c->length( ) == 0 ) // Pack::vAppendSequence skips empty sequences (pack.h:596-600)
+            continue;
         lens.push_back( c->length( ) );
-        cat.insert( cat.end( ), c->xCodes.begin( ), c->xCodes.end( ) );
+        // Pack::vAppendSequence (pack.h:625-666): every N (code >= 4) becomes rand() & 3 (the caller seeds libc's rand();
+        // the reference seeds it with the time, so N regions differ from run to run there), runs of N are recorded
+        uint64_t uiHoles = 0;
+        unsigned int uiPrev = 0;
+        for( size_t i = 0; i < c->xCodes.size( ); i++ )
+        {
+            unsigned int uiCode = c->xCodes[ i ];
+            if( uiCode >= 4 )
+            {
+                if( uiPrev == uiCode )
+                    pPack->vHoles.back( ).second++;
+                else
+                {
+                    pPack->vHoles.emplace_back( off + i, 1 );
+                    uiHoles++;
+                }
+            }
+            uiPrev = uiCode;
+            cat.push_back( uiCode >= 4 ? (uint8_t)( rand( ) & 3 ) : (uint8_t)uiCode );
+        }
+        pPack->vNumHoles.push_back( uiHoles );
         pPack->vNames.push_back( c->sName );
         pPack->vStarts.push_back( off );
         pPack->vLengths.push_back( c->length( ) );
@@ -312,11 +337,14 @@ inline void storeIndex( const std::string& sPrefix, const std::shared_ptr<Pack>&
         f << uiF << " " << nContigs << " " << 0 << "\n";
         for( int32_t i = 0; i < nContigs; i++ )
             f << 0 << " " << ( (size_t)i < pPack->vNames.size( ) ? pPack->vNames[ i ] : "chr" + std::to_string( i + 1 ) ) << " none\n"
-              << vStarts[ i ] << " " << vLens[ i ] << " " << 0 << "\n";
+              << vStarts[ i ] << " " << vLens[ i ] << " " << ( (size_t)i < pPack->vNumHoles.size( ) ? pPack->vNumHoles[ i ] : 0 )
+              << "\n";
     }
     {
         std::ofstream f( sPrefix + ".amb" );
-        f << uiF << " " << nContigs << " " << 0 << "\n";
+        f << uiF << " " << nContigs << " " << pPack->vHoles.size( ) << "\n";
+        for( auto& rHole : pPack->vHoles )
+            f << rHole.first << " " << rHole.second << " N\n";
     }
 }
 

@@ -882,4 +882,20 @@ class PairedFileReader : public libMS::Module<PairedReadsContainer, true, Paired
         return pRet;
     }
 };
+
+// Genome FASTA -> index on the GPU: the contigs as FileReader returns them (names up to the first blank, IUPAC codes and N
+// become N), Ns replaced like Pack::vAppendSequence does (buildIndex).  (The reference ingests genomes with a second FASTA
+// parser, FastaStreamReader in pack.cpp:510-537; record names and sequences agree for plain FASTA files.)
+inline void buildIndexFromFasta( const std::string& sFastaFilePath, std::shared_ptr<Pack>& pPack, std::shared_ptr<FMIndex>& pFM )
+{
+    ParameterSetManager xParameters;
+    FileReader xReader( xParameters );
+    auto pStream = fileStreamFromPath( sFastaFilePath );
+    std::vector<std::shared_ptr<NucSeq>> vContigs;
+    while( auto pContig = xReader.execute( pStream ) )
+        vContigs.push_back( pContig );
+    if( vContigs.empty( ) )
+        throw std::runtime_error( "File open error." );
+    buildIndex( vContigs, pPack, pFM );
+}
 } // namespace libMA

@@ -533,6 +533,13 @@ int main( int argc, char** argv )
         g_sIndexPrefix = argv[ 2 ];
         return cmdTime( argv[ 3 ], argv[ 4 ], atoi( argv[ 5 ] ) );
     }
+    if( argc >= 4 && !strcmp( argv[ 1 ], "fastapack" ) ) // fastapack <genome.fa> <prefix>: Pack::vAppendFASTA + vStoreCollection
+    {
+        Pack xPack;
+        xPack.vAppendFASTA( argv[ 2 ] );
+        xPack.vStoreCollection( argv[ 3 ] );
+        return 0;
+    }
     if( argc >= 5 && !strcmp( argv[ 1 ], "time" ) )
         return cmdTime( argv[ 2 ], argv[ 3 ], atoi( argv[ 4 ] ) );
     if( argc >= 4 && !strcmp( argv[ 1 ], "read" ) )

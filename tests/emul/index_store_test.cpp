@@ -1,9 +1,10 @@
 // SURVEY 8(f) f1, file side: builds the index of a case on the GPU, writes it with storeIndex as the reference's
 // .bwt/.sa/.pac/.ann/.amb files, loads those files again with loadIndex and checks the round trip.
 // usage: index_store_test <case> <prefix> [genome title -> <folder>/<title>.json]
-#include "../../ma_amd/host/ma_modules.h"
+#include "../../ma_amd/host/ma_sam.h"
 #include "../../oracle/dump_format.h"
 #include <cstdio>
+#include <cstring>
 
 using namespace libMA;
 
@@ -11,6 +12,23 @@ int main( int argc, char** argv )
 {
     if( argc < 3 )
         return 2;
+    if( argc >= 5 && !strcmp( argv[ 4 ], "fasta" ) ) // index_store_test <genome.fa> <prefix> <title> fasta
+    {
+        try
+        {
+            std::shared_ptr<Pack> pPack;
+            std::shared_ptr<FMIndex> pFM;
+            srand( 12345 );
+            buildIndexFromFasta( argv[ 1 ], pPack, pFM );
+            storeIndex( argv[ 2 ], pPack, pFM, argv[ 3 ] );
+        }
+        catch( const std::runtime_error& e )
+        {
+            fprintf( stderr, "error: %s\n", e.what( ) );
+            return 1;
+        }
+        return 0;
+    }
     CaseFile c = readCase( argv[ 1 ] );
     std::vector<std::shared_ptr<NucSeq>> vContigs;
     for( size_t i = 0; i < c.contigs.size( ); i++ )

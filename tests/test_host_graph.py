@@ -97,3 +97,47 @@ def test_gpu_built_index_is_stored_in_the_reference_file_formats(tmp_path, gpu_d
         subprocess.check_call([ref_dump, "pipeidx", str(tmp_path / "odd"), case2, "default", "1", str(tmp_path / "a.pipe")])
         subprocess.check_call([ref_dump, "pipe", case2, "default", "1", str(tmp_path / "b.pipe")])
         assert open(str(tmp_path / "a.pipe")).read() == open(str(tmp_path / "b.pipe")).read()
+
+
+@pytest.mark.gpu
+def test_index_from_genome_fasta_with_n_runs(tmp_path, gpu_device):
+    """buildIndexFromFasta + storeIndex on a FASTA with runs of N: contig table and hole records (.ann / .amb) as the
+    reference's Pack::vAppendFASTA writes them (the random bases that replace the Ns differ by design: the reference seeds
+    rand() with the time), and the reference loads the files."""
+    import numpy as np
+    from ma_testlib import rand_genome
+    exe = os.path.join(ROOT, "tests", "emul", "index_store_test")
+    rng = np.random.default_rng(5)
+    g = rand_genome(78, [5000, 3001])
+    fa = str(tmp_path / "g.fa")
+    with open(fa, "w") as f:
+        for k, c in enumerate(g):
+            s = "".join("ACGT"[int(b)] for b in c)
+            if k == 0:
+                s = s[:100] + "N" * 37 + s[137:2000] + "NNN" + s[2003:]
+            else:
+                s = "N" * 5 + s[5:-2] + "NN"
+            f.write(">ctg%d some description\n" % k)
+            for i in range(0, len(s), 61):
+                f.write(s[i:i + 61] + "\n")
+    prefix = str(tmp_path / "fx")
+    subprocess.check_call([exe, fa, prefix, "fasta genome", "fasta"])
+    assert open(prefix + ".amb").read() == "8001 2 4\n100 37 N\n2000 3 N\n5000 5 N\n7999 2 N\n"
+    ann = open(prefix + ".ann").read().split("\n")
+    assert ann[1:5] == ["0 ctg0 none", "0 5000 2", "0 ctg1 none", "5000 3001 2"]
+    ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if os.path.exists(ref_dump):
+        subprocess.check_call([ref_dump, "fastapack", fa, str(tmp_path / "rf")])
+        assert open(str(tmp_path / "rf.amb")).read() == open(prefix + ".amb").read()
+        rann = open(str(tmp_path / "rf.ann")).read().split("\n")
+        assert [l.split()[:2] for l in rann[1::2] if l] == [l.split()[:2] for l in ann[1::2] if l]  # gi, name
+        assert rann[2::2] == ann[2::2]  # offset, length, holes
+        # the packs agree outside the holes
+        a, b = open(prefix + ".pac", "rb").read(), open(str(tmp_path / "rf.pac"), "rb").read()
+        assert len(a) == len(b)
+        holes = set()
+        for o, n in ((100, 37), (2000, 3), (5000, 5), (7999, 2)):
+            holes.update(range(o, o + n))
+        for p in range(8001):
+            if p not in holes:
+                assert (a[p >> 2] >> ((~p & 3) << 1)) & 3 == (b[p >> 2] >> ((~p & 3) << 1)) & 3, p
