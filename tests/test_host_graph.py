@@ -141,3 +141,30 @@ def test_index_from_genome_fasta_with_n_runs(tmp_path, gpu_device):
         for p in range(8001):
             if p not in holes:
                 assert (a[p >> 2] >> ((~p & 3) << 1)) & 3 == (b[p >> 2] >> ((~p & 3) << 1)) & 3, p
+
+
+@pytest.mark.gpu
+def test_example_fastq_to_sam_end_to_end(tmp_path, gpu_device):
+    """examples/ma_align.cpp: genome FASTA -> index on the GPU, FASTQ reads -> BatchAligner -> FileWriter; the SAM records
+    equal what the reference's FileReader + modules + FileWriter wrote for the same files (tests/golden/reader)."""
+    from ma_testlib import read_case
+    exe = os.path.join(ROOT, "examples", "ma_align")
+    src = exe + ".cpp"
+    deps = [src] + [os.path.join(ROOT, "ma_amd", "host", h) for h in ("ma_sam.h", "ma_modules.h", "ms_graph.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        zl = os.path.exists("/usr/include/zlib.h")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall"] + (["-DMA_WITH_ZLIB"] if zl else []) +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", exe,
+                               "-L" + os.path.join(ROOT, "ma_amd"), "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"),
+                               "-lpthread"] + (["-lz"] if zl else []))
+    contigs, _, names = read_case(gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case")))
+    fa = str(tmp_path / "genome.fa")
+    with open(fa, "w") as f:
+        for nm, c in zip(names, contigs):
+            f.write(">%s\n%s\n" % (nm, "".join("ACGT"[int(b)] for b in c)))
+    out = str(tmp_path / "out.sam")
+    subprocess.check_call([exe, fa, os.path.join(G, "reader", "small24.fq"), out, "default"])
+    got = open(out).read().split("\n")
+    want = gzip.open(os.path.join(G, "reader", "small24.fq.sam.gz"), "rt").read().split("\n")
+    assert got[0] == "@SQ\tSN:chr1\tLN:30000"  # file-name constructor: tabs (fileWriter.h:385-400)
+    assert [l for l in got if not l.startswith("@")] == [l for l in want if not l.startswith("@")]
