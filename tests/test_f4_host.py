@@ -19,10 +19,11 @@ def build(name):
     deps = [src, os.path.join(ROOT, "include", "ma_amd.h")] + [os.path.join(ROOT, "ma_amd", "host", h)
                                                               for h in ("ma_sam.h", "ma_modules.h", "ms_graph.h")]
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+        zl = ["-DMA_WITH_ZLIB"] if os.path.exists("/usr/include/zlib.h") else []  # same flags as tests/test_sam_writer.py
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall"] + zl + ["-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", exe,
                                "-L" + os.path.join(ROOT, "ma_amd"), "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"),
-                               "-lpthread"])
+                               "-lpthread"] + (["-lz"] if zl else []))
     return exe
 
 
