@@ -57,12 +57,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # test hook: MA_BENCH_ONE_DEVICE=1 runs all ranks on GPU 0 over gloo, so that the multi-rank code path (barriers,
+    # MAX/SUM reductions, rank-0 reporting) can be exercised on a one-GPU box; the driver's runs use RCCL, one GPU per rank
+    one_dev = os.environ.get("MA_BENCH_ONE_DEVICE") == "1"
+    gpu = 0 if one_dev else local_rank
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    ma_amd.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if one_dev:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
+    torch.cuda.set_device(gpu)
+    ma_amd.set_device(gpu)
+    dev = torch.device("cuda", gpu)
+    local_rank = gpu
     L = ma_amd.lib()
 
     def chk(rc):
@@ -167,7 +175,7 @@ def main():
     ctr = sum(a["ctr"] for a in acc)
     segs = sum(a["segs"] for a in acc)
     aligned = sum(a["aligned"] for a in acc)
-    dt, (aligned_all,) = reduce_timing_and_counts(dist, dev, dt, [aligned])
+    dt, (aligned_all,) = reduce_timing_and_counts(dist, torch.device("cpu") if one_dev else dev, dt, [aligned])
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the K launches) --
     names = ["k_seed", "k_seed_rows+k_lf_walk+k_seed_final", "k_chain", "k_dp_enum", "k_ksw", "k_stitch+k_finish"]
