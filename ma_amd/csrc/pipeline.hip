@@ -781,7 +781,7 @@ struct StitchKernelArgs
     unsigned long long* ctr;
 };
 
-__global__ void k_stitch( StitchKernelArgs A )
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 ) ) ) k_stitch( StitchKernelArgs A )
 {
     const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
     if( s >= A.n_sets )
