@@ -123,19 +123,74 @@ struct DeviceIndex
     }
 };
 
-class SuffixArrayInterface : public libMS::Container // fMIndex.h:155-175
+// SAInterval (fMIndex.h:44-150): bi-interval (start, start of the reverse complement's interval, size)
+class SAInterval
+{
+  public:
+    int64_t iStart = 0, iStartRevComp = 0, iSize = 0;
+    SAInterval( )
+    {}
+    SAInterval( int64_t iStart, int64_t iStartRevComp, int64_t iSize ) : iStart( iStart ), iStartRevComp( iStartRevComp ), iSize( iSize )
+    {}
+    int64_t start( ) const
+    {
+        return iStart;
+    }
+    int64_t startRevComp( ) const
+    {
+        return iStartRevComp;
+    }
+    int64_t size( ) const
+    {
+        return iSize;
+    }
+    int64_t end( ) const
+    {
+        return iStart + iSize;
+    }
+    SAInterval revComp( ) const // fMIndex.h:85-88
+    {
+        return SAInterval( iStartRevComp, iStart, iSize );
+    }
+};
+// SuffixArrayInterface (fMIndex.h:155-175): the fine-grained seam of the seeding stage.  One call = one tiny GPU launch;
+// it is there for code written against the interface (and for tests), the modules use the batch entry points.
+class SuffixArrayInterface : public libMS::Container
 {
   public:
     std::shared_ptr<DeviceIndex> pDev;
-};
-class FMIndex : public SuffixArrayInterface
-{
-  public:
-    uint64_t getRefSeqLength( ) const
+    virtual SAInterval extend_backward( const SAInterval& ik, const uint8_t c ) // fMIndex.cpp:21-101
+    {
+        const int64_t in[ 3 ] = { ik.iStart, ik.iStartRevComp, ik.iSize };
+        int64_t out[ 3 ];
+        maCheck( ma_extend_backward_batch( pDev->p, in, &c, 1, out ) );
+        return SAInterval( out[ 0 ], out[ 1 ], out[ 2 ] );
+    }
+    virtual SAInterval init_interval( uint8_t c ) // fMIndex.h:768-775
+    {
+        uint64_t L2[ 5 ];
+        maCheck( ma_index_download( pDev->p, nullptr, nullptr, L2, nullptr, nullptr, nullptr, nullptr ) );
+        if( c >= 4 )
+            return SAInterval( 0, 0, 0 );
+        return SAInterval( (int64_t)L2[ c ] + 1, (int64_t)L2[ 3 - c ] + 1, (int64_t)( L2[ c + 1 ] - L2[ c ] ) );
+    }
+    virtual uint64_t getRefSeqLength( ) const
     {
         uint64_t n = 0;
         maCheck( ma_index_sizes( pDev->p, nullptr, nullptr, &n, nullptr ) );
         return n;
+    }
+    virtual ~SuffixArrayInterface( )
+    {}
+};
+class FMIndex : public SuffixArrayInterface
+{
+  public:
+    int64_t bwt_sa( int64_t iRow ) // fMIndex.h:788-814: text position of a suffix array row
+    {
+        int64_t iPos = 0;
+        maCheck( ma_bwt_sa_batch( pDev->p, &iRow, 1, &iPos ) );
+        return iPos;
     }
 };
 class Pack : public libMS::Container

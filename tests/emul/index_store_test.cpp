@@ -44,6 +44,29 @@ int main( int argc, char** argv )
         std::shared_ptr<FMIndex> pFM, pFM2;
         buildIndex( vContigs, pPack, pFM );
         storeIndex( argv[ 2 ], pPack, pFM, argc >= 4 ? argv[ 3 ] : "" );
+        // the reference's own index test (libs/ma/tests/index_generation.cpp): every substring of the genome is found by
+        // backward search through the SuffixArrayInterface seam, and bwt_sa of its interval names its position
+        {
+            std::vector<uint8_t> vText;
+            for( auto& pC : vContigs )
+                vText.insert( vText.end( ), pC->xCodes.begin( ), pC->xCodes.end( ) );
+            srand( 7 );
+            for( int k = 0; k < 40; k++ )
+            {
+                const size_t uiLen = 25, uiPos = (size_t)rand( ) % ( vText.size( ) - uiLen );
+                SAInterval ik = pFM->init_interval( vText[ uiPos + uiLen - 1 ] );
+                for( size_t j = uiLen - 1; j-- > 0 && ik.size( ) > 0; )
+                    ik = pFM->extend_backward( ik, vText[ uiPos + j ] );
+                bool bFound = false;
+                for( int64_t r = ik.start( ); r < ik.end( ) && r < ik.start( ) + 64; r++ )
+                    bFound = bFound || pFM->bwt_sa( r ) == (int64_t)uiPos;
+                if( ik.size( ) < 1 || !bFound )
+                {
+                    fprintf( stderr, "substring at %zu not found (interval size %lld)\n", uiPos, (long long)ik.size( ) );
+                    return 1;
+                }
+            }
+        }
         loadIndex( argv[ 2 ], pPack2, pFM2 );
         uint64_t a[ 3 ], b[ 3 ];
         int32_t na, nb;
