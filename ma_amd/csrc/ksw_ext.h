@@ -316,8 +316,10 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         prof[ 13 ] += tp0 - tpB; // target bytes + state initialisation
 #endif
     i32 recycled = 0; // cells below this index have been handed to cells RING further up
-    // granularity of that hand-over: 16 cells when the ring has room for 15 dead cells beside the live window, else one lane
-    const i32 gran = ( qlen + 15 <= RING || tlen <= RING ) ? 16 : 2;
+    // granularity of that hand-over: 16 cells when the ring has room for 15 dead cells beside the live window, else 8, 4 or
+    // one lane (2 cells): each hand-over costs the same, so the coarsest one that fits is the cheapest per diagonal
+    const i32 room = tlen <= RING ? 16 : RING - qlen + 1; // dead cells the ring can hold beside the live window
+    const i32 gran = room >= 16 ? 16 : ( room >= 8 ? 8 : ( room >= 4 ? 4 : 2 ) );
     // cells handed on are >= RING: beyond long_thres their first-row difference is the constant -e2 (initOf)
     const bool uFar = RING > long_thres + 1;
     const u32 K_UFAR = pk_val( -e2, 0 );
