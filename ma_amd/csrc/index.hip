@@ -3,6 +3,7 @@
 #include "internal.h"
 #include <algorithm>
 #include <cstring>
+#include <memory>
 
 namespace ma
 {
@@ -135,17 +136,14 @@ int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t*
 {
     if( !bwt_words || !sa || !pac || !out || n_contigs <= 0 )
         return fail( "ma_index_create: null argument" );
-    ma_index* x = new ma_index( );
+    std::unique_ptr<ma_index> x( new ma_index( ) ); // freed with its buffers on any early error return
     MA_HIP( hipGetDevice( &x->device ) );
     x->n_words = n_words;
     x->n_sa = n_sa;
     const uint64_t F = ref_len / 2;
     if( x->bwt.reserve( n_words * 4 + 64 ) || x->sa.reserve( n_sa * 8 ) || x->pac.reserve( ( F + 3 ) / 4 + 16 ) ||
         x->cstart.reserve( n_contigs * 8 ) || x->clen.reserve( n_contigs * 8 ) )
-    {
-        delete x;
         return 1;
-    }
     MA_HIP( hipMemcpy( x->bwt.p, bwt_words, n_words * 4, hipMemcpyHostToDevice ) );
     MA_HIP( hipMemcpy( x->sa.p, sa, n_sa * 8, hipMemcpyHostToDevice ) );
     MA_HIP( hipMemcpy( x->pac.p, pac, ( F + 3 ) / 4, hipMemcpyHostToDevice ) );
@@ -164,7 +162,7 @@ int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t*
     for( int i = 0; i < 5; i++ )
         x->v.L2[ i ] = L2[ i ];
     x->v.n_contigs = n_contigs;
-    *out = x;
+    *out = x.release( );
     return 0;
 }
 
@@ -172,6 +170,7 @@ int ma_index_destroy( ma_index* x )
 {
     if( !x )
         return 0;
+    MA_BIND_DEVICE( x->device );
     x->bwt.release( );
     x->sa.release( );
     x->pac.release( );
@@ -201,6 +200,7 @@ int ma_index_download( const ma_index* x, uint32_t* bwt_words, int64_t* sa, uint
 {
     if( !x )
         return fail( "ma_index_download: null index" );
+    MA_BIND_DEVICE( x->device );
     if( bwt_words )
         MA_HIP( hipMemcpy( bwt_words, x->bwt.p, x->n_words * 4, hipMemcpyDeviceToHost ) );
     if( sa )
@@ -225,6 +225,7 @@ int ma_pack_extract( const ma_index* x, const uint64_t* begin, const uint64_t* e
 {
     if( !x || ( n && ( !begin || !end || !out ) ) )
         return fail( "ma_pack_extract: null argument" );
+    MA_BIND_DEVICE( x->device );
     std::vector<uint8_t> bytes;
     for( uint64_t i = 0; i < n; i++ )
     {

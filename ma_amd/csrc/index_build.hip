@@ -9,6 +9,7 @@
 //            length" field that orders suffixes running into '$' before their padded twins;
 //   round r: only suffixes still tied (repeats) are re-keyed 29 bases further down and sorted by
 //            (group, key) with two stable radix passes, until no ties remain.
+#include <memory>
 #include "internal.h"
 #include "fm_device.h"
 #include <cstring>
@@ -361,10 +362,8 @@ static int refine( Builder& B, const TextView& T, DevBuf& dPos, DevBuf& dGid, u6
             MA_HIP( hipMemcpy( np.p, outPos.p, outOffset * 8, hipMemcpyDeviceToDevice ) );
             MA_HIP( hipMemcpy( ng.p, outGid.p, outOffset * 8, hipMemcpyDeviceToDevice ) );
         }
-        outPos.release( );
-        outGid.release( );
-        outPos = np;
-        outGid = ng;
+        outPos = std::move( np );
+        outGid = std::move( ng );
     }
     MA_HIP( rocprim::select( B.tmp.p, tb4, sPos, tied.as<uint8_t>( ), outPos.as<u64>( ) + outOffset, cnt.as<u64>( ), m ) );
     MA_HIP( rocprim::select( B.tmp.p, tb4, newGid.as<u64>( ), tied.as<uint8_t>( ), outGid.as<u64>( ) + outOffset,
@@ -390,7 +389,7 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
     if( F == 0 )
         return fail( "ma_index_build: empty genome" );
     const u64 n = 2 * F;
-    ma_index* x = new ma_index( );
+    std::unique_ptr<ma_index> x( new ma_index( ) ); // freed with its buffers on any early error return
     MA_HIP( hipGetDevice( &x->device ) );
     DevBuf hist;
     if( x->pac.reserve( ( F + 3 ) / 4 + 16 ) || hist.reserve( 64 ) )
@@ -482,10 +481,8 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
         u64 c = 0;
         if( refine( B, T, tPos, tGid, nTied, depth, false, SA.as<i64>( ), nPos, nGid, c, 0 ) )
             return 1;
-        tPos.release( );
-        tGid.release( );
-        tPos = nPos;
-        tGid = nGid;
+        tPos = std::move( nPos );
+        tGid = std::move( nGid );
         nTied = c;
         depth += 29;
         if( ++rounds > 100000 )
@@ -548,7 +545,7 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
     for( int i = 0; i < 5; i++ )
         x->v.L2[ i ] = L2[ i ];
     x->v.n_contigs = n_contigs;
-    *out = x;
+    *out = x.release( );
     return 0;
 }
 } // namespace

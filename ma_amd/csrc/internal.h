@@ -18,11 +18,35 @@ int fail( const std::string& s );
             return ma::fail( std::string( #call ) + ": " + hipGetErrorString( _e ) );                                  \
     } while( 0 )
 
-// grow-only device buffer
+// grow-only device buffer; owns its allocation (freed on destruction, so an early error return leaks nothing)
 struct DevBuf
 {
     void* p = nullptr;
     size_t cap = 0;
+    DevBuf( ) = default;
+    DevBuf( const DevBuf& ) = delete;
+    DevBuf& operator=( const DevBuf& ) = delete;
+    DevBuf( DevBuf&& o ) noexcept : p( o.p ), cap( o.cap )
+    {
+        o.p = nullptr;
+        o.cap = 0;
+    }
+    DevBuf& operator=( DevBuf&& o ) noexcept
+    {
+        if( this != &o )
+        {
+            release( );
+            p = o.p;
+            cap = o.cap;
+            o.p = nullptr;
+            o.cap = 0;
+        }
+        return *this;
+    }
+    ~DevBuf( )
+    {
+        release( );
+    }
     int reserve( size_t bytes );
     void release( );
     template <typename T> T* as( ) const
@@ -30,6 +54,36 @@ struct DevBuf
         return reinterpret_cast<T*>( p );
     }
 };
+
+// HIP's current device is a per-host-thread setting that defaults to 0: every entry point that takes an index or
+// a batch binds the calling thread to the device that object lives on (and restores the previous one on return), so a
+// worker thread spawned by the host graph never allocates or launches on the wrong GPU.
+struct DeviceGuard
+{
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard( int dev )
+    {
+        err = hipGetDevice( &prev );
+        if( err == hipSuccess && prev != dev )
+        {
+            err = hipSetDevice( dev );
+            switched = err == hipSuccess;
+        }
+    }
+    DeviceGuard( const DeviceGuard& ) = delete;
+    DeviceGuard& operator=( const DeviceGuard& ) = delete;
+    ~DeviceGuard( )
+    {
+        if( switched )
+            (void)hipSetDevice( prev );
+    }
+};
+#define MA_BIND_DEVICE( dev )                                                                                          \
+    ma::DeviceGuard _ma_guard( dev );                                                                                  \
+    if( _ma_guard.err != hipSuccess )                                                                                  \
+    return ma::fail( std::string( "hipSetDevice(" ) + std::to_string( dev ) + "): " + hipGetErrorString( _ma_guard.err ) )
 } // namespace ma
 
 struct ma_index

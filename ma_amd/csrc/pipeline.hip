@@ -9,6 +9,7 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstring>
+#include <memory>
 
 using namespace ma;
 
@@ -839,6 +840,7 @@ __global__ void k_finish( NwParams P, u32 n_reads, const u64* hset_off, const u6
 struct ma_batch
 {
     const ma_index* idx = nullptr;
+    int device = 0; // the index's device: every entry point binds the calling thread to it
     ma_params P;
     hipStream_t stream = nullptr;
     u64 max_reads = 0, max_bases = 0;
@@ -850,7 +852,7 @@ struct ma_batch
     DevBuf reads, roff, ctr, seedStack, seedRow, seedSteps, seedSeg, hlocal, hdense, hseedCnt, hseedOff;
     // seeding
     DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt;
-    u64 segPoolCap = 0;
+    u64 segPoolCap = 0, segPoolMin = 0;
     // extraction
     DevBuf segSeedCnt, segSeedOff, seedOff, seedCnt, seeds, cubTmp;
     u64 nSegs = 0, nSeeds = 0;
@@ -860,7 +862,7 @@ struct ma_batch
     u64 hpoolCap = 0, nHsets = 0, nHseeds = 0;
     // dp
     DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, clsLists, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
-    u64 cigPoolCap = 0, nOpsCap = 0, nJobSlots = 0;
+    u64 cigPoolCap = 0, cigPoolMin = 0, nOpsCap = 0, nJobSlots = 0;
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
     bool timing = false;
     hipEvent_t ev[ 16 ];
@@ -931,17 +933,19 @@ int ma_batch_create( const ma_index* idx, const ma_params* P, uint64_t max_reads
 {
     if( !idx || !P || !out )
         return fail( "ma_batch_create: null argument" );
-    ma_batch* b = new ma_batch( );
+    if( P->seeding_technique < 0 || P->seeding_technique > 2 )
+        return fail( "ma_batch_create: unknown seeding technique " + std::to_string( P->seeding_technique ) +
+                     " (0 maxSpan, 1 SMEMs, 2 MEMs; binarySeeding.h:560-561)" );
+    MA_BIND_DEVICE( idx->device );
+    std::unique_ptr<ma_batch> b( new ma_batch( ) );
     b->idx = idx;
+    b->device = idx->device;
     b->P = *P;
     b->max_reads = max_reads;
     b->max_bases = max_bases;
     if( b->ctr.reserve( CTR_COUNT * 8 ) || b->reads.reserve( max_bases + 64 ) || b->roff.reserve( ( max_reads + 1 ) * 8 ) )
-    {
-        delete b;
         return 1;
-    }
-    *out = b;
+    *out = b.release( );
     return 0;
 }
 
@@ -949,17 +953,7 @@ int ma_batch_destroy( ma_batch* b )
 {
     if( !b )
         return 0;
-    DevBuf* all[] = { &b->reads,   &b->roff,    &b->ctr,      &b->stage,   &b->smemA,  &b->smemB,      &b->segPool,
-                      &b->segRead, &b->segOff,  &b->segCnt,   &b->segSeedCnt, &b->segSeedOff, &b->seedOff, &b->seedCnt,
-                      &b->seeds,   &b->cubTmp,  &b->cWork,    &b->cMax,    &b->cMm,    &b->cA,         &b->cB,
-                      &b->cOut,    &b->cSh1,    &b->cSh2,     &b->cVx,     &b->cVy,    &b->cMed,       &b->cInl,
-                      &b->cBest,   &b->hpool,   &b->setTab,   &b->nsets,   &b->hsetOff, &b->hsetFlat,  &b->hsetRead,
-                      &b->jobs,    &b->info,    &b->ez,       &b->cigOff,  &b->cigPool, &b->kswScratch, &b->opsCap,
-                      &b->opsOff,  &b->ops,     &b->hdr,      &b->order,   &b->mqOrder, &b->mqCnt,     &b->clsLists,
-                      &b->seedStack, &b->seedRow, &b->seedSteps, &b->seedSeg, &b->hlocal, &b->hdense,  &b->hseedCnt,
-                      &b->hseedOff };
-    for( DevBuf* d : all )
-        d->release( );
+    MA_BIND_DEVICE( b->device );
     if( b->evInit )
         for( int i = 0; i < 16; i++ )
             (void)hipEventDestroy( b->ev[ i ] );
@@ -979,6 +973,7 @@ int ma_batch_enable_timing( ma_batch* b, int on )
 {
     if( !b )
         return fail( "null batch" );
+    MA_BIND_DEVICE( b->device );
     if( on && !b->evInit )
     {
         for( int i = 0; i < 16; i++ )
@@ -993,6 +988,7 @@ int ma_batch_set_reads( ma_batch* b, const uint8_t* codes, const uint64_t* offse
 {
     if( !b || !offsets || ( n && !codes ) )
         return fail( "ma_batch_set_reads: null argument" );
+    MA_BIND_DEVICE( b->device );
     if( n > b->max_reads || offsets[ n ] > b->max_bases )
         return fail( "ma_batch_set_reads: batch capacity exceeded" );
     b->n_reads = n;
@@ -1023,6 +1019,7 @@ int ma_batch_set_reads_device( ma_batch* b, const void* d_codes, const void* d_o
 {
     if( !b || !d_offsets || ( n && !d_codes ) )
         return fail( "ma_batch_set_reads_device: null argument" );
+    MA_BIND_DEVICE( b->device );
     b->n_reads = n;
     b->n_bases = n_bases;
     b->d_reads = (const uint8_t*)d_codes;
@@ -1056,6 +1053,7 @@ int ma_seed_batch( ma_batch* b )
 {
     if( !b || !b->d_roff )
         return fail( "ma_seed_batch: no reads set" );
+    MA_BIND_DEVICE( b->device );
     const u64 n = b->n_reads;
     MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
     b->nSegs = b->nSeeds = b->nHsets = b->nHseeds = 0;
@@ -1070,6 +1068,12 @@ int ma_seed_batch( ma_batch* b )
     b->segPoolCap = std::max<u64>( b->n_bases / 2 + 64 * n, 1024 );
     if( smem )
         b->segPoolCap *= 2;
+    // the pool size above is a heuristic (a read can emit up to 2x / 6x its length in segments): a batch that needs more
+    // is seeded again with the counted need (segPoolMin, kept for the later batches of this object)
+    b->segPoolCap = std::max( b->segPoolCap, b->segPoolMin );
+    if( const char* e = getenv( "MA_SEG_POOL_CAP" ) ) // test hook: force a (too) small pool on the first attempt
+        if( b->segPoolMin == 0 )
+            b->segPoolCap = (u64)std::max( 1, atoi( e ) );
     // Resident lanes: up to 8 waves per SIMD on 256 CUs, bounded by the reads and by a staging budget of a third of
     // the free HBM.  A lane walks its read serially, so lanes in flight are what hides the gather latency; for long
     // reads the worst-case staging (0.8 MB per 10 kb read) would leave too few of them, so the first attempt stages
@@ -1085,7 +1089,7 @@ int ma_seed_batch( ma_batch* b )
         seg_cap = std::min<u32>( worst_cap, ( smem ? 3 : 1 ) * ( b->max_qlen / 4 ) + 64 );
     if( const char* e = getenv( "MA_SEED_STAGE_CAP" ) ) // test hook: force a (too) small first attempt
         seg_cap = std::min<u32>( worst_cap, (u32)std::max( 1, atoi( e ) ) );
-    for( int attempt = 0; attempt < 2; attempt++ )
+    for( int attempt = 0; attempt < 3; attempt++ )
     {
         const u64 lane_bytes = (u64)seg_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment );
         const u64 lanes = std::min<u64>( want, std::max<u64>( 256, ( budget / lane_bytes ) / 256 * 256 ) );
@@ -1125,15 +1129,25 @@ int ma_seed_batch( ma_batch* b )
             hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
         }
         MA_HIP( hipGetLastError( ) );
-        if( seg_cap == worst_cap )
-            break;
-        // reduced staging: did every read fit?
+        // did every read fit its staging area, and all segments the pool?
         if( read_ctr( b ) )
             return 1;
         if( !( (u32)b->hctr[ CTR_ERR ] & MA_ERR_SEG_OVERFLOW ) )
             break;
+        bool retry = false;
+        if( b->hctr[ CTR_SEG_USED ] > b->segPoolCap ) // the pool pointer counts every segment, stored or not
+        {
+            b->segPoolMin = b->segPoolCap = b->hctr[ CTR_SEG_USED ] + 1024;
+            retry = true;
+        }
+        if( seg_cap < worst_cap )
+        {
+            seg_cap = worst_cap;
+            retry = true;
+        }
+        if( !retry || attempt == 2 )
+            break; // surfaces as an error in the next stage
         MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
-        seg_cap = worst_cap;
     }
     b->stage_done = 1;
     return 0;
@@ -1143,6 +1157,7 @@ int ma_extract_seeds_batch( ma_batch* b )
 {
     if( !b || b->stage_done < 1 )
         return fail( "ma_extract_seeds_batch: run ma_seed_batch first" );
+    MA_BIND_DEVICE( b->device );
     const u64 n = b->n_reads;
     if( n == 0 )
     {
@@ -1227,6 +1242,7 @@ int ma_chain_batch( ma_batch* b )
 {
     if( !b || b->stage_done < 2 )
         return fail( "ma_chain_batch: run ma_extract_seeds_batch first" );
+    MA_BIND_DEVICE( b->device );
     const u64 n = b->n_reads;
     if( n == 0 )
     {
@@ -1359,6 +1375,7 @@ int ma_dp_batch( ma_batch* b )
 {
     if( !b || b->stage_done < 3 )
         return fail( "ma_dp_batch: run ma_chain_batch first" );
+    MA_BIND_DEVICE( b->device );
     const u64 n = b->n_reads, nh = b->nHsets, nhs = b->nHseeds;
     if( b->mqCnt.reserve( ( n + 1 ) * 4 ) )
         return 1;
@@ -1415,28 +1432,49 @@ int ma_dp_batch( ma_batch* b )
             S.cls[ k ] = b->hctr[ CTR_CLS0 + k ];
         // every wave of the ksw launches may leave one partly used 4096-word reservation per class launch
         b->cigPoolCap = std::max<u64>( 64 * nJobs + ( 1 << 20 ), b->n_bases / 2 ) + 4096ull * 256 * 32 * 4;
-        if( b->cigPool.reserve( b->cigPoolCap * 4 ) )
-            return 1;
+        b->cigPoolCap = std::max( b->cigPoolCap, b->cigPoolMin );
+        if( const char* e = getenv( "MA_CIG_POOL_CAP" ) ) // test hook: force a (too) small pool on the first attempt
+            if( b->cigPoolMin == 0 )
+                b->cigPoolCap = (u64)std::max( 1, atoi( e ) );
         KswScoring SC{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
         unsigned long long* c = b->ctr.as<unsigned long long>( );
-        KswOut O;
-        O.ez = b->ez.as<ma_ez>( );
-        O.cig_off = b->cigOff.as<u64>( );
-        O.cig_pool = b->cigPool.as<u32>( );
-        O.cig_pool_cap = b->cigPoolCap;
-        O.cig_used = c + CTR_CIG_USED;
-        O.cells = c + CTR_CELLS;
-        O.njobs = c + CTR_KSW_JOBS;
-        O.err = (u32*)( c + CTR_ERR );
-        O.path = c + CTR_PATH_BYTES;
-        O.cig_chunk = 4096;
-        O.cig_words = c + CTR_CIG_WORDS;
         PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
-        EvTimer t( b, 4 );
-        if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
-                         b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ) ) )
+        // the pool size is a heuristic as well: if the cigars did not fit, the DP stage is run again with the counted need
+        for( int attempt = 0; attempt < 2; attempt++ )
+        {
+            if( b->cigPool.reserve( b->cigPoolCap * 4 ) )
+                return 1;
+            KswOut O;
+            O.ez = b->ez.as<ma_ez>( );
+            O.cig_off = b->cigOff.as<u64>( );
+            O.cig_pool = b->cigPool.as<u32>( );
+            O.cig_pool_cap = b->cigPoolCap;
+            O.cig_used = c + CTR_CIG_USED;
+            O.cells = c + CTR_CELLS;
+            O.njobs = c + CTR_KSW_JOBS;
+            O.err = (u32*)( c + CTR_ERR );
+            O.path = c + CTR_PATH_BYTES;
+            O.cig_chunk = 4096;
+            O.cig_words = c + CTR_CIG_WORDS;
+            {
+                EvTimer t( b, 4 );
+                if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
+                                 b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ) ) )
+                    return 1;
+                MA_HIP( hipGetLastError( ) );
+            }
+            if( read_ctr( b ) )
+                return 1;
+            if( !( (u32)b->hctr[ CTR_ERR ] & MA_ERR_CIGAR_OVERFLOW ) || attempt == 1 )
+                break;
+            b->cigPoolMin = b->cigPoolCap = b->hctr[ CTR_CIG_USED ] + 4096ull * 256 * 32 * 4;
+            MA_HIP( hipMemsetAsync( c + CTR_ERR, 0, ( CTR_KSW_JOBS - CTR_ERR + 1 ) * 8, b->stream ) ); // ERR, CIG_USED, CELLS, KSW_JOBS
+            MA_HIP( hipMemsetAsync( c + CTR_PATH_BYTES, 0, 8, b->stream ) );
+            MA_HIP( hipMemsetAsync( c + CTR_NEXT_SLOTS, 0, ( CTR_NEXT_SEED - CTR_NEXT_SLOTS ) * 8, b->stream ) ); // queues, N_REDO, CIG_WORDS
+            MA_HIP( hipMemsetAsync( b->ez.p, 0, ( nSlots + 2 ) * sizeof( ma_ez ), b->stream ) );
+        }
+        if( check_err( b, "ma_dp_batch(ksw)" ) )
             return 1;
-        MA_HIP( hipGetLastError( ) );
     }
     {
         EvTimer t( b, 5 );
@@ -1492,6 +1530,7 @@ int ma_batch_sync( ma_batch* b )
 {
     if( !b )
         return fail( "ma_batch_sync: null batch" );
+    MA_BIND_DEVICE( b->device );
     if( read_ctr( b ) )
         return 1;
     if( b->timing && b->evInit )
@@ -1557,6 +1596,7 @@ int ma_batch_get_segments( ma_batch* b, uint64_t* seg_off, ma_segment* segs )
 {
     if( !b || b->stage_done < 1 )
         return fail( "ma_batch_get_segments: stage not run" );
+    MA_BIND_DEVICE( b->device );
     if( ma_batch_sync( b ) )
         return 1;
     const u64 n = b->n_reads, ns = b->hctr[ CTR_SEG_USED ];
@@ -1589,6 +1629,7 @@ int ma_batch_get_seeds( ma_batch* b, uint64_t* seed_off, ma_seed* seeds )
 {
     if( !b || b->stage_done < 2 )
         return fail( "ma_batch_get_seeds: stage not run" );
+    MA_BIND_DEVICE( b->device );
     if( ma_batch_sync( b ) )
         return 1;
     const u64 n = b->n_reads;
@@ -1621,6 +1662,7 @@ int ma_batch_get_hsets( ma_batch* b, uint64_t* hset_off, uint64_t* hseed_off, ui
 {
     if( !b || b->stage_done < 3 )
         return fail( "ma_batch_get_hsets: stage not run" );
+    MA_BIND_DEVICE( b->device );
     if( ma_batch_sync( b ) )
         return 1;
     const u64 n = b->n_reads, nh = b->nHsets;
@@ -1655,6 +1697,7 @@ static int get_alns( ma_batch* b, bool mq, uint64_t* aln_off, ma_alignment* alns
 {
     if( !b || b->stage_done < 4 )
         return fail( "ma_batch_get_alignments: stage not run" );
+    MA_BIND_DEVICE( b->device );
     if( ma_batch_sync( b ) )
         return 1;
     const u64 n = b->n_reads, nh = b->nHsets;
@@ -1725,6 +1768,7 @@ int ma_batch_get_dp_jobs( ma_batch* b, uint64_t* n_jobs, int32_t* shapes /* 8 x 
 {
     if( !b || b->stage_done < 4 )
         return fail( "ma_batch_get_dp_jobs: stage not run" );
+    MA_BIND_DEVICE( b->device );
     if( ma_batch_sync( b ) )
         return 1;
     const u64 nSlots = b->nJobSlots;

@@ -33,6 +33,7 @@ extern "C" int ma_extend_backward_batch( const ma_index* x, const int64_t* ik, c
 {
     if( !x )
         return fail( "ma_extend_backward_batch: null index" );
+    MA_BIND_DEVICE( x->device );
     if( n == 0 )
         return 0;
     DevBuf dik, dc, dok;
@@ -44,9 +45,6 @@ extern "C" int ma_extend_backward_batch( const ma_index* x, const int64_t* ik, c
                         dc.as<uint8_t>( ), n, dok.as<i64>( ) );
     MA_HIP( hipGetLastError( ) );
     MA_HIP( hipMemcpy( ok, dok.p, n * 24, hipMemcpyDeviceToHost ) );
-    dik.release( );
-    dc.release( );
-    dok.release( );
     return 0;
 }
 
@@ -54,6 +52,7 @@ extern "C" int ma_bwt_sa_batch( const ma_index* x, const int64_t* rows, uint64_t
 {
     if( !x )
         return fail( "ma_bwt_sa_batch: null index" );
+    MA_BIND_DEVICE( x->device );
     if( n == 0 )
         return 0;
     DevBuf dr, dp;
@@ -64,8 +63,6 @@ extern "C" int ma_bwt_sa_batch( const ma_index* x, const int64_t* rows, uint64_t
                         dp.as<i64>( ) );
     MA_HIP( hipGetLastError( ) );
     MA_HIP( hipMemcpy( pos, dp.p, n * 8, hipMemcpyDeviceToHost ) );
-    dr.release( );
-    dp.release( );
     return 0;
 }
 
@@ -198,15 +195,6 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
         if( cigar && h[ 0 ] )
             MA_HIP( hipMemcpy( cigar, dpool.p, h[ 0 ] * 4, hipMemcpyDeviceToHost ) );
     }
-    dlists.release( );
-    dj.release( );
-    dq.release( );
-    dt.release( );
-    dez.release( );
-    doff.release( );
-    dpool.release( );
-    dscr.release( );
-    dctr.release( );
     return rc;
 }
 
@@ -222,4 +210,32 @@ extern "C" int ma_ksw_ext_batch( const ma_params* P, const ma_ksw_job* jobs, uin
                                  uint32_t* cigar, uint64_t cigar_cap )
 {
     return ksw_batch_impl<ByteFetchPipe>( P, jobs, n, q_bytes, q_len, t_bytes, t_len, ez, cigar_off, cigar, cigar_cap );
+}
+
+// ---- diagnostics: the device libm values the chaining stage decides with (chain.h: tan, sin, atan, log), evaluated
+// exactly like there (same translation-unit flags, -ffp-contract=off), so a test can compare their bits with glibc's
+// (harmonization.h:82-89 and ransac.cpp:112,131-135 run on glibc in the reference)
+__global__ void k_libm_probe( int op, const double* in, u64 n, double* out )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    const double x = in[ i ];
+    out[ i ] = op == 0 ? tan( x ) : op == 1 ? sin( x ) : op == 2 ? atan( x ) : log( x );
+}
+extern "C" int ma_debug_libm( int op, const double* in, uint64_t n, double* out )
+{
+    if( !in || !out || op < 0 || op > 3 )
+        return fail( "ma_debug_libm: bad argument" );
+    if( n == 0 )
+        return 0;
+    DevBuf di, dout;
+    if( di.reserve( n * 8 ) || dout.reserve( n * 8 ) )
+        return 1;
+    MA_HIP( hipMemcpy( di.p, in, n * 8, hipMemcpyHostToDevice ) );
+    hipLaunchKernelGGL( k_libm_probe, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, 0, op, di.as<double>( ), n,
+                        dout.as<double>( ) );
+    MA_HIP( hipGetLastError( ) );
+    MA_HIP( hipMemcpy( out, dout.p, n * 8, hipMemcpyDeviceToHost ) );
+    return 0;
 }

@@ -142,6 +142,7 @@ extern "C" int ma_synth_reads_device( const ma_index* x, uint64_t seed, uint64_t
 {
     if( !x || !d_codes || !d_offsets )
         return fail( "ma_synth_reads_device: null argument" );
+    MA_BIND_DEVICE( x->device );
     ReadGen G;
     G.X = x->v;
     G.seed = seed;

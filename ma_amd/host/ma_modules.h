@@ -237,7 +237,24 @@ inline void loadIndex( const std::string& sPrefix, std::shared_ptr<Pack>& pPack,
     memcpy( &seqLen, sa.data( ) + 44, 8 );
     if( seqLen != L2[ 4 ] )
         throw std::runtime_error( "SA-BWT inconsistency: suffix array has non matching sequence length stored." );
+    // the files are not trusted: the sampling interval is read (the device code assumes 32, the value every index the
+    // reference writes has, fMIndex.h:391), every array length is checked against the sequence length before a byte is
+    // copied or uploaded (vRestoreBWT / vRestoreSuffixArray, fMIndex.h:555-663, fail the same way on short files)
+    int32_t iSaIntv = 0;
+    memcpy( &iSaIntv, sa.data( ) + 40, 4 );
+    if( iSaIntv != 32 )
+        throw std::runtime_error( "Suffix array sampling interval " + std::to_string( iSaIntv ) +
+                                  " is not supported (the MI355X index expects 32)." );
     const uint64_t nWords = ( bwt.size( ) - 40 ) / 4, nSa = ( seqLen + 32 ) / 32;
+    // occ-injected BWT: ceil(n / 16) symbol words + 8 counter words per 128-nt block incl. the final one (fMIndex.cpp:204-264)
+    if( ( bwt.size( ) - 40 ) % 4 != 0 || nWords != ( seqLen + 15 ) / 16 + ( ( seqLen + 127 ) / 128 + 1 ) * 8 )
+        throw std::runtime_error( "Unexpected fail after reading BWT from stream. " );
+    if( sa.size( ) < 52 + ( nSa - 1 ) * 8 )
+        throw std::runtime_error( "Unexpected bad after reading suffix array from stream. " );
+    if( sa.size( ) != 52 + ( nSa - 1 ) * 8 )
+        throw std::runtime_error( "Reading suffix array from file system failed due to non matching expected size." );
+    if( seqLen % 2 != 0 || pac.size( ) < ( seqLen / 2 + 3 ) / 4 + 1 )
+        throw std::runtime_error( "Pack and FM index do not match: unexpected size of " + sPrefix + ".pac" );
     std::vector<int64_t> vSa( nSa );
     vSa[ 0 ] = -1;
     memcpy( &vSa[ 1 ], sa.data( ) + 52, ( nSa - 1 ) * 8 );

@@ -1,6 +1,7 @@
 // SURVEY 8(f) f1, file side: builds the index of a case on the GPU, writes it with storeIndex as the reference's
 // .bwt/.sa/.pac/.ann/.amb files, loads those files again with loadIndex and checks the round trip.
 // usage: index_store_test <case> <prefix> [genome title -> <folder>/<title>.json]
+//        index_store_test loadcheck <prefix>   (prints "ok" or "error: <what loadIndex threw>")
 #include "../../ma_amd/host/ma_sam.h"
 #include "../../oracle/dump_format.h"
 #include <cstdio>
@@ -12,6 +13,21 @@ int main( int argc, char** argv )
 {
     if( argc < 3 )
         return 2;
+    if( !strcmp( argv[ 1 ], "loadcheck" ) ) // index_store_test loadcheck <prefix>: loadIndex's validation of the files
+    {
+        try
+        {
+            std::shared_ptr<Pack> pPack;
+            std::shared_ptr<FMIndex> pFM;
+            loadIndex( argv[ 2 ], pPack, pFM );
+            printf( "ok\n" );
+        }
+        catch( const std::runtime_error& e )
+        {
+            printf( "error: %s\n", e.what( ) );
+        }
+        return 0;
+    }
     if( argc >= 5 && !strcmp( argv[ 4 ], "fasta" ) ) // index_store_test <genome.fa> <prefix> <title> fasta
     {
         try

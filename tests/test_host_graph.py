@@ -59,18 +59,55 @@ def test_graph_of_dropin_modules_matches_reference(tmp_path, gpu_device, preset,
     assert open(out + ".sam").read() == sam_want
 
 
+def build_index_store_exe():
+    exe = os.path.join(ROOT, "tests", "emul", "index_store_test")
+    src = exe + ".cpp"
+    deps = [src] + [os.path.join(ROOT, "ma_amd", "host", h) for h in ("ma_modules.h", "ms_graph.h", "ma_sam.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                               "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", exe, "-L" + os.path.join(ROOT, "ma_amd"),
+                               "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"), "-lpthread"])
+    return exe
+
+
+def test_load_index_rejects_truncated_or_foreign_files(tmp_path):
+    """loadIndex does not trust the files: a truncated .sa / .bwt / .pac or a suffix array written with
+    another sampling interval is refused with the reference's messages before anything is copied or uploaded
+    (vRestoreBWT / vRestoreSuffixArray, fMIndex.h:555-663).  No GPU needed: validation comes first."""
+    exe = build_index_store_exe()
+    good = {ext: gzip.open(os.path.join(G, "small_ref." + ext + ".gz"), "rb").read() for ext in ("bwt", "sa", "pac")}
+    ann = "61000 3 0\n0 chr1 none\n0 30000 0\n0 chr2 none\n30000 22000 0\n0 chr3 none\n52000 9000 0\n"
+
+    def check(files):
+        prefix = str(tmp_path / "idx")
+        for ext in ("bwt", "sa", "pac"):
+            with open(prefix + "." + ext, "wb") as f:
+                f.write(files[ext])
+        with open(prefix + ".ann", "w") as f:
+            f.write(ann)
+        return subprocess.check_output([exe, "loadcheck", prefix]).decode().strip()
+
+    assert "Unexpected bad after reading suffix array" in check(dict(good, sa=good["sa"][:-8]))
+    assert "non matching expected size" in check(dict(good, sa=good["sa"] + b"\0" * 8))
+    other = bytearray(good["sa"])
+    other[40:44] = (64).to_bytes(4, "little")
+    assert "sampling interval 64" in check(dict(good, sa=bytes(other)))
+    assert "Unexpected fail after reading BWT" in check(dict(good, bwt=good["bwt"][:-64]))
+    assert "unexpected size" in check(dict(good, pac=good["pac"][:100]))
+    bad_primary = bytearray(good["sa"])
+    bad_primary[0] ^= 1
+    assert "different primary" in check(dict(good, sa=bytes(bad_primary)))
+    # the untouched files pass validation and only then need a device
+    res = check(good)
+    assert res == "ok" or "hip" in res.lower() or "device" in res.lower(), res
+
+
 @pytest.mark.gpu
 def test_gpu_built_index_is_stored_in_the_reference_file_formats(tmp_path, gpu_device):
     """f1, file side: storeIndex writes .bwt/.sa/.pac byte-identical to the reference's files for the same genome
     (tests/golden/small_ref.*), .ann/.amb in its text format, and the reference's own loaders accept them
     (oracle/_ref/ref_dump pipeidx, when that build is present: same pipeline dump as with its own index)."""
-    exe = os.path.join(ROOT, "tests", "emul", "index_store_test")
-    src = exe + ".cpp"
-    deps = [src] + [os.path.join(ROOT, "ma_amd", "host", h) for h in ("ma_modules.h", "ms_graph.h")]
-    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
-                               "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", exe, "-L" + os.path.join(ROOT, "ma_amd"),
-                               "-lma_amd", "-Wl,-rpath," + os.path.join(ROOT, "ma_amd"), "-lpthread"])
+    exe = build_index_store_exe()
     case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
     prefix = str(tmp_path / "idx")
     subprocess.check_call([exe, case, prefix, "small genome"])
