@@ -1,21 +1,35 @@
 #!/usr/bin/env python3
-"""bench.py -- aligned reads/s of the MI355X seed-and-extend path on BASELINE.json's workload.
+"""bench.py -- aligned reads/s of the MI355X seed-and-extend path on BASELINE.json's workloads.
 
 A "step" is one pass of the whole hot path (FMD seeding -> seed extraction -> SoC/harmonization ->
 banded-DP gap fill/extension -> mapping quality) over one batch of synthetic reads that is already
-resident in HBM.  Default workload = BASELINE.json configs[1]: 150 bp Illumina-like reads (0.5 %
-substitutions) against a GRCh38-sized synthetic genome (24 contigs, 3.09 Gnt, planted repeat
-families), Default preset, 10 steps x 1 M reads = 10 M reads on one MI355X.
+resident in HBM.  The metric is quoted on "150bp & 10kb" reads, so the default invocation runs, against ONE
+GRCh38-sized synthetic genome (24 contigs, 3.09 Gnt, planted repeat families) and in one process per GPU:
+
+  C2  150 bp Illumina-like reads (0.5 % substitutions), 1 M reads per step            -> `value` (headline, history)
+  C3  10 kb CCS-like reads (0.4 / 0.3 / 0.3 % sub / ins / del), 200 k reads per step
+  C5  50 kb ONT-like reads (3 / 3 / 4 %), 20 k reads per step (stress shape)
+
+each with its own timed region (barrier + synchronize on both sides, MAX over ranks), roofline block, CPU baseline (the
+compiled reference on the host cores, N = 1 only) and a parity check of the GPU results against the oracle.  The line's
+top-level value / ms_per_step / roofline / cpu_baseline are those of C2; config.workloads[] carries all three.
+--workload {150bp,10kb,50kb} or an explicit --read-len runs a single workload.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used only for the barrier and the
-max-over-ranks time); reads are partitioned by index, the index is replicated, there is no data-path
-collective.  Prints ONE JSON line on rank 0.
+max-over-ranks time); the index is replicated, there is no data-path collective.  --scaling weak (default): every rank
+aligns its own steps x reads_per_step reads; --scaling strong: ONE read set of steps x reads_per_step reads is
+partitioned into contiguous blocks over the ranks.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
+import threading
 import time
 
 import numpy as np
@@ -27,90 +41,127 @@ GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1593
           133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616,
           64444167, 46709983, 50818468, 156040895, 57227415]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-GATHER_CEILING_GBLOCKS = 51.8  # measured on MI355X by tools/gups.hip: random 64-B blocks/s, all CUs (profiles/r01_gups.txt)
+STAGES = ["k_seed", "k_seed_rows+k_lf_walk+k_seed_final", "k_chain", "k_dp_enum", "k_ksw", "k_stitch+k_finish"]
+
+WORKLOADS = {
+    # name: read_len, sub, ins, dele, reads seed, reads/step, default steps, warm-up, CPU sample (reads)
+    "150bp": dict(read_len=150, sub=0.005, ins=0.0, dele=0.0, seed=11, reads_per_step=1000000, steps=None, warmup=None,
+                  cpu_sample=None, baseline_config="configs[1] (C2)"),
+    "10kb": dict(read_len=10000, sub=0.004, ins=0.003, dele=0.003, seed=12, reads_per_step=200000, steps=3, warmup=1,
+                 cpu_sample=15360, baseline_config="configs[2] (C3)"),
+    "50kb": dict(read_len=50000, sub=0.03, ins=0.03, dele=0.04, seed=13, reads_per_step=20000, steps=2, warmup=1,
+                 cpu_sample=2048, baseline_config="configs[4] (C5 shape, one GPU)"),
+}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads-per-step", type=int, default=0, help="default: 1 M reads (<= 1 kb), else 2 Gbase worth of reads")
-    ap.add_argument("--read-len", type=int, default=150)
-    ap.add_argument("--sub", type=float, default=0.005)
-    ap.add_argument("--ins", type=float, default=0.0)
-    ap.add_argument("--dele", type=float, default=0.0)
-    ap.add_argument("--genome-scale", type=float, default=1.0, help="fraction of GRCh38 contig lengths (tests only)")
-    ap.add_argument("--preset", default="default")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 auto, 0 off)")
-    ap.add_argument("--no-repeats", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="batches in flight per GPU (own stream + host thread each): while one batch is in its "
-                         "VALU-bound DP kernels another runs its memory-bound seeding / chaining")
-    args = ap.parse_args()
+def load_calibration():
+    """profiles/r02_calibration.json: the measured ceilings the roofline fractions are quoted against (tools/calibrate.sh)."""
+    cal = {"gather_ceiling_gblocks": 50.59, "valu_mix_peak_ginst": 576.9, "source": "built-in (profiles/r02_calibration.json missing)"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_calibration.json")) as f:
+            cal.update(json.load(f))
+    except (OSError, ValueError):
+        pass
+    return cal
 
-    import torch
-    import ma_amd
-    from ma_amd.shard import weak_shard_first_index, reduce_timing_and_counts
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    # test hook: MA_BENCH_ONE_DEVICE=1 runs all ranks on GPU 0 over gloo, so that the multi-rank code path (barriers,
-    # MAX/SUM reductions, rank-0 reporting) can be exercised on a one-GPU box; the driver's runs use RCCL, one GPU per rank
-    one_dev = os.environ.get("MA_BENCH_ONE_DEVICE") == "1"
-    gpu = 0 if one_dev else local_rank
-    if world > 1:
-        import torch.distributed as dist
-        if one_dev:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", gpu))
-    torch.cuda.set_device(gpu)
-    ma_amd.set_device(gpu)
-    dev = torch.device("cuda", gpu)
-    local_rank = gpu
-    L = ma_amd.lib()
+class Env:
+    """Process-wide state: device, library, distributed group, genome index."""
 
-    def chk(rc):
+    def __init__(self, args):
+        import torch
+        import ma_amd
+        self.torch, self.ma = torch, ma_amd
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        # test hook: MA_BENCH_ONE_DEVICE=1 runs all ranks on GPU 0 over gloo, so that the multi-rank code path (barriers,
+        # MAX/SUM reductions, rank-0 reporting) can be exercised on a one-GPU box; the driver's runs use RCCL, one GPU per rank
+        self.one_dev = os.environ.get("MA_BENCH_ONE_DEVICE") == "1"
+        self.gpu = 0 if self.one_dev else local_rank
+        if self.world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+            if self.one_dev:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.gpu))
+        torch.cuda.set_device(self.gpu)
+        ma_amd.set_device(self.gpu)
+        self.dev = torch.device("cuda", self.gpu)
+        self.L = ma_amd.lib()
+        self.cal = load_calibration()
+        # ---- synthetic genome + index (not timed: one-off preprocessing, SURVEY 8(f1)) -----------------
+        self.lens = np.array([max(1000, int(x * args.genome_scale)) for x in GRCH38], dtype=np.uint64)
+        self.F = int(self.lens.sum())
+        t0 = time.perf_counter()
+        g = torch.empty(self.F, dtype=torch.uint8, device=self.dev)
+        self.chk(self.L.ma_synth_genome_device(C.c_uint64(2), C.c_uint64(self.F), C.c_int32(0 if args.no_repeats else 1),
+                                               C.c_void_p(g.data_ptr())))
+        self.idx = ma_amd.Index.build_device(self.lens, g.data_ptr())
+        del g
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        self.t_index = time.perf_counter() - t0
+        self.ref_dir = None  # index files for the compiled reference, written once
+
+    def chk(self, rc):
         if rc != 0:
-            raise RuntimeError(L.ma_last_error().decode())
+            raise RuntimeError(self.L.ma_last_error().decode())
 
-    # ---- synthetic genome + index (not timed: one-off preprocessing) -----------------
-    lens = np.array([max(1000, int(x * args.genome_scale)) for x in GRCH38], dtype=np.uint64)
-    F = int(lens.sum())
-    t0 = time.perf_counter()
-    g = torch.empty(F, dtype=torch.uint8, device=dev)
-    chk(L.ma_synth_genome_device(C.c_uint64(2), C.c_uint64(F), C.c_int32(0 if args.no_repeats else 1),
-                                 C.c_void_p(g.data_ptr())))
-    idx = ma_amd.Index.build_device(lens, g.data_ptr())
-    del g
-    torch.cuda.empty_cache()
-    torch.cuda.synchronize()
-    t_index = time.perf_counter() - t0
+    def reference_index(self):
+        """The GPU-built index in the reference's file formats (read by its own loaders), written once per run."""
+        if self.ref_dir is None:
+            self.ref_dir = tempfile.mkdtemp(prefix="ma_ref_")
+            self.idx.store(os.path.join(self.ref_dir, "idx"))
+        return os.path.join(self.ref_dir, "idx")
 
-    # ---- reads: every rank owns steps x reads_per_step reads (weak scaling), resident in HBM ---------
-    B = args.reads_per_step if args.reads_per_step > 0 else (1000000 if args.read_len <= 1000 else max(10000, int(2e9 / args.read_len)))
-    K, W = args.steps, args.warmup
+    def close(self):
+        if self.ref_dir:
+            shutil.rmtree(self.ref_dir, ignore_errors=True)
+
+
+def run_workload(E, name, wl, args):
+    """Times K steps of one workload; returns its result block (rank 0) incl. roofline, cpu_baseline, parity_check."""
+    from ma_amd.shard import reduce_timing_and_counts, shard_range, weak_shard_first_index
+    torch, ma_amd, L, dev, dist = E.torch, E.ma, E.L, E.dev, E.dist
+    rank, world = E.rank, E.world
+    read_len, preset = wl["read_len"], args.preset
+    K, W = wl["steps"], wl["warmup"]
+    B_total = wl["reads_per_step"]  # reads per step and GPU (weak) / per step over all GPUs (strong)
+    if args.scaling == "strong":
+        lo, hi = shard_range(B_total, world, rank)
+        B = hi - lo  # this rank's share of every step
+        first = lambda k: k * B_total + lo  # noqa: E731  global index of this rank's first read of step k
+        n_global = B_total * K
+    else:
+        B = B_total
+        first = lambda k: weak_shard_first_index(B_total * K, rank) + k * B  # noqa: E731
+        n_global = B_total * K * world
     n_reads = B * K
-    cap = int(n_reads * (args.read_len * (1.0 + 2 * args.ins) + 8)) + 1024
+    cap = int(n_reads * (read_len * (1.0 + 2 * wl["ins"]) + 8)) + 1024
     codes = torch.empty(cap, dtype=torch.uint8, device=dev)
-    offs = torch.empty(n_reads + 1, dtype=torch.int64, device=dev)
-    nb = C.c_uint64()
-    seed = 11 if args.read_len <= 1000 else (12 if args.read_len <= 20000 else 13)
-    chk(L.ma_synth_reads_device(idx.h, C.c_uint64(seed), C.c_uint64(n_reads), C.c_uint32(args.read_len),
-                                C.c_double(args.sub), C.c_double(args.ins), C.c_double(args.dele),
-                                C.c_uint64(weak_shard_first_index(n_reads, rank)), C.c_void_p(codes.data_ptr()), C.c_void_p(offs.data_ptr()),
-                                C.c_uint64(cap), C.byref(nb)))
-    offs_h = offs.cpu().numpy().astype(np.uint64)
-
-    P = ma_amd.Params.preset(args.preset)
-    max_bases = int((offs_h[B::B] - offs_h[:-1:B]).max()) if K > 0 else 0
+    # reads of step k are the contiguous global indices first(k) .. first(k) + B; every step has its own CSR (B + 1
+    # offsets starting at 0, relative to the step's first base) so that a batch takes (codes + base, offsets) as they are
+    offs = torch.empty(K * (B + 1) + 1, dtype=torch.int64, device=dev)
+    nb_total = 0
+    offs_h = np.zeros(n_reads + 1, dtype=np.uint64)
+    for k in range(K):
+        nb = C.c_uint64()
+        E.chk(L.ma_synth_reads_device(E.idx.h, C.c_uint64(wl["seed"]), C.c_uint64(B), C.c_uint32(read_len),
+                                      C.c_double(wl["sub"]), C.c_double(wl["ins"]), C.c_double(wl["dele"]),
+                                      C.c_uint64(first(k)), C.c_void_p(codes.data_ptr() + nb_total),
+                                      C.c_void_p(offs.data_ptr() + 8 * k * (B + 1)), C.c_uint64(cap - nb_total), C.byref(nb)))
+        o = offs[k * (B + 1):k * (B + 1) + B + 1].cpu().numpy().astype(np.uint64)
+        offs_h[k * B:k * B + B + 1] = o + np.uint64(nb_total)
+        nb_total += int(nb.value)
+    P = ma_amd.Params.preset(preset)
+    max_bases = int((offs_h[B::B] - offs_h[:-1:B]).max()) if K > 0 and B > 0 else 0
     NB = max(1, min(args.inflight, K))
     batches = []
     for i in range(NB):
-        bt = ma_amd.Batch(idx, P, B, max_bases + 64)
+        bt = ma_amd.Batch(E.idx, P, max(B, 1), max_bases + 64)
         st = torch.cuda.current_stream() if NB == 1 else torch.cuda.Stream()
         bt.set_stream(st.cuda_stream)
         bt.enable_timing(True)
@@ -118,23 +169,21 @@ def main():
 
     def step(i, k):
         bt = batches[i][0]
-        lo = k * B
-        nbases = int(offs_h[lo + B] - offs_h[lo])
-        bt.set_reads_device(codes.data_ptr(), offs.data_ptr() + 8 * lo, B, nbases)
+        lo_r = k * B
+        nbases = int(offs_h[lo_r + B] - offs_h[lo_r])
+        bt.set_reads_device(codes.data_ptr() + int(offs_h[lo_r]), offs.data_ptr() + 8 * k * (B + 1), B, nbases)
         bt.align()
         bt.sync()
 
-    # warm-up: W steps on every batch object (each sizes its own buffers); untimed
-    for w in range(W):
+    for w in range(W):  # warm-up: W steps on every batch object (each sizes its own buffers); untimed
         for i in range(NB):
             step(i, (w + i) % K)
 
-    import threading
     acc = [dict(kms=np.zeros(8), ctr=np.zeros(8), segs=0, aligned=0, err=None) for _ in range(NB)]
 
     def worker(i):
         try:
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(E.gpu)
             a = acc[i]
             for k in range(i, K, NB):
                 tk = time.perf_counter()
@@ -142,8 +191,8 @@ def main():
                 bt = batches[i][0]
                 km = bt.kernel_ms().astype(np.float64)
                 if os.environ.get("MA_BENCH_VERBOSE"):
-                    print("step %d wall %.1f ms, stage ms %s" % (k, (time.perf_counter() - tk) * 1e3, np.round(km[:6], 2).tolist()),
-                          file=sys.stderr, flush=True)
+                    print("%s step %d wall %.1f ms, stage ms %s" % (name, k, (time.perf_counter() - tk) * 1e3,
+                                                                    np.round(km[:6], 2).tolist()), file=sys.stderr, flush=True)
                 a["kms"] += km
                 a["ctr"] += bt.counters().astype(np.float64)
                 c = bt.counts()
@@ -175,151 +224,263 @@ def main():
     ctr = sum(a["ctr"] for a in acc)
     segs = sum(a["segs"] for a in acc)
     aligned = sum(a["aligned"] for a in acc)
-    dt, (aligned_all,) = reduce_timing_and_counts(dist, torch.device("cpu") if one_dev else dev, dt, [aligned])
+    dt, (aligned_all,) = reduce_timing_and_counts(dist, torch.device("cpu") if E.one_dev else dev, dt, [aligned])
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the K launches) --
-    names = ["k_seed", "k_seed_rows+k_lf_walk+k_seed_final", "k_chain", "k_dp_enum", "k_ksw", "k_stitch+k_finish"]
     total_bases = float(offs_h[n_reads] - offs_h[0])
     alg = [64.0 * ctr[1] + total_bases + 40.0 * segs,  # seeding: occ blocks + read bases + segments out
            64.0 * ctr[2] + 8.0 * ctr[3] + 48.0 * ctr[3],  # SA lookup: LF blocks + SA sample + seed out
            0.0, 0.0,
            ctr[6] + ctr[4] + ctr[7],  # DP: sequences in + 1 B per band cell + back-trace reads + cigar out
            0.0]
+    Kd = max(K, 1)
     dom = int(np.argmax(kms[:6]))
-    avg_s = kms[dom] / 1e3 / max(K, 1)
-    ach = (alg[dom] / max(K, 1)) / avg_s / 1e9 if avg_s > 0 else 0.0
-    # HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see
-    # DESIGN.md 3.4); only meaningful for the workload those passes were taken on
+    avg_s = kms[dom] / 1e3 / Kd
+    ach = (alg[dom] / Kd) / avg_s / 1e9 if avg_s > 0 else 0.0
+    # PMC-derived quantities are NOT measured in this process: they come from the committed rocprofv3 passes of the same
+    # workload (tools/collect_profiles.sh) and carry their source; null when no pass of this workload is committed
     traffic = None
-    valu_issue = None
+    valu = None
+    src = os.path.join("profiles", "r02_pmc_traffic.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pt = json.load(f)
-        if pt.get("workload_key") == [args.read_len, B, args.preset, args.genome_scale]:
-            traffic = pt["bytes_per_launch"].get(names[dom])
-            vi = pt.get("valu_wave_insts_per_launch", {}).get(names[dom])
-            if vi and avg_s > 0:
-                # the DP kernels are VALU-issue bound, not HBM bound: instructions from the committed PMC pass over
-                # the live launch time, against 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 instruction
-                valu_issue = {"wave_insts_per_launch": vi, "achieved_Ginst_s": round(vi / avg_s / 1e9, 1),
-                              "peak_Ginst_s": 614.4, "frac": round(vi / avg_s / 1e9 / 614.4, 3)}
+        with open(os.path.join(ROOT, src)) as f:
+            for pt in json.load(f).get("workloads", []):
+                if pt.get("workload_key") == [read_len, B_total, preset, args.genome_scale]:
+                    traffic = pt["bytes_per_launch"].get(STAGES[dom])
+                    valu = pt.get("valu_wave_insts_per_launch", {}).get(STAGES[dom])
     except (OSError, ValueError, KeyError):
-        traffic = None
-    roofline = {"kernel": names[dom], "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_issue": valu_issue,
-                "avg_launch_ms": round(kms[dom] / max(K, 1), 3),
-                "algorithmic_bytes_per_launch": int(alg[dom] / max(K, 1)),
-                "kernel_ms_per_step": {names[i]: round(kms[i] / max(K, 1), 3) for i in range(6)},
-                "seeding_GBps": round((alg[0] / max(K, 1)) / (kms[0] / 1e3 / max(K, 1)) / 1e9, 2) if kms[0] > 0 else 0.0,
-                "seeding_frac_of_gather_ceiling": round(ctr[1] / (kms[0] / 1e3) / 1e9 / GATHER_CEILING_GBLOCKS, 4) if kms[0] > 0 else 0.0,
-                "dp_GCUPS": round(ctr[4] / (kms[4] / 1e3) / 1e9, 3) if kms[4] > 0 else 0.0}
+        pass
+    hbm = {"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+           "traffic": traffic, "traffic_source": src if traffic is not None else None,
+           "algorithmic_bytes_per_launch": int(alg[dom] / Kd)}
+    roofline = {"kernel": STAGES[dom], "avg_launch_ms": round(kms[dom] / Kd, 3)}
+    if dom == 4 and valu and avg_s > 0:
+        # the DP kernels are bound by VALU issue, not by HBM: wave-level VALU instructions of the committed PMC pass over
+        # the live launch time, against the MEASURED issue rate of the kernel's instruction mix (tools/valu_mix.hip)
+        peak = float(E.cal["valu_mix_peak_ginst"])
+        roofline.update({"bound": "valu", "achieved": round(valu / avg_s / 1e9, 1), "peak": peak, "unit": "G wave-inst/s",
+                         "frac": round(valu / avg_s / 1e9 / peak, 3), "traffic": traffic,
+                         "wave_insts_per_launch": valu, "wave_insts_source": src,
+                         "peak_source": "profiles/r02_valu_mix.txt (dp_mix, 8 waves/SIMD)", "hbm": hbm})
+    else:
+        roofline.update({"bound": "hbm"})
+        roofline.update(hbm)
+    roofline.update({
+        "kernel_ms_per_step": {STAGES[i]: round(kms[i] / Kd, 3) for i in range(6)},
+        "seeding_GBps": round((alg[0] / Kd) / (kms[0] / 1e3 / Kd) / 1e9, 2) if kms[0] > 0 else 0.0,
+        "seeding_frac_of_gather_ceiling": round(ctr[1] / (kms[0] / 1e3) / 1e9 / float(E.cal["gather_ceiling_gblocks"]), 4) if kms[0] > 0 else 0.0,
+        "gather_ceiling_Gblocks_s": float(E.cal["gather_ceiling_gblocks"]),
+        "dp_GCUPS": round(ctr[4] / (kms[4] / 1e3) / 1e9, 3) if kms[4] > 0 else 0.0,
+        "dp_band_cells_per_read_executed": round(ctr[4] / max(n_reads, 1), 1)})
 
-    # ---- CPU baseline: the oracle (bit-exact restatement of the reference) on this host's cores -----------
+    # ---- CPU baseline (rank 0, N = 1): the compiled reference and the oracle on this host's cores, then parity ---------
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample != 0:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from ma_testlib import OrIndex, or_params
-        ncores = os.cpu_count() or 1
-        S = args.cpu_sample if args.cpu_sample > 0 else min(n_reads, max(2000, int(4000 * ncores * 150 / max(args.read_len, 1))))
-        oidx = OrIndex.from_parts(idx.download())
-        hb = int(offs_h[S])
-        rc = codes[:hb].cpu().numpy()
-        reads = [rc[int(offs_h[i]):int(offs_h[i + 1])] for i in range(S)]
-        op = or_params(args.preset, 1)
-        t1 = time.perf_counter()
-        res = oidx.align(reads, op, threads=ncores)
-        tc = time.perf_counter() - t1
-        cpu = {"value": round(res["n_aligned"] / tc, 1), "unit": "aligned reads/s", "cores": ncores, "kind": "port",
-               "sample": "first %d reads of the same workload, oracle with %d threads, %.1f s" % (S, ncores, tc),
-               # the reference computes every diagonal of an extension; the GPU path stops once ez.max is final
-               "dp_band_cells_per_read": round(float(res["counters"][4]) / S, 1)}
-        roofline["dp_band_cells_per_read_executed"] = round(ctr[4] / max(n_reads, 1), 1)
-        # ---- the REAL reference (compiled from its own sources into oracle/_ref by oracle/Makefile.ref) on the same
-        # sample: the GPU-built index is written in the reference's file formats, the reference's own loaders read it,
-        # its modules (BinarySeeding .. MappingQuality) run on all host threads (oracle/ref_dump.cpp timeidx)
-        ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
-        if os.path.exists(ref_dump) and not os.environ.get("MA_BENCH_NO_REFERENCE"):
-            import shutil
-            import subprocess
-            import tempfile
-            from ma_testlib import write_case
-            td = tempfile.mkdtemp(prefix="ma_ref_")
-            try:
-                t2 = time.perf_counter()
-                idx.store(os.path.join(td, "idx"))
-                write_case(os.path.join(td, "reads.case"), [], reads)
-                out = subprocess.run([ref_dump, "timeidx", os.path.join(td, "idx"), os.path.join(td, "reads.case"), args.preset,
-                                      str(ncores)], capture_output=True, text=True, timeout=1800)
-                m = __import__("re").search(r"(\d+) reads \((\d+) aligned\) in ([0-9.]+) s on (\d+) threads", out.stdout)
-                if out.returncode == 0 and m:
-                    tr = float(m.group(3))
-                    cpu = dict(cpu, value=round(int(m.group(2)) / tr, 1), kind="reference",
-                               sample="first %d reads of the same workload, the reference's own modules on %d threads, %.1f s "
-                                      "(index written by the GPU builder and loaded by the reference's loaders: %.0f s, not "
-                                      "counted)" % (S, ncores, tr, time.perf_counter() - t2 - tr),
-                               port={"value": cpu["value"], "sample": cpu["sample"]})
-                else:
-                    cpu["reference_error"] = (out.stderr or out.stdout)[-300:]
-            except Exception as e:  # the oracle's number stays
-                cpu["reference_error"] = repr(e)[:300]
-            finally:
-                shutil.rmtree(td, ignore_errors=True)
-        # ---- parity at full scale: the GPU results of the sampled reads of step 0 against the oracle's, bit for bit
-        # (NeedlemanWunsch output incl. every alignment op, and the MappingQuality records incl. mapq doubles)
-        Pn = min(S, B)
-        step(0, 0)
-        bt = batches[0][0]
-        goff, galn, gops = bt.alignments()
-        moff, mq, _ = bt.mapq_alignments()
-        na, nm = int(res["aln_off"][Pn]), int(res["mq_off"][Pn])
-        nops = int(res["alns"]["ops_off"][na - 1] + res["alns"]["n_ops"][na - 1]) if na else 0
-        same = (np.array_equal(goff[:Pn + 1], res["aln_off"][:Pn + 1]) and int(goff[Pn]) == na
-                and galn[:na].tobytes() == res["alns"][:na].tobytes()
-                and np.array_equal(gops[:2 * nops], res["ops"][:2 * nops])
-                and np.array_equal(moff[:Pn + 1], res["mq_off"][:Pn + 1]))
-        if same:
-            for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops", "secondary", "supplementary"):
-                same = same and np.array_equal(mq[f][:nm], res["mq"][f][:nm])
-            same = same and mq["mapq"][:nm].tobytes() == res["mq"]["mapq"][:nm].tobytes()
-        bad = 0
-        if not same:  # count the reads that differ
-            for r in range(Pn):
-                a0, a1 = int(res["aln_off"][r]), int(res["aln_off"][r + 1])
-                g0, g1 = int(goff[r]), int(goff[r + 1])
-                ok = (a1 - a0) == (g1 - g0)
-                if ok:
-                    for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops"):
-                        ok = ok and np.array_equal(galn[f][g0:g1], res["alns"][f][a0:a1])
-                    for k in range(a1 - a0):
-                        oa, ga = res["alns"][a0 + k], galn[g0 + k]
-                        ok = ok and np.array_equal(gops[2 * int(ga["ops_off"]):2 * int(ga["ops_off"] + ga["n_ops"])],
-                                                   res["ops"][2 * int(oa["ops_off"]):2 * int(oa["ops_off"] + oa["n_ops"])])
-                bad += 0 if ok else 1
-            bad = max(bad, 1)
-        cpu["parity_check"] = {"reads": Pn, "alignments": na, "alignment_ops": nops, "mapq_records": nm,
-                               "mismatching_reads": bad,
-                               "what": "GPU vs oracle on the first reads of step 0: every NeedlemanWunsch alignment (positions, score, "
-                                       "ops) and MappingQuality record (flags, mapq bits)"}
+    if rank == 0 and world == 1 and args.cpu_sample != 0 and n_reads > 0:
+        cpu = cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, batches, roofline)
 
+    res = None
     if rank == 0:
-        out = {
-            "metric": "aligned reads/sec (whole node), 150bp & 10kb synthetic vs GRCh38",
-            "value": round(aligned_all / dt, 1), "unit": "aligned reads/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(dt / max(K, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/int8 (2-bit BWT ranks, int8 DP differences, int16/32 scores)",
-            "data": "synthetic",
-            "config": {"workload": "%d x %d bp reads (%.2f%% sub, %.2f%% ins, %.2f%% del) vs GRCh38-like synthetic genome "
-                       "(%d contigs, %d nt%s), %s preset, %d reads/step per GPU" % (
-                           n_reads * world, args.read_len, 100 * args.sub, 100 * args.ins, 100 * args.dele, len(lens), F,
-                           "" if args.no_repeats else ", planted repeats", args.preset, B),
-                       "reads_per_s_total": round(n_reads * world / dt, 1), "index_build_s": round(t_index, 2),
-                       "parallelism": "reads partitioned over %d GPU(s), index replicated, no collective; %d batches in "
-                                      "flight per GPU" % (world, NB)},
+        res = {
+            "name": name, "baseline_config": wl.get("baseline_config"),
+            "workload": "%d x %d bp reads (%.2f%% sub, %.2f%% ins, %.2f%% del), %s preset, %d reads/step %s" % (
+                n_global, read_len, 100 * wl["sub"], 100 * wl["ins"], 100 * wl["dele"], preset, B_total,
+                "per GPU" if args.scaling == "weak" else "over all GPUs"),
+            "value": round(aligned_all / dt, 1), "unit": "aligned reads/s", "steps": K, "warmup": W,
+            "ms_per_step": round(dt / Kd * 1e3, 3), "reads_per_s_total": round(n_global / dt, 1),
+            "gbases_per_s": round(total_bases * (world if args.scaling == "weak" else 1) / dt / 1e9, 3),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+    for bt, _ in batches:
+        bt.close()
+    del codes, offs
+    torch.cuda.empty_cache()
+    return res
+
+
+def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, batches, roofline):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ma_testlib import OrIndex, or_params, write_case
+    ncores = os.cpu_count() or 1
+    read_len = wl["read_len"]
+    S = args.cpu_sample if args.cpu_sample > 0 else (wl["cpu_sample"] or min(n_reads, max(2000, int(4000 * ncores * 150 / max(read_len, 1)))))
+    S = min(S, n_reads)
+    oidx = OrIndex.from_parts(E.idx.download())
+    hb = int(offs_h[S])
+    rc = codes[:hb].cpu().numpy()
+    reads = [rc[int(offs_h[i]):int(offs_h[i + 1])] for i in range(S)]
+    op = or_params(args.preset, 1)
+    t1 = time.perf_counter()
+    res = oidx.align(reads, op, threads=ncores)
+    tc = time.perf_counter() - t1
+    cpu = {"value": round(res["n_aligned"] / tc, 1), "unit": "aligned reads/s", "cores": ncores, "kind": "port",
+           "sample": "first %d reads of the same workload, oracle with %d threads, %.1f s" % (S, ncores, tc),
+           # the reference computes every diagonal of an extension; the GPU path stops once ez.max is final
+           "dp_band_cells_per_read": round(float(res["counters"][4]) / S, 1)}
+    # ---- the REAL reference (compiled from its own sources into oracle/_ref by oracle/Makefile.ref) on the same
+    # sample: the GPU-built index is written in the reference's file formats, the reference's own loaders read it,
+    # its modules (BinarySeeding .. MappingQuality) run on the host threads (oracle/ref_dump.cpp timeidx).  The reference
+    # scales badly over many threads (glibc rand() lock, allocator), so a few thread counts are timed and the best is
+    # the baseline; the 1-thread rate is measured on a smaller sample.
+    ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+    if os.path.exists(ref_dump) and not os.environ.get("MA_BENCH_NO_REFERENCE"):
+        td = tempfile.mkdtemp(prefix="ma_reads_")
+        try:
+            t2 = time.perf_counter()
+            prefix = E.reference_index()
+            t_store = time.perf_counter() - t2
+            write_case(os.path.join(td, "reads.case"), [], reads)
+            S1 = max(4, min(S // 64, int(1e6 / max(read_len, 1))))
+            write_case(os.path.join(td, "reads1.case"), [], reads[:S1])
+
+            def timed(case, threads):
+                out = subprocess.run([ref_dump, "timeidx", prefix, os.path.join(td, case), args.preset, str(threads)],
+                                     capture_output=True, text=True, timeout=1800)
+                m = re.search(r"(\d+) reads \((\d+) aligned\) in ([0-9.]+) s on (\d+) threads", out.stdout)
+                if out.returncode != 0 or not m:
+                    raise RuntimeError((out.stderr or out.stdout)[-300:])
+                return int(m.group(2)) / float(m.group(3)), float(m.group(3))
+
+            runs = {}
+            cand = sorted(set([ncores] + ([max(1, ncores // 4)] if args.cpu_threads_sweep and name in ("150bp", "custom") else [])))
+            for t in cand:
+                runs[t] = timed("reads.case", t)
+            best = max(runs, key=lambda t: runs[t][0])
+            one = timed("reads1.case", 1)
+            cpu = dict(cpu, value=round(runs[best][0], 1), cores=best, kind="reference",
+                       sample="first %d reads of the same workload, the reference's own modules (BinarySeeding .. "
+                              "MappingQuality), %.1f s on %d threads; index written by the GPU builder and loaded by the "
+                              "reference's loaders (%.0f s to write, not counted)" % (S, runs[best][1], best, t_store),
+                       by_threads={str(t): round(v[0], 1) for t, v in runs.items()},
+                       one_thread={"value": round(one[0], 1), "sample": "first %d reads, %.1f s" % (S1, one[1])},
+                       port={"value": cpu["value"], "sample": cpu["sample"]})
+        except Exception as e:  # the oracle's number stays
+            cpu["reference_error"] = repr(e)[:300]
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    # ---- parity at full scale: the GPU results of the sampled reads of step 0 against the oracle's, bit for bit
+    # (NeedlemanWunsch output incl. every alignment op, and the MappingQuality records incl. mapq doubles)
+    Pn = min(S, B)
+    step(0, 0)
+    bt = batches[0][0]
+    goff, galn, gops = bt.alignments()
+    moff, mq, _ = bt.mapq_alignments()
+    na, nm = int(res["aln_off"][Pn]), int(res["mq_off"][Pn])
+    nops = int(res["alns"]["ops_off"][na - 1] + res["alns"]["n_ops"][na - 1]) if na else 0
+    same = (np.array_equal(goff[:Pn + 1], res["aln_off"][:Pn + 1]) and int(goff[Pn]) == na
+            and galn[:na].tobytes() == res["alns"][:na].tobytes()
+            and np.array_equal(gops[:2 * nops], res["ops"][:2 * nops])
+            and np.array_equal(moff[:Pn + 1], res["mq_off"][:Pn + 1]))
+    if same:
+        for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops", "secondary", "supplementary"):
+            same = same and np.array_equal(mq[f][:nm], res["mq"][f][:nm])
+        same = same and mq["mapq"][:nm].tobytes() == res["mq"]["mapq"][:nm].tobytes()
+    bad = 0
+    if not same:  # count the reads that differ
+        for r in range(Pn):
+            a0, a1 = int(res["aln_off"][r]), int(res["aln_off"][r + 1])
+            g0, g1 = int(goff[r]), int(goff[r + 1])
+            ok = (a1 - a0) == (g1 - g0)
+            if ok:
+                for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops"):
+                    ok = ok and np.array_equal(galn[f][g0:g1], res["alns"][f][a0:a1])
+                for k in range(a1 - a0):
+                    oa, ga = res["alns"][a0 + k], galn[g0 + k]
+                    ok = ok and np.array_equal(gops[2 * int(ga["ops_off"]):2 * int(ga["ops_off"] + ga["n_ops"])],
+                                               res["ops"][2 * int(oa["ops_off"]):2 * int(oa["ops_off"] + oa["n_ops"])])
+            bad += 0 if ok else 1
+        bad = max(bad, 1)
+    cpu["parity_check"] = {"reads": Pn, "alignments": na, "alignment_ops": nops, "mapq_records": nm,
+                           "mismatching_reads": bad,
+                           "what": "GPU vs oracle on the first reads of step 0: every NeedlemanWunsch alignment (positions, score, "
+                                   "ops) and MappingQuality record (flags, mapq bits)"}
+    return cpu
+
+
+def boundary_leg(E, args):
+    """Host-fed end-to-end rate through the drop-in boundary (reads in host memory -> BatchAligner -> Alignment
+    containers -> SAM text), examples/ma_boundary_bench.cpp; reported in config.boundary, never in `value`."""
+    exe = os.path.join(ROOT, "examples", "ma_boundary_bench")
+    if not os.path.exists(exe):
+        return {"error": "examples/ma_boundary_bench not built (run __graft_entry__.build())"}
+    try:
+        out = subprocess.run([exe, E.reference_index(), str(args.boundary_reads), "150", args.preset, str(E.gpu)],
+                             capture_output=True, text=True, timeout=900)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        if out.returncode != 0 or not line:
+            return {"error": (out.stderr or out.stdout)[-300:]}
+        return json.loads(line[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="all", choices=["all", "150bp", "10kb", "50kb"])
+    ap.add_argument("--reads-per-step", type=int, default=0, help="override the workload's reads per step")
+    ap.add_argument("--read-len", type=int, default=0, help="custom single workload with --sub/--ins/--dele")
+    ap.add_argument("--sub", type=float, default=0.005)
+    ap.add_argument("--ins", type=float, default=0.0)
+    ap.add_argument("--dele", type=float, default=0.0)
+    ap.add_argument("--genome-scale", type=float, default=1.0, help="fraction of GRCh38 contig lengths (tests only)")
+    ap.add_argument("--preset", default="default")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 per workload, 0 off)")
+    ap.add_argument("--cpu-threads-sweep", type=int, default=1, help="also time the reference on a quarter of the threads")
+    ap.add_argument("--boundary-reads", type=int, default=1000000, help="reads of the host-fed boundary leg (0 off)")
+    ap.add_argument("--no-repeats", action="store_true")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight per GPU (own stream + host thread each): while one batch is in its "
+                         "VALU-bound DP kernels another runs its memory-bound seeding / chaining")
+    args = ap.parse_args()
+
+    E = Env(args)
+    wls = []
+    if args.read_len > 0:  # custom single workload
+        B = args.reads_per_step if args.reads_per_step > 0 else (1000000 if args.read_len <= 1000 else max(10000, int(2e9 / args.read_len)))
+        wls.append(("custom", dict(read_len=args.read_len, sub=args.sub, ins=args.ins, dele=args.dele,
+                                   seed=11 if args.read_len <= 1000 else (12 if args.read_len <= 20000 else 13),
+                                   reads_per_step=B, steps=args.steps, warmup=args.warmup, cpu_sample=None,
+                                   baseline_config=None)))
+    else:
+        for name in (["150bp", "10kb", "50kb"] if args.workload == "all" else [args.workload]):
+            wl = dict(WORKLOADS[name])
+            if wl["steps"] is None or args.workload != "all":
+                wl["steps"], wl["warmup"] = args.steps, args.warmup
+            if args.reads_per_step > 0 and (name == "150bp" or args.workload != "all"):
+                wl["reads_per_step"] = args.reads_per_step
+            wls.append((name, wl))
+    results = []
+    for name, wl in wls:
+        r = run_workload(E, name, wl, args)
+        if r is not None:
+            results.append(r)
+    boundary = None
+    if E.rank == 0 and E.world == 1 and args.boundary_reads > 0 and args.cpu_sample != 0 and args.read_len == 0:
+        boundary = boundary_leg(E, args)
+    if E.rank == 0:
+        head = results[0]
+        out = {
+            "metric": "aligned reads/sec (whole node), 150bp & 10kb synthetic vs GRCh38",
+            "value": head["value"], "unit": "aligned reads/s", "n_gpus": E.world, "steps": head["steps"], "warmup": head["warmup"],
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "u8/int8 (2-bit BWT ranks, int8 DP differences, int16/32 scores)",
+            "data": "synthetic",
+            "config": {"workload": head["workload"] + " vs GRCh38-like synthetic genome (%d contigs, %d nt%s)" % (
+                           len(E.lens), E.F, "" if args.no_repeats else ", planted repeats"),
+                       "value_is": "workload '%s' (%s)" % (head["name"], head["baseline_config"]),
+                       "reads_per_s_total": head["reads_per_s_total"], "index_build_s": round(E.t_index, 2),
+                       "parallelism": "reads partitioned over %d GPU(s) (%s scaling), index replicated, no collective; %d "
+                                      "batch(es) in flight per GPU" % (E.world, args.scaling, max(1, args.inflight)),
+                       "workloads": results, "boundary": boundary},
+            "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"],
+        }
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    E.close()
+    if E.dist is not None:
+        E.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -64,7 +64,8 @@ typedef struct
     int32_t search_inversions; /* 0                              xSearchInversions */
     int32_t zdrop_inversion; /* 100                              xZDropInversion */
     int32_t use_paired_reads; /* 0                               xUsePairedReads */
-    int32_t pad_;
+    int32_t libm_probe; /* 0. Diagnostics only (tests): != 0 nudges every tan / sin / atan / log result of the chaining
+                           stage by one ulp (ma_amd/csrc/chain.h LibmProbe); results must not change */
     double mean_paired_dist; /* 400                              xMeanPairedReadDistance */
     double std_paired_dist; /* 150                               xStdPairedReadDistance */
     double paired_bonus; /* 1.25                                 xPairedBonus */

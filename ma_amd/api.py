@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("harm_score_min_rel", C.c_double), ("soc_score_decrease_tol", C.c_double),
         ("score_diff_tol", C.c_double), ("max_delta_dist", C.c_double), ("min_alignment_score", C.c_int32),
         ("report_n_best", C.c_int32), ("max_supplementary", C.c_int32), ("max_overlap_supplementary", C.c_double),
-        ("search_inversions", C.c_int32), ("zdrop_inversion", C.c_int32), ("use_paired_reads", C.c_int32), ("pad_", C.c_int32),
+        ("search_inversions", C.c_int32), ("zdrop_inversion", C.c_int32), ("use_paired_reads", C.c_int32), ("libm_probe", C.c_int32),
         ("mean_paired_dist", C.c_double), ("std_paired_dist", C.c_double), ("paired_bonus", C.c_double),
     ]
 

@@ -29,6 +29,7 @@ struct ChainParams
     double score_diff_tol;
     double max_delta_dist;
     u32 rng_ring[ 31 ]; // glibc random() state after srand(seed) (310 discards done)
+    u32 libm_probe; // ma_params::libm_probe: 0 = off (the product), else every libm result is nudged (see LibmProbe)
 };
 
 struct SoCEntry // tuple<SoCOrder, it, it> (soc.h:26-90, 192)
@@ -92,6 +93,35 @@ struct GlibcRand // glibc stdlib/random_r.c, TYPE_3: r[i] = r[i-3] + r[i-31], ou
         if( ++b >= 31 )
             b = 0;
         return (i32)res;
+    }
+};
+
+// Sensitivity probe for the four libm functions the stage decides with (tan, sin, atan, log): the reference evaluates them
+// with glibc, the device with ocml, and the two differ in the last bit for ~13 % of the arguments
+// (tests/test_gpu_round2.py).  With mode != 0 every result is moved by one ulp -- 1: up, 2: down, >= 3: up / same / down
+// by a hash of the call count and the mode -- so that a test can assert that no decision of a whole corpus depends on the
+// last bit of these functions.  mode 0 (always, outside that test) returns the value untouched.
+struct LibmProbe
+{
+    u32 mode, calls;
+    MA_HD double operator( )( double v )
+    {
+        if( mode == 0 || !( v == v ) || v == 0.0 || v - v != 0.0 )
+            return v;
+        calls++;
+        u32 h = calls * 2654435761u + mode * 0x9E3779B9u;
+        h ^= h >> 15;
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 13;
+        const i32 d = mode == 1 ? 1 : ( mode == 2 ? -1 : (i32)( h % 3u ) - 1 );
+        union
+        {
+            double f;
+            i64 b;
+        } u;
+        u.f = v;
+        u.b += v > 0 ? d : -d;
+        return u.f;
     }
 };
 
@@ -260,11 +290,11 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
 
 #define MA_PI_TRUNC 3.14159265 /* harmonization.h:23 (sic) */
 
-MA_HD double delta_distance( const ma_seed& s, const double fAngle, const i64 rStart ) // harmonization.h:82-89
+MA_HD double delta_distance( const ma_seed& s, const double fAngle, const i64 rStart, LibmProbe& lp ) // harmonization.h:82-89
 {
-    const double y = (double)(u64)s.r_start + (double)(u64)s.q_start / tan( MA_PI_TRUNC / 2 - fAngle );
-    const double x = ( y - (double)rStart ) * sin( fAngle );
-    const double x_1 = (double)(u64)s.q_start / sin( MA_PI_TRUNC / 2 - fAngle );
+    const double y = (double)(u64)s.r_start + (double)(u64)s.q_start / lp( tan( MA_PI_TRUNC / 2 - fAngle ) );
+    const double x = ( y - (double)rStart ) * lp( sin( fAngle ) );
+    const double x_1 = (double)(u64)s.q_start / lp( sin( MA_PI_TRUNC / 2 - fAngle ) );
     return fabs( x - x_1 );
 }
 
@@ -282,7 +312,7 @@ MA_HD double median_of( double* a, u32 n ) // test_ransac.h:21-40 (sorts its pri
 
 // run_ransac -> (angle, rStart as double); NaNs when no model was found
 MA_HD_OUTLINE void run_ransac( const double* X, const double* Y, u32 nPts, double fMAD, GlibcRand& rng, i32* inl, i32* best,
-                       double* scratch, double& outAngle, double& outIntercept )
+                       double* scratch, double& outAngle, double& outIntercept, LibmProbe& lp )
 {
     int iterations = 0;
     int nBest = -2147483647;
@@ -317,7 +347,7 @@ MA_HD_OUTLINE void run_ransac( const double* X, const double* Y, u32 nPts, doubl
         }
         double dAngle = -90;
         if( dH > 0 && dV > 0 )
-            dAngle = atan( dV / dH ) * 180 / 3.141592653589793;
+            dAngle = lp( atan( dV / dH ) ) * 180 / 3.141592653589793;
         if( dAngle >= 20 && dAngle <= 70 )
         {
             const double sqrT = fMAD * fMAD;
@@ -344,7 +374,7 @@ MA_HD_OUTLINE void run_ransac( const double* X, const double* Y, u32 nPts, doubl
                 double pNo = 1 - w * w; // pow(w, 2.0)
                 pNo = mmax( 2.220446049250313e-16, pNo );
                 pNo = mmin( 1 - 2.220446049250313e-16, pNo );
-                k = log( 1 - 0.99 ) / log( pNo );
+                k = lp( log( 1 - 0.99 ) ) / lp( log( pNo ) );
             }
         }
         else
@@ -384,7 +414,7 @@ MA_HD_OUTLINE void run_ransac( const double* X, const double* Y, u32 nPts, doubl
         sum_xy = sum_xy + dx[ i ] * dy[ i ];
     const double slope = sum_xy / sx;
     const double intercept = mean_y - slope * mean_x;
-    outAngle = atan( slope );
+    outAngle = lp( atan( slope ) );
     outIntercept = -intercept / slope;
 }
 
@@ -396,7 +426,8 @@ MA_HD i64 double_to_i64( double d ) // (int64_t)d with x86 cvttsd2si semantics f
 }
 
 // linesweep (harmonization.cpp:182-249): in = sh (n), out = ends; returns count
-MA_HD_OUTLINE u32 linesweep( Shadow* sh, u32 n, Shadow* ends, const ma_seed* seeds, const i64 rStart, const double fAngle )
+MA_HD_OUTLINE u32 linesweep( Shadow* sh, u32 n, Shadow* ends, const ma_seed* seeds, const i64 rStart, const double fAngle,
+                             LibmProbe& lp )
 {
     ss::sort( sh, (i64)n, ShadowOrder( ) );
     u32 ne = 0;
@@ -411,12 +442,12 @@ MA_HD_OUTLINE u32 linesweep( Shadow* sh, u32 n, Shadow* ends, const ma_seed* see
         }
         else
         {
-            const double fD = delta_distance( seeds[ t.seed ], fAngle, rStart );
+            const double fD = delta_distance( seeds[ t.seed ], fAngle, rStart, lp );
             u32 pos = ne;
             bool closer = true;
             while( pos > 0 && ends[ pos - 1 ].b >= t.b )
             {
-                const double fO = delta_distance( seeds[ ends[ pos - 1 ].seed ], fAngle, rStart );
+                const double fO = delta_distance( seeds[ ends[ pos - 1 ].seed ], fAngle, rStart, lp );
                 if( fO <= fD )
                 {
                     closer = false;
@@ -436,7 +467,7 @@ MA_HD_OUTLINE u32 linesweep( Shadow* sh, u32 n, Shadow* ends, const ma_seed* see
 }
 
 // harmonizeOne (harmonization.cpp:251-373): S (n seeds, modified) -> out; returns count
-MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScratch& C, GlibcRand& rng )
+MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScratch& C, GlibcRand& rng, LibmProbe& lp )
 {
     if( n > 1 )
     {
@@ -463,12 +494,12 @@ MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScr
         }
         const double fMAD = median_of( C.med, np );
         double fAngle, fIcpt;
-        run_ransac( C.vX, C.vY, np, fMAD, rng, C.inl, C.best, C.med, fAngle, fIcpt );
+        run_ransac( C.vX, C.vY, np, fMAD, rng, C.inl, C.best, C.med, fAngle, fIcpt, lp );
         const i64 rStart = double_to_i64( fIcpt );
         // remove outliers (stable remove_if)
         u32 m = 0;
         for( u32 i = 0; i < n; i++ )
-            if( !( delta_distance( S[ i ], fAngle, rStart ) > fMAD ) )
+            if( !( delta_distance( S[ i ], fAngle, rStart, lp ) > fMAD ) )
             {
                 if( m != i )
                     S[ m ] = S[ i ];
@@ -481,7 +512,7 @@ MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScr
             C.sh1[ i ].a = (u64)S[ i ].q_start;
             C.sh1[ i ].b = (u64)S[ i ].r_start + (u64)S[ i ].len;
         }
-        u32 n2 = linesweep( C.sh1, n, C.sh2, S, rStart, fAngle );
+        u32 n2 = linesweep( C.sh1, n, C.sh2, S, rStart, fAngle, lp );
         for( u32 i = 0; i < n2; i++ )
         {
             const u32 sd = C.sh2[ i ].seed;
@@ -489,7 +520,7 @@ MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScr
             C.sh1[ i ].a = (u64)S[ sd ].r_start;
             C.sh1[ i ].b = (u64)S[ sd ].q_start + (u64)S[ sd ].len;
         }
-        const u32 n3 = linesweep( C.sh1, n2, C.sh2, S, rStart, fAngle );
+        const u32 n3 = linesweep( C.sh1, n2, C.sh2, S, rStart, fAngle, lp );
         for( u32 i = 0; i < n3; i++ )
             out[ i ] = S[ C.sh2[ i ].seed ];
         ss::sort( out, (i64)n3, SeedByRefQ( ) );
@@ -631,6 +662,7 @@ MA_HD u32 chain_read( const IndexView& X, const ChainParams& P, const ChainScrat
     u32 nmx = nmx0;
     GlibcRand rng;
     rng.init( P.rng_ring );
+    LibmProbe lp{ P.libm_probe, 0 };
     u32 nsets = 0;
     u32 numTries = 0, socIndex = 0, repeat = 0;
     u64 lastHarm = 0, bestSoC = 0;
@@ -711,11 +743,11 @@ MA_HD u32 chain_read( const IndexView& X, const ChainParams& P, const ChainScrat
             }
         }
         // forward strand first, then reverse: both consume RANSAC draws in this order
-        const u32 nOutF = harmonize_one( C.setA, nF, C.outA, C, rng );
+        const u32 nOutF = harmonize_one( C.setA, nF, C.outA, C, rng, lp );
         // the reverse output reuses setA's tail-free storage: setA is dead after harmonize_one
         ma_seed* outB = C.setA;
         // harmonize_one(setB) may read setB while writing outB (= setA): distinct arrays, fine
-        const u32 nOutR = harmonize_one( C.setB, nR, outB, C, rng );
+        const u32 nOutR = harmonize_one( C.setB, nR, outB, C, rng, lp );
         u64 curHarm = 0;
         for( u32 i = 0; i < nOutF; i++ )
             curHarm += (u64)C.outA[ i ].len;

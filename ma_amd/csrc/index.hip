@@ -116,7 +116,7 @@ void ma_params_default( ma_params* p )
     p->search_inversions = 0;
     p->zdrop_inversion = 100;
     p->use_paired_reads = 0;
-    p->pad_ = 0;
+    p->libm_probe = 0;
     p->mean_paired_dist = 400;
     p->std_paired_dist = 150;
     p->paired_bonus = 1.25;

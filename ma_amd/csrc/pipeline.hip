@@ -1283,6 +1283,7 @@ int ma_chain_batch( ma_batch* b )
     A.P.score_diff_tol = b->P.score_diff_tol;
     A.P.max_delta_dist = b->P.max_delta_dist;
     glibc_srand_ring( b->P.srand_seed, A.P.rng_ring );
+    A.P.libm_probe = (u32)b->P.libm_probe;
     A.n_reads = (u32)n;
     A.roff = b->d_roff;
     A.seed_off = b->seedOff.as<u64>( );

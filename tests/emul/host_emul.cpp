@@ -204,6 +204,7 @@ int main( int argc, char** argv )
     CP.score_diff_tol = OP.score_diff_tol;
     CP.max_delta_dist = OP.max_delta_dist;
     glibc_srand_ring( OP.srand_seed, CP.rng_ring );
+    CP.libm_probe = 0;
     NwParams NP;
     NP.max_gap_area = OP.max_gap_area;
     NP.padding = OP.padding;

@@ -71,58 +71,140 @@ def _glibc(op, x):
     return (math.tan, math.sin, math.atan, math.log)[op](x)
 
 
-def test_device_libm_matches_glibc_on_reachable_arguments(gpu_device):
-    """The chaining stage decides with tan / sin / atan / log (harmonization.h:82-89, ransac.cpp:112,131-135): the
-    reference evaluates them with glibc, the device with ocml.  Over the arguments those call sites can see -- the guide
-    line's angle atan(slope) with a RANSAC-accepted slope (20..70 degrees) and its complement to MA_PI_TRUNC / 2, the
-    quotients dV / dH of half-integer coordinate differences, and the inlier fractions of the adaptive iteration count
-    -- every device result must have glibc's bits; CPython's math module is the glibc of this image."""
+def _device_libm(op, x):
     import ma_amd
     L = ma_amd.lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.empty_like(x)
+    assert L.ma_debug_libm(C.c_int(op), x.ctypes.data_as(C.c_void_p), C.c_uint64(len(x)),
+                           out.ctypes.data_as(C.c_void_p)) == 0, L.ma_last_error()
+    return out
+
+
+def test_device_libm_is_within_one_ulp_of_glibc(gpu_device):
+    """The chaining stage decides with tan / sin / atan / log (harmonization.h:82-89, ransac.cpp:112,131-135): the
+    reference evaluates them with glibc, the device with ocml.  They are NOT bit-identical (about 1 in 8 atan results
+    differs in the last bit), which is why the decisions are pinned separately below; here the distance is bounded:
+    over the arguments the call sites can see no device result is further than one ulp from glibc's (CPython's math
+    module is the glibc of this image)."""
     rng = np.random.default_rng(77)
     PI_TRUNC = 3.14159265
 
-    def device(op, x):
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        out = np.empty_like(x)
-        assert L.ma_debug_libm(C.c_int(op), x.ctypes.data_as(C.c_void_p), C.c_uint64(len(x)),
-                               out.ctypes.data_as(C.c_void_p)) == 0, L.ma_last_error()
-        return out
-
     def check(op, x, what):
-        got = device(op, x)
+        got = _device_libm(op, x)
         want = np.array([_glibc(op, float(v)) for v in x], dtype=np.float64)
-        bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
-        assert len(bad) == 0, "%s: %d of %d arguments differ from glibc, first %r: device %r glibc %r" % (
-            what, len(bad), len(x), x[bad[0]], got[bad[0]], want[bad[0]])
+        d = np.abs(got.view(np.int64) - want.view(np.int64))
+        assert d.max() <= 1, "%s: device is %d ulp from glibc at %r" % (what, d.max(), x[int(d.argmax())])
+        return float((d != 0).mean())
 
-    # (1) atan(dV / dH): coordinate differences are multiples of 0.5 up to 2 x the longest read (here 2 x 50 kb)
-    dv = rng.integers(1, 400000, 150000) * 0.5
-    dh = rng.integers(1, 400000, 150000) * 0.5
-    check(2, dv / dh, "atan(dV/dH)")
-    small = np.array([(a * 0.5) / (b * 0.5) for a in range(1, 301) for b in range(1, 301)])
-    check(2, small, "atan(dV/dH), short reads")
-    # (2) the fitted slope: least squares over inliers of a 20..70 degree model; fAngle = atan(slope)
-    slope = np.tan(np.deg2rad(rng.uniform(15.0, 75.0, 200000)))
-    check(2, slope, "atan(slope)")
+    rates = {}
+    dv = rng.integers(1, 400000, 100000) * 0.5
+    dh = rng.integers(1, 400000, 100000) * 0.5
+    rates["atan(dV/dH)"] = check(2, dv / dh, "atan(dV/dH)")
+    slope = np.tan(np.deg2rad(rng.uniform(15.0, 75.0, 100000)))
+    rates["atan(slope)"] = check(2, slope, "atan(slope)")
     ang = np.array([math.atan(float(s)) for s in slope])
-    check(1, ang, "sin(fAngle)")
-    check(1, PI_TRUNC / 2 - ang, "sin(pi/2 - fAngle)")
-    check(0, PI_TRUNC / 2 - ang, "tan(pi/2 - fAngle)")
-    # exactly diagonal guide lines (slope 1 is what error-free seeds give)
-    near = np.array([math.atan(1.0 + k * 2.0 ** -40) for k in range(-2000, 2001)])
-    check(1, near, "sin near 45 degrees")
-    check(0, PI_TRUNC / 2 - near, "tan near 45 degrees")
-    # (3) log(1 - 0.99) and log(pNo), pNo = 1 - (nIn / nPts)^2 clamped to [eps, 1 - eps]
-    fr = []
-    for npts in list(range(2, 400)) + [3 * k for k in (200, 500, 1000, 5000, 20000)]:
-        for nin in sorted(set([1, 2, 3, npts // 3, npts // 2, npts - 1, npts] + list(rng.integers(1, npts + 1, 6)))):
-            w = float(nin) / float(npts)
-            p = 1 - w * w
-            p = max(2.220446049250313e-16, p)
-            p = min(1 - 2.220446049250313e-16, p)
-            fr.append(p)
-    check(3, np.array(fr + [1 - 0.99]), "log(pNo)")
+    rates["sin(a)"] = check(1, ang, "sin(fAngle)")
+    rates["sin(pi/2-a)"] = check(1, PI_TRUNC / 2 - ang, "sin(pi/2 - fAngle)")
+    rates["tan(pi/2-a)"] = check(0, PI_TRUNC / 2 - ang, "tan(pi/2 - fAngle)")
+    w = rng.integers(1, 3000, 50000) / 3000.0
+    p = np.clip(1 - w * w, 2.220446049250313e-16, 1 - 2.220446049250313e-16)
+    rates["log(pNo)"] = check(3, p, "log(pNo)")
+    print("fraction of arguments whose device result differs from glibc in the last bit:", rates)
+
+
+def test_ransac_decisions_do_not_depend_on_the_last_bits_of_libm(gpu_device):
+    """Two of the libm call sites feed DISCRETE decisions whose worst cases can be enumerated (ransac.cpp:112,131-135):
+    (a) a sampled model is accepted iff 20 <= atan(dV / dH) * 180 / pi <= 70, dV and dH differences of half-integer
+        coordinates: the rationals closest to tan(20 deg) and tan(70 deg) with numerator / denominator up to 2^21 half-units
+        (reads of 1 Mb) -- the convergents and semiconvergents of the two thresholds' continued fractions -- are decided
+        by the device exactly like exact arithmetic decides them, and their margin is > 10^3 ulp;
+    (b) the adaptive iteration count k = log(1 - 0.99) / log(1 - (nIn / nPts)^2) is only compared with integers
+        (`while iterations < k`, at most 100): over all 1 <= nIn <= nPts <= 3 x 6000 points, k < 101 is never closer
+        than 10^-9 (relative) to an integer, a million times more than the libm's error."""
+    from fractions import Fraction
+    from decimal import Decimal, getcontext
+    getcontext().prec = 60
+
+    def tan_deg(d):  # tan of d degrees to 60 digits (Taylor series of sin and cos)
+        x = Decimal(d) * Decimal("3.14159265358979323846264338327950288419716939937510582097494") / 180
+        s, c, t = Decimal(0), Decimal(0), Decimal(1)
+        for n in range(60):
+            if n % 2 == 0:
+                c += t if n % 4 == 0 else -t
+            else:
+                s += t if n % 4 == 1 else -t
+            t = t * x / (n + 1)
+        return s / c
+
+    cases = []
+    LIM = 1 << 21
+    for deg in (20, 70):
+        T = tan_deg(deg)
+        # continued fraction of T; convergents and semiconvergents with denominator / numerator <= LIM
+        h0, h1, k0, k1 = 0, 1, 1, 0
+        x = T
+        for _ in range(40):
+            a = int(x)
+            for m in range(1, a + 1):  # semiconvergents ... the convergent itself at m == a
+                p, q = h0 + m * h1, k0 + m * k1
+                if 0 < q <= LIM and 0 < p <= LIM:
+                    cases.append((deg, p, q, Decimal(p) / Decimal(q) >= T))
+            h0, h1, k0, k1 = h1, h0 + a * h1, k1, k0 + a * k1
+            if k1 > LIM or h1 > LIM:
+                break
+            fr = x - a
+            if fr == 0:
+                break
+            x = 1 / fr
+    assert len(cases) > 40
+    q = np.array([(p * 0.5) / (d * 0.5) for _, p, d, _ in cases])
+    ang = _device_libm(2, q) * 180 / 3.141592653589793
+    for (deg, p, d, above), a in zip(cases, ang):
+        got = (a >= 20) if deg == 20 else (a > 70)  # "inside at the lower bound" / "outside at the upper bound"
+        assert got == above, "atan(%d/%d) is decided differently from exact arithmetic at %d degrees" % (p, d, deg)
+        assert abs(a - deg) > 1000 * np.spacing(float(deg)), "margin at %d/%d" % (p, d)
+    # (b) in double arithmetic with numpy (error ~1e-15 relative), chunked over nPts
+    worst = 1.0
+    for npts in range(2, 18001):
+        nin = np.arange(1, npts + 1, dtype=np.float64)
+        w = nin / npts
+        p = np.clip(1 - w * w, 2.220446049250313e-16, 1 - 2.220446049250313e-16)
+        k = math.log(1 - 0.99) / np.log(p)
+        k = k[(k < 101.5) & (k > 0.5)]
+        if len(k):
+            worst = min(worst, float(np.min(np.abs(k - np.rint(k)) / k)))
+    assert worst > 1e-9, worst
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+def test_pipeline_is_insensitive_to_one_ulp_of_libm(gpu_device, tmp_path, mode):
+    """The continuous libm call sites (the guide line's angle and delta distances, harmonization.h:82-89) cannot be
+    enumerated.  ma_params.libm_probe nudges EVERY tan / sin / atan / log result of the chaining stage by one ulp (the
+    measured distance between ocml and glibc): up, down, or up / same / down by call (three different patterns).  Over a
+    corpus with repeats, nested SMEM seeds, N bases and long high-error reads the results must stay bit-identical."""
+    import ma_amd
+    g = rand_genome(29, [2800000, 1500000, 900000], repeat_unit=300, repeat_copies=400, repeat_div=0.06)
+    reads = (sample_reads(g, 6000, 150, 151, sub=0.01) + sample_reads(g, 1500, 150, 152, sub=0.05, ins=0.01, dele=0.01)
+             + sample_reads(g, 1500, 250, 153, sub=0.02, ins=0.005, dele=0.005) + sample_reads(g, 40, 8000, 154, sub=0.01, ins=0.01, dele=0.01)
+             + sample_reads(g, 6, 40000, 155, sub=0.03, ins=0.03, dele=0.04))
+    idx = ma_amd.Index.build(g)
+    for preset in ("default", "illumina"):
+        out = []
+        for m in (0, mode):
+            P = ma_amd.Params.preset(preset)
+            P.srand_seed = 3
+            P.libm_probe = m
+            b = ma_amd.Batch(idx, P, len(reads), sum(len(r) for r in reads) + 64)
+            b.set_reads(reads)
+            b.align()
+            b.sync()
+            hs = b.hsets()
+            al = b.mapq_alignments()
+            out.append([np.asarray(x).tobytes() for x in hs] + [np.asarray(x).tobytes() for x in al])
+            b.close()
+        assert out[0] == out[1], "preset %s: results change when libm results move by one ulp (mode %d)" % (preset, mode)
+    idx.close()
 
 
 def test_c_abi_from_fresh_host_threads(gpu_device, tmp_path):
