@@ -341,7 +341,7 @@ def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, 
                 return int(m.group(2)) / float(m.group(3)), float(m.group(3))
 
             runs = {}
-            cand = sorted(set([ncores] + ([max(1, ncores // 4)] if args.cpu_threads_sweep and name in ("150bp", "custom") else [])))
+            cand = sorted(set([ncores] + ([max(1, ncores // 4)] if args.cpu_threads_sweep else [])))
             for t in cand:
                 runs[t] = timed("reads.case", t)
             best = max(runs, key=lambda t: runs[t][0])

@@ -1,0 +1,192 @@
+// examples/ma_boundary_bench.cpp -- host-fed end-to-end throughput through the drop-in boundary (what
+// ExecutionContext::doAlign, libs/ma/inc/ma/util/execution-context.h:291-406, does with the reference's modules):
+// reads in HOST memory -> H2D -> all stages on the GPU -> D2H -> Alignment containers -> SAM text.
+// Three legs over the same synthetic 150 bp reads of the indexed genome:
+//   batch_aligner   BatchAligner::execute, device batches of 256 k reads, 1 and 2 in flight; wall + the time of each phase
+//   sam             FileWriter::execute for every read on T host threads into a counting sink
+//   graph           the UNCHANGED per-read graph of setUpCompGraph (export.cpp:99-126), T graph threads over one shared
+//                   reader, per-read execute() calls funnelled into device batches by the DeviceBatcher
+// Prints one JSON line.  bench.py runs it after its timed regions and reports it as config.boundary (never as `value`).
+//
+//   ma_boundary_bench <index prefix> <reads> <read length> <preset> <device> [graph threads]
+//
+// build: g++ -std=c++17 -O2 -Iinclude -Ima_amd/host examples/ma_boundary_bench.cpp -Lma_amd -lma_amd -lpthread
+#include "ma_sam.h"
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+using namespace libMA;
+using namespace libMS;
+typedef ContainerVector<std::shared_ptr<NucSeq>> ReadVec;
+
+static double now( )
+{
+    return std::chrono::duration<double>( std::chrono::steady_clock::now( ).time_since_epoch( ) ).count( );
+}
+
+struct CountingSink : public OutStream
+{
+    std::atomic<uint64_t> uiBytes{ 0 };
+    void put( const char*, size_t n ) override
+    {
+        uiBytes += n;
+    }
+};
+
+class VecReader : public Module<NucSeq, true>
+{
+  public:
+    const ReadVec& r;
+    std::atomic<size_t> i{ 0 };
+    VecReader( const ReadVec& r ) : r( r )
+    {}
+    std::shared_ptr<NucSeq> execute( ) override
+    {
+        const size_t k = i++;
+        return k < r.size( ) ? r[ k ] : nullptr;
+    }
+};
+
+int main( int argc, char** argv )
+{
+    if( argc < 6 )
+    {
+        fprintf( stderr, "usage: ma_boundary_bench <index prefix> <reads> <read length> <preset> <device> [graph threads]\n" );
+        return 2;
+    }
+    try
+    {
+        const size_t n = (size_t)atoll( argv[ 2 ] ), uiLen = (size_t)atoll( argv[ 3 ] );
+        ParameterSetManager xParams;
+        xParams.setSelected( argv[ 4 ] );
+        maCheck( ma_set_device( atoi( argv[ 5 ] ) ) );
+        const unsigned uiHw = std::max( 1u, std::thread::hardware_concurrency( ) );
+        const int iGraphThreads = argc >= 7 ? atoi( argv[ 6 ] ) : (int)std::min( 2048u, 8 * uiHw );
+        std::shared_ptr<Pack> pPack;
+        std::shared_ptr<FMIndex> pFM;
+        double t0 = now( );
+        loadIndex( argv[ 1 ], pPack, pFM );
+        const double fLoad = now( ) - t0;
+        // ---- reads: sampled on the host from the packed forward strand, 0.5 % substitutions, every second one reverse
+        uint64_t uiN = 0;
+        maCheck( ma_index_sizes( pFM->pDev->p, nullptr, nullptr, &uiN, nullptr ) );
+        const uint64_t uiF = uiN / 2;
+        std::vector<uint8_t> vPac( ( uiF + 3 ) / 4 + 1 );
+        maCheck( ma_index_download( pFM->pDev->p, nullptr, nullptr, nullptr, nullptr, vPac.data( ), nullptr, nullptr ) );
+        auto pReads = std::make_shared<ReadVec>( );
+        uint64_t uiState = 0x9E3779B97F4A7C15ull;
+        auto rnd = [ & ]( ) {
+            uiState ^= uiState << 13, uiState ^= uiState >> 7, uiState ^= uiState << 17;
+            return uiState;
+        };
+        for( size_t i = 0; i < n; i++ )
+        {
+            auto pQ = std::make_shared<NucSeq>( );
+            pQ->sName = "r" + std::to_string( i );
+            pQ->xCodes.resize( uiLen );
+            const uint64_t uiPos = rnd( ) % ( uiF - uiLen );
+            for( size_t j = 0; j < uiLen; j++ )
+            {
+                const uint64_t p = uiPos + j;
+                uint8_t b = ( vPac[ p >> 2 ] >> ( ( ~p & 3 ) << 1 ) ) & 3;
+                if( rnd( ) % 200 == 0 )
+                    b = ( b + 1 + rnd( ) % 3 ) & 3;
+                pQ->xCodes[ j ] = b;
+            }
+            if( i & 1 )
+            {
+                std::reverse( pQ->xCodes.begin( ), pQ->xCodes.end( ) );
+                for( auto& b : pQ->xCodes )
+                    b = 3 - b;
+            }
+            pReads->push_back( pQ );
+        }
+        std::vector<uint8_t>( ).swap( vPac );
+        // ---- leg 1: BatchAligner
+        std::string sBatch;
+        std::shared_ptr<BatchAligner::TP_RESULT> pRes;
+        for( size_t uiInflight : { (size_t)1, (size_t)2 } )
+        {
+            BatchAligner xAligner( xParams );
+            xAligner.uiInflight = uiInflight;
+            xAligner.execute( pFM, std::make_shared<ReadVec>( pReads->begin( ), pReads->begin( ) + std::min<size_t>( n, 4096 ) ) ); // warm-up
+            pRes = xAligner.execute( pFM, pReads );
+            const AlignerTiming& T = xAligner.xLast;
+            char buf[ 512 ];
+            snprintf( buf, sizeof( buf ),
+                      "%s\"inflight_%zu\": {\"reads_per_s\": %.1f, \"wall_s\": %.4f, \"h2d_s\": %.4f, \"kernels_s\": %.4f, \"d2h_s\": %.4f, "
+                      "\"containers_s\": %.4f, \"device_batches\": %llu, \"aligned_reads\": %llu}",
+                      sBatch.empty( ) ? "" : ", ", uiInflight, n / T.fWall, T.fWall, T.fH2D, T.fKernels, T.fD2H, T.fContainers,
+                      (unsigned long long)T.uiBatches, (unsigned long long)T.uiAlignedReads );
+            sBatch += buf;
+        }
+        // ---- leg 2: SAM text of every read
+        auto pSink = std::make_shared<CountingSink>( );
+        FileWriter xWriter( xParams, std::static_pointer_cast<OutStream>( pSink ), pPack );
+        const unsigned uiSamThreads = std::min( 64u, uiHw );
+        t0 = now( );
+        {
+            std::atomic<size_t> uiNext{ 0 };
+            std::vector<std::thread> vT;
+            for( unsigned t = 0; t < uiSamThreads; t++ )
+                vT.emplace_back( [ & ]( ) {
+                    for( size_t i = uiNext++; i < n; i = uiNext++ )
+                        xWriter.execute( ( *pReads )[ i ], ( *pRes )[ i ], pPack );
+                } );
+            for( auto& t : vT )
+                t.join( );
+        }
+        const double fSam = now( ) - t0;
+        pRes.reset( );
+        // ---- leg 3: the unchanged per-read graph with many graph threads
+        auto pPackP = std::make_shared<Pledge<Pack>>( );
+        pPackP->set( pPack );
+        auto pFmP = std::make_shared<Pledge<FMIndex>>( );
+        pFmP->set( pFM );
+        auto pSai = std::make_shared<Pledge<SuffixArrayInterface>>( );
+        pSai->set( pFM );
+        auto pReader = std::make_shared<VecReader>( *pReads );
+        auto pSeeding = std::make_shared<BinarySeeding>( xParams );
+        auto pSOC = std::make_shared<StripOfConsideration>( xParams );
+        auto pHarm = std::make_shared<Harmonization>( xParams );
+        auto pDP = std::make_shared<NeedlemanWunsch>( xParams );
+        auto pMq = std::make_shared<MappingQuality>( xParams );
+        auto pSink2 = std::make_shared<CountingSink>( );
+        auto pWriter = std::make_shared<FileWriter>( xParams, std::static_pointer_cast<OutStream>( pSink2 ), pPack );
+        std::vector<std::shared_ptr<BasePledge>> vSinks;
+        for( int t = 0; t < iGraphThreads; t++ )
+        {
+            auto pQuery = promiseMe( std::make_shared<Lock<NucSeq>>( ), promiseMe( pReader ) );
+            auto pSeeds = promiseMe( pSeeding, pSai, pQuery );
+            auto pSOCs = promiseMe( pSOC, pSeeds, pQuery, pPackP, pFmP );
+            auto pHarmonized = promiseMe( pHarm, pSOCs, pQuery, pFmP );
+            auto pAlignments = promiseMe( pDP, pHarmonized, pQuery, pPackP );
+            auto pWithQuality = promiseMe( pMq, pQuery, pAlignments );
+            auto pWritten = promiseMe( pWriter, pQuery, pWithQuality, pPackP );
+            vSinks.push_back( promiseMe( std::make_shared<UnLock<Container>>( pQuery ), pWritten ) );
+        }
+        t0 = now( );
+        BasePledge::simultaneousGet( vSinks );
+        const double fGraph = now( ) - t0;
+        auto xStat = pSeeding->batchStatistics( );
+        printf( "{\"reads\": %zu, \"read_len\": %zu, \"host_threads\": %u, \"index_load_s\": %.2f, "
+                "\"batch_aligner\": {%s, \"what\": \"reads in host memory -> BatchAligner::execute (H2D, all stages, D2H, Alignment "
+                "containers); 256 k reads per device batch; phase times summed over the batches\"}, "
+                "\"sam\": {\"reads_per_s\": %.1f, \"threads\": %u, \"bytes\": %llu, \"what\": \"FileWriter::execute per read into a "
+                "counting sink\"}, "
+                "\"graph\": {\"reads_per_s\": %.1f, \"graph_threads\": %d, \"device_batches\": %llu, \"mean_reads_per_device_batch\": %.1f, "
+                "\"what\": \"the unchanged per-read graph (reader -> BinarySeeding -> StripOfConsideration -> Harmonization -> "
+                "NeedlemanWunsch -> MappingQuality -> FileWriter) on that many graph threads; per-read execute() calls funnelled into "
+                "device batches\"}}\n",
+                n, uiLen, uiHw, fLoad, sBatch.c_str( ), n / fSam, uiSamThreads, (unsigned long long)pSink->uiBytes.load( ), n / fGraph,
+                iGraphThreads, (unsigned long long)xStat.first, xStat.first ? (double)xStat.second / xStat.first : 0.0 );
+    }
+    catch( const std::exception& e )
+    {
+        fprintf( stderr, "error: %s\n", e.what( ) );
+        return 1;
+    }
+    return 0;
+}

@@ -99,6 +99,12 @@ typedef struct
 } ma_alignment;
 typedef struct
 {
+    uint64_t acc_len; /* SoCOrder (soc.h:26-90): accumulated seed length = the score the queue is ordered by */
+    uint32_t ambiguity, n_seeds; /* accumulated seed ambiguity (ties: more = smaller), seeds in the strip */
+    uint32_t begin, end; /* its seeds: [begin, end) of the read's seeds re-sorted by reference position (soc.h:196-231) */
+} ma_soc;
+typedef struct
+{
     int32_t qlen, tlen, w, zdrop, flag; /* kswcpp_dispatch arguments (kswcpp.h:165-190) */
     uint32_t reserved;
     uint64_t q_off, t_off; /* offsets into the query / target byte arrays handed to ma_ksw_batch */
@@ -169,6 +175,25 @@ int ma_chain_batch( ma_batch* ); /* StripOfConsiderationSeeds::execute + Harmoni
 int ma_dp_batch( ma_batch* ); /* NeedlemanWunsch::execute + MappingQuality::execute */
 int ma_align_batch( ma_batch* ); /* all four */
 int ma_batch_sync( ma_batch* ); /* wait for the stream; surfaces asynchronous kernel errors / capacity overflows */
+
+/* streams for callers that keep several batches in flight without including HIP headers (host layer: DeviceBatcher,
+ * MultiDeviceAligner); created on the index's device, non-blocking with respect to the default stream */
+int ma_stream_create( const ma_index*, void** out_hip_stream );
+int ma_stream_destroy( const ma_index*, void* hip_stream );
+
+/* stage INPUTS from the host: a module of this library takes over in the middle of a chain whose earlier stages ran
+ * elsewhere (e.g. the reference's BinarySeeding followed by the MI355X StripOfConsideration).  Reads must be set; each
+ * call replaces the output of the preceding stage (CSR offsets per read, records as the get functions return them). */
+int ma_batch_set_segments( ma_batch*, const uint64_t* seg_off /*n+1*/, const ma_segment* segs ); /* -> ma_extract_seeds_batch */
+int ma_batch_set_seeds( ma_batch*, const uint64_t* seed_off /*n+1*/, const ma_seed* seeds ); /* -> ma_chain_batch */
+int ma_batch_set_hsets( ma_batch*, const uint64_t* hset_off /*n+1*/, const uint64_t* hseed_off /*n_hsets+1*/,
+                        const uint32_t* hset_soc, const ma_seed* hseeds ); /* -> ma_dp_batch */
+/* The SoC queue of every read (StripOfConsiderationSeeds::execute stripOfConsideration.cpp:12-161; requires extracted
+ * seeds): socs[soc_off[r] .. soc_off[r+1]) are read r's strips in pop() order (SoCPriorityQueue::pop soc.h:240-284, i.e.
+ * index_of_strip = position), their seed ranges refer to sorted_seeds[seed_off[r] ..), the read's seeds re-sorted by
+ * reference position as rectangularSoC leaves them.  n_socs first (other pointers NULL), then the arrays. */
+int ma_batch_get_socs( ma_batch*, uint64_t* n_socs, uint64_t* soc_off /*n+1*/, ma_soc* socs, uint64_t* seed_off /*n+1*/,
+                       ma_seed* sorted_seeds );
 
 /* results: counts first, then download into caller-allocated arrays (any pointer may be NULL) */
 int ma_batch_counts( ma_batch*, uint64_t* n_segments, uint64_t* n_seeds, uint64_t* n_hsets, uint64_t* n_hseeds,

@@ -288,6 +288,28 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
     return nmx;
 }
 
+// The queue alone (SoCPriorityQueue across the boundary): sweep, then pop() until the heap is empty (soc.h:240-284).
+// work[] ends up sorted by reference position; out[k] = k-th popped strip.  Returns the number of strips.
+MA_HD u32 soc_dump_read( const IndexView& X, const ChainParams& P, ma_seed* work, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm,
+                         ma_soc* out )
+{
+    u32 nmx = soc_sweep( X, P, work, n, qlen, mx, mm );
+    u32 k = 0;
+    while( nmx > 0 )
+    {
+        const SoCEntry f = mx[ 0 ];
+        out[ k ].acc_len = f.accLen;
+        out[ k ].ambiguity = f.amb;
+        out[ k ].n_seeds = f.cnt;
+        out[ k ].begin = f.b;
+        out[ k ].end = f.e;
+        k++;
+        ss::pop_heap( mx, (i64)nmx, SoCHeapOrder( ) );
+        nmx--;
+    }
+    return k;
+}
+
 #define MA_PI_TRUNC 3.14159265 /* harmonization.h:23 (sic) */
 
 MA_HD double delta_distance( const ma_seed& s, const double fAngle, const i64 rStart, LibmProbe& lp ) // harmonization.h:82-89

@@ -449,6 +449,21 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4,
         atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
 }
 
+// the SoC queue of every read in pop order (ma_batch_get_socs); scratch and output carved by the read's seed offset
+__global__ void __launch_bounds__( 64 ) k_soc_dump( IndexView X, ChainParams P, u32 n_reads, const u64* roff, const u64* seed_off,
+                                                   const u32* seed_cnt, const ma_seed* seeds, ma_seed* work, SoCEntry* maxima,
+                                                   RefMinMax* mm, ma_soc* socs, u32* nsocs )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    const u64 off = seed_off[ r ];
+    const u32 n = seed_cnt[ r ];
+    for( u32 i = 0; i < n; i++ )
+        work[ off + i ] = seeds[ off + i ];
+    nsocs[ r ] = soc_dump_read( X, P, work + off, n, (u32)( roff[ r + 1 ] - roff[ r ] ), maxima + off, mm + off, socs + off );
+}
+
 // harmonized seeds of a read (sum of its sets' sizes), input of the scan that lays out the dense pool
 __global__ void k_hseed_counts( const HSet* sets, u32 set_cap, const u32* nsets, u32 n_reads, u64* cnt )
 {
@@ -1238,6 +1253,31 @@ static void glibc_srand_ring( u32 seed, u32 ring[ 31 ] )
     // after 310 = 10*31 steps f and r are back at 3 and 0
 }
 
+static ChainParams chain_params( const ma_params& P )
+{
+    ChainParams C;
+    C.max_num_soc = (u32)P.max_num_soc;
+    C.min_num_soc = (u32)P.min_num_soc;
+    C.harm_score_min = (u32)P.harm_score_min;
+    C.max_score_lookahead = (u32)P.max_score_lookahead;
+    C.switch_qlen = (u32)P.switch_qlen;
+    C.min_delta_dist = (u32)P.min_delta_dist;
+    C.sv_penalty = (u32)P.sv_penalty;
+    C.match = (u32)P.match;
+    C.gap = (u32)P.gap;
+    C.extend = (u32)P.extend;
+    C.disable_heuristics = (u32)P.disable_heuristics;
+    C.soc_width = (u32)P.soc_width;
+    C.genome_size_disable = P.genome_size_disable;
+    C.harm_score_min_rel = P.harm_score_min_rel;
+    C.soc_score_decrease_tol = P.soc_score_decrease_tol;
+    C.score_diff_tol = P.score_diff_tol;
+    C.max_delta_dist = P.max_delta_dist;
+    glibc_srand_ring( P.srand_seed, C.rng_ring );
+    C.libm_probe = (u32)P.libm_probe;
+    return C;
+}
+
 int ma_chain_batch( ma_batch* b )
 {
     if( !b || b->stage_done < 2 )
@@ -1265,25 +1305,7 @@ int ma_chain_batch( ma_batch* b )
         return 1;
     ChainKernelArgs A;
     A.X = b->idx->v;
-    A.P.max_num_soc = (u32)b->P.max_num_soc;
-    A.P.min_num_soc = (u32)b->P.min_num_soc;
-    A.P.harm_score_min = (u32)b->P.harm_score_min;
-    A.P.max_score_lookahead = (u32)b->P.max_score_lookahead;
-    A.P.switch_qlen = (u32)b->P.switch_qlen;
-    A.P.min_delta_dist = (u32)b->P.min_delta_dist;
-    A.P.sv_penalty = (u32)b->P.sv_penalty;
-    A.P.match = (u32)b->P.match;
-    A.P.gap = (u32)b->P.gap;
-    A.P.extend = (u32)b->P.extend;
-    A.P.disable_heuristics = (u32)b->P.disable_heuristics;
-    A.P.soc_width = (u32)b->P.soc_width;
-    A.P.genome_size_disable = b->P.genome_size_disable;
-    A.P.harm_score_min_rel = b->P.harm_score_min_rel;
-    A.P.soc_score_decrease_tol = b->P.soc_score_decrease_tol;
-    A.P.score_diff_tol = b->P.score_diff_tol;
-    A.P.max_delta_dist = b->P.max_delta_dist;
-    glibc_srand_ring( b->P.srand_seed, A.P.rng_ring );
-    A.P.libm_probe = (u32)b->P.libm_probe;
+    A.P = chain_params( b->P );
     A.n_reads = (u32)n;
     A.roff = b->d_roff;
     A.seed_off = b->seedOff.as<u64>( );
@@ -1517,6 +1539,206 @@ int ma_dp_batch( ma_batch* b )
     }
     MA_HIP( hipGetLastError( ) );
     b->stage_done = 4;
+    return 0;
+}
+
+// ---- streams -----------------------------------------------------------------------------------------------
+int ma_stream_create( const ma_index* x, void** out )
+{
+    if( !x || !out )
+        return fail( "ma_stream_create: null argument" );
+    MA_BIND_DEVICE( x->device );
+    hipStream_t s = nullptr;
+    MA_HIP( hipStreamCreateWithFlags( &s, hipStreamNonBlocking ) );
+    *out = (void*)s;
+    return 0;
+}
+int ma_stream_destroy( const ma_index* x, void* s )
+{
+    if( !x )
+        return fail( "ma_stream_destroy: null index" );
+    if( !s )
+        return 0;
+    MA_BIND_DEVICE( x->device );
+    MA_HIP( hipStreamDestroy( (hipStream_t)s ) );
+    return 0;
+}
+
+// ---- stage inputs from the host -------------------------------------------------------------------------------
+static int reset_ctr( ma_batch* b )
+{
+    MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
+    return 0;
+}
+// per-read counts (u32) and exclusive offsets (u64) from a host CSR
+static void csr_parts( const uint64_t* off, u64 n, std::vector<u64>& o, std::vector<u32>& c )
+{
+    o.resize( n + 1 );
+    c.resize( n + 1 );
+    for( u64 r = 0; r < n; r++ )
+    {
+        o[ r ] = off[ r ];
+        c[ r ] = (u32)( off[ r + 1 ] - off[ r ] );
+    }
+    o[ n ] = off[ n ];
+    c[ n ] = 0;
+}
+
+int ma_batch_set_segments( ma_batch* b, const uint64_t* seg_off, const ma_segment* segs )
+{
+    if( !b || !b->d_roff || !seg_off || ( seg_off[ b->n_reads ] && !segs ) )
+        return fail( "ma_batch_set_segments: no reads set or null argument" );
+    MA_BIND_DEVICE( b->device );
+    const u64 n = b->n_reads, ns = seg_off[ n ];
+    std::vector<u64> o;
+    std::vector<u32> c, rd( ns + 1 );
+    csr_parts( seg_off, n, o, c );
+    for( u64 r = 0; r < n; r++ )
+        for( u64 k = seg_off[ r ]; k < seg_off[ r + 1 ]; k++ )
+            rd[ k ] = (u32)r;
+    b->segPoolCap = std::max<u64>( ns + 1024, b->segPoolCap );
+    if( reset_ctr( b ) || b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
+        b->segOff.reserve( ( n + 1 ) * 8 ) || b->segCnt.reserve( ( n + 1 ) * 4 ) )
+        return 1;
+    if( ns )
+    {
+        MA_HIP( hipMemcpyAsync( b->segPool.p, segs, ns * sizeof( ma_segment ), hipMemcpyHostToDevice, b->stream ) );
+        MA_HIP( hipMemcpyAsync( b->segRead.p, rd.data( ), ns * 4, hipMemcpyHostToDevice, b->stream ) );
+    }
+    MA_HIP( hipMemcpyAsync( b->segOff.p, o.data( ), ( n + 1 ) * 8, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipMemcpyAsync( b->segCnt.p, c.data( ), ( n + 1 ) * 4, hipMemcpyHostToDevice, b->stream ) );
+    const unsigned long long used = ns;
+    MA_HIP( hipMemcpyAsync( b->ctr.as<unsigned long long>( ) + CTR_SEG_USED, &used, 8, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipStreamSynchronize( b->stream ) ); // the host vectors go out of scope
+    b->nSegs = ns;
+    b->nSeeds = b->nHsets = b->nHseeds = 0;
+    b->stage_done = 1;
+    return 0;
+}
+
+int ma_batch_set_seeds( ma_batch* b, const uint64_t* seed_off, const ma_seed* seeds )
+{
+    if( !b || !b->d_roff || !seed_off || ( seed_off[ b->n_reads ] && !seeds ) )
+        return fail( "ma_batch_set_seeds: no reads set or null argument" );
+    MA_BIND_DEVICE( b->device );
+    const u64 n = b->n_reads, total = seed_off[ n ];
+    std::vector<u64> o;
+    std::vector<u32> c;
+    csr_parts( seed_off, n, o, c );
+    if( reset_ctr( b ) || b->seeds.reserve( ( total + 1 ) * sizeof( ma_seed ) ) || b->seedOff.reserve( ( n + 1 ) * 8 ) ||
+        b->seedCnt.reserve( ( n + 1 ) * 4 ) )
+        return 1;
+    if( total )
+        MA_HIP( hipMemcpyAsync( b->seeds.p, seeds, total * sizeof( ma_seed ), hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipMemcpyAsync( b->seedOff.p, o.data( ), ( n + 1 ) * 8, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipMemcpyAsync( b->seedCnt.p, c.data( ), ( n + 1 ) * 4, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipStreamSynchronize( b->stream ) );
+    b->nSeeds = total;
+    b->nHsets = b->nHseeds = 0;
+    b->stage_done = 2;
+    return 0;
+}
+
+int ma_batch_set_hsets( ma_batch* b, const uint64_t* hset_off, const uint64_t* hseed_off, const uint32_t* hset_soc,
+                        const ma_seed* hseeds )
+{
+    if( !b || !b->d_roff || !hset_off )
+        return fail( "ma_batch_set_hsets: no reads set or null argument" );
+    const u64 n = b->n_reads, nh = hset_off[ n ];
+    if( nh && ( !hseed_off || !hset_soc ) )
+        return fail( "ma_batch_set_hsets: null argument" );
+    const u64 nhs = nh ? hseed_off[ nh ] : 0;
+    if( nhs && !hseeds )
+        return fail( "ma_batch_set_hsets: null argument" );
+    MA_BIND_DEVICE( b->device );
+    std::vector<HSet> flat( nh + 1 );
+    std::vector<u32> rd( nh + 1 );
+    for( u64 r = 0; r < n; r++ )
+        for( u64 s = hset_off[ r ]; s < hset_off[ r + 1 ]; s++ )
+        {
+            flat[ s ].off = hseed_off[ s ];
+            flat[ s ].cnt = (u32)( hseed_off[ s + 1 ] - hseed_off[ s ] );
+            flat[ s ].soc = hset_soc[ s ];
+            rd[ s ] = (u32)r;
+        }
+    if( reset_ctr( b ) || b->hsetFlat.reserve( ( nh + 1 ) * sizeof( HSet ) ) || b->hsetRead.reserve( ( nh + 1 ) * 4 ) ||
+        b->hdense.reserve( ( nhs + 1 ) * sizeof( ma_seed ) ) || b->hsetOff.reserve( ( n + 2 ) * 8 ) )
+        return 1;
+    if( nh )
+    {
+        MA_HIP( hipMemcpyAsync( b->hsetFlat.p, flat.data( ), nh * sizeof( HSet ), hipMemcpyHostToDevice, b->stream ) );
+        MA_HIP( hipMemcpyAsync( b->hsetRead.p, rd.data( ), nh * 4, hipMemcpyHostToDevice, b->stream ) );
+    }
+    if( nhs )
+        MA_HIP( hipMemcpyAsync( b->hdense.p, hseeds, nhs * sizeof( ma_seed ), hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipMemcpyAsync( b->hsetOff.p, hset_off, ( n + 1 ) * 8, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipStreamSynchronize( b->stream ) );
+    b->nHsets = nh;
+    b->nHseeds = nhs;
+    b->stage_done = 3;
+    return 0;
+}
+
+// ---- the SoC queue across the boundary ------------------------------------------------------------------------
+int ma_batch_get_socs( ma_batch* b, uint64_t* n_socs, uint64_t* soc_off, ma_soc* socs, uint64_t* seed_off, ma_seed* sorted_seeds )
+{
+    if( !b || b->stage_done < 2 )
+        return fail( "ma_batch_get_socs: run ma_extract_seeds_batch first" );
+    MA_BIND_DEVICE( b->device );
+    const u64 n = b->n_reads, ts = b->nSeeds + 1;
+    if( n_socs )
+        *n_socs = 0;
+    if( soc_off )
+        soc_off[ 0 ] = 0;
+    if( seed_off )
+        seed_off[ 0 ] = 0;
+    if( n == 0 )
+        return 0;
+    DevBuf dSocs, dN;
+    if( b->cWork.reserve( ts * sizeof( ma_seed ) ) || b->cMax.reserve( ts * sizeof( SoCEntry ) ) ||
+        b->cMm.reserve( ts * sizeof( RefMinMax ) ) || dSocs.reserve( ts * sizeof( ma_soc ) ) || dN.reserve( ( n + 1 ) * 4 ) )
+        return 1;
+    hipLaunchKernelGGL( k_soc_dump, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, b->idx->v, chain_params( b->P ),
+                        (u32)n, b->d_roff, b->seedOff.as<u64>( ), b->seedCnt.as<u32>( ), b->seeds.as<ma_seed>( ),
+                        b->cWork.as<ma_seed>( ), b->cMax.as<SoCEntry>( ), b->cMm.as<RefMinMax>( ), dSocs.as<ma_soc>( ),
+                        dN.as<u32>( ) );
+    MA_HIP( hipGetLastError( ) );
+    std::vector<u32> cnt( n ), scnt( n );
+    std::vector<u64> off( n );
+    MA_HIP( hipMemcpyAsync( cnt.data( ), dN.p, n * 4, hipMemcpyDeviceToHost, b->stream ) );
+    MA_HIP( hipMemcpyAsync( scnt.data( ), b->seedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream ) );
+    MA_HIP( hipMemcpyAsync( off.data( ), b->seedOff.p, n * 8, hipMemcpyDeviceToHost, b->stream ) );
+    MA_HIP( hipStreamSynchronize( b->stream ) );
+    u64 total = 0;
+    for( u64 r = 0; r < n; r++ )
+        total += cnt[ r ];
+    if( n_socs )
+        *n_socs = total;
+    if( !soc_off && !socs && !seed_off && !sorted_seeds )
+        return 0;
+    std::vector<ma_soc> hs( b->nSeeds + 1 );
+    std::vector<ma_seed> hw( b->nSeeds + 1 );
+    if( b->nSeeds )
+    {
+        MA_HIP( hipMemcpy( hs.data( ), dSocs.p, b->nSeeds * sizeof( ma_soc ), hipMemcpyDeviceToHost ) );
+        MA_HIP( hipMemcpy( hw.data( ), b->cWork.p, b->nSeeds * sizeof( ma_seed ), hipMemcpyDeviceToHost ) );
+    }
+    u64 so = 0, sd = 0;
+    for( u64 r = 0; r < n; r++ )
+    {
+        if( socs )
+            for( u32 k = 0; k < cnt[ r ]; k++ )
+                socs[ so + k ] = hs[ off[ r ] + k ];
+        if( sorted_seeds )
+            for( u32 k = 0; k < scnt[ r ]; k++ )
+                sorted_seeds[ sd + k ] = hw[ off[ r ] + k ];
+        so += cnt[ r ];
+        sd += scnt[ r ];
+        if( soc_off )
+            soc_off[ r + 1 ] = so;
+        if( seed_off )
+            seed_off[ r + 1 ] = sd;
+    }
     return 0;
 }
 

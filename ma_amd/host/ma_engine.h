@@ -1,0 +1,280 @@
+// ma_engine.h -- the host-side machinery between MA's per-read Module graph and the batch-oriented C ABI:
+//   Engine        one device batch (ma_batch) + one HIP stream on the device of its index: reads in host memory ->
+//                 H2D -> all four stages -> D2H of every stage's records (BatchResult), with the time of each phase
+//   DeviceBatcher thread-safe funnel: the graph threads of libMA::setUpCompGraph (export.cpp:84-126, one graph copy per
+//                 thread, every copy calling BinarySeeding::execute concurrently and lock-free, module.h:303-369) hand in
+//                 ONE read each and block; the reads that arrive while the GPU is busy form the next device batch, whose
+//                 results every waiting thread then picks its slice from (SURVEY 8(b) "Threading")
+// Nothing here computes: every stage runs on the GPU behind include/ma_amd.h; a non-zero status becomes
+// std::runtime_error like in the module wrappers.
+#pragma once
+#include "../../include/ma_amd.h"
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace libMA
+{
+namespace detail
+{
+inline void engineCheck( int rc )
+{
+    if( rc != 0 )
+        throw std::runtime_error( ma_last_error( ) );
+}
+inline double secondsSince( const std::chrono::steady_clock::time_point& t0 )
+{
+    return std::chrono::duration<double>( std::chrono::steady_clock::now( ) - t0 ).count( );
+}
+
+// Host copies of the records of one device batch, CSR by read (offset arrays have n + 1 entries).
+struct BatchResult
+{
+    size_t uiReads = 0;
+    bool bStages = false; // segments / seeds / harmonized sets / unsorted-quality alignments present?
+    std::vector<uint64_t> vSegOff, vSeedOff, vHsetOff, vHseedOff, vAlnOff, vMqOff;
+    std::vector<ma_segment> vSegs;
+    std::vector<ma_seed> vSeeds, vHseeds;
+    std::vector<uint32_t> vHsetSoc;
+    std::vector<ma_alignment> vAlns, vMq; // NeedlemanWunsch output / MappingQuality output
+    std::vector<uint64_t> vAlnOps, vMqOps; // (type, length) pairs
+    uint64_t uiAlignedReads = 0;
+    double fH2D = 0, fKernels = 0, fD2H = 0; // seconds
+};
+
+class Engine
+{
+    const ma_index* pIndex;
+    const ma_params xP;
+    ma_batch* pBatch = nullptr;
+    void* pStream = nullptr;
+    uint64_t uiCapReads = 0, uiCapBases = 0;
+    std::vector<uint8_t> vCodes;
+    std::vector<uint64_t> vOff;
+
+    void fit( uint64_t uiReads, uint64_t uiBases )
+    {
+        if( pBatch != nullptr && uiReads <= uiCapReads && uiBases <= uiCapBases )
+            return;
+        if( pBatch != nullptr )
+            ma_batch_destroy( pBatch );
+        pBatch = nullptr;
+        uiCapReads = std::max<uint64_t>( uiReads + uiReads / 4, 64 );
+        uiCapBases = std::max<uint64_t>( uiBases + uiBases / 4, 4096 );
+        engineCheck( ma_batch_create( pIndex, &xP, uiCapReads, uiCapBases + 64, &pBatch ) );
+        engineCheck( ma_batch_set_stream( pBatch, pStream ) );
+    }
+
+  public:
+    Engine( const ma_index* pIndex, const ma_params& rP ) : pIndex( pIndex ), xP( rP )
+    {
+        engineCheck( ma_stream_create( pIndex, &pStream ) );
+    }
+    Engine( const Engine& ) = delete;
+    Engine& operator=( const Engine& ) = delete;
+    ~Engine( )
+    {
+        if( pBatch != nullptr )
+            ma_batch_destroy( pBatch );
+        ma_stream_destroy( pIndex, pStream );
+    }
+
+    // vReads[i] = codes of read i (A0 C1 G2 T3 N4).  bStages: also fetch the records of the intermediate stages.
+    std::shared_ptr<BatchResult> run( const std::vector<const std::vector<uint8_t>*>& vReads, bool bStages )
+    {
+        auto pRes = std::make_shared<BatchResult>( );
+        BatchResult& R = *pRes;
+        const size_t n = vReads.size( );
+        R.uiReads = n;
+        R.bStages = bStages;
+        vOff.assign( n + 1, 0 );
+        for( size_t i = 0; i < n; i++ )
+            vOff[ i + 1 ] = vOff[ i ] + vReads[ i ]->size( );
+        vCodes.resize( vOff[ n ] + 1 );
+        for( size_t i = 0; i < n; i++ )
+            if( !vReads[ i ]->empty( ) )
+                std::copy( vReads[ i ]->begin( ), vReads[ i ]->end( ), vCodes.begin( ) + vOff[ i ] );
+        fit( n, vOff[ n ] );
+        auto t0 = std::chrono::steady_clock::now( );
+        engineCheck( ma_batch_set_reads( pBatch, vCodes.data( ), vOff.data( ), n ) );
+        R.fH2D = secondsSince( t0 );
+        t0 = std::chrono::steady_clock::now( );
+        engineCheck( ma_align_batch( pBatch ) );
+        engineCheck( ma_batch_sync( pBatch ) );
+        R.fKernels = secondsSince( t0 );
+        t0 = std::chrono::steady_clock::now( );
+        uint64_t nSeg = 0, nSeed = 0, nHset = 0, nHseed = 0, nAln = 0, nOps = 0;
+        engineCheck( ma_batch_counts( pBatch, &nSeg, &nSeed, &nHset, &nHseed, &nAln, &nOps, &R.uiAlignedReads ) );
+        if( bStages )
+        {
+            R.vSegOff.resize( n + 1 );
+            R.vSegs.resize( nSeg + 1 );
+            engineCheck( ma_batch_get_segments( pBatch, R.vSegOff.data( ), R.vSegs.data( ) ) );
+            R.vSeedOff.resize( n + 1 );
+            R.vSeeds.resize( nSeed + 1 );
+            engineCheck( ma_batch_get_seeds( pBatch, R.vSeedOff.data( ), R.vSeeds.data( ) ) );
+            R.vHsetOff.resize( n + 1 );
+            R.vHseedOff.resize( nHset + 1 );
+            R.vHsetSoc.resize( nHset + 1 );
+            R.vHseeds.resize( nHseed + 1 );
+            engineCheck( ma_batch_get_hsets( pBatch, R.vHsetOff.data( ), R.vHseedOff.data( ), R.vHsetSoc.data( ), R.vHseeds.data( ) ) );
+            R.vAlnOff.resize( n + 1 );
+            R.vAlns.resize( nAln + 1 );
+            R.vAlnOps.resize( 2 * nOps + 2 );
+            engineCheck( ma_batch_get_alignments( pBatch, R.vAlnOff.data( ), R.vAlns.data( ), R.vAlnOps.data( ) ) );
+        }
+        R.vMqOff.resize( n + 1 );
+        R.vMq.resize( nAln + 1 );
+        R.vMqOps.resize( 2 * nOps + 2 );
+        engineCheck( ma_batch_get_mapq_alignments( pBatch, R.vMqOff.data( ), R.vMq.data( ), R.vMqOps.data( ) ) );
+        R.fD2H = secondsSince( t0 );
+        return pRes;
+    }
+};
+
+// One read's place in a finished device batch.
+struct Ticket
+{
+    std::shared_ptr<const BatchResult> pResult;
+    size_t uiRead = 0;
+    explicit operator bool( ) const
+    {
+        return pResult != nullptr;
+    }
+};
+
+struct BatcherOptions
+{
+    size_t uiMaxBatch = 1u << 18; // reads per device batch at most
+    size_t uiEngines = 2; // device batches in flight (own stream each)
+    std::chrono::microseconds xGather{ 40 }; // an idle GPU still waits this long for more reads to arrive
+    std::chrono::microseconds xMaxWait{ 20000 }; // a read never waits longer than this for its batch to be sealed
+};
+
+class DeviceBatcher
+{
+    struct Slot
+    {
+        std::vector<const std::vector<uint8_t>*> vReads;
+        std::shared_ptr<const BatchResult> pResult;
+        std::string sError;
+        bool bSealed = false, bDone = false;
+    };
+    const ma_index* pIndex;
+    const ma_params xP;
+    const BatcherOptions xOpt;
+    std::mutex xMutex;
+    std::condition_variable xChanged;
+    std::shared_ptr<Slot> pOpen;
+    std::vector<std::unique_ptr<Engine>> vIdle; // engines not running a batch
+    size_t uiEnginesMade = 0, uiRunning = 0;
+    uint64_t uiBatches = 0, uiReadsTotal = 0;
+
+    // called with the lock held by the thread that sealed the slot; releases the lock while the GPU works
+    void runSealed( std::unique_lock<std::mutex>& rLock, const std::shared_ptr<Slot>& pSlot )
+    {
+        xChanged.wait( rLock, [ & ]( ) { return !vIdle.empty( ) || uiEnginesMade < xOpt.uiEngines; } );
+        std::unique_ptr<Engine> pEngine;
+        if( !vIdle.empty( ) )
+        {
+            pEngine = std::move( vIdle.back( ) );
+            vIdle.pop_back( );
+        }
+        else
+            uiEnginesMade++; // constructed below, outside the lock
+        uiRunning++;
+        rLock.unlock( );
+        try
+        {
+            if( pEngine == nullptr )
+                pEngine.reset( new Engine( pIndex, xP ) );
+            pSlot->pResult = pEngine->run( pSlot->vReads, true );
+        }
+        catch( const std::exception& rE )
+        {
+            pSlot->sError = rE.what( );
+            if( pSlot->sError.empty( ) )
+                pSlot->sError = "device batch failed";
+        }
+        rLock.lock( );
+        if( pEngine != nullptr )
+            vIdle.push_back( std::move( pEngine ) );
+        else
+            uiEnginesMade--;
+        uiRunning--;
+        uiBatches++;
+        uiReadsTotal += pSlot->vReads.size( );
+        pSlot->bDone = true;
+        xChanged.notify_all( );
+    }
+
+  public:
+    DeviceBatcher( const ma_index* pIndex, const ma_params& rP, const BatcherOptions& rOpt = BatcherOptions( ) )
+        : pIndex( pIndex ), xP( rP ), xOpt( rOpt )
+    {}
+    DeviceBatcher( const DeviceBatcher& ) = delete;
+
+    // Blocks until the batch that contains this read has been through all stages.  rCodes must stay alive meanwhile
+    // (the caller holds the NucSeq).  Re-entrant: called concurrently by all graph threads.
+    Ticket align( const std::vector<uint8_t>& rCodes )
+    {
+        std::unique_lock<std::mutex> xLock( xMutex );
+        if( pOpen == nullptr )
+            pOpen = std::make_shared<Slot>( );
+        std::shared_ptr<Slot> pSlot = pOpen;
+        const size_t uiMine = pSlot->vReads.size( );
+        pSlot->vReads.push_back( &rCodes );
+        auto seal = [ & ]( ) {
+            pSlot->bSealed = true;
+            if( pOpen == pSlot )
+                pOpen = nullptr;
+        };
+        if( pSlot->vReads.size( ) >= xOpt.uiMaxBatch )
+        {
+            seal( );
+            runSealed( xLock, pSlot );
+        }
+        else if( uiMine == 0 )
+        {
+            // the first read of a batch leads it: it seals the batch once a device slot is free and the arrivals have had
+            // a moment to gather (while all device slots are busy the batch simply keeps growing), or after xMaxWait
+            const auto tOpened = std::chrono::steady_clock::now( );
+            while( !pSlot->bSealed )
+            {
+                const auto tNow = std::chrono::steady_clock::now( );
+                const bool bGathered = tNow - tOpened >= xOpt.xGather;
+                if( ( bGathered && uiRunning < xOpt.uiEngines ) || tNow - tOpened >= xOpt.xMaxWait )
+                    break;
+                xChanged.wait_for( xLock, bGathered ? std::chrono::microseconds( 500 ) : xOpt.xGather );
+            }
+            if( !pSlot->bSealed )
+            {
+                seal( );
+                runSealed( xLock, pSlot );
+            }
+        }
+        xChanged.wait( xLock, [ & ]( ) { return pSlot->bDone; } );
+        if( !pSlot->sError.empty( ) )
+            throw std::runtime_error( pSlot->sError );
+        Ticket xT;
+        xT.pResult = pSlot->pResult;
+        xT.uiRead = uiMine;
+        return xT;
+    }
+
+    // statistics: device batches run so far, reads they carried
+    void stats( uint64_t& rBatches, uint64_t& rReads )
+    {
+        std::lock_guard<std::mutex> xLock( xMutex );
+        rBatches = uiBatches;
+        rReads = uiReadsTotal;
+    }
+};
+} // namespace detail
+} // namespace libMA

@@ -10,11 +10,14 @@
 //                                                                                            (mappingQuality.h:22-23)
 // so that libMA::setUpCompGraph (libs/ma/src/util/export.cpp:104-108) builds unchanged.  All compute
 // goes through the C ABI in include/ma_amd.h; a non-zero status becomes std::runtime_error (the
-// convention of module.h:339-377).  The per-read execute() runs a batch of one read on the GPU -- correct
-// but latency-bound; BatchAligner below is the throughput API (one ma_batch per call, 10^5..10^6 reads).
+// convention of module.h:339-377).  The per-read execute() calls of all graph threads are funnelled into device batches
+// (ma_engine.h: DeviceBatcher); BatchAligner / MultiDeviceAligner below are the throughput APIs for callers that hold
+// many reads at once (one or several GPUs, 10^5..10^6 reads per device batch).
 #pragma once
 #include "../../include/ma_amd.h"
 #include "ms_graph.h"
+#include "ma_engine.h"
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <tuple>
@@ -420,17 +423,10 @@ inline void storeIndex( const std::string& sPrefix, const std::shared_ptr<Pack>&
     }
 }
 
-// Stage outputs keep the device batch alive so the next module continues where this one stopped.
-struct DeviceBatch
-{
-    ma_batch* p = nullptr;
-    ~DeviceBatch( )
-    {
-        if( p )
-            ma_batch_destroy( p );
-    }
-};
-
+// Every stage output remembers, where it has one, the device batch its read was part of (a Ticket): the next module then
+// only picks the read's slice of records that are already in host memory.  A container WITHOUT a ticket -- built by client
+// code or by a module of the reference -- is uploaded instead and the stage runs for it alone (stage inputs of the C ABI:
+// ma_batch_set_segments / _seeds / _hsets), so the MI355X modules can replace the reference's one stage at a time.
 class Segment : public libMS::Container // segment.h:31-113
 {
   public:
@@ -448,11 +444,15 @@ class Segment : public libMS::Container // segment.h:31-113
     {
         return iStart + iSize;
     }
+    SAInterval saInterval( ) const
+    {
+        return SAInterval( saStart, saStartRevComp, saSize );
+    }
 };
 class SegmentVector : public libMS::Container, public std::vector<Segment> // segment.h:126-399
 {
   public:
-    std::shared_ptr<DeviceBatch> pBatch;
+    detail::Ticket xTicket;
 };
 class Seed : public libMS::Container // seed.h:34-46
 {
@@ -460,6 +460,7 @@ class Seed : public libMS::Container // seed.h:34-46
     nucSeqIndex iStart = 0, iSize = 0, uiPosOnReference = 0, uiDelta = 0;
     unsigned int uiAmbiguity = 0;
     bool bOnForwStrand = true;
+    nucSeqIndex uiSoCNt = 0; // accumulated length of the strip the seed was popped with (soc.h:276)
     nucSeqIndex start( ) const
     {
         return iStart;
@@ -478,14 +479,121 @@ class Seeds : public libMS::Container, public std::vector<Seed> // seed.h:249-63
   public:
     unsigned int index_of_strip = 0; // xStats.index_of_strip
 };
-class SoCPriorityQueue : public libMS::Container // soc.h:96-420; here an opaque handle on the extracted seeds
+namespace detail
 {
-  public:
-    std::shared_ptr<DeviceBatch> pBatch;
-    std::shared_ptr<Seeds> pSeeds; // seeds after ExtractSeeds (read-only view)
-    bool empty( ) const
+inline Seed toSeed( const ma_seed& r )
+{
+    Seed s;
+    s.iStart = r.q_start, s.iSize = r.len, s.uiPosOnReference = r.r_start;
+    s.uiDelta = r.delta, s.uiAmbiguity = r.ambiguity, s.bOnForwStrand = r.on_forward != 0;
+    return s;
+}
+inline ma_seed fromSeed( const Seed& s )
+{
+    ma_seed r;
+    r.q_start = (int64_t)s.iStart, r.len = (int64_t)s.iSize, r.r_start = (int64_t)s.uiPosOnReference;
+    r.delta = (int64_t)s.uiDelta, r.ambiguity = s.uiAmbiguity, r.on_forward = s.bOnForwStrand ? 1 : 0;
+    return r;
+}
+// a device batch of exactly one read for the stage-at-a-time path
+struct SingleRead
+{
+    ma_batch* p = nullptr;
+    SingleRead( const ma_index* pIndex, const ma_params& rP, const NucSeq& rQuery )
     {
-        return pSeeds == nullptr || pSeeds->empty( );
+        maCheck( ma_batch_create( pIndex, &rP, 1, rQuery.length( ) + 64, &p ) );
+        const uint64_t off[ 2 ] = { 0, rQuery.length( ) };
+        const uint8_t dummy = 0;
+        try
+        {
+            maCheck( ma_batch_set_reads( p, rQuery.length( ) ? rQuery.xCodes.data( ) : &dummy, off, 1 ) );
+        }
+        catch( ... )
+        {
+            ma_batch_destroy( p );
+            throw;
+        }
+    }
+    SingleRead( const SingleRead& ) = delete;
+    ~SingleRead( )
+    {
+        ma_batch_destroy( p );
+    }
+};
+} // namespace detail
+
+// SoCPriorityQueue (soc.h:96-420): the strips of consideration of one read, best first.  pSeeds are the read's extracted
+// seeds (ExtractSeeds order); pop() / empty() / size() serve the queue itself, which the device computes on demand
+// (ma_batch_get_socs: the sweep of stripOfConsideration.cpp:12-161 and the heap pops of soc.h:240-284 run on the GPU,
+// here the strips are only handed out).
+class SoCPriorityQueue : public libMS::Container
+{
+    std::vector<ma_soc> vSocs;
+    std::vector<ma_seed> vSorted;
+    size_t uiNext = 0;
+    bool bHaveQueue = false;
+    void ensureQueue( )
+    {
+        if( bHaveQueue )
+            return;
+        bHaveQueue = true;
+        if( pSeeds == nullptr || pSeeds->empty( ) )
+            return;
+        if( pIndex == nullptr || pQuery == nullptr )
+            throw std::runtime_error( "SoCPriorityQueue: the queue was not produced by StripOfConsideration" );
+        detail::SingleRead xB( pIndex->p, xP, *pQuery );
+        std::vector<ma_seed> v;
+        for( const Seed& s : *pSeeds )
+            v.push_back( detail::fromSeed( s ) );
+        const uint64_t off[ 2 ] = { 0, v.size( ) };
+        maCheck( ma_batch_set_seeds( xB.p, off, v.data( ) ) );
+        uint64_t nSocs = 0;
+        maCheck( ma_batch_get_socs( xB.p, &nSocs, nullptr, nullptr, nullptr, nullptr ) );
+        vSocs.resize( nSocs + 1 );
+        vSorted.resize( v.size( ) + 1 );
+        uint64_t so[ 2 ], sd[ 2 ];
+        maCheck( ma_batch_get_socs( xB.p, &nSocs, so, vSocs.data( ), sd, vSorted.data( ) ) );
+        vSocs.resize( nSocs );
+    }
+
+  public:
+    detail::Ticket xTicket;
+    std::shared_ptr<Seeds> pSeeds; // seeds after ExtractSeeds (read-only view)
+    std::shared_ptr<DeviceIndex> pIndex;
+    std::shared_ptr<NucSeq> pQuery;
+    ma_params xP;
+    bool empty( )
+    {
+        ensureQueue( );
+        return uiNext >= vSocs.size( );
+    }
+    size_t size( )
+    {
+        ensureQueue( );
+        return vSocs.size( ) - uiNext;
+    }
+    // score and ambiguity of the strip pop() would return next (std::get<0>( vMaxima.front( ) ), soc.h:192)
+    std::pair<nucSeqIndex, unsigned int> front( )
+    {
+        ensureQueue( );
+        if( uiNext >= vSocs.size( ) )
+            throw std::runtime_error( "SoCPriorityQueue::front on an empty queue" );
+        return std::make_pair( (nucSeqIndex)vSocs[ uiNext ].acc_len, (unsigned int)vSocs[ uiNext ].ambiguity );
+    }
+    std::shared_ptr<Seeds> pop( ) // soc.h:240-284
+    {
+        ensureQueue( );
+        if( uiNext >= vSocs.size( ) )
+            throw std::runtime_error( "SoCPriorityQueue::pop on an empty queue" );
+        const ma_soc& rSoc = vSocs[ uiNext ];
+        auto pRet = std::make_shared<Seeds>( );
+        pRet->index_of_strip = (unsigned int)uiNext++;
+        for( uint32_t i = rSoc.begin; i < rSoc.end; i++ )
+        {
+            pRet->push_back( detail::toSeed( vSorted[ i ] ) );
+            pRet->back( ).uiSoCNt = rSoc.acc_len;
+        }
+        return pRet;
     }
 };
 enum MatchType // alignment.h:39-46
@@ -581,148 +689,232 @@ typedef libMS::ContainerVector<std::shared_ptr<Seeds>> SeedsSetVector;
 class AlignmentVector : public libMS::ContainerVector<std::shared_ptr<Alignment>>
 {
   public:
-    std::shared_ptr<DeviceBatch> pBatch;
+    detail::Ticket xTicket;
+    // stage-at-a-time path: the MappingQuality view of the same DP run (computed together on the device)
+    std::shared_ptr<libMS::ContainerVector<std::shared_ptr<Alignment>>> pStandalone;
 };
 class HarmonizedSets : public SeedsSetVector
 {
   public:
-    std::shared_ptr<DeviceBatch> pBatch;
+    detail::Ticket xTicket;
 };
 
 namespace detail
 {
-inline std::shared_ptr<DeviceBatch> requireBatch( const std::shared_ptr<DeviceBatch>& p, const char* sWho )
+// alignment records [uiFrom, uiTo) of a download -> Alignment containers
+inline void appendAlignments( const std::vector<ma_alignment>& vAlns, const std::vector<uint64_t>& vOps, uint64_t uiFrom,
+                              uint64_t uiTo, bool bMapq, libMS::ContainerVector<std::shared_ptr<Alignment>>& rOut )
 {
-    if( p == nullptr || p->p == nullptr )
-        throw std::runtime_error( std::string( sWho ) +
-                                  ": input container was not produced by the preceding MI355X module of this graph" );
-    return p;
+    for( uint64_t i = uiFrom; i < uiTo; i++ )
+    {
+        const ma_alignment& r = vAlns[ i ];
+        auto pA = std::make_shared<Alignment>( );
+        pA->uiBeginOnRef = r.begin_ref;
+        pA->uiEndOnRef = r.end_ref;
+        pA->uiBeginOnQuery = r.begin_q;
+        pA->uiEndOnQuery = r.end_q;
+        pA->iScore = r.score;
+        pA->index_of_strip = r.soc_index;
+        pA->bSecondary = r.secondary != 0;
+        pA->bSupplementary = r.supplementary != 0;
+        pA->fMappingQuality = bMapq ? r.mapq : NAN;
+        pA->data.reserve( r.n_ops );
+        for( uint32_t k = 0; k < r.n_ops; k++ )
+            pA->data.emplace_back( (MatchType)vOps[ 2 * ( r.ops_off + k ) ], vOps[ 2 * ( r.ops_off + k ) + 1 ] );
+        rOut.push_back( pA );
+    }
 }
-inline void fillAlignments( ma_batch* b, bool bMapq, libMS::ContainerVector<std::shared_ptr<Alignment>>& out )
+inline void downloadAlignments( ma_batch* b, bool bMapq, libMS::ContainerVector<std::shared_ptr<Alignment>>& rOut )
 {
     uint64_t nAln = 0, nOps = 0;
     maCheck( ma_batch_counts( b, nullptr, nullptr, nullptr, nullptr, &nAln, &nOps, nullptr ) );
     std::vector<uint64_t> off( 2 ), ops( 2 * nOps + 2 );
     std::vector<ma_alignment> alns( nAln + 1 );
     maCheck( ( bMapq ? ma_batch_get_mapq_alignments : ma_batch_get_alignments )( b, off.data( ), alns.data( ), ops.data( ) ) );
-    for( uint64_t i = 0; i < off[ 1 ]; i++ )
+    appendAlignments( alns, ops, 0, off[ 1 ], bMapq, rOut );
+}
+// harmonized sets of one read out of CSR arrays
+inline void appendHsets( const std::vector<uint64_t>& vHseedOff, const std::vector<uint32_t>& vSoc, const std::vector<ma_seed>& vSeeds,
+                         uint64_t uiFrom, uint64_t uiTo, SeedsSetVector& rOut )
+{
+    for( uint64_t h = uiFrom; h < uiTo; h++ )
     {
-        auto pA = std::make_shared<Alignment>( );
-        pA->uiBeginOnRef = alns[ i ].begin_ref;
-        pA->uiEndOnRef = alns[ i ].end_ref;
-        pA->uiBeginOnQuery = alns[ i ].begin_q;
-        pA->uiEndOnQuery = alns[ i ].end_q;
-        pA->iScore = alns[ i ].score;
-        pA->index_of_strip = alns[ i ].soc_index;
-        pA->bSecondary = alns[ i ].secondary != 0;
-        pA->bSupplementary = alns[ i ].supplementary != 0;
-        pA->fMappingQuality = bMapq ? alns[ i ].mapq : NAN;
-        for( uint32_t k = 0; k < alns[ i ].n_ops; k++ )
-            pA->data.emplace_back( (MatchType)ops[ 2 * ( alns[ i ].ops_off + k ) ], ops[ 2 * ( alns[ i ].ops_off + k ) + 1 ] );
-        out.push_back( pA );
+        auto pS = std::make_shared<Seeds>( );
+        pS->index_of_strip = vSoc[ h ];
+        for( uint64_t i = vHseedOff[ h ]; i < vHseedOff[ h + 1 ]; i++ )
+            pS->push_back( toSeed( vSeeds[ i ] ) );
+        rOut.push_back( pS );
     }
 }
+// harmonized sets of one read -> CSR arrays for ma_batch_set_hsets
+inline void uploadHsets( ma_batch* b, const SeedsSetVector& rSets )
+{
+    std::vector<uint64_t> hoff{ 0, rSets.size( ) }, soff{ 0 };
+    std::vector<uint32_t> soc;
+    std::vector<ma_seed> v;
+    for( const auto& pS : rSets )
+    {
+        soc.push_back( pS->index_of_strip );
+        for( const Seed& s : *pS )
+            v.push_back( fromSeed( s ) );
+        soff.push_back( v.size( ) );
+    }
+    soc.push_back( 0 );
+    v.push_back( ma_seed( ) );
+    maCheck( ma_batch_set_hsets( b, hoff.data( ), soff.data( ), soc.data( ), v.data( ) ) );
+}
 } // namespace detail
+
+// Options of the funnel behind the per-read modules (process-wide default; a BinarySeeding instance copies it when it
+// opens its batcher)
+inline detail::BatcherOptions& defaultBatcherOptions( )
+{
+    static detail::BatcherOptions xOptions;
+    return xOptions;
+}
 
 class BinarySeeding : public libMS::Module<SegmentVector, false, SuffixArrayInterface, NucSeq>
 {
     ma_params xP;
+    std::mutex xBatcherMutex;
+    std::shared_ptr<DeviceIndex> pBatcherIndex;
+    std::shared_ptr<detail::DeviceBatcher> pBatcher;
+
+    std::shared_ptr<detail::DeviceBatcher> batcherFor( const std::shared_ptr<DeviceIndex>& pDev )
+    {
+        std::lock_guard<std::mutex> xGuard( xBatcherMutex );
+        if( pBatcher == nullptr || pBatcherIndex != pDev )
+        {
+            pBatcher = std::make_shared<detail::DeviceBatcher>( pDev->p, xP, defaultBatcherOptions( ) );
+            pBatcherIndex = pDev;
+        }
+        return pBatcher;
+    }
 
   public:
     BinarySeeding( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) )
     {}
-    // binarySeeding.cpp:86-178
+    // binarySeeding.cpp:86-178.  Called concurrently by all graph threads: the reads of the callers that arrive together
+    // go through the device as ONE batch, and through all stages at once (the modules downstream pick their slices).
     virtual std::shared_ptr<SegmentVector> execute( std::shared_ptr<SuffixArrayInterface> pFM_index,
                                                     std::shared_ptr<NucSeq> pQuerySeq ) override
     {
         auto pRet = std::make_shared<SegmentVector>( );
         if( pQuerySeq == nullptr )
             return pRet;
-        pRet->pBatch = std::make_shared<DeviceBatch>( );
-        maCheck( ma_batch_create( pFM_index->pDev->p, &xP, 1, pQuerySeq->length( ) + 64, &pRet->pBatch->p ) );
-        const uint64_t off[ 2 ] = { 0, pQuerySeq->length( ) };
-        const uint8_t dummy = 0;
-        maCheck( ma_batch_set_reads( pRet->pBatch->p, pQuerySeq->length( ) ? pQuerySeq->xCodes.data( ) : &dummy, off, 1 ) );
-        maCheck( ma_seed_batch( pRet->pBatch->p ) );
-        uint64_t nSeg = 0;
-        maCheck( ma_batch_counts( pRet->pBatch->p, &nSeg, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr ) );
-        std::vector<ma_segment> segs( nSeg + 1 );
-        uint64_t so[ 2 ];
-        maCheck( ma_batch_get_segments( pRet->pBatch->p, so, segs.data( ) ) );
-        for( uint64_t i = 0; i < so[ 1 ]; i++ )
+        pRet->xTicket = batcherFor( pFM_index->pDev )->align( pQuerySeq->xCodes );
+        const detail::BatchResult& R = *pRet->xTicket.pResult;
+        for( uint64_t i = R.vSegOff[ pRet->xTicket.uiRead ]; i < R.vSegOff[ pRet->xTicket.uiRead + 1 ]; i++ )
         {
             Segment s;
-            s.iStart = segs[ i ].q_start;
-            s.iSize = segs[ i ].q_size;
-            s.saStart = segs[ i ].sa_start;
-            s.saStartRevComp = segs[ i ].sa_start_rc;
-            s.saSize = segs[ i ].sa_size;
+            s.iStart = R.vSegs[ i ].q_start;
+            s.iSize = R.vSegs[ i ].q_size;
+            s.saStart = R.vSegs[ i ].sa_start;
+            s.saStartRevComp = R.vSegs[ i ].sa_start_rc;
+            s.saSize = R.vSegs[ i ].sa_size;
             pRet->push_back( s );
         }
         return pRet;
+    }
+    // device batches run so far and the reads they carried (diagnostics)
+    std::pair<uint64_t, uint64_t> batchStatistics( )
+    {
+        std::lock_guard<std::mutex> xGuard( xBatcherMutex );
+        uint64_t b = 0, r = 0;
+        if( pBatcher != nullptr )
+            pBatcher->stats( b, r );
+        return std::make_pair( b, r );
     }
 };
 
 class StripOfConsideration : public libMS::Module<SoCPriorityQueue, false, SegmentVector, NucSeq, Pack, FMIndex>
 {
+    const ma_params xP;
+
   public:
-    StripOfConsideration( const ParameterSetManager& )
+    StripOfConsideration( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) )
     {}
-    // stripOfConsideration.cpp:162-173 (ExtractSeeds; the sweep itself runs fused with Harmonization on the device)
-    virtual std::shared_ptr<SoCPriorityQueue> execute( std::shared_ptr<SegmentVector> pSegments, std::shared_ptr<NucSeq>,
-                                                       std::shared_ptr<Pack>, std::shared_ptr<FMIndex> ) override
+    // stripOfConsideration.cpp:162-173: ExtractSeeds here; the sweep runs fused with Harmonization on the device and is
+    // materialised only if somebody pops the queue
+    virtual std::shared_ptr<SoCPriorityQueue> execute( std::shared_ptr<SegmentVector> pSegments, std::shared_ptr<NucSeq> pQuery,
+                                                       std::shared_ptr<Pack>, std::shared_ptr<FMIndex> pFM_index ) override
     {
         auto pRet = std::make_shared<SoCPriorityQueue>( );
-        pRet->pBatch = detail::requireBatch( pSegments->pBatch, "StripOfConsideration" );
-        maCheck( ma_extract_seeds_batch( pRet->pBatch->p ) );
+        pRet->pSeeds = std::make_shared<Seeds>( );
+        pRet->pIndex = pFM_index->pDev;
+        pRet->pQuery = pQuery;
+        pRet->xP = xP;
+        if( pSegments->xTicket )
+        {
+            pRet->xTicket = pSegments->xTicket;
+            const detail::BatchResult& R = *pRet->xTicket.pResult;
+            for( uint64_t i = R.vSeedOff[ pRet->xTicket.uiRead ]; i < R.vSeedOff[ pRet->xTicket.uiRead + 1 ]; i++ )
+                pRet->pSeeds->push_back( detail::toSeed( R.vSeeds[ i ] ) );
+            return pRet;
+        }
+        // segments from elsewhere (e.g. the reference's BinarySeeding): upload them, extract on the device
+        detail::SingleRead xB( pFM_index->pDev->p, xP, *pQuery );
+        std::vector<ma_segment> vSegs;
+        for( const Segment& s : *pSegments )
+        {
+            ma_segment r;
+            r.q_start = (int64_t)s.iStart, r.q_size = (int64_t)s.iSize;
+            r.sa_start = s.saStart, r.sa_start_rc = s.saStartRevComp, r.sa_size = s.saSize;
+            vSegs.push_back( r );
+        }
+        const uint64_t off[ 2 ] = { 0, vSegs.size( ) };
+        vSegs.push_back( ma_segment( ) );
+        maCheck( ma_batch_set_segments( xB.p, off, vSegs.data( ) ) );
+        maCheck( ma_extract_seeds_batch( xB.p ) );
         uint64_t nSeeds = 0;
-        maCheck( ma_batch_counts( pRet->pBatch->p, nullptr, &nSeeds, nullptr, nullptr, nullptr, nullptr, nullptr ) );
+        maCheck( ma_batch_counts( xB.p, nullptr, &nSeeds, nullptr, nullptr, nullptr, nullptr, nullptr ) );
         std::vector<ma_seed> v( nSeeds + 1 );
         uint64_t so[ 2 ];
-        maCheck( ma_batch_get_seeds( pRet->pBatch->p, so, v.data( ) ) );
-        pRet->pSeeds = std::make_shared<Seeds>( );
+        maCheck( ma_batch_get_seeds( xB.p, so, v.data( ) ) );
         for( uint64_t i = 0; i < so[ 1 ]; i++ )
-        {
-            Seed s;
-            s.iStart = v[ i ].q_start, s.iSize = v[ i ].len, s.uiPosOnReference = v[ i ].r_start;
-            s.uiDelta = v[ i ].delta, s.uiAmbiguity = v[ i ].ambiguity, s.bOnForwStrand = v[ i ].on_forward != 0;
-            pRet->pSeeds->push_back( s );
-        }
+            pRet->pSeeds->push_back( detail::toSeed( v[ i ] ) );
         return pRet;
     }
 };
 
 class Harmonization : public libMS::Module<SeedsSetVector, false, SoCPriorityQueue, NucSeq, FMIndex>
 {
+    const ma_params xP;
+
   public:
-    Harmonization( const ParameterSetManager& )
+    Harmonization( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) )
     {}
     // harmonization.cpp:374-555 (+ the SoC sweep of stripOfConsideration.cpp:12-161)
-    virtual std::shared_ptr<SeedsSetVector> execute( std::shared_ptr<SoCPriorityQueue> pSoCIn, std::shared_ptr<NucSeq>,
-                                                     std::shared_ptr<FMIndex> ) override
+    virtual std::shared_ptr<SeedsSetVector> execute( std::shared_ptr<SoCPriorityQueue> pSoCIn, std::shared_ptr<NucSeq> pQuery,
+                                                     std::shared_ptr<FMIndex> pFM_index ) override
     {
         auto pRet = std::make_shared<HarmonizedSets>( );
-        pRet->pBatch = detail::requireBatch( pSoCIn->pBatch, "Harmonization" );
-        maCheck( ma_chain_batch( pRet->pBatch->p ) );
+        if( pSoCIn->xTicket )
+        {
+            pRet->xTicket = pSoCIn->xTicket;
+            const detail::BatchResult& R = *pRet->xTicket.pResult;
+            detail::appendHsets( R.vHseedOff, R.vHsetSoc, R.vHseeds, R.vHsetOff[ pRet->xTicket.uiRead ],
+                                 R.vHsetOff[ pRet->xTicket.uiRead + 1 ], *pRet );
+            return pRet;
+        }
+        // a queue from elsewhere: its seeds are uploaded, sweep + harmonization run on the device
+        if( pSoCIn->pSeeds == nullptr )
+            throw std::runtime_error( "Harmonization: the SoC queue carries no seeds" );
+        detail::SingleRead xB( pFM_index->pDev->p, xP, *pQuery );
+        std::vector<ma_seed> v;
+        for( const Seed& s : *pSoCIn->pSeeds )
+            v.push_back( detail::fromSeed( s ) );
+        const uint64_t off[ 2 ] = { 0, v.size( ) };
+        v.push_back( ma_seed( ) );
+        maCheck( ma_batch_set_seeds( xB.p, off, v.data( ) ) );
+        maCheck( ma_chain_batch( xB.p ) );
         uint64_t nSets = 0, nSeeds = 0;
-        maCheck( ma_batch_counts( pRet->pBatch->p, nullptr, nullptr, &nSets, &nSeeds, nullptr, nullptr, nullptr ) );
+        maCheck( ma_batch_counts( xB.p, nullptr, nullptr, &nSets, &nSeeds, nullptr, nullptr, nullptr ) );
         std::vector<uint64_t> hoff( 2 ), soff( nSets + 1 );
         std::vector<uint32_t> soc( nSets + 1 );
-        std::vector<ma_seed> v( nSeeds + 1 );
-        maCheck( ma_batch_get_hsets( pRet->pBatch->p, hoff.data( ), soff.data( ), soc.data( ), v.data( ) ) );
-        for( uint64_t h = 0; h < nSets; h++ )
-        {
-            auto pS = std::make_shared<Seeds>( );
-            pS->index_of_strip = soc[ h ];
-            for( uint64_t i = soff[ h ]; i < soff[ h + 1 ]; i++ )
-            {
-                Seed s;
-                s.iStart = v[ i ].q_start, s.iSize = v[ i ].len, s.uiPosOnReference = v[ i ].r_start;
-                s.uiDelta = v[ i ].delta, s.uiAmbiguity = v[ i ].ambiguity, s.bOnForwStrand = v[ i ].on_forward != 0;
-                pS->push_back( s );
-            }
-            pRet->push_back( pS );
-        }
+        std::vector<ma_seed> hs( nSeeds + 1 );
+        maCheck( ma_batch_get_hsets( xB.p, hoff.data( ), soff.data( ), soc.data( ), hs.data( ) ) );
+        detail::appendHsets( soff, soc, hs, 0, nSets, *pRet );
         return pRet;
     }
 };
@@ -730,18 +922,32 @@ class Harmonization : public libMS::Module<SeedsSetVector, false, SoCPriorityQue
 class NeedlemanWunsch
     : public libMS::Module<libMS::ContainerVector<std::shared_ptr<Alignment>>, false, SeedsSetVector, NucSeq, Pack>
 {
+    const ma_params xP;
+
   public:
-    NeedlemanWunsch( const ParameterSetManager& )
+    NeedlemanWunsch( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) )
     {}
     // needlemanWunsch.h:111-134
     virtual std::shared_ptr<libMS::ContainerVector<std::shared_ptr<Alignment>>>
-    execute( std::shared_ptr<SeedsSetVector> pSeedSets, std::shared_ptr<NucSeq>, std::shared_ptr<Pack> ) override
+    execute( std::shared_ptr<SeedsSetVector> pSeedSets, std::shared_ptr<NucSeq> pQuery, std::shared_ptr<Pack> pPack ) override
     {
         auto pIn = std::dynamic_pointer_cast<HarmonizedSets>( pSeedSets );
         auto pRet = std::make_shared<AlignmentVector>( );
-        pRet->pBatch = detail::requireBatch( pIn ? pIn->pBatch : nullptr, "NeedlemanWunsch" );
-        maCheck( ma_dp_batch( pRet->pBatch->p ) );
-        detail::fillAlignments( pRet->pBatch->p, false, *pRet );
+        if( pIn != nullptr && pIn->xTicket )
+        {
+            pRet->xTicket = pIn->xTicket;
+            const detail::BatchResult& R = *pRet->xTicket.pResult;
+            detail::appendAlignments( R.vAlns, R.vAlnOps, R.vAlnOff[ pRet->xTicket.uiRead ], R.vAlnOff[ pRet->xTicket.uiRead + 1 ],
+                                      false, *pRet );
+            return pRet;
+        }
+        // seed sets from elsewhere: upload, run the DP stage (+ mapping quality, fetched by MappingQuality if it follows)
+        detail::SingleRead xB( pPack->pDev->p, xP, *pQuery );
+        detail::uploadHsets( xB.p, *pSeedSets );
+        maCheck( ma_dp_batch( xB.p ) );
+        detail::downloadAlignments( xB.p, false, *pRet );
+        pRet->pStandalone = std::make_shared<libMS::ContainerVector<std::shared_ptr<Alignment>>>( );
+        detail::downloadAlignments( xB.p, true, *pRet->pStandalone );
         return pRet;
     }
 };
@@ -752,15 +958,28 @@ class MappingQuality : public libMS::Module<libMS::ContainerVector<std::shared_p
   public:
     MappingQuality( const ParameterSetManager& )
     {}
-    // mappingQuality.cpp:11-131 (computed on the device together with the DP stage; fetched here)
+    // mappingQuality.cpp:11-131: computed on the device together with the DP stage; handed out here
     virtual std::shared_ptr<libMS::ContainerVector<std::shared_ptr<Alignment>>>
     execute( std::shared_ptr<NucSeq>, std::shared_ptr<libMS::ContainerVector<std::shared_ptr<Alignment>>> pAlignments ) override
     {
         auto pIn = std::dynamic_pointer_cast<AlignmentVector>( pAlignments );
         auto pRet = std::make_shared<AlignmentVector>( );
-        pRet->pBatch = detail::requireBatch( pIn ? pIn->pBatch : nullptr, "MappingQuality" );
-        detail::fillAlignments( pRet->pBatch->p, true, *pRet );
-        return pRet;
+        if( pIn != nullptr && pIn->xTicket )
+        {
+            pRet->xTicket = pIn->xTicket;
+            const detail::BatchResult& R = *pRet->xTicket.pResult;
+            detail::appendAlignments( R.vMq, R.vMqOps, R.vMqOff[ pRet->xTicket.uiRead ], R.vMqOff[ pRet->xTicket.uiRead + 1 ], true,
+                                      *pRet );
+            return pRet;
+        }
+        if( pIn != nullptr && pIn->pStandalone != nullptr )
+        {
+            for( auto& pA : *pIn->pStandalone )
+                pRet->push_back( pA );
+            return pRet;
+        }
+        throw std::runtime_error( "MappingQuality: the alignments were not produced by the MI355X NeedlemanWunsch module "
+                                  "(mapping quality is computed on the device together with the DP stage)" );
     }
 };
 
@@ -783,57 +1002,65 @@ class SmallInversions : public libMS::Module<libMS::ContainerVector<std::shared_
     SmallInversions( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) )
     {}
 
-    // smallInversions.h:54-120
+    // Walks one alignment and reports every stretch between two seeds in which the running score falls by at least
+    // "Z Drop Inversions" below its maximum (behaviour of smallInversions.h:54-120).  The walk is a small state machine: a
+    // seed closes the stretch before it and opens the next one; within a stretch the score follows the global scoring
+    // parameters and the drop is measured against the best prefix, less the gap cost of getting back to its diagonal.
+    struct DropScan
+    {
+        const ma_params& rP;
+        nucSeqIndex uiQ, uiR; // current position
+        nucSeqIndex uiFromQ, uiFromR; // where the open stretch began (end of the last seed)
+        nucSeqIndex uiBestQ, uiBestR; // position of the best prefix of the stretch
+        int iScore = 0, iBest = std::numeric_limits<int>::min( ), iDrop = 0;
+        DropScan( const ma_params& rP, const Alignment& rA )
+            : rP( rP ), uiQ( rA.uiBeginOnQuery ), uiR( rA.uiBeginOnRef ), uiFromQ( uiQ ), uiFromR( uiR ), uiBestQ( uiQ ), uiBestR( uiR )
+        {}
+        bool dropped( ) const
+        {
+            return iDrop >= (int)(size_t)rP.zdrop_inversion;
+        }
+        void reopenBehind( nucSeqIndex uiSeedLen ) // the stretch restarts behind the seed that is about to be consumed
+        {
+            uiFromQ = uiQ + uiSeedLen;
+            uiFromR = uiR + uiSeedLen;
+            iScore = iDrop = 0;
+            iBest = std::numeric_limits<int>::min( );
+        }
+        void consume( MatchType xType, nucSeqIndex uiLen )
+        {
+            const bool bOnQ = xType != MatchType::deletion, bOnR = xType != MatchType::insertion;
+            if( xType == MatchType::seed || xType == MatchType::match )
+                iScore += rP.match * (int)uiLen;
+            else if( xType == MatchType::missmatch )
+                iScore -= rP.mismatch * (int)uiLen;
+            else
+                iScore -= rP.gap + rP.extend * (int)uiLen;
+            uiQ += bOnQ ? uiLen : 0;
+            uiR += bOnR ? uiLen : 0;
+            if( iScore >= iBest )
+            {
+                iBest = iScore;
+                uiBestQ = uiQ;
+                uiBestR = uiR;
+                return;
+            }
+            const int iAway = (int)std::max( uiQ - uiBestQ, uiR - uiBestR );
+            iDrop = std::max( iDrop, iBest - iScore - iAway * rP.extend );
+        }
+    };
     template <typename F> void forAllDropPos( F&& fDo, const Alignment& rAlignment ) const
     {
-        nucSeqIndex uiMaxScorePosQ = rAlignment.uiBeginOnQuery, uiPosQ = uiMaxScorePosQ, uiStartQ = uiMaxScorePosQ;
-        nucSeqIndex uiMaxScorePosR = rAlignment.uiBeginOnRef, uiPosR = uiMaxScorePosR, uiStartR = uiMaxScorePosR;
-        int iMaxScore = std::numeric_limits<int>::min( ), iCurrScore = 0, iMaxDrop = 0;
-        for( const std::pair<MatchType, nucSeqIndex>& section : rAlignment.data )
+        DropScan xScan( xP, rAlignment );
+        for( const auto& rSection : rAlignment.data )
         {
-            if( section.first == MatchType::seed )
+            if( rSection.first == MatchType::seed )
             {
-                if( iMaxDrop >= (int)(size_t)xP.zdrop_inversion )
-                    fDo( uiStartQ, uiStartR, uiPosQ, uiPosR );
-                uiStartQ = section.second + uiPosQ;
-                uiStartR = section.second + uiPosR;
-                iMaxDrop = 0;
-                iCurrScore = 0;
-                iMaxScore = std::numeric_limits<int>::min( );
+                if( xScan.dropped( ) )
+                    fDo( xScan.uiFromQ, xScan.uiFromR, xScan.uiQ, xScan.uiR );
+                xScan.reopenBehind( rSection.second );
             }
-            switch( section.first )
-            {
-                case MatchType::seed: // the reference falls through from seed into match
-                case MatchType::match:
-                    iCurrScore += xP.match * (int)section.second;
-                    uiPosQ += section.second;
-                    uiPosR += section.second;
-                    break;
-                case MatchType::missmatch:
-                    iCurrScore -= xP.mismatch * (int)section.second;
-                    uiPosQ += section.second;
-                    uiPosR += section.second;
-                    break;
-                case MatchType::insertion:
-                    iCurrScore -= xP.gap + xP.extend * (int)section.second;
-                    uiPosQ += section.second;
-                    break;
-                case MatchType::deletion:
-                    iCurrScore -= xP.gap + xP.extend * (int)section.second;
-                    uiPosR += section.second;
-                    break;
-            }
-            if( iCurrScore >= iMaxScore )
-            {
-                iMaxScore = iCurrScore;
-                uiMaxScorePosQ = uiPosQ;
-                uiMaxScorePosR = uiPosR;
-            }
-            else
-            {
-                const int uiDiff = (int)std::max( uiPosQ - uiMaxScorePosQ, uiPosR - uiMaxScorePosR );
-                iMaxDrop = std::max( iMaxDrop, iMaxScore - iCurrScore - uiDiff * xP.extend );
-            }
+            xScan.consume( rSection.first, rSection.second );
         }
     }
 
@@ -979,6 +1206,37 @@ class PairedReads : public libMS::Module<libMS::ContainerVector<std::shared_ptr<
     PairedReads( const ParameterSetManager& rParameters )
         : xP( *rParameters.getSelected( ) ), u( xP.paired_bonus ), mean( (size_t)xP.mean_paired_dist ), std( xP.std_paired_dist )
     {}
+    // One candidate = one alignment of each mate.  Key: combined score (times the bonus when the two lie on opposite
+    // strands at a plausible insert size), proper pairs first among equal scores (pairedReads.cpp:14-110).
+    struct Candidate
+    {
+        int64_t iScore;
+        bool bProper;
+        size_t uiFirst, uiSecond;
+        bool before( const Candidate& rO ) const
+        {
+            return iScore != rO.iScore ? iScore > rO.iScore : ( bProper && !rO.bProper );
+        }
+        bool sameKey( const Candidate& rO ) const
+        {
+            return iScore == rO.iScore && bProper == rO.bProper;
+        }
+    };
+    Candidate rate( const Alignment& rA, const Alignment& rB, size_t i, size_t j, uint64_t uiN ) const
+    {
+        Candidate xC{ rA.score( ) + rB.score( ), false, i, j };
+        const uint64_t uiF = uiN / 2;
+        if( ( rA.beginOnRef( ) >= uiF ) == ( rB.beginOnRef( ) >= uiF ) )
+            return xC; // same strand: never a proper Illumina pair
+        const nucSeqIndex uiMirrored = uiN - ( rB.beginOnRef( ) + 1 );
+        const double fDist = (double)( rA.beginOnRef( ) > uiMirrored ? rA.beginOnRef( ) - uiMirrored : uiMirrored - rA.beginOnRef( ) );
+        if( fDist >= (double)mean - std * 3 && fDist <= (double)mean + std * 3 )
+        {
+            xC.iScore = (int64_t)( xC.iScore * u );
+            xC.bProper = true;
+        }
+        return xC;
+    }
     virtual std::shared_ptr<TP_ALIGNMENTS> execute( std::shared_ptr<NucSeq> pQ1, std::shared_ptr<NucSeq> pQ2,
                                                     std::shared_ptr<TP_ALIGNMENTS> pAlignments1,
                                                     std::shared_ptr<TP_ALIGNMENTS> pAlignments2, std::shared_ptr<Pack> pPack ) override
@@ -987,66 +1245,61 @@ class PairedReads : public libMS::Module<libMS::ContainerVector<std::shared_ptr<
             pA->xStats.bFirst = true;
         for( auto& pA : *pAlignments2 )
             pA->xStats.bFirst = false;
-        if( pAlignments1->size( ) == 0 )
+        if( pAlignments1->empty( ) )
             return pAlignments2;
-        if( pAlignments2->size( ) == 0 )
+        if( pAlignments2->empty( ) )
             return pAlignments1;
-        const uint64_t uiN = pPack->uiUnpackedSizeForwardPlusReverse( ), uiF = uiN / 2;
-        std::vector<std::tuple<int64_t, bool, size_t, size_t>> vScores;
+        const uint64_t uiN = pPack->uiUnpackedSizeForwardPlusReverse( );
+        std::vector<Candidate> vCand;
+        vCand.reserve( pAlignments1->size( ) * pAlignments2->size( ) );
         for( size_t i = 0; i < pAlignments1->size( ); i++ )
-        {
-            const Alignment& rA1 = *( *pAlignments1 )[ i ];
-            if( rA1.length( ) == 0 )
-                continue;
             for( size_t j = 0; j < pAlignments2->size( ); j++ )
-            {
-                const Alignment& rA2 = *( *pAlignments2 )[ j ];
-                if( rA2.length( ) == 0 )
-                    continue;
-                int64_t iScore = rA1.score( ) + rA2.score( );
-                bool bIsPaired = false;
-                // illumina reads must be on opposite strands
-                if( ( rA1.beginOnRef( ) >= uiF ) != ( rA2.beginOnRef( ) >= uiF ) )
-                {
-                    const nucSeqIndex uiP1 = rA1.beginOnRef( ), uiP2 = uiN - ( rA2.beginOnRef( ) + 1 );
-                    const nucSeqIndex d = uiP1 < uiP2 ? uiP2 - uiP1 : uiP1 - uiP2;
-                    if( ( (double)d ) >= ( (double)mean ) - std * 3 && ( (double)d ) <= ( (double)mean ) + std * 3 )
-                    {
-                        iScore = ( int64_t )( iScore * u );
-                        bIsPaired = true;
-                    }
-                }
-                vScores.emplace_back( iScore, bIsPaired, i, j );
-            }
-        }
-        if( vScores.empty( ) )
+                if( ( *pAlignments1 )[ i ]->length( ) != 0 && ( *pAlignments2 )[ j ]->length( ) != 0 )
+                    vCand.push_back( rate( *( *pAlignments1 )[ i ], *( *pAlignments2 )[ j ], i, j, uiN ) );
+        if( vCand.empty( ) )
             throw std::runtime_error( "PairedReads: no alignment of non-zero length to pair" );
-        // same container, comparator and libstdc++ std::sort as the reference: ties keep its order
-        std::sort( vScores.begin( ), vScores.end( ),
-                   []( const std::tuple<int64_t, bool, size_t, size_t>& rtA, const std::tuple<int64_t, bool, size_t, size_t>& rtB ) {
-                       if( std::get<0>( rtA ) == std::get<0>( rtB ) )
-                           return std::get<1>( rtA ) && !std::get<1>( rtB );
-                       return std::get<0>( rtA ) > std::get<0>( rtB );
-                   } );
-        auto pA = ( *pAlignments1 )[ std::get<2>( vScores[ 0 ] ) ];
-        auto pB = ( *pAlignments2 )[ std::get<3>( vScores[ 0 ] ) ];
-        pA->bSecondary = pB->bSecondary = false;
-        pA->bSupplementary = pB->bSupplementary = false;
-        pA->xStats.pOther = std::weak_ptr<Alignment>( pB );
-        pB->xStats.pOther = std::weak_ptr<Alignment>( pA );
-        if( std::get<1>( vScores[ 0 ] ) && vScores.size( ) > 1 )
+        // the winner and the runner-up's score.  One scan settles it when the best key is unique.  Among several
+        // candidates with the best key the reference takes whichever its (unstable) std::sort over all candidates puts
+        // first, so only then the candidates are sorted: same sequence, same comparisons, same libstdc++ => same pick.
+        size_t uiBest = 0, uiTied = 1;
+        for( size_t k = 1; k < vCand.size( ); k++ )
         {
-            float fMapQ = ( (float)( std::get<0>( vScores[ 0 ] ) - std::get<0>( vScores[ 1 ] ) ) ) / std::get<0>( vScores[ 0 ] );
+            if( vCand[ k ].before( vCand[ uiBest ] ) )
+                uiBest = k, uiTied = 1;
+            else if( vCand[ k ].sameKey( vCand[ uiBest ] ) )
+                uiTied++;
+        }
+        Candidate xWin = vCand[ uiBest ];
+        int64_t iRunnerUp = xWin.iScore;
+        if( uiTied > 1 )
+        {
+            std::sort( vCand.begin( ), vCand.end( ), []( const Candidate& rX, const Candidate& rY ) { return rX.before( rY ); } );
+            xWin = vCand[ 0 ];
+        }
+        else if( vCand.size( ) > 1 )
+        {
+            iRunnerUp = std::numeric_limits<int64_t>::min( );
+            for( size_t k = 0; k < vCand.size( ); k++ )
+                if( k != uiBest )
+                    iRunnerUp = std::max( iRunnerUp, vCand[ k ].iScore );
+        }
+        auto pA = ( *pAlignments1 )[ xWin.uiFirst ];
+        auto pB = ( *pAlignments2 )[ xWin.uiSecond ];
+        for( auto& pX : { pA, pB } )
+            pX->bSecondary = pX->bSupplementary = false;
+        pA->xStats.pOther = pB;
+        pB->xStats.pOther = pA;
+        if( xWin.bProper && vCand.size( ) > 1 )
+        {
+            // confidence of the pair: lead over the runner-up relative to the winner (single precision like the reference)
+            float fConfidence = ( (float)( xWin.iScore - iRunnerUp ) ) / xWin.iScore;
             if( pA->getNumSeeds( ) <= 1 && pB->getNumSeeds( ) <= 1 )
-                fMapQ /= 2;
-            if( pA->score( ) >= xP.match * pQ1->length( ) * 0.8 && pAlignments1->size( ) >= 3 )
-                fMapQ *= 2;
-            else if( pB->score( ) >= xP.match * pQ2->length( ) * 0.8 && pAlignments2->size( ) >= 3 )
-                fMapQ *= 2;
-            if( fMapQ > 1 )
-                fMapQ = 1;
-            pA->fMappingQuality = fMapQ;
-            pB->fMappingQuality = fMapQ;
+                fConfidence /= 2;
+            const bool bStrongA = pA->score( ) >= xP.match * pQ1->length( ) * 0.8 && pAlignments1->size( ) >= 3;
+            const bool bStrongB = pB->score( ) >= xP.match * pQ2->length( ) * 0.8 && pAlignments2->size( ) >= 3;
+            if( bStrongA || bStrongB )
+                fConfidence *= 2;
+            pA->fMappingQuality = pB->fMappingQuality = fConfidence > 1 ? 1 : fConfidence;
         }
         auto pRet = std::make_shared<TP_ALIGNMENTS>( );
         pRet->push_back( pA );
@@ -1055,7 +1308,17 @@ class PairedReads : public libMS::Module<libMS::ContainerVector<std::shared_ptr<
     }
 };
 
-// Throughput API: a whole batch of reads through all stages in one go.
+// Phase times of a throughput run (seconds, summed over the device batches; the phases of different batches overlap when
+// several are in flight, so their sum can exceed the wall time)
+struct AlignerTiming
+{
+    double fWall = 0, fH2D = 0, fKernels = 0, fD2H = 0, fContainers = 0;
+    uint64_t uiReads = 0, uiBatches = 0, uiAlignedReads = 0;
+};
+
+// Throughput API, one GPU: reads in host memory -> device batches of uiBatchReads reads, uiInflight of them in flight
+// (own stream and host thread each: while one batch is in its kernels the next one is uploaded and the previous one is
+// turned into Alignment containers) -> per read the MappingQuality-annotated alignments, in input order.
 class BatchAligner
     : public libMS::Module<libMS::ContainerVector<std::shared_ptr<AlignmentVector>>, false, FMIndex,
                            libMS::ContainerVector<std::shared_ptr<NucSeq>>>
@@ -1064,47 +1327,79 @@ class BatchAligner
     ParameterSetManager xParams;
 
   public:
+    typedef libMS::ContainerVector<std::shared_ptr<AlignmentVector>> TP_RESULT;
+    size_t uiBatchReads = 1u << 18;
+    size_t uiInflight = 2;
+    AlignerTiming xLast; // of the last execute()
+
     BatchAligner( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) ), xParams( rParameters )
     {}
-    virtual std::shared_ptr<libMS::ContainerVector<std::shared_ptr<AlignmentVector>>>
-    execute( std::shared_ptr<FMIndex> pFM_index, std::shared_ptr<libMS::ContainerVector<std::shared_ptr<NucSeq>>> pQueries ) override
+
+    // Aligns reads [uiFrom, uiTo) of rQueries on the device of pIndex and stores the result of read i in rOut[ i ].
+    void alignRange( const ma_index* pIndex, const libMS::ContainerVector<std::shared_ptr<NucSeq>>& rQueries, size_t uiFrom,
+                     size_t uiTo, TP_RESULT& rOut, AlignerTiming& rT ) const
     {
-        std::vector<uint64_t> off{ 0 };
-        std::vector<uint8_t> cat;
-        for( auto& q : *pQueries )
-        {
-            cat.insert( cat.end( ), q->xCodes.begin( ), q->xCodes.end( ) );
-            off.push_back( cat.size( ) );
-        }
-        cat.push_back( 0 );
-        DeviceBatch B;
-        maCheck( ma_batch_create( pFM_index->pDev->p, &xP, pQueries->size( ) + 1, cat.size( ) + 64, &B.p ) );
-        maCheck( ma_batch_set_reads( B.p, cat.data( ), off.data( ), pQueries->size( ) ) );
-        maCheck( ma_align_batch( B.p ) );
-        uint64_t nAln = 0, nOps = 0;
-        maCheck( ma_batch_counts( B.p, nullptr, nullptr, nullptr, nullptr, &nAln, &nOps, nullptr ) );
-        std::vector<uint64_t> aoff( pQueries->size( ) + 1 ), ops( 2 * nOps + 2 );
-        std::vector<ma_alignment> alns( nAln + 1 );
-        maCheck( ma_batch_get_mapq_alignments( B.p, aoff.data( ), alns.data( ), ops.data( ) ) );
-        auto pRet = std::make_shared<libMS::ContainerVector<std::shared_ptr<AlignmentVector>>>( );
-        for( size_t r = 0; r < pQueries->size( ); r++ )
-        {
-            auto pV = std::make_shared<AlignmentVector>( );
-            for( uint64_t i = aoff[ r ]; i < aoff[ r + 1 ]; i++ )
+        std::mutex xNext;
+        size_t uiNext = uiFrom;
+        std::string sFailure;
+        auto worker = [ & ]( ) {
+            try
             {
-                auto pA = std::make_shared<Alignment>( );
-                pA->uiBeginOnRef = alns[ i ].begin_ref, pA->uiEndOnRef = alns[ i ].end_ref;
-                pA->uiBeginOnQuery = alns[ i ].begin_q, pA->uiEndOnQuery = alns[ i ].end_q;
-                pA->iScore = alns[ i ].score, pA->index_of_strip = alns[ i ].soc_index;
-                pA->bSecondary = alns[ i ].secondary != 0, pA->bSupplementary = alns[ i ].supplementary != 0;
-                pA->fMappingQuality = alns[ i ].mapq;
-                for( uint32_t k = 0; k < alns[ i ].n_ops; k++ )
-                    pA->data.emplace_back( (MatchType)ops[ 2 * ( alns[ i ].ops_off + k ) ],
-                                           ops[ 2 * ( alns[ i ].ops_off + k ) + 1 ] );
-                pV->push_back( pA );
+                detail::Engine xEngine( pIndex, xP );
+                for( ;; )
+                {
+                    size_t lo, hi;
+                    {
+                        std::lock_guard<std::mutex> xGuard( xNext );
+                        if( uiNext >= uiTo || !sFailure.empty( ) )
+                            return;
+                        lo = uiNext;
+                        hi = uiNext = std::min( uiTo, uiNext + uiBatchReads );
+                    }
+                    std::vector<const std::vector<uint8_t>*> vReads;
+                    for( size_t i = lo; i < hi; i++ )
+                        vReads.push_back( &rQueries[ i ]->xCodes );
+                    auto pRes = xEngine.run( vReads, false );
+                    const auto t0 = std::chrono::steady_clock::now( );
+                    for( size_t i = lo; i < hi; i++ )
+                    {
+                        auto pV = std::make_shared<AlignmentVector>( );
+                        detail::appendAlignments( pRes->vMq, pRes->vMqOps, pRes->vMqOff[ i - lo ], pRes->vMqOff[ i - lo + 1 ], true, *pV );
+                        rOut[ i ] = pV;
+                    }
+                    const double fContainers = detail::secondsSince( t0 );
+                    std::lock_guard<std::mutex> xGuard( xNext );
+                    rT.fH2D += pRes->fH2D, rT.fKernels += pRes->fKernels, rT.fD2H += pRes->fD2H, rT.fContainers += fContainers;
+                    rT.uiBatches++, rT.uiReads += hi - lo, rT.uiAlignedReads += pRes->uiAlignedReads;
+                }
             }
-            pRet->push_back( pV );
-        }
+            catch( const std::exception& rE )
+            {
+                std::lock_guard<std::mutex> xGuard( xNext );
+                if( sFailure.empty( ) )
+                    sFailure = rE.what( );
+            }
+        };
+        const size_t uiWorkers = std::max<size_t>( 1, std::min( uiInflight, ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) ) );
+        std::vector<std::thread> vWorkers;
+        for( size_t k = 1; k < uiWorkers; k++ )
+            vWorkers.emplace_back( worker );
+        worker( );
+        for( auto& rW : vWorkers )
+            rW.join( );
+        if( !sFailure.empty( ) )
+            throw std::runtime_error( sFailure );
+    }
+
+    virtual std::shared_ptr<TP_RESULT> execute( std::shared_ptr<FMIndex> pFM_index,
+                                                std::shared_ptr<libMS::ContainerVector<std::shared_ptr<NucSeq>>> pQueries ) override
+    {
+        auto pRet = std::make_shared<TP_RESULT>( );
+        pRet->resize( pQueries->size( ) );
+        xLast = AlignerTiming( );
+        const auto t0 = std::chrono::steady_clock::now( );
+        if( !pQueries->empty( ) )
+            alignRange( pFM_index->pDev->p, *pQueries, 0, pQueries->size( ), *pRet, xLast );
         // "Detect Small Inversions" (export.cpp:118-121): all reads' inversion DP in one more GPU launch
         if( xP.search_inversions )
         {
@@ -1126,13 +1421,14 @@ class BatchAligner
                 ( *pRet )[ r ] = pV;
             }
         }
+        xLast.fWall = detail::secondsSince( t0 );
         return pRet;
     }
 
     // Paired mode (setUpCompGraphPaired, export.cpp:130-202) for a batch: vMates holds the mates of pair k at 2k and
-    // 2k + 1; both mates of all pairs go through ONE device batch, PairedReads then picks per pair on the host.
-    std::shared_ptr<libMS::ContainerVector<std::shared_ptr<AlignmentVector>>>
-    executePaired( std::shared_ptr<FMIndex> pFM_index, std::shared_ptr<libMS::ContainerVector<std::shared_ptr<NucSeq>>> vMates )
+    // 2k + 1; both mates of all pairs go through the device together, PairedReads then picks per pair on the host.
+    std::shared_ptr<TP_RESULT> executePaired( std::shared_ptr<FMIndex> pFM_index,
+                                              std::shared_ptr<libMS::ContainerVector<std::shared_ptr<NucSeq>>> vMates )
     {
         if( vMates->size( ) % 2 )
             throw std::runtime_error( "BatchAligner::executePaired: odd number of reads" );
@@ -1140,7 +1436,7 @@ class BatchAligner
         auto pPack = std::make_shared<Pack>( );
         pPack->pDev = pFM_index->pDev;
         PairedReads xPairedReads( xParams );
-        auto pRet = std::make_shared<libMS::ContainerVector<std::shared_ptr<AlignmentVector>>>( );
+        auto pRet = std::make_shared<TP_RESULT>( );
         for( size_t k = 0; 2 * k + 1 < vMates->size( ); k++ )
         {
             auto pPicked = xPairedReads.execute( ( *vMates )[ 2 * k ], ( *vMates )[ 2 * k + 1 ], ( *pPerRead )[ 2 * k ],
@@ -1150,6 +1446,114 @@ class BatchAligner
                 pV->push_back( pA );
             pRet->push_back( pV );
         }
+        return pRet;
+    }
+};
+
+// Throughput API, several GPUs of one node: reads are independent, so the read set is cut into one
+// contiguous block per index replica (the shares differ by at most one read), every replica's block is aligned by its own
+// host thread on the replica's device with BatchAligner's double-buffered batches, and the results land at the reads'
+// input positions.  No collective, no inter-GPU traffic; the only shared state is the output vector (disjoint slots).
+// Replicas may live on the same device (tests on a one-GPU box use two "virtual shards" on device 0).
+class MultiDeviceAligner
+{
+    ParameterSetManager xParams;
+    std::vector<std::shared_ptr<FMIndex>> vReplicas;
+
+  public:
+    size_t uiBatchReads = 1u << 18;
+    size_t uiInflight = 2;
+    std::vector<AlignerTiming> vLast; // per replica, of the last execute()
+
+    MultiDeviceAligner( const ParameterSetManager& rParameters, const std::vector<std::shared_ptr<FMIndex>>& vReplicas )
+        : xParams( rParameters ), vReplicas( vReplicas )
+    {
+        if( vReplicas.empty( ) )
+            throw std::runtime_error( "MultiDeviceAligner: no index replica" );
+    }
+
+    // One replica of pFM's index on every device of vDevices (the arrays are downloaded once and uploaded per device;
+    // a device that already holds pFM's index reuses it).
+    static std::vector<std::shared_ptr<FMIndex>> replicate( const std::shared_ptr<FMIndex>& pFM, const std::vector<int>& vDevices,
+                                                            int iDeviceOfOriginal = 0 )
+    {
+        uint64_t nWords = 0, nSa = 0, uiN = 0;
+        int32_t nContigs = 0;
+        maCheck( ma_index_sizes( pFM->pDev->p, &nWords, &nSa, &uiN, &nContigs ) );
+        std::vector<uint32_t> vBwt;
+        std::vector<int64_t> vSa;
+        std::vector<uint8_t> vPac;
+        std::vector<uint64_t> vStarts( nContigs ), vLens( nContigs );
+        uint64_t L2[ 5 ];
+        int64_t primary = 0;
+        std::vector<std::shared_ptr<FMIndex>> vRet;
+        bool bUsedOriginal = false;
+        for( int iDev : vDevices )
+        {
+            if( iDev == iDeviceOfOriginal && !bUsedOriginal )
+            {
+                vRet.push_back( pFM );
+                bUsedOriginal = true;
+                continue;
+            }
+            if( vBwt.empty( ) )
+            {
+                vBwt.resize( nWords );
+                vSa.resize( nSa );
+                vPac.resize( ( uiN / 2 + 3 ) / 4 + 1 );
+                maCheck( ma_index_download( pFM->pDev->p, vBwt.data( ), vSa.data( ), L2, &primary, vPac.data( ), vStarts.data( ),
+                                            vLens.data( ) ) );
+            }
+            auto pDev = std::make_shared<DeviceIndex>( );
+            std::string sFailure;
+            std::thread xCreator( [ & ]( ) { // the upload binds its own thread to the target device
+                if( ma_set_device( iDev ) != 0 ||
+                    ma_index_create( vBwt.data( ), nWords, vSa.data( ), nSa, L2, primary, uiN, vPac.data( ), nContigs, vStarts.data( ),
+                                     vLens.data( ), &pDev->p ) != 0 )
+                    sFailure = ma_last_error( );
+            } );
+            xCreator.join( );
+            if( !sFailure.empty( ) )
+                throw std::runtime_error( sFailure );
+            auto pCopy = std::make_shared<FMIndex>( );
+            pCopy->pDev = pDev;
+            vRet.push_back( pCopy );
+        }
+        return vRet;
+    }
+
+    std::shared_ptr<BatchAligner::TP_RESULT> execute( std::shared_ptr<libMS::ContainerVector<std::shared_ptr<NucSeq>>> pQueries )
+    {
+        auto pRet = std::make_shared<BatchAligner::TP_RESULT>( );
+        pRet->resize( pQueries->size( ) );
+        const size_t uiG = vReplicas.size( ), n = pQueries->size( );
+        vLast.assign( uiG, AlignerTiming( ) );
+        std::vector<std::string> vFailure( uiG );
+        std::vector<std::thread> vWorkers;
+        for( size_t g = 0; g < uiG; g++ )
+            vWorkers.emplace_back( [ &, g ]( ) {
+                const size_t uiBase = n / uiG, uiRem = n % uiG;
+                const size_t lo = g * uiBase + std::min( g, uiRem ), hi = lo + uiBase + ( g < uiRem ? 1 : 0 );
+                try
+                {
+                    BatchAligner xAligner( xParams );
+                    xAligner.uiBatchReads = uiBatchReads;
+                    xAligner.uiInflight = uiInflight;
+                    const auto t0 = std::chrono::steady_clock::now( );
+                    if( hi > lo )
+                        xAligner.alignRange( vReplicas[ g ]->pDev->p, *pQueries, lo, hi, *pRet, vLast[ g ] );
+                    vLast[ g ].fWall = detail::secondsSince( t0 );
+                }
+                catch( const std::exception& rE )
+                {
+                    vFailure[ g ] = rE.what( );
+                }
+            } );
+        for( auto& rW : vWorkers )
+            rW.join( );
+        for( const std::string& sF : vFailure )
+            if( !sF.empty( ) )
+                throw std::runtime_error( sF );
         return pRet;
     }
 };

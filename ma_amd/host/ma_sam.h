@@ -253,11 +253,18 @@ inline std::string computeTag( const Alignment& rA, bool bLong )
 }
 } // namespace sam
 
-class OutStream // fileWriter.h:21-34
+// Output sinks of the writers (interface of fileWriter.h:21-78: `*pOut << text`).  Here every sink implements ONE
+// primitive, put(); operator<< is the reference's spelling of it and stays virtual so that client subclasses written
+// against the reference's OutStream keep working.
+class OutStream
 {
+  protected:
+    virtual void put( const char*, size_t )
+    {} // the base class swallows its input (fileWriter.h:24-27)
   public:
-    virtual OutStream& operator<<( std::string )
+    virtual OutStream& operator<<( std::string sText )
     {
+        put( sText.data( ), sText.size( ) );
         return *this;
     }
     virtual ~OutStream( )
@@ -265,30 +272,36 @@ class OutStream // fileWriter.h:21-34
 };
 class StdOutStream : public OutStream
 {
-  public:
-    StdOutStream& operator<<( std::string s ) override
+  protected:
+    void put( const char* p, size_t n ) override
     {
-        std::cout << s << std::flush;
-        return *this;
+        fwrite( p, 1, n, stdout );
+        fflush( stdout ); // every record is visible at once, like the reference's std::flush
     }
 };
 class FileOutStream : public OutStream
 {
+    FILE* pHandle;
+
+  protected:
+    void put( const char* p, size_t n ) override
+    {
+        if( n != 0 && fwrite( p, 1, n, pHandle ) != n )
+            throw std::runtime_error( "Unable to write to output file" );
+        fflush( pHandle );
+    }
+
   public:
-    std::ofstream file;
-    FileOutStream( std::string sFileName ) : file( sFileName, std::ofstream::out | std::ofstream::trunc )
+    explicit FileOutStream( std::string sFileName ) : pHandle( fopen( sFileName.c_str( ), "w" ) ) // truncates
     {
-        if( !file.good( ) )
-            throw std::runtime_error( "Unable to open file" + sFileName );
+        if( pHandle == nullptr )
+            throw std::runtime_error( "Unable to open file" + sFileName ); // (sic) no blank: the reference's text
     }
-    ~FileOutStream( )
+    FileOutStream( const FileOutStream& ) = delete;
+    FileOutStream& operator=( const FileOutStream& ) = delete;
+    ~FileOutStream( ) override
     {
-        file.close( );
-    }
-    FileOutStream& operator<<( std::string s ) override
-    {
-        file << s << std::flush;
-        return *this;
+        fclose( pHandle );
     }
 };
 class StringOutStream : public OutStream // convenience for tests and in-memory pipelines
@@ -563,31 +576,29 @@ class FileStream : public libMS::Container
 };
 namespace detail
 {
-// fileReader.h:152-186: \n, \r\n and \r line ends; a last line without line end is still a line
-inline void safeGetLine( std::istream& xStream, std::string& t )
+// One text line off a stream buffer; "\n", "\r\n" and a lone "\r" all end a line, and a final line without a line end
+// still counts.  Reaching the end with nothing read marks the stream as exhausted (what FileStream::eof() reports;
+// behaviour of fileReader.h:152-186).
+inline void safeGetLine( std::istream& rIn, std::string& rLine )
 {
-    t.clear( );
-    std::istream::sentry se( xStream, true );
-    std::streambuf* sb = xStream.rdbuf( );
-    while( true )
+    typedef std::streambuf::traits_type TR;
+    std::streambuf* const pBuf = rIn.rdbuf( );
+    rLine.clear( );
+    for( TR::int_type iNext = pBuf->sbumpc( ); !TR::eq_int_type( iNext, TR::eof( ) ); iNext = pBuf->sbumpc( ) )
     {
-        int c = sb->sbumpc( );
-        switch( c )
+        const char cNext = TR::to_char_type( iNext );
+        if( cNext == '\n' )
+            return;
+        if( cNext == '\r' )
         {
-            case '\n':
-                return;
-            case '\r':
-                if( sb->sgetc( ) == '\n' )
-                    sb->sbumpc( );
-                return;
-            case std::streambuf::traits_type::eof( ):
-                if( t.empty( ) )
-                    xStream.setstate( std::ios::eofbit );
-                return;
-            default:
-                t += (char)c;
+            if( TR::eq_int_type( pBuf->sgetc( ), TR::to_int_type( '\n' ) ) )
+                pBuf->sbumpc( ); // the second half of a Windows line end
+            return;
         }
+        rLine.push_back( cNext );
     }
+    if( rLine.empty( ) )
+        rIn.setstate( std::ios::eofbit );
 }
 } // namespace detail
 class StdFileStream : public FileStream
@@ -675,23 +686,30 @@ class GzFileStream : public FileStream
         const size_t uiDot = sName.find_last_of( '.' );
         return uiDot == std::string::npos || uiDot == 0 ? sName : sName.substr( 0, uiDot );
     }
-    void safeGetLine( std::string& t ) override
+    // One line of the decompressed text through the one-byte look-ahead cBuff.  (sic) A "\r" is dropped wherever it
+    // stands -- before a "\n" it makes a Windows line end, anywhere else the line simply goes on (fileReader.h:395-420).
+    void safeGetLine( std::string& rLine ) override
     {
         open( );
-        t.clear( );
-        while( true )
+        rLine.clear( );
+        auto have = [ this ]( ) { return lastReadReturn == 1; };
+        auto advance = [ this ]( ) { lastReadReturn = gzread( pFile, &cBuff, 1 ); };
+        while( have( ) )
         {
-            if( lastReadReturn != 1 )
-                break;
             if( cBuff == '\r' )
-                lastReadReturn = gzread( pFile, &cBuff, 1 );
-            if( lastReadReturn != 1 || cBuff == '\n' )
-                break;
-            t += (char)cBuff;
-            lastReadReturn = gzread( pFile, &cBuff, 1 );
+            {
+                advance( );
+                if( !have( ) )
+                    return;
+            }
+            if( cBuff == '\n' )
+            {
+                advance( ); // step over the line end
+                return;
+            }
+            rLine.push_back( (char)cBuff );
+            advance( );
         }
-        if( lastReadReturn == 1 )
-            lastReadReturn = gzread( pFile, &cBuff, 1 );
     }
 };
 #endif
@@ -831,27 +849,37 @@ class FileReader : public libMS::Module<NucSeq, true, FileStream>
 // PairedFileStream / PairedFileReader (fileReader.h:499-617): one read from each of two streams per call
 class PairedFileStream : public FileStream, public std::pair<std::shared_ptr<FileStream>, std::shared_ptr<FileStream>>
 {
+    // a pair of streams is not itself a character stream: the single-stream operations have no meaning here
+    [[noreturn]] static void noSingleStream( )
+    {
+        throw std::runtime_error( "This function should have been overridden" );
+    }
+
   public:
-    using std::pair<std::shared_ptr<FileStream>, std::shared_ptr<FileStream>>::pair;
-    bool eof( ) const override
+    typedef std::pair<std::shared_ptr<FileStream>, std::shared_ptr<FileStream>> TP_MATES;
+    using TP_MATES::TP_MATES;
+    bool eof( ) const override // the shorter file ends the pair stream
     {
-        return first->eof( ) || second->eof( );
-    }
-    char peek( ) override
-    {
-        throw std::runtime_error( "This function should have been overridden" );
-    }
-    char pop( ) override
-    {
-        throw std::runtime_error( "This function should have been overridden" );
+        return first->eof( ) ? true : second->eof( );
     }
     std::string fileName( ) override
     {
-        return first->fileName( ) + std::string( "," ) + second->fileName( );
+        std::string sBoth = first->fileName( );
+        sBoth += ',';
+        sBoth += second->fileName( );
+        return sBoth;
+    }
+    char peek( ) override
+    {
+        noSingleStream( );
+    }
+    char pop( ) override
+    {
+        noSingleStream( );
     }
     void safeGetLine( std::string& ) override
     {
-        throw std::runtime_error( "This function should have been overridden" );
+        noSingleStream( );
     }
 };
 typedef libMS::ContainerVector<std::shared_ptr<NucSeq>> PairedReadsContainer;

@@ -9,6 +9,7 @@
 // This is our own code against the reference's interface; when integrating into MA itself the
 // reference's module.h is used instead and only ma_modules.h is added.
 #pragma once
+#include <algorithm>
 #include <atomic>
 #include <functional>
 #include <memory>
@@ -81,43 +82,58 @@ class BasePledge
     virtual void reset( ) = 0; // forget the cached content of this pledge and of everything downstream
     virtual void addSuccessor( BasePledge* ) = 0;
 
+    // Drives all sinks of a graph to exhaustion (interface and semantics of BasePledge::simultaneousGet,
+    // module.h:268-378): every sink is pulled until its volatile source runs dry, sink 0 reports progress through the
+    // callback (false = stop everybody), and the first failure of any worker stops the others and reaches the caller as
+    // std::runtime_error once all workers are back.  numThreads workers share the sinks (0 = one worker per sink).
     static inline void simultaneousGet(
         std::vector<std::shared_ptr<BasePledge>> vPledges, std::function<bool( )> callback = []( ) { return true; },
         unsigned int numThreads = 0 )
     {
-        (void)numThreads; // one worker per sink, like the reference with numThreads == vPledges.size()
-        std::mutex xExceptionMutex;
-        std::string sExceptionMessageFromWorker;
-        std::atomic_bool bContinue( true );
-        std::vector<std::thread> vThreads;
-        for( size_t uiTid = 0; uiTid < vPledges.size( ); uiTid++ )
-            vThreads.emplace_back( [ &, uiTid ]( ) {
-                auto pPledge = vPledges[ uiTid ];
-                bool bLoop = pPledge->hasVolatile( );
-                do
+        struct Run
+        {
+            std::atomic<size_t> uiNextSink{ 0 };
+            std::atomic<bool> bGo{ true };
+            std::once_flag xFirstFailure;
+            std::string sFailure;
+            bool bFailed = false;
+        } xRun;
+        auto drain = [ & ]( size_t uiSink ) {
+            BasePledge& rSink = *vPledges[ uiSink ];
+            const bool bRepeats = rSink.hasVolatile( );
+            for( ;; )
+            {
+                const bool bMore = rSink.getAsBaseType( ) != nullptr && bRepeats;
+                if( uiSink == 0 && !callback( ) )
+                    xRun.bGo = false;
+                if( !bMore || !xRun.bGo )
+                    return;
+            }
+        };
+        auto work = [ & ]( ) {
+            for( size_t uiSink = xRun.uiNextSink++; uiSink < vPledges.size( ); uiSink = xRun.uiNextSink++ )
+                try
                 {
-                    try
-                    {
-                        bLoop &= pPledge->getAsBaseType( ) != nullptr;
-                        if( uiTid == 0 )
-                            bContinue = callback( );
-                    }
-                    catch( const std::exception& rxException )
-                    {
-                        std::lock_guard<std::mutex> xGuard( xExceptionMutex );
-                        if( sExceptionMessageFromWorker.empty( ) )
-                        {
-                            sExceptionMessageFromWorker = rxException.what( );
-                            bContinue = false;
-                        }
-                        return;
-                    }
-                } while( bLoop && bContinue );
-            } );
-        for( auto& t : vThreads )
-            t.join( );
-        if( !sExceptionMessageFromWorker.empty( ) )
-            throw std::runtime_error( sExceptionMessageFromWorker );
+                    drain( uiSink );
+                }
+                catch( const std::exception& rFailure )
+                {
+                    std::call_once( xRun.xFirstFailure, [ & ]( ) {
+                        xRun.sFailure = rFailure.what( );
+                        xRun.bFailed = true;
+                    } );
+                    xRun.bGo = false;
+                    return;
+                }
+        };
+        const size_t uiWorkers = numThreads == 0 ? vPledges.size( ) : std::min<size_t>( numThreads, vPledges.size( ) );
+        std::vector<std::thread> vWorkers;
+        for( size_t k = 0; k < uiWorkers; k++ )
+            vWorkers.emplace_back( work );
+        for( auto& rWorker : vWorkers )
+            rWorker.join( );
+        if( xRun.bFailed )
+            throw std::runtime_error( xRun.sFailure );
     }
 };
 

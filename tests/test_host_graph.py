@@ -59,6 +59,82 @@ def test_graph_of_dropin_modules_matches_reference(tmp_path, gpu_device, preset,
     assert open(out + ".sam").read() == sam_want
 
 
+def _same_alns_and_mq(got, want, alns=True):
+    assert len(got) == len(want)
+    for i, (g, w) in enumerate(zip(got, want)):
+        if alns:
+            assert g["alns"] == w["alns"], "read %d alignments" % i
+        assert len(g["mq"]) == len(w["mq"]), "read %d" % i
+        for a, b in zip(g["mq"], w["mq"]):
+            assert a == b, "read %d mapq record" % i
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,name", [("default", "small_ref.default.pipe"), ("illumina", "small_ref.illumina.pipe")])
+@pytest.mark.parametrize("threads", [8, 64])
+def test_unchanged_graph_with_many_threads_funnels_into_device_batches(tmp_path, gpu_device, preset, name, threads):
+    """N copies of the setUpCompGraph chain over one shared reader, driven by simultaneousGet with N threads
+    (export.cpp:84-126): the per-read execute() calls of all threads go through the device as batches (DeviceBatcher) and
+    every read still gets exactly the reference's records."""
+    import json
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    out = str(tmp_path / "graph.out")
+    line = subprocess.check_output([exe, case, preset, out, "threads", str(threads)]).decode().strip().splitlines()[-1]
+    info = json.loads(line)
+    want = parse_pipe_dump(os.path.join(G, name + ".gz"))
+    assert info["reads"] == len(want)
+    assert info["device_batches"] < info["reads"], info  # reads did share device batches
+    _same_alns_and_mq(parse_pipe_dump(out), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,name", [("default", "small_ref.default.pipe"), ("illumina", "small_ref.illumina.pipe")])
+def test_modules_take_over_mid_chain_from_plain_containers(tmp_path, gpu_device, preset, name):
+    """Drop-in one stage at a time: every module is fed a container that does NOT come from the preceding MI355X module
+    (rebuilt field by field, as the reference's modules would hand it over); each stage then runs on its own through
+    ma_batch_set_segments / _seeds / _hsets.  Same records as the reference."""
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    out = str(tmp_path / "graph.out")
+    subprocess.check_call([exe, case, preset, out, "mixed"])
+    _same_alns_and_mq(parse_pipe_dump(out), parse_pipe_dump(os.path.join(G, name + ".gz")))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,name", [("default", "small_ref.default.pipe"), ("illumina", "small_ref.illumina.pipe")])
+def test_soc_queue_pops_like_the_reference(tmp_path, gpu_device, preset, name):
+    """SoCPriorityQueue::pop across the boundary (soc.h:240-284): strip index, score, ambiguity and the seeds of every
+    popped strip equal the reference's SOC records (golden vectors G5)."""
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    out = str(tmp_path / "socs.out")
+    subprocess.check_call([exe, case, preset, out, "socs"])
+    got = parse_pipe_dump(out)
+    want = parse_pipe_dump(os.path.join(G, name + ".gz"))
+    assert len(got) == len(want)
+    n = 0
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g["socs"] == w["socs"], "read %d: SoC queue differs" % i
+        n += len(w["socs"])
+    assert n > len(want) // 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shards", [1, 2, 3])
+def test_multi_device_aligner_on_virtual_shards(tmp_path, gpu_device, shards):
+    """MultiDeviceAligner: the read set is cut into one block per index replica, each block aligned by its own host thread
+    with double-buffered device batches, results at the input positions; here the replicas are virtual shards on GPU 0."""
+    import json
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    out = str(tmp_path / "multi.out")
+    info = json.loads(subprocess.check_output([exe, case, "default", out, "multi", str(shards)]).decode().strip().splitlines()[-1])
+    want = parse_pipe_dump(os.path.join(G, "small_ref.default.pipe.gz"))
+    assert info["reads"] == len(want) and info["device_batches_shard0"] >= 2
+    _same_alns_and_mq(parse_pipe_dump(out), want, alns=False)
+
+
 def build_index_store_exe():
     exe = os.path.join(ROOT, "tests", "emul", "index_store_test")
     src = exe + ".cpp"
