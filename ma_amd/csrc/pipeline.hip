@@ -232,6 +232,116 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
     atomicAdd( &A.ctr[ CTR_BLOCKS ], (unsigned long long)blocks );
 }
 
+__device__ __forceinline__ u64 wave_sum_u64( u64 v );
+// ---- MEMs seeding (binarySeeding.h:460-537): every start position of every read is independent, so one lane per base.
+// Pass 1 counts the segments of each position, a scan lays them out in (read, position) order -- the order the reference
+// pushes them in -- pass 2 writes them, k_mems_finish derives the per-read ranges and applies execute()'s drop rule.
+struct MemsArgs
+{
+    IndexView X;
+    SeedParams P;
+    const uint8_t* reads;
+    const u64* roff;
+    u32 n_reads;
+    u64 n_bases;
+    u64* cnt; // pass 1: out, n_bases + 1
+    const u64* off; // pass 2: in
+    ma_segment* pool;
+    u32* pool_read;
+    unsigned long long* ctr;
+};
+struct MemsCount
+{
+    u64 n = 0;
+    MA_HD void emit( u32, u32, i64, i64 )
+    {
+        n++;
+    }
+};
+struct MemsFill
+{
+    ma_segment* out;
+    u32* out_read;
+    u32 read;
+    u64 n = 0;
+    MA_HD void emit( u32 qs, u32 qsz, i64 sa, i64 san )
+    {
+        ma_segment s;
+        s.q_start = qs, s.q_size = qsz, s.sa_start = sa, s.sa_start_rc = -1, s.sa_size = san;
+        out[ n ] = s;
+        out_read[ n ] = read;
+        n++;
+    }
+};
+template <bool FILL> __global__ void __launch_bounds__( 256 ) k_mems( MemsArgs A )
+{
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 steps = 0, blocks = 0;
+    if( t < A.n_bases )
+    {
+        const u64 b = A.roff[ 0 ] + t;
+        // the read of base b: the last r with roff[r] <= b
+        u32 lo = 0, hi = A.n_reads;
+        while( hi - lo > 1 )
+        {
+            const u32 mid = ( lo + hi ) / 2;
+            if( A.roff[ mid ] <= b )
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const u64 r0 = A.roff[ lo ];
+        const u32 qlen = (u32)( A.roff[ lo + 1 ] - r0 ), i = (u32)( b - r0 );
+        if( FILL )
+        {
+            MemsFill sink{ A.pool + A.off[ t ], A.pool_read + A.off[ t ], lo };
+            if( A.off[ t + 1 ] > A.off[ t ] )
+                mems_from( A.X, A.P, A.reads + r0, qlen, i, sink, steps, blocks );
+        }
+        else
+        {
+            MemsCount sink;
+            mems_from( A.X, A.P, A.reads + r0, qlen, i, sink, steps, blocks );
+            A.cnt[ t ] = sink.n;
+        }
+    }
+    if( !FILL )
+    {
+        steps = wave_sum_u64( steps );
+        blocks = wave_sum_u64( blocks );
+        if( ( threadIdx.x & 63 ) == 0 && steps )
+        {
+            atomicAdd( &A.ctr[ CTR_STEPS ], (unsigned long long)steps );
+            atomicAdd( &A.ctr[ CTR_BLOCKS ], (unsigned long long)blocks );
+        }
+    }
+}
+// per read: its segment range; BinarySeeding::execute's drop rule (binarySeeding.cpp:172-175, numSeedsLarger segment.h:278-289):
+// a dropped read keeps no segment (its pool entries are blanked so that they yield no seeds)
+__global__ void k_mems_finish( IndexView X, SeedParams P, const u64* roff, u32 n_reads, const u64* off, ma_segment* pool, u64* seg_off,
+                               u32* seg_cnt )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    const u64 b = off[ roff[ r ] - roff[ 0 ] ], e = off[ roff[ r + 1 ] - roff[ 0 ] ];
+    u32 n = (u32)( e - b );
+    if( !P.disable_heuristics && P.min_seed_size_drop != 0 )
+    {
+        u64 sum = 0;
+        for( u64 k = b; k < e; k++ )
+            sum += (u64)pool[ k ].q_size / (u64)P.min_seed_size_drop;
+        if( (double)sum < P.rel_min_seed_size_amount * (double)( roff[ r + 1 ] - roff[ r ] ) && P.genome_size_disable < X.n )
+        {
+            for( u64 k = b; k < e; k++ )
+                pool[ k ].q_size = 0, pool[ k ].sa_size = 0;
+            n = 0;
+        }
+    }
+    seg_off[ r ] = b;
+    seg_cnt[ r ] = n;
+}
+
 // per pooled segment: number of seeds it yields (segment.h:316-349 filters)
 __global__ void k_seg_seed_counts( const ma_segment* pool, u64 n, u32 min_len, u32 max_amb, u64* cnt )
 {
@@ -866,7 +976,7 @@ struct ma_batch
     const u64* d_roff = nullptr;
     DevBuf reads, roff, ctr, seedStack, seedRow, seedSteps, seedSeg, hlocal, hdense, hseedCnt, hseedOff;
     // seeding
-    DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt;
+    DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt, memsCnt, memsOff;
     u64 segPoolCap = 0, segPoolMin = 0;
     // extraction
     DevBuf segSeedCnt, segSeedOff, seedOff, seedCnt, seeds, cubTmp;
@@ -1055,6 +1165,7 @@ static SeedParams seed_params( const ma_params& P )
 {
     SeedParams S;
     S.technique = (u32)P.seeding_technique;
+    S.min_seed_len = (u32)P.min_seed_len;
     S.min_amb = (u32)P.min_ambiguity;
     S.max_amb = (u32)P.max_ambiguity;
     S.min_seed_size_drop = (u32)P.min_seed_size_drop;
@@ -1062,6 +1173,54 @@ static SeedParams seed_params( const ma_params& P )
     S.rel_min_seed_size_amount = P.rel_min_seed_size_amount;
     S.genome_size_disable = P.genome_size_disable;
     return S;
+}
+
+static int seed_mems( ma_batch* b )
+{
+    const u64 n = b->n_reads, nb = b->n_bases;
+    if( b->segOff.reserve( ( n + 1 ) * 8 ) || b->segCnt.reserve( ( n + 1 ) * 4 ) || b->memsCnt.reserve( ( nb + 2 ) * 8 ) ||
+        b->memsOff.reserve( ( nb + 2 ) * 8 ) )
+        return 1;
+    MemsArgs A;
+    A.X = b->idx->v;
+    A.P = seed_params( b->P );
+    A.reads = b->d_reads;
+    A.roff = b->d_roff;
+    A.n_reads = (u32)n;
+    A.n_bases = nb;
+    A.cnt = b->memsCnt.as<u64>( );
+    A.off = b->memsOff.as<u64>( );
+    A.pool = nullptr;
+    A.pool_read = nullptr;
+    A.ctr = b->ctr.as<unsigned long long>( );
+    EvTimer t( b, 0 );
+    u64 total = 0;
+    if( nb )
+    {
+        hipLaunchKernelGGL( k_mems<false>, dim3( (unsigned)( ( nb + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, A );
+        MA_HIP( hipMemsetAsync( (char*)b->memsCnt.p + nb * 8, 0, 8, b->stream ) );
+        if( scan_exclusive<u64>( b, b->memsCnt.as<u64>( ), b->memsOff.as<u64>( ), nb + 1 ) )
+            return 1;
+        MA_HIP( hipMemcpyAsync( &total, (char*)b->memsOff.p + nb * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
+        MA_HIP( hipStreamSynchronize( b->stream ) );
+    }
+    else
+        MA_HIP( hipMemsetAsync( b->memsOff.p, 0, 16, b->stream ) );
+    b->segPoolCap = std::max<u64>( total + 1024, b->segPoolCap );
+    if( b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) )
+        return 1;
+    A.pool = b->segPool.as<ma_segment>( );
+    A.pool_read = b->segRead.as<u32>( );
+    if( nb && total )
+        hipLaunchKernelGGL( k_mems<true>, dim3( (unsigned)( ( nb + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, A );
+    hipLaunchKernelGGL( k_mems_finish, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, A.X, A.P, b->d_roff, (u32)n,
+                        b->memsOff.as<u64>( ), b->segPool.as<ma_segment>( ), b->segOff.as<u64>( ), b->segCnt.as<u32>( ) );
+    const unsigned long long used = total;
+    MA_HIP( hipMemcpyAsync( b->ctr.as<unsigned long long>( ) + CTR_SEG_USED, &used, 8, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipStreamSynchronize( b->stream ) );
+    MA_HIP( hipGetLastError( ) );
+    b->stage_done = 1;
+    return 0;
 }
 
 int ma_seed_batch( ma_batch* b )
@@ -1077,6 +1236,8 @@ int ma_seed_batch( ma_batch* b )
         b->stage_done = 1;
         return 0;
     }
+    if( b->P.seeding_technique == 2 )
+        return seed_mems( b );
     const bool smem = b->P.seeding_technique == 1;
     const u32 worst_cap = ( smem ? 6 : 2 ) * b->max_qlen + 8; // segments one read can emit at most
     const u32 smem_cap = smem ? b->max_qlen + 2 : 0;

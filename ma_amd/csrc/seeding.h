@@ -9,7 +9,8 @@ namespace ma
 {
 struct SeedParams
 {
-    u32 technique; // 0 maxSpan, 1 SMEMs
+    u32 technique; // 0 maxSpan, 1 SMEMs, 2 MEMs (mems_from below; the state machine serves 0 and 1)
+    u32 min_seed_len; // MEMs only: xMinSeedLength (binarySeeding.h:568)
     u32 min_amb, max_amb;
     u32 min_seed_size_drop;
     u32 disable_heuristics;
@@ -459,6 +460,76 @@ MA_HD u32 seed_finish( const SeedLane& L, const SeedParams& P, const SeedScratch
             n = 0;
     }
     return n;
+}
+
+// memExtension (binarySeeding.h:460-537) for ONE start position i of a read: extend rightwards from q[i]; whenever rows
+// drop out of the interval (and the match is longer than the minimal seed length and not too ambiguous), the dropped rows
+// are maximal to the right, and those of them that cannot be extended to the left by q[i-1] are reported -- per row when
+// only some of them can.  SINK::emit( q_start, q_size, sa_start, sa_size ) receives the segments in the reference's order;
+// the intervals of dropped rows carry -1 as start of the reverse-complement interval (fMIndex.h:123-150), which
+// extend_backward's start and size do not depend on.  Every position is independent: one lane per (read, position).
+template <typename SINK>
+MA_HD void mems_from( const IndexView& X, const SeedParams& P, const uint8_t* q, u32 qlen, u32 i, SINK& sink, u64& steps, u64& blocks )
+{
+    if( q[ i ] >= 4 )
+        return;
+    const i64 minAmb = (i64)P.min_amb, maxAmb = (i64)P.max_amb;
+    i64 ik[ 3 ];
+    init_interval( X, 3u - q[ i ], ik );
+    u32 nb;
+    for( u32 j = i + 1; j <= qlen && ik[ 2 ] > minAmb; j++ )
+    {
+        i64 ok[ 3 ] = { 0, -1, 0 };
+        if( j < qlen && q[ j ] < 4 )
+        {
+            extend_backward( X, ik, 3u - q[ j ], ok, nb );
+            steps++, blocks += nb;
+        }
+        if( j - i - 1 > P.min_seed_len && ok[ 2 ] < ik[ 2 ] && ik[ 2 ] < maxAmb )
+        {
+            // ik.revComp( ) minus ok.revComp( ): at most two runs of rows (do_for_difference)
+            const i64 aS = ik[ 1 ], aE = ik[ 1 ] + ik[ 2 ], bS = ok[ 1 ], bE = ok[ 1 ] + ok[ 2 ];
+            const i64 uiY = mmin( bS, aE ), uiX = mmax( bE, aS );
+            for( int part = 0; part < 2; part++ )
+            {
+                const i64 dS = part == 0 ? aS : uiX, dN = part == 0 ? uiY - aS : aE - uiX;
+                if( dN <= 0 )
+                    continue; // start( ) < uiY / uiX < end( ) do not hold
+                i64 xe[ 3 ] = { 0, -1, 0 };
+                if( i > 0 )
+                {
+                    const i64 xd[ 3 ] = { dS, -1, dN };
+                    extend_backward( X, xd, q[ i - 1 ], xe, nb );
+                    steps++, blocks += nb;
+                }
+                if( xe[ 2 ] == 0 )
+                    sink.emit( i, j - i - 1, dS, dN );
+                else if( xe[ 2 ] < dN )
+                {
+                    i64 kLast = dS;
+                    for( i64 k = dS; k <= dS + dN; k++ )
+                    {
+                        bool cut = k == dS + dN;
+                        if( !cut )
+                        {
+                            const i64 xr[ 3 ] = { k, -1, 1 };
+                            i64 xo[ 3 ];
+                            extend_backward( X, xr, q[ i - 1 ], xo, nb );
+                            steps++, blocks += nb;
+                            cut = xo[ 2 ] != 0;
+                        }
+                        if( cut )
+                        {
+                            if( k > kLast )
+                                sink.emit( i, j - i - 1, kLast, k - kLast );
+                            kLast = k + 1;
+                        }
+                    }
+                }
+            }
+        }
+        ik[ 0 ] = ok[ 0 ], ik[ 1 ] = ok[ 1 ], ik[ 2 ] = ok[ 2 ];
+    }
 }
 
 // Whole read on one lane (used by the host emulation and as the loop body of the kernel).

@@ -658,13 +658,81 @@ static void procesInterval( const Ctx& c, u64 aS, u64 aSize, const uint8_t* q, u
     }
 }
 
+// memExtension (binarySeeding.h:460-537): every maximal exact match, found by extending rightwards from every query
+// position and checking the rows that drop out of the interval for left-maximality.  The intervals it hands on carry -1 as
+// start of the reverse-complement interval (SAInterval::do_for_difference, fMIndex.h:123-150); extend_backward's start and
+// size do not depend on it.
+static void memsExt( const Ctx& c, const uint8_t* q, u64 qlen, std::vector<Seg>& out )
+{
+    const i64 minAmb = (i64)(unsigned)c.P.min_ambiguity, maxAmb = (i64)(unsigned)c.P.max_ambiguity;
+    const u64 minSeed = (u64)(unsigned)c.P.min_seed_len;
+    for( u64 i = 0; i < qlen; i++ )
+    {
+        if( q[ i ] >= 4 )
+            continue;
+        i64 ik[ 3 ];
+        initInterval( c.x, (uint8_t)( 3 - q[ i ] ), ik );
+        for( u64 j = i + 1; j <= qlen && ik[ 2 ] > minAmb; j++ )
+        {
+            i64 ok[ 3 ] = { 0, -1, 0 };
+            if( j < qlen && q[ j ] < 4 )
+                extendBackward( c.x, ik, (uint8_t)( 3 - q[ j ] ), ok );
+            if( j - i - 1 > minSeed && ok[ 2 ] < ik[ 2 ] && ik[ 2 ] < maxAmb )
+            {
+                // ik.revComp( ).do_for_difference( ok.revComp( ), ... )
+                const i64 aS = ik[ 1 ], aE = ik[ 1 ] + ik[ 2 ], bS = ok[ 1 ], bE = ok[ 1 ] + ok[ 2 ];
+                const i64 uiY = std::min( bS, aE ), uiX = std::max( bE, aS );
+                i64 part[ 2 ][ 2 ];
+                int np = 0;
+                if( aS < uiY )
+                    part[ np ][ 0 ] = aS, part[ np ][ 1 ] = uiY - aS, np++;
+                if( uiX < aE )
+                    part[ np ][ 0 ] = uiX, part[ np ][ 1 ] = aE - uiX, np++;
+                for( int p = 0; p < np; p++ )
+                {
+                    const i64 dS = part[ p ][ 0 ], dN = part[ p ][ 1 ];
+                    i64 xd[ 3 ] = { dS, -1, dN }, xe[ 3 ] = { 0, -1, 0 };
+                    if( i > 0 )
+                        extendBackward( c.x, xd, q[ i - 1 ], xe );
+                    if( xe[ 2 ] == 0 )
+                        out.push_back( Seg{ i, j - i - 1, dS, -1, dN } );
+                    else if( xe[ 2 ] < dN )
+                    {
+                        i64 kLast = dS;
+                        for( i64 k = dS; k <= dS + dN; k++ )
+                        {
+                            bool cut = k == dS + dN;
+                            if( !cut )
+                            {
+                                i64 xr[ 3 ] = { k, -1, 1 }, xo[ 3 ];
+                                extendBackward( c.x, xr, q[ i - 1 ], xo );
+                                cut = xo[ 2 ] != 0;
+                            }
+                            if( cut )
+                            {
+                                if( k > kLast )
+                                    out.push_back( Seg{ i, j - i - 1, kLast, -1, k - kLast } );
+                                kLast = k + 1;
+                            }
+                        }
+                    }
+                }
+            }
+            ik[ 0 ] = ok[ 0 ], ik[ 1 ] = ok[ 1 ], ik[ 2 ] = ok[ 2 ];
+        }
+    }
+}
+
 // BinarySeeding::execute (binarySeeding.cpp:86-178), numSeedsLarger (segment.h:278-289)
 static void seedRead( const Ctx& c, const uint8_t* q, u64 qlen, std::vector<Seg>& out )
 {
     out.clear( );
     if( qlen == 0 )
         return;
-    procesInterval( c, 0, qlen, q, qlen, out );
+    if( c.P.seeding_technique == 2 )
+        memsExt( c, q, qlen, out );
+    else
+        procesInterval( c, 0, qlen, q, qlen, out );
     if( !c.P.disable_heuristics && c.P.min_seed_size_drop != 0 )
     {
         size_t sum = 0;

@@ -33,10 +33,12 @@ int main( int argc, char** argv )
         CaseFile c = readCase( argv[ 2 ] );
         ma_or_index* x = build( c );
         ma_or_params P;
-        if( !strcmp( argv[ 3 ], "illumina" ) )
+        if( !strncmp( argv[ 3 ], "illumina", 8 ) )
             ma_or_params_illumina( &P );
         else
             ma_or_params_default( &P );
+        if( strstr( argv[ 3 ], "+mems" ) ) // the preset with the MEMs seeding technique (see ref_dump.cpp selectPreset)
+            P.seeding_technique = 2;
         P.srand_seed = (uint32_t)atoi( argv[ 4 ] );
         if( argc >= 12 ) // pipe <case> <preset> <seed> <out> match mismatch gap extend gap2 extend2
         {

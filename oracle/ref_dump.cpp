@@ -73,6 +73,19 @@ static RefIndex buildIndex( const CaseFile& c )
     return r;
 }
 
+// "<preset>+mems" = the preset with "Seeding Technique" switched to its third choice, MEMs (parameter.h:671-675;
+// no preset of the reference selects it)
+static void selectPreset( ParameterSetManager& xParams, const char* sPreset )
+{
+    std::string s( sPreset );
+    const bool bMems = s.size( ) > 5 && s.compare( s.size( ) - 5, 5, "+mems" ) == 0;
+    if( bMems )
+        s.resize( s.size( ) - 5 );
+    xParams.setSelected( s );
+    if( bMems )
+        xParams.getSelected( )->xSeedingTechnique->set( 2 );
+}
+
 static int cmdIndex( const char* sCase, const char* sPrefix )
 {
     CaseFile c = readCase( sCase );
@@ -95,7 +108,7 @@ static int cmdPipe( const char* sCase, const char* sPreset, unsigned uiSeed, con
     CaseFile c = readCase( sCase );
     RefIndex idx = buildIndex( c );
     ParameterSetManager xParams;
-    xParams.setSelected( sPreset );
+    selectPreset( xParams, sPreset );
     BinarySeeding xSeeding( xParams );
     StripOfConsideration xSoc( xParams );
     Harmonization xHarm( xParams );
@@ -182,7 +195,7 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     CaseFile c = readCase( sCase );
     RefIndex idx = buildIndex( c );
     ParameterSetManager xParams;
-    xParams.setSelected( sPreset );
+    selectPreset( xParams, sPreset );
     xParams.getSelected( )->xSoftClip->set( ( iOptions & 1 ) != 0 );
     xParams.getSelected( )->xOutputMCigar->set( ( iOptions & 2 ) == 0 );
     BinarySeeding xSeeding( xParams );
@@ -241,7 +254,7 @@ static int cmdF4( const char* sCase, const char* sPreset, unsigned uiSeed, const
     CaseFile c = readCase( sCase );
     RefIndex idx = buildIndex( c );
     ParameterSetManager xParams;
-    xParams.setSelected( sPreset );
+    selectPreset( xParams, sPreset );
     xParams.getSelected( )->xSearchInversions->set( bInv );
     xParams.getSelected( )->xZDropInversion->set( iZDropInv );
     xParams.getSelected( )->xSoftClip->set( ( iOptions & 1 ) != 0 );
@@ -401,7 +414,7 @@ static int cmdTime( const char* sCase, const char* sPreset, int iThreads )
     CaseFile c = readCase( sCase );
     RefIndex idx = buildIndex( c );
     ParameterSetManager xParams;
-    xParams.setSelected( sPreset );
+    selectPreset( xParams, sPreset );
     BinarySeeding xSeeding( xParams );
     StripOfConsideration xSoc( xParams );
     Harmonization xHarm( xParams );

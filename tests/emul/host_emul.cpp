@@ -172,13 +172,16 @@ int main( int argc, char** argv )
         X.n_contigs = (i32)lens.size( );
     }
     ma_or_params OP;
-    if( std::string( argv[ 2 ] ) == "illumina" )
+    if( std::string( argv[ 2 ] ).compare( 0, 8, "illumina" ) == 0 )
         ma_or_params_illumina( &OP );
     else
         ma_or_params_default( &OP );
+    if( std::string( argv[ 2 ] ).find( "+mems" ) != std::string::npos ) // the preset with the MEMs seeding technique
+        OP.seeding_technique = 2;
     OP.srand_seed = (u32)atoi( argv[ 3 ] );
     SeedParams SP;
     SP.technique = OP.seeding_technique;
+    SP.min_seed_len = OP.min_seed_len;
     SP.min_amb = OP.min_ambiguity;
     SP.max_amb = OP.max_ambiguity;
     SP.min_seed_size_drop = OP.min_seed_size_drop;
@@ -235,14 +238,46 @@ int main( int argc, char** argv )
         std::vector<u32> seedStack( 2 * MA_SEED_STACK );
         SeedScratch SS{ stage.data( ), seg_cap, sa.data( ), sb.data( ), qlen + 2, SP.min_seed_size_drop, seedStack.data( ) };
         SeedLane L;
-        seed_begin_read( L, q.data( ), qlen );
-        seed_read_serial( L, SP, SS, X );
-        if( L.err )
+        u32 nseg = 0;
+        if( SP.technique == 2 )
         {
-            fprintf( stderr, "seeding overflow %u\n", L.err );
-            return 1;
+            // MEMs: one independent extension per start position (the kernel runs them as one lane each, k_mems)
+            struct VecSink
+            {
+                std::vector<ma_segment>& v;
+                void emit( u32 qs, u32 qsz, i64 sa, i64 san )
+                {
+                    ma_segment s;
+                    s.q_start = qs, s.q_size = qsz, s.sa_start = sa, s.sa_start_rc = -1, s.sa_size = san;
+                    v.push_back( s );
+                }
+            };
+            stage.clear( );
+            VecSink sink{ stage };
+            u64 st = 0, bl = 0;
+            for( u32 i = 0; i < qlen; i++ )
+                mems_from( X, SP, q.data( ), qlen, i, sink, st, bl );
+            nseg = (u32)stage.size( );
+            if( !SP.disable_heuristics && SP.min_seed_size_drop != 0 ) // k_mems_finish
+            {
+                u64 sum = 0;
+                for( auto& s : stage )
+                    sum += (u64)s.q_size / (u64)SP.min_seed_size_drop;
+                if( (double)sum < SP.rel_min_seed_size_amount * (double)qlen && SP.genome_size_disable < X.n )
+                    nseg = 0;
+            }
         }
-        const u32 nseg = seed_finish( L, SP, SS, X );
+        else
+        {
+            seed_begin_read( L, q.data( ), qlen );
+            seed_read_serial( L, SP, SS, X );
+            if( L.err )
+            {
+                fprintf( stderr, "seeding overflow %u\n", L.err );
+                return 1;
+            }
+            nseg = seed_finish( L, SP, SS, X );
+        }
         fprintf( f, "SEG %u\n", nseg );
         for( u32 k = 0; k < nseg; k++ )
             fprintf( f, "s %lld %lld %lld %lld %lld\n", (long long)stage[ k ].q_start, (long long)stage[ k ].q_size,

@@ -132,6 +132,7 @@ def main():
     for preset in ("default", "illumina"):
         run_ref("pipe", "small.case", preset, 1, "small_ref.%s.pipe" % preset)
     run_ref("pipe", "small.case", "default", 7, "small_ref.default.seed7.pipe")
+    run_ref("pipe", "small.case", "default+mems", 1, "small_ref.mems.pipe")  # "Seeding Technique" = MEMs (binarySeeding.h:460-537)
     sam_goldens()
     reader_goldens()
     # G7: kswcpp cases (all three flag modes, N bases, narrow bands, int16/int32 boundary)
@@ -141,7 +142,7 @@ def main():
     ksw_scoring_goldens()
     f4_goldens()
     for f in ("small_ref.ext", "small_ref.default.pipe", "small_ref.illumina.pipe", "small_ref.default.seed7.pipe",
-              "ksw_ref.out", "small.case", "ksw.case", "small_ref.bwt", "small_ref.sa", "small_ref.pac"):
+              "small_ref.mems.pipe", "ksw_ref.out", "small.case", "ksw.case", "small_ref.bwt", "small_ref.sa", "small_ref.pac"):
         gz(f)
     print("golden vectors written to", HERE)
 

@@ -388,10 +388,12 @@ def orlib():
 
 def or_params(preset="default", seed=1):
     p = OrParams()
-    if preset == "illumina":
+    if preset.startswith("illumina"):
         orlib().ma_or_params_illumina(C.byref(p))
     else:
         orlib().ma_or_params_default(C.byref(p))
+    if preset.endswith("+mems"):  # the MEMs seeding technique (binarySeeding.h:460-537), selected by no preset
+        p.seeding_technique = 2
     p.srand_seed = seed
     return p
 

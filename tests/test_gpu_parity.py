@@ -12,10 +12,18 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(ROOT, "tests", "golden")
 
 
+def gpu_params(preset, seed):
+    import ma_amd
+    P = ma_amd.Params.preset("illumina" if preset.startswith("illumina") else "default")
+    if preset.endswith("+mems"):  # "Seeding Technique" = MEMs (binarySeeding.h:460-537, selected by no preset)
+        P.seeding_technique = 2
+    P.srand_seed = seed
+    return P
+
+
 def gpu_pipeline(index, preset, seed, reads, stages=True):
     import ma_amd
-    P = ma_amd.Params.preset(preset)
-    P.srand_seed = seed
+    P = gpu_params(preset, seed)
     b = ma_amd.Batch(index, P, max(len(reads), 1), sum(len(r) for r in reads) + 64)
     b.set_reads(reads)
     b.seed()
@@ -318,7 +326,7 @@ def test_ksw_other_scoring_schemes(gpu_device, scoring):
         assert np.array_equal(cigs2[i], ocig), "pipeline semantics: case %d cigar" % i
 
 
-@pytest.mark.parametrize("preset", ["default", "illumina"])
+@pytest.mark.parametrize("preset", ["default", "illumina", "default+mems"])
 def test_pipeline_vs_compiled_reference_direct(gpu_device, tmp_path, preset):
     """No oracle in the loop: when the compiled reference travelled with the repository (oracle/_ref, built from
     /root/reference by oracle/Makefile.ref), its own modules and the GPU path align the same reads of a genome large enough
@@ -343,7 +351,8 @@ def test_pipeline_vs_compiled_reference_direct(gpu_device, tmp_path, preset):
 
 @pytest.mark.parametrize("preset,seed,name", [("default", 1, "small_ref.default.pipe"),
                                               ("illumina", 1, "small_ref.illumina.pipe"),
-                                              ("default", 7, "small_ref.default.seed7.pipe")])
+                                              ("default", 7, "small_ref.default.seed7.pipe"),
+                                              ("default+mems", 1, "small_ref.mems.pipe")])
 def test_pipeline_vs_reference_golden(small, preset, seed, name):
     want = parse_pipe_dump(os.path.join(G, name + ".gz"))
     got, counters, counts = gpu_pipeline(small["gidx"], preset, seed, small["reads"])

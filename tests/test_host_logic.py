@@ -30,7 +30,8 @@ def test_stdsort_matches_libstdcxx(emul):
     assert "sortcheck ok" in out
 
 
-@pytest.mark.parametrize("preset,name", [("default", "small_ref.default.pipe"), ("illumina", "small_ref.illumina.pipe")])
+@pytest.mark.parametrize("preset,name", [("default", "small_ref.default.pipe"), ("illumina", "small_ref.illumina.pipe"),
+                                         ("default+mems", "small_ref.mems.pipe")])
 def test_stage_logic_vs_reference_golden(emul, tmp_path, preset, name):
     case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
     ref = gunzip_to(os.path.join(G, name + ".gz"), str(tmp_path / name))
@@ -45,7 +46,7 @@ def test_stage_logic_vs_oracle_long_reads(emul, tmp_path):
              + sample_reads(g, 1, 20000, 3, sub=0.03, ins=0.03, dele=0.03))
     case = str(tmp_path / "c.case")
     write_case(case, g, reads)
-    for preset in ("default", "illumina"):
+    for preset in ("default", "illumina", "default+mems"):
         run_oracle("pipe", case, preset, 5, str(tmp_path / "or.pipe"))
         subprocess.check_call([emul, case, preset, "5", str(tmp_path / "em.pipe"), "all"])
         assert first_diff(str(tmp_path / "or.pipe"), str(tmp_path / "em.pipe")) is None

@@ -35,7 +35,8 @@ def test_extend_backward_traces_identical(small_case):
 
 @pytest.mark.parametrize("preset,seed,name", [("default", 1, "small_ref.default.pipe"),
                                               ("illumina", 1, "small_ref.illumina.pipe"),
-                                              ("default", 7, "small_ref.default.seed7.pipe")])
+                                              ("default", 7, "small_ref.default.seed7.pipe"),
+                                              ("default+mems", 1, "small_ref.mems.pipe")])
 def test_pipeline_dump_identical(small_case, preset, seed, name):
     case, d = small_case
     out = str(d / (name + ".or"))

@@ -42,7 +42,7 @@ def test_ksw_other_scoring_schemes(tmp_path, sc):
 # kswcpp itself takes its parameters explicitly and is pinned above.
 
 
-@pytest.mark.parametrize("preset", ["default", "illumina"])
+@pytest.mark.parametrize("preset", ["default", "illumina", "default+mems", "illumina+mems"])
 def test_pipeline_with_heuristics_and_repeats(tmp_path, preset):
     # doubled length > 10 Mnt so that the genome-size gated heuristics are active
     g = rand_genome(5, [2600000, 1500000, 1000000], repeat_unit=300, repeat_copies=200, repeat_div=0.08)
