@@ -147,6 +147,8 @@ int main( int argc, char** argv )
         pFmP->set( pFM );
         auto pSai = std::make_shared<Pledge<SuffixArrayInterface>>( );
         pSai->set( pFM );
+        // the chain of export.cpp:104-108 only hands its intermediate containers from one MI355X module to the next
+        defaultBatcherOptions( ).bStages = false;
         auto pReader = std::make_shared<VecReader>( *pReads );
         auto pSeeding = std::make_shared<BinarySeeding>( xParams );
         auto pSOC = std::make_shared<StripOfConsideration>( xParams );
@@ -171,6 +173,11 @@ int main( int argc, char** argv )
         BasePledge::simultaneousGet( vSinks );
         const double fGraph = now( ) - t0;
         auto xStat = pSeeding->batchStatistics( );
+        double fRun = 0, fUp = 0, fKern = 0, fDown = 0;
+        if( pSeeding->batcher( ) != nullptr )
+            pSeeding->batcher( )->phaseSeconds( fRun, fUp, fKern, fDown );
+        fprintf( stderr, "graph leg: %.3f s wall; device batches: run %.3f s (h2d %.3f, kernels %.3f, d2h %.3f) summed over %llu batches\n",
+                 fGraph, fRun, fUp, fKern, fDown, (unsigned long long)xStat.first );
         printf( "{\"reads\": %zu, \"read_len\": %zu, \"host_threads\": %u, \"index_load_s\": %.2f, "
                 "\"batch_aligner\": {%s, \"what\": \"reads in host memory -> BatchAligner::execute (H2D, all stages, D2H, Alignment "
                 "containers); 256 k reads per device batch; phase times summed over the batches\"}, "

@@ -47,7 +47,14 @@ __device__ __forceinline__ u32 pk_lshr15( u32 a ) { return KR( KU2( a ) >> (unsi
 __device__ __forceinline__ u32 pk_mad( u32 a, u32 b, u32 c ) { return KR( KU2( a ) * KU2( b ) + KU2( c ) ); }
 __device__ __forceinline__ u32 pk_bfi( u32 mask, u32 a, u32 b ) // mask ? a : b, bitwise
 {
-    return b ^ ( ( a ^ b ) & mask ); // one v_bitop3_b32
+    // ONE v_bitop3_b32 (truth table 0xCA = multiplexer).  Written as b ^ ((a ^ b) & mask) the compiler emits v_xor + v_bitop3;
+    // v_bitop3_b32 issues at the full VALU rate (2.2 cycles per wave64 instruction, v_bfi_b32 / v_and_or_b32 at 4.1:
+    // profiles/r02_valu_mix.txt)
+    return __builtin_amdgcn_bitop3_b32( mask, a, b, 0xCA );
+}
+__device__ __forceinline__ u32 and_or( u32 a, u32 m, u32 c ) // (a & m) | c as one full-rate v_bitop3_b32 (not v_and_or_b32)
+{
+    return __builtin_amdgcn_bitop3_b32( a, m, c, 0xEA );
 }
 // Opaque to the optimiser: keeps a per-half 0 / 0xffff mask a plain 32-bit value, so that pk_bfi stays ONE v_bfi_b32
 // instead of being rewritten into per-half compares + v_cndmask + v_perm (4-5 instructions per select).
@@ -461,8 +468,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             // continuation flags = sign bit of a packed difference (no overflow: the scoring guard of ksw_ext_slots keeps
             // every difference vector far inside int8): LEFT a > 0, RIGHT !(a < 0) (kswcpp_core.h:653-699)
             const u32 fa = pk_sub( K_FX, a ), fb = pk_sub( K_FY, b ), fa2 = pk_sub( K_FX2, a2 ), fb2 = pk_sub( K_FY2, b2 );
-            d |= ( ( fa >> 12 ) & 0x00080008u ) | ( ( fb >> 11 ) & 0x00100010u ) | ( ( fa2 >> 10 ) & 0x00200020u ) |
-                 ( ( fb2 >> 9 ) & 0x00400040u );
+            d = and_or( fa >> 12, 0x00080008u, and_or( fb >> 11, 0x00100010u, and_or( fa2 >> 10, 0x00200020u, and_or( fb2 >> 9, 0x00400040u, d ) ) ) );
             // ---- commit: u, y, y2 of cells that are not born yet keep their first-row initialisation
             U[ s ] = pk_bfi( LM, nu, ut );
             Y[ s ] = pk_bfi( LM, ny, Y[ s ] );

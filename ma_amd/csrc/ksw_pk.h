@@ -302,8 +302,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                     fa2 = ~pk_subsat( a2, K_TX2 );
                     fb2 = ~pk_subsat( b2, K_TY2 );
                 }
-                d |= ( ( fa >> 12 ) & 0x00080008u ) | ( ( fb >> 11 ) & 0x00100010u ) | ( ( fa2 >> 10 ) & 0x00200020u ) |
-                     ( ( fb2 >> 9 ) & 0x00400040u );
+                d = and_or( fa >> 12, 0x00080008u, and_or( fb >> 11, 0x00100010u, and_or( fa2 >> 10, 0x00200020u, and_or( fb2 >> 9, 0x00400040u, d ) ) ) );
                 if( tt >= st && tt <= en ) // st is even, en odd: a lane is inside with both cells or not at all
                 {
                     U[ s ] = nu;

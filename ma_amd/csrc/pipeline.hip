@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cstring>
 #include <memory>
+#include <mutex>
 
 using namespace ma;
 
@@ -44,6 +45,9 @@ enum : int
     CTR_N_REDO = 34, // u32: jobs the extension kernel handed back
     CTR_CIG_WORDS = 35, // cigar words written (CTR_CIG_USED counts pool words reserved)
     CTR_NEXT_SEED = 36, // queue of k_lf_walk
+    CTR_OPS_ALL = 37, // alignment ops of all alignments / of the MappingQuality selection (exact sizes of the downloads)
+    CTR_OPS_MQ = 38,
+    CTR_ALN_MQ = 39, // alignments MappingQuality keeps
     CTR_COUNT = 40
 };
 
@@ -949,14 +953,83 @@ __global__ void k_finish( NwParams P, u32 n_reads, const u64* hset_off, const u6
                           u32* order, u32* mq_order, u32* mq_cnt, unsigned long long* ctr )
 {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 b = r < n_reads ? hset_off[ r ] : 0;
+    const u32 n = r < n_reads ? (u32)( hset_off[ r + 1 ] - b ) : 0;
+    u32 m = 0;
+    u64 opsAll = 0, opsMq = 0;
+    if( r < n_reads )
+    {
+        m = finish_read( P, hdr + b, ops, n, roff[ r + 1 ] - roff[ r ], order + b, mq_order + b );
+        mq_cnt[ r ] = m;
+        for( u32 k = 0; k < n; k++ )
+            opsAll += hdr[ b + k ].n_ops;
+        for( u32 k = 0; k < m; k++ )
+            opsMq += hdr[ b + mq_order[ b + k ] ].n_ops;
+    }
+    // one atomic per wave and quantity
+    const u64 al = wave_sum_u64( m ? 1 : 0 ), am = wave_sum_u64( m ), oa = wave_sum_u64( opsAll ), om = wave_sum_u64( opsMq );
+    if( ( threadIdx.x & 63 ) == 0 )
+    {
+        if( al )
+            atomicAdd( &ctr[ CTR_N_ALIGNED ], (unsigned long long)al );
+        if( oa )
+        {
+            atomicAdd( &ctr[ CTR_OPS_ALL ], (unsigned long long)oa );
+            atomicAdd( &ctr[ CTR_OPS_MQ ], (unsigned long long)om );
+            atomicAdd( &ctr[ CTR_ALN_MQ ], (unsigned long long)am );
+        }
+    }
+}
+
+// ---- results in the order and layout of the C ABI, packed on the device so that a download is three plain copies:
+// per read its alignments (NeedlemanWunsch order, or the MappingQuality selection), their ops as (type, length) pairs
+__global__ void k_aln_sizes( u32 n_reads, const u64* hset_off, const AlnHeader* hdr, const u32* order, const u32* mq_cnt, int mq,
+                             u64* cnt, u64* nops )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if( r >= n_reads )
         return;
     const u64 b = hset_off[ r ];
-    const u32 n = (u32)( hset_off[ r + 1 ] - b );
-    const u32 m = finish_read( P, hdr + b, ops, n, roff[ r + 1 ] - roff[ r ], order + b, mq_order + b );
-    mq_cnt[ r ] = m;
-    if( m )
-        atomicAdd( &ctr[ CTR_N_ALIGNED ], 1ull );
+    const u32 c = mq ? mq_cnt[ r ] : (u32)( hset_off[ r + 1 ] - b );
+    u64 o = 0;
+    for( u32 k = 0; k < c; k++ )
+        o += hdr[ b + order[ b + k ] ].n_ops;
+    cnt[ r ] = c;
+    nops[ r ] = o;
+}
+__global__ void k_aln_pack( u32 n_reads, const u64* hset_off, const AlnHeader* hdr, const u32* order, const u64* pool, int mq,
+                            const u64* aln_off, const u64* ops_off, ma_alignment* alns, u64* ops )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    const u64 b = hset_off[ r ];
+    const u32 c = (u32)( aln_off[ r + 1 ] - aln_off[ r ] );
+    u64 po = ops_off[ r ];
+    for( u32 k = 0; k < c; k++ )
+    {
+        const AlnHeader& h = hdr[ b + order[ b + k ] ];
+        ma_alignment a;
+        a.begin_ref = (i64)h.begin_ref;
+        a.end_ref = (i64)h.end_ref;
+        a.begin_q = (i64)h.begin_q;
+        a.end_q = (i64)h.end_q;
+        a.score = h.score;
+        a.soc_index = h.soc_index;
+        a.n_ops = h.n_ops;
+        a.ops_off = po;
+        a.secondary = mq ? h.secondary : 0;
+        a.supplementary = mq ? h.supplementary : 0;
+        a.mapq = mq ? h.mapq : 0.0;
+        alns[ aln_off[ r ] + k ] = a;
+        for( u32 j = 0; j < h.n_ops; j++ )
+        {
+            const u64 o = pool[ h.ops_off + j ];
+            ops[ 2 * ( po + j ) ] = op_type( o );
+            ops[ 2 * ( po + j ) + 1 ] = op_len( o );
+        }
+        po += h.n_ops;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -987,6 +1060,7 @@ struct ma_batch
     u64 hpoolCap = 0, nHsets = 0, nHseeds = 0;
     // dp
     DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, clsLists, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
+    DevBuf outCnt, outOps, outAlnOff, outOpsOff, outAlns, outOpsPairs; // packed results (get_alns)
     u64 cigPoolCap = 0, cigPoolMin = 0, nOpsCap = 0, nJobSlots = 0;
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
     bool timing = false;
@@ -1555,6 +1629,24 @@ static NwParams nw_params( const ma_params& P )
     return N;
 }
 
+// The DP kernels are bound by VALU issue: two batches' DP stages running at the same time only slow each other down
+// (measured: each takes ~1.8x as long), while a DP stage next to another batch's memory-bound seeding / chaining kernels
+// does overlap.  With several batches in flight per device (own streams, own host threads) the DP stages therefore take
+// turns: one at a time per device.  MA_DP_EXCLUSIVE=0 switches the turn-taking off (tuning hook).
+static std::mutex& dp_turn( int device )
+{
+    static std::mutex turn[ 64 ];
+    return turn[ device & 63 ];
+}
+static bool dp_exclusive( )
+{
+    static const bool on = []( ) {
+        const char* e = getenv( "MA_DP_EXCLUSIVE" );
+        return !( e && atoi( e ) == 0 );
+    }( );
+    return on;
+}
+
 int ma_dp_batch( ma_batch* b )
 {
     if( !b || b->stage_done < 3 )
@@ -1623,6 +1715,9 @@ int ma_dp_batch( ma_batch* b )
         KswScoring SC{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
         unsigned long long* c = b->ctr.as<unsigned long long>( );
         PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
+        std::unique_lock<std::mutex> xTurn( dp_turn( b->device ), std::defer_lock );
+        if( dp_exclusive( ) )
+            xTurn.lock( ); // released when the launches below have drained (read_ctr synchronises the stream)
         // the pool size is a heuristic as well: if the cigars did not fit, the DP stage is run again with the counted need
         for( int attempt = 0; attempt < 2; attempt++ )
         {
@@ -1968,8 +2063,8 @@ int ma_batch_counts( ma_batch* b, uint64_t* n_segments, uint64_t* n_seeds, uint6
         *n_hseeds = b->nHseeds;
     if( n_alignments )
         *n_alignments = b->stage_done >= 4 ? b->nHsets : 0;
-    if( n_ops )
-        *n_ops = b->stage_done >= 4 ? b->nOpsCap : 0;
+    if( n_ops ) // exact: the ops of all alignments (the MappingQuality selection has at most as many)
+        *n_ops = b->stage_done >= 4 ? b->hctr[ CTR_OPS_ALL ] : 0;
     if( n_aligned_reads )
         *n_aligned_reads = b->hctr[ CTR_N_ALIGNED ];
     return 0;
@@ -2085,57 +2180,41 @@ static int get_alns( ma_batch* b, bool mq, uint64_t* aln_off, ma_alignment* alns
     if( ma_batch_sync( b ) )
         return 1;
     const u64 n = b->n_reads, nh = b->nHsets;
-    std::vector<u64> hoff( n + 1, 0 );
-    std::vector<AlnHeader> hdr( nh );
-    std::vector<u32> ord( nh ), mqc( n + 1, 0 );
-    std::vector<u64> pool( b->nOpsCap + 1 );
-    if( n && nh )
-    {
-        MA_HIP( hipMemcpy( hoff.data( ), b->hsetOff.p, ( n + 1 ) * 8, hipMemcpyDeviceToHost ) );
-        MA_HIP( hipMemcpy( hdr.data( ), b->hdr.p, nh * sizeof( AlnHeader ), hipMemcpyDeviceToHost ) );
-        MA_HIP( hipMemcpy( ord.data( ), mq ? b->mqOrder.p : b->order.p, nh * 4, hipMemcpyDeviceToHost ) );
-        MA_HIP( hipMemcpy( mqc.data( ), b->mqCnt.p, n * 4, hipMemcpyDeviceToHost ) );
-        if( b->nOpsCap )
-            MA_HIP( hipMemcpy( pool.data( ), b->ops.p, b->nOpsCap * 8, hipMemcpyDeviceToHost ) );
-    }
-    u64 o = 0, po = 0;
-    for( u64 r = 0; r < n; r++ )
+    if( aln_off )
+        aln_off[ 0 ] = 0;
+    if( n == 0 )
+        return 0;
+    if( nh == 0 )
     {
         if( aln_off )
-            aln_off[ r ] = o;
-        const u64 base = hoff[ r ];
-        const u32 cnt = mq ? mqc[ r ] : (u32)( hoff[ r + 1 ] - hoff[ r ] );
-        for( u32 k = 0; k < cnt; k++ )
-        {
-            const AlnHeader& h = hdr[ base + ord[ base + k ] ];
-            if( alns )
-            {
-                ma_alignment a;
-                a.begin_ref = (i64)h.begin_ref;
-                a.end_ref = (i64)h.end_ref;
-                a.begin_q = (i64)h.begin_q;
-                a.end_q = (i64)h.end_q;
-                a.score = h.score;
-                a.soc_index = h.soc_index;
-                a.n_ops = h.n_ops;
-                a.ops_off = po;
-                a.secondary = mq ? h.secondary : 0;
-                a.supplementary = mq ? h.supplementary : 0;
-                a.mapq = mq ? h.mapq : 0.0;
-                alns[ o + k ] = a;
-            }
-            if( ops )
-                for( u32 j = 0; j < h.n_ops; j++ )
-                {
-                    ops[ 2 * ( po + j ) ] = op_type( pool[ h.ops_off + j ] );
-                    ops[ 2 * ( po + j ) + 1 ] = op_len( pool[ h.ops_off + j ] );
-                }
-            po += h.n_ops;
-        }
-        o += cnt;
+            memset( aln_off, 0, ( n + 1 ) * 8 );
+        return 0;
     }
+    const u64 totalA = mq ? b->hctr[ CTR_ALN_MQ ] : nh, totalO = mq ? b->hctr[ CTR_OPS_MQ ] : b->hctr[ CTR_OPS_ALL ];
+    if( b->outCnt.reserve( ( n + 2 ) * 8 ) || b->outOps.reserve( ( n + 2 ) * 8 ) || b->outAlnOff.reserve( ( n + 2 ) * 8 ) ||
+        b->outOpsOff.reserve( ( n + 2 ) * 8 ) || b->outAlns.reserve( ( totalA + 1 ) * sizeof( ma_alignment ) ) ||
+        b->outOpsPairs.reserve( ( totalO + 1 ) * 16 ) )
+        return 1;
+    const u32* ord = mq ? b->mqOrder.as<u32>( ) : b->order.as<u32>( );
+    const dim3 grid( (unsigned)( ( n + 255 ) / 256 ) ), block( 256 );
+    hipLaunchKernelGGL( k_aln_sizes, grid, block, 0, b->stream, (u32)n, b->hsetOff.as<u64>( ), b->hdr.as<AlnHeader>( ), ord,
+                        b->mqCnt.as<u32>( ), mq ? 1 : 0, b->outCnt.as<u64>( ), b->outOps.as<u64>( ) );
+    MA_HIP( hipMemsetAsync( (char*)b->outCnt.p + n * 8, 0, 8, b->stream ) );
+    MA_HIP( hipMemsetAsync( (char*)b->outOps.p + n * 8, 0, 8, b->stream ) );
+    if( scan_exclusive<u64>( b, b->outCnt.as<u64>( ), b->outAlnOff.as<u64>( ), n + 1 ) ||
+        scan_exclusive<u64>( b, b->outOps.as<u64>( ), b->outOpsOff.as<u64>( ), n + 1 ) )
+        return 1;
+    hipLaunchKernelGGL( k_aln_pack, grid, block, 0, b->stream, (u32)n, b->hsetOff.as<u64>( ), b->hdr.as<AlnHeader>( ), ord,
+                        b->ops.as<u64>( ), mq ? 1 : 0, b->outAlnOff.as<u64>( ), b->outOpsOff.as<u64>( ), b->outAlns.as<ma_alignment>( ),
+                        b->outOpsPairs.as<u64>( ) );
+    MA_HIP( hipGetLastError( ) );
     if( aln_off )
-        aln_off[ n ] = o;
+        MA_HIP( hipMemcpyAsync( aln_off, b->outAlnOff.p, ( n + 1 ) * 8, hipMemcpyDeviceToHost, b->stream ) );
+    if( alns && totalA )
+        MA_HIP( hipMemcpyAsync( alns, b->outAlns.p, totalA * sizeof( ma_alignment ), hipMemcpyDeviceToHost, b->stream ) );
+    if( ops && totalO )
+        MA_HIP( hipMemcpyAsync( ops, b->outOpsPairs.p, totalO * 16, hipMemcpyDeviceToHost, b->stream ) );
+    MA_HIP( hipStreamSynchronize( b->stream ) );
     return 0;
 }
 

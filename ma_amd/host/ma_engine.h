@@ -155,6 +155,11 @@ struct BatcherOptions
     size_t uiEngines = 2; // device batches in flight (own stream each)
     std::chrono::microseconds xGather{ 40 }; // an idle GPU still waits this long for more reads to arrive
     std::chrono::microseconds xMaxWait{ 20000 }; // a read never waits longer than this for its batch to be sealed
+    // true: every stage's records are fetched, so SegmentVector / SoCPriorityQueue / seed sets / NeedlemanWunsch's
+    // alignments carry their content (what a graph needs whose nodes are not all MI355X modules).  false: only the
+    // MappingQuality-annotated alignments are fetched; the intermediate containers are empty shells that just pass the
+    // ticket on -- enough for the chain of export.cpp:104-108 and several times cheaper per read.
+    bool bStages = true;
 };
 
 class DeviceBatcher
@@ -165,6 +170,7 @@ class DeviceBatcher
         std::shared_ptr<const BatchResult> pResult;
         std::string sError;
         bool bSealed = false, bDone = false;
+        std::condition_variable xDone; // only this batch's readers wait here: a finished batch wakes nobody else
     };
     const ma_index* pIndex;
     const ma_params xP;
@@ -175,6 +181,7 @@ class DeviceBatcher
     std::vector<std::unique_ptr<Engine>> vIdle; // engines not running a batch
     size_t uiEnginesMade = 0, uiRunning = 0;
     uint64_t uiBatches = 0, uiReadsTotal = 0;
+    double fSumH2D = 0, fSumKernels = 0, fSumD2H = 0, fSumRun = 0; // seconds over all batches
 
     // called with the lock held by the thread that sealed the slot; releases the lock while the GPU works
     void runSealed( std::unique_lock<std::mutex>& rLock, const std::shared_ptr<Slot>& pSlot )
@@ -190,11 +197,12 @@ class DeviceBatcher
             uiEnginesMade++; // constructed below, outside the lock
         uiRunning++;
         rLock.unlock( );
+        const auto tRun = std::chrono::steady_clock::now( );
         try
         {
             if( pEngine == nullptr )
                 pEngine.reset( new Engine( pIndex, xP ) );
-            pSlot->pResult = pEngine->run( pSlot->vReads, true );
+            pSlot->pResult = pEngine->run( pSlot->vReads, xOpt.bStages );
         }
         catch( const std::exception& rE )
         {
@@ -210,8 +218,12 @@ class DeviceBatcher
         uiRunning--;
         uiBatches++;
         uiReadsTotal += pSlot->vReads.size( );
+        fSumRun += secondsSince( tRun );
+        if( pSlot->pResult != nullptr )
+            fSumH2D += pSlot->pResult->fH2D, fSumKernels += pSlot->pResult->fKernels, fSumD2H += pSlot->pResult->fD2H;
         pSlot->bDone = true;
-        xChanged.notify_all( );
+        pSlot->xDone.notify_all( );
+        xChanged.notify_all( ); // leaders of open batches and sealers waiting for a device slot
     }
 
   public:
@@ -259,7 +271,7 @@ class DeviceBatcher
                 runSealed( xLock, pSlot );
             }
         }
-        xChanged.wait( xLock, [ & ]( ) { return pSlot->bDone; } );
+        pSlot->xDone.wait( xLock, [ & ]( ) { return pSlot->bDone; } );
         if( !pSlot->sError.empty( ) )
             throw std::runtime_error( pSlot->sError );
         Ticket xT;
@@ -274,6 +286,12 @@ class DeviceBatcher
         std::lock_guard<std::mutex> xLock( xMutex );
         rBatches = uiBatches;
         rReads = uiReadsTotal;
+    }
+    // seconds summed over all device batches: whole run() calls, and inside them upload / kernels / download
+    void phaseSeconds( double& rRun, double& rH2D, double& rKernels, double& rD2H )
+    {
+        std::lock_guard<std::mutex> xLock( xMutex );
+        rRun = fSumRun, rH2D = fSumH2D, rKernels = fSumKernels, rD2H = fSumD2H;
     }
 };
 } // namespace detail

@@ -804,7 +804,7 @@ class BinarySeeding : public libMS::Module<SegmentVector, false, SuffixArrayInte
             return pRet;
         pRet->xTicket = batcherFor( pFM_index->pDev )->align( pQuerySeq->xCodes );
         const detail::BatchResult& R = *pRet->xTicket.pResult;
-        for( uint64_t i = R.vSegOff[ pRet->xTicket.uiRead ]; i < R.vSegOff[ pRet->xTicket.uiRead + 1 ]; i++ )
+        for( uint64_t i = R.bStages ? R.vSegOff[ pRet->xTicket.uiRead ] : 0; R.bStages && i < R.vSegOff[ pRet->xTicket.uiRead + 1 ]; i++ )
         {
             Segment s;
             s.iStart = R.vSegs[ i ].q_start;
@@ -815,6 +815,11 @@ class BinarySeeding : public libMS::Module<SegmentVector, false, SuffixArrayInte
             pRet->push_back( s );
         }
         return pRet;
+    }
+    std::shared_ptr<detail::DeviceBatcher> batcher( ) // diagnostics
+    {
+        std::lock_guard<std::mutex> xGuard( xBatcherMutex );
+        return pBatcher;
     }
     // device batches run so far and the reads they carried (diagnostics)
     std::pair<uint64_t, uint64_t> batchStatistics( )
@@ -848,7 +853,7 @@ class StripOfConsideration : public libMS::Module<SoCPriorityQueue, false, Segme
         {
             pRet->xTicket = pSegments->xTicket;
             const detail::BatchResult& R = *pRet->xTicket.pResult;
-            for( uint64_t i = R.vSeedOff[ pRet->xTicket.uiRead ]; i < R.vSeedOff[ pRet->xTicket.uiRead + 1 ]; i++ )
+            for( uint64_t i = R.bStages ? R.vSeedOff[ pRet->xTicket.uiRead ] : 0; R.bStages && i < R.vSeedOff[ pRet->xTicket.uiRead + 1 ]; i++ )
                 pRet->pSeeds->push_back( detail::toSeed( R.vSeeds[ i ] ) );
             return pRet;
         }
@@ -893,8 +898,9 @@ class Harmonization : public libMS::Module<SeedsSetVector, false, SoCPriorityQue
         {
             pRet->xTicket = pSoCIn->xTicket;
             const detail::BatchResult& R = *pRet->xTicket.pResult;
-            detail::appendHsets( R.vHseedOff, R.vHsetSoc, R.vHseeds, R.vHsetOff[ pRet->xTicket.uiRead ],
-                                 R.vHsetOff[ pRet->xTicket.uiRead + 1 ], *pRet );
+            if( R.bStages )
+                detail::appendHsets( R.vHseedOff, R.vHsetSoc, R.vHseeds, R.vHsetOff[ pRet->xTicket.uiRead ],
+                                     R.vHsetOff[ pRet->xTicket.uiRead + 1 ], *pRet );
             return pRet;
         }
         // a queue from elsewhere: its seeds are uploaded, sweep + harmonization run on the device
@@ -937,8 +943,9 @@ class NeedlemanWunsch
         {
             pRet->xTicket = pIn->xTicket;
             const detail::BatchResult& R = *pRet->xTicket.pResult;
-            detail::appendAlignments( R.vAlns, R.vAlnOps, R.vAlnOff[ pRet->xTicket.uiRead ], R.vAlnOff[ pRet->xTicket.uiRead + 1 ],
-                                      false, *pRet );
+            if( R.bStages )
+                detail::appendAlignments( R.vAlns, R.vAlnOps, R.vAlnOff[ pRet->xTicket.uiRead ], R.vAlnOff[ pRet->xTicket.uiRead + 1 ],
+                                          false, *pRet );
             return pRet;
         }
         // seed sets from elsewhere: upload, run the DP stage (+ mapping quality, fetched by MappingQuality if it follows)
