@@ -164,6 +164,9 @@ int ma_batch_create( const ma_index*, const ma_params*, uint64_t max_reads, uint
 int ma_batch_destroy( ma_batch* );
 /* stream: a hipStream_t (as void*) all stage kernels of this batch are launched on; NULL = default stream */
 int ma_batch_set_stream( ma_batch*, void* hip_stream );
+/* waits of this batch's calls: 0 = the runtime's spinning stream synchronisation (lowest latency, default), 1 = sleep on
+ * an interrupt-driven event (hosts running far more threads than cores: the DeviceBatcher of the host layer) */
+int ma_batch_set_blocking_sync( ma_batch*, int on );
 /* reads as 1 byte/base codes, CSR offsets[n+1]; host or device pointers */
 int ma_batch_set_reads( ma_batch*, const uint8_t* codes, const uint64_t* offsets, uint64_t n_reads );
 int ma_batch_set_reads_device( ma_batch*, const void* d_codes, const void* d_offsets, uint64_t n_reads,

@@ -487,6 +487,26 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             }
         }
         nCells += (u32)( en0 - st0 + 1 );
+#if defined( MA_EXP_SALU ) // experiment (tools/dp_bound_experiment.sh): which issue port bounds the loop?
+        {
+            u32 t0 = (u32)r;
+            asm volatile( "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
+                          "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
+                          : "+s"( t0 ) );
+            if( t0 == 0xdeadbeefu )
+                nCells++;
+        }
+#endif
+#if defined( MA_EXP_VALU )
+        {
+            u32 t0 = U[ 0 ];
+            asm volatile( "v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n"
+                          "v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n"
+                          : "+v"( t0 ) );
+            if( t0 == 0xdeadbeefu )
+                nCells++;
+        }
+#endif
         if( GLOBAL )
             continue;
         // ---- the diagonal's maximum

@@ -1064,16 +1064,37 @@ struct ma_batch
     u64 cigPoolCap = 0, cigPoolMin = 0, nOpsCap = 0, nJobSlots = 0;
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
     bool timing = false;
+    bool blocking = false; // batch_wait: sleep on an event instead of spinning
+    hipEvent_t waitEv = nullptr;
     hipEvent_t ev[ 16 ];
     bool evInit = false;
     float kms[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long hctr[ CTR_COUNT ];
 };
 
+// Waits for the batch's stream.  Default: hipStreamSynchronize (the runtime spins: lowest latency, one host core busy).
+// With blocking waits (ma_batch_set_blocking_sync) the host thread sleeps on an interrupt-driven event instead: the mode for
+// hosts that run many more threads than cores (the per-read graph funnel), where a spinning runner burns the time slice
+// it then lacks for the next launch.
+static int batch_wait( ma_batch* b )
+{
+    if( !b->blocking )
+    {
+        MA_HIP( hipStreamSynchronize( b->stream ) );
+        return 0;
+    }
+    if( !b->waitEv )
+        MA_HIP( hipEventCreateWithFlags( &b->waitEv, hipEventBlockingSync | hipEventDisableTiming ) );
+    MA_HIP( hipEventRecord( b->waitEv, b->stream ) );
+    MA_HIP( hipEventSynchronize( b->waitEv ) );
+    return 0;
+}
+
 static int read_ctr( ma_batch* b )
 {
     MA_HIP( hipMemcpyAsync( b->hctr, b->ctr.p, sizeof( b->hctr ), hipMemcpyDeviceToHost, b->stream ) );
-    MA_HIP( hipStreamSynchronize( b->stream ) );
+    if( batch_wait( b ) )
+        return 1;
     return 0;
 }
 
@@ -1156,6 +1177,8 @@ int ma_batch_destroy( ma_batch* b )
     if( b->evInit )
         for( int i = 0; i < 16; i++ )
             (void)hipEventDestroy( b->ev[ i ] );
+    if( b->waitEv )
+        (void)hipEventDestroy( b->waitEv );
     delete b;
     return 0;
 }
@@ -1165,6 +1188,14 @@ int ma_batch_set_stream( ma_batch* b, void* s )
     if( !b )
         return fail( "ma_batch_set_stream: null batch" );
     b->stream = (hipStream_t)s;
+    return 0;
+}
+
+int ma_batch_set_blocking_sync( ma_batch* b, int on )
+{
+    if( !b )
+        return fail( "ma_batch_set_blocking_sync: null batch" );
+    b->blocking = on != 0;
     return 0;
 }
 
@@ -1199,7 +1230,8 @@ int ma_batch_set_reads( ma_batch* b, const uint8_t* codes, const uint64_t* offse
     if( b->n_bases )
         MA_HIP( hipMemcpyAsync( b->reads.p, codes, b->n_bases, hipMemcpyHostToDevice, b->stream ) );
     MA_HIP( hipMemcpyAsync( b->roff.p, offsets, ( n + 1 ) * 8, hipMemcpyHostToDevice, b->stream ) );
-    MA_HIP( hipStreamSynchronize( b->stream ) );
+    if( batch_wait( b ) )
+        return 1;
     b->d_reads = b->reads.as<uint8_t>( );
     b->d_roff = b->roff.as<u64>( );
     b->reads_external = false;
@@ -1276,7 +1308,8 @@ static int seed_mems( ma_batch* b )
         if( scan_exclusive<u64>( b, b->memsCnt.as<u64>( ), b->memsOff.as<u64>( ), nb + 1 ) )
             return 1;
         MA_HIP( hipMemcpyAsync( &total, (char*)b->memsOff.p + nb * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
-        MA_HIP( hipStreamSynchronize( b->stream ) );
+        if( batch_wait( b ) )
+        return 1;
     }
     else
         MA_HIP( hipMemsetAsync( b->memsOff.p, 0, 16, b->stream ) );
@@ -1291,7 +1324,8 @@ static int seed_mems( ma_batch* b )
                         b->memsOff.as<u64>( ), b->segPool.as<ma_segment>( ), b->segOff.as<u64>( ), b->segCnt.as<u32>( ) );
     const unsigned long long used = total;
     MA_HIP( hipMemcpyAsync( b->ctr.as<unsigned long long>( ) + CTR_SEG_USED, &used, 8, hipMemcpyHostToDevice, b->stream ) );
-    MA_HIP( hipStreamSynchronize( b->stream ) );
+    if( batch_wait( b ) )
+        return 1;
     MA_HIP( hipGetLastError( ) );
     b->stage_done = 1;
     return 0;
@@ -1432,7 +1466,8 @@ int ma_extract_seeds_batch( ma_batch* b )
         if( scan_exclusive<u64>( b, b->segSeedCnt.as<u64>( ), b->segSeedOff.as<u64>( ), ns + 1 ) )
             return 1;
         MA_HIP( hipMemcpyAsync( &total, (char*)b->segSeedOff.p + ns * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
-        MA_HIP( hipStreamSynchronize( b->stream ) );
+        if( batch_wait( b ) )
+        return 1;
     }
     b->nSeeds = total;
     if( b->seeds.reserve( ( total + 1 ) * sizeof( ma_seed ) ) )
@@ -1632,7 +1667,8 @@ static NwParams nw_params( const ma_params& P )
 // The DP kernels are bound by VALU issue: two batches' DP stages running at the same time only slow each other down
 // (measured: each takes ~1.8x as long), while a DP stage next to another batch's memory-bound seeding / chaining kernels
 // does overlap.  With several batches in flight per device (own streams, own host threads) the DP stages therefore take
-// turns: one at a time per device.  MA_DP_EXCLUSIVE=0 switches the turn-taking off (tuning hook).
+// turns when MA_DP_EXCLUSIVE=1: one at a time per device.  Measured (tools/overlap_matrix.sh): no gain over free overlap --
+// a DP stage is slowed just as much by another batch's seeding / chaining kernels -- so the default is off.
 static std::mutex& dp_turn( int device )
 {
     static std::mutex turn[ 64 ];
@@ -1642,7 +1678,7 @@ static bool dp_exclusive( )
 {
     static const bool on = []( ) {
         const char* e = getenv( "MA_DP_EXCLUSIVE" );
-        return !( e && atoi( e ) == 0 );
+        return e && atoi( e ) != 0;
     }( );
     return on;
 }
@@ -1765,7 +1801,8 @@ int ma_dp_batch( ma_batch* b )
             return 1;
         u64 totalOps = 0;
         MA_HIP( hipMemcpyAsync( &totalOps, (char*)b->opsOff.p + nh * 8, 8, hipMemcpyDeviceToHost, b->stream ) );
-        MA_HIP( hipStreamSynchronize( b->stream ) );
+        if( batch_wait( b ) )
+        return 1;
         b->nOpsCap = totalOps;
         if( b->ops.reserve( ( totalOps + 2 ) * 8 ) )
             return 1;
@@ -1865,7 +1902,8 @@ int ma_batch_set_segments( ma_batch* b, const uint64_t* seg_off, const ma_segmen
     MA_HIP( hipMemcpyAsync( b->segCnt.p, c.data( ), ( n + 1 ) * 4, hipMemcpyHostToDevice, b->stream ) );
     const unsigned long long used = ns;
     MA_HIP( hipMemcpyAsync( b->ctr.as<unsigned long long>( ) + CTR_SEG_USED, &used, 8, hipMemcpyHostToDevice, b->stream ) );
-    MA_HIP( hipStreamSynchronize( b->stream ) ); // the host vectors go out of scope
+    if( batch_wait( b ) )
+        return 1; // the host vectors go out of scope
     b->nSegs = ns;
     b->nSeeds = b->nHsets = b->nHseeds = 0;
     b->stage_done = 1;
@@ -1888,7 +1926,8 @@ int ma_batch_set_seeds( ma_batch* b, const uint64_t* seed_off, const ma_seed* se
         MA_HIP( hipMemcpyAsync( b->seeds.p, seeds, total * sizeof( ma_seed ), hipMemcpyHostToDevice, b->stream ) );
     MA_HIP( hipMemcpyAsync( b->seedOff.p, o.data( ), ( n + 1 ) * 8, hipMemcpyHostToDevice, b->stream ) );
     MA_HIP( hipMemcpyAsync( b->seedCnt.p, c.data( ), ( n + 1 ) * 4, hipMemcpyHostToDevice, b->stream ) );
-    MA_HIP( hipStreamSynchronize( b->stream ) );
+    if( batch_wait( b ) )
+        return 1;
     b->nSeeds = total;
     b->nHsets = b->nHseeds = 0;
     b->stage_done = 2;
@@ -1928,7 +1967,8 @@ int ma_batch_set_hsets( ma_batch* b, const uint64_t* hset_off, const uint64_t* h
     if( nhs )
         MA_HIP( hipMemcpyAsync( b->hdense.p, hseeds, nhs * sizeof( ma_seed ), hipMemcpyHostToDevice, b->stream ) );
     MA_HIP( hipMemcpyAsync( b->hsetOff.p, hset_off, ( n + 1 ) * 8, hipMemcpyHostToDevice, b->stream ) );
-    MA_HIP( hipStreamSynchronize( b->stream ) );
+    if( batch_wait( b ) )
+        return 1;
     b->nHsets = nh;
     b->nHseeds = nhs;
     b->stage_done = 3;
@@ -1964,7 +2004,8 @@ int ma_batch_get_socs( ma_batch* b, uint64_t* n_socs, uint64_t* soc_off, ma_soc*
     MA_HIP( hipMemcpyAsync( cnt.data( ), dN.p, n * 4, hipMemcpyDeviceToHost, b->stream ) );
     MA_HIP( hipMemcpyAsync( scnt.data( ), b->seedCnt.p, n * 4, hipMemcpyDeviceToHost, b->stream ) );
     MA_HIP( hipMemcpyAsync( off.data( ), b->seedOff.p, n * 8, hipMemcpyDeviceToHost, b->stream ) );
-    MA_HIP( hipStreamSynchronize( b->stream ) );
+    if( batch_wait( b ) )
+        return 1;
     u64 total = 0;
     for( u64 r = 0; r < n; r++ )
         total += cnt[ r ];
@@ -2214,7 +2255,8 @@ static int get_alns( ma_batch* b, bool mq, uint64_t* aln_off, ma_alignment* alns
         MA_HIP( hipMemcpyAsync( alns, b->outAlns.p, totalA * sizeof( ma_alignment ), hipMemcpyDeviceToHost, b->stream ) );
     if( ops && totalO )
         MA_HIP( hipMemcpyAsync( ops, b->outOpsPairs.p, totalO * 16, hipMemcpyDeviceToHost, b->stream ) );
-    MA_HIP( hipStreamSynchronize( b->stream ) );
+    if( batch_wait( b ) )
+        return 1;
     return 0;
 }
 

@@ -57,6 +57,7 @@ class Engine
     uint64_t uiCapReads = 0, uiCapBases = 0;
     std::vector<uint8_t> vCodes;
     std::vector<uint64_t> vOff;
+    const bool bBlocking; // waits sleep instead of spinning (hosts that run far more threads than cores)
 
     void fit( uint64_t uiReads, uint64_t uiBases )
     {
@@ -69,10 +70,11 @@ class Engine
         uiCapBases = std::max<uint64_t>( uiBases + uiBases / 4, 4096 );
         engineCheck( ma_batch_create( pIndex, &xP, uiCapReads, uiCapBases + 64, &pBatch ) );
         engineCheck( ma_batch_set_stream( pBatch, pStream ) );
+        engineCheck( ma_batch_set_blocking_sync( pBatch, bBlocking ? 1 : 0 ) );
     }
 
   public:
-    Engine( const ma_index* pIndex, const ma_params& rP ) : pIndex( pIndex ), xP( rP )
+    Engine( const ma_index* pIndex, const ma_params& rP, bool bBlocking = false ) : pIndex( pIndex ), xP( rP ), bBlocking( bBlocking )
     {
         engineCheck( ma_stream_create( pIndex, &pStream ) );
     }
@@ -201,7 +203,7 @@ class DeviceBatcher
         try
         {
             if( pEngine == nullptr )
-                pEngine.reset( new Engine( pIndex, xP ) );
+                pEngine.reset( new Engine( pIndex, xP, true ) );
             pSlot->pResult = pEngine->run( pSlot->vReads, xOpt.bStages );
         }
         catch( const std::exception& rE )

@@ -84,42 +84,71 @@ inline uint64_t posInSequence( const Pack& rPack, uint64_t uiBegin, uint64_t uiE
     return (uint64_t)uiPosition - rPack.vStarts[ (size_t)uiSequenceIdForPosition( rPack, (uint64_t)uiPosition ) ];
 }
 
+// ---- text assembly: a SAM record is appended to ONE buffer, number by number and base by base (no temporaries)
+inline void appendNumber( std::string& rOut, uint64_t uiValue )
+{
+    char aDigits[ 24 ];
+    int n = 0;
+    do
+    {
+        aDigits[ n++ ] = (char)( '0' + uiValue % 10 );
+        uiValue /= 10;
+    } while( uiValue != 0 );
+    while( n > 0 )
+        rOut.push_back( aDigits[ --n ] );
+}
+
 // ---- NucSeq (nucSeq.h:558-569,605-626,667-713)
 inline char charOf( uint8_t c )
 {
     static const char chars[ 4 ] = { 'A', 'C', 'G', 'T' };
     return c < 4 ? chars[ c ] : 'N';
 }
-inline std::string fromTo( const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
+inline void appendFromTo( std::string& rOut, const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
 {
-    std::string ret;
     for( nucSeqIndex i = uiStart; i < uiEnd && i < rQ.length( ); i++ )
-        ret += charOf( rQ.xCodes[ i ] );
-    return ret;
+        rOut.push_back( charOf( rQ.xCodes[ i ] ) );
 }
-inline std::string fromToComplement( const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
+inline void appendFromToComplement( std::string& rOut, const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
 {
-    std::string ret;
     for( nucSeqIndex i = uiEnd; i > uiStart; i-- )
     {
         if( i - 1 >= rQ.length( ) )
             throw std::runtime_error( "Index out of range (compCharAt)" );
         const uint8_t c = rQ.xCodes[ i - 1 ];
-        ret += charOf( c < 4 ? (uint8_t)( 3 - c ) : (uint8_t)5 ); // nucleotideComplement nucSeq.h:524-532
+        rOut.push_back( charOf( c < 4 ? (uint8_t)( 3 - c ) : (uint8_t)5 ) ); // nucleotideComplement nucSeq.h:524-532
     }
+}
+inline void appendFromToQual( std::string& rOut, const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd ) // nucSeq.h:697-709
+{
+    if( rQ.xQuality.empty( ) )
+    {
+        rOut.push_back( '*' );
+        return;
+    }
+    for( nucSeqIndex i = uiStart; i < uiEnd && i < rQ.length( ); i++ )
+        rOut.push_back( (char)rQ.xQuality[ i ] );
+}
+inline std::string fromTo( const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
+{
+    std::string ret;
+    appendFromTo( ret, rQ, uiStart, uiEnd );
+    return ret;
+}
+inline std::string fromToComplement( const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
+{
+    std::string ret;
+    appendFromToComplement( ret, rQ, uiStart, uiEnd );
     return ret;
 }
 inline std::string toString( const NucSeq& rQ )
 {
     return fromTo( rQ, 0, rQ.length( ) );
 }
-inline std::string fromToQual( const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd ) // nucSeq.h:697-709
+inline std::string fromToQual( const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
 {
-    if( rQ.xQuality.empty( ) )
-        return "*";
     std::string ret;
-    for( nucSeqIndex i = uiStart; i < uiEnd && i < rQ.length( ); i++ )
-        ret += (char)rQ.xQuality[ i ];
+    appendFromToQual( ret, rQ, uiStart, uiEnd );
     return ret;
 }
 
@@ -131,63 +160,66 @@ inline nucSeqIndex length( const Alignment& rA )
         n += x.second;
     return n;
 }
-inline std::string clip( nucSeqIndex n, bool bSoftClip )
+inline void appendClip( std::string& rOut, nucSeqIndex n, bool bSoftClip )
 {
-    return std::to_string( n ) + ( bSoftClip ? "S" : "H" );
+    appendNumber( rOut, n );
+    rOut.push_back( bSoftClip ? 'S' : 'H' );
 }
-inline std::string cigarString( const Alignment& rA, const Pack& rPack, size_t uiQuerySize, bool bSoftClip, bool bM )
+// Alignment::cigarString (alignment.h:367-467): clipping, then the sections in reference direction; with bM runs of
+// matches, mismatches and seeds merge into one M
+inline void appendCigar( std::string& rOut, const Alignment& rA, const Pack& rPack, size_t uiQuerySize, bool bSoftClip, bool bM )
 {
     const bool bRev = bPositionIsOnReversStrand( rPack, rA.uiBeginOnRef );
-    std::string sCigar;
-    if( bRev )
-    {
-        if( rA.uiEndOnQuery < uiQuerySize )
-            sCigar += clip( uiQuerySize - rA.uiEndOnQuery, bSoftClip );
-    }
-    else if( rA.uiBeginOnQuery > 0 )
-        sCigar += clip( rA.uiBeginOnQuery, bSoftClip );
-    std::vector<std::pair<MatchType, nucSeqIndex>> vData( rA.data );
-    if( bRev )
-        std::reverse( vData.begin( ), vData.end( ) );
+    const nucSeqIndex uiHead = bRev ? ( rA.uiEndOnQuery < uiQuerySize ? uiQuerySize - rA.uiEndOnQuery : 0 ) : rA.uiBeginOnQuery;
+    const nucSeqIndex uiTail = bRev ? rA.uiBeginOnQuery : ( rA.uiEndOnQuery < uiQuerySize ? uiQuerySize - rA.uiEndOnQuery : 0 );
+    if( uiHead > 0 )
+        appendClip( rOut, uiHead, bSoftClip );
     size_t uiSequentialM = 0;
-    for( auto& section : vData )
+    const size_t uiSections = rA.data.size( );
+    for( size_t k = 0; k < uiSections; k++ )
+    {
+        const auto& section = rA.data[ bRev ? uiSections - 1 - k : k ];
         switch( section.first )
         {
             case MatchType::seed:
             case MatchType::match:
-                if( bM )
-                    uiSequentialM += section.second;
-                else
-                    sCigar += std::to_string( section.second ) + "=";
-                break;
             case MatchType::missmatch:
                 if( bM )
                     uiSequentialM += section.second;
                 else
-                    sCigar += std::to_string( section.second ) + "X";
+                {
+                    appendNumber( rOut, section.second );
+                    rOut.push_back( section.first == MatchType::missmatch ? 'X' : '=' );
+                }
                 break;
             case MatchType::insertion:
             case MatchType::deletion:
                 if( bM && uiSequentialM > 0 )
                 {
-                    sCigar += std::to_string( uiSequentialM ) + "M";
+                    appendNumber( rOut, uiSequentialM );
+                    rOut.push_back( 'M' );
                     uiSequentialM = 0;
                 }
-                sCigar += std::to_string( section.second ) + ( section.first == MatchType::insertion ? "I" : "D" );
+                appendNumber( rOut, section.second );
+                rOut.push_back( section.first == MatchType::insertion ? 'I' : 'D' );
                 break;
             default:
                 std::cerr << "WARNING invalid cigar symbol" << std::endl;
                 break;
         }
-    if( bM && uiSequentialM > 0 )
-        sCigar += std::to_string( uiSequentialM ) + "M";
-    if( bRev )
-    {
-        if( rA.uiBeginOnQuery > 0 )
-            sCigar += clip( rA.uiBeginOnQuery, bSoftClip );
     }
-    else if( rA.uiEndOnQuery < uiQuerySize )
-        sCigar += clip( uiQuerySize - rA.uiEndOnQuery, bSoftClip );
+    if( bM && uiSequentialM > 0 )
+    {
+        appendNumber( rOut, uiSequentialM );
+        rOut.push_back( 'M' );
+    }
+    if( uiTail > 0 )
+        appendClip( rOut, uiTail, bSoftClip );
+}
+inline std::string cigarString( const Alignment& rA, const Pack& rPack, size_t uiQuerySize, bool bSoftClip, bool bM )
+{
+    std::string sCigar;
+    appendCigar( sCigar, rA, rPack, uiQuerySize, bSoftClip, bM );
     return sCigar;
 }
 inline uint32_t getSamFlag( const Alignment& rA, const Pack& rPack )
@@ -366,47 +398,75 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
              std::shared_ptr<Pack> pPack ) override
     {
         std::string sCombined;
-        for( std::shared_ptr<Alignment> pAlignment : *pAlignments )
+        sCombined.reserve( pAlignments->size( ) * ( 2 * pQuery->length( ) + 96 ) + 64 );
+        auto unmapped = [ & ]( const char* sMapQ ) { // fileWriter.cpp:126-140
+            sCombined += pQuery->sName;
+            sCombined.push_back( '\t' );
+            sam::appendNumber( sCombined, MA_SAM_SEGMENT_UNMAPPED );
+            sCombined += "\t*\t0\t";
+            sCombined += sMapQ;
+            sCombined += "\t*\t*\t0\t0\t";
+            sam::appendFromTo( sCombined, *pQuery, 0, pQuery->length( ) );
+            sCombined.push_back( '\t' );
+            sam::appendFromToQual( sCombined, *pQuery, 0, pQuery->length( ) );
+            sCombined.push_back( '\n' );
+        };
+        for( const std::shared_ptr<Alignment>& pAlignment : *pAlignments )
         {
-            if( sam::length( *pAlignment ) == 0 )
+            const Alignment& rA = *pAlignment;
+            if( sam::length( rA ) == 0 )
                 continue;
-            if( xOptions.bNoSecondary && pAlignment->bSecondary )
+            if( ( xOptions.bNoSecondary && rA.bSecondary ) || ( xOptions.bNoSupplementary && rA.bSupplementary ) )
                 continue;
-            if( xOptions.bNoSupplementary && pAlignment->bSupplementary )
-                continue;
-            const bool bLong = xOptions.bCGTag && pAlignment->data.size( ) >= uiMaxCigarLen;
-            std::string sCigar;
+            const bool bLong = xOptions.bCGTag && rA.data.size( ) >= uiMaxCigarLen;
+            const bool bRev = sam::bPositionIsOnReversStrand( *pPack, rA.uiBeginOnRef );
+            // QNAME FLAG RNAME POS MAPQ
+            sCombined += pQuery->sName;
+            sCombined.push_back( '\t' );
+            sam::appendNumber( sCombined, sam::getSamFlag( rA, *pPack ) );
+            sCombined.push_back( '\t' );
+            sCombined += pPack->vNames[ (size_t)sam::uiSequenceIdForPosition( *pPack, rA.uiBeginOnRef ) ];
+            sCombined.push_back( '\t' );
+            sam::appendNumber( sCombined, sam::getSamPosition( rA, *pPack ) );
+            sCombined.push_back( '\t' );
+            if( std::isnan( rA.fMappingQuality ) )
+                sCombined += "255";
+            else
+                sCombined += std::to_string( static_cast<int>( std::ceil( rA.fMappingQuality * 254 ) ) );
+            sCombined.push_back( '\t' );
+            // CIGAR RNEXT PNEXT TLEN
             if( bLong )
-                sCigar = std::to_string( pAlignment->uiEndOnQuery - pAlignment->uiBeginOnQuery ).append( "S" );
+            {
+                sam::appendNumber( sCombined, rA.uiEndOnQuery - rA.uiBeginOnQuery );
+                sCombined.push_back( 'S' );
+            }
             else
-                sCigar = sam::cigarString( *pAlignment, *pPack, pQuery->length( ), xOptions.bSoftClip, xOptions.bOutputMCigar );
-            const uint32_t flag = sam::getSamFlag( *pAlignment, *pPack );
-            std::string sSegment;
-            if( xOptions.bSoftClip )
-                sSegment = sam::bPositionIsOnReversStrand( *pPack, pAlignment->uiBeginOnRef )
-                               ? sam::fromToComplement( *pQuery, 0, pQuery->length( ) )
-                               : sam::toString( *pQuery );
+                sam::appendCigar( sCombined, rA, *pPack, pQuery->length( ), xOptions.bSoftClip, xOptions.bOutputMCigar );
+            sCombined += "\t*\t0\t0\t";
+            // SEQ: the whole read when soft clipping, else the aligned part; reverse-complemented on the reverse strand
+            const nucSeqIndex uiFrom = xOptions.bSoftClip ? 0 : rA.uiBeginOnQuery, uiTo = xOptions.bSoftClip ? pQuery->length( ) : rA.uiEndOnQuery;
+            const size_t uiBefore = sCombined.size( );
+            if( bRev )
+                sam::appendFromToComplement( sCombined, *pQuery, uiFrom, uiTo );
             else
-                sSegment = sam::getQuerySequence( *pAlignment, *pQuery, *pPack );
-            // (sic) not reversed for reverse-strand alignments (alignment.h:611-614)
-            const std::string sQual = sam::fromToQual( *pQuery, pAlignment->uiBeginOnQuery, pAlignment->uiEndOnQuery );
-            const std::string sRefName = sam::nameOfSequenceForPosition( *pPack, pAlignment->uiBeginOnRef );
-            const nucSeqIndex uiRefPos = sam::getSamPosition( *pAlignment, *pPack );
-            const std::string sTag = sam::computeTag( *pAlignment, bLong );
-            std::string sMapQual;
-            if( std::isnan( pAlignment->fMappingQuality ) )
-                sMapQual = "255";
-            else
-                sMapQual = std::to_string( static_cast<int>( std::ceil( pAlignment->fMappingQuality * 254 ) ) );
-            sCombined += pQuery->sName + "\t" + std::to_string( flag ) + "\t" + sRefName + "\t" + std::to_string( uiRefPos ) +
-                         "\t" + sMapQual + "\t" + sCigar + "\t*\t0\t0\t" + sSegment + "\t" + sQual + sTag + "\n";
+                sam::appendFromTo( sCombined, *pQuery, uiFrom, uiTo );
+            if( !xOptions.bSoftClip )
+            {
+                const int64_t iOff = (int64_t)( sCombined.size( ) - uiBefore ) - (int64_t)( rA.uiEndOnQuery - rA.uiBeginOnQuery );
+                if( iOff != 0 )
+                    throw std::runtime_error( "Query length is off by " + std::to_string( iOff ) + "." );
+            }
+            sCombined.push_back( '\t' );
+            // QUAL (sic) not reversed for reverse-strand alignments (alignment.h:611-614), then the tags
+            sam::appendFromToQual( sCombined, *pQuery, rA.uiBeginOnQuery, rA.uiEndOnQuery );
+            if( bLong )
+                sCombined += sam::computeTag( rA, bLong );
+            sCombined.push_back( '\n' );
         }
         if( pAlignments->size( ) == 0 )
-            sCombined += pQuery->sName + "\t" + std::to_string( MA_SAM_SEGMENT_UNMAPPED ) + "\t*\t0\t255\t*\t*\t0\t0\t" +
-                         sam::toString( *pQuery ) + "\t" + sam::fromToQual( *pQuery, 0, pQuery->length( ) ) + "\n";
+            unmapped( "255" );
         if( sCombined.size( ) == 0 )
-            sCombined += pQuery->sName + "\t" + std::to_string( MA_SAM_SEGMENT_UNMAPPED ) + "\t*\t0\t0\t*\t*\t0\t0\t" +
-                         sam::toString( *pQuery ) + "\t" + sam::fromToQual( *pQuery, 0, pQuery->length( ) ) + "\n";
+            unmapped( "0" );
         {
             std::lock_guard<std::mutex> xGuard( *pLock );
             *pOut << sCombined;
