@@ -205,6 +205,9 @@ class Pack : public libMS::Container
     // runs of N of the input that were replaced by random bases (pack.h:630-666): offset, length; written to .amb
     std::vector<std::pair<uint64_t, uint64_t>> vHoles;
     std::vector<uint64_t> vNumHoles; // per contig, for .ann
+    // optional host copy of the packed forward strand (2 bit / base, MSB first): consumers of reference BASES on the host
+    // (FileWriter's NGMLR tag emulation) use it when present and ask the device otherwise (ma_pack_extract)
+    std::vector<uint8_t> vPacHost;
     uint64_t uiUnpackedSizeForwardPlusReverse( ) const // pack.h:881-884: twice the forward strand
     {
         if( !vStarts.empty( ) )

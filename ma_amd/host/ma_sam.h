@@ -250,6 +250,189 @@ inline std::string getQuerySequence( const Alignment& rA, const NucSeq& rQuery, 
         throw std::runtime_error( "Query length is off by " + std::to_string( iOff ) + "." );
     return sRet;
 }
+// ---- reference bases for the tags (Pack::vExtract pack.h:1440-1450, vExtractSubsectionN 1238-1330): codes of the doubled
+// text [uiBegin, uiEnd) on one strand; with bMarkHoles the positions inside recorded runs of N read 4
+inline std::vector<uint8_t> referenceCodes( const Pack& rPack, uint64_t uiBegin, uint64_t uiEnd, bool bMarkHoles )
+{
+    std::vector<uint8_t> vCodes( uiEnd > uiBegin ? uiEnd - uiBegin : 0 );
+    if( vCodes.empty( ) )
+        return vCodes;
+    const uint64_t uiF = fwdSize( rPack );
+    if( !rPack.vPacHost.empty( ) )
+    {
+        if( uiEnd > 2 * uiF || ( uiBegin >= uiF ) != ( uiEnd - 1 >= uiF ) )
+            throw std::runtime_error( "(vExtractSubsection) Try to extract bridging sequence. This is impossible." );
+        for( uint64_t p = uiBegin; p < uiEnd; p++ )
+        {
+            const uint64_t a = p < uiF ? p : 2 * uiF - 1 - p;
+            const uint8_t b = ( rPack.vPacHost[ a >> 2 ] >> ( ( ~a & 3 ) << 1 ) ) & 3;
+            vCodes[ p - uiBegin ] = p < uiF ? b : (uint8_t)( 3 - b );
+        }
+    }
+    else
+    {
+        if( rPack.pDev == nullptr )
+            throw std::runtime_error( "Pack: no reference bases available on the host or on the device" );
+        maCheck( ma_pack_extract( rPack.pDev->p, &uiBegin, &uiEnd, 1, vCodes.data( ) ) );
+    }
+    if( bMarkHoles )
+        for( const auto& rHole : rPack.vHoles )
+            for( uint64_t p = uiBegin; p < uiEnd; p++ )
+            {
+                const uint64_t a = p < uiF ? p : 2 * uiF - 1 - p;
+                if( rHole.first <= a && a < rHole.first + rHole.second )
+                    vCodes[ p - uiBegin ] = 4;
+            }
+    return vCodes;
+}
+inline double amountOfRegionCoveredByHole( const Pack& rPack, uint64_t uiStart, uint64_t uiEnd ) // pack.h:551-566 (sic: raw positions)
+{
+    uint64_t uiCovered = 0;
+    for( const auto& rHole : rPack.vHoles )
+        if( rHole.first <= uiEnd && rHole.first + rHole.second > uiStart )
+            uiCovered += std::min( uiEnd, rHole.first + rHole.second ) - std::max( uiStart, rHole.first );
+    return uiCovered / (double)( uiEnd - uiStart );
+}
+// Alignment::getNumDifferences (alignment.h:287-319): mismatches + inserted + deleted bases + reference Ns under matches
+inline size_t getNumDifferences( const Alignment& rA, const Pack& rPack )
+{
+    const std::vector<uint8_t> vRef = referenceCodes( rPack, rA.uiBeginOnRef, rA.uiEndOnRef, true );
+    size_t uiDiff = 0, uiRPos = 0;
+    for( const auto& rSection : rA.data )
+    {
+        if( rSection.first == MatchType::seed || rSection.first == MatchType::match )
+        {
+            for( size_t i = 0; i < rSection.second; i++ )
+                if( vRef[ i + uiRPos ] >= 4 )
+                    uiDiff++;
+        }
+        else
+            uiDiff += rSection.second;
+        if( rSection.first != MatchType::insertion )
+            uiRPos += rSection.second;
+    }
+    return uiDiff;
+}
+// the tags NGMLR writes, in its order (TagGenerator::computeTag with "Emulate NGMLR's tag output", fileWriter.h:120-326)
+inline std::string ngmlrTags( const NucSeq& rQuery, const std::shared_ptr<Alignment>& pAlignment, const Pack& rPack,
+                              const libMS::ContainerVector<std::shared_ptr<Alignment>>& rAll, bool bSoftClip )
+{
+    const Alignment& rA = *pAlignment;
+    std::string sTag = "\tMD:Z:";
+    {
+        const std::vector<uint8_t> vRef = referenceCodes( rPack, rA.uiBeginOnRef, rA.uiEndOnRef, false );
+        size_t uiRPos = 0;
+        nucSeqIndex uiPending = 0; // matches and seeds not yet written
+        bool bLastWasDeletion = false;
+        for( const auto& rSection : rA.data )
+        {
+            const bool bBreaksRun = rSection.first == MatchType::missmatch || rSection.first == MatchType::deletion;
+            if( bBreaksRun && uiPending > 0 )
+            {
+                appendNumber( sTag, uiPending );
+                uiPending = 0;
+            }
+            bool bFirst = !bLastWasDeletion;
+            bLastWasDeletion = false;
+            switch( rSection.first )
+            {
+                case MatchType::match:
+                case MatchType::seed:
+                    uiPending += rSection.second;
+                    uiRPos += rSection.second;
+                    break;
+                case MatchType::insertion:
+                    break;
+                case MatchType::missmatch:
+                    for( nucSeqIndex i = 0; i < rSection.second; i++ )
+                    {
+                        if( bFirst )
+                            bFirst = false;
+                        else
+                            sTag.push_back( '0' );
+                        sTag.push_back( charOf( vRef[ uiRPos + i ] ) );
+                    }
+                    uiRPos += rSection.second;
+                    break;
+                case MatchType::deletion:
+                    sTag.push_back( '^' );
+                    for( nucSeqIndex i = 0; i < rSection.second; i++ )
+                        sTag.push_back( charOf( vRef[ uiRPos + i ] ) );
+                    uiRPos += rSection.second;
+                    bLastWasDeletion = true;
+                    break;
+                default:
+                    throw std::runtime_error( "Invalid symbol in cigar!" );
+            }
+        }
+        if( uiPending > 0 )
+            appendNumber( sTag, uiPending );
+    }
+    {
+        size_t uiSv = 0;
+        if( amountOfRegionCoveredByHole( rPack, rA.uiBeginOnRef - 100, rA.uiBeginOnRef ) > .8 ||
+            amountOfRegionCoveredByHole( rPack, rA.uiEndOnRef, rA.uiEndOnRef + 100 ) > .8 )
+            uiSv += 1;
+        if( rA.uiEndOnQuery - rA.uiBeginOnQuery >= rQuery.length( ) * 0.95 || bSoftClip )
+            uiSv += 2;
+        sTag.append( "\tSV:i:" ).append( std::to_string( uiSv ) );
+    }
+    const size_t uiNm = getNumDifferences( rA, rPack );
+    sTag.append( "\tAS:i:" ).append( std::to_string( rA.score( ) ) );
+    sTag.append( "\tNM:i:" ).append( std::to_string( uiNm ) );
+    {
+        size_t uiMatches = 0;
+        for( const auto& rSection : rA.data )
+            if( rSection.first == MatchType::seed || rSection.first == MatchType::match )
+                uiMatches += rSection.second;
+        const float fIdentity = uiMatches / (float)std::min( rA.uiEndOnQuery - rA.uiBeginOnQuery, rA.uiEndOnRef - rA.uiBeginOnRef );
+        sTag.append( "\tXI:f:" ).append( std::to_string( fIdentity ) );
+    }
+    sTag.append( "\tXE:i:" ).append( std::to_string( rA.score( ) ) ); // (sic) NGMLR puts the score here
+    sTag.append( "\tXR:i:" ).append( std::to_string( rA.uiEndOnQuery - rA.uiBeginOnQuery ) );
+    {
+        const float fCoverage = 100.0f * ( rA.uiEndOnQuery - rA.uiBeginOnQuery ) / (float)rQuery.length( );
+        sTag.append( "\tCV:f:" ).append( std::to_string( fCoverage ) );
+    }
+    if( rAll.size( ) > 1 )
+    {
+        std::string sSisters;
+        for( const auto& pOther : rAll )
+        {
+            if( pOther == pAlignment || pOther->bSecondary || pOther->xStats.bFirst != rA.xStats.bFirst )
+                continue;
+            sSisters += nameOfSequenceForPosition( rPack, pOther->uiBeginOnRef );
+            sSisters.push_back( ',' );
+            appendNumber( sSisters, getSamPosition( *pOther, rPack ) );
+            sSisters += bPositionIsOnReversStrand( rPack, pOther->uiBeginOnRef ) ? ",-," : ",+,";
+            appendCigar( sSisters, *pOther, rPack, rQuery.length( ), bSoftClip, true );
+            sSisters.push_back( ',' );
+            sSisters += std::isnan( pOther->fMappingQuality ) ? std::string( "255" )
+                                                              : std::to_string( static_cast<int>( std::ceil( pOther->fMappingQuality * 254 ) ) );
+            sSisters.push_back( ',' );
+            appendNumber( sSisters, uiNm ); // (sic) the differences of THIS alignment, not of the sister
+            sSisters.push_back( ';' );
+        }
+        if( !sSisters.empty( ) )
+            sTag.append( "\tSA:Z:" ).append( sSisters );
+    }
+    sTag.append( "\tQS:i:" ).append( std::to_string( rA.uiBeginOnQuery ) ).append( "\tQE:i:" ).append( std::to_string( rA.uiEndOnQuery ) );
+    return sTag;
+}
+// Alignment::invertSuccessiveInserionAndDeletion (alignment.h:328-345): an insertion directly followed by a deletion (or the
+// other way round) swaps places; applied to reverse-strand alignments so that the order is the same for every read
+inline void invertSuccessiveInsertionAndDeletion( Alignment& rA )
+{
+    for( size_t i = 1; i < rA.data.size( ); i++ )
+    {
+        const MatchType a = rA.data[ i - 1 ].first, b = rA.data[ i ].first;
+        if( ( a == MatchType::insertion && b == MatchType::deletion ) || ( a == MatchType::deletion && b == MatchType::insertion ) )
+        {
+            std::swap( rA.data[ i - 1 ], rA.data[ i ] );
+            i++;
+        }
+    }
+}
 // TagGenerator::computeTag (fileWriter.h:215-357) for the default options: only the CG tag of over-long cigars
 inline std::string computeTag( const Alignment& rA, bool bLong )
 {
@@ -350,11 +533,8 @@ class StringOutStream : public OutStream // convenience for tests and in-memory 
 class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::ContainerVector<std::shared_ptr<Alignment>>, Pack>
 {
     static const size_t uiMaxCigarLen = 0x10000;
-    void init( const SamOptions& rO )
-    {
-        if( rO.bEmulateNgmlrTags )
-            throw std::runtime_error( "FileWriter: the NGMLR tag emulation is not available in the MI355X host layer" );
-    }
+    void init( const SamOptions& )
+    {}
 
   public:
     std::shared_ptr<OutStream> pOut;
@@ -420,6 +600,8 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
                 continue;
             const bool bLong = xOptions.bCGTag && rA.data.size( ) >= uiMaxCigarLen;
             const bool bRev = sam::bPositionIsOnReversStrand( *pPack, rA.uiBeginOnRef );
+            if( xOptions.bEmulateNgmlrTags && bRev ) // fileWriter.cpp:27-31
+                sam::invertSuccessiveInsertionAndDeletion( *pAlignment );
             // QNAME FLAG RNAME POS MAPQ
             sCombined += pQuery->sName;
             sCombined.push_back( '\t' );
@@ -441,7 +623,8 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
                 sCombined.push_back( 'S' );
             }
             else
-                sam::appendCigar( sCombined, rA, *pPack, pQuery->length( ), xOptions.bSoftClip, xOptions.bOutputMCigar );
+                sam::appendCigar( sCombined, rA, *pPack, pQuery->length( ), xOptions.bSoftClip,
+                                  xOptions.bOutputMCigar || xOptions.bEmulateNgmlrTags );
             sCombined += "\t*\t0\t0\t";
             // SEQ: the whole read when soft clipping, else the aligned part; reverse-complemented on the reverse strand
             const nucSeqIndex uiFrom = xOptions.bSoftClip ? 0 : rA.uiBeginOnQuery, uiTo = xOptions.bSoftClip ? pQuery->length( ) : rA.uiEndOnQuery;
@@ -459,6 +642,8 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
             sCombined.push_back( '\t' );
             // QUAL (sic) not reversed for reverse-strand alignments (alignment.h:611-614), then the tags
             sam::appendFromToQual( sCombined, *pQuery, rA.uiBeginOnQuery, rA.uiEndOnQuery );
+            if( xOptions.bEmulateNgmlrTags )
+                sCombined += sam::ngmlrTags( *pQuery, pAlignment, *pPack, *pAlignments, xOptions.bSoftClip );
             if( bLong )
                 sCombined += sam::computeTag( rA, bLong );
             sCombined.push_back( '\n' );

@@ -198,6 +198,7 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     selectPreset( xParams, sPreset );
     xParams.getSelected( )->xSoftClip->set( ( iOptions & 1 ) != 0 );
     xParams.getSelected( )->xOutputMCigar->set( ( iOptions & 2 ) == 0 );
+    xParams.getSelected( )->xEmulateNgmlrTags->set( ( iOptions & 4 ) != 0 );
     BinarySeeding xSeeding( xParams );
     StripOfConsideration xSoc( xParams );
     Harmonization xHarm( xParams );

@@ -1,7 +1,7 @@
 // CPU-only check of the SAM writer of the host layer (ma_amd/host/ma_sam.h): alignments are taken from a pipeline
 // dump (golden of the compiled reference, MQ + ALN records), the reads and contigs from the case file, and the SAM
 // text must equal what the reference's FileWriter printed for the same reads (tests/golden/*.sam.gz).
-// usage: sam_test <case> <pipe dump> <out.sam> <options: bit0 soft clip, bit1 =/X cigar> [reads.fastq]
+// usage: sam_test <case> <pipe dump> <out.sam> <options: bit0 soft clip, bit1 =/X cigar, bit2 NGMLR tags> [reads.fastq]
 // with a FASTA/FASTQ file the reads (names, qualities) come from the host layer's FileReader; they must be the first
 // reads of the case in order, because the alignments are looked up in the dump by read index
 #include "../../oracle/dump_format.h"
@@ -31,6 +31,18 @@ int main( int argc, char** argv )
     ParameterSetManager xParams;
     xParams.xSam.bSoftClip = ( iOptions & 1 ) != 0;
     xParams.xSam.bOutputMCigar = ( iOptions & 2 ) == 0;
+    xParams.xSam.bEmulateNgmlrTags = ( iOptions & 4 ) != 0; // needs reference bases: the contigs, packed on the host
+    if( iOptions & 4 )
+    {
+        pPack->vPacHost.assign( ( off + 3 ) / 4 + 1, 0 );
+        uint64_t p = 0;
+        for( auto& rContig : c.contigs )
+            for( uint8_t b : rContig )
+            {
+                pPack->vPacHost[ p >> 2 ] |= (uint8_t)( ( b & 3 ) << ( ( ~p & 3 ) << 1 ) );
+                p++;
+            }
+    }
     auto pStream = std::make_shared<StringOutStream>( );
     FileWriter xWriter( xParams, std::static_pointer_cast<OutStream>( pStream ), pPack );
     std::vector<std::shared_ptr<NucSeq>> vFileReads;

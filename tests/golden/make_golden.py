@@ -21,12 +21,13 @@ def gz(path):
     os.remove(path)
 
 
-SAM_GOLDENS = [("default", 0), ("default", 1), ("default", 2), ("default", 3), ("illumina", 0)]
+SAM_GOLDENS = [("default", 0), ("default", 1), ("default", 2), ("default", 3), ("illumina", 0), ("default", 4), ("default", 5),
+               ("illumina", 4)]
 
 
 def sam_goldens():
     """SAM text of the reference's FileWriter (fileWriter.cpp:11-158) for small.case; options: bit 0 = soft clip,
-    bit 1 = '='/'X' cigars instead of 'M'."""
+    bit 1 = '='/'X' cigars instead of 'M', bit 2 = "Emulate NGMLR's tag output" (MD SV AS NM XI XE XR CV SA QS QE)."""
     for preset, opt in SAM_GOLDENS:
         name = "small_ref.%s.opt%d.sam" % (preset, opt)
         run_ref("sam", "small.case", preset, 1, name, opt)

@@ -23,7 +23,8 @@ def build_exe():
     return EXE
 
 
-@pytest.mark.parametrize("preset,opt", [("default", 0), ("default", 1), ("default", 2), ("default", 3), ("illumina", 0)])
+@pytest.mark.parametrize("preset,opt", [("default", 0), ("default", 1), ("default", 2), ("default", 3), ("illumina", 0),
+                                        ("default", 4), ("default", 5), ("illumina", 4)])  # bit 2: NGMLR tag emulation
 def test_sam_text_matches_reference_filewriter(tmp_path, preset, opt):
     exe = build_exe()
     case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))

@@ -1,6 +1,10 @@
-"""Summarises the rocprofv3 outputs of tools/collect_profiles.sh: per kernel group and per bench step (1 M reads) the
-average duration, HBM bytes (FETCH_SIZE, WRITE_SIZE; KB -> bytes, FETCH_SIZE doubled: gfx950 tallies 128-B requests at
-64 B, MI355X_MICROARCH.md) and wave-level VALU / SALU instructions.  usage: pmc_summarize.py <dir> <steps incl. warm-up>"""
+"""Summarises the rocprofv3 outputs of tools/collect_profiles.sh: per kernel group and per bench step the average
+duration, HBM bytes (FETCH_SIZE, WRITE_SIZE in KB) and wave-level VALU / SALU instructions.
+FETCH_SIZE counts fabric read requests x 64 B; a request is 64 B for the random occ-block gathers of k_seed / k_lf_walk
+(raw value = bytes, calibrated on tools/gups launches of known size: profiles/r02_counter_calibration.txt) but 128 B for
+wide coalesced streams (the x2 of MI355X_MICROARCH.md).  Kernels with a mixed pattern get both readings (hbm_bytes_min /
+_max) and the x2 reading as hbm_bytes_per_step.
+usage: pmc_summarize.py <dir> <steps incl. warm-up> [<out.json> <read_len> <reads_per_step> <preset>]"""
 import csv
 import glob
 import json
@@ -36,15 +40,17 @@ def traffic_json(summary, workload_key):
     b = {g: o["hbm_bytes_per_step"] for g, o in summary.items() if not g.startswith("k_ksw") and "hbm_bytes_per_step" in o}
     b["k_ksw"] = int(tot("hbm_bytes_per_step"))
     return {"workload_key": workload_key,
-            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / SQ_INSTS_SALU in separate passes of `bench.py --steps 3 "
-                    "--warmup 1 --cpu-sample 0` (tools/collect_profiles.sh); KB -> bytes, FETCH_SIZE doubled (MI355X_MICROARCH.md: "
-                    "gfx950 tallies 128-B requests at 64 B); per step = per launch of each stage",
+            "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / SQ_INSTS_SALU in separate passes of `bench.py --workload .. "
+                    "--steps 3 --warmup 1 --cpu-sample 0` (tools/collect_profiles.sh); FETCH_SIZE (KB) = fabric read requests x 64 B: "
+                    "taken as bytes for the random 64-B gathers (k_seed, k_lf_walk; calibrated in profiles/r02_counter_calibration.txt) "
+                    "and doubled for the other kernels (128-B requests, MI355X_MICROARCH.md); per step = per launch of each stage",
             "bytes_per_launch": b,
             "valu_wave_insts_per_launch": {"k_ksw": tot("SQ_INSTS_VALU")},
             "salu_insts_per_launch": {"k_ksw": tot("SQ_INSTS_SALU")},
             "per_kernel": summary,
-            "note_valu": "SQ_INSTS_VALU = wave-level VALU instructions per step; a wave64 VALU instruction occupies its SIMD for 4 "
-                         "cycles, 1024 SIMDs at 2.4 GHz = 614.4 G wave-inst/s; the scalar unit of a CU issues one instruction per cycle"}
+            "note_valu": "SQ_INSTS_VALU = wave-level VALU instructions per step; measured issue rate of the DP kernels' opcode mix: "
+                         "576.9 G wave-inst/s over 1024 SIMDs (profiles/r02_valu_mix.txt); the scalar unit of a CU issues one "
+                         "instruction per cycle"}
 
 
 def main():
@@ -69,13 +75,27 @@ def main():
             if g:
                 o = out.setdefault(g, {})
                 o[c] = o.get(c, 0.0) + float(row["Counter_Value"]) / steps
+    GATHER = ("k_seed", "k_seed_rows+k_lf_walk+k_seed_final")  # random 64-B blocks: FETCH_SIZE needs no doubling
     for g, o in out.items():
         if "FETCH_SIZE" in o and "WRITE_SIZE" in o:
-            o["hbm_bytes_per_step"] = int(o["FETCH_SIZE"] * 1024 * 2 + o["WRITE_SIZE"] * 1024)
+            lo = int(o["FETCH_SIZE"] * 1024 + o["WRITE_SIZE"] * 1024)
+            hi = int(o["FETCH_SIZE"] * 1024 * 2 + o["WRITE_SIZE"] * 1024)
+            o["hbm_bytes_min"], o["hbm_bytes_max"] = lo, hi
+            o["fetch_request_bytes"] = 64 if g in GATHER else 128
+            o["hbm_bytes_per_step"] = lo if g in GATHER else hi
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 3:
+        key = [int(sys.argv[4]), int(sys.argv[5]), sys.argv[6], 1.0] if len(sys.argv) > 6 else [150, 1000000, "default", 1.0]
+        entry = traffic_json(out, key)
+        doc = {"workloads": []}
+        if os.path.exists(sys.argv[3]):
+            try:
+                doc = json.load(open(sys.argv[3]))
+            except ValueError:
+                pass
+        doc["workloads"] = [w for w in doc.get("workloads", []) if w.get("workload_key") != key] + [entry]
         with open(sys.argv[3], "w") as f:
-            json.dump(traffic_json(out, [150, 1000000, "default", 1.0]), f, indent=1)
+            json.dump(doc, f, indent=1)
 
 
 if __name__ == "__main__":
