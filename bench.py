@@ -285,7 +285,7 @@ def run_workload(E, name, wl, args):
             "workload": "%d x %d bp reads (%.2f%% sub, %.2f%% ins, %.2f%% del), %s preset, %d reads/step %s" % (
                 n_global, read_len, 100 * wl["sub"], 100 * wl["ins"], 100 * wl["dele"], preset, B_total,
                 "per GPU" if args.scaling == "weak" else "over all GPUs"),
-            "value": round(aligned_all / dt, 1), "unit": "aligned reads/s", "steps": K, "warmup": W,
+            "value": round(aligned_all / dt, 1), "unit": "aligned reads/s", "aligned_reads": int(aligned_all), "steps": K, "warmup": W,
             "ms_per_step": round(dt / Kd * 1e3, 3), "reads_per_s_total": round(n_global / dt, 1),
             "gbases_per_s": round(total_bases * (world if args.scaling == "weak" else 1) / dt / 1e9, 3),
             "roofline": roofline, "cpu_baseline": cpu,
@@ -431,6 +431,7 @@ def main():
     ap.add_argument("--cpu-threads-sweep", type=int, default=1, help="also time the reference on a quarter of the threads")
     ap.add_argument("--boundary-reads", type=int, default=1000000, help="reads of the host-fed boundary leg (0 off)")
     ap.add_argument("--no-repeats", action="store_true")
+    ap.add_argument("--overlap", type=int, default=3, help="batches in flight of the additional overlapped leg (0/1 off)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight per GPU (own stream + host thread each): while one batch is in its "
                          "VALU-bound DP kernels another runs its memory-bound seeding / chaining")
@@ -455,6 +456,18 @@ def main():
     results = []
     for name, wl in wls:
         r = run_workload(E, name, wl, args)
+        # the same workload once more with several batches in flight (own streams and host threads): the memory-bound
+        # stages of one batch overlap the issue-bound DP kernels of another.  Reported beside the single-stream numbers,
+        # whose per-kernel times stay those of undisturbed launches.
+        if args.overlap > 1 and args.inflight == 1:
+            import copy
+            a2 = copy.copy(args)
+            a2.inflight, a2.cpu_sample = args.overlap, 0
+            r2 = run_workload(E, name, wl, a2)
+            if r is not None and r2 is not None:
+                r["overlapped"] = {"batches_in_flight": args.overlap, "value": r2["value"], "unit": r2["unit"],
+                                   "ms_per_step": r2["ms_per_step"], "gbases_per_s": r2["gbases_per_s"],
+                                   "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"]}
         if r is not None:
             results.append(r)
     boundary = None

@@ -269,12 +269,29 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     const u32 V_SCHI = pk_opaque( ( (u32)( -e2 ) & 0xffu ) | tS << 8 );
     const u32 V_Q = pk_opaque( K_Q ), V_Q2 = pk_opaque( K_Q2 ), V_QE = pk_opaque( K_QE ), V_QE2 = pk_opaque( K_QE2 );
 
-    // the query, four bases per lane (qlen <= 256)
-    u32 Qall = 0;
-    for( int k = 0; k < 4; k++ )
+    // First-column boundary of every diagonal r < qlen, tabulated in LDS once per job (16 bytes per diagonal: the words the
+    // cell update takes for cell 0's left neighbour): [0] v = initOf(r) << 24, [1] H(-1, r) << 16, [2] query base r << 16.
+    // The loop reads its entry with one ds_read_b128 instead of deriving the three values with ~20 scalar instructions and
+    // five v_writelane per diagonal -- the scalar unit, shared by all waves of a CU, is this kernel's busiest port.
+    // H(-1, r) = the offset kswcpp seeds H[0] with + the sum of initOf(0..r), in closed form (same sequence as the first row).
+    auto hBoundary = [ & ]( i32 n ) -> i32 { // H(n-1, -1) = H(-1, n-1)
+        const i32 a = max( 0, min( n, long_thres ) - 1 ); // cells 1..n-1 below long_thres
+        const i32 has = long_thres >= 1 && long_thres < n ? 1 : 0;
+        const i32 rest = ( n - 1 ) - a - has;
+        return ( q + e ) - qe0 + ( n < 1 ? 0 : -( q + e ) - e * a + ( has ? long_diff : 0 ) - e2 * rest );
+    };
     {
-        const i32 i = 4 * lane + k;
-        Qall |= ( i < qlen ? (u32)qbase( i ) & 0xffu : 4u ) << ( 8 * k );
+        uint4* tab = (uint4*)lds;
+        for( i32 i = lane; i < qlen; i += 64 )
+        {
+            uint4 w;
+            w.x = ( (u32)initOf( i ) & 0xffu ) << 24;
+            w.y = (u32)hBoundary( i + 1 ) << 16;
+            w.z = ( (u32)qbase( i ) & 0xffu ) << 16;
+            w.w = 0;
+            tab[ i ] = w;
+        }
+        __syncthreads( );
     }
 #if defined( MA_KSW_PROF )
     asm volatile( "s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory" );
@@ -330,16 +347,11 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     // cells handed on are >= RING: beyond long_thres their first-row difference is the constant -e2 (initOf)
     const bool uFar = RING > long_thres + 1;
     const u32 K_UFAR = pk_val( -e2, 0 );
-    // H(-1, r-1) of the first column, H(r-1, -1) of the first row.  (sic) When the two gap models were swapped, kswcpp's
-    // H[0] = v[0] - (q+e) uses the UNswapped sum, which offsets every score of the matrix by (q+e)_swapped - (q+e)_given.
-    i32 hLeft = ( q + e ) - qe0;
-    // H(n-1, -1) = hLeft's offset + the sum of initOf(0..n-1) in closed form (only the early stop reads it)
-    auto hTopBefore = [ & ]( i32 n ) -> i32 {
-        const i32 a = max( 0, min( n, long_thres ) - 1 ); // cells 1..n-1 below long_thres
-        const i32 has = long_thres >= 1 && long_thres < n ? 1 : 0;
-        const i32 rest = ( n - 1 ) - a - has;
-        return ( q + e ) - qe0 + ( n < 1 ? 0 : -( q + e ) - e * a + ( has ? long_diff : 0 ) - e2 * rest );
-    };
+    // (sic) When the two gap models were swapped, kswcpp's H[0] = v[0] - (q+e) uses the UNswapped sum, which offsets every
+    // score of the matrix by (q+e)_swapped - (q+e)_given: part of hBoundary.
+    auto hTopBefore = [ & ]( i32 n ) -> i32 { return hBoundary( n ); }; // H(n-1, -1): only the early stop reads it
+    const u32 M_LANE0 = lane == 0 ? 0xffffffffu : 0u;
+    const u32 S_X0 = K_X0 << 16, S_X20 = K_X20 << 16; // cell 0's left neighbour never had a gap open
     i32 boundPrev = 0x7fffffff;
     const i32 nDiag = qlen + tlen - 1;
     bool stop = false;
@@ -394,16 +406,14 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                 {
                     // cell 0 (slot 0, lane 0, low half until it is recycled at r >= qlen + 15): first-column carry-in
                     // (kswcpp_core.h:562-579) and the query base that enters the band.  The shift takes the low half of
-                    // lane 0 from the HIGH half of its predecessor: write the boundary values there (v_writelane, scalar).
-                    const u32 qb = ( (u32)lane_bcast( (i32)Qall, r >> 2 ) >> ( 8 * ( r & 3 ) ) ) & 0xffu;
-                    const i32 ini = initOf( r );
-                    hLeft += ini; // H(-1, r)
-                    ax = lane0_write( ax, K_X0 << 16 );
-                    ax2 = lane0_write( ax2, K_X20 << 16 );
-                    av = lane0_write( av, ( (u32)ini & 0xffu ) << 24 );
+                    // lane 0 from the HIGH half of its predecessor: lane 0 takes this diagonal's table entry there.
+                    const uint4 bnd = ( (const uint4*)lds )[ r ];
+                    ax = pk_bfi( M_LANE0, S_X0, ax );
+                    ax2 = pk_bfi( M_LANE0, S_X20, ax2 );
+                    av = pk_bfi( M_LANE0, bnd.x, av );
                     if( !GLOBAL )
-                        ah = lane0_write( ah, (u32)hLeft << 16 );
-                    aq = lane0_write( aq, qb << 16 );
+                        ah = pk_bfi( M_LANE0, bnd.y, ah );
+                    aq = pk_bfi( M_LANE0, bnd.z, aq );
                 }
                 xt1[ s ] = cells_shift1( X[ s ], ax );
                 vt1[ s ] = cells_shift1( V[ s ], av );

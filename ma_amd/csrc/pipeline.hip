@@ -914,8 +914,9 @@ struct StitchKernelArgs
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 ) ) ) k_stitch( StitchKernelArgs A )
 {
     const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
-    if( s >= A.n_sets )
-        return;
+    u64 nOps = 0;
+    if( s < A.n_sets )
+    {
     const HSet hs = A.sets[ s ];
     const u32 rd = A.set_read[ s ];
     const SetInfo I = A.info[ s ];
@@ -946,6 +947,12 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 
     A.hdr[ s ] = h;
     if( err )
         atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
+    nOps = h.n_ops;
+    }
+    // exact size of the ops download (all alignments): one atomic per wave
+    const u64 total = wave_sum_u64( nOps );
+    if( ( threadIdx.x & 63 ) == 0 && total )
+        atomicAdd( &A.ctr[ CTR_OPS_ALL ], (unsigned long long)total );
 }
 
 // per read: NeedlemanWunsch::execute's final sort + MappingQuality::execute
@@ -956,28 +963,21 @@ __global__ void k_finish( NwParams P, u32 n_reads, const u64* hset_off, const u6
     const u64 b = r < n_reads ? hset_off[ r ] : 0;
     const u32 n = r < n_reads ? (u32)( hset_off[ r + 1 ] - b ) : 0;
     u32 m = 0;
-    u64 opsAll = 0, opsMq = 0;
+    u64 opsMq = 0;
     if( r < n_reads )
     {
         m = finish_read( P, hdr + b, ops, n, roff[ r + 1 ] - roff[ r ], order + b, mq_order + b );
         mq_cnt[ r ] = m;
-        for( u32 k = 0; k < n; k++ )
-            opsAll += hdr[ b + k ].n_ops;
         for( u32 k = 0; k < m; k++ )
             opsMq += hdr[ b + mq_order[ b + k ] ].n_ops;
     }
     // one atomic per wave and quantity
-    const u64 al = wave_sum_u64( m ? 1 : 0 ), am = wave_sum_u64( m ), oa = wave_sum_u64( opsAll ), om = wave_sum_u64( opsMq );
-    if( ( threadIdx.x & 63 ) == 0 )
+    const u64 al = wave_sum_u64( m ? 1 : 0 ), am = wave_sum_u64( m ), om = wave_sum_u64( opsMq );
+    if( ( threadIdx.x & 63 ) == 0 && al )
     {
-        if( al )
-            atomicAdd( &ctr[ CTR_N_ALIGNED ], (unsigned long long)al );
-        if( oa )
-        {
-            atomicAdd( &ctr[ CTR_OPS_ALL ], (unsigned long long)oa );
-            atomicAdd( &ctr[ CTR_OPS_MQ ], (unsigned long long)om );
-            atomicAdd( &ctr[ CTR_ALN_MQ ], (unsigned long long)am );
-        }
+        atomicAdd( &ctr[ CTR_N_ALIGNED ], (unsigned long long)al );
+        atomicAdd( &ctr[ CTR_OPS_MQ ], (unsigned long long)om );
+        atomicAdd( &ctr[ CTR_ALN_MQ ], (unsigned long long)am );
     }
 }
 

@@ -270,3 +270,32 @@ def test_unknown_seeding_technique_is_rejected(gpu_device, tmp_path):
     with pytest.raises(ma_amd.MaError, match="unknown seeding technique 7"):
         ma_amd.Batch(idx, P, 4, 1000)
     idx.close()
+
+
+def _bench(args, nproc=1, env=None):
+    import sys
+    e = dict(os.environ, **(env or {}))
+    base = [sys.executable]
+    if nproc > 1:
+        base += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+                 "--master-port", "29617"]
+    out = subprocess.check_output(base + [os.path.join(ROOT, "bench.py")] + args, env=e, stderr=subprocess.DEVNULL).decode()
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+def test_bench_two_ranks_partition_one_read_set(gpu_device):
+    """The multi-rank flow of bench.py with the real engine (both ranks on GPU 0 over gloo: MA_BENCH_ONE_DEVICE, the
+    driver's runs use one GPU per rank over RCCL): weak scaling = every rank its own reads; strong scaling = ONE read set
+    cut into contiguous blocks, so two ranks must align exactly the reads (and find exactly the alignments) of one."""
+    common = ["--workload", "150bp", "--genome-scale", "0.01", "--steps", "2", "--warmup", "1", "--reads-per-step", "30000",
+              "--cpu-sample", "0", "--boundary-reads", "0"]
+    one = _bench(common + ["--gpus", "1"])
+    weak = _bench(common + ["--gpus", "2"], nproc=2, env={"MA_BENCH_ONE_DEVICE": "1"})
+    strong = _bench(common + ["--gpus", "2", "--scaling", "strong"], nproc=2, env={"MA_BENCH_ONE_DEVICE": "1"})
+    w1, ww, ws = one["config"]["workloads"][0], weak["config"]["workloads"][0], strong["config"]["workloads"][0]
+    assert weak["n_gpus"] == 2 and strong["n_gpus"] == 2 and weak["scaling"] == "weak" and strong["scaling"] == "strong"
+    assert w1["aligned_reads"] > 0.95 * 60000
+    # strong: the same 60 000 reads as the single process, so the same number of aligned reads
+    assert ws["aligned_reads"] == w1["aligned_reads"]
+    # weak: rank 0 repeats the single process' reads, rank 1 adds as many others
+    assert 1.9 * w1["aligned_reads"] < ww["aligned_reads"] < 2.1 * w1["aligned_reads"]
