@@ -459,7 +459,7 @@ def main():
         # the same workload once more with several batches in flight (own streams and host threads): the memory-bound
         # stages of one batch overlap the issue-bound DP kernels of another.  Reported beside the single-stream numbers,
         # whose per-kernel times stay those of undisturbed launches.
-        if args.overlap > 1 and args.inflight == 1:
+        if args.overlap > 1 and args.inflight == 1 and wl["read_len"] <= 1000:  # a long-read batch holds ~150 GB of HBM: one at a time
             import copy
             a2 = copy.copy(args)
             a2.inflight, a2.cpu_sample = args.overlap, 0

@@ -176,8 +176,11 @@ int main( int argc, char** argv )
         double fRun = 0, fUp = 0, fKern = 0, fDown = 0;
         if( pSeeding->batcher( ) != nullptr )
             pSeeding->batcher( )->phaseSeconds( fRun, fUp, fKern, fDown );
-        fprintf( stderr, "graph leg: %.3f s wall; device batches: run %.3f s (h2d %.3f, kernels %.3f, d2h %.3f) summed over %llu batches\n",
-                 fGraph, fRun, fUp, fKern, fDown, (unsigned long long)xStat.first );
+        double aStage[ 4 ] = { 0, 0, 0, 0 };
+        if( pSeeding->batcher( ) != nullptr )
+            pSeeding->batcher( )->stageSeconds( aStage );
+        fprintf( stderr, "graph leg: %.3f s wall; device batches: run %.3f s (h2d %.3f, kernels %.3f = seed %.3f + extract %.3f + chain %.3f + dp %.3f, d2h %.3f) summed over %llu batches\n",
+                 fGraph, fRun, fUp, fKern, aStage[ 0 ], aStage[ 1 ], aStage[ 2 ], aStage[ 3 ], fDown, (unsigned long long)xStat.first );
         printf( "{\"reads\": %zu, \"read_len\": %zu, \"host_threads\": %u, \"index_load_s\": %.2f, "
                 "\"batch_aligner\": {%s, \"what\": \"reads in host memory -> BatchAligner::execute (H2D, all stages, D2H, Alignment "
                 "containers); 256 k reads per device batch; phase times summed over the batches\"}, "

@@ -217,6 +217,9 @@ int ma_batch_get_dp_jobs( ma_batch*, uint64_t* n_jobs, int32_t* shapes, uint64_t
  * [3] dp-jobs [4] ksw [5] stitch; requires ma_batch_enable_timing(b,1) */
 int ma_batch_enable_timing( ma_batch*, int on );
 int ma_batch_kernel_ms( ma_batch*, float out[ 8 ] );
+/* host wall time in ms of the stage calls of the last ma_align_batch: [0] seed [1] extract [2] chain [3] dp (launches,
+ * stream waits and size read-backs included: what a small batch pays beside its kernels) */
+int ma_batch_host_ms( ma_batch*, float out[ 8 ] );
 /* diagnostics: the device libm the chaining stage decides with (harmonization.h:82-89, ransac.cpp:112,131-135 use
  * glibc's): op 0 tan, 1 sin, 2 atan, 3 log over n doubles (host arrays); tests compare the bits with glibc's */
 int ma_debug_libm( int op, const double* in, uint64_t n, double* out );

@@ -9,6 +9,7 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cstring>
+#include <chrono>
 #include <memory>
 #include <mutex>
 
@@ -1069,6 +1070,7 @@ struct ma_batch
     hipEvent_t ev[ 16 ];
     bool evInit = false;
     float kms[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    float hostMs[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // wall time of the last stage calls on the host: seed, extract, chain, dp
     unsigned long long hctr[ CTR_COUNT ];
 };
 
@@ -2041,8 +2043,25 @@ int ma_batch_get_socs( ma_batch* b, uint64_t* n_socs, uint64_t* soc_off, ma_soc*
 
 int ma_align_batch( ma_batch* b )
 {
-    if( ma_seed_batch( b ) || ma_extract_seeds_batch( b ) || ma_chain_batch( b ) || ma_dp_batch( b ) )
-        return 1;
+    if( !b )
+        return fail( "ma_align_batch: null batch" );
+    int ( *const stage[ 4 ] )( ma_batch* ) = { ma_seed_batch, ma_extract_seeds_batch, ma_chain_batch, ma_dp_batch };
+    for( int k = 0; k < 4; k++ )
+    {
+        const auto t0 = std::chrono::steady_clock::now( );
+        if( stage[ k ]( b ) )
+            return 1;
+        b->hostMs[ k ] = std::chrono::duration<float, std::milli>( std::chrono::steady_clock::now( ) - t0 ).count( );
+    }
+    return 0;
+}
+
+int ma_batch_host_ms( ma_batch* b, float out[ 8 ] )
+{
+    if( !b )
+        return fail( "null batch" );
+    for( int i = 0; i < 8; i++ )
+        out[ i ] = b->hostMs[ i ];
     return 0;
 }
 

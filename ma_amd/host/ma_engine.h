@@ -46,6 +46,7 @@ struct BatchResult
     std::vector<uint64_t> vAlnOps, vMqOps; // (type, length) pairs
     uint64_t uiAlignedReads = 0;
     double fH2D = 0, fKernels = 0, fD2H = 0; // seconds
+    float aStageMs[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // host wall time of seed / extract / chain / dp (ma_batch_host_ms)
 };
 
 class Engine
@@ -110,6 +111,7 @@ class Engine
         engineCheck( ma_align_batch( pBatch ) );
         engineCheck( ma_batch_sync( pBatch ) );
         R.fKernels = secondsSince( t0 );
+        engineCheck( ma_batch_host_ms( pBatch, R.aStageMs ) );
         t0 = std::chrono::steady_clock::now( );
         uint64_t nSeg = 0, nSeed = 0, nHset = 0, nHseed = 0, nAln = 0, nOps = 0;
         engineCheck( ma_batch_counts( pBatch, &nSeg, &nSeed, &nHset, &nHseed, &nAln, &nOps, &R.uiAlignedReads ) );
@@ -184,6 +186,7 @@ class DeviceBatcher
     size_t uiEnginesMade = 0, uiRunning = 0;
     uint64_t uiBatches = 0, uiReadsTotal = 0;
     double fSumH2D = 0, fSumKernels = 0, fSumD2H = 0, fSumRun = 0; // seconds over all batches
+    double aSumStageMs[ 4 ] = { 0, 0, 0, 0 };
 
     // called with the lock held by the thread that sealed the slot; releases the lock while the GPU works
     void runSealed( std::unique_lock<std::mutex>& rLock, const std::shared_ptr<Slot>& pSlot )
@@ -222,7 +225,11 @@ class DeviceBatcher
         uiReadsTotal += pSlot->vReads.size( );
         fSumRun += secondsSince( tRun );
         if( pSlot->pResult != nullptr )
+        {
             fSumH2D += pSlot->pResult->fH2D, fSumKernels += pSlot->pResult->fKernels, fSumD2H += pSlot->pResult->fD2H;
+            for( int k = 0; k < 4; k++ )
+                aSumStageMs[ k ] += pSlot->pResult->aStageMs[ k ];
+        }
         pSlot->bDone = true;
         pSlot->xDone.notify_all( );
         xChanged.notify_all( ); // leaders of open batches and sealers waiting for a device slot
@@ -294,6 +301,12 @@ class DeviceBatcher
     {
         std::lock_guard<std::mutex> xLock( xMutex );
         rRun = fSumRun, rH2D = fSumH2D, rKernels = fSumKernels, rD2H = fSumD2H;
+    }
+    void stageSeconds( double aOut[ 4 ] ) // host wall time of the four stage calls, summed over all batches
+    {
+        std::lock_guard<std::mutex> xLock( xMutex );
+        for( int k = 0; k < 4; k++ )
+            aOut[ k ] = aSumStageMs[ k ] / 1e3;
     }
 };
 } // namespace detail
