@@ -347,6 +347,236 @@ __global__ void k_mems_finish( IndexView X, SeedParams P, const u64* roff, u32 n
     seg_cnt[ r ] = n;
 }
 
+// ---- task-parallel maxSpan seeding for long reads --------------------------------------------------------------
+// procesInterval (binarySeeding.cpp:32-84) is a binary recursion: the centre of an area is extended, then the part left
+// of the covered interval and the part right of it are processed independently.  A read-per-lane walk leaves a 50 kb
+// read on ONE lane (20 k reads = 1.2 wavefronts per CU); here every AREA is a task.  The tree is walked level by level
+// (the centre is the middle of its area, so an area halves from level to level: depth <= log2(read length) + 1); the
+// lanes of a level's launch pull tasks from the level's array, extend, append their 0..2 segments to the pool with the
+// task's PRE-ORDER key -- node before its left subtree before its right subtree, two bits per level: exactly the order in
+// which the recursion pushes segments -- and append the child areas to the next level's array.  A stable sort by
+// (read, key) then restores the reference's segment order.
+struct SeedTask
+{
+    u32 read, aS, aN, depth;
+    u64 key; // pre-order path: digit 1 = left, 2 = right, 2 bits per level from bit 38 downwards
+};
+#define MA_TASK_KEY_BITS 40
+struct TaskKernelArgs
+{
+    IndexView X;
+    SeedParams P;
+    const uint8_t* reads;
+    const u64* roff;
+    const SeedTask* in;
+    const unsigned long long* nIn; // device: tasks of this level
+    SeedTask* out;
+    unsigned long long* nOut; // device: tasks of the next level (bump pointer)
+    u64 task_cap;
+    ma_segment* pool;
+    u64* pool_key; // read << MA_TASK_KEY_BITS | path
+    u64 pool_cap;
+    unsigned long long* ctr;
+};
+__global__ void k_task_roots( const u64* roff, u32 n_reads, SeedTask* out, unsigned long long* nOut )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r == 0 )
+        *nOut = n_reads;
+    if( r >= n_reads )
+        return;
+    SeedTask t;
+    t.read = r, t.aS = 0, t.aN = (u32)( roff[ r + 1 ] - roff[ r ] ), t.depth = 0, t.key = 0;
+    out[ r ] = t;
+}
+__global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
+{
+    const u32 wl = threadIdx.x & 63;
+    const u64 nIn = *A.nIn;
+    SeedLane L;
+    L.phase = PH_DONE;
+    L.err = 0;
+    ma_segment mine[ 2 ]; // a centre yields at most two segments (maxSpan)
+    SeedScratch S;
+    S.stage = mine;
+    S.seg_cap = 2;
+    S.smem_a = S.smem_b = nullptr;
+    S.smem_cap = 0;
+    S.stack = nullptr;
+    S.drop_div = 0;
+    SeedTask T;
+    T.read = 0xffffffffu;
+    bool alive = true;
+    u64 steps = 0, blocks = 0;
+    u64 qCur = 0, qEnd = 0; // this wave's slice of the level's task array
+    while( true )
+    {
+        const bool done = alive && L.phase == PH_DONE;
+        const unsigned long long dm = __ballot( done ), am = __ballot( alive );
+        if( dm && ( __popcll( dm ) >= 8 || dm == am ) )
+        {
+            // ---- finished tasks: segments to the pool, child areas to the next level (one atomic per wave and array)
+            const bool flush = done && T.read != 0xffffffffu;
+            const u32 ns = flush ? ( L.nseg < 2 ? L.nseg : 2 ) : 0;
+            const u32 nc = flush ? ( L.childN[ 0 ] ? 1 : 0 ) + ( L.childN[ 1 ] ? 1 : 0 ) : 0;
+            u32 incS = ns, incC = nc;
+            for( int d = 1; d < 64; d <<= 1 )
+            {
+                const u32 o = (u32)__shfl_up( (int)incS, d, 64 ), o2 = (u32)__shfl_up( (int)incC, d, 64 );
+                if( wl >= (u32)d )
+                    incS += o, incC += o2;
+            }
+            const u32 totS = (u32)__shfl( (int)incS, 63, 64 ), totC = (u32)__shfl( (int)incC, 63, 64 );
+            unsigned long long baseS = 0, baseC = 0;
+            if( wl == 0 )
+            {
+                if( totS )
+                    baseS = atomicAdd( &A.ctr[ CTR_SEG_USED ], (unsigned long long)totS );
+                if( totC )
+                    baseC = atomicAdd( A.nOut, (unsigned long long)totC );
+            }
+            baseS = ( (u64)(u32)__shfl( (int)( baseS >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)baseS, 0, 64 );
+            baseC = ( (u64)(u32)__shfl( (int)( baseC >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)baseC, 0, 64 );
+            if( flush )
+            {
+                const u64 so = baseS + incS - ns, co = baseC + incC - nc;
+                if( so + ns <= A.pool_cap )
+                    for( u32 k = 0; k < ns; k++ )
+                    {
+                        A.pool[ so + k ] = mine[ k ];
+                        A.pool_key[ so + k ] = ( (u64)T.read << MA_TASK_KEY_BITS ) | T.key;
+                    }
+                else
+                    L.err |= MA_ERR_SEG_OVERFLOW;
+                if( co + nc <= A.task_cap && T.depth + 1 < MA_TASK_KEY_BITS / 2 )
+                {
+                    u32 w = 0;
+                    for( int side = 0; side < 2; side++ )
+                        if( L.childN[ side ] )
+                        {
+                            SeedTask c;
+                            c.read = T.read, c.aS = L.childS[ side ], c.aN = L.childN[ side ], c.depth = T.depth + 1;
+                            c.key = T.key | ( (u64)( side + 1 ) << ( MA_TASK_KEY_BITS - 2 * ( T.depth + 1 ) ) );
+                            A.out[ co + w++ ] = c;
+                        }
+                }
+                else if( nc )
+                    L.err |= MA_ERR_STACK_OVERFLOW;
+                if( L.err )
+                    atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)L.err );
+                steps += L.steps;
+                blocks += L.blocks;
+                T.read = 0xffffffffu;
+            }
+            // ---- next tasks
+            if( qCur == qEnd )
+            {
+                unsigned long long base = 0;
+                if( wl == 0 )
+                    base = atomicAdd( &A.ctr[ CTR_NEXT_READ ], 256ull );
+                base = ( (u64)(u32)__shfl( (int)( base >> 32 ), 0, 64 ) << 32 ) | (u32)__shfl( (int)(u32)base, 0, 64 );
+                qCur = base < nIn ? base : nIn;
+                qEnd = base + 256 < nIn ? base + 256 : nIn;
+            }
+            const u64 avail = qEnd - qCur;
+            const u64 rank = (u64)__popcll( dm & ( ( 1ull << wl ) - 1 ) );
+            if( done )
+            {
+                if( rank < avail )
+                {
+                    T = A.in[ qCur + rank ];
+                    const u64 r0 = A.roff[ T.read ];
+                    seed_begin_area( L, A.reads + r0, (u32)( A.roff[ T.read + 1 ] - r0 ), T.aS, T.aN );
+                }
+                else if( qEnd == nIn )
+                    alive = false;
+            }
+            const u64 want = (u64)__popcll( dm );
+            qCur += want < avail ? want : avail;
+        }
+        if( __ballot( alive ) == 0 )
+            break;
+        u32 c = 0;
+        const bool act = alive && L.phase != PH_DONE;
+        bool ext = act && seed_try( L, c );
+        {
+            const unsigned long long sm = __ballot( act && !ext );
+            if( sm && ( (u32)__popcll( sm ) >= 4 || __ballot( ext ) == 0 ) )
+                if( act && !ext )
+                    ext = seed_prepare( L, A.P, S, A.X, c );
+        }
+        if( ext )
+        {
+            i64 ok[ 3 ];
+            u32 nb;
+            extend_backward( A.X, L.ik, c, ok, nb );
+            L.steps++;
+            L.blocks += nb;
+            seed_apply( L, A.P, S, ok );
+        }
+    }
+    steps = wave_sum_u64( steps );
+    blocks = wave_sum_u64( blocks );
+    if( wl == 0 && steps )
+    {
+        atomicAdd( &A.ctr[ CTR_STEPS ], (unsigned long long)steps );
+        atomicAdd( &A.ctr[ CTR_BLOCKS ], (unsigned long long)blocks );
+    }
+}
+// segments into (read, pre-order) order; read id per segment
+__global__ void k_task_permute( const ma_segment* in, const u64* sorted_key, const u32* perm, u64 n, ma_segment* out, u32* out_read )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    out[ i ] = in[ perm[ i ] ];
+    out_read[ i ] = (u32)( sorted_key[ i ] >> MA_TASK_KEY_BITS );
+}
+__global__ void k_iota32( u32* p, u64 n )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i < n )
+        p[ i ] = (u32)i;
+}
+// per read: first segment and count (the read ids are sorted), then BinarySeeding::execute's drop rule
+__global__ void k_task_ranges( const u32* seg_read, u64 n, u64* seg_off, u32* seg_cnt )
+{
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    const u32 r = seg_read[ i ];
+    if( i == 0 || seg_read[ i - 1 ] != r )
+        seg_off[ r ] = i;
+    if( i + 1 == n || seg_read[ i + 1 ] != r )
+        seg_cnt[ r ] = (u32)( i + 1 ); // end; turned into a count by k_task_finish
+}
+__global__ void k_task_finish( IndexView X, SeedParams P, const u64* roff, u32 n_reads, ma_segment* pool, u64* seg_off, u32* seg_cnt )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    if( seg_cnt[ r ] == 0 )
+    {
+        seg_off[ r ] = 0;
+        return;
+    }
+    const u64 b = seg_off[ r ], e = seg_cnt[ r ];
+    u32 n = (u32)( e - b );
+    if( !P.disable_heuristics && P.min_seed_size_drop != 0 )
+    {
+        u64 sum = 0;
+        for( u64 k = b; k < e; k++ )
+            sum += (u64)pool[ k ].q_size / (u64)P.min_seed_size_drop;
+        if( (double)sum < P.rel_min_seed_size_amount * (double)( roff[ r + 1 ] - roff[ r ] ) && P.genome_size_disable < X.n )
+        {
+            for( u64 k = b; k < e; k++ )
+                pool[ k ].q_size = 0, pool[ k ].sa_size = 0;
+            n = 0;
+        }
+    }
+    seg_cnt[ r ] = n;
+}
+
 // per pooled segment: number of seeds it yields (segment.h:316-349 filters)
 __global__ void k_seg_seed_counts( const ma_segment* pool, u64 n, u32 min_len, u32 max_amb, u64* cnt )
 {
@@ -1051,6 +1281,7 @@ struct ma_batch
     DevBuf reads, roff, ctr, seedStack, seedRow, seedSteps, seedSeg, hlocal, hdense, hseedCnt, hseedOff;
     // seeding
     DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt, memsCnt, memsOff;
+    DevBuf taskA, taskB, taskCnt, taskKey, taskKey2, taskPerm, taskPerm2; // area tasks of long reads (seed_tasks)
     u64 segPoolCap = 0, segPoolMin = 0;
     // extraction
     DevBuf segSeedCnt, segSeedOff, seedOff, seedCnt, seeds, cubTmp;
@@ -1333,6 +1564,89 @@ static int seed_mems( ma_batch* b )
     return 0;
 }
 
+// maxSpan seeding of long reads as area tasks (k_seed_tasks); returns 2 when the task arrays were too small (the caller
+// falls back to the read-per-lane kernel)
+static int seed_tasks( ma_batch* b )
+{
+    const u64 n = b->n_reads, nb = b->n_bases;
+    int levels = 2;
+    for( u32 q = b->max_qlen; q > 1; q >>= 1 )
+        levels++;
+    if( levels >= MA_TASK_KEY_BITS / 2 )
+        return 2;
+    const u64 taskCap = nb / 16 + 2 * n + 1024;
+    b->segPoolCap = std::max( std::max<u64>( nb / 2 + 64 * n, 1024 ), b->segPoolMin );
+    if( b->segOff.reserve( ( n + 1 ) * 8 ) || b->segCnt.reserve( ( n + 1 ) * 4 ) || b->taskA.reserve( taskCap * sizeof( SeedTask ) ) ||
+        b->taskB.reserve( taskCap * sizeof( SeedTask ) ) || b->taskCnt.reserve( 64 * 8 ) ||
+        b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
+        b->stage.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->taskKey.reserve( b->segPoolCap * 8 ) ||
+        b->taskKey2.reserve( b->segPoolCap * 8 ) || b->taskPerm.reserve( b->segPoolCap * 4 ) || b->taskPerm2.reserve( b->segPoolCap * 4 ) )
+        return 1;
+    unsigned long long* cnt = b->taskCnt.as<unsigned long long>( );
+    MA_HIP( hipMemsetAsync( cnt, 0, 64 * 8, b->stream ) );
+    TaskKernelArgs A;
+    A.X = b->idx->v;
+    A.P = seed_params( b->P );
+    A.reads = b->d_reads;
+    A.roff = b->d_roff;
+    A.task_cap = taskCap;
+    A.pool = b->stage.as<ma_segment>( ); // unsorted
+    A.pool_key = b->taskKey.as<u64>( );
+    A.pool_cap = b->segPoolCap;
+    A.ctr = b->ctr.as<unsigned long long>( );
+    {
+        EvTimer t( b, 0 );
+        hipLaunchKernelGGL( k_task_roots, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->d_roff, (u32)n,
+                            b->taskA.as<SeedTask>( ), cnt );
+        for( int lv = 0; lv < levels; lv++ )
+        {
+            A.in = ( lv & 1 ) ? b->taskB.as<SeedTask>( ) : b->taskA.as<SeedTask>( );
+            A.out = ( lv & 1 ) ? b->taskA.as<SeedTask>( ) : b->taskB.as<SeedTask>( );
+            A.nIn = cnt + lv;
+            A.nOut = cnt + lv + 1;
+            MA_HIP( hipMemsetAsync( A.ctr + CTR_NEXT_READ, 0, 8, b->stream ) );
+            hipLaunchKernelGGL( k_seed_tasks, dim3( 2048 ), dim3( 256 ), 0, b->stream, A );
+        }
+    }
+    MA_HIP( hipGetLastError( ) );
+    if( read_ctr( b ) )
+        return 1;
+    const u32 err = (u32)b->hctr[ CTR_ERR ];
+    const u64 ns = b->hctr[ CTR_SEG_USED ];
+    if( ( err & MA_ERR_STACK_OVERFLOW ) )
+    {
+        MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
+        return 2; // task array too small: the classic kernel takes over
+    }
+    if( ( err & MA_ERR_SEG_OVERFLOW ) || ns > b->segPoolCap )
+    {
+        b->segPoolMin = ns + 1024; // counted need: run again
+        MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
+        return seed_tasks( b );
+    }
+    MA_HIP( hipMemsetAsync( b->segCnt.p, 0, ( n + 1 ) * 4, b->stream ) );
+    if( ns )
+    {
+        hipLaunchKernelGGL( k_iota32, dim3( (unsigned)( ( ns + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->taskPerm.as<u32>( ), ns );
+        size_t tb = 0;
+        MA_HIP( hipcub::DeviceRadixSort::SortPairs( nullptr, tb, b->taskKey.as<u64>( ), b->taskKey2.as<u64>( ), b->taskPerm.as<u32>( ),
+                                                    b->taskPerm2.as<u32>( ), (int)ns, 0, 64, b->stream ) );
+        if( b->cubTmp.reserve( tb + 256 ) )
+            return 1;
+        MA_HIP( hipcub::DeviceRadixSort::SortPairs( b->cubTmp.p, tb, b->taskKey.as<u64>( ), b->taskKey2.as<u64>( ), b->taskPerm.as<u32>( ),
+                                                    b->taskPerm2.as<u32>( ), (int)ns, 0, 64, b->stream ) );
+        const dim3 grid( (unsigned)( ( ns + 255 ) / 256 ) ), block( 256 );
+        hipLaunchKernelGGL( k_task_permute, grid, block, 0, b->stream, b->stage.as<ma_segment>( ), b->taskKey2.as<u64>( ),
+                            b->taskPerm2.as<u32>( ), ns, b->segPool.as<ma_segment>( ), b->segRead.as<u32>( ) );
+        hipLaunchKernelGGL( k_task_ranges, grid, block, 0, b->stream, b->segRead.as<u32>( ), ns, b->segOff.as<u64>( ), b->segCnt.as<u32>( ) );
+    }
+    hipLaunchKernelGGL( k_task_finish, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->idx->v, seed_params( b->P ),
+                        b->d_roff, (u32)n, b->segPool.as<ma_segment>( ), b->segOff.as<u64>( ), b->segCnt.as<u32>( ) );
+    MA_HIP( hipGetLastError( ) );
+    b->stage_done = 1;
+    return 0;
+}
+
 int ma_seed_batch( ma_batch* b )
 {
     if( !b || !b->d_roff )
@@ -1348,6 +1662,19 @@ int ma_seed_batch( ma_batch* b )
     }
     if( b->P.seeding_technique == 2 )
         return seed_mems( b );
+    // long reads: one lane per AREA of the recursion instead of one per read (reads up to 240 bases keep the
+    // read-per-lane kernel with the read staged in LDS); MA_SEED_TASKS=0 / 1 forces the choice (tests, tuning)
+    {
+        bool tasks = b->P.seeding_technique == 0 && b->max_qlen > 240;
+        if( const char* e = getenv( "MA_SEED_TASKS" ) )
+            tasks = b->P.seeding_technique == 0 && atoi( e ) != 0;
+        if( tasks )
+        {
+            const int rc = seed_tasks( b );
+            if( rc != 2 )
+                return rc;
+        }
+    }
     const bool smem = b->P.seeding_technique == 1;
     const u32 worst_cap = ( smem ? 6 : 2 ) * b->max_qlen + 8; // segments one read can emit at most
     const u32 smem_cap = smem ? b->max_qlen + 2 : 0;

@@ -70,6 +70,10 @@ struct SeedLane
     u64 drop_sum; // sum over emitted segments of q_size / min_seed_size_drop (numSeedsLarger, segment.h:278-289)
     // counters
     u32 steps, blocks;
+    // task mode (one lane per AREA instead of per read, pipeline.hip k_seed_tasks): after the area's centre has been
+    // extended the lane stops and reports the two remaining areas instead of walking them itself
+    u32 task_mode;
+    u32 childS[ 2 ], childN[ 2 ]; // [0] left of the covered interval, [1] right of it; N == 0: none
 };
 
 MA_HD u32 comp_base( u32 c ) // NucSeq::nucleotideComplement (nucSeq.h:524-532)
@@ -107,7 +111,19 @@ MA_HD void seed_begin_read( SeedLane& L, const uint8_t* q, u32 qlen )
     L.drop_sum = 0;
     L.err = 0;
     L.steps = L.blocks = 0;
+    L.task_mode = 0;
     L.phase = qlen == 0 ? PH_DONE : PH_NEW_CENTER;
+}
+// task mode: the lane extends the centre of [aS, aS + aN) of the read and stops
+MA_HD void seed_begin_area( SeedLane& L, const uint8_t* q, u32 qlen, u32 aS, u32 aN )
+{
+    seed_begin_read( L, q, qlen );
+    L.task_mode = 1;
+    L.aS = aS;
+    L.aN = aN;
+    L.childN[ 0 ] = L.childN[ 1 ] = 0;
+    L.childS[ 0 ] = L.childS[ 1 ] = 0;
+    L.phase = aN == 0 ? PH_DONE : PH_NEW_CENTER;
 }
 
 // After an extension around `center` covered [cS, cS+cN] (reference convention), split the area
@@ -117,6 +133,13 @@ MA_HD void seed_after_center( SeedLane& L, const SeedScratch& S, u32 cS, u32 cN 
     const u32 cE = cS + cN, aE = L.aS + L.aN;
     const bool hasLeft = cS != 0 && L.aS + 1 < cS;
     const bool hasRight = aE > cE + 1;
+    if( L.task_mode )
+    {
+        L.childS[ 0 ] = L.aS, L.childN[ 0 ] = hasLeft ? cS - L.aS : 0;
+        L.childS[ 1 ] = cE, L.childN[ 1 ] = hasRight ? aE - cE : 0;
+        L.phase = PH_DONE;
+        return;
+    }
     if( hasLeft )
     {
         if( hasRight )

@@ -12,7 +12,7 @@ OUT=gpurun_out/prof_${TAG}_$WL
 mkdir -p $OUT
 export TMPDIR=/tmp
 case $WL in 150bp) RL=150; RPS=1000000;; 10kb) RL=10000; RPS=200000;; 50kb) RL=50000; RPS=20000;; esac
-ARGS="bench.py --workload $WL --preset $PRESET --steps 3 --warmup 1 --cpu-sample 0 --boundary-reads 0"
+ARGS="bench.py --workload $WL --preset $PRESET --steps 3 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 $ARGS > $OUT/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_SALU; do
   rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$C -o pmc --output-format csv -- python3 $ARGS > $OUT/pmc_$C.log 2>&1
