@@ -1662,10 +1662,12 @@ int ma_seed_batch( ma_batch* b )
     }
     if( b->P.seeding_technique == 2 )
         return seed_mems( b );
-    // long reads: one lane per AREA of the recursion instead of one per read (reads up to 240 bases keep the
-    // read-per-lane kernel with the read staged in LDS); MA_SEED_TASKS=0 / 1 forces the choice (tests, tuning)
+    // few long reads: one lane per AREA of the recursion instead of one per read.  With >= 128 k reads in the batch the
+    // read-per-lane kernel already fills the machine and is faster (10 kb x 200 k reads: 157 vs 184 ms; the level-by-level
+    // walk pays a tail per level), with 20 k reads of 50 kb the task kernel is 6.5x faster (83 vs 546 ms).
+    // MA_SEED_TASKS=0 / 1 forces the choice (tests, tuning)
     {
-        bool tasks = b->P.seeding_technique == 0 && b->max_qlen > 240;
+        bool tasks = b->P.seeding_technique == 0 && b->max_qlen > 240 && n < 131072;
         if( const char* e = getenv( "MA_SEED_TASKS" ) )
             tasks = b->P.seeding_technique == 0 && atoi( e ) != 0;
         if( tasks )
