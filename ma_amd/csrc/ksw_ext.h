@@ -39,6 +39,14 @@ __device__ __forceinline__ u32 pk_sub( u32 a, u32 b ) { return KR( KU2( a ) - KU
 __device__ __forceinline__ u32 pk_max( u32 a, u32 b ) { return KR( __builtin_elementwise_max( KS2( a ), KS2( b ) ) ); }
 __device__ __forceinline__ u32 pk_min( u32 a, u32 b ) { return KR( __builtin_elementwise_min( KS2( a ), KS2( b ) ) ); }
 __device__ __forceinline__ u32 pk_minu( u32 a, u32 b ) { return KR( __builtin_elementwise_min( KU2( a ), KU2( b ) ) ); }
+// min(x, 1) per half as ONE instruction: written with the builtin the compiler turns it into x != 0 ? 1 : 0 and a
+// multiply by it into per-half compares + v_cndmask + v_perm (8 instructions in the score profile of ksw_pk.h)
+__device__ __forceinline__ u32 pk_min1( u32 x, u32 ones /* 0x00010001 in a register */ )
+{
+    u32 r;
+    asm( "v_pk_min_u16 %0, %1, %2" : "=v"( r ) : "v"( x ), "v"( ones ) );
+    return r;
+}
 __device__ __forceinline__ u32 pk_subsat( u32 a, u32 b ) { return KR( __builtin_elementwise_sub_sat( KS2( a ), KS2( b ) ) ); }
 __device__ __forceinline__ u32 pk_subsatu( u32 a, u32 b ) { return KR( __builtin_elementwise_sub_sat( KU2( a ), KU2( b ) ) ); }
 __device__ __forceinline__ u32 pk_ashr8( u32 a ) { return KR( KS2( a ) >> (short)8 ); }
@@ -397,11 +405,11 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             for( int s = 0; s < R; s++ )
             {
                 const int sp = s == 0 ? R - 1 : s - 1; // lane 0 continues lane 63 of the previous slot of the ring
-                u32 ax = R == 1 ? px[ s ] : ( lane == 0 ? px[ sp ] : px[ s ] );
-                u32 av = R == 1 ? pv[ s ] : ( lane == 0 ? pv[ sp ] : pv[ s ] );
-                u32 ax2 = R == 1 ? px2[ s ] : ( lane == 0 ? px2[ sp ] : px2[ s ] );
-                u32 ah = R == 1 ? ph[ s ] : ( lane == 0 ? ph[ sp ] : ph[ s ] );
-                u32 aq = R == 1 ? pq[ s ] : ( lane == 0 ? pq[ sp ] : pq[ s ] );
+                u32 ax = R == 1 ? px[ s ] : pk_bfi( M_LANE0, px[ sp ], px[ s ] );
+                u32 av = R == 1 ? pv[ s ] : pk_bfi( M_LANE0, pv[ sp ], pv[ s ] );
+                u32 ax2 = R == 1 ? px2[ s ] : pk_bfi( M_LANE0, px2[ sp ], px2[ s ] );
+                u32 ah = R == 1 ? ph[ s ] : pk_bfi( M_LANE0, ph[ sp ], ph[ s ] );
+                u32 aq = R == 1 ? pq[ s ] : pk_bfi( M_LANE0, pq[ sp ], pq[ s ] );
                 if( s == 0 && st0 == 0 )
                 {
                     // cell 0 (slot 0, lane 0, low half until it is recycled at r >= qlen + 15): first-column carry-in

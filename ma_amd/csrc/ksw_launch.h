@@ -69,6 +69,17 @@ MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i
     return e ? 4 + e : ksw_job_class( qlen, tlen, w );
 }
 
+// per-wave scratch of one job: direction bytes of the exact kernels (n_col bytes per diagonal) / of the extension kernel
+// (one ring row per diagonal)
+MA_HD u64 ksw_p_bytes( i32 qlen, i32 tlen, i32 w )
+{
+    return (u64)( (i64)qlen + tlen - 1 ) * (u64)( ksw_ncol( qlen, tlen, w ) * 16 ) + 16;
+}
+MA_HD u64 ksw_ext_p_bytes( i32 qlen, i32 tlen, int R )
+{
+    return (u64)( (i64)qlen + tlen - 1 ) * (u64)( 128 * R ) + 16;
+}
+
 // result record + cigar of one finished job -> output arrays (all 64 lanes call this)
 __device__ __forceinline__ void ksw_publish( const KswOut& O, KswWaveAcc& A, u32 slot, const KswEz& ez, u32 nCig, u64 cells,
                                              u64 path, const u32* cig, unsigned long long* sOff )
@@ -164,6 +175,7 @@ struct KswJobs
     u32 n;
     const unsigned int* nDev;
     int mode, cls;
+    u64 pMin, pMax; // only jobs with pMin < ksw_p_bytes <= pMax (a class with a few huge jobs is run as two launches)
 };
 
 #if defined( MA_KSW_PROF )
@@ -263,6 +275,11 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( S 
         const KswJobView J = F.view( slot );
         if( JB.mode != 0 && ksw_job_class( J.qlen, J.tlen, J.w ) != JB.cls )
             continue;
+        {
+            const u64 pj = ksw_p_bytes( J.qlen, J.tlen, J.w );
+            if( pj <= JB.pMin || pj > JB.pMax )
+                continue;
+        }
         KswEz ez;
         u32 nCig = 0;
         u64 cells = 0, path = 0;
@@ -336,16 +353,22 @@ struct KswSizing
     u64 state = 0, h = 0, p = 0, cig = 0;
     u64 qlen = 0; // longest query (LDS bytes of the register kernels)
     u64 cls[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0 }; // jobs per class
+    u64 pc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0 }; // largest direction-byte scratch of a job, per class (0: use p)
+    u64 cigc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0 }; // largest cigar scratch in words, per class (0: use cig)
+    u64 pRedo = 0, cigRedo = 0; // the same for jobs the extension kernel hands back to the exact kernels (0: use p / cig)
 };
 inline void ksw_size_job( KswSizing& S, i32 qlen, i32 tlen, i32 w )
 {
     if( qlen <= 0 || tlen <= 0 )
         return;
-    S.cls[ ksw_job_class( qlen, tlen, w ) ]++;
+    const int k = ksw_job_class( qlen, tlen, w );
+    S.cls[ k ]++;
     S.qlen = S.qlen > (u64)qlen ? S.qlen : (u64)qlen;
     const u64 st = ksw_state_bytes( qlen, tlen );
     const u64 L = (u64)( ( tlen + 15 ) / 16 ) * 16;
-    const u64 p = (u64)( (i64)qlen + tlen - 1 ) * (u64)( ksw_ncol( qlen, tlen, w ) * 16 ) + 16;
+    const u64 p = ksw_p_bytes( qlen, tlen, w );
+    S.pc[ k ] = S.pc[ k ] > p ? S.pc[ k ] : p;
+    S.cigc[ k ] = S.cigc[ k ] > (u64)qlen + tlen + 2 ? S.cigc[ k ] : (u64)qlen + tlen + 2;
     S.state = S.state > st ? S.state : st;
     S.h = S.h > L * 4 ? S.h : L * 4;
     S.p = S.p > p ? S.p : p;
@@ -389,16 +412,41 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
     return P;
 }
 
-// Launches every class that has jobs.  `next` = 12 zeroed counters (one per launch).  `lists` (device, or null) holds
-// the job slots of class k at lists + k * list_stride, SZ.cls[k] entries, and room for the jobs the extension
-// kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every launch scans
-// nSlots and there are no extension-kernel classes.
+// Launches every class that has jobs.  `next` = 12 zeroed counters (one per launch), `nextBig` = 4 more.  `lists`
+// (device, or null) holds the job slots of class k at lists + k * list_stride, SZ.cls[k] entries, and room for the jobs
+// the extension kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every
+// launch scans nSlots and there are no extension-kernel classes.
+//
+// Scratch: every wave owns `stride` bytes (direction bytes + cigar of the job it is working on) of one allocation that
+// the launches, which run back to back on one stream, share.  Each launch is sized for ITS class: the classes differ
+// by orders of magnitude (gap between two seeds: KBs; end extension of a 50 kb read: 27 MB), and one stride for all
+// would cut every launch down to the few hundred waves the largest job allows -- less than one wave per SIMD
+// (50 kb reads: DP stage 2.4 s -> see DESIGN.md 3.6).  A class whose own largest job still does not leave room for a
+// full set of waves is run as two launches: the jobs that fit a full set, then the few huge ones on fewer waves.
 #define KSW_REG_LDS 6144u // per-wave LDS of the exact register kernels: reversed query, later the back-trace staging block
 #define KSW_EXT_LDS 4096u // extension kernel: back-trace staging only (8 waves per SIMD fit)
+#define KSW_SCRATCH_BUDGET ( 24ull << 30 )
+struct KswLaunchPlan
+{
+    u64 p_cap = 0, stride = 0, pMax = ~0ull; // pMax: largest job scratch this launch takes
+    u32 waves = 0;
+};
+inline KswLaunchPlan ksw_plan_launch( u64 p, u64 cigWords, u64 jobs, u64 wantWaves )
+{
+    auto al = []( u64 x ) { return ( x + 255 ) / 256 * 256; };
+    KswLaunchPlan L;
+    L.p_cap = al( p );
+    L.stride = al( L.p_cap + al( cigWords * 4 ) );
+    u64 waves = std::max<u64>( 1, std::min<u64>( wantWaves, jobs ) );
+    if( L.stride * waves > KSW_SCRATCH_BUDGET )
+        waves = std::max<u64>( 1, KSW_SCRATCH_BUDGET / L.stride );
+    L.waves = (u32)waves;
+    return L;
+}
 template <typename FETCH>
 int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
                  unsigned int* next, KswOut O, hipStream_t stream, u32* lists = nullptr, u64 list_stride = 0,
-                 unsigned int* nRedo = nullptr )
+                 unsigned int* nRedo = nullptr, unsigned int* nextBig = nullptr )
 {
     auto al = []( u64 x ) { return ( x + 255 ) / 256 * 256; };
     u64 nJobs = 0;
@@ -407,20 +455,46 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( nJobs == 0 )
         return 0;
     const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ];
-    const u64 p_cap = al( SZ.p );
-    const u64 regStride = al( p_cap + al( SZ.cig * 4 ) );
-    KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, 24ull << 30 );
+    KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, KSW_SCRATCH_BUDGET );
     u64 perCu = 32; // waves per CU of the persistent ksw launches (MA_KSW_WAVES_PER_CU: tuning hook)
     if( const char* e = getenv( "MA_KSW_WAVES_PER_CU" ) )
         perCu = (u64)std::max( 1, atoi( e ) );
-    u64 regWaves = std::min<u64>( 256ull * perCu, nJobs );
-    if( regStride * regWaves > ( 24ull << 30 ) )
-        regWaves = std::max<u64>( 1, ( 24ull << 30 ) / regStride );
-    u64 need = std::max<u64>( regStride * regWaves, SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0 );
-    // the per-wave scratch follows the LARGEST job of the batch, which varies a lot from batch to batch for long
+    const u64 wantWaves = 256ull * perCu;
+    // pass 0 launches of the register kernels: classes 0..3 (exact), 5 / 6 (extension); [7..10]: classes 0..3 of the
+    // second pass (jobs handed back), [11..14]: the huge jobs of classes 0..3
+    KswLaunchPlan LP[ 15 ];
+    for( int k = 0; k < KSW_N_CLASSES; k++ )
+    {
+        if( k == 4 || SZ.cls[ k ] == 0 )
+            continue;
+        const u64 pk = SZ.pc[ k ] ? SZ.pc[ k ] : ( k >= 5 ? std::max( SZ.p, ksw_ext_p_bytes( 256, 2048, k - 4 ) ) : SZ.p );
+        const u64 cg = SZ.cigc[ k ] ? SZ.cigc[ k ] : SZ.cig;
+        LP[ k ] = ksw_plan_launch( pk, cg, SZ.cls[ k ], wantWaves );
+        const u64 full = std::min<u64>( wantWaves, SZ.cls[ k ] );
+        if( k < 4 && nextBig && LP[ k ].waves < full && LP[ k ].waves < 256 * 16 )
+        {
+            // not even 4 waves per SIMD: the jobs that leave room for that many first, then the rest
+            const u64 room = KSW_SCRATCH_BUDGET / std::min<u64>( full, 256 * 16 );
+            const u64 cgB = al( cg * 4 ) + 512;
+            if( room > cgB + 4096 )
+            {
+                const u64 pSmall = ( room - cgB ) / 256 * 256;
+                LP[ 11 + k ] = LP[ k ]; // the huge jobs: pMin = pSmall
+                LP[ k ] = ksw_plan_launch( pSmall, cg, SZ.cls[ k ], wantWaves );
+                LP[ k ].pMax = pSmall;
+            }
+        }
+    }
+    if( nExt )
+        for( int k = 0; k < 4; k++ )
+            LP[ 7 + k ] = ksw_plan_launch( SZ.pRedo ? SZ.pRedo : SZ.p, SZ.cigRedo ? SZ.cigRedo : SZ.cig, std::min<u64>( nExt, 256 * 4 ), wantWaves );
+    u64 need = SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0;
+    for( int k = 0; k < 15; k++ )
+        need = std::max<u64>( need, LP[ k ].stride * LP[ k ].waves );
+    // the per-wave scratch follows the largest jobs of the batch, which vary a lot from batch to batch for long
     // reads: once it is in the GB range take the whole budget so that later batches never re-allocate mid-step
     if( need > ( 2ull << 30 ) )
-        need = 24ull << 30;
+        need = std::max<u64>( need, KSW_SCRATCH_BUDGET );
     if( scratch.reserve( need ) )
         return 1;
     const u32 ldsReg = std::max<u32>( (u32)( ( ( std::min<u64>( SZ.qlen, 150000 ) + 15 ) / 16 ) * 16 + 64 ), KSW_REG_LDS );
@@ -433,50 +507,55 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     }
     uint8_t* base = scratch.as<uint8_t>( );
     u32* redo = lists ? lists + (u64)KSW_N_CLASSES * list_stride : nullptr;
-    auto grid = [ & ]( u64 jobs ) { return dim3( (unsigned)std::max<u64>( 1, std::min<u64>( regWaves, jobs ) ) ); };
-    // the launches run back to back on one stream, so they can share the scratch
     if( SZ.cls[ 5 ] )
-        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), grid( SZ.cls[ 5 ] ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
-                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base, regStride, p_cap, KSW_EXT_LDS, O, redo,
-                            nRedo );
+        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), dim3( LP[ 5 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
+                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base, LP[ 5 ].stride, LP[ 5 ].p_cap, KSW_EXT_LDS,
+                            O, redo, nRedo );
     if( SZ.cls[ 6 ] )
-        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), grid( SZ.cls[ 6 ] ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
-                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base, regStride, p_cap, KSW_EXT_LDS, O, redo,
-                            nRedo );
-    for( int pass = 0; pass < ( nExt ? 2 : 1 ); pass++ )
+        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), dim3( LP[ 6 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
+                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base, LP[ 6 ].stride, LP[ 6 ].p_cap, KSW_EXT_LDS,
+                            O, redo, nRedo );
+    // pass 0: the classes' own jobs; pass 1: whatever the extension kernel handed back (usually nothing); pass 2:
+    // the huge jobs of a class that was split
+    for( int pass = 0; pass < 3; pass++ )
     {
-        // pass 0: the classes' own jobs; pass 1: whatever the extension kernel handed back (usually nothing)
-        auto jobs = [ & ]( int k ) {
+        if( pass == 1 && !nExt )
+            continue;
+        auto launch = [ & ]( int k, auto kernel ) {
+            const KswLaunchPlan& L = LP[ pass == 0 ? k : ( pass == 1 ? 7 + k : 11 + k ) ];
+            if( L.waves == 0 )
+                return;
             KswJobs JB;
-            JB.list = pass ? redo : ( lists ? lists + (u64)k * list_stride : nullptr );
+            JB.list = pass == 1 ? redo : ( lists ? lists + (u64)k * list_stride : nullptr );
             JB.n = lists ? (u32)SZ.cls[ k ] : nSlots;
             JB.nDev = nRedo;
-            JB.mode = pass ? 2 : ( lists ? 0 : 1 );
+            JB.mode = pass == 1 ? 2 : ( lists ? 0 : 1 );
             JB.cls = k;
-            return JB;
+            JB.pMin = pass == 2 ? LP[ k ].pMax : 0;
+            JB.pMax = L.pMax;
+            unsigned int* nx = pass == 0 ? next + k : ( pass == 1 ? next + 7 + k : nextBig + k );
+            hipLaunchKernelGGL( kernel, dim3( L.waves ), dim3( 64 ), ldsReg, stream, F, SC, JB, nx, base, L.stride, L.p_cap, ldsReg, O );
         };
-        auto cnt = [ & ]( int k ) { return pass ? std::min<u64>( nExt, 256 * 4 ) : SZ.cls[ k ]; };
-        unsigned int* nx = next + ( pass ? 7 : 0 );
-        if( cnt( 0 ) )
-            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S0> ), grid( cnt( 0 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 0 ),
-                                nx + 0, base, regStride, p_cap, ldsReg, O );
-        if( cnt( 1 ) )
-            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S1> ), grid( cnt( 1 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 1 ),
-                                nx + 1, base, regStride, p_cap, ldsReg, O );
-        if( cnt( 2 ) )
-            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S2> ), grid( cnt( 2 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 2 ),
-                                nx + 2, base, regStride, p_cap, ldsReg, O );
-        if( cnt( 3 ) )
-            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S3> ), grid( cnt( 3 ) ), dim3( 64 ), ldsReg, stream, F, SC, jobs( 3 ),
-                                nx + 3, base, regStride, p_cap, ldsReg, O );
-        if( !pass && cnt( 4 ) ) // a handed-back job always fits a register kernel
+        launch( 0, k_ksw_pk<FETCH, KSW_S0> );
+        launch( 1, k_ksw_pk<FETCH, KSW_S1> );
+        launch( 2, k_ksw_pk<FETCH, KSW_S2> );
+        launch( 3, k_ksw_pk<FETCH, KSW_S3> );
+        if( pass == 0 && SZ.cls[ 4 ] ) // a handed-back job always fits a register kernel
         {
+            KswJobs JB;
+            JB.list = lists ? lists + (u64)4 * list_stride : nullptr;
+            JB.n = lists ? (u32)SZ.cls[ 4 ] : nSlots;
+            JB.nDev = nRedo;
+            JB.mode = lists ? 0 : 1;
+            JB.cls = 4;
+            JB.pMin = 0;
+            JB.pMax = ~0ull;
             plan.ws.base = base;
             if( plan.lds_bytes > 48 * 1024 )
                 MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)plan.lds_bytes ) );
-            hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC,
-                                jobs( 4 ), nx + 4, plan.ws, plan.lds_bytes, O );
+            hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, JB, next + 4,
+                                plan.ws, plan.lds_bytes, O );
         }
     }
     MA_HIP( hipGetLastError( ) );

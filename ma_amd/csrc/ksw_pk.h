@@ -100,6 +100,10 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     const u32 K_Q = pk_val( q, 0 ), K_Q2 = pk_val( q2, 0 ), K_QE = pk_val( q + e, 0 ), K_QE2 = pk_val( q2 + e2, 0 );
     const u32 K_MCH = pk_val( sc_mch, tS ), K_NDIFF = pk_val( sc_mis - sc_mch, 0 ), K_NADJ = pk_val( -e2 - sc_mis, 0 );
     const u32 K_CLIP = pk_val( sc_mch, 0xff );
+    // lane 0 continues lane 63 of the previous ring slot: a bit mask for ONE v_bitop3 per neighbour view (written as
+    // lane == 0 ? px[sp] : px[s] the compiler indexes the register array dynamically: 4 v_cndmask per view for R = 5)
+    const u32 M_LANE0 = pk_opaque( lane == 0 ? 0xffffffffu : 0u );
+    const u32 K_ONES = pk_opaque( 0x00010001u );
 
     for( i32 t = lane; t < qrBytes; t += 64 )
         qr[ t ] = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
@@ -117,10 +121,12 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
 
     u32 U[ R ], V[ R ], X[ R ], Y[ R ], X2[ R ], Y2[ R ], Sp[ R ], T[ R ];
     i32 Hlo[ R ], Hhi[ R ], TT[ R ];
+    u32 PT[ R ]; // the two cell indices of the lane mod 2^16, one per half (range tests with packed arithmetic)
 #pragma unroll
     for( int s = 0; s < R; s++ )
     {
         TT[ s ] = 128 * s + 2 * lane;
+        PT[ s ] = (u32)( 128 * s + 2 * lane ) | (u32)( 128 * s + 2 * lane + 1 ) << 16;
         U[ s ] = V[ s ] = K_V0;
         X[ s ] = K_X0;
         Y[ s ] = K_Y0;
@@ -174,6 +180,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                     if( TT[ s ] < st )
                     {
                         TT[ s ] += RING;
+                        PT[ s ] = pk_add( PT[ s ], pk_bcast( RING ) );
                         U[ s ] = V[ s ] = K_V0;
                         X[ s ] = K_X0;
                         Y[ s ] = K_Y0;
@@ -189,6 +196,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         const i32 uInit = initOf( r );
         const bool initRow = en >= r; // kswcpp_core.h:580-585
         const i32 pEnd = st0 + ( ( en0 - st0 ) / 16 + 1 ) * 16; // score profile refreshes [st0, pEnd)
+        const u32 profSt = pk_bcast_s( st0 ), profLen = pk_bcast_s( pEnd - st0 );
         const i32 qoff = qlen - 1 - r;
         uint8_t* pr = P + (size_t)r * (size_t)n_col - st;
         cells += (u64)( en - st + 1 );
@@ -221,10 +229,10 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             const int sp = s == 0 ? R - 1 : s - 1;
             const i32 tt = TT[ s ]; // low cell; the high half is cell tt + 1
             // neighbours t-1 (values of the previous diagonal)
-            u32 xt1 = cells_shift1( X[ s ], R == 1 ? px[ s ] : ( lane == 0 ? px[ sp ] : px[ s ] ) );
-            u32 vt1 = cells_shift1( V[ s ], R == 1 ? pv[ s ] : ( lane == 0 ? pv[ sp ] : pv[ s ] ) );
-            u32 x2t1 = cells_shift1( X2[ s ], R == 1 ? px2[ s ] : ( lane == 0 ? px2[ sp ] : px2[ s ] ) );
-            i32 hupLo = R == 1 ? ph[ s ] : ( lane == 0 ? ph[ sp ] : ph[ s ] );
+            u32 xt1 = cells_shift1( X[ s ], R == 1 ? px[ s ] : pk_bfi( M_LANE0, px[ sp ], px[ s ] ) );
+            u32 vt1 = cells_shift1( V[ s ], R == 1 ? pv[ s ] : pk_bfi( M_LANE0, pv[ sp ], pv[ s ] ) );
+            u32 x2t1 = cells_shift1( X2[ s ], R == 1 ? px2[ s ] : pk_bfi( M_LANE0, px2[ sp ], px2[ s ] ) );
+            i32 hupLo = R == 1 ? ph[ s ] : (i32)pk_bfi( M_LANE0, (u32)ph[ sp ], (u32)ph[ s ] );
             const i32 hupHi = Hlo[ s ];
             if( s == j0 )
             {
@@ -248,12 +256,12 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             {
                 const u32 b = (u32)qr[ qoff + tt ] | (u32)qr[ qoff + tt + 1 ] << 16;
                 const u32 isN = pk_lshr( T[ s ] | b, 2 );
-                const u32 differ = pk_minu( ( T[ s ] ^ b ) | isN, 0x00010001u );
+                const u32 differ = pk_min1( ( T[ s ] ^ b ) | isN, K_ONES );
                 u32 val = pk_mad( differ, K_NDIFF, K_MCH );
                 val = pk_mad( isN, K_NADJ, val );
-                const u32 mlo = ( tt >= st0 && tt < pEnd ) ? 0x0000ffffu : 0u;
-                const u32 mhi = ( tt + 1 >= st0 && tt + 1 < pEnd ) ? 0xffff0000u : 0u;
-                Sp[ s ] = pk_bfi( mlo | mhi, val, Sp[ s ] );
+                // cells in [st0, pEnd): (t - st0) mod 2^16 < pEnd - st0, per half (the window is < 2^15 cells wide)
+                const u32 inProf = pk_nonzero15( pk_subsatu( profLen, pk_sub( PT[ s ], profSt ) ) );
+                Sp[ s ] = pk_bfi( inProf, val, Sp[ s ] );
             }
             // DP cell (kswcpp_core.h:653-766)
             u32 nu, nv;

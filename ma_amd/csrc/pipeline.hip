@@ -49,7 +49,12 @@ enum : int
     CTR_OPS_ALL = 37, // alignment ops of all alignments / of the MappingQuality selection (exact sizes of the downloads)
     CTR_OPS_MQ = 38,
     CTR_ALN_MQ = 39, // alignments MappingQuality keeps
-    CTR_COUNT = 40
+    CTR_MAX_PC0 = 40, // per kernel class: largest direction-byte scratch of a job (7 words) ...
+    CTR_MAX_CIGC0 = 47, // ... and largest cigar scratch in words (7 words)
+    CTR_MAX_P_REDO = 54, // the same two for the extension kernel's jobs if they are handed back to the exact kernel
+    CTR_MAX_CIG_REDO = 55,
+    CTR_NEXT_BIG = 56, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
+    CTR_COUNT = 58
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -968,21 +973,44 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
     sink.slot0 = 0;
     if( s < A.n_sets )
         dp_enum_one( A, s, sink );
+    u32 pcl[ KSW_N_CLASSES ], cgl[ KSW_N_CLASSES ], pRedo = 0, cgRedo = 0;
     // append the jobs to the per-class lists: one atomic per wave, class and round instead of one per job
     {
         const u32 mine = sink.n < sink.cap ? sink.n : sink.cap;
         const u32 rounds = (u32)wave_max_u64( mine );
         const int lane = threadIdx.x & 63;
+        // scratch per wave of each class's launch: the classes differ by orders of magnitude (a 50 kb end extension
+        // needs 27 MB of direction bytes, a gap between two seeds a few KB), and a launch sized for the largest job of
+        // the whole batch would leave most of the machine without waves
+#pragma unroll
+        for( int c = 0; c < KSW_N_CLASSES; c++ )
+            pcl[ c ] = cgl[ c ] = 0;
         for( u32 k = 0; k < rounds; k++ )
         {
             int cls = -1;
+            u32 pj = 0, cj = 0;
             if( k < mine )
             {
                 const DpJob& j = A.jobs[ sink.slot0 + k ];
-                cls = ksw_job_class_pipe( A.SC, (i32)( j.q_to - j.q_from ), (i32)( j.r_to - j.r_from ), j.w, j.zdrop, j.flag );
+                const i32 ql = (i32)( j.q_to - j.q_from ), tl = (i32)( j.r_to - j.r_from );
+                cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
+                const u64 pk = ksw_p_bytes( ql, tl, j.w );
+                pj = (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 ); // 256-byte units
+                cj = (u32)( ql + tl + 2 );
+                if( cls >= 5 )
+                {
+                    pRedo = max( pRedo, (u32)( ( pk + 255 ) >> 8 ) );
+                    cgRedo = max( cgRedo, cj );
+                }
             }
+#pragma unroll
             for( int c = 0; c < KSW_N_CLASSES; c++ )
             {
+                if( cls == c )
+                {
+                    pcl[ c ] = max( pcl[ c ], pj );
+                    cgl[ c ] = max( cgl[ c ], cj );
+                }
                 const unsigned long long m = __ballot( cls == c );
                 if( m == 0 )
                     continue;
@@ -1000,6 +1028,14 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
     const u64 st = wave_max_u64( sink.mx_state ), h = wave_max_u64( sink.mx_h ), p = wave_max_u64( sink.mx_p );
     const u64 cg = wave_max_u64( sink.mx_cig ), ql = wave_max_u64( sink.mx_qlen );
     const u64 nj = wave_sum_u64( sink.n_jobs ), sb = wave_sum_u64( sink.seq_bytes );
+    u64 pcW[ KSW_N_CLASSES ], cgW[ KSW_N_CLASSES ];
+#pragma unroll
+    for( int c = 0; c < KSW_N_CLASSES; c++ )
+    {
+        pcW[ c ] = wave_max_u64( pcl[ c ] );
+        cgW[ c ] = wave_max_u64( cgl[ c ] );
+    }
+    const u64 pRedoW = wave_max_u64( pRedo ), cgRedoW = wave_max_u64( cgRedo );
     if( ( threadIdx.x & 63 ) == 0 && nj )
     {
         atomicMax( &A.ctr[ CTR_MAX_STATE ], (unsigned long long)st );
@@ -1007,6 +1043,19 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
         atomicMax( &A.ctr[ CTR_MAX_P ], (unsigned long long)p );
         atomicMax( &A.ctr[ CTR_MAX_CIG ], (unsigned long long)cg );
         atomicMax( &A.ctr[ CTR_MAX_QLEN ], (unsigned long long)ql );
+#pragma unroll
+        for( int c = 0; c < KSW_N_CLASSES; c++ )
+        {
+            if( pcW[ c ] )
+                atomicMax( &A.ctr[ CTR_MAX_PC0 + c ], (unsigned long long)pcW[ c ] << 8 );
+            if( cgW[ c ] )
+                atomicMax( &A.ctr[ CTR_MAX_CIGC0 + c ], (unsigned long long)cgW[ c ] );
+        }
+        if( pRedoW )
+        {
+            atomicMax( &A.ctr[ CTR_MAX_P_REDO ], (unsigned long long)pRedoW << 8 );
+            atomicMax( &A.ctr[ CTR_MAX_CIG_REDO ], (unsigned long long)cgRedoW );
+        }
         atomicAdd( &A.ctr[ CTR_N_JOBS ], (unsigned long long)nj );
         atomicAdd( &A.ctr[ CTR_SEQ_BYTES ], (unsigned long long)sb );
     }
@@ -1566,6 +1615,15 @@ static int seed_mems( ma_batch* b )
 
 // maxSpan seeding of long reads as area tasks (k_seed_tasks); returns 2 when the task arrays were too small (the caller
 // falls back to the read-per-lane kernel)
+// First-attempt size of the segment pool.  Measured: 0.017 - 0.019 maxSpan segments per base (150 bp, 10 kb and 50 kb
+// reads against GRCh38-like references); the pool takes 1/16 per base + 16 per read (>3x that), 24 bytes each plus the
+// sort keys of the task kernel.  It used to be 1/2 per base: 45 GB for a 2 Gbase batch of which 0.9 GB were used, which
+// kept a second long-read batch from being in flight on the same GPU.
+static u64 seg_pool_heuristic( u64 n_bases, u64 n_reads )
+{
+    return std::max<u64>( n_bases / 16 + 16 * n_reads, 1024 );
+}
+
 static int seed_tasks( ma_batch* b )
 {
     const u64 n = b->n_reads, nb = b->n_bases;
@@ -1575,7 +1633,7 @@ static int seed_tasks( ma_batch* b )
     if( levels >= MA_TASK_KEY_BITS / 2 )
         return 2;
     const u64 taskCap = nb / 16 + 2 * n + 1024;
-    b->segPoolCap = std::max( std::max<u64>( nb / 2 + 64 * n, 1024 ), b->segPoolMin );
+    b->segPoolCap = std::max( seg_pool_heuristic( nb, n ), b->segPoolMin );
     if( b->segOff.reserve( ( n + 1 ) * 8 ) || b->segCnt.reserve( ( n + 1 ) * 4 ) || b->taskA.reserve( taskCap * sizeof( SeedTask ) ) ||
         b->taskB.reserve( taskCap * sizeof( SeedTask ) ) || b->taskCnt.reserve( 64 * 8 ) ||
         b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
@@ -1680,9 +1738,9 @@ int ma_seed_batch( ma_batch* b )
     const bool smem = b->P.seeding_technique == 1;
     const u32 worst_cap = ( smem ? 6 : 2 ) * b->max_qlen + 8; // segments one read can emit at most
     const u32 smem_cap = smem ? b->max_qlen + 2 : 0;
-    b->segPoolCap = std::max<u64>( b->n_bases / 2 + 64 * n, 1024 );
+    b->segPoolCap = seg_pool_heuristic( b->n_bases, n );
     if( smem )
-        b->segPoolCap *= 2;
+        b->segPoolCap *= 4;
     // the pool size above is a heuristic (a read can emit up to 2x / 6x its length in segments): a batch that needs more
     // is seeded again with the counted need (segPoolMin, kept for the later batches of this object)
     b->segPoolCap = std::max( b->segPoolCap, b->segPoolMin );
@@ -2072,7 +2130,13 @@ int ma_dp_batch( ma_batch* b )
         S.cig = b->hctr[ CTR_MAX_CIG ];
         S.qlen = b->hctr[ CTR_MAX_QLEN ];
         for( int k = 0; k < KSW_N_CLASSES; k++ )
+        {
             S.cls[ k ] = b->hctr[ CTR_CLS0 + k ];
+            S.pc[ k ] = b->hctr[ CTR_MAX_PC0 + k ];
+            S.cigc[ k ] = b->hctr[ CTR_MAX_CIGC0 + k ];
+        }
+        S.pRedo = b->hctr[ CTR_MAX_P_REDO ];
+        S.cigRedo = b->hctr[ CTR_MAX_CIG_REDO ];
         // every wave of the ksw launches may leave one partly used 4096-word reservation per class launch
         b->cigPoolCap = std::max<u64>( 64 * nJobs + ( 1 << 20 ), b->n_bases / 2 ) + 4096ull * 256 * 32 * 4;
         b->cigPoolCap = std::max( b->cigPoolCap, b->cigPoolMin );
@@ -2105,7 +2169,7 @@ int ma_dp_batch( ma_batch* b )
             {
                 EvTimer t( b, 4 );
                 if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
-                                 b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ) ) )
+                                 b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ), (unsigned int*)( c + CTR_NEXT_BIG ) ) )
                     return 1;
                 MA_HIP( hipGetLastError( ) );
             }
@@ -2117,6 +2181,7 @@ int ma_dp_batch( ma_batch* b )
             MA_HIP( hipMemsetAsync( c + CTR_ERR, 0, ( CTR_KSW_JOBS - CTR_ERR + 1 ) * 8, b->stream ) ); // ERR, CIG_USED, CELLS, KSW_JOBS
             MA_HIP( hipMemsetAsync( c + CTR_PATH_BYTES, 0, 8, b->stream ) );
             MA_HIP( hipMemsetAsync( c + CTR_NEXT_SLOTS, 0, ( CTR_NEXT_SEED - CTR_NEXT_SLOTS ) * 8, b->stream ) ); // queues, N_REDO, CIG_WORDS
+            MA_HIP( hipMemsetAsync( c + CTR_NEXT_BIG, 0, 16, b->stream ) );
             MA_HIP( hipMemsetAsync( b->ez.p, 0, ( nSlots + 2 ) * sizeof( ma_ez ), b->stream ) );
         }
         if( check_err( b, "ma_dp_batch(ksw)" ) )
@@ -2381,6 +2446,36 @@ int ma_align_batch( ma_batch* b )
         if( stage[ k ]( b ) )
             return 1;
         b->hostMs[ k ] = std::chrono::duration<float, std::milli>( std::chrono::steady_clock::now( ) - t0 ).count( );
+    }
+    if( getenv( "MA_MEM_REPORT" ) ) // diagnostics: device bytes this batch holds after a full pass
+    {
+        struct Row
+        {
+            const char* name;
+            size_t cap;
+        };
+#define MA_ROW( x ) Row{ #x, b->x.cap }
+        std::vector<Row> rows = { MA_ROW( reads ), MA_ROW( roff ), MA_ROW( seedStack ), MA_ROW( seedRow ), MA_ROW( seedSteps ), MA_ROW( seedSeg ),
+            MA_ROW( hlocal ), MA_ROW( hdense ), MA_ROW( hseedCnt ), MA_ROW( hseedOff ), MA_ROW( stage ), MA_ROW( smemA ), MA_ROW( smemB ),
+            MA_ROW( segPool ), MA_ROW( segRead ), MA_ROW( segOff ), MA_ROW( segCnt ), MA_ROW( memsCnt ), MA_ROW( memsOff ), MA_ROW( taskA ),
+            MA_ROW( taskB ), MA_ROW( taskCnt ), MA_ROW( taskKey ), MA_ROW( taskKey2 ), MA_ROW( taskPerm ), MA_ROW( taskPerm2 ),
+            MA_ROW( segSeedCnt ), MA_ROW( segSeedOff ), MA_ROW( seedOff ), MA_ROW( seedCnt ), MA_ROW( seeds ), MA_ROW( cubTmp ), MA_ROW( cWork ),
+            MA_ROW( cMax ), MA_ROW( cMm ), MA_ROW( cA ), MA_ROW( cB ), MA_ROW( cOut ), MA_ROW( cSh1 ), MA_ROW( cSh2 ), MA_ROW( cVx ), MA_ROW( cVy ),
+            MA_ROW( cMed ), MA_ROW( cInl ), MA_ROW( cBest ), MA_ROW( hpool ), MA_ROW( setTab ), MA_ROW( nsets ), MA_ROW( hsetOff ),
+            MA_ROW( hsetFlat ), MA_ROW( hsetRead ), MA_ROW( jobs ), MA_ROW( info ), MA_ROW( ez ), MA_ROW( cigOff ), MA_ROW( cigPool ),
+            MA_ROW( kswScratch ), MA_ROW( clsLists ), MA_ROW( opsCap ), MA_ROW( opsOff ), MA_ROW( ops ), MA_ROW( hdr ), MA_ROW( order ),
+            MA_ROW( mqOrder ), MA_ROW( mqCnt ), MA_ROW( outCnt ), MA_ROW( outOps ), MA_ROW( outAlnOff ), MA_ROW( outOpsOff ), MA_ROW( outAlns ),
+            MA_ROW( outOpsPairs ) };
+#undef MA_ROW
+        std::sort( rows.begin( ), rows.end( ), []( const Row& a, const Row& c ) { return a.cap > c.cap; } );
+        size_t total = 0;
+        for( const Row& r : rows )
+            total += r.cap;
+        fprintf( stderr, "[ma_amd] batch of %llu reads / %llu bases holds %.2f GB on the device:", (unsigned long long)b->n_reads,
+                 (unsigned long long)b->n_bases, total / 1e9 );
+        for( size_t i = 0; i < rows.size( ) && i < 14; i++ )
+            fprintf( stderr, " %s %.2f", rows[ i ].name, rows[ i ].cap / 1e9 );
+        fprintf( stderr, "\n" );
     }
     return 0;
 }

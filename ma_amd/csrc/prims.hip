@@ -136,14 +136,23 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     if( FETCH::EARLY )
     {
         for( int k = 0; k < KSW_N_CLASSES; k++ )
-            S.cls[ k ] = 0;
+            S.cls[ k ] = S.pc[ k ] = S.cigc[ k ] = 0;
         lists.assign( (size_t)( KSW_N_CLASSES + 1 ) * n, 0u );
         for( uint64_t i = 0; i < n; i++ )
         {
-            if( jobs[ i ].qlen <= 0 || jobs[ i ].tlen <= 0 )
+            const i32 ql = jobs[ i ].qlen, tl = jobs[ i ].tlen;
+            if( ql <= 0 || tl <= 0 )
                 continue;
-            const int c = ksw_job_class_pipe( SC, jobs[ i ].qlen, jobs[ i ].tlen, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
+            const int c = ksw_job_class_pipe( SC, ql, tl, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
             lists[ (size_t)c * n + S.cls[ c ]++ ] = (u32)i;
+            const u64 pk = ksw_p_bytes( ql, tl, jobs[ i ].w ), cg = (u64)ql + tl + 2;
+            S.pc[ c ] = std::max( S.pc[ c ], c >= 5 ? ksw_ext_p_bytes( ql, tl, c - 4 ) : pk );
+            S.cigc[ c ] = std::max( S.cigc[ c ], cg );
+            if( c >= 5 )
+            {
+                S.pRedo = std::max( S.pRedo, pk );
+                S.cigRedo = std::max( S.cigRedo, cg );
+            }
         }
         if( dlists.reserve( lists.size( ) * 4 + 16 ) )
             return 1;
@@ -179,7 +188,7 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     F.qb = dq.as<uint8_t>( );
     F.tb = dt.as<uint8_t>( );
     if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0, FETCH::EARLY ? dlists.as<u32>( ) : nullptr, n,
-                     (unsigned int*)( ctr + 11 ) ) )
+                     (unsigned int*)( ctr + 11 ), (unsigned int*)( ctr + 12 ) ) )
         return 1;
     MA_HIP( hipDeviceSynchronize( ) );
     unsigned long long h[ 8 ];
