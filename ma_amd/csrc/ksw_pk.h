@@ -87,7 +87,10 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     const bool h16 = ksw_h16( SC, qlen, tlen );
     const i32 HL = h16 ? 8 : 4, HLs = h16 ? 3 : 2; // lanes of one SSE register of H, log2
     const bool LEFT = !( J.flag & KSW_EZ_RIGHT );
-    auto TH = [ & ]( i32 x ) -> i32 { return h16 ? (i32)(int16_t)x : x; };
+    // int16 wrap-around of the reference's 16-bit H as a shift pair with a wave-uniform amount (a select between x and
+    // its sign extension costs a v_bfe, a v_cndmask and the vcc shuffling around it)
+    const i32 hSh = __builtin_amdgcn_readfirstlane( h16 ? 16 : 0 );
+    auto TH = [ & ]( i32 x ) -> i32 { return (i32)( (u32)x << hSh ) >> hSh; };
     const i32 NEG = h16 ? -32768 : (i32)0x80000000;
     auto initOf = [ & ]( i32 r ) -> i32 {
         return (int8_t)( r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2 );
@@ -195,6 +198,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         }
         const i32 uInit = initOf( r );
         const bool initRow = en >= r; // kswcpp_core.h:580-585
+        const int initRowU = __builtin_amdgcn_readfirstlane( initRow ? 1 : 0 ); // only the first ~w diagonals: a scalar branch
         const i32 pEnd = st0 + ( ( en0 - st0 ) / 16 + 1 ) * 16; // score profile refreshes [st0, pEnd)
         const u32 profSt = pk_bcast_s( st0 ), profLen = pk_bcast_s( pEnd - st0 );
         const i32 qoff = qlen - 1 - r;
@@ -202,29 +206,54 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         cells += (u64)( en - st + 1 );
         const i32 hi = max( en, pEnd - 1 );
         const i32 en1 = st0 + ( ( ( en0 - st0 ) >> HLs ) << HLs );
-        const int b0 = st >> 7, j0 = b0 % R;
+        const int b0 = st >> 7, j0 = __builtin_amdgcn_readfirstlane( b0 % R );
+        const int nAct = __builtin_amdgcn_readfirstlane( ( hi >> 7 ) - b0 + 1 ); // ring slots from j0 on that hold touched cells
+        // wave-uniform access to ONE cell of the ring (t in [st, st + RING)): slot, then a lane read
+        auto slotOf = [ & ]( i32 t ) -> int {
+            int sl = j0 + ( ( t >> 7 ) - b0 );
+            return __builtin_amdgcn_readfirstlane( sl >= R ? sl - R : sl );
+        };
+        auto pickCell = [ & ]( const i32( &lo )[ R ], const i32( &hiH )[ R ], i32 t ) -> i32 {
+            const int sl = slotOf( t ), ln = ( t >> 1 ) & 63;
+            i32 v = 0;
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+                if( s == sl )
+                    v = lane_bcast( ( t & 1 ) ? hiH[ s ] : lo[ s ], ln );
+            return v;
+        };
+        auto pickByte = [ & ]( const u32( &A )[ R ], i32 t ) -> i32 { // int8 value of cell t of a packed difference vector
+            const int sl = slotOf( t ), ln = ( t >> 1 ) & 63;
+            u32 v = 0;
+#pragma unroll
+            for( int s = 0; s < R; s++ )
+                if( s == sl )
+                    v = (u32)lane_bcast( (i32)A[ s ], ln );
+            return ( t & 1 ) ? pk_hi8( v ) : pk_lo8( v );
+        };
         const int stLane = ( st >> 1 ) & 63; // cell st = low half of this lane of slot j0
         // previous-lane views (lane i <- lane i-1; lane 0 continues lane 63 of the previous slot of the ring)
         u32 px[ R ], pv[ R ], px2[ R ];
-        i32 ph[ R ];
 #pragma unroll
         for( int s = 0; s < R; s++ )
         {
             px[ s ] = lanes_ror1( X[ s ] );
             pv[ s ] = lanes_ror1( V[ s ] );
             px2[ s ] = lanes_ror1( X2[ s ] );
-            ph[ s ] = dpp_wave_ror1( Hhi[ s ] );
         }
-        i32 hEn0c = 0, hSt0c = 0; // owner-lane candidates
         i32 laneMax = (i32)0x80000000; // largest new H of this lane's cells in [st0, en0)
+        // query bases of all slots up front: the LDS latency (~100 cycles) is paid once per diagonal, not once per slot
+        // (30 % of the wave cycles of the long-read launches were spent parked on these loads)
+        u32 QB[ R ];
+#pragma unroll
+        for( int s = 0; s < R; s++ )
+            QB[ s ] = (u32)qr[ qoff + TT[ s ] ] | (u32)qr[ qoff + TT[ s ] + 1 ] << 16;
+        __builtin_amdgcn_sched_barrier( 0 );
 #pragma unroll
         for( int s = 0; s < R; s++ )
         {
             // wave-uniform skip of slots whose cells are all above the touched range
-            int dj = s - j0;
-            if( dj < 0 )
-                dj += R;
-            if( dj != 0 && ( ( b0 + dj ) << 7 ) > hi )
+            if( ( s >= j0 ? s - j0 : s - j0 + R ) >= nAct )
                 continue;
             const int sp = s == 0 ? R - 1 : s - 1;
             const i32 tt = TT[ s ]; // low cell; the high half is cell tt + 1
@@ -232,8 +261,6 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             u32 xt1 = cells_shift1( X[ s ], R == 1 ? px[ s ] : pk_bfi( M_LANE0, px[ sp ], px[ s ] ) );
             u32 vt1 = cells_shift1( V[ s ], R == 1 ? pv[ s ] : pk_bfi( M_LANE0, pv[ sp ], pv[ s ] ) );
             u32 x2t1 = cells_shift1( X2[ s ], R == 1 ? px2[ s ] : pk_bfi( M_LANE0, px2[ sp ], px2[ s ] ) );
-            i32 hupLo = R == 1 ? ph[ s ] : (i32)pk_bfi( M_LANE0, (u32)ph[ sp ], (u32)ph[ s ] );
-            const i32 hupHi = Hlo[ s ];
             if( s == j0 )
             {
                 // cell st takes the carry-in
@@ -241,20 +268,19 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                 xt1 = pk_bfi( m, x1, xt1 );
                 vt1 = pk_bfi( m, v1, vt1 );
                 x2t1 = pk_bfi( m, x21, x2t1 );
-                if( lane == stLane )
-                    hupLo = hBelow;
             }
             // first row / column initialisation of cell r
-            if( initRow && tt <= r && r <= tt + 1 )
+            if( initRowU )
             {
-                const u32 m = tt == r ? 0x0000ffffu : 0xffff0000u;
+                // cell r = half (r - tt) of the lane with tt <= r <= tt + 1
+                const u32 m = pk_opaque( tt == r ? 0x0000ffffu : ( tt + 1 == r ? 0xffff0000u : 0u ) );
                 Y[ s ] = pk_bfi( m, K_Y0, Y[ s ] );
                 Y2[ s ] = pk_bfi( m, K_Y20, Y2[ s ] );
                 U[ s ] = pk_bfi( m, pk_val( uInit, 0 ), U[ s ] );
             }
             // score profile of the cells in [st0, pEnd): match / mismatch, -e2 when either base is N
             {
-                const u32 b = (u32)qr[ qoff + tt ] | (u32)qr[ qoff + tt + 1 ] << 16;
+                const u32 b = QB[ s ];
                 const u32 isN = pk_lshr( T[ s ] | b, 2 );
                 const u32 differ = pk_min1( ( T[ s ] ^ b ) | isN, K_ONES );
                 u32 val = pk_mad( differ, K_NDIFF, K_MCH );
@@ -323,15 +349,12 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                 }
             }
             // ---- calcMaxScore pieces (kswcpp_core.h:156-299) with this diagonal's u / v
-            // (cells of [st0, en0] lie inside [st, en], so nu / nv are the committed values there)
-            const i32 ulo = pk_lo8( nu ), uhi = pk_hi8( nu ), vlo = pk_lo8( nv ), vhi = pk_hi8( nv );
-            // H[en0] = en0 > 0 ? Hold[en0-1] + u[en0] : Hold[en0] + v[en0]
-            if( tt == en0 )
-                hEn0c = TH( en0 > 0 ? hupLo + ulo : Hlo[ s ] + vlo );
-            if( tt + 1 == en0 )
-                hEn0c = TH( hupHi + uhi );
+            // (cells of [st0, en0] lie inside [st, en], so nu / nv are the committed values there).  Only the running H
+            // of the cells in [st0, en0) is advanced here; H[en0] and H[st0] belong to ONE lane of ONE slot each and
+            // are picked out of the registers after the loop with wave-uniform lane reads.
             if( r > 0 )
             {
+                const i32 vlo = pk_lo8( nv ), vhi = pk_hi8( nv );
                 if( tt >= st0 && tt < en0 )
                 {
                     Hlo[ s ] = TH( Hlo[ s ] + vlo );
@@ -343,27 +366,44 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                     laneMax = max( laneMax, Hhi[ s ] );
                 }
             }
-            if( tt == st0 )
-                hSt0c = Hlo[ s ];
-            if( tt + 1 == st0 )
-                hSt0c = Hhi[ s ];
             // keep the slots' instruction streams apart: interleaving them multiplies the live temporaries by R
             __builtin_amdgcn_sched_barrier( 0 );
         }
         i32 max_H, max_t, hEnd, hS;
         if( r > 0 )
         {
-            const i32 hEn0 = lane_bcast( hEn0c, ( en0 >> 1 ) & 63 );
-#pragma unroll
-            for( int s = 0; s < R; s++ )
+            // H[en0] = en0 > 0 ? Hold[en0-1] + u[en0] : Hold[en0] + v[en0].  Cell en0 - 1 was advanced above when it
+            // lies in [st0, en0): its old value is the new one minus this diagonal's v (16-bit wrap-around is a ring
+            // homomorphism, so TH commutes); below st it has left the ring and is the carry-in hBelow.
+            i32 hEn0;
+            if( en0 > 0 )
             {
-                if( TT[ s ] == en0 )
-                    Hlo[ s ] = hEn0;
-                if( TT[ s ] + 1 == en0 )
-                    Hhi[ s ] = hEn0;
+                const i32 c = en0 - 1;
+                i32 hOld = hBelow;
+                if( c >= st )
+                {
+                    hOld = pickCell( Hlo, Hhi, c );
+                    if( c >= st0 )
+                        hOld -= pickByte( V, c );
+                }
+                hEn0 = TH( hOld + pickByte( U, en0 ) );
+            }
+            else
+                hEn0 = TH( pickCell( Hlo, Hhi, 0 ) + pickByte( V, 0 ) );
+            {
+                const int sE = slotOf( en0 ), lE = ( en0 >> 1 ) & 63;
+#pragma unroll
+                for( int s = 0; s < R; s++ )
+                    if( s == sE )
+                    {
+                        if( en0 & 1 )
+                            Hhi[ s ] = lane == lE ? hEn0 : Hhi[ s ];
+                        else
+                            Hlo[ s ] = lane == lE ? hEn0 : Hlo[ s ];
+                    }
             }
             hEnd = hEn0;
-            hS = st0 == en0 ? hEn0 : lane_bcast( hSt0c, ( st0 >> 1 ) & 63 );
+            hS = st0 == en0 ? hEn0 : pickCell( Hlo, Hhi, st0 );
             // the exact (max_H, max_t) is only consumed when the diagonal raises ez.max or could z-drop (ksw_reg.h)
             max_H = (i32)0x80000000;
             max_t = 0;

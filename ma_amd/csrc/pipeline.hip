@@ -758,12 +758,13 @@ struct ChainKernelArgs
     u32 set_cap;
     u32* nsets; // per read
     unsigned long long* ctr;
+    u32 lanes; // reads per wavefront (lanes_per_wave)
 };
 
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4, 4 ) ) ) k_chain( ChainKernelArgs A )
 {
-    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
-    if( r >= A.n_reads )
+    const u32 r = blockIdx.x * A.lanes + threadIdx.x;
+    if( threadIdx.x >= A.lanes || r >= A.n_reads )
         return;
     const u64 off = A.seed_off[ r ];
     const u32 n = A.seed_cnt[ r ];
@@ -915,6 +916,7 @@ struct DpKernelArgs
     u32* lists;
     u64 list_stride;
     KswScoring SC;
+    u32 lanes; // sets per wavefront (lanes_per_wave)
 };
 
 #if defined( __HIPCC__ )
@@ -966,12 +968,12 @@ __device__ void dp_enum_one( const DpKernelArgs& A, u32 s, EnumSink& sink )
 
 __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
 {
-    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 s = blockIdx.x * A.lanes + threadIdx.x;
     EnumSink sink;
     sink.n = 0;
     sink.cap = 0;
     sink.slot0 = 0;
-    if( s < A.n_sets )
+    if( threadIdx.x < A.lanes && s < A.n_sets )
         dp_enum_one( A, s, sink );
     u32 pcl[ KSW_N_CLASSES ], cgl[ KSW_N_CLASSES ], pRedo = 0, cgRedo = 0;
     // append the jobs to the per-class lists: one atomic per wave, class and round instead of one per job
@@ -1189,13 +1191,14 @@ struct StitchKernelArgs
     u64* ops;
     AlnHeader* hdr;
     unsigned long long* ctr;
+    u32 lanes; // sets per wavefront (lanes_per_wave)
 };
 
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 ) ) ) k_stitch( StitchKernelArgs A )
 {
-    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 s = blockIdx.x * A.lanes + threadIdx.x;
     u64 nOps = 0;
-    if( s < A.n_sets )
+    if( threadIdx.x < A.lanes && s < A.n_sets )
     {
     const HSet hs = A.sets[ s ];
     const u32 rd = A.set_read[ s ];
@@ -1937,6 +1940,22 @@ static ChainParams chain_params( const ma_params& P )
     return C;
 }
 
+// Lanes of a wavefront that get a read / a seed set in the one-item-per-lane kernels (k_chain, k_dp_enum, k_stitch).
+// Their lanes run long data-dependent loops (std::sort emulation, RANSAC, the walk over the seeds of an alignment), so
+// the lanes of a wave diverge and are executed one after the other: a wave costs about the SUM of its lanes.  A batch
+// of 1 M short reads fills the machine with full waves; a batch of 20 k long reads is only 313 full waves on 1024
+// SIMDs, each serialising 64 lanes (50 kb reads: k_chain 545 ms).  Fewer items per wave spread the same lanes over
+// ~4 waves per SIMD.
+static u32 lanes_per_wave( u64 items )
+{
+    if( const char* e = getenv( "MA_LANES_PER_WAVE" ) ) // tuning hook
+        return (u32)std::min( 64, std::max( 1, atoi( e ) ) );
+    if( items >= 131072 )
+        return 64; // >= 2 full waves per SIMD: measured no gain from thinner waves (10 kb x 200 k reads)
+    const u64 waves = 256ull * 4 * 4;
+    return (u32)std::max<u64>( 1, std::min<u64>( 64, ( items + waves - 1 ) / waves ) );
+}
+
 int ma_chain_batch( ma_batch* b )
 {
     if( !b || b->stage_done < 2 )
@@ -1992,7 +2011,8 @@ int ma_chain_batch( ma_batch* b )
     A.ctr = b->ctr.as<unsigned long long>( );
     {
         EvTimer t( b, 2 );
-        hipLaunchKernelGGL( k_chain, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, A );
+        A.lanes = lanes_per_wave( n );
+        hipLaunchKernelGGL( k_chain, dim3( (unsigned)( ( n + A.lanes - 1 ) / A.lanes ) ), dim3( 64 ), 0, b->stream, A );
     }
     MA_HIP( hipGetLastError( ) );
     // CSR of sets per read: widen counts to u64 via a scan over u32->u64 transform
@@ -2115,7 +2135,8 @@ int ma_dp_batch( ma_batch* b )
         // zero-fill: a slot is a job iff q_to > q_from (pool regions of dropped sets stay empty)
         MA_HIP( hipMemsetAsync( b->ez.p, 0, ( nSlots + 2 ) * sizeof( ma_ez ), b->stream ) );
         MA_HIP( hipMemsetAsync( b->jobs.p, 0, ( nSlots + 2 ) * sizeof( DpJob ), b->stream ) );
-        hipLaunchKernelGGL( k_dp_enum, dim3( (unsigned)( ( nh + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, D );
+        D.lanes = 64; // this kernel's per-wave work is the list building, not the lanes' walks (50 kb: 8.6 ms full waves, 55 ms thin)
+        hipLaunchKernelGGL( k_dp_enum, dim3( (unsigned)( ( nh + D.lanes - 1 ) / D.lanes ) ), dim3( 64 ), 0, b->stream, D );
     }
     MA_HIP( hipGetLastError( ) );
     if( read_ctr( b ) || check_err( b, "ma_dp_batch(enumerate)" ) )
@@ -2220,7 +2241,8 @@ int ma_dp_batch( ma_batch* b )
         T.ops = b->ops.as<u64>( );
         T.hdr = b->hdr.as<AlnHeader>( );
         T.ctr = b->ctr.as<unsigned long long>( );
-        hipLaunchKernelGGL( k_stitch, dim3( (unsigned)( ( nh + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, T );
+        T.lanes = lanes_per_wave( nh );
+        hipLaunchKernelGGL( k_stitch, dim3( (unsigned)( ( nh + T.lanes - 1 ) / T.lanes ) ), dim3( 64 ), 0, b->stream, T );
         hipLaunchKernelGGL( k_finish, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, NP, (u32)n,
                             b->hsetOff.as<u64>( ), b->d_roff, b->hdr.as<AlnHeader>( ), b->ops.as<u64>( ),
                             b->order.as<u32>( ), b->mqOrder.as<u32>( ), b->mqCnt.as<u32>( ),
