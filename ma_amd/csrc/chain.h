@@ -12,6 +12,19 @@
 
 namespace ma
 {
+// phase cycle counters of the diagnostics build (-DMA_CHAIN_PROF, tools/chain_prof.py); run with MA_LANES_PER_WAVE=1 so
+// that a lane's clock does not include the turns of the other lanes of its wave
+#if defined( MA_CHAIN_PROF ) && defined( __HIPCC__ )
+static __device__ unsigned long long g_chain_prof[ 16 ];
+#endif
+#if defined( MA_CHAIN_PROF ) && defined( __HIP_DEVICE_COMPILE__ )
+#define CH_T( v ) const unsigned long long v = clock64( )
+#define CH_ADD( i, a, b ) atomicAdd( &g_chain_prof[ i ], ( b ) - ( a ) )
+#else
+#define CH_T( v )
+#define CH_ADD( i, a, b )
+#endif
+
 struct ChainParams
 {
     u32 max_num_soc, min_num_soc;
@@ -221,7 +234,56 @@ MA_HD void soc_push_no_overlap( const ma_seed* s, SoCEntry* mx, u32& nmx, SoCEnt
 }
 
 // StripOfConsiderationSeeds::execute; returns number of maxima (heap order, then rectangularSoC)
-MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm )
+// Sorting 40-byte seeds by one 64-bit key: the sort runs on (key, index) pairs and the seeds are permuted once.  The
+// permutation is the one std::sort produces on the seeds themselves -- its moves depend on comparison results only.
+struct KeyIdx
+{
+    u64 key;
+    u32 idx, pad;
+};
+struct KeyIdxLess
+{
+    MA_HD bool operator( )( const KeyIdx& a, const KeyIdx& b ) const
+    {
+        return a.key < b.key;
+    }
+};
+template <typename KEY> MA_HD void sort_seeds_by_key( ma_seed* s, u32 n, KeyIdx* ki, ma_seed* tmp, KEY key )
+{
+    for( u32 i = 0; i < n; i++ )
+    {
+        ki[ i ].key = key( s[ i ] );
+        ki[ i ].idx = i;
+    }
+    ss::sort( ki, (i64)n, KeyIdxLess( ) );
+    for( u32 i = 0; i < n; i++ )
+        tmp[ i ] = s[ ki[ i ].idx ];
+    for( u32 i = 0; i < n; i++ )
+        s[ i ] = tmp[ i ];
+}
+
+// seq_id_for_position with the contig of the previous query remembered: neighbouring seeds of a sweep lie on the same
+// contig, and the binary search over the contig table is five dependent loads
+struct SeqIdCache
+{
+    i64 lo = 1, hi = 0, id = 0; // [lo, hi) of absolute forward positions with that id
+    MA_HD i64 get( const IndexView& X, u64 pos )
+    {
+        const i64 iAbs = pos >= X.F ? (i64)( X.n - ( pos + 1 ) ) : (i64)pos;
+        if( iAbs >= lo && iAbs < hi )
+            return id;
+        id = seq_id_for_position( X, pos );
+        lo = (i64)X.cstart[ id ];
+        hi = id + 1 < (i64)X.n_contigs ? (i64)X.cstart[ id + 1 ] : (i64)0x7fffffffffffffffll;
+        if( iAbs < lo )
+            hi = lo; // below the first contig start: nothing to remember
+        return id;
+    }
+};
+
+// scratch of the keyed sorts (optional): ki1 / ki2 = n (key, index) pairs each, usable while mm / after mm is filled; tmp = n seeds
+MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm,
+                     KeyIdx* ki2 = nullptr, ma_seed* tmp = nullptr )
 {
     if( n == 0 )
         return 0;
@@ -229,15 +291,22 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
     if( P.genome_size_disable >= X.n )
         fMinLen = 0;
     const u64 strip = P.soc_width != 0 ? (u64)P.soc_width : ( (u64)P.match * (u64)qlen - (u64)P.gap ) / (u64)P.extend;
-    ss::sort( s, (i64)n, SeedByDelta( ) );
+    CH_T( c0 );
+    if( tmp && n >= 64 ) // short reads have a handful of seeds: not worth the two extra passes
+        sort_seeds_by_key( s, n, (KeyIdx*)mm, tmp, []( const ma_seed& x ) { return (u64)x.delta; } ); // mm is free until the rectangles
+    else
+        ss::sort( s, (i64)n, SeedByDelta( ) );
+    CH_T( c1 );
+    CH_ADD( 0, c0, c1 );
     u32 nmx = 0;
     SoCEntry cur;
     cur.accLen = 0, cur.amb = 0, cur.cnt = 0, cur.b = cur.e = 0;
     u32 S = 0, E = 0;
-    i64 cidE = seq_id_for_position( X, (u64)s[ 0 ].r_start );
+    SeqIdCache cacheS, cacheE;
+    i64 cidE = cacheE.get( X, (u64)s[ 0 ].r_start );
     while( E != n && S != n )
     {
-        const i64 cidS = seq_id_for_position( X, (u64)s[ S ].r_start );
+        const i64 cidS = cacheS.get( X, (u64)s[ S ].r_start );
         while( E != n && (u64)s[ S ].delta + strip >= (u64)s[ E ].delta && cidS == cidE )
         {
             cur.amb += s[ E ].ambiguity;
@@ -245,7 +314,7 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
             cur.accLen += (u64)s[ E ].len;
             E++;
             if( E != n )
-                cidE = seq_id_for_position( X, (u64)s[ E ].r_start );
+                cidE = cacheE.get( X, (u64)s[ E ].r_start );
         }
         if( (double)cur.accLen >= fMinLen )
             soc_push_no_overlap( s, mx, nmx, cur, S, E, (u64)fMinLen );
@@ -254,6 +323,8 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
         cur.cnt--;
         S++;
     }
+    CH_T( c2 );
+    CH_ADD( 1, c1, c2 );
     ss::make_heap( mx, (i64)nmx, SoCHeapOrder( ) );
     // rectangularSoC (soc.h:196-231)
     for( u32 k = 0; k < nmx; k++ )
@@ -267,7 +338,14 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
         mm[ k ].lo = lo;
         mm[ k ].hi = hi;
     }
-    ss::sort( s, (i64)n, SeedByRef( ) );
+    CH_T( c3 );
+    CH_ADD( 2, c2, c3 );
+    if( tmp && ki2 && n >= 64 )
+        sort_seeds_by_key( s, n, ki2, tmp, []( const ma_seed& x ) { return (u64)x.r_start; } );
+    else
+        ss::sort( s, (i64)n, SeedByRef( ) );
+    CH_T( c4 );
+    CH_ADD( 3, c3, c4 );
     for( u32 k = 0; k < nmx; k++ )
     {
         SoCEntry e;
@@ -285,6 +363,8 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
         e.e = it;
         mx[ k ] = e;
     }
+    CH_T( c5 );
+    CH_ADD( 4, c4, c5 );
     return nmx;
 }
 
@@ -320,16 +400,84 @@ MA_HD double delta_distance( const ma_seed& s, const double fAngle, const i64 rS
     return fabs( x - x_1 );
 }
 
-MA_HD double median_of( double* a, u32 n ) // test_ransac.h:21-40 (sorts its private copy)
+// k-th smallest of a[0..n) to a[k], everything before it <= a[k] (quickselect, median-of-three pivots)
+MA_HD void nth_select( double* a, i64 n, i64 k )
 {
-    ss::sort( a, (i64)n, DoubleLess( ) );
+    i64 lo = 0, hi = n - 1;
+    for( int round = 0; hi > lo; round++ )
+    {
+        if( hi - lo < 16 || round > 96 )
+        {
+            if( hi - lo >= 16 )
+                ss::sort( a + lo, hi - lo + 1, DoubleLess( ) ); // adversarial input: give up on linear time
+            else
+                for( i64 i = lo + 1; i <= hi; i++ )
+                {
+                    const double v = a[ i ];
+                    i64 j = i;
+                    for( ; j > lo && v < a[ j - 1 ]; j-- )
+                        a[ j ] = a[ j - 1 ];
+                    a[ j ] = v;
+                }
+            return;
+        }
+        const i64 mid = lo + ( hi - lo ) / 2;
+        auto order2 = [ & ]( i64 x, i64 y ) {
+            if( a[ y ] < a[ x ] )
+            {
+                const double t = a[ x ];
+                a[ x ] = a[ y ];
+                a[ y ] = t;
+            }
+        };
+        order2( lo, mid );
+        order2( lo, hi );
+        order2( mid, hi );
+        const double pivot = a[ mid ];
+        a[ mid ] = a[ hi - 1 ];
+        a[ hi - 1 ] = pivot;
+        i64 i = lo, j = hi - 1;
+        while( true )
+        {
+            while( a[ ++i ] < pivot )
+                ;
+            while( pivot < a[ --j ] )
+                ;
+            if( i >= j )
+                break;
+            const double t = a[ i ];
+            a[ i ] = a[ j ];
+            a[ j ] = t;
+        }
+        a[ hi - 1 ] = a[ i ];
+        a[ i ] = pivot;
+        if( k < i )
+            hi = i - 1;
+        else if( k > i )
+            lo = i + 1;
+        else
+            return;
+    }
+}
+
+// test_ransac.h:21-40 sorts a private copy and reads the middle element(s): order statistics, whatever the algorithm.
+// Selection instead of the full std::sort (the array is scratch here as well); 16 % of k_chain for 50 kb reads.
+MA_HD double median_of( double* a, u32 n )
+{
     if( n == 0 )
         return 0;
     if( n == 1 )
         return a[ 0 ];
+    const u32 k = n / 2;
+    nth_select( a, (i64)n, (i64)k );
     if( n % 2 == 0 )
-        return ( a[ n / 2 - 1 ] + a[ n / 2 ] ) / 2;
-    return a[ n / 2 ];
+    {
+        double below = a[ 0 ]; // a[n/2 - 1] of the sorted array = largest element before position k
+        for( u32 i = 1; i < k; i++ )
+            below = a[ i ] > below ? a[ i ] : below;
+        return ( below + a[ k ] ) / 2;
+    }
+    return a[ k ];
 }
 
 // run_ransac -> (angle, rStart as double); NaNs when no model was found
@@ -505,6 +653,7 @@ MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScr
             C.vY[ 3 * i + 2 ] = q + (double)len;
         }
         const u32 np = 3 * n;
+        CH_T( h0 );
         // medianAbsoluteDeviation (test_ransac.h:58-76)
         for( u32 i = 0; i < np; i++ )
             C.med[ i ] = C.vY[ i ];
@@ -516,7 +665,11 @@ MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScr
         }
         const double fMAD = median_of( C.med, np );
         double fAngle, fIcpt;
+        CH_T( h1 );
+        CH_ADD( 5, h0, h1 );
         run_ransac( C.vX, C.vY, np, fMAD, rng, C.inl, C.best, C.med, fAngle, fIcpt, lp );
+        CH_T( h2 );
+        CH_ADD( 6, h1, h2 );
         const i64 rStart = double_to_i64( fIcpt );
         // remove outliers (stable remove_if)
         u32 m = 0;
@@ -543,9 +696,13 @@ MA_HD_OUTLINE u32 harmonize_one( ma_seed* S, u32 n, ma_seed* out, const ChainScr
             C.sh1[ i ].b = (u64)S[ sd ].q_start + (u64)S[ sd ].len;
         }
         const u32 n3 = linesweep( C.sh1, n2, C.sh2, S, rStart, fAngle, lp );
+        CH_T( h3 );
+        CH_ADD( 7, h2, h3 );
         for( u32 i = 0; i < n3; i++ )
             out[ i ] = S[ C.sh2[ i ].seed ];
         ss::sort( out, (i64)n3, SeedByRefQ( ) );
+        CH_T( h4 );
+        CH_ADD( 8, h3, h4 );
         if( n3 <= 1 )
         {
             out[ 0 ] = S[ n / 2 ];
@@ -680,7 +837,8 @@ MA_HD u64 bump_alloc( unsigned long long* ctr, u64 n )
 MA_HD u32 chain_read( const IndexView& X, const ChainParams& P, const ChainScratch& C, u32 nSeeds, u32 qlen,
                       const ChainOut& O, u32& err )
 {
-    const u32 nmx0 = soc_sweep( X, P, C.work, nSeeds, qlen, C.maxima, C.mm );
+    CH_T( t0 );
+    const u32 nmx0 = soc_sweep( X, P, C.work, nSeeds, qlen, C.maxima, C.mm, (KeyIdx*)C.sh1, C.setA );
     u32 nmx = nmx0;
     GlibcRand rng;
     rng.init( P.rng_ring );
@@ -809,6 +967,13 @@ MA_HD u32 chain_read( const IndexView& X, const ChainParams& P, const ChainScrat
     if( heur )
         for( u32 ui = 0; ui < repeat && nsets > P.min_num_soc; ui++ )
             nsets--;
+    CH_T( t1 );
+    CH_ADD( 9, t0, t1 );
+#if defined( MA_CHAIN_PROF ) && defined( __HIP_DEVICE_COMPILE__ )
+    atomicAdd( &g_chain_prof[ 10 ], 1ull );
+    atomicAdd( &g_chain_prof[ 11 ], (unsigned long long)numTries );
+    atomicAdd( &g_chain_prof[ 12 ], (unsigned long long)nSeeds );
+#endif
     return nsets;
 }
 } // namespace ma

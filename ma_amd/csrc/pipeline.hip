@@ -2774,6 +2774,14 @@ int ma_batch_get_dp_jobs( ma_batch* b, uint64_t* n_jobs, int32_t* shapes /* 8 x 
     return 0;
 }
 
+#if defined( MA_CHAIN_PROF )
+int ma_debug_chain_prof( unsigned long long* out )
+{
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_chain_prof ), 16 * 8 ) );
+    return 0;
+}
+#endif
+
 #if defined( MA_KSW_PROF )
 int ma_debug_ksw_prof( unsigned long long* out )
 {
