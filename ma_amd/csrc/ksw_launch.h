@@ -443,10 +443,18 @@ inline KswLaunchPlan ksw_plan_launch( u64 p, u64 cigWords, u64 jobs, u64 wantWav
     L.waves = (u32)waves;
     return L;
 }
+// a second stream for the few huge jobs of a split class: they run beside the other launches (own scratch region)
+// instead of leaving a tail of a few long jobs at the end of the stage
+struct KswSide
+{
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+#define KSW_SIDE_WAVES 512u
 template <typename FETCH>
 int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
                  unsigned int* next, KswOut O, hipStream_t stream, u32* lists = nullptr, u64 list_stride = 0,
-                 unsigned int* nRedo = nullptr, unsigned int* nextBig = nullptr )
+                 unsigned int* nRedo = nullptr, unsigned int* nextBig = nullptr, const KswSide* side = nullptr )
 {
     auto al = []( u64 x ) { return ( x + 255 ) / 256 * 256; };
     u64 nJobs = 0;
@@ -489,13 +497,24 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         for( int k = 0; k < 4; k++ )
             LP[ 7 + k ] = ksw_plan_launch( SZ.pRedo ? SZ.pRedo : SZ.p, SZ.cigRedo ? SZ.cigRedo : SZ.cig, std::min<u64>( nExt, 256 * 4 ), wantWaves );
     u64 need = SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0;
+    u64 needSide = 0;
+    const bool useSide = side && side->stream;
     for( int k = 0; k < 15; k++ )
-        need = std::max<u64>( need, LP[ k ].stride * LP[ k ].waves );
+    {
+        if( k >= 11 && useSide && LP[ k ].waves )
+        {
+            LP[ k ].waves = std::min<u32>( LP[ k ].waves, KSW_SIDE_WAVES );
+            needSide = std::max<u64>( needSide, LP[ k ].stride * LP[ k ].waves );
+        }
+        else
+            need = std::max<u64>( need, LP[ k ].stride * LP[ k ].waves );
+    }
     // the per-wave scratch follows the largest jobs of the batch, which vary a lot from batch to batch for long
     // reads: once it is in the GB range take the whole budget so that later batches never re-allocate mid-step
     if( need > ( 2ull << 30 ) )
         need = std::max<u64>( need, KSW_SCRATCH_BUDGET );
-    if( scratch.reserve( need ) )
+    need = al( need );
+    if( scratch.reserve( need + needSide ) )
         return 1;
     const u32 ldsReg = std::max<u32>( (u32)( ( ( std::min<u64>( SZ.qlen, 150000 ) + 15 ) / 16 ) * 16 + 64 ), KSW_REG_LDS );
     if( ldsReg > 48 * 1024 )
@@ -507,20 +526,18 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     }
     uint8_t* base = scratch.as<uint8_t>( );
     u32* redo = lists ? lists + (u64)KSW_N_CLASSES * list_stride : nullptr;
-    if( SZ.cls[ 5 ] )
-        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), dim3( LP[ 5 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
-                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base, LP[ 5 ].stride, LP[ 5 ].p_cap, KSW_EXT_LDS,
-                            O, redo, nRedo );
-    if( SZ.cls[ 6 ] )
-        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), dim3( LP[ 6 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
-                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base, LP[ 6 ].stride, LP[ 6 ].p_cap, KSW_EXT_LDS,
-                            O, redo, nRedo );
-    // pass 0: the classes' own jobs; pass 1: whatever the extension kernel handed back (usually nothing); pass 2:
-    // the huge jobs of a class that was split
-    for( int pass = 0; pass < 3; pass++ )
+    // the huge jobs run from the start of the stage when they have their own stream and scratch region
+    if( useSide && needSide )
     {
+        MA_HIP( hipEventRecord( side->fork, stream ) );
+        MA_HIP( hipStreamWaitEvent( side->stream, side->fork, 0 ) );
+    }
+    auto launchPass = [ & ]( int pass ) -> int {
         if( pass == 1 && !nExt )
-            continue;
+            return 0;
+        const bool onSide = pass == 2 && useSide && needSide;
+        hipStream_t st = onSide ? side->stream : stream;
+        uint8_t* sbase = onSide ? base + need : base;
         auto launch = [ & ]( int k, auto kernel ) {
             const KswLaunchPlan& L = LP[ pass == 0 ? k : ( pass == 1 ? 7 + k : 11 + k ) ];
             if( L.waves == 0 )
@@ -534,29 +551,51 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
             JB.pMin = pass == 2 ? LP[ k ].pMax : 0;
             JB.pMax = L.pMax;
             unsigned int* nx = pass == 0 ? next + k : ( pass == 1 ? next + 7 + k : nextBig + k );
-            hipLaunchKernelGGL( kernel, dim3( L.waves ), dim3( 64 ), ldsReg, stream, F, SC, JB, nx, base, L.stride, L.p_cap, ldsReg, O );
+            hipLaunchKernelGGL( kernel, dim3( L.waves ), dim3( 64 ), ldsReg, st, F, SC, JB, nx, sbase, L.stride, L.p_cap, ldsReg, O );
         };
         launch( 0, k_ksw_pk<FETCH, KSW_S0> );
         launch( 1, k_ksw_pk<FETCH, KSW_S1> );
         launch( 2, k_ksw_pk<FETCH, KSW_S2> );
         launch( 3, k_ksw_pk<FETCH, KSW_S3> );
-        if( pass == 0 && SZ.cls[ 4 ] ) // a handed-back job always fits a register kernel
-        {
-            KswJobs JB;
-            JB.list = lists ? lists + (u64)4 * list_stride : nullptr;
-            JB.n = lists ? (u32)SZ.cls[ 4 ] : nSlots;
-            JB.nDev = nRedo;
-            JB.mode = lists ? 0 : 1;
-            JB.cls = 4;
-            JB.pMin = 0;
-            JB.pMax = ~0ull;
-            plan.ws.base = base;
-            if( plan.lds_bytes > 48 * 1024 )
-                MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)plan.lds_bytes ) );
-            hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, JB, next + 4,
-                                plan.ws, plan.lds_bytes, O );
-        }
+        return 0;
+    };
+    if( useSide && needSide )
+        launchPass( 2 );
+    if( SZ.cls[ 5 ] )
+        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), dim3( LP[ 5 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
+                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base, LP[ 5 ].stride, LP[ 5 ].p_cap, KSW_EXT_LDS,
+                            O, redo, nRedo );
+    if( SZ.cls[ 6 ] )
+        hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), dim3( LP[ 6 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
+                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base, LP[ 6 ].stride, LP[ 6 ].p_cap, KSW_EXT_LDS,
+                            O, redo, nRedo );
+    // pass 0: the classes' own jobs; pass 1: whatever the extension kernel handed back (usually nothing); pass 2:
+    // the huge jobs of a class that was split, unless they already run on the side stream
+    launchPass( 0 );
+    if( SZ.cls[ 4 ] ) // a handed-back job always fits a register kernel
+    {
+        KswJobs JB;
+        JB.list = lists ? lists + (u64)4 * list_stride : nullptr;
+        JB.n = lists ? (u32)SZ.cls[ 4 ] : nSlots;
+        JB.nDev = nRedo;
+        JB.mode = lists ? 0 : 1;
+        JB.cls = 4;
+        JB.pMin = 0;
+        JB.pMax = ~0ull;
+        plan.ws.base = base;
+        if( plan.lds_bytes > 48 * 1024 )
+            MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)plan.lds_bytes ) );
+        hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, JB, next + 4,
+                            plan.ws, plan.lds_bytes, O );
+    }
+    launchPass( 1 );
+    if( !( useSide && needSide ) )
+        launchPass( 2 );
+    if( useSide && needSide )
+    {
+        MA_HIP( hipEventRecord( side->join, side->stream ) );
+        MA_HIP( hipStreamWaitEvent( stream, side->join, 0 ) );
     }
     MA_HIP( hipGetLastError( ) );
     return 0;

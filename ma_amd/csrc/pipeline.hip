@@ -1346,6 +1346,7 @@ struct ma_batch
     DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, clsLists, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
     DevBuf outCnt, outOps, outAlnOff, outOpsOff, outAlns, outOpsPairs; // packed results (get_alns)
     u64 cigPoolCap = 0, cigPoolMin = 0, nOpsCap = 0, nJobSlots = 0;
+    KswSide kswSide; // created on first use
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
     bool timing = false;
     bool blocking = false; // batch_wait: sleep on an event instead of spinning
@@ -1464,6 +1465,12 @@ int ma_batch_destroy( ma_batch* b )
             (void)hipEventDestroy( b->ev[ i ] );
     if( b->waitEv )
         (void)hipEventDestroy( b->waitEv );
+    if( b->kswSide.stream )
+    {
+        (void)hipStreamDestroy( b->kswSide.stream );
+        (void)hipEventDestroy( b->kswSide.fork );
+        (void)hipEventDestroy( b->kswSide.join );
+    }
     delete b;
     return 0;
 }
@@ -2189,8 +2196,15 @@ int ma_dp_batch( ma_batch* b )
             O.cig_words = c + CTR_CIG_WORDS;
             {
                 EvTimer t( b, 4 );
+                if( !b->kswSide.stream && b->max_qlen > 20000 ) // only reads that long produce jobs for the second tier
+                {
+                    MA_HIP( hipStreamCreateWithFlags( &b->kswSide.stream, hipStreamNonBlocking ) );
+                    MA_HIP( hipEventCreateWithFlags( &b->kswSide.fork, hipEventDisableTiming ) );
+                    MA_HIP( hipEventCreateWithFlags( &b->kswSide.join, hipEventDisableTiming ) );
+                }
                 if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
-                                 b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ), (unsigned int*)( c + CTR_NEXT_BIG ) ) )
+                                 b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ), (unsigned int*)( c + CTR_NEXT_BIG ),
+                                 &b->kswSide ) )
                     return 1;
                 MA_HIP( hipGetLastError( ) );
             }
