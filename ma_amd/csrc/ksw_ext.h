@@ -507,7 +507,7 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         nCells += (u32)( en0 - st0 + 1 );
 #if defined( MA_EXP_SALU ) // experiment (tools/dp_bound_experiment.sh): which issue port bounds the loop?
         {
-            u32 t0 = (u32)r;
+            u32 t0 = (u32)__builtin_amdgcn_readfirstlane( r );
             asm volatile( "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
                           "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
                           : "+s"( t0 ) );
