@@ -143,7 +143,13 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     i32 hBelow = NEG; // H[st-1]: the only recycled cell that is read again (as H[en0-1] when en0 == st)
     const i32 nDiag = qlen + tlen - 1;
     bool stop = false;
-    const bool early = EARLY && ( J.flag & KSW_EZ_EXTZ_ONLY ) && qlen <= w + 1;
+    // early stop of pipeline extensions (ksw_reg.h).  Bands that cut the rectangle (qlen > w + 1: the long end extensions
+    // of long reads) are covered by the second part of the proof there; for them the bound is evaluated sparsely -- two
+    // consecutive diagonals out of 16, and only once the band has reached the last target column (before that a cell on
+    // the alignment's diagonal always has room left) -- because it costs about as much as 0.15 diagonals.
+    const bool early = EARLY && ( J.flag & KSW_EZ_EXTZ_ONLY );
+    const bool earlySparse = qlen > w + 1;
+    const i32 earlyFrom = earlySparse ? w + 3 : qlen; // first diagonal at which B_r and B_{r-1} cover every in-band chain
     i32 topH = 0, boundPrev = 0x7fffffff; // H(r-1,-1) of the first-row boundary; B_{r-1} (ksw_reg.h)
     for( i32 r = 0; r < nDiag && !stop; ++r )
     {
@@ -509,7 +515,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         }
         if( !stop && r == qlen + tlen - 2 && en0 == tlen - 1 )
             ez.score = hEnd;
-        if( EARLY && early && r >= qlen - 1 )
+        if( EARLY && early && r >= earlyFrom - 1 && ( !earlySparse || ( en0 == tlen - 1 && ( r & 15 ) <= 1 ) ) )
         {
             // early stop of pipeline extensions (proof in ksw_reg.h)
             i32 bnd = (i32)0x80000000;
@@ -523,8 +529,13 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                     bnd = max( bnd, Hhi[ s ] + sc_mch * min( qoff + tt + 1, tlen - 2 - tt ) );
             }
             bnd = wave_max_i32( bnd );
-            if( r >= qlen && max( max( bnd, boundPrev ), topH + sc_mch * qlen ) <= (i32)ez.max )
-                stop = true;
+            if( !earlySparse )
+            {
+                if( r >= qlen && max( max( bnd, boundPrev ), topH + sc_mch * qlen ) <= (i32)ez.max )
+                    stop = true;
+            }
+            else if( ( r & 15 ) == 1 && r >= earlyFrom && max( bnd, boundPrev ) <= (i32)ez.max )
+                stop = true; // boundPrev = B_{r-1} of the diagonal before (r & 15 == 0); no first-row chain starts after diagonal w + 1
             boundPrev = bnd;
         }
         topH += uInit; // H(r,-1)

@@ -55,5 +55,18 @@ __device__ __forceinline__ i32 wave_max_i32( i32 v )
 // B_d = max over cells (t, d-t) of diagonal d of  H + match * min(qlen-1-(d-t), tlen-1-t).
 // When that bound is <= ez.max the remaining diagonals cannot change max/max_q/max_t; the other ez
 // fields (mqe, mte, score, zdropped) are then unspecified, which is why ma_ksw_batch never uses EARLY.
+//
+// Bands that cut the rectangle (qlen > w+1; ksw_pk.h only).  The band [st0, en0] = [(r-w+1)>>1, (r+w)>>1] (clipped to the
+// rectangle) is a set of DP diagonals: st0(r) - 1 = st0(r-2) and en0(r) - 1 = en0(r-2), so the diagonal predecessor
+// (t-1, r-2) of an in-band cell (t, r) is in the band, or is a first-row / first-column boundary cell.  The H kswcpp
+// tracks for the cells of [st0, en0] -- H(t,r) = H(t,r-1) + v(t,r), and H(en0,r) = H(en0-1,r-1) + u(en0,r) for the cell
+// that enters -- satisfies H(t,r) = H(t-1,r-2) + z(t,r) there whatever stale values the cells at the band edge read from
+// outside the band (those only enter z through a, b, a2, b2, and z is clipped to <= match afterwards): with
+// u(t,r) = z - v(t-1,r-1) and v(t,r) = z - u(t,r-1), H(t-1,r-1) - v(t-1,r-1) = H(t-1,r-2) = H(t,r-1) - u(t,r-1), because
+// the v / u on both sides are the stored values of in-band cells.  A chain that starts at a boundary cell has offset
+// |t - q| <= w, i.e. its first cell lies on a diagonal <= w + 1.  Hence for r >= w + 3 every later in-band cell has its
+// chain pass through diagonal r or r-1 and  later H <= max( B_r, B_{r-1} ).  The row q = qlen-1 is made of later cells
+// as well, so mqe cannot exceed ez.max either and the back-trace starts at (max_t, max_q) as it does when the band runs
+// out (zdropped = 1, kswcpp_core.h:541-559).
 } // namespace ma
 #endif
