@@ -203,13 +203,13 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
 #endif
         u32 c = 0;
         const bool act = alive && L.phase != PH_DONE;
-        bool ext = act && seed_try( L, c );
+        bool ext = act && seed_try<true>( L, A.P, c );
         {
             // phase transitions are batched like the refills: run them when enough lanes wait for one (or nobody can step)
             const unsigned long long sm = __ballot( act && !ext );
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare( L, A.P, S, A.X, c );
+                    ext = seed_prepare<true>( L, A.P, S, A.X, c );
         }
 #if defined( MA_KSW_PROF )
         const unsigned long long tC = clock64( );
@@ -503,7 +503,7 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
             break;
         u32 c = 0;
         const bool act = alive && L.phase != PH_DONE;
-        bool ext = act && seed_try( L, c );
+        bool ext = act && seed_try( L, A.P, c );
         {
             const unsigned long long sm = __ballot( act && !ext );
             if( sm && ( (u32)__popcll( sm ) >= 4 || __ballot( ext ) == 0 ) )
@@ -1570,7 +1570,20 @@ static SeedParams seed_params( const ma_params& P )
     S.disable_heuristics = (u32)P.disable_heuristics;
     S.rel_min_seed_size_amount = P.rel_min_seed_size_amount;
     S.genome_size_disable = P.genome_size_disable;
+    S.window_begin = S.window_end = nullptr;
     return S;
+}
+// reads that stay in HBM are read through a 16-byte register window (seed_qbyte): the bounds of the reads array
+static void seed_window( SeedParams& S, const ma_batch* b, bool on )
+{
+    const u64 bytes = b->n_bases + ( b->reads_external ? 0 : 64 ); // the batch's own copy is padded
+    if( const char* e = getenv( "MA_SEED_WINDOW" ) ) // tuning hook
+        on = on && atoi( e ) != 0;
+    if( on && bytes >= 16 )
+    {
+        S.window_begin = b->d_reads;
+        S.window_end = b->d_reads + bytes;
+    }
 }
 
 static int seed_mems( ma_batch* b )
@@ -1805,6 +1818,7 @@ int ma_seed_batch( ma_batch* b )
             // reads up to 240 bases are staged in LDS (256 lanes x q_lds bytes <= 64 KB)
             const u32 qb = (u32)( ( b->max_qlen + 7 ) / 8 * 8 + 4 );
             A.q_lds = qb * 256 <= 64 * 1024 ? qb : 0;
+            seed_window( A.P, b, A.q_lds == 0 );
             // measured per 1 M x 150 bp reads: maxSpan 8.98 ms (1) / 8.56 (4) / 8.87 (8); SMEMs 114 ms (4) / 96 (8) / 96 (16) / 101 (32)
             A.slow_batch = A.P.technique == 0 ? 4 : 8;
             if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook

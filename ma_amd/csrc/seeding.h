@@ -16,6 +16,8 @@ struct SeedParams
     u32 disable_heuristics;
     double rel_min_seed_size_amount;
     u64 genome_size_disable;
+    const uint8_t* window_begin; // device kernels whose reads stay in HBM: the reads array, for seed_qbyte's 16-byte window
+    const uint8_t* window_end; // (null: off)
 };
 
 // Scratch a read needs while it is being seeded (lives in HBM, one slot per resident lane).
@@ -74,7 +76,48 @@ struct SeedLane
     // extended the lane stops and reports the two remaining areas instead of walking them itself
     u32 task_mode;
     u32 childS[ 2 ], childN[ 2 ]; // [0] left of the covered interval, [1] right of it; N == 0: none
+    // 16 read bytes in registers for reads that stay in HBM (seed_qbyte): a lane walks its read base by base, and one
+    // byte load per step is one 64-byte fabric request per step once the line has left L2 -- a third of the requests
+    // k_seed issued on 10 kb reads (431 GB of fetches for 299 GB of occ blocks)
+    u32 qwinLo;
+    u32 qw[ 4 ];
 };
+
+// base i of the lane's read.  P.window_begin / window_end (wave-uniform; null = off: the read is in LDS, or host code)
+// delimit the reads array: the 16 bytes are taken aligned, or flush with an end of the array where an aligned block
+// would leave it.
+template <bool WIN> MA_HD u32 seed_qbyte( SeedLane& L, const SeedParams& P, u32 i )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( WIN && P.window_end )
+    {
+        u32 d = i - L.qwinLo;
+        if( d >= 16u )
+        {
+            const uintptr_t a = (uintptr_t)( L.q + i );
+            uintptr_t base = a & ~(uintptr_t)15;
+            uint4 v;
+            if( base + 16 > (uintptr_t)P.window_end || base < (uintptr_t)P.window_begin )
+            {
+                // first / last bytes of the reads array: flush with its end, byte loads
+                if( base + 16 > (uintptr_t)P.window_end )
+                    base = (uintptr_t)P.window_end - 16;
+                if( base < (uintptr_t)P.window_begin )
+                    base = (uintptr_t)P.window_begin;
+                __builtin_memcpy( &v, (const void*)base, 16 );
+            }
+            else
+                v = *(const uint4*)base; // one global_load_dwordx4
+            L.qw[ 0 ] = v.x, L.qw[ 1 ] = v.y, L.qw[ 2 ] = v.z, L.qw[ 3 ] = v.w;
+            d = (u32)( a - base );
+            L.qwinLo = i - d;
+        }
+        const u32 lo = d & 8u ? L.qw[ 2 ] : L.qw[ 0 ], hi = d & 8u ? L.qw[ 3 ] : L.qw[ 1 ]; // selects, not a register index
+        return ( ( d & 4u ? hi : lo ) >> ( 8u * ( d & 3u ) ) ) & 0xffu;
+    }
+#endif
+    return L.q[ i ];
+}
 
 MA_HD u32 comp_base( u32 c ) // NucSeq::nucleotideComplement (nucSeq.h:524-532)
 {
@@ -104,6 +147,7 @@ MA_HD void seed_begin_read( SeedLane& L, const uint8_t* q, u32 qlen )
 {
     L.q = q;
     L.qlen = qlen;
+    L.qwinLo = 0x80000000u; // empty
     L.sp = 0;
     L.aS = 0;
     L.aN = qlen;
@@ -183,14 +227,14 @@ MA_HD bool seed_stop( const SeedParams& P, const i64 ok[ 3 ], const i64 ik[ 3 ] 
 // Can the lane extend right away, i.e. without any phase transition?  (The kernel batches the transitions of a
 // wavefront: a lane whose transition is due idles for a few steps until enough lanes wait, so that the divergent
 // bookkeeping of seed_prepare is executed once for many lanes instead of on every step for one or two.)
-MA_HD bool seed_try( const SeedLane& L, u32& c )
+template <bool WIN = false> MA_HD bool seed_try( SeedLane& L, const SeedParams& P, u32& c )
 {
     const bool right = L.phase == PH_P1_RIGHT || L.phase == PH_P2_RIGHT || L.phase == PH_SMEM_FWD;
     const bool left = L.phase == PH_P1_LEFT || L.phase == PH_P2_LEFT;
     const bool ok = right ? L.i < L.qlen : ( left && L.i != 0xffffffffu );
     if( ok )
     {
-        const u32 b = L.q[ L.i ];
+        const u32 b = seed_qbyte<WIN>( L, P, L.i );
         c = right ? comp_base( b ) : b;
     }
     return ok;
@@ -198,7 +242,7 @@ MA_HD bool seed_try( const SeedLane& L, u32& c )
 
 // ---- transitions (no index access) ----------------------------------------------------------
 // Runs cheap bookkeeping until the lane either needs an extension (returns true and sets c) or is done.
-MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
+template <bool WIN = false> MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
 {
     while( true )
     {
@@ -209,7 +253,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
             case PH_NEW_CENTER:
             {
                 L.center = L.aS + L.aN / 2;
-                const u32 qc = L.q[ L.center ];
+                const u32 qc = seed_qbyte<WIN>( L, P, L.center );
                 if( qc >= 4 )
                 { // N covers one position (binarySeeding.h:70-72 / 275-277)
                     seed_after_center( L, S, L.center, 1 );
@@ -240,7 +284,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
             case PH_P1_RIGHT:
                 if( L.i < L.qlen )
                 {
-                    c = comp_base( L.q[ L.i ] );
+                    c = comp_base( seed_qbyte<WIN>( L, P, L.i ) );
                     return true;
                 }
                 // end of query: switch direction (binarySeeding.h:118-120)
@@ -258,14 +302,14 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
             case PH_P1_LEFT:
                 if( L.i != 0xffffffffu )
                 {
-                    c = L.q[ L.i ];
+                    c = seed_qbyte<WIN>( L, P, L.i );
                     return true;
                 }
                 // record first segment and start the second pass (binarySeeding.h:152-163)
                 seed_emit( L, S, L.start, L.end - L.start, L.ik[ 0 ], L.ik[ 1 ], L.ik[ 2 ] );
                 L.s1_start = L.start;
                 L.s1_end = L.end;
-                init_interval( X, L.q[ L.center ], L.ik );
+                init_interval( X, seed_qbyte<WIN>( L, P, L.center ), L.ik );
                 L.start = L.center;
                 L.phase = PH_P2_LEFT;
                 L.i = L.center > 0 ? L.center - 1 : 0xffffffffu;
@@ -273,7 +317,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
             case PH_P2_LEFT:
                 if( L.i != 0xffffffffu )
                 {
-                    c = L.q[ L.i ];
+                    c = seed_qbyte<WIN>( L, P, L.i );
                     return true;
                 }
                 mswap( L.ik[ 0 ], L.ik[ 1 ] );
@@ -284,7 +328,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
             case PH_P2_RIGHT:
                 if( L.i < L.qlen )
                 {
-                    c = comp_base( L.q[ L.i ] );
+                    c = comp_base( seed_qbyte<WIN>( L, P, L.i ) );
                     return true;
                 }
                 {
@@ -303,7 +347,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
             case PH_SMEM_FWD:
                 if( L.i < L.qlen )
                 {
-                    c = comp_base( L.q[ L.i ] );
+                    c = comp_base( seed_qbyte<WIN>( L, P, L.i ) );
                     return true;
                 }
                 // forward phase over: reverse the list (binarySeeding.h:343) and go backwards
@@ -348,7 +392,7 @@ MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S,
                     L.ik[ 2 ] = s.sa_size;
                     L.curQStart = (u32)s.q_start;
                     L.curQSize = (u32)s.q_size;
-                    c = L.q[ L.i ];
+                    c = seed_qbyte<WIN>( L, P, L.i );
                     return true;
                 }
                 // end of one backward position: swap lists (binarySeeding.h:416-433)
