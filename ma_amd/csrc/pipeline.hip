@@ -1571,6 +1571,7 @@ static SeedParams seed_params( const ma_params& P )
     S.rel_min_seed_size_amount = P.rel_min_seed_size_amount;
     S.genome_size_disable = P.genome_size_disable;
     S.window_begin = S.window_end = nullptr;
+    S.smem_compact = 0;
     return S;
 }
 // reads that stay in HBM are read through a 16-byte register window (seed_qbyte): the bounds of the reads array
@@ -1819,6 +1820,9 @@ int ma_seed_batch( ma_batch* b )
             const u32 qb = (u32)( ( b->max_qlen + 7 ) / 8 * 8 + 4 );
             A.q_lds = qb * 256 <= 64 * 1024 ? qb : 0;
             seed_window( A.P, b, A.q_lds == 0 );
+            A.P.smem_compact = smem && b->max_qlen < 2048 && b->idx->v.n < ( 1ull << 35 ) ? 1 : 0;
+            if( const char* e = getenv( "MA_SMEM_COMPACT" ) ) // tuning / test hook
+                A.P.smem_compact = A.P.smem_compact && atoi( e ) != 0 ? 1 : 0;
             // measured per 1 M x 150 bp reads: maxSpan 8.98 ms (1) / 8.56 (4) / 8.87 (8); SMEMs 114 ms (4) / 96 (8) / 96 (16) / 101 (32)
             A.slow_batch = A.P.technique == 0 ? 4 : 8;
             if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook

@@ -16,8 +16,9 @@ struct SeedParams
     u32 disable_heuristics;
     double rel_min_seed_size_amount;
     u64 genome_size_disable;
-    const uint8_t* window_begin; // device kernels whose reads stay in HBM: the reads array, for seed_qbyte's 16-byte window
-    const uint8_t* window_end; // (null: off)
+    const uint8_t* window_begin = nullptr; // device kernels whose reads stay in HBM: the reads array, for seed_qbyte's 16-byte window
+    const uint8_t* window_end = nullptr; // (null: off)
+    u32 smem_compact = 0; // SMEM pending lists hold 16-byte entries (smem_put / smem_get): reads < 2048 bases, text < 2^35
 };
 
 // Scratch a read needs while it is being seeded (lives in HBM, one slot per resident lane).
@@ -122,6 +123,52 @@ template <bool WIN> MA_HD u32 seed_qbyte( SeedLane& L, const SeedParams& P, u32 
 MA_HD u32 comp_base( u32 c ) // NucSeq::nucleotideComplement (nucSeq.h:524-532)
 {
     return c < 4 ? 3 - c : 5;
+}
+
+// Entries of the SMEM pending lists (binarySeeding.h:296-433).  The lists live in HBM, one pair per resident lane, and
+// their traffic is as large as that of the occ blocks (Illumina preset: 99 GB of reads and 94 GB of writes per 1 M reads
+// beside 105 GB of occ blocks).  A 40-byte record straddles 64-byte lines; packed into 16 bytes -- three 35-bit interval
+// fields, two 11-bit query fields -- an entry is one aligned dwordx4 and four of them share a line.
+MA_HD void smem_put( const SeedParams& P, ma_segment* list, u32 idx, u32 qs, u32 qz, i64 a, i64 b, i64 c )
+{
+    if( P.smem_compact )
+    {
+        u64* w = (u64*)list + 2 * (u64)idx;
+        const u64 w0 = (u64)a | ( ( (u64)c & 0x1fffffffull ) << 35 );
+        const u64 w1 = (u64)b | ( ( (u64)c >> 29 ) << 35 ) | ( (u64)qs << 41 ) | ( (u64)qz << 52 );
+#if defined( __HIP_DEVICE_COMPILE__ )
+        *(ulonglong2*)w = make_ulonglong2( w0, w1 );
+#else
+        w[ 0 ] = w0, w[ 1 ] = w1;
+#endif
+    }
+    else
+    {
+        ma_segment s;
+        s.q_start = qs, s.q_size = qz, s.sa_start = a, s.sa_start_rc = b, s.sa_size = c;
+        list[ idx ] = s;
+    }
+}
+MA_HD ma_segment smem_get( const SeedParams& P, const ma_segment* list, u32 idx )
+{
+    if( P.smem_compact )
+    {
+        const u64* w = (const u64*)list + 2 * (u64)idx;
+#if defined( __HIP_DEVICE_COMPILE__ )
+        const ulonglong2 v = *(const ulonglong2*)w;
+        const u64 w0 = v.x, w1 = v.y;
+#else
+        const u64 w0 = w[ 0 ], w1 = w[ 1 ];
+#endif
+        ma_segment s;
+        s.sa_start = (i64)( w0 & 0x7ffffffffull );
+        s.sa_start_rc = (i64)( w1 & 0x7ffffffffull );
+        s.sa_size = (i64)( ( w0 >> 35 ) | ( ( ( w1 >> 35 ) & 0x3full ) << 29 ) );
+        s.q_start = (i64)( ( w1 >> 41 ) & 0x7ffull );
+        s.q_size = (i64)( ( w1 >> 52 ) & 0x7ffull );
+        return s;
+    }
+    return list[ idx ];
 }
 
 MA_HD void seed_emit( SeedLane& L, const SeedScratch& S, u32 start, u32 size, i64 a, i64 b, i64 c )
@@ -355,9 +402,9 @@ template <bool WIN = false> MA_HD bool seed_prepare( SeedLane& L, const SeedPara
                     ma_segment* cur = S.smem_a;
                     for( u32 a = 0, b = L.nCurr; a + 1 < b; a++, b-- )
                     {
-                        ma_segment t = cur[ a ];
-                        cur[ a ] = cur[ b - 1 ];
-                        cur[ b - 1 ] = t;
+                        const ma_segment t = smem_get( P, cur, a ), u = smem_get( P, cur, b - 1 );
+                        smem_put( P, cur, a, (u32)u.q_start, (u32)u.q_size, u.sa_start, u.sa_start_rc, u.sa_size );
+                        smem_put( P, cur, b - 1, (u32)t.q_start, (u32)t.q_size, t.sa_start, t.sa_start_rc, t.sa_size );
                     }
                     L.nPrev = L.nCurr;
                     L.nCurr = 0;
@@ -374,7 +421,7 @@ template <bool WIN = false> MA_HD bool seed_prepare( SeedLane& L, const SeedPara
                         // cannot extend backwards at all (binarySeeding.h:354, 437-448)
                         if( L.nPrev > 0 )
                         {
-                            const ma_segment& f = S.smem_a[ 0 ];
+                            const ma_segment f = smem_get( P, S.smem_a, 0 );
                             seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
                         }
                         seed_after_center( L, S, L.retS, L.retE - L.retS );
@@ -386,7 +433,7 @@ template <bool WIN = false> MA_HD bool seed_prepare( SeedLane& L, const SeedPara
                 ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
                 if( L.jPrev < L.nPrev )
                 {
-                    const ma_segment s = prev[ L.jPrev ];
+                    const ma_segment s = smem_get( P, prev, L.jPrev );
                     L.ik[ 0 ] = s.sa_start;
                     L.ik[ 1 ] = s.sa_start_rc;
                     L.ik[ 2 ] = s.sa_size;
@@ -416,7 +463,7 @@ template <bool WIN = false> MA_HD bool seed_prepare( SeedLane& L, const SeedPara
                 {
                     if( L.nPrev > 0 )
                     {
-                        const ma_segment& f = ( L.flip ? S.smem_b : S.smem_a )[ 0 ];
+                        const ma_segment f = smem_get( P, L.flip ? S.smem_b : S.smem_a, 0 );
                         seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
                     }
                     seed_after_center( L, S, L.retS, L.retE - L.retS );
@@ -461,11 +508,7 @@ MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, c
             ma_segment* cur = S.smem_a;
             auto push = [ & ]( u32 st, u32 sz, i64 a, i64 b, i64 c ) {
                 if( L.nCurr < S.smem_cap )
-                {
-                    ma_segment s;
-                    s.q_start = st, s.q_size = sz, s.sa_start = a, s.sa_start_rc = b, s.sa_size = c;
-                    cur[ L.nCurr ] = s;
-                }
+                    smem_put( P, cur, L.nCurr, st, sz, a, b, c );
                 else
                     L.err |= MA_ERR_SMEM_OVERFLOW;
                 L.nCurr++;
@@ -497,12 +540,7 @@ MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, c
             else if( ok[ 2 ] > (i64)P.min_amb || ( ok[ 2 ] > 0 && (u64)s.q_size >= (u64)P.max_amb ) )
             {
                 if( L.nCurr < S.smem_cap )
-                {
-                    ma_segment t;
-                    t.q_start = L.i, t.q_size = s.q_size + 1, t.sa_start = ok[ 0 ], t.sa_start_rc = ok[ 1 ],
-                    t.sa_size = ok[ 2 ];
-                    curr[ L.nCurr ] = t;
-                }
+                    smem_put( P, curr, L.nCurr, L.i, (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ] );
                 else
                     L.err |= MA_ERR_SMEM_OVERFLOW;
                 L.nCurr++;
