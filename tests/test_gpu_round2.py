@@ -299,3 +299,71 @@ def test_bench_two_ranks_partition_one_read_set(gpu_device):
     assert ws["aligned_reads"] == w1["aligned_reads"]
     # weak: rank 0 repeats the single process' reads, rank 1 adds as many others
     assert 1.9 * w1["aligned_reads"] < ww["aligned_reads"] < 2.1 * w1["aligned_reads"]
+
+
+def band_cut_extension_cases(n, seed):
+    """Extension jobs whose band cuts the DP rectangle (qlen > w + 1), shaped like the end extensions of long reads: the
+    query is a noisy copy of the (shorter) target followed by sequence that is not in the target, so the maximum sits at
+    the last target column and the rest of the band can only be left by the early stop or by running out of band."""
+    from ma_testlib import KSW_EXTZ, KSW_REV, KSW_RIGHT
+    rng = np.random.default_rng(seed)
+    cases = []
+    for k in range(n):
+        w = int(rng.choice([64, 128, 300, 512]))
+        tl = int(rng.integers(40, 1300))
+        ql = int(rng.integers(w + 2, w + 2 + 2500))
+        t = rng.integers(0, 4, size=tl, dtype=np.uint8)
+        kind = rng.random()
+        if kind < 0.15:  # tandem repeat target: late maxima are plausible
+            unit = rng.integers(0, 4, size=int(rng.integers(1, 7)), dtype=np.uint8)
+            t = np.tile(unit, tl // len(unit) + 1)[:tl].copy()
+        if kind < 0.8:
+            body = t.copy()
+            er = rng.choice([0.0, 0.01, 0.05, 0.15])
+            mut = rng.random(len(body)) < er
+            body[mut] = (body[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) % 4
+            for _ in range(int(rng.integers(0, 4))):  # a few indels
+                if len(body) > 20:
+                    p = int(rng.integers(5, len(body) - 5))
+                    if rng.random() < 0.5:
+                        body = np.concatenate([body[:p], body[p + int(rng.integers(1, 30)):]])
+                    else:
+                        body = np.concatenate([body[:p], rng.integers(0, 4, size=int(rng.integers(1, 30)), dtype=np.uint8), body[p:]])
+            q = np.concatenate([body, rng.integers(0, 4, size=max(0, ql - len(body)), dtype=np.uint8)])[:ql]
+            if len(q) < ql:
+                q = np.concatenate([q, rng.integers(0, 4, size=ql - len(q), dtype=np.uint8)])
+        else:  # unrelated
+            q = rng.integers(0, 4, size=ql, dtype=np.uint8)
+        if rng.random() < 0.1:
+            q[int(rng.integers(0, ql))] = 4
+        flag = KSW_EXTZ if k % 2 == 0 else (KSW_EXTZ | KSW_RIGHT | KSW_REV)
+        cases.append((np.ascontiguousarray(q, dtype=np.uint8), t, w, int(rng.choice([200, 200, 50, -1])), flag))
+    return cases
+
+
+@pytest.mark.parametrize("scoring", [None, (3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 24, 1, 4, 2)])
+def test_band_cut_extensions_stop_early_with_the_same_result(gpu_device, scoring):
+    """The early stop of ksw_pk for bands that cut the rectangle (ksw_reg.h, second part of the proof): pipeline semantics
+    against the exact kernel (which computes every diagonal) on max / max_q / max_t and the cigar, and against the
+    oracle's kswcpp for a sample."""
+    import ma_amd
+    from ma_testlib import or_ksw, or_params
+    P = ma_amd.Params.preset("default")
+    op = or_params()
+    if scoring is not None:
+        for prm in (P, op):
+            prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
+    cases = band_cut_extension_cases(240, 7 if scoring is None else 70 + scoring[0])
+    ez, cigs = ma_amd.ksw_batch(P, cases)
+    ez2, cigs2 = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
+    for i, (q, t, w, zd, fl) in enumerate(cases):
+        for f in ("max", "max_q", "max_t"):
+            assert int(ez2[f][i]) == int(ez[f][i]), "case %d field %s: %d vs %d (qlen %d tlen %d w %d zdrop %d flag %d)" % (
+                i, f, int(ez2[f][i]), int(ez[f][i]), len(q), len(t), w, zd, fl)
+        assert np.array_equal(cigs2[i], cigs[i]), "case %d cigar (qlen %d tlen %d w %d zdrop %d flag %d)" % (i, len(q), len(t), w, zd, fl)
+    for i in range(0, len(cases), 8):
+        q, t, w, zd, fl = cases[i]
+        oez, ocig = or_ksw(op, q, t, w, zd, fl)
+        for f in oez.dtype.names:
+            assert int(ez[f][i]) == int(oez[f]), "exact kernel vs oracle: case %d field %s" % (i, f)
+        assert np.array_equal(cigs[i], ocig)
