@@ -106,6 +106,9 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     // lane 0 continues lane 63 of the previous ring slot: a bit mask for ONE v_bitop3 per neighbour view (written as
     // lane == 0 ? px[sp] : px[s] the compiler indexes the register array dynamically: 4 v_cndmask per view for R = 5)
     const u32 M_LANE0 = pk_opaque( lane == 0 ? 0xffffffffu : 0u );
+    const u32 M_LEFT = pk_opaque( LEFT ? 0xffffffffu : 0u ), K_DX = pk_opaque( LEFT ? 0x00070007u : 0u ), K_DS = pk_opaque( LEFT ? 0x00030003u : 0u );
+    const u32 K_FX = pk_sub( K_TX, LEFT ? 0u : 0x00010001u ), K_FY = pk_sub( K_TY, LEFT ? 0u : 0x00010001u ),
+              K_FX2 = pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ), K_FY2 = pk_sub( K_TY2, LEFT ? 0u : 0x00010001u );
     const u32 K_ONES = pk_opaque( 0x00010001u );
 
     for( i32 t = lane; t < qrBytes; t += 64 )
@@ -304,18 +307,12 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                 u32 b = pk_add( Y[ s ], ut );
                 u32 a2 = pk_add( x2t1, vt1 );
                 u32 b2 = pk_add( Y2[ s ], ut );
-                u32 d;
-                if( LEFT )
-                {
-                    z = pk_max( pk_max( z, a ), pk_max( pk_max( b, a2 ), b2 ) );
-                    d = pk_sub( 0x00040004u, z & 0x00070007u );
-                }
-                else
-                {
-                    z = pk_max( pk_max( z, a ), pk_max( b, a2 ) );
-                    d = z & 0x00070007u;
-                    z = pk_max( z, b2 ); // state 4 is never recorded (kswcpp_core.h:693-699)
-                }
+                // LEFT: d = 4 - tag of max(s, a, b, a2, b2); RIGHT: d = tag of max(s, a, b, a2), state 4 is never recorded
+                // (kswcpp_core.h:693-699).  One instruction stream for both (the two variants as run-time branches cost ~20
+                // scalar instructions and four branches per slot): 4 - t = (t ^ 7) - 3 for a tag t in 0..7.
+                const u32 z4 = pk_max( pk_max( z, a ), pk_max( b, a2 ) );
+                z = pk_max( z4, b2 );
+                const u32 d = pk_sub( ( pk_bfi( M_LEFT, z, z4 ) & 0x00070007u ) ^ K_DX, K_DS );
                 const u32 zc = pk_min( z, K_CLIP ) & 0xff00ff00u;
                 nu = pk_sub( zc, vt1 );
                 nv = pk_sub( zc, ut );
@@ -327,22 +324,9 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                 b2 = pk_sub( b2, tmp );
                 const u32 nx = pk_sub( pk_max( a, K_TX ), K_QE ), ny = pk_sub( pk_max( b, K_TY ), K_QE );
                 const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), K_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), K_QE2 );
-                u32 fa, fb, fa2, fb2; // bit 15 of a half = continuation flag
-                if( LEFT )
-                {
-                    fa = pk_subsat( K_TX, a ); // a > 0
-                    fb = pk_subsat( K_TY, b );
-                    fa2 = pk_subsat( K_TX2, a2 );
-                    fb2 = pk_subsat( K_TY2, b2 );
-                }
-                else
-                {
-                    fa = ~pk_subsat( a, K_TX ); // !(a < 0)
-                    fb = ~pk_subsat( b, K_TY );
-                    fa2 = ~pk_subsat( a2, K_TX2 );
-                    fb2 = ~pk_subsat( b2, K_TY2 );
-                }
-                d = and_or( fa >> 12, 0x00080008u, and_or( fb >> 11, 0x00100010u, and_or( fa2 >> 10, 0x00200020u, and_or( fb2 >> 9, 0x00400040u, d ) ) ) );
+                // bit 15 of a half = continuation flag: LEFT a > 0, RIGHT !(a < 0) = a > -1 (the thresholds K_F*)
+                const u32 fa = pk_subsat( K_FX, a ), fb = pk_subsat( K_FY, b ), fa2 = pk_subsat( K_FX2, a2 ), fb2 = pk_subsat( K_FY2, b2 );
+                const u32 dd = and_or( fa >> 12, 0x00080008u, and_or( fb >> 11, 0x00100010u, and_or( fa2 >> 10, 0x00200020u, and_or( fb2 >> 9, 0x00400040u, d ) ) ) );
                 if( tt >= st && tt <= en ) // st is even, en odd: a lane is inside with both cells or not at all
                 {
                     U[ s ] = nu;
@@ -351,7 +335,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                     Y[ s ] = ny;
                     X2[ s ] = nx2;
                     Y2[ s ] = ny2;
-                    *(uint16_t*)( pr + tt ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
+                    *(uint16_t*)( pr + tt ) = (uint16_t)__builtin_amdgcn_perm( 0u, dd, 0x0c0c0200u );
                 }
             }
             // ---- calcMaxScore pieces (kswcpp_core.h:156-299) with this diagonal's u / v
@@ -539,6 +523,26 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                 stop = true; // boundPrev = B_{r-1} of the diagonal before (r & 15 == 0); no first-row chain starts after diagonal w + 1
             boundPrev = bnd;
         }
+#if defined( MA_EXP_SALU ) // experiment (tools/dp_bound_experiment.sh): which issue port bounds the loop?
+        {
+            u32 t0 = (u32)__builtin_amdgcn_readfirstlane( r );
+            asm volatile( "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
+                          "s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %0, %0, 1\n"
+                          : "+s"( t0 ) );
+            if( t0 == 0xdeadbeefu )
+                cells++;
+        }
+#endif
+#if defined( MA_EXP_VALU )
+        {
+            u32 t0 = U[ 0 ];
+            asm volatile( "v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n"
+                          "v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n v_pk_add_u16 %0, %0, %0\n"
+                          : "+v"( t0 ) );
+            if( t0 == 0xdeadbeefu )
+                cells++;
+        }
+#endif
         topH += uInit; // H(r,-1)
         last_st = st;
         last_en = en;
