@@ -154,6 +154,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     const bool earlySparse = qlen > w + 1;
     const i32 earlyFrom = earlySparse ? w + 3 : qlen; // first diagonal at which B_r and B_{r-1} cover every in-band chain
     i32 topH = 0, boundPrev = 0x7fffffff; // H(r-1,-1) of the first-row boundary; B_{r-1} (ksw_reg.h)
+    uint8_t* prow = P; // direction row of the current diagonal
     for( i32 r = 0; r < nDiag && !stop; ++r )
     {
         // ---- bounds (kswcpp_core.h:541-559)
@@ -211,7 +212,8 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         const i32 pEnd = st0 + ( ( en0 - st0 ) / 16 + 1 ) * 16; // score profile refreshes [st0, pEnd)
         const u32 profSt = pk_bcast_s( st0 ), profLen = pk_bcast_s( pEnd - st0 );
         const i32 qoff = qlen - 1 - r;
-        uint8_t* pr = P + (size_t)r * (size_t)n_col - st;
+        uint8_t* pr = prow - st; // P + r * n_col - st
+        prow += n_col;
         cells += (u64)( en - st + 1 );
         const i32 hi = max( en, pEnd - 1 );
         const i32 en1 = st0 + ( ( ( en0 - st0 ) >> HLs ) << HLs );
@@ -366,22 +368,48 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             // lies in [st0, en0): its old value is the new one minus this diagonal's v (16-bit wrap-around is a ring
             // homomorphism, so TH commutes); below st it has left the ring and is the carry-in hBelow.
             i32 hEn0;
-            if( en0 > 0 )
+            const int sE = slotOf( en0 ), lE = ( en0 >> 1 ) & 63;
+            if( ( en0 & 127 ) != 0 && en0 - 1 >= st )
             {
+                // the usual case: cells en0 - 1 and en0 sit in the same ring slot -- one pass over the slots reads the three
+                // registers involved and puts H[en0] in place (each separate pick is an R-way chain of scalar branches)
                 const i32 c = en0 - 1;
-                i32 hOld = hBelow;
-                if( c >= st )
-                {
-                    hOld = pickCell( Hlo, Hhi, c );
-                    if( c >= st0 )
-                        hOld -= pickByte( V, c );
-                }
-                hEn0 = TH( hOld + pickByte( U, en0 ) );
+                const int lC = ( c >> 1 ) & 63;
+                hEn0 = 0;
+#pragma unroll
+                for( int s = 0; s < R; s++ )
+                    if( s == sE )
+                    {
+                        i32 hOld = lane_bcast( ( c & 1 ) ? Hhi[ s ] : Hlo[ s ], lC );
+                        if( c >= st0 )
+                        {
+                            const u32 vC = (u32)lane_bcast( (i32)V[ s ], lC );
+                            hOld -= ( c & 1 ) ? pk_hi8( vC ) : pk_lo8( vC );
+                        }
+                        const u32 uE = (u32)lane_bcast( (i32)U[ s ], lE );
+                        hEn0 = TH( hOld + ( ( en0 & 1 ) ? pk_hi8( uE ) : pk_lo8( uE ) ) );
+                        if( en0 & 1 )
+                            Hhi[ s ] = lane == lE ? hEn0 : Hhi[ s ];
+                        else
+                            Hlo[ s ] = lane == lE ? hEn0 : Hlo[ s ];
+                    }
             }
             else
-                hEn0 = TH( pickCell( Hlo, Hhi, 0 ) + pickByte( V, 0 ) );
             {
-                const int sE = slotOf( en0 ), lE = ( en0 >> 1 ) & 63;
+                if( en0 > 0 )
+                {
+                    const i32 c = en0 - 1;
+                    i32 hOld = hBelow;
+                    if( c >= st )
+                    {
+                        hOld = pickCell( Hlo, Hhi, c );
+                        if( c >= st0 )
+                            hOld -= pickByte( V, c );
+                    }
+                    hEn0 = TH( hOld + pickByte( U, en0 ) );
+                }
+                else
+                    hEn0 = TH( pickCell( Hlo, Hhi, 0 ) + pickByte( V, 0 ) );
 #pragma unroll
                 for( int s = 0; s < R; s++ )
                     if( s == sE )
