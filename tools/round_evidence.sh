@@ -1,14 +1,29 @@
 #!/bin/bash
-# Everything the round's numbers come from, in one GPU call: parity tests, rocprofv3 evidence, the three bench lines.
-TAG=${1:-r01}
+# Everything the round's committed numbers come from, in one GPU call (≈30 min): parity tests, the driver's bench line and
+# the Illumina-preset line, rocprofv3 kernel stats + PMC passes of the four workloads, SQ counters of the 10 kb DP stage,
+# the launch timeline of a 50 kb step.  Copy what is to be judged from gpurun_out/ into profiles/ (profiles/README.md).
+#   usage: bash tools/round_evidence.sh [tag=r02]
+TAG=${1:-r02}
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_gpu_tests.txt
+export TMPDIR=/tmp
+python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/${TAG}_gpu_tests.txt
 cat gpurun_out/${TAG}_gpu_tests.txt
-bash tools/collect_profiles.sh $TAG > /dev/null 2>&1
-python bench.py 2> gpurun_out/${TAG}_bench_default.err | tail -1 > gpurun_out/${TAG}_bench_default.json
-python bench.py --read-len 10000 --sub 0.004 --ins 0.003 --dele 0.003 --steps 5 --warmup 1 2> gpurun_out/${TAG}_bench_10kb.err | tail -1 > gpurun_out/${TAG}_bench_10kb.json
-python bench.py --preset illumina --steps 5 --warmup 1 2> gpurun_out/${TAG}_bench_illumina.err | tail -1 > gpurun_out/${TAG}_bench_illumina.json
-for f in default 10kb illumina; do python3 -c "
-import json,sys
-j=json.load(open('gpurun_out/${TAG}_bench_$f.json')); c=j.get('cpu_baseline') or {}
-print('$f', j['value'], j['ms_per_step'], j['roofline']['frac'], (j['roofline'].get('valu_issue') or {}).get('frac'), c.get('value'), (c.get('parity_check') or {}).get('mismatching_reads'), (c.get('parity_check') or {}).get('reads'))"; done
+python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
+python bench.py --workload 150bp --preset illumina --boundary-reads 0 > gpurun_out/${TAG}_bench_illumina.json 2> gpurun_out/${TAG}_bench_illumina.err
+for wl in 150bp 10kb 50kb; do bash tools/collect_profiles.sh $TAG $wl > gpurun_out/collect_$wl.log 2>&1; done
+bash tools/collect_profiles.sh ${TAG}i 150bp illumina > gpurun_out/collect_illumina.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU \
+  -d gpurun_out/sq10 -o pmc --output-format csv -- python3 bench.py --workload 10kb --steps 1 --warmup 0 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/sq10.log 2>&1
+python3 tools/pmc_sq.py gpurun_out/sq10 k_ksw > gpurun_out/${TAG}_sq_counters_10kb_dp.txt; rm -rf gpurun_out/sq10
+rocprofv3 --kernel-trace -d gpurun_out/tr_50kb -o tr --output-format csv -- python3 bench.py --workload 50kb --steps 1 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/tr_50kb.log 2>&1
+python3 tools/launch_list.py gpurun_out/tr_50kb k_ksw k_chain k_stitch > gpurun_out/${TAG}_launch_timeline_50kb.txt; rm -rf gpurun_out/tr_50kb
+python3 - <<PY
+import json
+d = json.loads(open("gpurun_out/${TAG}_bench_default.json").read().strip().splitlines()[-1])
+print("value", d["value"], d["ms_per_step"])
+for w in d["config"]["workloads"]:
+    o = w.get("overlapped") or {}
+    c = (w.get("cpu_baseline") or {})
+    print(w["name"], w["value"], w["ms_per_step"], "overlapped", o.get("value"), "reference", c.get("value"),
+          "mismatching reads", (c.get("parity_check") or {}).get("mismatching_reads"), "of", (c.get("parity_check") or {}).get("reads"))
+PY
