@@ -161,13 +161,6 @@ def run_workload(E, name, wl, args):
     max_bases = int((offs_h[B::B] - offs_h[:-1:B]).max()) if K > 0 and B > 0 else 0
     NB = max(1, min(args.inflight, K))
     batches = []
-    for i in range(NB):
-        bt = ma_amd.Batch(E.idx, P, max(B, 1), max_bases + 64)
-        st = torch.cuda.current_stream() if NB == 1 else torch.cuda.Stream()
-        bt.set_stream(st.cuda_stream)
-        bt.enable_timing(True)
-        batches.append((bt, st))
-        E.live.append(bt)  # closed by the caller if this workload fails half-way
 
     def step(i, k):
         bt = batches[i][0]
@@ -177,9 +170,27 @@ def run_workload(E, name, wl, args):
         bt.align()
         bt.sync()
 
-    for w in range(W):  # warm-up: W steps on every batch object (each sizes its own buffers); untimed
+    setup_err = None
+    try:
         for i in range(NB):
-            step(i, (w + i) % K)
+            bt = ma_amd.Batch(E.idx, P, max(B, 1), max_bases + 64)
+            st = torch.cuda.current_stream() if NB == 1 else torch.cuda.Stream()
+            bt.set_stream(st.cuda_stream)
+            bt.enable_timing(True)
+            batches.append((bt, st))
+            E.live.append(bt)  # closed by the caller if this workload fails half-way
+        for w in range(W):  # warm-up: W steps on every batch object (each sizes its own buffers); untimed
+            for i in range(NB):
+                step(i, (w + i) % K)
+    except RuntimeError as e:  # e.g. not enough HBM for that many batches in flight
+        setup_err = e
+    # a rank that failed to set up must not leave the others waiting at the barrier: agree on the outcome first
+    failed = torch.tensor([0.0 if setup_err is None else 1.0], dtype=torch.float64, device=torch.device("cpu") if E.one_dev else dev)
+    if dist is not None:
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+    if float(failed.item()) > 0:
+        raise RuntimeError("setting up %d batch(es) of workload %s failed on %s: %s" % (
+            NB, name, "this rank" if setup_err is not None else "another rank", setup_err))
 
     acc = [dict(kms=np.zeros(8), ctr=np.zeros(8), segs=0, aligned=0, err=None) for _ in range(NB)]
 
