@@ -302,11 +302,11 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
     SoCEntry cur;
     cur.accLen = 0, cur.amb = 0, cur.cnt = 0, cur.b = cur.e = 0;
     u32 S = 0, E = 0;
-    SeqIdCache cacheS, cacheE;
-    i64 cidE = cacheE.get( X, (u64)s[ 0 ].r_start );
+    SeqIdCache cache; // both ends of the window: they are on the same contig nearly always
+    i64 cidE = cache.get( X, (u64)s[ 0 ].r_start );
     while( E != n && S != n )
     {
-        const i64 cidS = cacheS.get( X, (u64)s[ S ].r_start );
+        const i64 cidS = cache.get( X, (u64)s[ S ].r_start );
         while( E != n && (u64)s[ S ].delta + strip >= (u64)s[ E ].delta && cidS == cidE )
         {
             cur.amb += s[ E ].ambiguity;
@@ -314,7 +314,7 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
             cur.accLen += (u64)s[ E ].len;
             E++;
             if( E != n )
-                cidE = cacheE.get( X, (u64)s[ E ].r_start );
+                cidE = cache.get( X, (u64)s[ E ].r_start );
         }
         if( (double)cur.accLen >= fMinLen )
             soc_push_no_overlap( s, mx, nmx, cur, S, E, (u64)fMinLen );
