@@ -7,7 +7,8 @@ for r in csv.DictReader(open(sys.argv[1])):
     n = r["Kernel_Name"]
     if "k_" not in n and "rocprim" not in n and "hipcub" not in n:
         continue
-    m = re.search(r"(k_\w+)(<[^(]*?(\d)>)?\(", n)
+    # "void ma::k_ksw_pk<(anonymous namespace)::PipeFetch, 5>(...)": the template arguments contain parentheses themselves
+    m = re.search(r"(k_\w+)(<.*?, (\d)>)?\(", n.replace("(anonymous namespace)::", ""))
     name = (m.group(1) + ("<%s>" % m.group(3) if m and m.group(3) else "")) if m else "scan/prim"
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name, r.get("Queue_Id", "?"), r.get("Stream_Id", "?")))
 rows.sort()
