@@ -367,3 +367,45 @@ def test_band_cut_extensions_stop_early_with_the_same_result(gpu_device, scoring
         for f in oez.dtype.names:
             assert int(ez[f][i]) == int(oez[f]), "exact kernel vs oracle: case %d field %s" % (i, f)
         assert np.array_equal(cigs[i], ocig)
+
+
+@pytest.mark.parametrize("scoring,pacbio", [((3, 5, 6, 3, 30, 2), False), ((1, 3, 5, 2, 24, 1), True), (None, True)])
+def test_long_reads_other_scoring_and_pacbio_settings_vs_oracle(gpu_device, scoring, pacbio):
+    """Long reads (end extensions whose band cuts the rectangle -> sparse early stop; dual extensions between seeds;
+    thin-wave chaining) under non-default scoring and under the PacBio / Nanopore preset's settings (SMEM seeding, at least
+    5 strips, up to 100 supplementary alignments, parameter.h:1096-1104), on a 3.4 Mnt genome with repeats: every
+    NeedlemanWunsch alignment and every MappingQuality record against the oracle (which computes every diagonal)."""
+    import ma_amd
+    from ma_testlib import OrIndex, or_params
+    g = rand_genome(19, [1700000, 1100000, 600000], repeat_unit=300, repeat_copies=150, repeat_div=0.08)
+    reads = (sample_reads(g, 150, 150, 41, sub=0.01) + sample_reads(g, 10, 6000, 42, sub=0.005, ins=0.003, dele=0.003)
+             + sample_reads(g, 3, 25000, 43, sub=0.03, ins=0.03, dele=0.04) + sample_reads(g, 2, 12000, 44, sub=0.01, ins=0.01, dele=0.01))
+    gidx = ma_amd.Index.build(g)
+    oidx = OrIndex.from_parts(gidx.download())
+    P = ma_amd.Params.preset("default")
+    op = or_params("default", 1)
+    for prm in (P, op):
+        if scoring is not None:
+            prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
+        if pacbio:
+            prm.max_supplementary, prm.min_num_soc, prm.seeding_technique = 100, 5, 1
+        prm.srand_seed = 1
+    b = ma_amd.Batch(gidx, P, len(reads), sum(len(r) for r in reads) + 64)
+    b.set_reads(reads)
+    b.align()
+    b.sync()
+    res = oidx.align(reads, op, threads=8)
+    aoff, alns, ops = b.alignments()
+    assert np.array_equal(aoff, res["aln_off"])
+    for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops"):
+        assert np.array_equal(alns[f], res["alns"][f]), f
+    for ga, oa in zip(alns, res["alns"]):
+        assert np.array_equal(ops[2 * int(ga["ops_off"]):2 * int(ga["ops_off"] + ga["n_ops"])],
+                              res["ops"][2 * int(oa["ops_off"]):2 * int(oa["ops_off"] + oa["n_ops"])])
+    moff, malns, _ = b.mapq_alignments()
+    assert np.array_equal(moff, res["mq_off"])
+    for f in ("begin_ref", "end_ref", "score", "secondary", "supplementary"):
+        assert np.array_equal(malns[f], res["mq"][f]), f
+    assert np.array_equal(malns["mapq"].view(np.uint64), res["mq"]["mapq"].view(np.uint64))
+    assert len(alns) >= len(reads) - 5
+    gidx.close()
