@@ -409,3 +409,51 @@ def test_long_reads_other_scoring_and_pacbio_settings_vs_oracle(gpu_device, scor
     assert np.array_equal(malns["mapq"].view(np.uint64), res["mq"]["mapq"].view(np.uint64))
     assert len(alns) >= len(reads) - 5
     gidx.close()
+
+
+@pytest.mark.parametrize("shift", [0, 5, 11])
+def test_reads_in_a_caller_owned_device_array_without_padding(gpu_device, shift):
+    """ma_batch_set_reads_device with long reads in an unaligned, unpadded device array: the seeding kernels read such
+    reads through a 16-byte register window that must stay inside [codes, codes + n_bases) at both ends of the array."""
+    import torch
+    import ma_amd
+    g = rand_genome(23, [900000, 400000], repeat_unit=300, repeat_copies=60, repeat_div=0.08)
+    reads = sample_reads(g, 5, 3000, 51, sub=0.01, ins=0.003, dele=0.003) + sample_reads(g, 3, 700, 52, sub=0.01) + \
+        sample_reads(g, 1, 17, 53) + sample_reads(g, 2, 5000, 54, sub=0.02)
+    gidx = ma_amd.Index.build(g)
+    P = ma_amd.Params.preset("default")
+    nb = sum(len(r) for r in reads)
+    ref = ma_amd.Batch(gidx, P, len(reads), nb + 64)
+    ref.set_reads(reads)
+    ref.align()
+    ref.sync()
+    want = ref.alignments()
+    want_segs = ref.segments()
+    # poison around the array: bytes outside [shift, shift + nb) must never influence the result
+    host = np.full(nb + shift + 40, 3, dtype=np.uint8)
+    host[shift:shift + nb] = np.concatenate(reads)
+    dev = torch.from_numpy(host).cuda()
+    offs = torch.from_numpy(np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)).cuda()
+    for technique in (0, 1):
+        P.seeding_technique = technique
+        b0 = ma_amd.Batch(gidx, P, len(reads), nb + 64)
+        b0.set_reads(reads)
+        b0.align()
+        b0.sync()
+        b = ma_amd.Batch(gidx, P, len(reads), nb + 64)
+        b.set_reads_device(dev.data_ptr() + shift, offs.data_ptr(), len(reads), nb)
+        b.align()
+        b.sync()
+        for x, y in zip(b.segments(), b0.segments()):
+            assert np.array_equal(x, y)
+        for x, y in zip(b.alignments(), b0.alignments()):
+            assert np.array_equal(x, y)
+        if technique == 0:
+            for x, y in zip(b.alignments(), want):
+                assert np.array_equal(x, y)
+            for x, y in zip(b.segments(), want_segs):
+                assert np.array_equal(x, y)
+        b.close()
+        b0.close()
+    ref.close()
+    gidx.close()
