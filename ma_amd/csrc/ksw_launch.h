@@ -425,7 +425,17 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
 // full set of waves is run as two launches: the jobs that fit a full set, then the few huge ones on fewer waves.
 #define KSW_REG_LDS 6144u // per-wave LDS of the exact register kernels: reversed query, later the back-trace staging block
 #define KSW_EXT_LDS 4096u // extension kernel: back-trace staging only (8 waves per SIMD fit)
-#define KSW_SCRATCH_BUDGET ( 24ull << 30 )
+// per-wave scratch of all resident waves of a launch may take this much HBM (MA_KSW_SCRATCH_MB: test hook that makes small
+// batches take the paths of the large ones -- fewer waves, classes split in two launches, the side stream)
+inline u64 ksw_scratch_budget( )
+{
+    static const u64 budget = []( ) -> u64 {
+        const char* e = getenv( "MA_KSW_SCRATCH_MB" );
+        return e && atoi( e ) > 0 ? (u64)atoi( e ) << 20 : 24ull << 30;
+    }( );
+    return budget;
+}
+#define KSW_SCRATCH_BUDGET ksw_scratch_budget( )
 struct KswLaunchPlan
 {
     u64 p_cap = 0, stride = 0, pMax = ~0ull; // pMax: largest job scratch this launch takes

@@ -457,3 +457,27 @@ def test_reads_in_a_caller_owned_device_array_without_padding(gpu_device, shift)
         b0.close()
     ref.close()
     gidx.close()
+
+
+def test_dp_scratch_budget_paths(gpu_device):
+    """The launch planning of the DP stage (ksw_launch.h): with a small scratch budget a modest batch takes the paths of a
+    large long-read batch -- fewer waves per launch, classes split into two launches by job size, the huge jobs on the side
+    stream with their own scratch region.  Same alignments as with the default budget."""
+    import sys
+    probe = os.path.join(ROOT, "tests", "gpu_probe_dp_budget.py")
+
+    def run(mb):
+        env = dict(os.environ)
+        env.pop("MA_KSW_SCRATCH_MB", None)
+        if mb:
+            env["MA_KSW_SCRATCH_MB"] = str(mb)
+        out = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1].split()
+        return line[1], int(line[2])
+
+    want, n = run(0)
+    assert n >= 300
+    for mb in (256, 40):
+        got, m = run(mb)
+        assert (got, m) == (want, n), "scratch budget %d MB" % mb
