@@ -481,3 +481,41 @@ def test_dp_scratch_budget_paths(gpu_device):
     for mb in (256, 40):
         got, m = run(mb)
         assert (got, m) == (want, n), "scratch budget %d MB" % mb
+
+
+@pytest.mark.parametrize("env", [{"MA_SEED_TASKS": "0"}, {"MA_SEED_TASKS": "0", "MA_SEED_WINDOW": "0"}, {"MA_SEED_TASKS": "1"},
+                                 {"MA_LANES_PER_WAVE": "64"}, {"MA_LANES_PER_WAVE": "1"}, {"MA_LANES_PER_WAVE": "7"},
+                                 {"MA_SMEM_COMPACT": "0", "technique": "1"}, {"technique": "1"}])
+def test_kernel_variants_give_identical_results(gpu_device, monkeypatch, env):
+    """The variants a batch's shape selects between -- read-per-lane vs area-per-lane maxSpan seeding, the register window
+    on the read, full vs thin waves in the one-item-per-lane kernels, 16- vs 40-byte SMEM list entries -- forced through
+    their environment hooks on one mixed read set: every stage record equals the default choice's."""
+    import ma_amd
+    g = rand_genome(31, [1200000, 500000], repeat_unit=300, repeat_copies=60, repeat_div=0.08)
+    reads = (sample_reads(g, 400, 150, 71, sub=0.01) + sample_reads(g, 8, 5000, 72, sub=0.005, ins=0.003, dele=0.003)
+             + sample_reads(g, 2, 16000, 73, sub=0.03, ins=0.02, dele=0.02) + sample_reads(g, 30, 1000, 74, sub=0.02))
+    env = dict(env)
+    technique = int(env.pop("technique", "0"))
+    if env.get("MA_SMEM_COMPACT") == "0" or technique == 1:
+        reads = [r for r in reads if len(r) < 2000]  # the packed entries are for reads < 2048 bases
+    idx = ma_amd.Index.build(g)
+
+    def run():
+        P = ma_amd.Params.preset("default")
+        P.seeding_technique = technique
+        b = ma_amd.Batch(idx, P, len(reads), sum(len(r) for r in reads) + 64)
+        b.set_reads(reads)
+        b.align()
+        b.sync()
+        out = [b.segments(), b.seeds(), b.hsets(), b.alignments(), b.mapq_alignments()]
+        b.close()
+        return out
+
+    want = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = run()
+    for gs, ws in zip(got, want):
+        for x, y in zip(gs, ws):
+            assert np.array_equal(x, y)
+    idx.close()
