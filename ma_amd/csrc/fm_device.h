@@ -153,17 +153,24 @@ MA_HD i64 inv_psi( const IndexView& x, i64 k )
     return (i64)( l2c + cc );
 }
 
+// SA value of a sampled row (k a multiple of the sampling interval in use)
+MA_HD i64 sa_sample( const IndexView& x, i64 k )
+{
+    return ( x.sa_dense ? x.sa_dense : x.sa )[ k >> x.sa_shift ];
+}
+
 // bwt_sa (fMIndex.h:788-814)
 MA_HD i64 bwt_sa( const IndexView& x, i64 k, u32& steps )
 {
     i64 s = 0;
-    while( k & 31 )
+    const i64 mask = ( (i64)1 << x.sa_shift ) - 1;
+    while( k & mask )
     {
         ++s;
         k = inv_psi( x, k );
     }
     steps = (u32)s;
-    return s + x.sa[ k >> 5 ];
+    return s + sa_sample( x, k );
 }
 
 // ---- Pack helpers (pack.h:900-1087) ----

@@ -1,7 +1,9 @@
 // index.hip -- index handle: upload / download of the FMD-index + pack (FMIndex::vLoadFMIndex
 // fMIndex.h:555-663, Pack::vLoadCollection pack.h:271-470 replaced by ma_index_create), runtime helpers.
 #include "internal.h"
+#include "fm_device.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -130,6 +132,53 @@ void ma_params_illumina( ma_params* p )
     p->max_num_soc = 20;
 }
 
+extern "C++" {
+// Dense SA sample (every 2^shift-th row) out of the reference's every-32nd one: each dense row that is not in
+// the sparse sample walks LF steps until it hits one (one-off, ~1 s for GRCh38).  MA_SA_DENSE=0 keeps the sparse sample.
+__global__ void k_sa_densify( ma::IndexView X, u64 n_dense, i64* dense, u32 shift )
+{
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( j >= n_dense )
+        return;
+    i64 k = (i64)( j << shift ), s = 0;
+    while( k & 31 )
+    {
+        k = ma::inv_psi( X, k );
+        ++s;
+    }
+    dense[ j ] = j == 0 ? (i64)-1 : s + X.sa[ k >> 5 ];
+}
+namespace ma
+{
+// log2 of the dense sample's interval: 3 (every 8th row) by default; MA_SA_DENSE=0 keeps the sparse sample only,
+// MA_SA_DENSE=1..4 choose another interval (tuning hook: 2 = 12.4 GB for GRCh38)
+u32 sa_dense_shift( )
+{
+    const char* e = getenv( "MA_SA_DENSE" );
+    if( !e )
+        return 3;
+    const int v = atoi( e );
+    return v <= 0 ? 0u : (u32)( v > 4 ? 4 : v );
+}
+// x->v must be complete (sparse sample, bwt, L2, primary) and x->v.sa_dense null
+int index_densify( ma_index* x )
+{
+    const u32 shift = sa_dense_shift( );
+    if( shift == 0 )
+        return 0;
+    const u64 nd = ( x->v.n + ( 1ull << shift ) ) >> shift;
+    if( x->saDense.reserve( nd * 8 ) )
+        return 1;
+    hipLaunchKernelGGL( k_sa_densify, dim3( (unsigned)( ( nd + 255 ) / 256 ) ), dim3( 256 ), 0, 0, x->v, nd, x->saDense.as<i64>( ), shift );
+    MA_HIP( hipGetLastError( ) );
+    MA_HIP( hipDeviceSynchronize( ) );
+    x->v.sa_dense = x->saDense.as<i64>( );
+    x->v.sa_shift = shift;
+    return 0;
+}
+} // namespace ma
+} // extern "C++"
+
 int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t* sa, uint64_t n_sa,
                      const uint64_t L2[ 5 ], int64_t primary, uint64_t ref_len, const uint8_t* pac, int32_t n_contigs,
                      const uint64_t* contig_starts, const uint64_t* contig_lens, ma_index** out )
@@ -162,6 +211,8 @@ int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t*
     for( int i = 0; i < 5; i++ )
         x->v.L2[ i ] = L2[ i ];
     x->v.n_contigs = n_contigs;
+    if( ma::index_densify( x.get( ) ) )
+        return 1;
     *out = x.release( );
     return 0;
 }
@@ -173,6 +224,7 @@ int ma_index_destroy( ma_index* x )
     MA_BIND_DEVICE( x->device );
     x->bwt.release( );
     x->sa.release( );
+    x->saDense.release( );
     x->pac.release( );
     x->cstart.release( );
     x->clen.release( );

@@ -254,12 +254,12 @@ __global__ void k_bwt_assemble( const u32* words, const u64* cA, const u64* cC, 
         o[ 8 + k ] = words[ blk * 8 + k ];
 }
 
-__global__ void k_sa_samples( const i64* SA, u64 n, u64 nsa, i64* out )
+__global__ void k_sa_samples( const i64* SA, u64 n, u64 nsa, i64* out, u32 shift = 5 )
 {
     const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if( j >= nsa )
         return;
-    out[ j ] = j == 0 ? (i64)-1 : SA[ 32 * j - 1 ];
+    out[ j ] = j == 0 ? (i64)-1 : SA[ ( j << shift ) - 1 ];
 }
 
 struct MaxOp
@@ -526,7 +526,16 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
     MA_HIP( hipMemset( x->bwt.p, 0, x->n_words * 4 + 128 ) );
     hipLaunchKernelGGL( k_bwt_assemble, GRID( nblk + 1 ), 0, 0, words.as<u32>( ), hA.as<u64>( ), hC.as<u64>( ),
                         hG.as<u64>( ), hT.as<u64>( ), n, nblk, x->bwt.as<u32>( ) );
-    hipLaunchKernelGGL( k_sa_samples, GRID( x->n_sa ), 0, 0, SA.as<i64>( ), n, x->n_sa, x->sa.as<i64>( ) );
+    hipLaunchKernelGGL( k_sa_samples, GRID( x->n_sa ), 0, 0, SA.as<i64>( ), n, x->n_sa, x->sa.as<i64>( ), 5u );
+    const u32 dShift = ma::sa_dense_shift( ); // the hot path's denser sample (ma_common.h), straight from the full suffix array
+    const u64 nDense = dShift ? ( n + ( 1ull << dShift ) ) >> dShift : 0;
+    const bool dense = dShift != 0;
+    if( dense )
+    {
+        if( x->saDense.reserve( nDense * 8 ) )
+            return 1;
+        hipLaunchKernelGGL( k_sa_samples, GRID( nDense ), 0, 0, SA.as<i64>( ), n, nDense, x->saDense.as<i64>( ), dShift );
+    }
     MA_HIP( hipMemcpy( x->cstart.p, cs.data( ), n_contigs * 8, hipMemcpyHostToDevice ) );
     MA_HIP( hipMemcpy( x->clen.p, cl.data( ), n_contigs * 8, hipMemcpyHostToDevice ) );
     MA_HIP( hipDeviceSynchronize( ) );
@@ -536,6 +545,11 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
     x->h_clen = cl;
     x->v.bwt = x->bwt.as<u32>( );
     x->v.sa = x->sa.as<i64>( );
+    if( dense )
+    {
+        x->v.sa_dense = x->saDense.as<i64>( );
+        x->v.sa_shift = dShift;
+    }
     x->v.pac = x->pac.as<uint8_t>( );
     x->v.cstart = x->cstart.as<u64>( );
     x->v.clen = x->clen.as<u64>( );

@@ -9,6 +9,7 @@ namespace ma
 {
 void set_error( const std::string& s );
 int fail( const std::string& s );
+u32 sa_dense_shift( ); // index.hip: log2 of the dense SA sample's interval (0: none)
 
 #define MA_HIP( call )                                                                                                 \
     do                                                                                                                 \
@@ -89,7 +90,7 @@ struct DeviceGuard
 struct ma_index
 {
     ma::IndexView v; // device pointers
-    ma::DevBuf bwt, sa, pac, cstart, clen;
+    ma::DevBuf bwt, sa, saDense, pac, cstart, clen;
     uint64_t n_words = 0, n_sa = 0;
     std::vector<uint64_t> h_cstart, h_clen;
     int device = 0;

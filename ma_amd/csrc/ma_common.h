@@ -65,7 +65,12 @@ template <typename T> MA_HD void mswap( T& a, T& b )
 struct IndexView
 {
     const u32* bwt; // 64-B aligned
-    const i64* sa; // every 32nd SA row, sa[0] = -1
+    const i64* sa; // every 32nd SA row, sa[0] = -1 (the reference's .sa file)
+    // A denser sample of the same suffix array for the hot path (null: use sa): the LF walk of bwt_sa ends at the first
+    // sampled row it hits, a geometric wait -- mean 31 steps at interval 32, the longest of 2 M rows ~450 dependent loads,
+    // which is what k_lf_walk's run time was.  Every 8th row costs 6.2 GB for GRCh38 (of 288 GB) and divides both by 4.
+    const i64* sa_dense = nullptr;
+    u32 sa_shift = 5; // log2 of the interval of the sample bwt_sa uses
     const uint8_t* pac; // forward strand, 2 bit/base, MSB first
     const u64* cstart; // contig start offsets (forward strand)
     const u64* clen;

@@ -638,6 +638,7 @@ __global__ void __launch_bounds__( 256 ) k_lf_walk( IndexView X, i64* row /* in:
                                                    u32* nsteps, u64 total, unsigned long long* next )
 {
     const u32 wl = threadIdx.x & 63;
+    const i64 saMask = ( (i64)1 << X.sa_shift ) - 1;
     bool alive = true, have = false;
     i64 k = 0;
     u64 j = 0;
@@ -645,7 +646,7 @@ __global__ void __launch_bounds__( 256 ) k_lf_walk( IndexView X, i64* row /* in:
     u64 qCur = 0, qEnd = 0; // this wave's slice of the seed queue: one device atomic per 256 seeds
     while( true )
     {
-        if( have && ( k & 31 ) == 0 )
+        if( have && ( k & saMask ) == 0 )
         {
             row[ j ] = k;
             nsteps[ j ] = st; // not bounded by the sampling interval: the walk ends when it HITS a sampled row
@@ -683,7 +684,7 @@ __global__ void __launch_bounds__( 256 ) k_lf_walk( IndexView X, i64* row /* in:
         }
         if( __ballot( alive ) == 0 )
             break;
-        if( have && ( k & 31 ) )
+        if( have && ( k & saMask ) )
         {
             k = inv_psi( X, k );
             st++;
@@ -702,7 +703,7 @@ __global__ void k_seed_final( IndexView X, const ma_segment* pool, const u32* po
         const u64 i = seg_of[ j ];
         const ma_segment s = pool[ i ];
         steps = nsteps[ j ];
-        u64 r = (u64)( (i64)steps + X.sa[ row[ j ] >> 5 ] ); // bwt_sa (fMIndex.h:788-814)
+        u64 r = (u64)( (i64)steps + sa_sample( X, row[ j ] ) ); // bwt_sa (fMIndex.h:788-814)
         const bool fwd = r < X.n / 2;
         if( !fwd )
             r = X.n - r - 1;

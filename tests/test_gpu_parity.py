@@ -366,7 +366,8 @@ def test_pipeline_counters_match_oracle(small):
     c = res["counters"]
     assert int(counters[0]) == int(c[0])  # extend_backward steps
     assert int(counters[1]) == int(c[1])  # distinct occ blocks
-    assert int(counters[2]) == int(c[2])  # LF steps
+    # LF steps: the device walks to the next row of its denser SA sample (every 8th row), the oracle to the reference's every 32nd
+    assert 0 < int(counters[2]) <= int(c[2])
     assert int(counters[3]) == int(c[3])  # SA rows
     # DP band cells: the pipeline stops an extension once no later diagonal can raise ez.max (ksw_reg.h)
     assert 0 < int(counters[4]) <= int(c[4])
