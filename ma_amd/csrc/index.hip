@@ -177,6 +177,49 @@ int index_densify( ma_index* x )
     return 0;
 }
 } // namespace ma
+
+// K-mer table of the index (ma_common.h): one thread per K-mer runs the extension chain the seeding kernels would
+__global__ void k_kmer_table( ma::IndexView X, u32 K, u64 n_keys, u64* out )
+{
+    const u64 key = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if( key >= n_keys )
+        return;
+    i64 ik[ 3 ];
+    ma::init_interval( X, (u32)( key >> ( 2 * ( K - 1 ) ) ) & 3u, ik );
+    for( u32 j = 1; j < K && ik[ 2 ] > 0; j++ )
+    {
+        i64 ok[ 3 ];
+        u32 nb;
+        ma::extend_backward( X, ik, (u32)( key >> ( 2 * ( K - 1 - j ) ) ) & 3u, ok, nb );
+        ik[ 0 ] = ok[ 0 ], ik[ 1 ] = ok[ 1 ], ik[ 2 ] = ok[ 2 ];
+    }
+    if( ik[ 2 ] <= 0 )
+        ik[ 0 ] = ik[ 1 ] = ik[ 2 ] = 0;
+    out[ 2 * key ] = (u64)ik[ 0 ] | ( ( (u64)ik[ 2 ] & 0x1fffffffull ) << 35 );
+    out[ 2 * key + 1 ] = (u64)ik[ 1 ] | ( ( (u64)ik[ 2 ] >> 29 ) << 35 );
+}
+namespace ma
+{
+// MA_KMER_K: 0 = no table, default 12 (268 MB), at most 14 (4.3 GB)
+int index_kmer_table( ma_index* x )
+{
+    int K = 12;
+    if( const char* e = getenv( "MA_KMER_K" ) )
+        K = atoi( e );
+    if( K < 2 || x->v.n >= ( 1ull << 35 ) )
+        return 0;
+    K = K > 14 ? 14 : K;
+    const u64 keys = 1ull << ( 2 * K );
+    if( x->kmerTab.reserve( keys * 16 ) )
+        return 1;
+    hipLaunchKernelGGL( k_kmer_table, dim3( (unsigned)( ( keys + 255 ) / 256 ) ), dim3( 256 ), 0, 0, x->v, (u32)K, keys, x->kmerTab.as<u64>( ) );
+    MA_HIP( hipGetLastError( ) );
+    MA_HIP( hipDeviceSynchronize( ) );
+    x->v.kmer_tab = x->kmerTab.as<u64>( );
+    x->v.kmer_k = (u32)K;
+    return 0;
+}
+} // namespace ma
 } // extern "C++"
 
 int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t* sa, uint64_t n_sa,
@@ -211,7 +254,7 @@ int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t*
     for( int i = 0; i < 5; i++ )
         x->v.L2[ i ] = L2[ i ];
     x->v.n_contigs = n_contigs;
-    if( ma::index_densify( x.get( ) ) )
+    if( ma::index_densify( x.get( ) ) || ma::index_kmer_table( x.get( ) ) )
         return 1;
     *out = x.release( );
     return 0;
@@ -225,6 +268,7 @@ int ma_index_destroy( ma_index* x )
     x->bwt.release( );
     x->sa.release( );
     x->saDense.release( );
+    x->kmerTab.release( );
     x->pac.release( );
     x->cstart.release( );
     x->clen.release( );

@@ -559,6 +559,8 @@ static int build_impl( int32_t n_contigs, const uint64_t* contig_lens, const uin
     for( int i = 0; i < 5; i++ )
         x->v.L2[ i ] = L2[ i ];
     x->v.n_contigs = n_contigs;
+    if( ma::index_kmer_table( x.get( ) ) )
+        return 1;
     *out = x.release( );
     return 0;
 }

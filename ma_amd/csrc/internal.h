@@ -10,6 +10,11 @@ namespace ma
 void set_error( const std::string& s );
 int fail( const std::string& s );
 u32 sa_dense_shift( ); // index.hip: log2 of the dense SA sample's interval (0: none)
+}
+struct ma_index;
+namespace ma
+{
+int index_kmer_table( ma_index* x ); // index.hip: builds IndexView::kmer_tab (x->v otherwise complete)
 
 #define MA_HIP( call )                                                                                                 \
     do                                                                                                                 \
@@ -90,7 +95,7 @@ struct DeviceGuard
 struct ma_index
 {
     ma::IndexView v; // device pointers
-    ma::DevBuf bwt, sa, saDense, pac, cstart, clen;
+    ma::DevBuf bwt, sa, saDense, kmerTab, pac, cstart, clen;
     uint64_t n_words = 0, n_sa = 0;
     std::vector<uint64_t> h_cstart, h_clen;
     int device = 0;

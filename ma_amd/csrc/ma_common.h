@@ -71,6 +71,11 @@ struct IndexView
     // which is what k_lf_walk's run time was.  Every 8th row costs 6.2 GB for GRCh38 (of 288 GB) and divides both by 4.
     const i64* sa_dense = nullptr;
     u32 sa_shift = 5; // log2 of the interval of the sample bwt_sa uses
+    // bi-interval of every K-mer (null: none): entry[key] = init_interval( b0 ) extended by b1 .. b(K-1), key = b0 b1 .. in
+    // base 4, packed like the SMEM list entries (two u64: 35-bit starts, 35-bit size).  An extension run that starts from a
+    // single base (maxSpan: the first right run and the second left run of a centre) takes its first K-1 steps from here.
+    const u64* kmer_tab = nullptr;
+    u32 kmer_k = 0;
     const uint8_t* pac; // forward strand, 2 bit/base, MSB first
     const u64* cstart; // contig start offsets (forward strand)
     const u64* clen;

@@ -88,7 +88,8 @@ static __device__ unsigned long long g_seed_prof[ 8 ];
 #endif
 // One read per lane at a time; lanes refill from a global queue, so a wavefront keeps stepping 64
 // reads in lockstep through extend_backward until the batch is exhausted.
-__global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
+// LONG: the reads stay in HBM (longer than 240 bases) and are read through the register window of seed_qbyte.
+template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const SeedKernelArgs& A )
 {
     const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     SeedScratch S;
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
                     read = (u32)mine;
                     const uint8_t* src = A.reads + A.roff[ read ];
                     const u32 ql = (u32)( A.roff[ read + 1 ] - A.roff[ read ] );
-                    if( A.q_lds )
+                    if( !LONG )
                     {
                         u32 k = 0;
                         for( ; k + 16 <= ql; k += 16 )
@@ -203,13 +204,13 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
 #endif
         u32 c = 0;
         const bool act = alive && L.phase != PH_DONE;
-        bool ext = act && seed_try<true>( L, A.P, c );
+        bool ext = act && seed_try<LONG>( L, A.P, c );
         {
             // phase transitions are batched like the refills: run them when enough lanes wait for one (or nobody can step)
             const unsigned long long sm = __ballot( act && !ext );
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare<true>( L, A.P, S, A.X, c );
+                    ext = seed_prepare<LONG>( L, A.P, S, A.X, c );
         }
 #if defined( MA_KSW_PROF )
         const unsigned long long tC = clock64( );
@@ -240,6 +241,16 @@ __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
 #endif
     atomicAdd( &A.ctr[ CTR_STEPS ], (unsigned long long)steps );
     atomicAdd( &A.ctr[ CTR_BLOCKS ], (unsigned long long)blocks );
+}
+// Two register budgets: short reads (staged in LDS) run best without spills at 3 waves per SIMD (137 VGPRs: 8.4 vs 9.2 ms
+// per 1 M x 150 bp reads), long reads want the fourth wave more than the 16 spilled dwords hurt (200 k x 10 kb: 155 vs 180 ms).
+__global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
+{
+    seed_kernel_body<false>( A );
+}
+__global__ void __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( 4 ) ) ) k_seed_long( SeedKernelArgs A )
+{
+    seed_kernel_body<true>( A );
 }
 
 __device__ __forceinline__ u64 wave_sum_u64( u64 v );
@@ -508,7 +519,7 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
             const unsigned long long sm = __ballot( act && !ext );
             if( sm && ( (u32)__popcll( sm ) >= 4 || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare( L, A.P, S, A.X, c );
+                    ext = seed_prepare<false, true>( L, A.P, S, A.X, c );
         }
         if( ext )
         {
@@ -1828,7 +1839,10 @@ int ma_seed_batch( ma_batch* b )
             A.slow_batch = A.P.technique == 0 ? 4 : 8;
             if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook
                 A.slow_batch = (u32)std::max( 1, atoi( e ) );
-            hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
+            if( A.q_lds )
+                hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
+            else
+                hipLaunchKernelGGL( k_seed_long, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), 0, b->stream, A );
         }
         MA_HIP( hipGetLastError( ) );
         // did every read fit its staging area, and all segments the pool?

@@ -264,6 +264,39 @@ MA_HD void seed_after_center( SeedLane& L, const SeedScratch& S, u32 cS, u32 cN 
         L.phase = PH_DONE;
 }
 
+// The first K-1 extension steps of a run that starts at the centre with a single-base interval, from the K-mer table of
+// the index: right = true: bases q[centre .. centre+K-1] complemented (the run of PH_P1_RIGHT), else q[centre], q[centre-1],
+// .. (PH_P2_LEFT).  Valid when the interval after those steps is still larger than min_amb: interval sizes only shrink
+// along a run, so none of the skipped steps would have met the stop rule (binarySeeding.h:109-112).  Returns false (and
+// leaves the lane untouched) when the run has to be walked step by step.
+MA_HD bool seed_jump( SeedLane& L, const SeedParams& P, const IndexView& X, bool right )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    const u32 K = X.kmer_k;
+    if( K == 0 || ( right ? L.center + K > L.qlen : L.center + 1 < K ) )
+        return false;
+    u32 key = 0, bad = 0;
+    for( u32 j = 0; j < K; j++ )
+    {
+        const u32 b = L.q[ right ? L.center + j : L.center - j ]; // plain loads: K bytes of one or two lines
+        bad |= b >> 2;
+        key = ( key << 2 ) | ( ( right ? 3u - b : b ) & 3u );
+    }
+    if( bad )
+        return false; // an N inside the K-mer
+    const ulonglong2 e = ( (const ulonglong2*)X.kmer_tab )[ key ];
+    const i64 size = (i64)( ( e.x >> 35 ) | ( ( ( e.y >> 35 ) & 0x3full ) << 29 ) );
+    if( size <= (i64)P.min_amb )
+        return false;
+    L.ik[ 0 ] = (i64)( e.x & 0x7ffffffffull );
+    L.ik[ 1 ] = (i64)( e.y & 0x7ffffffffull );
+    L.ik[ 2 ] = size;
+    return true;
+#else
+    return false;
+#endif
+}
+
 MA_HD bool seed_stop( const SeedParams& P, const i64 ok[ 3 ], const i64 ik[ 3 ] ) // binarySeeding.h:109-112
 {
     if( ok[ 2 ] <= 0 )
@@ -289,7 +322,9 @@ template <bool WIN = false> MA_HD bool seed_try( SeedLane& L, const SeedParams& 
 
 // ---- transitions (no index access) ----------------------------------------------------------
 // Runs cheap bookkeeping until the lane either needs an extension (returns true and sets c) or is done.
-template <bool WIN = false> MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
+// JUMP: use the K-mer table of the index (only the kernel whose register budget has room for it: inlined into the
+// read-per-lane kernel it costs a wave of occupancy, 117 -> 138 VGPRs, which eats the gain)
+template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
 {
     while( true )
     {
@@ -316,6 +351,11 @@ template <bool WIN = false> MA_HD bool seed_prepare( SeedLane& L, const SeedPara
                     }
                     L.end = L.center;
                     L.i = L.center + 1;
+                    if( JUMP && seed_jump( L, P, X, true ) )
+                    {
+                        L.end = L.center + X.kmer_k - 1;
+                        L.i = L.center + X.kmer_k;
+                    }
                     L.phase = PH_P1_RIGHT;
                 }
                 else
@@ -360,6 +400,11 @@ template <bool WIN = false> MA_HD bool seed_prepare( SeedLane& L, const SeedPara
                 L.start = L.center;
                 L.phase = PH_P2_LEFT;
                 L.i = L.center > 0 ? L.center - 1 : 0xffffffffu;
+                if( JUMP && seed_jump( L, P, X, false ) )
+                {
+                    L.start = L.center - ( X.kmer_k - 1 );
+                    L.i = L.start > 0 ? L.start - 1 : 0xffffffffu;
+                }
                 break;
             case PH_P2_LEFT:
                 if( L.i != 0xffffffffu )

@@ -364,8 +364,9 @@ def test_pipeline_counters_match_oracle(small):
     res = small["oidx"].align(small["reads"], or_params("default", 1))
     got, counters, counts = gpu_pipeline(small["gidx"], "default", 1, small["reads"])
     c = res["counters"]
-    assert int(counters[0]) == int(c[0])  # extend_backward steps
-    assert int(counters[1]) == int(c[1])  # distinct occ blocks
+    # extend_backward steps / distinct occ blocks: runs that start at a centre take their first steps from the K-mer table
+    assert 0 < int(counters[0]) <= int(c[0])
+    assert 0 < int(counters[1]) <= int(c[1])
     # LF steps: the device walks to the next row of its denser SA sample (every 8th row), the oracle to the reference's every 32nd
     assert 0 < int(counters[2]) <= int(c[2])
     assert int(counters[3]) == int(c[3])  # SA rows
