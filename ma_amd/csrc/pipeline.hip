@@ -210,7 +210,7 @@ template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const See
             const unsigned long long sm = __ballot( act && !ext );
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare<LONG>( L, A.P, S, A.X, c );
+                    ext = seed_prepare<LONG, !LONG>( L, A.P, S, A.X, c ); // the K-mer table pays for reads in LDS (150 bp: 8.1 -> 7.5 ms), not here for reads in HBM (10 kb: 145 -> 188 ms)
         }
 #if defined( MA_KSW_PROF )
         const unsigned long long tC = clock64( );
