@@ -519,3 +519,45 @@ def test_kernel_variants_give_identical_results(gpu_device, monkeypatch, env):
         for x, y in zip(gs, ws):
             assert np.array_equal(x, y)
     idx.close()
+
+
+@pytest.mark.parametrize("env", [{"MA_SA_DENSE": "0"}, {"MA_SA_DENSE": "1"}, {"MA_KMER_K": "0"}, {"MA_KMER_K": "5"}, {"MA_KMER_K": "14"},
+                                 {"MA_SA_DENSE": "0", "MA_KMER_K": "0"}])
+def test_index_acceleration_structures_do_not_change_results(gpu_device, monkeypatch, env):
+    """The dense SA sample and the K-mer table are private accelerators of the index: with other intervals / K, or without
+    them, every stage record is the same; and an index created from the reference's arrays (dense sample derived by LF
+    walks) equals one built on the device (dense sample taken from the full suffix array)."""
+    import ma_amd
+    g = rand_genome(37, [900000, 300000], repeat_unit=300, repeat_copies=60, repeat_div=0.08)
+    reads = (sample_reads(g, 300, 150, 81, sub=0.01) + sample_reads(g, 6, 4000, 82, sub=0.01, ins=0.005, dele=0.005)
+             + sample_reads(g, 20, 150, 83, sub=0.05, n_rate=0.02) + sample_reads(g, 2, 14, 84))
+
+    def run(idx):
+        out = []
+        for technique in (0, 1):
+            P = ma_amd.Params.preset("default")
+            P.seeding_technique = technique
+            b = ma_amd.Batch(idx, P, len(reads), sum(len(r) for r in reads) + 64)
+            b.set_reads(reads)
+            b.align()
+            b.sync()
+            out += [b.segments(), b.seeds(), b.hsets(), b.alignments(), b.mapq_alignments()]
+            b.close()
+        return out
+
+    idx = ma_amd.Index.build(g)
+    want = run(idx)
+    parts = idx.download()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    idx2 = ma_amd.Index.build(g)
+    idx3 = ma_amd.Index.from_arrays(**parts) if isinstance(parts, dict) else None
+    for other in (idx2, idx3):
+        if other is None:
+            continue
+        got = run(other)
+        for gs, ws in zip(got, want):
+            for x, y in zip(gs, ws):
+                assert np.array_equal(x, y)
+        other.close()
+    idx.close()
