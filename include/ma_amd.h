@@ -30,7 +30,7 @@ typedef struct ma_batch ma_batch; /* device-resident batch of reads + all stage 
  * Presetting/GlobalParameter members named in the comments of ma_params_default(). */
 typedef struct
 {
-    int32_t seeding_technique; /* 0 maxSpan, 1 SMEMs            xSeedingTechnique  (binarySeeding.h:560) */
+    int32_t seeding_technique; /* 0 maxSpan, 1 SMEMs, 2 MEMs    xSeedingTechnique  (binarySeeding.h:560-561) */
     int32_t min_seed_len; /* 16                                  xMinSeedLength */
     int32_t min_ambiguity; /* 0                                  xMinimalSeedAmbiguity */
     int32_t max_ambiguity; /* 100                                xMaximalSeedAmbiguity */
@@ -191,12 +191,28 @@ int ma_batch_set_segments( ma_batch*, const uint64_t* seg_off /*n+1*/, const ma_
 int ma_batch_set_seeds( ma_batch*, const uint64_t* seed_off /*n+1*/, const ma_seed* seeds ); /* -> ma_chain_batch */
 int ma_batch_set_hsets( ma_batch*, const uint64_t* hset_off /*n+1*/, const uint64_t* hseed_off /*n_hsets+1*/,
                         const uint32_t* hset_soc, const ma_seed* hseeds ); /* -> ma_dp_batch */
+/* A SoC queue per read that was swept elsewhere (SoCPriorityQueue soc.h:96-420 as StripOfConsideration::execute returns
+ * it, stripOfConsideration.cpp:162-173): sorted_seeds = its pSeeds (re-sorted by reference position), socs = its vMaxima
+ * array (layout of ma_batch_get_soc_heap).  -> ma_chain_batch, which then runs Harmonization::execute only. */
+int ma_batch_set_soc_heap( ma_batch*, const uint64_t* soc_off /*n+1*/, const ma_soc* socs, const uint64_t* seed_off /*n+1*/,
+                           const ma_seed* sorted_seeds );
+/* MappingQuality::execute (mappingQuality.cpp:11-131) alone: alignments that were computed elsewhere (e.g. by the
+ * reference's NeedlemanWunsch), per read in the order NeedlemanWunsch::execute left them (needlemanWunsch.h:131-132), in
+ * the layout ma_batch_get_alignments returns.  Runs the MappingQuality kernel; ma_batch_get_mapq_alignments then serves
+ * its selection (flags, mapping quality, order), ma_batch_get_alignments the input. */
+int ma_batch_set_alignments( ma_batch*, const uint64_t* aln_off /*n+1*/, const ma_alignment* alns, const uint64_t* ops );
 /* The SoC queue of every read (StripOfConsiderationSeeds::execute stripOfConsideration.cpp:12-161; requires extracted
  * seeds): socs[soc_off[r] .. soc_off[r+1]) are read r's strips in pop() order (SoCPriorityQueue::pop soc.h:240-284, i.e.
  * index_of_strip = position), their seed ranges refer to sorted_seeds[seed_off[r] ..), the read's seeds re-sorted by
  * reference position as rectangularSoC leaves them.  n_socs first (other pointers NULL), then the arrays. */
 int ma_batch_get_socs( ma_batch*, uint64_t* n_socs, uint64_t* soc_off /*n+1*/, ma_soc* socs, uint64_t* seed_off /*n+1*/,
                        ma_seed* sorted_seeds );
+/* Same arguments, but socs[] is the queue's internal array `vMaxima` (soc.h:140) as StripOfConsiderationSeeds::execute
+ * leaves it -- std::make_heap, then rectangularSoC() without re-heapifying (stripOfConsideration.cpp:152-156) -- instead of
+ * the pop order.  A binding on the reference's own SoCPriorityQueue fills pSeeds / vMaxima with it and the reference's
+ * own pop() (soc.h:240-284) then yields the reference's order. */
+int ma_batch_get_soc_heap( ma_batch*, uint64_t* n_socs, uint64_t* soc_off /*n+1*/, ma_soc* socs, uint64_t* seed_off /*n+1*/,
+                           ma_seed* sorted_seeds );
 
 /* results: counts first, then download into caller-allocated arrays (any pointer may be NULL) */
 int ma_batch_counts( ma_batch*, uint64_t* n_segments, uint64_t* n_seeds, uint64_t* n_hsets, uint64_t* n_hseeds,

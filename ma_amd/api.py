@@ -53,6 +53,7 @@ EZ_DT = np.dtype([(k, "<i4") for k in ("max", "zdropped", "max_q", "max_t", "mqe
 ALIGNMENT_DT = np.dtype([("begin_ref", "<i8"), ("end_ref", "<i8"), ("begin_q", "<i8"), ("end_q", "<i8"),
                          ("score", "<i8"), ("soc_index", "<u4"), ("n_ops", "<u4"), ("ops_off", "<u8"),
                          ("secondary", "<u4"), ("supplementary", "<u4"), ("mapq", "<f8")])
+SOC_DT = np.dtype([("acc_len", "<u8"), ("ambiguity", "<u4"), ("n_seeds", "<u4"), ("begin", "<u4"), ("end", "<u4")])
 KSW_JOB_DT = np.dtype([("qlen", "<i4"), ("tlen", "<i4"), ("w", "<i4"), ("zdrop", "<i4"), ("flag", "<i4"),
                        ("reserved", "<u4"), ("q_off", "<u8"), ("t_off", "<u8")])
 
@@ -345,6 +346,41 @@ class Batch:
         seeds = np.zeros(c["hseeds"], dtype=SEED_DT)
         _chk(lib().ma_batch_get_hsets(self.h, _ptr(hoff), _ptr(soff), _ptr(soc), _ptr(seeds)))
         return hoff, soff, soc, seeds[: int(soff[-1])]
+
+    def set_seeds(self, off, seeds):
+        """Extracted seeds from elsewhere (CSR per read) -> chain()."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        seeds = np.ascontiguousarray(np.concatenate([seeds, np.zeros(1, dtype=SEED_DT)]))
+        _chk(lib().ma_batch_set_seeds(self.h, _ptr(off), _ptr(seeds)))
+
+    def socs(self, heap=False):
+        """The SoC queue of every read: strips in pop order, or (heap=True) the queue's array as the sweep leaves it;
+        returns (soc_off, socs, seed_off, seeds re-sorted by reference position)."""
+        fn = lib().ma_batch_get_soc_heap if heap else lib().ma_batch_get_socs
+        n = C.c_uint64()
+        _chk(fn(self.h, C.byref(n), None, None, None, None))
+        c = self.counts()
+        soff = np.zeros(self.n + 1, dtype=np.uint64)
+        socs = np.zeros(int(n.value) + 1, dtype=SOC_DT)
+        doff = np.zeros(self.n + 1, dtype=np.uint64)
+        seeds = np.zeros(c["seeds"] + 1, dtype=SEED_DT)
+        _chk(fn(self.h, C.byref(n), _ptr(soff), _ptr(socs), _ptr(doff), _ptr(seeds)))
+        return soff, socs[: int(n.value)], doff, seeds[: c["seeds"]]
+
+    def set_soc_heap(self, soc_off, socs, seed_off, seeds):
+        """SoC queues swept elsewhere (layout of socs(heap=True)) -> chain() only harmonizes."""
+        soc_off = np.ascontiguousarray(soc_off, dtype=np.uint64)
+        seed_off = np.ascontiguousarray(seed_off, dtype=np.uint64)
+        socs = np.ascontiguousarray(np.concatenate([socs, np.zeros(1, dtype=SOC_DT)]))
+        seeds = np.ascontiguousarray(np.concatenate([seeds, np.zeros(1, dtype=SEED_DT)]))
+        _chk(lib().ma_batch_set_soc_heap(self.h, _ptr(soc_off), _ptr(socs), _ptr(seed_off), _ptr(seeds)))
+
+    def set_alignments(self, off, alns, ops):
+        """Alignments computed elsewhere (NeedlemanWunsch order) -> the MappingQuality kernel alone."""
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        alns = np.ascontiguousarray(np.concatenate([alns, np.zeros(1, dtype=ALIGNMENT_DT)]))
+        ops = np.ascontiguousarray(np.concatenate([np.asarray(ops, dtype=np.uint64), np.zeros(2, dtype=np.uint64)]))
+        _chk(lib().ma_batch_set_alignments(self.h, _ptr(off), _ptr(alns), _ptr(ops)))
 
     def _alns(self, fn):
         c = self.counts()

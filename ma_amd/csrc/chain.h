@@ -371,10 +371,25 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
 // The queue alone (SoCPriorityQueue across the boundary): sweep, then pop() until the heap is empty (soc.h:240-284).
 // work[] ends up sorted by reference position; out[k] = k-th popped strip.  Returns the number of strips.
 MA_HD u32 soc_dump_read( const IndexView& X, const ChainParams& P, ma_seed* work, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm,
-                         ma_soc* out )
+                         ma_soc* out, bool heap_layout = false )
 {
     u32 nmx = soc_sweep( X, P, work, n, qlen, mx, mm );
     u32 k = 0;
+    if( heap_layout )
+    {
+        // vMaxima as the sweep leaves it (make_heap, then rectangularSoC WITHOUT re-heapifying, stripOfConsideration.cpp:
+        // 152-156): a binding that fills the reference's own SoCPriorityQueue with this array gets the reference's pop()
+        // order from the reference's pop() (soc.h:240-284)
+        for( ; k < nmx; k++ )
+        {
+            out[ k ].acc_len = mx[ k ].accLen;
+            out[ k ].ambiguity = mx[ k ].amb;
+            out[ k ].n_seeds = mx[ k ].cnt;
+            out[ k ].begin = mx[ k ].b;
+            out[ k ].end = mx[ k ].e;
+        }
+        return k;
+    }
     while( nmx > 0 )
     {
         const SoCEntry f = mx[ 0 ];
@@ -834,11 +849,27 @@ MA_HD u64 bump_alloc( unsigned long long* ctr, u64 n )
 #endif
 
 // Harmonization::execute (harmonization.cpp:374-555) for one read. Returns number of sets; err flags.
+// queue / nQueue: the strips were swept elsewhere (ma_batch_set_soc_heap: a SoCPriorityQueue of the reference): C.work holds
+// the seeds as rectangularSoC left them, queue[] the array vMaxima; the sweep is skipped.
 MA_HD u32 chain_read( const IndexView& X, const ChainParams& P, const ChainScratch& C, u32 nSeeds, u32 qlen,
-                      const ChainOut& O, u32& err )
+                      const ChainOut& O, u32& err, const ma_soc* queue = nullptr, u32 nQueue = 0 )
 {
     CH_T( t0 );
-    const u32 nmx0 = soc_sweep( X, P, C.work, nSeeds, qlen, C.maxima, C.mm, (KeyIdx*)C.sh1, C.setA );
+    u32 nmx0;
+    if( queue != nullptr )
+    {
+        nmx0 = nQueue < nSeeds ? nQueue : nSeeds; // a strip holds a seed at least: the scratch carved by seed count is enough
+        for( u32 k = 0; k < nmx0; k++ )
+        {
+            SoCEntry e;
+            e.accLen = queue[ k ].acc_len, e.amb = queue[ k ].ambiguity, e.cnt = queue[ k ].n_seeds;
+            e.b = queue[ k ].begin < nSeeds ? queue[ k ].begin : nSeeds;
+            e.e = queue[ k ].end < nSeeds ? queue[ k ].end : nSeeds;
+            C.maxima[ k ] = e;
+        }
+    }
+    else
+        nmx0 = soc_sweep( X, P, C.work, nSeeds, qlen, C.maxima, C.mm, (KeyIdx*)C.sh1, C.setA );
     u32 nmx = nmx0;
     GlibcRand rng;
     rng.init( P.rng_ring );

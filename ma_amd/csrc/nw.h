@@ -646,11 +646,14 @@ struct ByScore
     }
 };
 
-MA_HD u32 finish_read( const NwParams& P, AlnHeader* hdr, const u64* opsPool, u32 n, u64 qlen, u32* order, u32* mq_order )
+// nw_sort = false: the alignments were handed in (ma_batch_set_alignments) in the order their NeedlemanWunsch left them
+MA_HD u32 finish_read( const NwParams& P, AlnHeader* hdr, const u64* opsPool, u32 n, u64 qlen, u32* order, u32* mq_order,
+                       bool nw_sort = true )
 {
     for( u32 i = 0; i < n; i++ )
         order[ i ] = i;
-    ss::sort( order, (i64)n, ByLarger{ hdr } );
+    if( nw_sort )
+        ss::sort( order, (i64)n, ByLarger{ hdr } );
     if( n == 0 )
         return 0;
     for( u32 i = 0; i < n; i++ )

@@ -408,7 +408,11 @@ __global__ void k_task_roots( const u64* roff, u32 n_reads, SeedTask* out, unsig
 __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
 {
     const u32 wl = threadIdx.x & 63;
-    const u64 nIn = *A.nIn;
+    // a level that overflowed the task array bumped *nOut past task_cap without writing those tasks: the levels queued
+    // behind it must neither run on the unwritten slots nor read past the array (the host falls back to k_seed)
+    if( A.ctr[ CTR_ERR ] & MA_ERR_STACK_OVERFLOW )
+        return;
+    const u64 nIn = *A.nIn < A.task_cap ? *A.nIn : A.task_cap;
     SeedLane L;
     L.phase = PH_DONE;
     L.err = 0;
@@ -771,6 +775,9 @@ struct ChainKernelArgs
     u32* nsets; // per read
     unsigned long long* ctr;
     u32 lanes; // reads per wavefront (lanes_per_wave)
+    // optional: the SoC queues were swept elsewhere (ma_batch_set_soc_heap); carved by seed offset like the scratch
+    const ma_soc* queue;
+    const u32* queue_cnt;
 };
 
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4, 4 ) ) ) k_chain( ChainKernelArgs A )
@@ -806,7 +813,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4,
     O.local_cap = 3 * n;
     u32 err = 0;
     const u32 qlen = (u32)( A.roff[ r + 1 ] - A.roff[ r ] );
-    const u32 ns = chain_read( A.X, A.P, C, n, qlen, O, err );
+    const u32 ns = chain_read( A.X, A.P, C, n, qlen, O, err, A.queue ? A.queue + off : nullptr, A.queue ? A.queue_cnt[ r ] : 0 );
     A.nsets[ r ] = ns < A.set_cap ? ns : A.set_cap;
     if( err )
         atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
@@ -815,7 +822,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4,
 // the SoC queue of every read in pop order (ma_batch_get_socs); scratch and output carved by the read's seed offset
 __global__ void __launch_bounds__( 64 ) k_soc_dump( IndexView X, ChainParams P, u32 n_reads, const u64* roff, const u64* seed_off,
                                                    const u32* seed_cnt, const ma_seed* seeds, ma_seed* work, SoCEntry* maxima,
-                                                   RefMinMax* mm, ma_soc* socs, u32* nsocs )
+                                                   RefMinMax* mm, ma_soc* socs, u32* nsocs, int heap_layout )
 {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     if( r >= n_reads )
@@ -824,7 +831,7 @@ __global__ void __launch_bounds__( 64 ) k_soc_dump( IndexView X, ChainParams P, 
     const u32 n = seed_cnt[ r ];
     for( u32 i = 0; i < n; i++ )
         work[ off + i ] = seeds[ off + i ];
-    nsocs[ r ] = soc_dump_read( X, P, work + off, n, (u32)( roff[ r + 1 ] - roff[ r ] ), maxima + off, mm + off, socs + off );
+    nsocs[ r ] = soc_dump_read( X, P, work + off, n, (u32)( roff[ r + 1 ] - roff[ r ] ), maxima + off, mm + off, socs + off, heap_layout != 0 );
 }
 
 // harmonized seeds of a read (sum of its sets' sizes), input of the scan that lays out the dense pool
@@ -1252,7 +1259,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 
 
 // per read: NeedlemanWunsch::execute's final sort + MappingQuality::execute
 __global__ void k_finish( NwParams P, u32 n_reads, const u64* hset_off, const u64* roff, AlnHeader* hdr, const u64* ops,
-                          u32* order, u32* mq_order, u32* mq_cnt, unsigned long long* ctr )
+                          u32* order, u32* mq_order, u32* mq_cnt, unsigned long long* ctr, int nw_sort )
 {
     const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
     const u64 b = r < n_reads ? hset_off[ r ] : 0;
@@ -1261,7 +1268,7 @@ __global__ void k_finish( NwParams P, u32 n_reads, const u64* hset_off, const u6
     u64 opsMq = 0;
     if( r < n_reads )
     {
-        m = finish_read( P, hdr + b, ops, n, roff[ r + 1 ] - roff[ r ], order + b, mq_order + b );
+        m = finish_read( P, hdr + b, ops, n, roff[ r + 1 ] - roff[ r ], order + b, mq_order + b, nw_sort != 0 );
         mq_cnt[ r ] = m;
         for( u32 k = 0; k < m; k++ )
             opsMq += hdr[ b + mq_order[ b + k ] ].n_ops;
@@ -1354,6 +1361,8 @@ struct ma_batch
     DevBuf cWork, cMax, cMm, cA, cB, cOut, cSh1, cSh2, cVx, cVy, cMed, cInl, cBest, hpool, setTab, nsets, hsetOff,
         hsetFlat, hsetRead;
     u64 hpoolCap = 0, nHsets = 0, nHseeds = 0;
+    DevBuf socIn, socInCnt; // SoC queues swept elsewhere (ma_batch_set_soc_heap), carved by seed offset
+    bool socGiven = false;
     // dp
     DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, clsLists, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
     DevBuf outCnt, outOps, outAlnOff, outOpsOff, outAlns, outOpsPairs; // packed results (get_alns)
@@ -1773,7 +1782,7 @@ int ma_seed_batch( ma_batch* b )
     }
     const bool smem = b->P.seeding_technique == 1;
     const u32 worst_cap = ( smem ? 6 : 2 ) * b->max_qlen + 8; // segments one read can emit at most
-    const u32 smem_cap = smem ? b->max_qlen + 2 : 0;
+    const u32 smem_cap = smem ? ( ( b->max_qlen + 3 ) & ~1u ) : 0; // even: a lane's list of 16-byte compact entries stays 16-byte aligned
     b->segPoolCap = seg_pool_heuristic( b->n_bases, n );
     if( smem )
         b->segPoolCap *= 4;
@@ -1877,7 +1886,7 @@ int ma_extract_seeds_batch( ma_batch* b )
     const u64 n = b->n_reads;
     if( n == 0 )
     {
-        b->stage_done = 2;
+        b->socGiven = false, b->stage_done = 2;
         return 0;
     }
     if( read_ctr( b ) || check_err( b, "ma_seed_batch" ) )
@@ -1924,7 +1933,7 @@ int ma_extract_seeds_batch( ma_batch* b )
                             b->seeds.as<ma_seed>( ), c );
     }
     MA_HIP( hipGetLastError( ) );
-    b->stage_done = 2;
+    b->socGiven = false, b->stage_done = 2;
     return 0;
 }
 
@@ -2049,6 +2058,8 @@ int ma_chain_batch( ma_batch* b )
     A.set_cap = set_cap;
     A.nsets = b->nsets.as<u32>( );
     A.ctr = b->ctr.as<unsigned long long>( );
+    A.queue = b->socGiven ? b->socIn.as<ma_soc>( ) : nullptr;
+    A.queue_cnt = b->socGiven ? b->socInCnt.as<u32>( ) : nullptr;
     {
         EvTimer t( b, 2 );
         A.lanes = lanes_per_wave( n );
@@ -2141,11 +2152,16 @@ int ma_dp_batch( ma_batch* b )
     if( b->mqCnt.reserve( ( n + 1 ) * 4 ) )
         return 1;
     MA_HIP( hipMemsetAsync( b->mqCnt.p, 0, ( n + 1 ) * 4, b->stream ) );
+    // the counters this stage owns start from zero on EVERY call (the stage API is public: a second ma_dp_batch on the same
+    // batch must not double the job counts and the download sizes get_alns reads); [0, 8) and CTR_NEXT_SEED belong to the
+    // earlier stages
+    MA_HIP( hipMemsetAsync( b->ctr.as<unsigned long long>( ) + CTR_CIG_USED, 0, ( CTR_NEXT_SEED - CTR_CIG_USED ) * 8, b->stream ) );
+    MA_HIP( hipMemsetAsync( b->ctr.as<unsigned long long>( ) + CTR_OPS_ALL, 0, ( CTR_COUNT - CTR_OPS_ALL ) * 8, b->stream ) );
     if( n == 0 || nh == 0 )
     {
         b->nJobSlots = 0;
         b->stage_done = 4;
-        return 0;
+        return read_ctr( b );
     }
     const u64 nSlots = 2 * nhs;
     b->nJobSlots = nSlots;
@@ -2293,9 +2309,77 @@ int ma_dp_batch( ma_batch* b )
         hipLaunchKernelGGL( k_finish, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, NP, (u32)n,
                             b->hsetOff.as<u64>( ), b->d_roff, b->hdr.as<AlnHeader>( ), b->ops.as<u64>( ),
                             b->order.as<u32>( ), b->mqOrder.as<u32>( ), b->mqCnt.as<u32>( ),
-                            b->ctr.as<unsigned long long>( ) );
+                            b->ctr.as<unsigned long long>( ), 1 );
     }
     MA_HIP( hipGetLastError( ) );
+    b->stage_done = 4;
+    return 0;
+}
+
+// MappingQuality::execute (mappingQuality.cpp:11-131) ALONE, for alignments that were computed elsewhere (the reference's
+// NeedlemanWunsch in a mixed graph): per read its alignments in the order NeedlemanWunsch::execute left them
+// (needlemanWunsch.h:131-132), ops as (type, length) pairs like ma_batch_get_alignments returns them.  Afterwards
+// ma_batch_get_mapq_alignments serves the MappingQuality selection (ma_batch_get_alignments: the input, unchanged).
+static int reset_ctr( ma_batch* b );
+int ma_batch_set_alignments( ma_batch* b, const uint64_t* aln_off, const ma_alignment* alns, const uint64_t* ops )
+{
+    if( !b || !b->d_roff || !aln_off )
+        return fail( "ma_batch_set_alignments: no reads set or null argument" );
+    const u64 n = b->n_reads, na = aln_off[ n ];
+    if( na && !alns )
+        return fail( "ma_batch_set_alignments: null argument" );
+    MA_BIND_DEVICE( b->device );
+    u64 no = 0;
+    for( u64 i = 0; i < na; i++ )
+        no += alns[ i ].n_ops;
+    if( no && !ops )
+        return fail( "ma_batch_set_alignments: null argument" );
+    std::vector<AlnHeader> h( na + 1 );
+    std::vector<u64> pk( no + 1 );
+    u64 w = 0;
+    for( u64 i = 0; i < na; i++ )
+    {
+        const ma_alignment& a = alns[ i ];
+        AlnHeader& x = h[ i ];
+        x.begin_ref = (u64)a.begin_ref, x.end_ref = (u64)a.end_ref, x.begin_q = (u64)a.begin_q, x.end_q = (u64)a.end_q;
+        x.score = a.score;
+        x.length = 0;
+        x.ops_off = w;
+        x.n_ops = x.ops_cap = a.n_ops;
+        x.soc_index = a.soc_index;
+        x.secondary = a.secondary, x.supplementary = a.supplementary; // Alignment::larger reads them (all 0 after the DP stage)
+        x.mapq = a.mapq;
+        for( u32 k = 0; k < a.n_ops; k++ )
+        {
+            const u64 t = ops[ 2 * ( a.ops_off + k ) ], l = ops[ 2 * ( a.ops_off + k ) + 1 ];
+            if( t > MT_DEL )
+                return fail( "ma_batch_set_alignments: unknown match type" );
+            x.length += l;
+            pk[ w++ ] = op_pack( (u32)t, l );
+        }
+    }
+    if( reset_ctr( b ) || b->hsetOff.reserve( ( n + 2 ) * 8 ) || b->hdr.reserve( ( na + 1 ) * sizeof( AlnHeader ) ) ||
+        b->ops.reserve( ( no + 2 ) * 8 ) || b->order.reserve( ( na + 1 ) * 4 ) || b->mqOrder.reserve( ( na + 1 ) * 4 ) ||
+        b->mqCnt.reserve( ( n + 1 ) * 4 ) )
+        return 1;
+    MA_HIP( hipMemcpyAsync( b->hsetOff.p, aln_off, ( n + 1 ) * 8, hipMemcpyHostToDevice, b->stream ) );
+    if( na )
+        MA_HIP( hipMemcpyAsync( b->hdr.p, h.data( ), na * sizeof( AlnHeader ), hipMemcpyHostToDevice, b->stream ) );
+    if( no )
+        MA_HIP( hipMemcpyAsync( b->ops.p, pk.data( ), no * 8, hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipMemsetAsync( b->mqCnt.p, 0, ( n + 1 ) * 4, b->stream ) );
+    const unsigned long long all = no;
+    MA_HIP( hipMemcpyAsync( b->ctr.as<unsigned long long>( ) + CTR_OPS_ALL, &all, 8, hipMemcpyHostToDevice, b->stream ) );
+    if( n && na )
+        hipLaunchKernelGGL( k_finish, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, nw_params( b->P ), (u32)n,
+                            b->hsetOff.as<u64>( ), b->d_roff, b->hdr.as<AlnHeader>( ), b->ops.as<u64>( ), b->order.as<u32>( ),
+                            b->mqOrder.as<u32>( ), b->mqCnt.as<u32>( ), b->ctr.as<unsigned long long>( ), 0 );
+    MA_HIP( hipGetLastError( ) );
+    if( batch_wait( b ) )
+        return 1; // the host vectors go out of scope
+    b->nHsets = na; // one alignment per harmonized set: the bookkeeping get_alns walks
+    b->nHseeds = 0;
+    b->nJobSlots = 0;
     b->stage_done = 4;
     return 0;
 }
@@ -2395,7 +2479,44 @@ int ma_batch_set_seeds( ma_batch* b, const uint64_t* seed_off, const ma_seed* se
         return 1;
     b->nSeeds = total;
     b->nHsets = b->nHseeds = 0;
+    b->socGiven = false;
     b->stage_done = 2;
+    return 0;
+}
+
+// A SoC queue per read that was swept elsewhere -- the reference's StripOfConsideration in a mixed graph -- as input of
+// ma_chain_batch, which then only harmonizes: sorted_seeds = the read's seeds as rectangularSoC left them (pSeeds of the
+// SoCPriorityQueue), socs = its array vMaxima (score triple + seed range), both CSR per read (the layout
+// ma_batch_get_soc_heap returns).
+int ma_batch_set_soc_heap( ma_batch* b, const uint64_t* soc_off, const ma_soc* socs, const uint64_t* seed_off, const ma_seed* sorted_seeds )
+{
+    if( !b || !b->d_roff || !soc_off || !seed_off )
+        return fail( "ma_batch_set_soc_heap: no reads set or null argument" );
+    const u64 n = b->n_reads;
+    if( ( soc_off[ n ] && !socs ) || ( seed_off[ n ] && !sorted_seeds ) )
+        return fail( "ma_batch_set_soc_heap: null argument" );
+    for( u64 r = 0; r < n; r++ )
+        if( soc_off[ r + 1 ] - soc_off[ r ] > seed_off[ r + 1 ] - seed_off[ r ] )
+            return fail( "ma_batch_set_soc_heap: a read has more strips than seeds" );
+    if( ma_batch_set_seeds( b, seed_off, sorted_seeds ) )
+        return 1;
+    const u64 total = seed_off[ n ];
+    std::vector<ma_soc> q( total + 1 ); // the strips of read r at its SEED offset: the carving every chain scratch uses
+    std::vector<u32> c( n + 1 );
+    for( u64 r = 0; r < n; r++ )
+    {
+        c[ r ] = (u32)( soc_off[ r + 1 ] - soc_off[ r ] );
+        for( u32 k = 0; k < c[ r ]; k++ )
+            q[ seed_off[ r ] + k ] = socs[ soc_off[ r ] + k ];
+    }
+    if( b->socIn.reserve( ( total + 1 ) * sizeof( ma_soc ) ) || b->socInCnt.reserve( ( n + 1 ) * 4 ) )
+        return 1;
+    if( total )
+        MA_HIP( hipMemcpyAsync( b->socIn.p, q.data( ), total * sizeof( ma_soc ), hipMemcpyHostToDevice, b->stream ) );
+    MA_HIP( hipMemcpyAsync( b->socInCnt.p, c.data( ), ( n + 1 ) * 4, hipMemcpyHostToDevice, b->stream ) );
+    if( batch_wait( b ) )
+        return 1;
+    b->socGiven = true;
     return 0;
 }
 
@@ -2441,7 +2562,19 @@ int ma_batch_set_hsets( ma_batch* b, const uint64_t* hset_off, const uint64_t* h
 }
 
 // ---- the SoC queue across the boundary ------------------------------------------------------------------------
+static int get_socs( ma_batch* b, int heap_layout, uint64_t* n_socs, uint64_t* soc_off, ma_soc* socs, uint64_t* seed_off,
+                     ma_seed* sorted_seeds );
 int ma_batch_get_socs( ma_batch* b, uint64_t* n_socs, uint64_t* soc_off, ma_soc* socs, uint64_t* seed_off, ma_seed* sorted_seeds )
+{
+    return get_socs( b, 0, n_socs, soc_off, socs, seed_off, sorted_seeds );
+}
+int ma_batch_get_soc_heap( ma_batch* b, uint64_t* n_socs, uint64_t* soc_off, ma_soc* socs, uint64_t* seed_off, ma_seed* sorted_seeds )
+{
+    return get_socs( b, 1, n_socs, soc_off, socs, seed_off, sorted_seeds );
+}
+} // extern "C"
+static int get_socs( ma_batch* b, int heap_layout, uint64_t* n_socs, uint64_t* soc_off, ma_soc* socs, uint64_t* seed_off,
+                     ma_seed* sorted_seeds )
 {
     if( !b || b->stage_done < 2 )
         return fail( "ma_batch_get_socs: run ma_extract_seeds_batch first" );
@@ -2462,7 +2595,7 @@ int ma_batch_get_socs( ma_batch* b, uint64_t* n_socs, uint64_t* soc_off, ma_soc*
     hipLaunchKernelGGL( k_soc_dump, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, b->idx->v, chain_params( b->P ),
                         (u32)n, b->d_roff, b->seedOff.as<u64>( ), b->seedCnt.as<u32>( ), b->seeds.as<ma_seed>( ),
                         b->cWork.as<ma_seed>( ), b->cMax.as<SoCEntry>( ), b->cMm.as<RefMinMax>( ), dSocs.as<ma_soc>( ),
-                        dN.as<u32>( ) );
+                        dN.as<u32>( ), heap_layout );
     MA_HIP( hipGetLastError( ) );
     std::vector<u32> cnt( n ), scnt( n );
     std::vector<u64> off( n );
@@ -2503,6 +2636,7 @@ int ma_batch_get_socs( ma_batch* b, uint64_t* n_socs, uint64_t* soc_off, ma_soc*
     }
     return 0;
 }
+extern "C" {
 
 int ma_align_batch( ma_batch* b )
 {

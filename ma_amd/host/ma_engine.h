@@ -19,10 +19,23 @@
 #include <string>
 #include <vector>
 
-namespace libMA
+namespace ma_amd
 {
-namespace detail
+namespace engine
 {
+// a read in host memory: codes A0 C1 G2 T3 N4; the owner keeps it alive while its batch is in flight
+struct ReadRef
+{
+    const uint8_t* pCodes = nullptr;
+    size_t uiLength = 0;
+    ReadRef( )
+    {}
+    ReadRef( const uint8_t* pCodes, size_t uiLength ) : pCodes( pCodes ), uiLength( uiLength )
+    {}
+    ReadRef( const std::vector<uint8_t>& rCodes ) : pCodes( rCodes.data( ) ), uiLength( rCodes.size( ) )
+    {}
+};
+
 inline void engineCheck( int rc )
 {
     if( rc != 0 )
@@ -42,6 +55,12 @@ struct BatchResult
     std::vector<ma_segment> vSegs;
     std::vector<ma_seed> vSeeds, vHseeds;
     std::vector<uint32_t> vHsetSoc;
+    // the SoC queue of every read as the sweep leaves it (ma_batch_get_soc_heap): strips CSR by vSocOff, the read's seeds
+    // re-sorted by reference position at vSeedOff (what a binding on the reference's own SoCPriorityQueue fills it with)
+    std::vector<uint64_t> vSocOff;
+    std::vector<ma_soc> vSocHeap;
+    std::vector<ma_seed> vSortedSeeds;
+    bool bSocQueues = false;
     std::vector<ma_alignment> vAlns, vMq; // NeedlemanWunsch output / MappingQuality output
     std::vector<uint64_t> vAlnOps, vMqOps; // (type, length) pairs
     uint64_t uiAlignedReads = 0;
@@ -60,6 +79,10 @@ class Engine
     std::vector<uint64_t> vOff;
     const bool bBlocking; // waits sleep instead of spinning (hosts that run far more threads than cores)
 
+  public:
+    bool bFetchSocQueues = false; // run(): with bStages also fetch every read's SoC queue (one extra kernel per batch)
+
+  private:
     void fit( uint64_t uiReads, uint64_t uiBases )
     {
         if( pBatch != nullptr && uiReads <= uiCapReads && uiBases <= uiCapBases )
@@ -91,6 +114,14 @@ class Engine
     // vReads[i] = codes of read i (A0 C1 G2 T3 N4).  bStages: also fetch the records of the intermediate stages.
     std::shared_ptr<BatchResult> run( const std::vector<const std::vector<uint8_t>*>& vReads, bool bStages )
     {
+        std::vector<ReadRef> vRefs;
+        vRefs.reserve( vReads.size( ) );
+        for( const std::vector<uint8_t>* pRead : vReads )
+            vRefs.emplace_back( *pRead );
+        return run( vRefs, bStages );
+    }
+    std::shared_ptr<BatchResult> run( const std::vector<ReadRef>& vReads, bool bStages )
+    {
         auto pRes = std::make_shared<BatchResult>( );
         BatchResult& R = *pRes;
         const size_t n = vReads.size( );
@@ -98,11 +129,11 @@ class Engine
         R.bStages = bStages;
         vOff.assign( n + 1, 0 );
         for( size_t i = 0; i < n; i++ )
-            vOff[ i + 1 ] = vOff[ i ] + vReads[ i ]->size( );
+            vOff[ i + 1 ] = vOff[ i ] + vReads[ i ].uiLength;
         vCodes.resize( vOff[ n ] + 1 );
         for( size_t i = 0; i < n; i++ )
-            if( !vReads[ i ]->empty( ) )
-                std::copy( vReads[ i ]->begin( ), vReads[ i ]->end( ), vCodes.begin( ) + vOff[ i ] );
+            if( vReads[ i ].uiLength != 0 )
+                std::copy( vReads[ i ].pCodes, vReads[ i ].pCodes + vReads[ i ].uiLength, vCodes.begin( ) + vOff[ i ] );
         fit( n, vOff[ n ] );
         auto t0 = std::chrono::steady_clock::now( );
         engineCheck( ma_batch_set_reads( pBatch, vCodes.data( ), vOff.data( ), n ) );
@@ -128,6 +159,18 @@ class Engine
             R.vHsetSoc.resize( nHset + 1 );
             R.vHseeds.resize( nHseed + 1 );
             engineCheck( ma_batch_get_hsets( pBatch, R.vHsetOff.data( ), R.vHseedOff.data( ), R.vHsetSoc.data( ), R.vHseeds.data( ) ) );
+            if( bFetchSocQueues )
+            {
+                uint64_t nSocs = 0;
+                engineCheck( ma_batch_get_soc_heap( pBatch, &nSocs, nullptr, nullptr, nullptr, nullptr ) );
+                R.vSocOff.resize( n + 1 );
+                R.vSocHeap.resize( nSocs + 1 );
+                R.vSortedSeeds.resize( nSeed + 1 );
+                std::vector<uint64_t> vSeedOffAgain( n + 1 );
+                engineCheck( ma_batch_get_soc_heap( pBatch, &nSocs, R.vSocOff.data( ), R.vSocHeap.data( ), vSeedOffAgain.data( ),
+                                                    R.vSortedSeeds.data( ) ) );
+                R.bSocQueues = true;
+            }
             R.vAlnOff.resize( n + 1 );
             R.vAlns.resize( nAln + 1 );
             R.vAlnOps.resize( 2 * nOps + 2 );
@@ -164,13 +207,16 @@ struct BatcherOptions
     // MappingQuality-annotated alignments are fetched; the intermediate containers are empty shells that just pass the
     // ticket on -- enough for the chain of export.cpp:104-108 and several times cheaper per read.
     bool bStages = true;
+    // with bStages: also fetch every read's SoC queue (needed by bindings whose SoCPriorityQueue is the reference's own
+    // type and must therefore be filled eagerly; the mirror types of ma_modules.h compute it on demand)
+    bool bSocQueues = false;
 };
 
 class DeviceBatcher
 {
     struct Slot
     {
-        std::vector<const std::vector<uint8_t>*> vReads;
+        std::vector<ReadRef> vReads;
         std::shared_ptr<const BatchResult> pResult;
         std::string sError;
         bool bSealed = false, bDone = false;
@@ -206,7 +252,10 @@ class DeviceBatcher
         try
         {
             if( pEngine == nullptr )
+            {
                 pEngine.reset( new Engine( pIndex, xP, true ) );
+                pEngine->bFetchSocQueues = xOpt.bSocQueues;
+            }
             pSlot->pResult = pEngine->run( pSlot->vReads, xOpt.bStages );
         }
         catch( const std::exception& rE )
@@ -245,12 +294,16 @@ class DeviceBatcher
     // (the caller holds the NucSeq).  Re-entrant: called concurrently by all graph threads.
     Ticket align( const std::vector<uint8_t>& rCodes )
     {
+        return align( ReadRef( rCodes ) );
+    }
+    Ticket align( const ReadRef& rRead )
+    {
         std::unique_lock<std::mutex> xLock( xMutex );
         if( pOpen == nullptr )
             pOpen = std::make_shared<Slot>( );
         std::shared_ptr<Slot> pSlot = pOpen;
         const size_t uiMine = pSlot->vReads.size( );
-        pSlot->vReads.push_back( &rCodes );
+        pSlot->vReads.push_back( rRead );
         auto seal = [ & ]( ) {
             pSlot->bSealed = true;
             if( pOpen == pSlot )
@@ -309,5 +362,5 @@ class DeviceBatcher
             aOut[ k ] = aSumStageMs[ k ] / 1e3;
     }
 };
-} // namespace detail
-} // namespace libMA
+} // namespace engine
+} // namespace ma_amd

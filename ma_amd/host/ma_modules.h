@@ -29,6 +29,10 @@
 
 namespace libMA
 {
+namespace detail
+{
+using namespace ma_amd::engine; // Engine, DeviceBatcher, Ticket, BatchResult (reference-free, shared with ma_ref_binding.h)
+}
 typedef uint64_t nucSeqIndex;
 typedef int64_t t_bwtIndex;
 

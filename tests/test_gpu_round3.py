@@ -1,0 +1,162 @@
+"""Round-3 GPU tests: the stage inputs added for the binding on the reference's real types (SoC queue state in / out,
+MappingQuality alone), and the regressions of ADVICE round 2 (task-array overflow of the area-parallel seeding kernel, SMEM
+lists of odd read lengths, a second ma_dp_batch on the same batch)."""
+import numpy as np
+import pytest
+
+from ma_testlib import rand_genome, sample_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(idx, reads, technique=0, preset="default"):
+    import ma_amd
+    P = ma_amd.Params.preset(preset)
+    if technique is not None:
+        P.seeding_technique = technique
+    b = ma_amd.Batch(idx, P, len(reads), sum(len(r) for r in reads) + 64)
+    b.set_reads(reads)
+    return b
+
+
+def _all_records(b):
+    return [b.segments(), b.seeds(), b.hsets(), b.alignments(), b.mapq_alignments()]
+
+
+def _same(got, want):
+    for gs, ws in zip(got, want):
+        for x, y in zip(gs, ws):
+            assert np.array_equal(x, y)
+
+
+@pytest.fixture(scope="module")
+def genome_and_index(gpu_device):
+    import ma_amd
+    g = rand_genome(41, [700000, 260000], repeat_unit=300, repeat_copies=60, repeat_div=0.08)
+    idx = ma_amd.Index.build(g)
+    yield g, idx
+    idx.close()
+
+
+def test_soc_queue_state_round_trip(genome_and_index):
+    """ma_batch_get_soc_heap -> ma_batch_set_soc_heap -> ma_chain_batch (harmonization only) gives the harmonized sets of the
+    fused path; popping the heap array with libstdc++'s pop_heap rule (here: the device's own pop order) agrees with
+    ma_batch_get_socs."""
+    g, idx = genome_and_index
+    reads = sample_reads(g, 300, 150, 5, sub=0.02) + sample_reads(g, 12, 3000, 6, sub=0.01, ins=0.005, dele=0.005)
+    b = _batch(idx, reads)
+    b.align()
+    b.sync()
+    want = b.hsets()
+    want_alns = b.mapq_alignments()
+    pop_off, pop, _, _ = b.socs(heap=False)
+    heap_off, heap, seed_off, sorted_seeds = b.socs(heap=True)
+    assert np.array_equal(pop_off, heap_off)
+    for r in range(len(reads)):
+        a, e = int(pop_off[r]), int(pop_off[r + 1])
+        if e > a:
+            # the same strips, and the first pop is the heap's root
+            assert sorted(map(tuple, pop[a:e].tolist())) == sorted(map(tuple, heap[a:e].tolist()))
+            assert tuple(pop[a].tolist()) == tuple(heap[a].tolist())
+    b.close()
+    b2 = _batch(idx, reads)
+    b2.set_soc_heap(heap_off, heap, seed_off, sorted_seeds)
+    b2.chain()
+    b2.sync()
+    got = b2.hsets()
+    for x, y in zip(got, want):
+        assert np.array_equal(x, y)
+    b2.dp()
+    b2.sync()
+    for x, y in zip(b2.mapq_alignments(), want_alns):
+        assert np.array_equal(x, y)
+    b2.close()
+
+
+def test_mapping_quality_alone_on_uploaded_alignments(genome_and_index):
+    """ma_batch_set_alignments: the alignments of a NeedlemanWunsch that ran elsewhere, in its output order -> the
+    MappingQuality kernel alone -> the selection, flags and qualities of the fused path."""
+    g, idx = genome_and_index
+    reads = (sample_reads(g, 400, 150, 7, sub=0.02) + sample_reads(g, 10, 2500, 8, sub=0.01, ins=0.005, dele=0.005)
+             + sample_reads(g, 40, 150, 9, random_frac=1.0))
+    for technique, preset in ((0, "default"), (1, "illumina")):
+        b = _batch(idx, reads, technique=None, preset=preset)
+        b.align()
+        b.sync()
+        off, alns, ops = b.alignments()
+        want = b.mapq_alignments()
+        aligned = b.counts()["aligned_reads"]
+        b.close()
+        b2 = _batch(idx, reads, technique=None, preset=preset)
+        b2.set_alignments(off, alns, ops[: 2 * int(alns["n_ops"].sum())] if len(alns) else ops[:0])
+        b2.sync()
+        got = b2.mapq_alignments()
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)
+        again = b2.alignments()
+        assert np.array_equal(again[0], off) and np.array_equal(again[1][["begin_ref", "end_ref", "score", "n_ops"]],
+                                                                  alns[["begin_ref", "end_ref", "score", "n_ops"]])
+        assert b2.counts()["aligned_reads"] == aligned
+        b2.close()
+
+
+def test_second_dp_stage_on_the_same_batch_does_not_double_the_counters(genome_and_index):
+    """the DP stage owns its counters; running it twice must leave the same counts, sizes and downloads."""
+    g, idx = genome_and_index
+    reads = sample_reads(g, 500, 150, 11, sub=0.02) + sample_reads(g, 6, 4000, 12, sub=0.01, ins=0.005, dele=0.005)
+    b = _batch(idx, reads)
+    b.align()
+    b.sync()
+    c0, r0, k0 = b.counts(), _all_records(b), b.counters()
+    b.dp()
+    b.sync()
+    c1, r1, k1 = b.counts(), _all_records(b), b.counters()
+    assert c0 == c1
+    assert np.array_equal(k0[4:], k1[4:])
+    _same(r1, r0)
+    b.close()
+
+
+def test_task_array_overflow_falls_back_to_the_read_per_lane_kernel(genome_and_index, monkeypatch):
+    """reads made of N only expand the area tree down to single bases, a level then holds more areas than
+    the task array; the levels queued behind the overflow must not touch the unwritten slots and the batch must come out as
+    the read-per-lane kernel computes it."""
+    g, idx = genome_and_index
+    rng = np.random.default_rng(3)
+    reads = [np.full(6000, 4, dtype=np.uint8) for _ in range(3)]
+    mostly_n = np.full(9000, 4, dtype=np.uint8)
+    mostly_n[rng.integers(0, 9000, 300)] = rng.integers(0, 4, 300)
+    reads.append(mostly_n)
+    reads += sample_reads(g, 4, 5000, 13, sub=0.01)
+    monkeypatch.setenv("MA_SEED_TASKS", "0")
+    b = _batch(idx, reads)
+    b.align()
+    b.sync()
+    want = _all_records(b)
+    b.close()
+    monkeypatch.setenv("MA_SEED_TASKS", "1")
+    b = _batch(idx, reads)
+    b.align()
+    b.sync()
+    _same(_all_records(b), want)
+    b.close()
+
+
+@pytest.mark.parametrize("length", [151, 149, 37])
+def test_smem_lists_of_odd_read_lengths(genome_and_index, monkeypatch, length):
+    """the 16-byte SMEM list entries of a lane start at lane * stride; the stride must stay a multiple of 16 bytes
+    for odd read lengths too (151 bp Illumina reads).  Packed and 40-byte entries give the same records."""
+    g, idx = genome_and_index
+    reads = sample_reads(g, 700, length, 14, sub=0.02) + sample_reads(g, 50, length, 15, sub=0.05, n_rate=0.02)
+    monkeypatch.setenv("MA_SMEM_COMPACT", "0")
+    b = _batch(idx, reads, technique=1)
+    b.align()
+    b.sync()
+    want = _all_records(b)
+    b.close()
+    monkeypatch.delenv("MA_SMEM_COMPACT")
+    b = _batch(idx, reads, technique=1)
+    b.align()
+    b.sync()
+    _same(_all_records(b), want)
+    b.close()
