@@ -73,7 +73,7 @@ MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i
 // (one ring row per diagonal)
 MA_HD u64 ksw_p_bytes( i32 qlen, i32 tlen, i32 w )
 {
-    return (u64)( (i64)qlen + tlen - 1 ) * (u64)( ksw_ncol( qlen, tlen, w ) * 16 ) + 16;
+    return (u64)ksw_max_diags( qlen, tlen, w ) * (u64)( ksw_ncol( qlen, tlen, w ) * 16 ) + 16;
 }
 MA_HD u64 ksw_ext_p_bytes( i32 qlen, i32 tlen, int R )
 {
@@ -175,8 +175,19 @@ struct KswJobs
     u32 n;
     const unsigned int* nDev;
     int mode, cls;
-    u64 pMin, pMax; // only jobs with pMin < ksw_p_bytes <= pMax (a class with a few huge jobs is run as two launches)
+    // a class with a few huge jobs is run as two launches: tier 1 takes the jobs with ksw_p_bytes <= pSplit and
+    // ksw_q_lds <= qSplit (scratch and LDS of a full set of waves), tier 2 the others on fewer waves; tier 0 takes all
+    int tier;
+    u64 pSplit;
+    i32 qSplit;
 };
+MA_HD bool ksw_tier_takes( const KswJobs& JB, i32 qlen, i32 tlen, i32 w )
+{
+    if( JB.tier == 0 )
+        return true;
+    const bool small = ksw_p_bytes( qlen, tlen, w ) <= JB.pSplit && ksw_q_lds( qlen, tlen, w ) <= (i64)JB.qSplit;
+    return JB.tier == 1 ? small : !small;
+}
 
 #if defined( MA_KSW_PROF )
 #define KSW_PROF_T( v ) const unsigned long long v = clock64( )
@@ -275,11 +286,8 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( S 
         const KswJobView J = F.view( slot );
         if( JB.mode != 0 && ksw_job_class( J.qlen, J.tlen, J.w ) != JB.cls )
             continue;
-        {
-            const u64 pj = ksw_p_bytes( J.qlen, J.tlen, J.w );
-            if( pj <= JB.pMin || pj > JB.pMax )
-                continue;
-        }
+        if( !ksw_tier_takes( JB, J.qlen, J.tlen, J.w ) )
+            continue;
         KswEz ez;
         u32 nCig = 0;
         u64 cells = 0, path = 0;
@@ -438,29 +446,43 @@ inline u64 ksw_scratch_budget( )
 #define KSW_SCRATCH_BUDGET ksw_scratch_budget( )
 struct KswLaunchPlan
 {
-    u64 p_cap = 0, stride = 0, pMax = ~0ull; // pMax: largest job scratch this launch takes
+    u64 p_cap = 0, stride = 0;
     u32 waves = 0;
+    u32 lds = 0; // dynamic LDS bytes of the launch (register kernels: reversed query of ITS longest job)
+    int tier = 0; // KswJobs::tier
+    u64 region = 0; // byte offset of the launch's scratch region
 };
-inline KswLaunchPlan ksw_plan_launch( u64 p, u64 cigWords, u64 jobs, u64 wantWaves )
+inline KswLaunchPlan ksw_plan_launch( u64 p, u64 cigWords, u64 jobs, u64 wantWaves, u64 budget )
 {
     auto al = []( u64 x ) { return ( x + 255 ) / 256 * 256; };
     KswLaunchPlan L;
     L.p_cap = al( p );
     L.stride = al( L.p_cap + al( cigWords * 4 ) );
     u64 waves = std::max<u64>( 1, std::min<u64>( wantWaves, jobs ) );
-    if( L.stride * waves > KSW_SCRATCH_BUDGET )
-        waves = std::max<u64>( 1, KSW_SCRATCH_BUDGET / L.stride );
+    if( L.stride * waves > budget )
+        waves = std::max<u64>( 1, budget / L.stride );
     L.waves = (u32)waves;
     return L;
 }
-// a second stream for the few huge jobs of a split class: they run beside the other launches (own scratch region)
-// instead of leaving a tail of a few long jobs at the end of the stage
+// Streams of one DP stage.  The kernel classes of a stage are independent of each other, and each is a persistent launch
+// that ends in a tail -- a few waves still working on their last jobs while the rest of the machine idles.  On ONE stream
+// the tails add up (50 kb reads: five launches, five tails); on separate streams, each launch with its own scratch region,
+// the next class's waves take the SIMDs the moment a class's waves retire, so only the last tail of the stage is paid.
+//   lane 0 (the batch's stream): extension kernel classes, then the jobs they handed back, then the LDS kernel
+//   lane 1: k_ksw_pk<5>            lane 2: k_ksw_pk<3>, <2>, <1>            lane 3: the huge tiers of split classes
 struct KswSide
 {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t stream[ 3 ] = { nullptr, nullptr, nullptr };
+    hipEvent_t fork = nullptr, join[ 3 ] = { nullptr, nullptr, nullptr };
+    bool ready( ) const
+    {
+        return stream[ 0 ] && stream[ 1 ] && stream[ 2 ];
+    }
 };
 #define KSW_SIDE_WAVES 512u
+// LDS bytes of a job's query window (ksw_q_lds) up to which it runs in the class's first tier: the register kernels'
+// minimum per-wave LDS, so that 16 waves take 96 KB of a CU's 160 KB and the extension kernels' waves still fit beside them
+#define KSW_Q_SPLIT KSW_REG_LDS
 template <typename FETCH>
 int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizing& SZ, DevBuf& scratch,
                  unsigned int* next, KswOut O, hipStream_t stream, u32* lists = nullptr, u64 list_stride = 0,
@@ -473,115 +495,194 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( nJobs == 0 )
         return 0;
     const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ];
-    KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, KSW_SCRATCH_BUDGET );
+    const bool conc = side && side->ready( ) && lists; // classes on their own streams
     u64 perCu = 32; // waves per CU of the persistent ksw launches (MA_KSW_WAVES_PER_CU: tuning hook)
     if( const char* e = getenv( "MA_KSW_WAVES_PER_CU" ) )
         perCu = (u64)std::max( 1, atoi( e ) );
     const u64 wantWaves = 256ull * perCu;
+    // Concurrent launches each own a scratch region, so each asks only for the waves that can be RESIDENT (registers: 4 / 3
+    // waves per SIMD for the exact kernels, 7 / 4 for the extension kernels): a persistent wave beyond that would only start
+    // when another one retires and its scratch would sit idle until then.
+    const u64 resident[ KSW_N_CLASSES ] = { 256 * 12, 256 * 12, 256 * 12, 256 * 16, 0, 256 * 28, 256 * 16 };
+    auto wantOf = [ & ]( int k ) { return conc ? std::min<u64>( wantWaves, resident[ k ] ) : wantWaves; };
+    // budgets of the scratch regions: lane 0 / 1 / 2 (sequential launches of a lane share its region)
+    const u64 B = KSW_SCRATCH_BUDGET;
+    const u64 budgetOf[ KSW_N_CLASSES ] = { conc ? B / 3 : B, conc ? B / 3 : B, conc ? B / 3 : B, conc ? 5 * B / 12 : B, B, conc ? B / 4 : B, conc ? B / 4 : B };
+    auto ldsOf = []( u64 qBytes ) { return std::max<u32>( (u32)( ( ( std::min<u64>( qBytes, 150000 + 64 ) + 15 ) / 16 ) * 16 ), KSW_REG_LDS ); };
     // pass 0 launches of the register kernels: classes 0..3 (exact), 5 / 6 (extension); [7..10]: classes 0..3 of the
-    // second pass (jobs handed back), [11..14]: the huge jobs of classes 0..3
+    // second pass (jobs handed back), [11..14]: the huge tier of classes 0..3
     KswLaunchPlan LP[ 15 ];
+    u64 pSplit[ 4 ] = { 0, 0, 0, 0 };
     for( int k = 0; k < KSW_N_CLASSES; k++ )
     {
         if( k == 4 || SZ.cls[ k ] == 0 )
             continue;
         const u64 pk = SZ.pc[ k ] ? SZ.pc[ k ] : ( k >= 5 ? std::max( SZ.p, ksw_ext_p_bytes( 256, 2048, k - 4 ) ) : SZ.p );
         const u64 cg = SZ.cigc[ k ] ? SZ.cigc[ k ] : SZ.cig;
-        LP[ k ] = ksw_plan_launch( pk, cg, SZ.cls[ k ], wantWaves );
-        const u64 full = std::min<u64>( wantWaves, SZ.cls[ k ] );
-        if( k < 4 && nextBig && LP[ k ].waves < full && LP[ k ].waves < 256 * 16 )
+        LP[ k ] = ksw_plan_launch( pk, cg, SZ.cls[ k ], wantOf( k ), budgetOf[ k ] );
+        if( k >= 5 )
         {
-            // not even 4 waves per SIMD: the jobs that leave room for that many first, then the rest
-            const u64 room = KSW_SCRATCH_BUDGET / std::min<u64>( full, 256 * 16 );
-            const u64 cgB = al( cg * 4 ) + 512;
-            if( room > cgB + 4096 )
+            LP[ k ].lds = KSW_EXT_LDS;
+            continue;
+        }
+        // LDS bytes of the longest query of the class (ksw_q_lds <= round16( qlen ) + 32; qlen + tlen + 2 <= cigc[k])
+        const u64 qMaxK = std::min<u64>( SZ.qlen, SZ.cigc[ k ] ? SZ.cigc[ k ] : SZ.qlen ) + 48;
+        LP[ k ].lds = ldsOf( qMaxK );
+        const u64 full = std::min<u64>( wantOf( k ), SZ.cls[ k ] );
+        const bool fewWaves = LP[ k ].waves < full && LP[ k ].waves < 256 * 16;
+        // The reversed query of a job lives in LDS, sized for the longest job of the LAUNCH: one 49 kb end extension in a
+        // class of 10^5 gap fills would leave 3 waves per CU to all of them (this, not the tails, held the exact kernels of the
+        // 50 kb workload at a fifth of the issue rate).  Jobs whose query or direction matrix does not leave room for a full
+        // set of waves go to the class's second tier: few waves, own scratch, own stream.
+        const bool splitQ = qMaxK > KSW_Q_SPLIT;
+        bool splitP = false;
+        u64 pSmall = pk;
+        if( fewWaves )
+        {
+            // direction bytes one wave of a full set can have, after its cigar scratch (a job of the small tier has
+            // qlen + tlen <= pSmall / 16 + 1: a diagonal stores 16 bytes at least)
+            const u64 room = budgetOf[ k ] / std::min<u64>( full, 256 * 16 );
+            if( room > 8192 )
             {
-                const u64 pSmall = ( room - cgB ) / 256 * 256;
-                LP[ 11 + k ] = LP[ k ]; // the huge jobs: pMin = pSmall
-                LP[ k ] = ksw_plan_launch( pSmall, cg, SZ.cls[ k ], wantWaves );
-                LP[ k ].pMax = pSmall;
+                pSmall = std::min<u64>( pk, ( room - room / 5 - 512 ) / 256 * 256 ); // stride = p + 4 * (p / 16 + 3) + padding
+                splitP = pSmall < pk;
             }
+        }
+        if( nextBig && ( splitP || splitQ ) )
+        {
+            LP[ 11 + k ] = LP[ k ]; // the huge jobs: what the small tier leaves
+            LP[ 11 + k ].tier = 2;
+            if( conc )
+                LP[ 11 + k ].waves = std::min<u32>( LP[ 11 + k ].waves, KSW_SIDE_WAVES );
+            const u64 cgSmall = splitP ? std::min<u64>( cg, pSmall / 16 + 3 ) : cg;
+            LP[ k ] = ksw_plan_launch( pSmall, cgSmall, SZ.cls[ k ], wantOf( k ), budgetOf[ k ] );
+            LP[ k ].tier = 1;
+            LP[ k ].lds = ldsOf( std::min<u64>( qMaxK, KSW_Q_SPLIT ) );
+            pSplit[ k ] = pSmall;
         }
     }
     if( nExt )
         for( int k = 0; k < 4; k++ )
-            LP[ 7 + k ] = ksw_plan_launch( SZ.pRedo ? SZ.pRedo : SZ.p, SZ.cigRedo ? SZ.cigRedo : SZ.cig, std::min<u64>( nExt, 256 * 4 ), wantWaves );
-    u64 need = SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0;
-    u64 needSide = 0;
-    const bool useSide = side && side->stream;
-    for( int k = 0; k < 15; k++ )
-    {
-        if( k >= 11 && useSide && LP[ k ].waves )
         {
-            LP[ k ].waves = std::min<u32>( LP[ k ].waves, KSW_SIDE_WAVES );
-            needSide = std::max<u64>( needSide, LP[ k ].stride * LP[ k ].waves );
+            LP[ 7 + k ] = ksw_plan_launch( SZ.pRedo ? SZ.pRedo : SZ.p, SZ.cigRedo ? SZ.cigRedo : SZ.cig, std::min<u64>( nExt, 256 * 4 ), wantWaves,
+                                           conc ? B / 4 : B );
+            LP[ 7 + k ].lds = ldsOf( std::min<u64>( SZ.qlen, SZ.cigRedo ? SZ.cigRedo : SZ.qlen ) + 48 );
         }
-        else
-            need = std::max<u64>( need, LP[ k ].stride * LP[ k ].waves );
-    }
+    KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, conc ? B / 4 : B );
+    // scratch regions.  Sequential mode: one region for all launches (+ one for the huge tiers when they have a stream).
+    // Concurrent mode: lane 0 = extension classes, handed-back jobs, LDS kernel; lane 1 = class 3; lane 2 = classes 0..2;
+    // lane 3 = huge tiers.
+    auto laneOf = [ & ]( int i ) -> int {
+        if( !conc )
+            return i >= 11 && side && side->stream[ 2 ] ? 3 : 0;
+        if( i >= 11 )
+            return 3;
+        if( i == 3 )
+            return 1;
+        if( i <= 2 )
+            return 2;
+        return 0;
+    };
+    u64 needLane[ 4 ] = { SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0, 0, 0, 0 };
+    for( int i = 0; i < 15; i++ )
+        if( LP[ i ].waves )
+            needLane[ laneOf( i ) ] = std::max<u64>( needLane[ laneOf( i ) ], LP[ i ].stride * LP[ i ].waves );
     // the per-wave scratch follows the largest jobs of the batch, which vary a lot from batch to batch for long
     // reads: once it is in the GB range take the whole budget so that later batches never re-allocate mid-step
-    if( need > ( 2ull << 30 ) )
-        need = std::max<u64>( need, KSW_SCRATCH_BUDGET );
-    need = al( need );
-    if( scratch.reserve( need + needSide ) )
-        return 1;
-    const u32 ldsReg = std::max<u32>( (u32)( ( ( std::min<u64>( SZ.qlen, 150000 ) + 15 ) / 16 ) * 16 + 64 ), KSW_REG_LDS );
-    if( ldsReg > 48 * 1024 )
+    if( !conc && needLane[ 0 ] > ( 2ull << 30 ) )
+        needLane[ 0 ] = std::max<u64>( needLane[ 0 ], B );
+    if( conc && needLane[ 0 ] + needLane[ 1 ] + needLane[ 2 ] > ( 2ull << 30 ) )
     {
-        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReg ) );
-        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReg ) );
-        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReg ) );
-        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsReg ) );
+        needLane[ 0 ] = std::max<u64>( needLane[ 0 ], B / 4 );
+        needLane[ 1 ] = std::max<u64>( needLane[ 1 ], 5 * B / 12 );
+        needLane[ 2 ] = std::max<u64>( needLane[ 2 ], B / 3 );
+    }
+    u64 laneBase[ 4 ], total = 0;
+    for( int l = 0; l < 4; l++ )
+    {
+        laneBase[ l ] = total;
+        total += al( needLane[ l ] );
+    }
+    if( scratch.reserve( total ) )
+        return 1;
+    u32 ldsMax = 0;
+    for( int i = 0; i < 15; i++ )
+        if( i != 5 && i != 6 )
+            ldsMax = std::max( ldsMax, LP[ i ].lds );
+    if( ldsMax > 48 * 1024 )
+    {
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsMax ) );
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsMax ) );
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsMax ) );
+        MA_HIP( hipFuncSetAttribute( (const void*)k_ksw_pk<FETCH, KSW_S3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsMax ) );
     }
     uint8_t* base = scratch.as<uint8_t>( );
     u32* redo = lists ? lists + (u64)KSW_N_CLASSES * list_stride : nullptr;
-    // the huge jobs run from the start of the stage when they have their own stream and scratch region
-    if( useSide && needSide )
+    hipStream_t laneStream[ 4 ] = { stream, conc ? side->stream[ 0 ] : stream, conc ? side->stream[ 1 ] : stream,
+                                    side && side->stream[ 2 ] ? side->stream[ 2 ] : stream };
+    bool laneUsed[ 4 ] = { true, false, false, false };
+    for( int i = 0; i < 15; i++ )
+        if( LP[ i ].waves && laneStream[ laneOf( i ) ] != stream )
+            laneUsed[ laneOf( i ) ] = true;
+    const bool forked = laneUsed[ 1 ] || laneUsed[ 2 ] || laneUsed[ 3 ];
+    if( forked )
     {
         MA_HIP( hipEventRecord( side->fork, stream ) );
-        MA_HIP( hipStreamWaitEvent( side->stream, side->fork, 0 ) );
+        for( int l = 1; l < 4; l++ )
+            if( laneUsed[ l ] )
+                MA_HIP( hipStreamWaitEvent( laneStream[ l ], side->fork, 0 ) );
     }
-    auto launchPass = [ & ]( int pass ) -> int {
-        if( pass == 1 && !nExt )
-            return 0;
-        const bool onSide = pass == 2 && useSide && needSide;
-        hipStream_t st = onSide ? side->stream : stream;
-        uint8_t* sbase = onSide ? base + need : base;
-        auto launch = [ & ]( int k, auto kernel ) {
-            const KswLaunchPlan& L = LP[ pass == 0 ? k : ( pass == 1 ? 7 + k : 11 + k ) ];
-            if( L.waves == 0 )
-                return;
-            KswJobs JB;
-            JB.list = pass == 1 ? redo : ( lists ? lists + (u64)k * list_stride : nullptr );
-            JB.n = lists ? (u32)SZ.cls[ k ] : nSlots;
-            JB.nDev = nRedo;
-            JB.mode = pass == 1 ? 2 : ( lists ? 0 : 1 );
-            JB.cls = k;
-            JB.pMin = pass == 2 ? LP[ k ].pMax : 0;
-            JB.pMax = L.pMax;
-            unsigned int* nx = pass == 0 ? next + k : ( pass == 1 ? next + 7 + k : nextBig + k );
-            hipLaunchKernelGGL( kernel, dim3( L.waves ), dim3( 64 ), ldsReg, st, F, SC, JB, nx, sbase, L.stride, L.p_cap, ldsReg, O );
-        };
-        launch( 0, k_ksw_pk<FETCH, KSW_S0> );
-        launch( 1, k_ksw_pk<FETCH, KSW_S1> );
-        launch( 2, k_ksw_pk<FETCH, KSW_S2> );
-        launch( 3, k_ksw_pk<FETCH, KSW_S3> );
-        return 0;
+    // pass 0: the classes' own jobs; pass 1: whatever the extension kernel handed back (usually nothing); pass 2: the huge
+    // tier of a class that was split
+    auto launchPk = [ & ]( int pass, int k ) {
+        const int i = pass == 0 ? k : ( pass == 1 ? 7 + k : 11 + k );
+        const KswLaunchPlan& L = LP[ i ];
+        if( L.waves == 0 )
+            return;
+        KswJobs JB;
+        JB.list = pass == 1 ? redo : ( lists ? lists + (u64)k * list_stride : nullptr );
+        JB.n = lists ? (u32)SZ.cls[ k ] : nSlots;
+        JB.nDev = nRedo;
+        JB.mode = pass == 1 ? 2 : ( lists ? 0 : 1 );
+        JB.cls = k;
+        JB.tier = pass == 1 ? 0 : L.tier;
+        JB.pSplit = pSplit[ k ];
+        JB.qSplit = KSW_Q_SPLIT;
+        unsigned int* nx = pass == 0 ? next + k : ( pass == 1 ? next + 7 + k : nextBig + k );
+        hipStream_t st = laneStream[ laneOf( i ) ];
+        uint8_t* sbase = base + laneBase[ laneOf( i ) ];
+        switch( k )
+        {
+        case 0:
+            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S0> ), dim3( L.waves ), dim3( 64 ), L.lds, st, F, SC, JB, nx, sbase, L.stride, L.p_cap, L.lds, O );
+            break;
+        case 1:
+            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S1> ), dim3( L.waves ), dim3( 64 ), L.lds, st, F, SC, JB, nx, sbase, L.stride, L.p_cap, L.lds, O );
+            break;
+        case 2:
+            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S2> ), dim3( L.waves ), dim3( 64 ), L.lds, st, F, SC, JB, nx, sbase, L.stride, L.p_cap, L.lds, O );
+            break;
+        default:
+            hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S3> ), dim3( L.waves ), dim3( 64 ), L.lds, st, F, SC, JB, nx, sbase, L.stride, L.p_cap, L.lds, O );
+        }
     };
-    if( useSide && needSide )
-        launchPass( 2 );
+    // longest jobs first: the huge tiers, then the wide classes; the extension kernels' small jobs fill the tails
+    for( int k = 3; k >= 0; k-- )
+        launchPk( 2, k );
+    if( conc )
+        for( int k = 3; k >= 0; k-- )
+            launchPk( 0, k );
     if( SZ.cls[ 5 ] )
         hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), dim3( LP[ 5 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
-                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base, LP[ 5 ].stride, LP[ 5 ].p_cap, KSW_EXT_LDS,
+                            lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base + laneBase[ 0 ], LP[ 5 ].stride, LP[ 5 ].p_cap, KSW_EXT_LDS,
                             O, redo, nRedo );
     if( SZ.cls[ 6 ] )
         hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), dim3( LP[ 6 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
-                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base, LP[ 6 ].stride, LP[ 6 ].p_cap, KSW_EXT_LDS,
+                            lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base + laneBase[ 0 ], LP[ 6 ].stride, LP[ 6 ].p_cap, KSW_EXT_LDS,
                             O, redo, nRedo );
-    // pass 0: the classes' own jobs; pass 1: whatever the extension kernel handed back (usually nothing); pass 2:
-    // the huge jobs of a class that was split, unless they already run on the side stream
-    launchPass( 0 );
+    if( !conc )
+        for( int k = 0; k < 4; k++ )
+            launchPk( 0, k );
     if( SZ.cls[ 4 ] ) // a handed-back job always fits a register kernel
     {
         KswJobs JB;
@@ -590,23 +691,26 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         JB.nDev = nRedo;
         JB.mode = lists ? 0 : 1;
         JB.cls = 4;
-        JB.pMin = 0;
-        JB.pMax = ~0ull;
-        plan.ws.base = base;
+        JB.tier = 0;
+        JB.pSplit = 0;
+        JB.qSplit = 0;
+        plan.ws.base = base + laneBase[ 0 ];
         if( plan.lds_bytes > 48 * 1024 )
             MA_HIP( hipFuncSetAttribute( (const void*)k_ksw<FETCH>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)plan.lds_bytes ) );
         hipLaunchKernelGGL( k_ksw<FETCH>, dim3( plan.waves ), dim3( 64 ), plan.lds_bytes, stream, F, SC, JB, next + 4,
                             plan.ws, plan.lds_bytes, O );
     }
-    launchPass( 1 );
-    if( !( useSide && needSide ) )
-        launchPass( 2 );
-    if( useSide && needSide )
-    {
-        MA_HIP( hipEventRecord( side->join, side->stream ) );
-        MA_HIP( hipStreamWaitEvent( stream, side->join, 0 ) );
-    }
+    if( nExt )
+        for( int k = 0; k < 4; k++ )
+            launchPk( 1, k ); // on the batch's stream, behind the extension kernels that fill the list
+    if( forked )
+        for( int l = 1; l < 4; l++ )
+            if( laneUsed[ l ] )
+            {
+                MA_HIP( hipEventRecord( side->join[ l - 1 ], laneStream[ l ] ) );
+                MA_HIP( hipStreamWaitEvent( stream, side->join[ l - 1 ], 0 ) );
+            }
     MA_HIP( hipGetLastError( ) );
     return 0;
 }

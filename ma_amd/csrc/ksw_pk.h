@@ -111,18 +111,38 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
               K_FX2 = pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ), K_FY2 = pk_sub( K_TY2, LEFT ? 0u : 0x00010001u );
     const u32 K_ONES = pk_opaque( 0x00010001u );
 
-    for( i32 t = lane; t < qrBytes; t += 64 )
-        qr[ t ] = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
+    // The reversed query in LDS.  A diagonal r reads the bases r - t of its cells, and the loop below ends after
+    // ksw_max_diags diagonals at the latest, so only the first ksw_max_diags bases of the query -- the END of the reversed
+    // array -- can ever be read: a 20 kb query against 1000 padded target bases (the end extension of a long read) keeps
+    // 2.7 KB in LDS instead of 20.  Layout: head = qr[0, 64) (what the target view below can reach), tail = qr[qLo, qrBytes)
+    // at LDS offset 64; qrT[i] addresses the tail with the original index.
+    const i32 qLo = [ & ]( ) {
+        const i32 lo = qlen - 1 - (i32)ksw_max_diags( qlen, tlen, J.w ) - 48;
+        return lo > 64 ? ( lo & ~15 ) : 0;
+    }( );
+    const uint8_t* qrT = qLo ? qr + 64 - qLo : qr;
+    if( qLo == 0 )
+        for( i32 t = lane; t < qrBytes; t += 64 )
+            qr[ t ] = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
+    else
+    {
+        qr[ lane ] = lane < qlen ? (uint8_t)qbase( qlen - 1 - lane ) : (uint8_t)0;
+        for( i32 t = qLo + lane; t < qrBytes; t += 64 )
+            qr[ 64 + t - qLo ] = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
+    }
     __syncthreads( );
 
-    // target byte as the reference's contiguous scratch sees it: sf[t] for t < L, then the qr region
+    // target byte as the reference's contiguous scratch sees it: sf[t] for t < L, then the qr region (a score profile
+    // never reaches further than 15 bytes into it: pEnd <= en0 + 16)
     auto tgtAt = [ & ]( i32 tt ) -> u32 {
         if( tt < tlen )
             return (u32)tbase( tt ) & 0xffu;
         if( tt < L )
             return 0u;
         const i32 k = tt - L;
-        return k < qrBytes ? (u32)qr[ k ] : 0u;
+        if( k >= qrBytes )
+            return 0u;
+        return k < 64 || qLo == 0 ? (u32)qr[ k ] : ( k >= qLo ? (u32)qrT[ k ] : 0u );
     };
 
     u32 U[ R ], V[ R ], X[ R ], Y[ R ], X2[ R ], Y2[ R ], Sp[ R ], T[ R ];
@@ -258,7 +278,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         u32 QB[ R ];
 #pragma unroll
         for( int s = 0; s < R; s++ )
-            QB[ s ] = (u32)qr[ qoff + TT[ s ] ] | (u32)qr[ qoff + TT[ s ] + 1 ] << 16;
+            QB[ s ] = (u32)qrT[ qoff + TT[ s ] ] | (u32)qrT[ qoff + TT[ s ] + 1 ] << 16;
         __builtin_amdgcn_sched_barrier( 0 );
 #pragma unroll
         for( int s = 0; s < R; s++ )

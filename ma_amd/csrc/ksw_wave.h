@@ -69,6 +69,27 @@ MA_HD i64 ksw_ncol( i32 qlen, i32 tlen, i32 w ) // n_col_ (kswcpp_core.h:400-402
     return ( ( n < w + 1 ? n : w + 1 ) + 15 ) / 16 + 1;
 }
 
+// Diagonals kswcpp can run before the band leaves the rectangle (kswcpp_core.h:541-553: the loop ends at the first r with
+// st0 > en0): (r - w + 1) >> 1 > tlen - 1 from r = 2 tlen + w - 1 on, r - qlen + 1 > (r + w) >> 1 from r ~ 2 qlen + w on.
+// An end extension of a long read -- query = the rest of the read, target = 1000 padded reference bases, band 512 -- runs
+// 2 500 diagonals however long the query is; direction-matrix scratch and the query window in LDS follow THIS bound.
+MA_HD i64 ksw_max_diags( i32 qlen, i32 tlen, i32 w )
+{
+    if( w < 0 )
+        w = tlen > qlen ? tlen : qlen;
+    const i64 nd = (i64)qlen + tlen - 1;
+    const i64 lim = 2 * (i64)( qlen < tlen ? qlen : tlen ) + w + 2;
+    return nd < lim ? nd : lim;
+}
+// bytes of LDS the reversed query of a job takes in the register kernel (ksw_pk.h): a 64-byte head plus the window of the
+// bases a diagonal can reach
+MA_HD i64 ksw_q_lds( i32 qlen, i32 tlen, i32 w )
+{
+    const i64 all = ( ( (i64)qlen + 15 ) / 16 ) * 16 + 32;
+    const i64 win = ksw_max_diags( qlen, tlen, w ) + 64 + 64 + 48;
+    return all < win ? all : win;
+}
+
 struct KswBounds
 {
     i32 st, en, st0, en0;

@@ -1155,6 +1155,19 @@ struct PipeFetch
 };
 } // namespace
 
+// Longest jobs first: a persistent launch whose waves pull jobs from a queue ends when its LAST job ends, and a long job
+// taken late is a tail with one busy wave.  The lists of the exact register kernels (long-read batches: 10^4..10^6 jobs of
+// 10^3..10^8 cells) are therefore sorted by descending direction-matrix size before the launch (LPT rule).
+__global__ void k_job_cost( PipeFetch F, const u32* list, u32 n, u32* key )
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    const KswJobView J = F.view( list[ i ] );
+    const u64 c = ksw_p_bytes( J.qlen, J.tlen, J.w ) >> 6;
+    key[ i ] = c > 0xffffffffull ? 0xffffffffu : (u32)c;
+}
+
 // ops capacity of a set: |Q| + sum of its jobs' cigar lengths + 8 * seeds + 16 (see nw.h)
 __global__ void k_ops_caps( const HSet* sets, const SetInfo* info, const u32* set_read, const u64* roff,
                             const ma_ez* ez, u32 n_sets, u64* caps )
@@ -1366,6 +1379,7 @@ struct ma_batch
     // dp
     DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, clsLists, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
     DevBuf outCnt, outOps, outAlnOff, outOpsOff, outAlns, outOpsPairs; // packed results (get_alns)
+    DevBuf sortKey, sortKey2, sortVal2; // longest-job-first order of the DP job lists
     u64 cigPoolCap = 0, cigPoolMin = 0, nOpsCap = 0, nJobSlots = 0;
     KswSide kswSide; // created on first use
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
@@ -1486,11 +1500,16 @@ int ma_batch_destroy( ma_batch* b )
             (void)hipEventDestroy( b->ev[ i ] );
     if( b->waitEv )
         (void)hipEventDestroy( b->waitEv );
-    if( b->kswSide.stream )
+    if( b->kswSide.fork )
     {
-        (void)hipStreamDestroy( b->kswSide.stream );
         (void)hipEventDestroy( b->kswSide.fork );
-        (void)hipEventDestroy( b->kswSide.join );
+        for( int l = 0; l < 3; l++ )
+        {
+            if( b->kswSide.stream[ l ] )
+                (void)hipStreamDestroy( b->kswSide.stream[ l ] );
+            if( b->kswSide.join[ l ] )
+                (void)hipEventDestroy( b->kswSide.join[ l ] );
+        }
     }
     delete b;
     return 0;
@@ -2143,6 +2162,16 @@ static bool dp_exclusive( )
     return on;
 }
 
+// MA_DP_ONE_STREAM=1: all kernel classes of a DP stage back to back on the batch's stream, as before round 3 (A/B hook)
+static bool dp_one_stream( )
+{
+    static const bool on = []( ) {
+        const char* e = getenv( "MA_DP_ONE_STREAM" );
+        return e && atoi( e ) != 0;
+    }( );
+    return on;
+}
+
 int ma_dp_batch( ma_batch* b )
 {
     if( !b || b->stage_done < 3 )
@@ -2245,15 +2274,40 @@ int ma_dp_batch( ma_batch* b )
             O.cig_words = c + CTR_CIG_WORDS;
             {
                 EvTimer t( b, 4 );
-                if( !b->kswSide.stream && b->max_qlen > 20000 ) // only reads that long produce jobs for the second tier
+                // long reads: every kernel class on its own stream (ksw_launch.h), longest jobs first
+                const bool longReads = b->max_qlen > 254 && !dp_one_stream( );
+                if( longReads && !b->kswSide.ready( ) )
                 {
-                    MA_HIP( hipStreamCreateWithFlags( &b->kswSide.stream, hipStreamNonBlocking ) );
                     MA_HIP( hipEventCreateWithFlags( &b->kswSide.fork, hipEventDisableTiming ) );
-                    MA_HIP( hipEventCreateWithFlags( &b->kswSide.join, hipEventDisableTiming ) );
+                    for( int l = 0; l < 3; l++ )
+                    {
+                        MA_HIP( hipStreamCreateWithFlags( &b->kswSide.stream[ l ], hipStreamNonBlocking ) );
+                        MA_HIP( hipEventCreateWithFlags( &b->kswSide.join[ l ], hipEventDisableTiming ) );
+                    }
                 }
+                if( longReads )
+                    for( int k = 0; k < 4; k++ )
+                    {
+                        const u64 nk = S.cls[ k ];
+                        if( nk < 2048 )
+                            continue;
+                        u32* list = b->clsLists.as<u32>( ) + (u64)k * nSlots;
+                        if( b->sortKey.reserve( nk * 4 ) || b->sortKey2.reserve( nk * 4 ) || b->sortVal2.reserve( nk * 4 ) )
+                            return 1;
+                        hipLaunchKernelGGL( k_job_cost, dim3( (unsigned)( ( nk + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, F, list, (u32)nk,
+                                            b->sortKey.as<u32>( ) );
+                        size_t tb = 0;
+                        MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( nullptr, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
+                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 32, b->stream ) );
+                        if( b->cubTmp.reserve( tb + 256 ) )
+                            return 1;
+                        MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( b->cubTmp.p, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
+                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 32, b->stream ) );
+                        MA_HIP( hipMemcpyAsync( list, b->sortVal2.p, nk * 4, hipMemcpyDeviceToDevice, b->stream ) );
+                    }
                 if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
                                  b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ), (unsigned int*)( c + CTR_NEXT_BIG ),
-                                 &b->kswSide ) )
+                                 longReads ? &b->kswSide : nullptr ) )
                     return 1;
                 MA_HIP( hipGetLastError( ) );
             }
