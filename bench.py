@@ -7,12 +7,13 @@ resident in HBM.  The metric is quoted on "150bp & 10kb" reads, so the default i
 GRCh38-sized synthetic genome (24 contigs, 3.09 Gnt, planted repeat families) and in one process per GPU:
 
   C2  150 bp Illumina-like reads (0.5 % substitutions), 1 M reads per step            -> `value` (headline, history)
-  C3  10 kb CCS-like reads (0.4 / 0.3 / 0.3 % sub / ins / del), 200 k reads per step
-  C5  50 kb ONT-like reads (3 / 3 / 4 %), 20 k reads per step (stress shape)
+  C3  10 kb CCS-like reads (0.4 / 0.3 / 0.3 % sub / ins / del), 5 steps of 200 k reads = the 1 M reads of configs[2]
+  C5  50 kb ONT-like reads (3 / 3 / 4 %), 4 steps of 20 k reads (stress shape)
 
 each with its own timed region (barrier + synchronize on both sides, MAX over ranks), roofline block, CPU baseline (the
 compiled reference on the host cores, N = 1 only) and a parity check of the GPU results against the oracle.  The line's
-top-level value / ms_per_step / roofline / cpu_baseline are those of C2; config.workloads[] carries all three.
+top-level value / ms_per_step / roofline are those of ONE leg of C2 (several batches in flight when that is faster, else one
+batch at a time; config.value_is says which), cpu_baseline is C2's; config.workloads[] carries all three workloads.
 --workload {150bp,10kb,50kb} or an explicit --read-len runs a single workload.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used only for the barrier and the
@@ -47,11 +48,50 @@ WORKLOADS = {
     # name: read_len, sub, ins, dele, reads seed, reads/step, default steps, warm-up, CPU sample (reads)
     "150bp": dict(read_len=150, sub=0.005, ins=0.0, dele=0.0, seed=11, reads_per_step=1000000, steps=None, warmup=None,
                   cpu_sample=None, baseline_config="configs[1] (C2)"),
-    "10kb": dict(read_len=10000, sub=0.004, ins=0.003, dele=0.003, seed=12, reads_per_step=200000, steps=3, warmup=1,
+    "10kb": dict(read_len=10000, sub=0.004, ins=0.003, dele=0.003, seed=12, reads_per_step=200000, steps=5, warmup=1,
                  cpu_sample=15360, baseline_config="configs[2] (C3)"),
-    "50kb": dict(read_len=50000, sub=0.03, ins=0.03, dele=0.04, seed=13, reads_per_step=20000, steps=2, warmup=1,
+    "50kb": dict(read_len=50000, sub=0.03, ins=0.03, dele=0.04, seed=13, reads_per_step=20000, steps=4, warmup=1,
                  cpu_sample=2048, baseline_config="configs[4] (C5 shape, one GPU)"),
 }
+
+
+def kernel_source_hash():
+    """Identifies the build of the kernels: sha256 over ma_amd/csrc/*.{h,hip} (sorted by name), first 16 hex digits.  The
+    PMC passes under profiles/ carry the hash of the sources they were collected with (tools/pmc_summarize.py)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ma_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_replay(read_len, reads_per_step, preset, genome_scale, stage):
+    """HBM bytes and VALU instructions per launch of `stage` from the committed rocprofv3 PMC passes of the same workload
+    (they are not measured in this process).  Refused -- null + reason -- when no pass of this workload is committed or when
+    the pass was collected with other kernel sources than the ones libma_amd.so is built from now."""
+    cur = kernel_source_hash()
+    reason = "no PMC pass of this workload under profiles/"
+    for src in (os.path.join("profiles", "r03_pmc_traffic.json"), os.path.join("profiles", "r02_pmc_traffic.json")):
+        try:
+            with open(os.path.join(ROOT, src)) as f:
+                doc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for pt in doc.get("workloads", []):
+            if pt.get("workload_key") != [read_len, reads_per_step, preset, genome_scale]:
+                continue
+            have = pt.get("kernel_source_hash")
+            if have != cur:
+                reason = "%s was collected with kernel sources %s, the library is built from %s: re-run tools/collect_profiles.sh" % (
+                    src, have or "(unrecorded)", cur)
+                continue
+            return {"traffic": pt["bytes_per_launch"].get(stage), "valu": pt.get("valu_wave_insts_per_launch", {}).get(stage),
+                    "source": src, "refused": None}
+    return {"traffic": None, "valu": None, "source": None, "refused": reason}
 
 
 def load_calibration():
@@ -192,7 +232,7 @@ def run_workload(E, name, wl, args):
         raise RuntimeError("setting up %d batch(es) of workload %s failed on %s: %s" % (
             NB, name, "this rank" if setup_err is not None else "another rank", setup_err))
 
-    acc = [dict(kms=np.zeros(8), ctr=np.zeros(8), segs=0, aligned=0, err=None) for _ in range(NB)]
+    acc = [dict(kms=np.zeros(8), ctr=np.zeros(8), segs=0, aligned=0, err=None, wall=[]) for _ in range(NB)]
 
     def worker(i):
         try:
@@ -203,6 +243,7 @@ def run_workload(E, name, wl, args):
                 step(i, k)
                 bt = batches[i][0]
                 km = bt.kernel_ms().astype(np.float64)
+                a["wall"].append((time.perf_counter() - tk) * 1e3)
                 if os.environ.get("MA_BENCH_VERBOSE"):
                     print("%s step %d wall %.1f ms, stage ms %s" % (name, k, (time.perf_counter() - tk) * 1e3,
                                                                     np.round(km[:6], 2).tolist()), file=sys.stderr, flush=True)
@@ -234,6 +275,7 @@ def run_workload(E, name, wl, args):
         if a["err"] is not None:
             raise a["err"]
     kms = sum(a["kms"] for a in acc)
+    walls = [w for a in acc for w in a["wall"]]
     ctr = sum(a["ctr"] for a in acc)
     segs = sum(a["segs"] for a in acc)
     aligned = sum(a["aligned"] for a in acc)
@@ -252,20 +294,13 @@ def run_workload(E, name, wl, args):
     ach = (alg[dom] / Kd) / avg_s / 1e9 if avg_s > 0 else 0.0
     # PMC-derived quantities are NOT measured in this process: they come from the committed rocprofv3 passes of the same
     # workload (tools/collect_profiles.sh) and carry their source; null when no pass of this workload is committed
-    traffic = None
-    valu = None
-    src = os.path.join("profiles", "r02_pmc_traffic.json")
-    try:
-        with open(os.path.join(ROOT, src)) as f:
-            for pt in json.load(f).get("workloads", []):
-                if pt.get("workload_key") == [read_len, B_total, preset, args.genome_scale]:
-                    traffic = pt["bytes_per_launch"].get(STAGES[dom])
-                    valu = pt.get("valu_wave_insts_per_launch", {}).get(STAGES[dom])
-    except (OSError, ValueError, KeyError):
-        pass
+    pmc = pmc_replay(read_len, B_total, preset, args.genome_scale, STAGES[dom])
+    traffic, valu, src = pmc["traffic"], pmc["valu"], pmc["source"]
     hbm = {"achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
            "traffic": traffic, "traffic_source": src if traffic is not None else None,
            "algorithmic_bytes_per_launch": int(alg[dom] / Kd)}
+    if pmc["refused"]:
+        hbm["pmc_replay_refused"] = pmc["refused"]
     roofline = {"kernel": STAGES[dom], "avg_launch_ms": round(kms[dom] / Kd, 3)}
     if dom == 4 and valu and avg_s > 0:
         # the DP kernels are bound by VALU issue, not by HBM: wave-level VALU instructions of the committed PMC pass over
@@ -299,7 +334,10 @@ def run_workload(E, name, wl, args):
                 n_global, read_len, 100 * wl["sub"], 100 * wl["ins"], 100 * wl["dele"], preset, B_total,
                 "per GPU" if args.scaling == "weak" else "over all GPUs"),
             "value": round(aligned_all / dt, 1), "unit": "aligned reads/s", "aligned_reads": int(aligned_all), "steps": K, "warmup": W,
-            "ms_per_step": round(dt / Kd * 1e3, 3), "reads_per_s_total": round(n_global / dt, 1),
+            "ms_per_step": round(dt / Kd * 1e3, 3),
+            # wall time of the single steps on this rank (with several batches in flight: of a step on its own stream)
+            "step_ms_min": round(min(walls), 3) if walls else None, "step_ms_max": round(max(walls), 3) if walls else None,
+            "reads_per_s_total": round(n_global / dt, 1),
             "gbases_per_s": round(total_bases * (world if args.scaling == "weak" else 1) / dt / 1e9, 3),
             "roofline": roofline, "cpu_baseline": cpu,
         }
@@ -492,10 +530,13 @@ def main():
                 E.torch.cuda.empty_cache()
             if r is not None:
                 if r2 is not None:
+                    rf2 = dict(r2["roofline"])
+                    rf2["leg"] = ("%d batches in flight: a kernel's launch time includes the share of the chip the other batches' "
+                                  "kernels took meanwhile" % nfl)
                     r["overlapped"] = {"batches_in_flight": nfl, "value": r2["value"], "unit": r2["unit"], "steps": r2["steps"],
-                                       "ms_per_step": r2["ms_per_step"], "gbases_per_s": r2["gbases_per_s"],
-                                       "aligned_reads": r2["aligned_reads"],
-                                       "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"]}
+                                       "ms_per_step": r2["ms_per_step"], "step_ms_min": r2["step_ms_min"], "step_ms_max": r2["step_ms_max"],
+                                       "gbases_per_s": r2["gbases_per_s"], "aligned_reads": r2["aligned_reads"],
+                                       "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"], "roofline": rf2}
                 else:
                     r["overlapped"] = {"batches_in_flight": nfl, "error": err}
         if r is not None:
@@ -528,7 +569,8 @@ def main():
                                       "batch(es) in flight per GPU" % (E.world, args.scaling,
                                                                       ov["batches_in_flight"] if use_ov else max(1, args.inflight)),
                        "workloads": results, "boundary": boundary},
-            "roofline": head["roofline"], "cpu_baseline": head["cpu_baseline"],
+            # of the leg `value` comes from; the undisturbed one-batch-at-a-time launches are in workloads[0].roofline
+            "roofline": ov["roofline"] if use_ov else head["roofline"], "cpu_baseline": head["cpu_baseline"],
         }
         print(json.dumps(out))
     E.close()

@@ -11,7 +11,7 @@
 //   ma_boundary_bench <index prefix> <reads> <read length> <preset> <device> [graph threads]
 //
 // build: g++ -std=c++17 -O2 -Iinclude -Ima_amd/host examples/ma_boundary_bench.cpp -Lma_amd -lma_amd -lpthread
-#include "ma_sam.h"
+#include "ma_batch_nodes.h"
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -30,6 +30,10 @@ struct CountingSink : public OutStream
 {
     std::atomic<uint64_t> uiBytes{ 0 };
     void put( const char*, size_t n ) override
+    {
+        uiBytes += n;
+    }
+    void write( const char*, size_t n ) override
     {
         uiBytes += n;
     }
@@ -111,7 +115,7 @@ int main( int argc, char** argv )
         {
             BatchAligner xAligner( xParams );
             xAligner.uiInflight = uiInflight;
-            xAligner.execute( pFM, std::make_shared<ReadVec>( pReads->begin( ), pReads->begin( ) + std::min<size_t>( n, 4096 ) ) ); // warm-up
+            xAligner.execute( pFM, pReads ); // warm-up: every engine allocates its device pools and page-locked staging once
             pRes = xAligner.execute( pFM, pReads );
             const AlignerTiming& T = xAligner.xLast;
             char buf[ 512 ];
@@ -121,6 +125,84 @@ int main( int argc, char** argv )
                       sBatch.empty( ) ? "" : ", ", uiInflight, n / T.fWall, T.fWall, T.fH2D, T.fKernels, T.fD2H, T.fContainers,
                       (unsigned long long)T.uiBatches, (unsigned long long)T.uiAlignedReads );
             sBatch += buf;
+        }
+        // ---- leg 1b: the same with the results left flat (no Alignment containers), 1 .. 4 device batches in flight
+        std::string sFlat;
+        std::shared_ptr<BatchAligner::TP_FLAT> pFlat;
+        for( size_t uiInflight : { (size_t)1, (size_t)2, (size_t)3, (size_t)4 } )
+        {
+            BatchAligner xAligner( xParams );
+            xAligner.uiInflight = uiInflight;
+            xAligner.executeFlat( pFM, pReads ); // warm-up: engines size their buffers, page-locked arenas are touched
+            pFlat = xAligner.executeFlat( pFM, pReads );
+            const AlignerTiming& T = xAligner.xLast;
+            char buf[ 512 ];
+            snprintf( buf, sizeof( buf ),
+                      "%s\"inflight_%zu\": {\"reads_per_s\": %.1f, \"wall_s\": %.4f, \"gather_s\": %.4f, \"h2d_s\": %.4f, \"kernels_s\": %.4f, "
+                      "\"d2h_s\": %.4f, \"device_batches\": %llu, \"aligned_reads\": %llu}",
+                      sFlat.empty( ) ? "" : ", ", uiInflight, n / T.fWall, T.fWall, T.fPack, T.fH2D, T.fKernels, T.fD2H,
+                      (unsigned long long)T.uiBatches, (unsigned long long)T.uiAlignedReads );
+            sFlat += buf;
+        }
+        // ---- leg 2b: SAM text of the flat batches (BatchFileWriter: arenas, one write per batch)
+        double fSamFlat = 0;
+        uint64_t uiSamFlatBytes = 0;
+        {
+            auto pSinkF = std::make_shared<CountingSink>( );
+            BatchFileWriter xBatchWriter( xParams, std::static_pointer_cast<OutStream>( pSinkF ), pPack );
+            xBatchWriter.uiFormatThreads = std::min( 32u, uiHw );
+            t0 = now( );
+            for( auto& pB : *pFlat )
+            {
+                auto pSlice = std::make_shared<ReadVec>( pReads->begin( ) + pB->uiFirst, pReads->begin( ) + pB->uiFirst + pB->size( ) );
+                xBatchWriter.execute( pSlice, pB, pPack );
+            }
+            fSamFlat = now( ) - t0;
+            uiSamFlatBytes = pSinkF->uiBytes.load( );
+        }
+        pFlat.reset( );
+        // ---- leg 2c: the throughput path AS GRAPH NODES: source -> BatchAlign -> BatchFileWriter, T graph threads under
+        // simultaneousGet (each thread = one device batch in flight), reads in host memory -> SAM bytes in the sink
+        std::string sBatchGraph;
+        for( int iT : { 2, 3, 4 } )
+        {
+            auto pSinkG = std::make_shared<CountingSink>( );
+            auto pSource = std::make_shared<BatchSource>( pReads );
+            pSource->uiBatchReads = 1u << 17;
+            auto pAlign = std::make_shared<BatchAlign>( xParams );
+            auto pBatchWriter = std::make_shared<BatchFileWriter>( xParams, std::static_pointer_cast<OutStream>( pSinkG ), pPack );
+            pBatchWriter->uiFormatThreads = std::min( 16u, uiHw );
+            auto pPackP = std::make_shared<Pledge<Pack>>( );
+            pPackP->set( pPack );
+            auto pFmP = std::make_shared<Pledge<FMIndex>>( );
+            pFmP->set( pFM );
+            std::vector<std::shared_ptr<BasePledge>> vSinks;
+            for( int t = 0; t < iT; t++ )
+            {
+                auto pBatch = promiseMe( std::make_shared<Lock<ReadVec>>( ), promiseMe( pSource ) );
+                auto pAligned = promiseMe( pAlign, pFmP, pBatch );
+                auto pWritten = promiseMe( pBatchWriter, pBatch, pAligned, pPackP );
+                vSinks.push_back( promiseMe( std::make_shared<UnLock<Container>>( pBatch ), pWritten ) );
+            }
+            {
+                // warm-up: iT engines at once, each allocates its device pools and page-locked staging (they stay with pAlign)
+                std::vector<std::thread> vWarm;
+                for( int t = 0; t < iT; t++ )
+                    vWarm.emplace_back( [ & ]( ) {
+                        pAlign->execute( pFM, std::make_shared<ReadVec>( pReads->begin( ), pReads->begin( ) + std::min<size_t>( n, 1u << 17 ) ) );
+                    } );
+                for( auto& rT : vWarm )
+                    rT.join( );
+                pAlign->uiBatches = 0;
+            }
+            t0 = now( );
+            BasePledge::simultaneousGet( vSinks );
+            const double f = now( ) - t0;
+            char buf[ 384 ];
+            snprintf( buf, sizeof( buf ), "%s\"graph_threads_%d\": {\"reads_per_s\": %.1f, \"wall_s\": %.4f, \"device_batches\": %llu, \"sam_bytes\": %llu}",
+                      sBatchGraph.empty( ) ? "" : ", ", iT, n / f, f, (unsigned long long)pAlign->uiBatches.load( ),
+                      (unsigned long long)pSinkG->uiBytes.load( ) );
+            sBatchGraph += buf;
         }
         // ---- leg 2: SAM text of every read
         auto pSink = std::make_shared<CountingSink>( );
@@ -184,13 +266,20 @@ int main( int argc, char** argv )
         printf( "{\"reads\": %zu, \"read_len\": %zu, \"host_threads\": %u, \"index_load_s\": %.2f, "
                 "\"batch_aligner\": {%s, \"what\": \"reads in host memory -> BatchAligner::execute (H2D, all stages, D2H, Alignment "
                 "containers); 256 k reads per device batch; phase times summed over the batches\"}, "
+                "\"batch_aligner_flat\": {%s, \"what\": \"BatchAligner::executeFlat: the same without Alignment containers -- the result "
+                "of a device batch stays one header array + one ops array in page-locked memory\"}, "
+                "\"sam_flat\": {\"reads_per_s\": %.1f, \"bytes\": %llu, \"what\": \"BatchFileWriter::execute on the flat batches: formatted by "
+                "up to 32 threads into byte arenas, one write per batch\"}, "
+                "\"batch_graph\": {%s, \"what\": \"BatchSource -> BatchAlign -> BatchFileWriter as graph nodes under promiseMe / "
+                "simultaneousGet, 128 k reads per device batch, one device batch in flight per graph thread: reads in host memory -> SAM bytes\"}, "
                 "\"sam\": {\"reads_per_s\": %.1f, \"threads\": %u, \"bytes\": %llu, \"what\": \"FileWriter::execute per read into a "
                 "counting sink\"}, "
                 "\"graph\": {\"reads_per_s\": %.1f, \"graph_threads\": %d, \"device_batches\": %llu, \"mean_reads_per_device_batch\": %.1f, "
                 "\"what\": \"the unchanged per-read graph (reader -> BinarySeeding -> StripOfConsideration -> Harmonization -> "
                 "NeedlemanWunsch -> MappingQuality -> FileWriter) on that many graph threads; per-read execute() calls funnelled into "
                 "device batches\"}}\n",
-                n, uiLen, uiHw, fLoad, sBatch.c_str( ), n / fSam, uiSamThreads, (unsigned long long)pSink->uiBytes.load( ), n / fGraph,
+                n, uiLen, uiHw, fLoad, sBatch.c_str( ), sFlat.c_str( ), n / fSamFlat, (unsigned long long)uiSamFlatBytes, sBatchGraph.c_str( ),
+                n / fSam, uiSamThreads, (unsigned long long)pSink->uiBytes.load( ), n / fGraph,
                 iGraphThreads, (unsigned long long)xStat.first, xStat.first ? (double)xStat.second / xStat.first : 0.0 );
     }
     catch( const std::exception& e )

@@ -116,6 +116,12 @@ int ma_abi_version( void );
 int ma_device_count( int* n );
 int ma_set_device( int device );
 
+/* Page-locked host memory for the arrays handed to / filled by the batch calls: uploads and downloads of pageable memory go
+ * through the runtime's staging buffers at a fraction of the PCIe rate.  (The reference has no counterpart: its containers
+ * live in host memory only; this is what NucSeq / Alignment storage becomes on the way to and from the device.) */
+int ma_host_alloc( uint64_t bytes, void** out );
+int ma_host_free( void* p );
+
 /* ---- index: replaces FMIndex(std::string) / Pack(std::string) loading (fMIndex.h:952-955, pack.h:513-525) ---- */
 /* Upload an index whose arrays were read from the reference's own .bwt/.sa/.pac files. */
 int ma_index_create( const uint32_t* bwt_words, uint64_t n_words, const int64_t* sa, uint64_t n_sa,

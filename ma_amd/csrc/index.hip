@@ -76,6 +76,21 @@ int ma_set_device( int device )
     return 0;
 }
 
+int ma_host_alloc( uint64_t bytes, void** out )
+{
+    if( !out )
+        return fail( "ma_host_alloc: null argument" );
+    *out = nullptr;
+    MA_HIP( hipHostMalloc( out, bytes ? bytes : 1, hipHostMallocDefault ) );
+    return 0;
+}
+int ma_host_free( void* p )
+{
+    if( p )
+        MA_HIP( hipHostFree( p ) );
+    return 0;
+}
+
 void ma_params_default( ma_params* p )
 {
     memset( p, 0, sizeof( *p ) );

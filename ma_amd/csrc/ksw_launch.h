@@ -500,10 +500,10 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( const char* e = getenv( "MA_KSW_WAVES_PER_CU" ) )
         perCu = (u64)std::max( 1, atoi( e ) );
     const u64 wantWaves = 256ull * perCu;
-    // Concurrent launches each own a scratch region, so each asks only for the waves that can be RESIDENT (registers: 4 / 3
-    // waves per SIMD for the exact kernels, 7 / 4 for the extension kernels): a persistent wave beyond that would only start
-    // when another one retires and its scratch would sit idle until then.
-    const u64 resident[ KSW_N_CLASSES ] = { 256 * 12, 256 * 12, 256 * 12, 256 * 16, 0, 256 * 28, 256 * 16 };
+    // Concurrent launches each own a scratch region, so each asks only for the waves that can be RESIDENT (registers:
+    // k_ksw_pk<1> 74 VGPRs = 6 waves per SIMD, <2> 99, <3> 122, <5> 128 = 4; the extension kernels 7 / 4): a persistent wave
+    // beyond that would only start when another one retires and its scratch would sit idle until then.
+    const u64 resident[ KSW_N_CLASSES ] = { 256 * 24, 256 * 16, 256 * 16, 256 * 16, 0, 256 * 28, 256 * 16 };
     auto wantOf = [ & ]( int k ) { return conc ? std::min<u64>( wantWaves, resident[ k ] ) : wantWaves; };
     // budgets of the scratch regions: lane 0 / 1 / 2 (sequential launches of a lane share its region)
     const u64 B = KSW_SCRATCH_BUDGET;

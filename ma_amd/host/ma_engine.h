@@ -10,13 +10,22 @@
 #pragma once
 #include "../../include/ma_amd.h"
 #include <algorithm>
+#include <atomic>
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace ma_amd
@@ -46,12 +55,57 @@ inline double secondsSince( const std::chrono::steady_clock::time_point& t0 )
     return std::chrono::duration<double>( std::chrono::steady_clock::now( ) - t0 ).count( );
 }
 
+// Page-locked host array that only grows (ma_host_alloc): the arrays a device batch is uploaded from and downloaded into.
+// Not value-initialised: a download overwrites what it needs.
+template <typename T> class HostBuf
+{
+    T* p = nullptr;
+    size_t uiCap = 0;
+
+  public:
+    HostBuf( )
+    {}
+    HostBuf( const HostBuf& ) = delete;
+    HostBuf& operator=( const HostBuf& ) = delete;
+    ~HostBuf( )
+    {
+        if( p != nullptr )
+            ma_host_free( p );
+    }
+    T* need( size_t n ) // at least n elements (contents are lost when it grows)
+    {
+        if( n > uiCap )
+        {
+            if( p != nullptr )
+                ma_host_free( p );
+            p = nullptr;
+            uiCap = n + n / 4 + 64;
+            void* q = nullptr;
+            engineCheck( ma_host_alloc( uiCap * sizeof( T ), &q ) );
+            p = static_cast<T*>( q );
+        }
+        return p;
+    }
+    T* data( )
+    {
+        return p;
+    }
+    const T* data( ) const
+    {
+        return p;
+    }
+    const T& operator[]( size_t i ) const
+    {
+        return p[ i ];
+    }
+};
+
 // Host copies of the records of one device batch, CSR by read (offset arrays have n + 1 entries).
 struct BatchResult
 {
     size_t uiReads = 0;
     bool bStages = false; // segments / seeds / harmonized sets / unsorted-quality alignments present?
-    std::vector<uint64_t> vSegOff, vSeedOff, vHsetOff, vHseedOff, vAlnOff, vMqOff;
+    std::vector<uint64_t> vSegOff, vSeedOff, vHsetOff, vHseedOff, vAlnOff;
     std::vector<ma_segment> vSegs;
     std::vector<ma_seed> vSeeds, vHseeds;
     std::vector<uint32_t> vHsetSoc;
@@ -61,10 +115,16 @@ struct BatchResult
     std::vector<ma_soc> vSocHeap;
     std::vector<ma_seed> vSortedSeeds;
     bool bSocQueues = false;
-    std::vector<ma_alignment> vAlns, vMq; // NeedlemanWunsch output / MappingQuality output
-    std::vector<uint64_t> vAlnOps, vMqOps; // (type, length) pairs
+    std::vector<ma_alignment> vAlns; // NeedlemanWunsch output (bStages)
+    std::vector<uint64_t> vAlnOps; // (type, length) pairs
+    // MappingQuality output = the result of the path: a FLAT view, one header array + one ops array per device batch in
+    // page-locked memory that the engine recycles; Alignment containers are built from it only where somebody asks for them
+    HostBuf<uint64_t> vMqOff; // n + 1
+    HostBuf<ma_alignment> vMq;
+    HostBuf<uint64_t> vMqOps; // (type, length) pairs
+    uint64_t uiMqAlignments = 0, uiMqOps = 0;
     uint64_t uiAlignedReads = 0;
-    double fH2D = 0, fKernels = 0, fD2H = 0; // seconds
+    double fPack = 0, fH2D = 0, fKernels = 0, fD2H = 0; // seconds: gathering the reads, upload, all stages, download
     float aStageMs[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // host wall time of seed / extract / chain / dp (ma_batch_host_ms)
 };
 
@@ -75,9 +135,24 @@ class Engine
     ma_batch* pBatch = nullptr;
     void* pStream = nullptr;
     uint64_t uiCapReads = 0, uiCapBases = 0;
-    std::vector<uint8_t> vCodes;
-    std::vector<uint64_t> vOff;
+    HostBuf<uint8_t> vCodes; // page-locked staging of the reads
+    HostBuf<uint64_t> vOff;
     const bool bBlocking; // waits sleep instead of spinning (hosts that run far more threads than cores)
+    // results are handed out as shared_ptr; one that nobody holds any more is reused (its page-locked arrays are kept)
+    std::vector<std::shared_ptr<BatchResult>> vPool;
+
+    std::shared_ptr<BatchResult> freshResult( )
+    {
+        for( auto& pR : vPool )
+            if( pR.use_count( ) == 1 )
+                return pR;
+        if( vPool.size( ) < 8 )
+        {
+            vPool.push_back( std::make_shared<BatchResult>( ) );
+            return vPool.back( );
+        }
+        return std::make_shared<BatchResult>( ); // the caller keeps many results alive: not pooled
+    }
 
   public:
     bool bFetchSocQueues = false; // run(): with bStages also fetch every read's SoC queue (one extra kernel per batch)
@@ -122,21 +197,48 @@ class Engine
     }
     std::shared_ptr<BatchResult> run( const std::vector<ReadRef>& vReads, bool bStages )
     {
-        auto pRes = std::make_shared<BatchResult>( );
-        BatchResult& R = *pRes;
         const size_t n = vReads.size( );
+        auto tPack = std::chrono::steady_clock::now( );
+        uint64_t* pOff = vOff.need( n + 1 );
+        pOff[ 0 ] = 0;
+        for( size_t i = 0; i < n; i++ )
+            pOff[ i + 1 ] = pOff[ i ] + vReads[ i ].uiLength;
+        uint8_t* pCodes = vCodes.need( pOff[ n ] + 1 );
+        // gather the reads into the staging array; large batches on a few threads (10^6 scattered 150-byte copies)
+        auto gather = [ & ]( size_t lo, size_t hi ) {
+            for( size_t i = lo; i < hi; i++ )
+                if( vReads[ i ].uiLength != 0 )
+                    memcpy( pCodes + pOff[ i ], vReads[ i ].pCodes, vReads[ i ].uiLength );
+        };
+        const size_t uiThreads = n >= ( 1u << 16 ) ? 4 : 1;
+        if( uiThreads == 1 )
+            gather( 0, n );
+        else
+        {
+            std::vector<std::thread> vT;
+            for( size_t t = 1; t < uiThreads; t++ )
+                vT.emplace_back( gather, n * t / uiThreads, n * ( t + 1 ) / uiThreads );
+            gather( 0, n / uiThreads );
+            for( auto& rT : vT )
+                rT.join( );
+        }
+        const double fPack = secondsSince( tPack );
+        auto pRes = runFlat( pCodes, pOff, n, bStages );
+        pRes->fPack = fPack;
+        return pRes;
+    }
+    // reads that already are one array of codes + CSR offsets (n + 1), e.g. in page-locked memory the caller filled
+    std::shared_ptr<BatchResult> runFlat( const uint8_t* pCodes, const uint64_t* pOff, size_t n, bool bStages )
+    {
+        auto pRes = freshResult( );
+        BatchResult& R = *pRes;
         R.uiReads = n;
         R.bStages = bStages;
-        vOff.assign( n + 1, 0 );
-        for( size_t i = 0; i < n; i++ )
-            vOff[ i + 1 ] = vOff[ i ] + vReads[ i ].uiLength;
-        vCodes.resize( vOff[ n ] + 1 );
-        for( size_t i = 0; i < n; i++ )
-            if( vReads[ i ].uiLength != 0 )
-                std::copy( vReads[ i ].pCodes, vReads[ i ].pCodes + vReads[ i ].uiLength, vCodes.begin( ) + vOff[ i ] );
-        fit( n, vOff[ n ] );
+        R.bSocQueues = false;
+        R.fPack = 0;
+        fit( n, pOff[ n ] );
         auto t0 = std::chrono::steady_clock::now( );
-        engineCheck( ma_batch_set_reads( pBatch, vCodes.data( ), vOff.data( ), n ) );
+        engineCheck( ma_batch_set_reads( pBatch, pCodes, pOff, n ) );
         R.fH2D = secondsSince( t0 );
         t0 = std::chrono::steady_clock::now( );
         engineCheck( ma_align_batch( pBatch ) );
@@ -176,11 +278,19 @@ class Engine
             R.vAlnOps.resize( 2 * nOps + 2 );
             engineCheck( ma_batch_get_alignments( pBatch, R.vAlnOff.data( ), R.vAlns.data( ), R.vAlnOps.data( ) ) );
         }
-        R.vMqOff.resize( n + 1 );
-        R.vMq.resize( nAln + 1 );
-        R.vMqOps.resize( 2 * nOps + 2 );
-        engineCheck( ma_batch_get_mapq_alignments( pBatch, R.vMqOff.data( ), R.vMq.data( ), R.vMqOps.data( ) ) );
+        uint64_t* pMqOff = R.vMqOff.need( n + 1 );
+        engineCheck( ma_batch_get_mapq_alignments( pBatch, pMqOff, R.vMq.need( nAln + 1 ), R.vMqOps.need( 2 * nOps + 2 ) ) );
+        R.uiMqAlignments = n ? pMqOff[ n ] : 0;
+        R.uiMqOps = 0;
+        if( R.uiMqAlignments )
+        {
+            const ma_alignment& rLast = R.vMq[ R.uiMqAlignments - 1 ];
+            R.uiMqOps = rLast.ops_off + rLast.n_ops;
+        }
         R.fD2H = secondsSince( t0 );
+        if( getenv( "MA_ENGINE_TRACE" ) ) // diagnostics: the phases of every device batch
+            fprintf( stderr, "engine %p: %zu reads, h2d %.4f s, stages %.4f s (seed %.1f extract %.1f chain %.1f dp %.1f ms), d2h %.4f s\n",
+                     (void*)this, n, R.fH2D, R.fKernels, R.aStageMs[ 0 ], R.aStageMs[ 1 ], R.aStageMs[ 2 ], R.aStageMs[ 3 ], R.fD2H );
         return pRes;
     }
 };
@@ -199,7 +309,7 @@ struct Ticket
 struct BatcherOptions
 {
     size_t uiMaxBatch = 1u << 18; // reads per device batch at most
-    size_t uiEngines = 2; // device batches in flight (own stream each)
+    size_t uiEngines = 4; // device batches in flight (own stream each): a small batch is latency-bound (~5 ms whatever its size)
     std::chrono::microseconds xGather{ 40 }; // an idle GPU still waits this long for more reads to arrive
     std::chrono::microseconds xMaxWait{ 20000 }; // a read never waits longer than this for its batch to be sealed
     // true: every stage's records are fetched, so SegmentVector / SoCPriorityQueue / seed sets / NeedlemanWunsch's
@@ -212,6 +322,27 @@ struct BatcherOptions
     bool bSocQueues = false;
 };
 
+// One-shot gate many threads sleep at until it opens.  A condition variable makes every woken thread re-acquire the mutex it
+// waited with: the ~600 graph threads of one device batch then leave one by one (and fight the threads that are entering the
+// next batch for the same mutex) -- measured as ~45 ms per cycle of a graph thread, against 5 ms on the GPU.  A futex wakes
+// them all at once and none of them needs a lock afterwards.
+class Gate
+{
+    std::atomic<int> iOpen{ 0 };
+
+  public:
+    void wait( )
+    {
+        while( iOpen.load( std::memory_order_acquire ) == 0 )
+            syscall( SYS_futex, reinterpret_cast<int*>( &iOpen ), FUTEX_WAIT_PRIVATE, 0, nullptr, nullptr, 0 );
+    }
+    void open( )
+    {
+        iOpen.store( 1, std::memory_order_release );
+        syscall( SYS_futex, reinterpret_cast<int*>( &iOpen ), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0 );
+    }
+};
+
 class DeviceBatcher
 {
     struct Slot
@@ -219,8 +350,8 @@ class DeviceBatcher
         std::vector<ReadRef> vReads;
         std::shared_ptr<const BatchResult> pResult;
         std::string sError;
-        bool bSealed = false, bDone = false;
-        std::condition_variable xDone; // only this batch's readers wait here: a finished batch wakes nobody else
+        bool bSealed = false;
+        Gate xDone; // only this batch's readers wait here: a finished batch wakes nobody else
     };
     const ma_index* pIndex;
     const ma_params xP;
@@ -279,9 +410,8 @@ class DeviceBatcher
             for( int k = 0; k < 4; k++ )
                 aSumStageMs[ k ] += pSlot->pResult->aStageMs[ k ];
         }
-        pSlot->bDone = true;
-        pSlot->xDone.notify_all( );
         xChanged.notify_all( ); // leaders of open batches and sealers waiting for a device slot
+        pSlot->xDone.open( ); // result and error of the slot are published by the release store inside
     }
 
   public:
@@ -333,7 +463,8 @@ class DeviceBatcher
                 runSealed( xLock, pSlot );
             }
         }
-        pSlot->xDone.wait( xLock, [ & ]( ) { return pSlot->bDone; } );
+        xLock.unlock( );
+        pSlot->xDone.wait( );
         if( !pSlot->sError.empty( ) )
             throw std::runtime_error( pSlot->sError );
         Ticket xT;

@@ -709,7 +709,7 @@ class HarmonizedSets : public SeedsSetVector
 namespace detail
 {
 // alignment records [uiFrom, uiTo) of a download -> Alignment containers
-inline void appendAlignments( const std::vector<ma_alignment>& vAlns, const std::vector<uint64_t>& vOps, uint64_t uiFrom,
+inline void appendAlignments( const ma_alignment* vAlns, const uint64_t* vOps, uint64_t uiFrom,
                               uint64_t uiTo, bool bMapq, libMS::ContainerVector<std::shared_ptr<Alignment>>& rOut )
 {
     for( uint64_t i = uiFrom; i < uiTo; i++ )
@@ -738,7 +738,7 @@ inline void downloadAlignments( ma_batch* b, bool bMapq, libMS::ContainerVector<
     std::vector<uint64_t> off( 2 ), ops( 2 * nOps + 2 );
     std::vector<ma_alignment> alns( nAln + 1 );
     maCheck( ( bMapq ? ma_batch_get_mapq_alignments : ma_batch_get_alignments )( b, off.data( ), alns.data( ), ops.data( ) ) );
-    appendAlignments( alns, ops, 0, off[ 1 ], bMapq, rOut );
+    appendAlignments( alns.data( ), ops.data( ), 0, off[ 1 ], bMapq, rOut );
 }
 // harmonized sets of one read out of CSR arrays
 inline void appendHsets( const std::vector<uint64_t>& vHseedOff, const std::vector<uint32_t>& vSoc, const std::vector<ma_seed>& vSeeds,
@@ -951,7 +951,7 @@ class NeedlemanWunsch
             pRet->xTicket = pIn->xTicket;
             const detail::BatchResult& R = *pRet->xTicket.pResult;
             if( R.bStages )
-                detail::appendAlignments( R.vAlns, R.vAlnOps, R.vAlnOff[ pRet->xTicket.uiRead ], R.vAlnOff[ pRet->xTicket.uiRead + 1 ],
+                detail::appendAlignments( R.vAlns.data( ), R.vAlnOps.data( ), R.vAlnOff[ pRet->xTicket.uiRead ], R.vAlnOff[ pRet->xTicket.uiRead + 1 ],
                                           false, *pRet );
             return pRet;
         }
@@ -982,7 +982,7 @@ class MappingQuality : public libMS::Module<libMS::ContainerVector<std::shared_p
         {
             pRet->xTicket = pIn->xTicket;
             const detail::BatchResult& R = *pRet->xTicket.pResult;
-            detail::appendAlignments( R.vMq, R.vMqOps, R.vMqOff[ pRet->xTicket.uiRead ], R.vMqOff[ pRet->xTicket.uiRead + 1 ], true,
+            detail::appendAlignments( R.vMq.data( ), R.vMqOps.data( ), R.vMqOff[ pRet->xTicket.uiRead ], R.vMqOff[ pRet->xTicket.uiRead + 1 ], true,
                                       *pRet );
             return pRet;
         }
@@ -1322,11 +1322,56 @@ class PairedReads : public libMS::Module<libMS::ContainerVector<std::shared_ptr<
     }
 };
 
+typedef libMS::ContainerVector<std::shared_ptr<NucSeq>> ReadVector;
+
+// The result of one device batch as a FLAT view (ma_engine.h: BatchResult): for read i of the batch the MappingQuality
+// records [offsets()[i], offsets()[i+1]) of alignments(), their (type, length) pairs in ops() (ma_alignment::ops_off counts
+// pairs).  One header array + one ops array per batch in page-locked memory the engine recycles; Alignment containers are
+// built only where somebody asks for them (alignmentsOf) -- building 1.3 M shared_ptr<Alignment> + op vectors per 1 M reads
+// was what capped the host-fed path at 3-4 M reads/s.
+class AlignedBatch : public libMS::Container
+{
+  public:
+    std::shared_ptr<ReadVector> pReads; // the whole read set ...
+    size_t uiFirst = 0; // ... of which this batch is reads [uiFirst, uiFirst + size())
+    std::shared_ptr<const detail::BatchResult> pResult;
+    size_t size( ) const
+    {
+        return pResult == nullptr ? 0 : pResult->uiReads;
+    }
+    const std::shared_ptr<NucSeq>& read( size_t i ) const
+    {
+        return ( *pReads )[ uiFirst + i ];
+    }
+    const uint64_t* offsets( ) const
+    {
+        return pResult->vMqOff.data( );
+    }
+    const ma_alignment* alignments( ) const
+    {
+        return pResult->vMq.data( );
+    }
+    const uint64_t* ops( ) const
+    {
+        return pResult->vMqOps.data( );
+    }
+    uint64_t alignedReads( ) const
+    {
+        return pResult == nullptr ? 0 : pResult->uiAlignedReads;
+    }
+    std::shared_ptr<AlignmentVector> alignmentsOf( size_t uiRead ) const
+    {
+        auto pV = std::make_shared<AlignmentVector>( );
+        detail::appendAlignments( alignments( ), ops( ), offsets( )[ uiRead ], offsets( )[ uiRead + 1 ], true, *pV );
+        return pV;
+    }
+};
+
 // Phase times of a throughput run (seconds, summed over the device batches; the phases of different batches overlap when
 // several are in flight, so their sum can exceed the wall time)
 struct AlignerTiming
 {
-    double fWall = 0, fH2D = 0, fKernels = 0, fD2H = 0, fContainers = 0;
+    double fWall = 0, fPack = 0, fH2D = 0, fKernels = 0, fD2H = 0, fContainers = 0;
     uint64_t uiReads = 0, uiBatches = 0, uiAlignedReads = 0;
 };
 
@@ -1339,6 +1384,30 @@ class BatchAligner
 {
     ma_params xP;
     ParameterSetManager xParams;
+    // engines (stream + device batch + page-locked staging) live as long as the aligner: creating one allocates GBs of
+    // device memory and page-locks host memory, which stalls every other stream of the process for 0.3-0.8 s
+    mutable std::mutex xEngineMutex;
+    mutable std::vector<std::pair<const ma_index*, std::unique_ptr<detail::Engine>>> vIdleEngines;
+
+    std::unique_ptr<detail::Engine> takeEngine( const ma_index* pIndex ) const
+    {
+        {
+            std::lock_guard<std::mutex> xGuard( xEngineMutex );
+            for( size_t k = 0; k < vIdleEngines.size( ); k++ )
+                if( vIdleEngines[ k ].first == pIndex )
+                {
+                    auto pEngine = std::move( vIdleEngines[ k ].second );
+                    vIdleEngines.erase( vIdleEngines.begin( ) + k );
+                    return pEngine;
+                }
+        }
+        return std::unique_ptr<detail::Engine>( new detail::Engine( pIndex, xP ) );
+    }
+    void giveEngine( const ma_index* pIndex, std::unique_ptr<detail::Engine> pEngine ) const
+    {
+        std::lock_guard<std::mutex> xGuard( xEngineMutex );
+        vIdleEngines.emplace_back( pIndex, std::move( pEngine ) );
+    }
 
   public:
     typedef libMS::ContainerVector<std::shared_ptr<AlignmentVector>> TP_RESULT;
@@ -1349,41 +1418,60 @@ class BatchAligner
     BatchAligner( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) ), xParams( rParameters )
     {}
 
-    // Aligns reads [uiFrom, uiTo) of rQueries on the device of pIndex and stores the result of read i in rOut[ i ].
+    typedef libMS::ContainerVector<std::shared_ptr<AlignedBatch>> TP_FLAT;
+
+    // Aligns reads [uiFrom, uiTo) of rQueries on the device of pIndex.  pFlat: one AlignedBatch per device batch (in input
+    // order; entry k covers reads [uiFrom + k * uiBatchReads, ...)); pOut: per read its Alignment containers (rOut[ i ]).
     void alignRange( const ma_index* pIndex, const libMS::ContainerVector<std::shared_ptr<NucSeq>>& rQueries, size_t uiFrom,
-                     size_t uiTo, TP_RESULT& rOut, AlignerTiming& rT ) const
+                     size_t uiTo, TP_RESULT* pOut, AlignerTiming& rT, TP_FLAT* pFlat = nullptr,
+                     std::shared_ptr<ReadVector> pReadsOfFlat = nullptr ) const
     {
         std::mutex xNext;
         size_t uiNext = uiFrom;
         std::string sFailure;
+        const size_t uiFlatBase = pFlat ? pFlat->size( ) : 0;
+        if( pFlat )
+            pFlat->resize( uiFlatBase + ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) );
         auto worker = [ & ]( ) {
+            std::unique_ptr<detail::Engine> pEngine;
             try
             {
-                detail::Engine xEngine( pIndex, xP );
+                pEngine = takeEngine( pIndex );
+                detail::Engine& xEngine = *pEngine;
                 for( ;; )
                 {
                     size_t lo, hi;
                     {
                         std::lock_guard<std::mutex> xGuard( xNext );
                         if( uiNext >= uiTo || !sFailure.empty( ) )
-                            return;
+                            break;
                         lo = uiNext;
                         hi = uiNext = std::min( uiTo, uiNext + uiBatchReads );
                     }
-                    std::vector<const std::vector<uint8_t>*> vReads;
+                    std::vector<detail::ReadRef> vReads;
+                    vReads.reserve( hi - lo );
                     for( size_t i = lo; i < hi; i++ )
-                        vReads.push_back( &rQueries[ i ]->xCodes );
+                        vReads.emplace_back( rQueries[ i ]->xCodes );
                     auto pRes = xEngine.run( vReads, false );
                     const auto t0 = std::chrono::steady_clock::now( );
-                    for( size_t i = lo; i < hi; i++ )
+                    if( pFlat )
                     {
-                        auto pV = std::make_shared<AlignmentVector>( );
-                        detail::appendAlignments( pRes->vMq, pRes->vMqOps, pRes->vMqOff[ i - lo ], pRes->vMqOff[ i - lo + 1 ], true, *pV );
-                        rOut[ i ] = pV;
+                        auto pB = std::make_shared<AlignedBatch>( );
+                        pB->pReads = pReadsOfFlat;
+                        pB->uiFirst = lo;
+                        pB->pResult = pRes;
+                        ( *pFlat )[ uiFlatBase + ( lo - uiFrom ) / uiBatchReads ] = pB;
                     }
+                    if( pOut )
+                        for( size_t i = lo; i < hi; i++ )
+                        {
+                            auto pV = std::make_shared<AlignmentVector>( );
+                            detail::appendAlignments( pRes->vMq.data( ), pRes->vMqOps.data( ), pRes->vMqOff[ i - lo ], pRes->vMqOff[ i - lo + 1 ], true, *pV );
+                            ( *pOut )[ i ] = pV;
+                        }
                     const double fContainers = detail::secondsSince( t0 );
                     std::lock_guard<std::mutex> xGuard( xNext );
-                    rT.fH2D += pRes->fH2D, rT.fKernels += pRes->fKernels, rT.fD2H += pRes->fD2H, rT.fContainers += fContainers;
+                    rT.fPack += pRes->fPack, rT.fH2D += pRes->fH2D, rT.fKernels += pRes->fKernels, rT.fD2H += pRes->fD2H, rT.fContainers += fContainers;
                     rT.uiBatches++, rT.uiReads += hi - lo, rT.uiAlignedReads += pRes->uiAlignedReads;
                 }
             }
@@ -1393,6 +1481,8 @@ class BatchAligner
                 if( sFailure.empty( ) )
                     sFailure = rE.what( );
             }
+            if( pEngine != nullptr )
+                giveEngine( pIndex, std::move( pEngine ) );
         };
         const size_t uiWorkers = std::max<size_t>( 1, std::min( uiInflight, ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) ) );
         std::vector<std::thread> vWorkers;
@@ -1413,7 +1503,7 @@ class BatchAligner
         xLast = AlignerTiming( );
         const auto t0 = std::chrono::steady_clock::now( );
         if( !pQueries->empty( ) )
-            alignRange( pFM_index->pDev->p, *pQueries, 0, pQueries->size( ), *pRet, xLast );
+            alignRange( pFM_index->pDev->p, *pQueries, 0, pQueries->size( ), pRet.get( ), xLast );
         // "Detect Small Inversions" (export.cpp:118-121): all reads' inversion DP in one more GPU launch
         if( xP.search_inversions )
         {
@@ -1435,6 +1525,19 @@ class BatchAligner
                 ( *pRet )[ r ] = pV;
             }
         }
+        xLast.fWall = detail::secondsSince( t0 );
+        return pRet;
+    }
+
+    // The same alignment run with the results left FLAT: one AlignedBatch per device batch, in input order (no Alignment
+    // container is built; SmallInversions needs containers and is not applied here).
+    std::shared_ptr<TP_FLAT> executeFlat( std::shared_ptr<FMIndex> pFM_index, std::shared_ptr<ReadVector> pQueries )
+    {
+        auto pRet = std::make_shared<TP_FLAT>( );
+        xLast = AlignerTiming( );
+        const auto t0 = std::chrono::steady_clock::now( );
+        if( !pQueries->empty( ) )
+            alignRange( pFM_index->pDev->p, *pQueries, 0, pQueries->size( ), nullptr, xLast, pRet.get( ), pQueries );
         xLast.fWall = detail::secondsSince( t0 );
         return pRet;
     }
@@ -1555,7 +1658,7 @@ class MultiDeviceAligner
                     xAligner.uiInflight = uiInflight;
                     const auto t0 = std::chrono::steady_clock::now( );
                     if( hi > lo )
-                        xAligner.alignRange( vReplicas[ g ]->pDev->p, *pQueries, lo, hi, *pRet, vLast[ g ] );
+                        xAligner.alignRange( vReplicas[ g ]->pDev->p, *pQueries, lo, hi, pRet.get( ), vLast[ g ] );
                     vLast[ g ].fWall = detail::secondsSince( t0 );
                 }
                 catch( const std::exception& rE )

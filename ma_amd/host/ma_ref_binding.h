@@ -334,7 +334,7 @@ inline std::shared_ptr<TicketedSoCs> makeQueue( const ma_soc* pHeap, size_t uiSt
     return pQueue;
 }
 // alignment records [uiFrom, uiTo) of a download -> the reference's Alignment containers
-inline void appendAlignments( const std::vector<ma_alignment>& vAlns, const std::vector<uint64_t>& vOps, uint64_t uiFrom, uint64_t uiTo,
+inline void appendAlignments( const ma_alignment* vAlns, const uint64_t* vOps, uint64_t uiFrom, uint64_t uiTo,
                               bool bQuality, const libMA::NucSeq& rQuery, Alignments& rOut )
 {
     for( uint64_t i = uiFrom; i < uiTo; i++ )
@@ -366,7 +366,7 @@ inline void downloadAlignments( ma_batch* pBatch, bool bQuality, const libMA::Nu
     std::vector<uint64_t> vOff( 2 ), vOps( 2 * nOps + 2 );
     std::vector<ma_alignment> vAlns( nAln + 1 );
     check( ( bQuality ? ma_batch_get_mapq_alignments : ma_batch_get_alignments )( pBatch, vOff.data( ), vAlns.data( ), vOps.data( ) ) );
-    appendAlignments( vAlns, vOps, 0, vOff[ 1 ], bQuality, rQuery, rOut );
+    appendAlignments( vAlns.data( ), vOps.data( ), 0, vOff[ 1 ], bQuality, rQuery, rOut );
 }
 inline void appendSeedSets( const std::vector<uint64_t>& vSeedOff, const std::vector<uint32_t>& vSoc, const std::vector<ma_seed>& vSeeds,
                             uint64_t uiFrom, uint64_t uiTo, const libMA::NucSeq& rQuery, SeedSets& rOut )
@@ -592,7 +592,7 @@ class NeedlemanWunsch : public libMS::Module<Alignments, false, SeedSets, libMA:
             pRet->xTicket = pIn->xTicket;
             const engine::BatchResult& R = *pRet->xTicket.pResult;
             if( R.bStages )
-                detail::appendAlignments( R.vAlns, R.vAlnOps, R.vAlnOff[ pRet->xTicket.uiRead ], R.vAlnOff[ pRet->xTicket.uiRead + 1 ],
+                detail::appendAlignments( R.vAlns.data( ), R.vAlnOps.data( ), R.vAlnOff[ pRet->xTicket.uiRead ], R.vAlnOff[ pRet->xTicket.uiRead + 1 ],
                                           false, *pQuery, *pRet );
             return pRet;
         }
@@ -639,7 +639,7 @@ class MappingQuality : public libMS::Module<Alignments, false, libMA::NucSeq, Al
         {
             pRet->xTicket = pIn->xTicket;
             const engine::BatchResult& R = *pRet->xTicket.pResult;
-            detail::appendAlignments( R.vMq, R.vMqOps, R.vMqOff[ pRet->xTicket.uiRead ], R.vMqOff[ pRet->xTicket.uiRead + 1 ], true, *pQuery,
+            detail::appendAlignments( R.vMq.data( ), R.vMqOps.data( ), R.vMqOff[ pRet->xTicket.uiRead ], R.vMqOff[ pRet->xTicket.uiRead + 1 ], true, *pQuery,
                                       *pRet );
             return pRet;
         }

@@ -482,6 +482,12 @@ class OutStream
         put( sText.data( ), sText.size( ) );
         return *this;
     }
+    // a block of text (a whole batch of records) without a temporary string; a sink that only overrides operator<< -- client
+    // code written against the reference's OutStream -- still receives it through that operator
+    virtual void write( const char* pText, size_t uiLength )
+    {
+        *this << std::string( pText, uiLength );
+    }
     virtual ~OutStream( )
     {}
 };
@@ -492,6 +498,12 @@ class StdOutStream : public OutStream
     {
         fwrite( p, 1, n, stdout );
         fflush( stdout ); // every record is visible at once, like the reference's std::flush
+    }
+
+  public:
+    void write( const char* p, size_t n ) override
+    {
+        put( p, n );
     }
 };
 class FileOutStream : public OutStream
@@ -507,6 +519,10 @@ class FileOutStream : public OutStream
     }
 
   public:
+    void write( const char* p, size_t n ) override
+    {
+        put( p, n );
+    }
     explicit FileOutStream( std::string sFileName ) : pHandle( fopen( sFileName.c_str( ), "w" ) ) // truncates
     {
         if( pHandle == nullptr )
@@ -527,6 +543,10 @@ class StringOutStream : public OutStream // convenience for tests and in-memory 
     {
         sText += s;
         return *this;
+    }
+    void write( const char* p, size_t n ) override
+    {
+        sText.append( p, n );
     }
 };
 
@@ -996,99 +1016,130 @@ inline std::shared_ptr<FileStream> fileStreamFromPath( const std::string& sFileN
 #endif
     return std::make_shared<StdFileStream>( sFileName );
 }
+// FileReader (fileReader.h:28-200,475-496; fileReader.cpp:12-203): one FASTA or FASTQ record per call.  The record grammar
+// the reference accepts, as a scanner over the stream's lines:
+//   header    '>' or '@' line; the name ends at the first blank
+//   sequence  lines up to one that starts with the section's terminator ('+' for FASTQ, '>' for FASTA) or with a blank;
+//             a line contributes its characters up to the last IUPAC nucleotide letter on it; empty lines are skipped
+//   quality   (FASTQ, after a '+' line) lines up to one that starts with '@' -- but at least one, whatever it starts with:
+//             a quality string may begin with '@'; characters beyond the sequence length are dropped
+//   then everything up to the next '>' or '@' is skipped
 class FileReader : public libMS::Module<NucSeq, true, FileStream>
 {
-    static bool validNuc( char c ) // fileReader.cpp:12-18
+    // character classes of the scanner: bit 0 = IUPAC nucleotide letter (either case), bit 1 = line end
+    struct CharClasses
     {
-        for( char c2 : { 'A', 'C', 'G', 'T', 'N', 'U', 'R', 'Y', 'K', 'K', 'M', 'S', 'W', 'B', 'D', 'H', 'V' } )
-            if( c2 == toupper( c ) )
-                return true;
-        return false;
-    }
-    static size_t len( const std::string& sLine ) // trailing non-nucleotide characters are dropped (20-27)
-    {
-        size_t n = sLine.length( );
-        while( n > 0 && !validNuc( sLine[ n - 1 ] ) )
-            n--;
-        return n;
-    }
-    static size_t lenq( const std::string& sLine ) // 29-35
-    {
-        size_t n = sLine.length( );
-        while( n > 0 && ( sLine[ n - 1 ] == '\n' || sLine[ n - 1 ] == '\r' ) )
-            n--;
-        return n;
-    }
-    static uint8_t code( char c ) // NucSeq::xNucleotideTranslationTable (nucSeq.cpp:17-28)
-    {
-        return c == 'A' || c == 'a' ? 0 : c == 'C' || c == 'c' ? 1 : c == 'G' || c == 'g' ? 2 : c == 'T' || c == 't' ? 3 : 4;
-    }
-    static void advanceTillNext( FileStream& rS ) // fileReader.h:477-485
-    {
-        rS.peek( );
-        while( !( rS.eof( ) || rS.peek( ) == '>' || rS.peek( ) == '@' ) )
+        uint8_t a[ 256 ], aCode[ 256 ]; // aCode: A0 C1 G2 T3 (either case), everything else 4 (nucSeq.cpp:17-28)
+        CharClasses( )
         {
-            rS.pop( );
-            rS.peek( );
+            memset( a, 0, sizeof( a ) );
+            memset( aCode, 4, sizeof( aCode ) );
+            for( int k = 0; k < 4; k++ )
+                aCode[ (uint8_t)"ACGT"[ k ] ] = aCode[ (uint8_t)"acgt"[ k ] ] = (uint8_t)k;
+            for( const char* p = "ACGTUNRYKMSWBDHV"; *p; p++ )
+                a[ (uint8_t)*p ] |= 1, a[ (uint8_t)tolower( *p ) ] |= 1;
+            a[ (uint8_t)'\n' ] |= 2, a[ (uint8_t)'\r' ] |= 2;
         }
+    };
+    static const CharClasses& table( )
+    {
+        static const CharClasses xClasses;
+        return xClasses;
     }
+    static const uint8_t* classes( )
+    {
+        return table( ).a;
+    }
+    // length of a line without its trailing characters of the other class
+    static size_t trimmed( const std::string& sLine, uint8_t uiKeepBit, bool bKeepIfSet )
+    {
+        size_t n = sLine.size( );
+        while( n > 0 && ( ( classes( )[ (uint8_t)sLine[ n - 1 ] ] & uiKeepBit ) != 0 ) != bKeepIfSet )
+            n--;
+        return n;
+    }
+    struct Scanner
+    {
+        FileStream& rS;
+        std::string sLine;
+        bool more( ) const
+        {
+            return !rS.eof( );
+        }
+        bool nextStartsWith( char c )
+        {
+            return rS.peek( ) == c;
+        }
+        const std::string& line( )
+        {
+            sLine.clear( );
+            rS.safeGetLine( sLine );
+            return sLine;
+        }
+    };
 
   public:
     FileReader( const ParameterSetManager& )
     {}
+    // One record off the stream, nullptr at its end.  The caller holds the stream's lock.
+    static std::shared_ptr<NucSeq> parseRecord( FileStream& rStream )
+    {
+        Scanner xIn{ rStream, std::string( ) };
+        rStream.peek( );
+        if( !xIn.more( ) )
+            return nullptr;
+        const char cKind = rStream.peek( );
+        if( cKind != '>' && cKind != '@' )
+            throw std::runtime_error( "Error while reading file.\nIs your input really in FASTA/Q format?\nError occurred in file: " +
+                                      rStream.fileName( ) + "\npeek was:" + cKind );
+        const char cTerminator = cKind == '@' ? '+' : '>';
+        auto pRead = std::make_shared<NucSeq>( );
+        // ---- header
+        {
+            const std::string& sHeader = xIn.line( );
+            if( sHeader.empty( ) )
+                throw std::runtime_error( "Invalid line in fasta" );
+            const size_t uiBlank = sHeader.find( ' ' );
+            pRead->sName.assign( sHeader, 1, uiBlank == std::string::npos ? std::string::npos : uiBlank - 1 );
+        }
+        // ---- sequence
+        while( xIn.more( ) && !xIn.nextStartsWith( cTerminator ) && !xIn.nextStartsWith( ' ' ) )
+        {
+            const std::string& sBases = xIn.line( );
+            const size_t n = trimmed( sBases, 1, true );
+            for( size_t i = 0; i < n; i++ )
+                pRead->xCodes.push_back( table( ).aCode[ (uint8_t)sBases[ i ] ] );
+        }
+        // ---- quality
+        if( cKind == '@' )
+        {
+            pRead->xQuality.assign( pRead->xCodes.size( ), 0 );
+            const std::string& sPlus = xIn.line( );
+            if( !sPlus.empty( ) && sPlus[ 0 ] == '+' )
+            {
+                size_t uiFilled = 0;
+                while( xIn.more( ) && ( uiFilled == 0 || !xIn.nextStartsWith( '@' ) ) )
+                {
+                    const std::string& sQual = xIn.line( );
+                    const size_t n = trimmed( sQual, 2, false );
+                    for( size_t i = 0; i < n && uiFilled + i < pRead->xQuality.size( ); i++ )
+                        pRead->xQuality[ uiFilled + i ] = (uint8_t)sQual[ i ];
+                    uiFilled += n;
+                }
+            }
+        }
+        if( pRead->length( ) == 0 )
+            throw std::runtime_error( "found empty read: " + pRead->sName );
+        // ---- whatever follows, up to the next record
+        for( rStream.peek( ); xIn.more( ) && !xIn.nextStartsWith( '>' ) && !xIn.nextStartsWith( '@' ); rStream.peek( ) )
+            rStream.pop( );
+        return pRead;
+    }
     // nullptr = end of file (volatile source, module.h:688-695)
     virtual std::shared_ptr<NucSeq> execute( std::shared_ptr<FileStream> pStream ) override
     {
         std::lock_guard<std::mutex> xLock( pStream->xMutex );
-        pStream->peek( );
-        if( pStream->eof( ) )
-            return nullptr;
-        auto pRet = std::make_shared<NucSeq>( );
-        const char cFirst = pStream->peek( );
-        if( cFirst == '>' || cFirst == '@' )
-        {
-            const bool bFastq = cFirst == '@';
-            std::string sLine;
-            pStream->safeGetLine( sLine );
-            if( sLine.size( ) == 0 )
-                throw std::runtime_error( "Invalid line in fasta" );
-            pRet->sName = sLine.substr( 1, sLine.find( ' ' ) - 1 ); // everything past the first blank is description
-            while( !pStream->eof( ) && pStream->peek( ) != ( bFastq ? '+' : '>' ) && pStream->peek( ) != ' ' )
-            {
-                sLine = "";
-                pStream->safeGetLine( sLine );
-                if( sLine.size( ) == 0 )
-                    continue;
-                const size_t n = len( sLine );
-                for( size_t i = 0; i < n; i++ )
-                    pRet->xCodes.push_back( code( sLine[ i ] ) );
-            }
-            if( bFastq )
-            {
-                pRet->xQuality.assign( pRet->xCodes.size( ), 0 );
-                pStream->safeGetLine( sLine );
-                if( sLine[ 0 ] == '+' )
-                {
-                    size_t uiPos = 0;
-                    while( !pStream->eof( ) && ( pStream->peek( ) != '@' || uiPos == 0 ) )
-                    {
-                        pStream->safeGetLine( sLine );
-                        if( sLine.size( ) == 0 )
-                            continue;
-                        const size_t n = lenq( sLine );
-                        for( size_t i = 0; i < n && i + uiPos < pRet->xQuality.size( ); i++ )
-                            pRet->xQuality[ i + uiPos ] = (uint8_t)sLine[ i ];
-                        uiPos += n;
-                    }
-                }
-            }
-            if( pRet->length( ) == 0 )
-                throw std::runtime_error( "found empty read: " + pRet->sName );
-            advanceTillNext( *pStream );
-            return pRet;
-        }
-        throw std::runtime_error( "Error while reading file.\nIs your input really in FASTA/Q format?\nError occurred in file: " +
-                                  pStream->fileName( ) + "\npeek was:" + pStream->peek( ) );
+        return parseRecord( *pStream );
     }
 };
 // PairedFileStream / PairedFileReader (fileReader.h:499-617): one read from each of two streams per call

@@ -12,7 +12,7 @@
 //                         the reference's modules one at a time
 //   socs                  pops every read's SoC queue and writes the SOC records of the common dump format
 //   multi <shards>        MultiDeviceAligner over <shards> index replicas on device 0 (virtual shards)
-#include "../../ma_amd/host/ma_sam.h"
+#include "../../ma_amd/host/ma_batch_nodes.h"
 #include "../../oracle/dump_format.h"
 #include <atomic>
 #include <chrono>
@@ -289,6 +289,53 @@ static int runMulti( const CaseFile& c, const ParameterSetManager& xParams, std:
     return 0;
 }
 
+// The throughput form as graph nodes (ma_batch_nodes.h): BatchFileReader (a FASTQ text of the case's reads on an in-memory
+// stream, <batch> reads per call) -> BatchAlign -> BatchFileWriter, <threads> graph copies under simultaneousGet; the SAM
+// text goes to <out>.  <options>: bit 0 soft clip, bit 1 =/X cigars, bit 2 NGMLR tags (the writer's per-read fall-back).
+static int runBatchGraph( const CaseFile& c, ParameterSetManager xParams, std::shared_ptr<Pack> pPackC, std::shared_ptr<FMIndex> pFmC,
+                          const char* sOut, int iThreads, size_t uiBatch, int iOptions )
+{
+    xParams.xSam.bSoftClip = ( iOptions & 1 ) != 0;
+    xParams.xSam.bOutputMCigar = ( iOptions & 2 ) == 0;
+    xParams.xSam.bEmulateNgmlrTags = ( iOptions & 4 ) != 0;
+    std::string sFastq;
+    for( size_t i = 0; i < c.reads.size( ); i++ )
+    {
+        sFastq += "@r" + std::to_string( i ) + " the description is dropped\n";
+        for( uint8_t b : c.reads[ i ] )
+            sFastq.push_back( "ACGTN"[ b < 4 ? b : 4 ] );
+        sFastq += "\n+\n" + std::string( c.reads[ i ].size( ), 'I' ) + "\n";
+    }
+    auto pStream = std::make_shared<Pledge<FileStream>>( );
+    pStream->set( std::make_shared<StringStream>( sFastq ) );
+    auto pOut = std::make_shared<StringOutStream>( );
+    auto pReader = std::make_shared<BatchFileReader>( xParams );
+    pReader->uiBatchReads = uiBatch;
+    auto pAlign = std::make_shared<BatchAlign>( xParams );
+    auto pWriter = std::make_shared<BatchFileWriter>( xParams, std::static_pointer_cast<OutStream>( pOut ), pPackC );
+    pWriter->uiFormatThreads = 3;
+    auto pPack = std::make_shared<Pledge<Pack>>( );
+    pPack->set( pPackC );
+    auto pFMDIndex = std::make_shared<Pledge<FMIndex>>( );
+    pFMDIndex->set( pFmC );
+    std::vector<std::shared_ptr<BasePledge>> vSinks;
+    for( int t = 0; t < iThreads; t++ )
+    {
+        auto pBatch = promiseMe( std::make_shared<Lock<ReadVector>>( ), promiseMe( pReader, pStream ) );
+        auto pAligned = promiseMe( pAlign, pFMDIndex, pBatch );
+        auto pWritten = promiseMe( pWriter, pBatch, pAligned, pPack );
+        vSinks.push_back( promiseMe( std::make_shared<UnLock<Container>>( pBatch ), pWritten ) );
+    }
+    BasePledge::simultaneousGet( vSinks );
+    FILE* f = fopen( sOut, "w" );
+    fputs( pOut->sText.c_str( ), f );
+    fclose( f );
+    printf( "{\"graph_threads\": %d, \"reads\": %llu, \"device_batches\": %llu, \"aligned_reads\": %llu, \"sam_bytes\": %llu}\n", iThreads,
+            (unsigned long long)pAlign->uiReads.load( ), (unsigned long long)pAlign->uiBatches.load( ),
+            (unsigned long long)pAlign->uiAligned.load( ), (unsigned long long)pWriter->uiBytes.load( ) );
+    return 0;
+}
+
 int main( int argc, char** argv )
 {
     if( argc < 4 )
@@ -337,6 +384,9 @@ int main( int argc, char** argv )
             return runSocs( c, xParams, pPackC, pFmC, argv[ 3 ] );
         if( sMode == "multi" )
             return runMulti( c, xParams, pPackC, pFmC, argv[ 3 ], argc >= 6 ? atoi( argv[ 5 ] ) : 2 );
+        if( sMode == "batchgraph" )
+            return runBatchGraph( c, xParams, pPackC, pFmC, argv[ 3 ], argc >= 6 ? atoi( argv[ 5 ] ) : 2, argc >= 7 ? (size_t)atoi( argv[ 6 ] ) : 50,
+                                  argc >= 8 ? atoi( argv[ 7 ] ) : 0 );
     }
     catch( const std::exception& e )
     {

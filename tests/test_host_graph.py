@@ -16,7 +16,9 @@ G = os.path.join(ROOT, "tests", "golden")
 def build_exe():
     src = os.path.join(ROOT, "tests", "emul", "host_graph_test.cpp")
     deps = [src, os.path.join(ROOT, "ma_amd", "host", "ms_graph.h"), os.path.join(ROOT, "ma_amd", "host", "ma_modules.h"),
-            os.path.join(ROOT, "ma_amd", "host", "ma_sam.h"), os.path.join(ROOT, "include", "ma_amd.h")]
+            os.path.join(ROOT, "ma_amd", "host", "ma_sam.h"), os.path.join(ROOT, "include", "ma_amd.h"),
+            os.path.join(ROOT, "ma_amd", "host", "ma_batch_nodes.h"), os.path.join(ROOT, "ma_amd", "host", "ma_flat_sam.h"),
+            os.path.join(ROOT, "ma_amd", "host", "ma_engine.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
                                "-I" + os.path.join(ROOT, "ma_amd", "host"), src, "-o", EXE,
@@ -281,3 +283,33 @@ def test_example_fastq_to_sam_end_to_end(tmp_path, gpu_device):
     want = gzip.open(os.path.join(G, "reader", "small24.fq.sam.gz"), "rt").read().split("\n")
     assert got[0] == "@SQ\tSN:chr1\tLN:30000"  # file-name constructor: tabs (fileWriter.h:385-400)
     assert [l for l in got if not l.startswith("@")] == [l for l in want if not l.startswith("@")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,options", [("default", 0), ("default", 1), ("default", 2), ("default", 3), ("default", 4), ("illumina", 0)])
+@pytest.mark.parametrize("threads,batch", [(1, 1000), (3, 23)])
+def test_batch_graph_nodes_write_the_reference_sam(tmp_path, gpu_device, preset, options, threads, batch):
+    """The throughput form as graph nodes (ma_batch_nodes.h): BatchFileReader -> BatchAlign -> BatchFileWriter under
+    promiseMe / simultaneousGet.  The reads come from FASTQ text, the results stay flat (no Alignment containers) and the SAM
+    text is formatted from the flat view: the bytes are the reference FileWriter's (goldens written by the compiled
+    reference) except for the quality column, which the goldens' FASTA-like reads do not have."""
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    out = str(tmp_path / "batch.sam")
+    stats = subprocess.check_output([exe, case, preset, out, "batchgraph", str(threads), str(batch), str(options)]).decode()
+    want = gzip.open(os.path.join(G, "small_ref.%s.opt%d.sam.gz" % (preset, options)), "rt").read().splitlines()
+    got = open(out).read().splitlines()
+
+    def without_quality(line):
+        f = line.split("\t")
+        if len(f) > 10:
+            assert set(f[10]) <= {"I"} and len(f[10]) > 0
+            f[10] = "*"
+        return "\t".join(f)
+
+    got = [without_quality(l) for l in got]
+    if threads == 1:
+        assert got == want
+    else:  # the batches of different graph threads finish in any order; inside a batch the order is the input's
+        assert sorted(got) == sorted(want)
+    assert '"reads": 128' in stats

@@ -39,7 +39,10 @@ def traffic_json(summary, workload_key):
     tot = lambda key: sum(summary[g].get(key, 0) for g in ksw)
     b = {g: o["hbm_bytes_per_step"] for g, o in summary.items() if not g.startswith("k_ksw") and "hbm_bytes_per_step" in o}
     b["k_ksw"] = int(tot("hbm_bytes_per_step"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash
     return {"workload_key": workload_key,
+            "kernel_source_hash": kernel_source_hash(),  # bench.py replays these numbers only for this build of the kernels
             "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU / SQ_INSTS_SALU in separate passes of `bench.py --workload .. "
                     "--steps 3 --warmup 1 --cpu-sample 0` (tools/collect_profiles.sh); FETCH_SIZE (KB) = fabric read requests x 64 B: "
                     "taken as bytes for the random 64-B gathers (k_seed, k_lf_walk; calibrated in profiles/r02_counter_calibration.txt) "
