@@ -50,24 +50,10 @@ inline int64_t iAbsolutePosition( const Pack& rPack, uint64_t uiBegin, uint64_t 
 {
     return bPositionIsOnReversStrand( rPack, uiEnd ) ? (int64_t)( 2 * fwdSize( rPack ) - ( uiEnd + 1 ) ) : (int64_t)uiBegin;
 }
-inline int64_t uiSequenceIdForAbsolute( const Pack& rPack, int64_t iAbsPosition ) // binary search of pack.h:945-990
+inline int64_t uiSequenceIdForAbsolute( const Pack& rPack, int64_t iAbsPosition ) // pack.h:945-990: the contig that starts last at or before it
 {
-    uint64_t uiLeft = 0, uiMid = 0, uiRight = rPack.vStarts.size( );
-    while( uiLeft < uiRight )
-    {
-        uiMid = ( uiLeft + uiRight ) / 2;
-        if( iAbsPosition >= (int64_t)rPack.vStarts[ uiMid ] )
-        {
-            if( uiMid == rPack.vStarts.size( ) - 1 )
-                break;
-            if( iAbsPosition < (int64_t)rPack.vStarts[ uiMid + 1 ] )
-                break;
-            uiLeft = uiMid + 1;
-        }
-        else
-            uiRight = uiMid;
-    }
-    return (int64_t)uiMid;
+    const auto xNext = std::upper_bound( rPack.vStarts.begin( ), rPack.vStarts.end( ), (uint64_t)std::max<int64_t>( iAbsPosition, 0 ) );
+    return xNext == rPack.vStarts.begin( ) ? 0 : (int64_t)( xNext - rPack.vStarts.begin( ) ) - 1;
 }
 inline int64_t uiSequenceIdForPosition( const Pack& rPack, uint64_t uiPosition )
 {
@@ -98,11 +84,51 @@ inline void appendNumber( std::string& rOut, uint64_t uiValue )
         rOut.push_back( aDigits[ --n ] );
 }
 
+// One SAM line: columns appended to a shared buffer in order, a tab between two of them, a line feed at the end.
+class Columns
+{
+    std::string& rOut;
+    bool bFirst = true;
+    void separator( )
+    {
+        if( !bFirst )
+            rOut.push_back( '\t' );
+        bFirst = false;
+    }
+
+  public:
+    explicit Columns( std::string& rOut ) : rOut( rOut )
+    {}
+    Columns& text( const std::string& sText )
+    {
+        separator( );
+        rOut += sText;
+        return *this;
+    }
+    Columns& number( uint64_t uiValue );
+    template <typename FILL> Columns& column( FILL&& fFill ) // the column's text is appended by fFill( buffer )
+    {
+        separator( );
+        fFill( rOut );
+        return *this;
+    }
+    void end( )
+    {
+        rOut.push_back( '\n' );
+    }
+};
+
+inline Columns& Columns::number( uint64_t uiValue )
+{
+    separator( );
+    appendNumber( rOut, uiValue );
+    return *this;
+}
+
 // ---- NucSeq (nucSeq.h:558-569,605-626,667-713)
 inline char charOf( uint8_t c )
 {
-    static const char chars[ 4 ] = { 'A', 'C', 'G', 'T' };
-    return c < 4 ? chars[ c ] : 'N';
+    return "ACGTN"[ c < 4 ? c : 4 ];
 }
 inline void appendFromTo( std::string& rOut, const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
 {
@@ -111,12 +137,12 @@ inline void appendFromTo( std::string& rOut, const NucSeq& rQ, nucSeqIndex uiSta
 }
 inline void appendFromToComplement( std::string& rOut, const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd )
 {
-    for( nucSeqIndex i = uiEnd; i > uiStart; i-- )
+    if( uiEnd > uiStart && uiEnd > rQ.length( ) )
+        throw std::runtime_error( "Index out of range (compCharAt)" );
+    for( nucSeqIndex k = 0; k < uiEnd - std::min( uiStart, uiEnd ); k++ )
     {
-        if( i - 1 >= rQ.length( ) )
-            throw std::runtime_error( "Index out of range (compCharAt)" );
-        const uint8_t c = rQ.xCodes[ i - 1 ];
-        rOut.push_back( charOf( c < 4 ? (uint8_t)( 3 - c ) : (uint8_t)5 ) ); // nucleotideComplement nucSeq.h:524-532
+        const uint8_t c = rQ.xCodes[ uiEnd - 1 - k ];
+        rOut.push_back( "TGCAN"[ c < 4 ? c : 4 ] ); // nucleotideComplement nucSeq.h:524-532: anything but ACGT stays N
     }
 }
 inline void appendFromToQual( std::string& rOut, const NucSeq& rQ, nucSeqIndex uiStart, nucSeqIndex uiEnd ) // nucSeq.h:697-709
@@ -174,45 +200,39 @@ inline void appendCigar( std::string& rOut, const Alignment& rA, const Pack& rPa
     const nucSeqIndex uiTail = bRev ? rA.uiBeginOnQuery : ( rA.uiEndOnQuery < uiQuerySize ? uiQuerySize - rA.uiEndOnQuery : 0 );
     if( uiHead > 0 )
         appendClip( rOut, uiHead, bSoftClip );
-    size_t uiSequentialM = 0;
+    // one symbol per match type (seed, match, missmatch, insertion, deletion); with bM a run of the first three is one M
+    static const char aSymbol[ 5 ] = { '=', '=', 'X', 'I', 'D' };
+    nucSeqIndex uiRunOfM = 0;
+    auto flushRun = [ & ]( ) {
+        if( uiRunOfM > 0 )
+        {
+            appendNumber( rOut, uiRunOfM );
+            rOut.push_back( 'M' );
+        }
+        uiRunOfM = 0;
+    };
     const size_t uiSections = rA.data.size( );
     for( size_t k = 0; k < uiSections; k++ )
     {
-        const auto& section = rA.data[ bRev ? uiSections - 1 - k : k ];
-        switch( section.first )
+        const auto& rSection = rA.data[ bRev ? uiSections - 1 - k : k ];
+        const unsigned uiType = (unsigned)rSection.first;
+        if( uiType > (unsigned)MatchType::deletion )
         {
-            case MatchType::seed:
-            case MatchType::match:
-            case MatchType::missmatch:
-                if( bM )
-                    uiSequentialM += section.second;
-                else
-                {
-                    appendNumber( rOut, section.second );
-                    rOut.push_back( section.first == MatchType::missmatch ? 'X' : '=' );
-                }
-                break;
-            case MatchType::insertion:
-            case MatchType::deletion:
-                if( bM && uiSequentialM > 0 )
-                {
-                    appendNumber( rOut, uiSequentialM );
-                    rOut.push_back( 'M' );
-                    uiSequentialM = 0;
-                }
-                appendNumber( rOut, section.second );
-                rOut.push_back( section.first == MatchType::insertion ? 'I' : 'D' );
-                break;
-            default:
-                std::cerr << "WARNING invalid cigar symbol" << std::endl;
-                break;
+            std::cerr << "WARNING invalid cigar symbol" << std::endl;
+            continue;
         }
+        const bool bIndel = uiType >= (unsigned)MatchType::insertion;
+        if( bM && !bIndel )
+        {
+            uiRunOfM += rSection.second;
+            continue;
+        }
+        if( bM )
+            flushRun( );
+        appendNumber( rOut, rSection.second );
+        rOut.push_back( aSymbol[ uiType ] );
     }
-    if( bM && uiSequentialM > 0 )
-    {
-        appendNumber( rOut, uiSequentialM );
-        rOut.push_back( 'M' );
-    }
+    flushRun( );
     if( uiTail > 0 )
         appendClip( rOut, uiTail, bSoftClip );
 }
@@ -291,7 +311,7 @@ inline double amountOfRegionCoveredByHole( const Pack& rPack, uint64_t uiStart, 
     for( const auto& rHole : rPack.vHoles )
         if( rHole.first <= uiEnd && rHole.first + rHole.second > uiStart )
             uiCovered += std::min( uiEnd, rHole.first + rHole.second ) - std::max( uiStart, rHole.first );
-    return uiCovered / (double)( uiEnd - uiStart );
+    return (double)uiCovered / (double)( uiEnd - uiStart );
 }
 // Alignment::getNumDifferences (alignment.h:287-319): mismatches + inserted + deleted bases + reference Ns under matches
 inline size_t getNumDifferences( const Alignment& rA, const Pack& rPack )
@@ -319,51 +339,44 @@ inline std::string ngmlrTags( const NucSeq& rQuery, const std::shared_ptr<Alignm
 {
     const Alignment& rA = *pAlignment;
     std::string sTag = "\tMD:Z:";
+    auto appendTag = [ &sTag ]( const char* sKey, const std::string& sValue ) {
+        sTag += sKey;
+        sTag += sValue;
+    };
     {
         const std::vector<uint8_t> vRef = referenceCodes( rPack, rA.uiBeginOnRef, rA.uiEndOnRef, false );
         size_t uiRPos = 0;
         nucSeqIndex uiPending = 0; // matches and seeds not yet written
-        bool bLastWasDeletion = false;
+        bool bAfterDeletion = false; // a mismatch right behind deleted bases is separated from them by a "0"
         for( const auto& rSection : rA.data )
         {
-            const bool bBreaksRun = rSection.first == MatchType::missmatch || rSection.first == MatchType::deletion;
-            if( bBreaksRun && uiPending > 0 )
+            const MatchType eType = rSection.first;
+            if( eType == MatchType::insertion ) // invisible in MD (but it ends an "after deletion")
             {
-                appendNumber( sTag, uiPending );
+                bAfterDeletion = false;
+                continue;
+            }
+            if( eType == MatchType::match || eType == MatchType::seed )
+                uiPending += rSection.second;
+            else if( eType == MatchType::missmatch || eType == MatchType::deletion )
+            {
+                if( uiPending > 0 )
+                    appendNumber( sTag, uiPending );
                 uiPending = 0;
-            }
-            bool bFirst = !bLastWasDeletion;
-            bLastWasDeletion = false;
-            switch( rSection.first )
-            {
-                case MatchType::match:
-                case MatchType::seed:
-                    uiPending += rSection.second;
-                    uiRPos += rSection.second;
-                    break;
-                case MatchType::insertion:
-                    break;
-                case MatchType::missmatch:
-                    for( nucSeqIndex i = 0; i < rSection.second; i++ )
-                    {
-                        if( bFirst )
-                            bFirst = false;
-                        else
-                            sTag.push_back( '0' );
-                        sTag.push_back( charOf( vRef[ uiRPos + i ] ) );
-                    }
-                    uiRPos += rSection.second;
-                    break;
-                case MatchType::deletion:
+                if( eType == MatchType::deletion )
                     sTag.push_back( '^' );
-                    for( nucSeqIndex i = 0; i < rSection.second; i++ )
-                        sTag.push_back( charOf( vRef[ uiRPos + i ] ) );
-                    uiRPos += rSection.second;
-                    bLastWasDeletion = true;
-                    break;
-                default:
-                    throw std::runtime_error( "Invalid symbol in cigar!" );
+                for( nucSeqIndex i = 0; i < rSection.second; i++ )
+                {
+                    // "0" = no matching base between two mismatching ones (or between a deletion and a mismatch)
+                    if( eType == MatchType::missmatch && ( i > 0 || bAfterDeletion ) )
+                        sTag.push_back( '0' );
+                    sTag.push_back( charOf( vRef[ uiRPos + i ] ) );
+                }
             }
+            else
+                throw std::runtime_error( "Invalid symbol in cigar!" );
+            uiRPos += rSection.second;
+            bAfterDeletion = eType == MatchType::deletion;
         }
         if( uiPending > 0 )
             appendNumber( sTag, uiPending );
@@ -385,15 +398,11 @@ inline std::string ngmlrTags( const NucSeq& rQuery, const std::shared_ptr<Alignm
         for( const auto& rSection : rA.data )
             if( rSection.first == MatchType::seed || rSection.first == MatchType::match )
                 uiMatches += rSection.second;
-        const float fIdentity = uiMatches / (float)std::min( rA.uiEndOnQuery - rA.uiBeginOnQuery, rA.uiEndOnRef - rA.uiBeginOnRef );
-        sTag.append( "\tXI:f:" ).append( std::to_string( fIdentity ) );
+        appendTag( "\tXI:f:", std::to_string( uiMatches / (float)std::min( rA.uiEndOnQuery - rA.uiBeginOnQuery, rA.uiEndOnRef - rA.uiBeginOnRef ) ) );
     }
     sTag.append( "\tXE:i:" ).append( std::to_string( rA.score( ) ) ); // (sic) NGMLR puts the score here
     sTag.append( "\tXR:i:" ).append( std::to_string( rA.uiEndOnQuery - rA.uiBeginOnQuery ) );
-    {
-        const float fCoverage = 100.0f * ( rA.uiEndOnQuery - rA.uiBeginOnQuery ) / (float)rQuery.length( );
-        sTag.append( "\tCV:f:" ).append( std::to_string( fCoverage ) );
-    }
+    appendTag( "\tCV:f:", std::to_string( 100.0f * ( rA.uiEndOnQuery - rA.uiBeginOnQuery ) / (float)rQuery.length( ) ) );
     if( rAll.size( ) > 1 )
     {
         std::string sSisters;
@@ -440,28 +449,11 @@ inline std::string computeTag( const Alignment& rA, bool bLong )
     if( bLong ) // fileWriter.h:327-357
     {
         sTag.append( "\tCG:B:I" );
-        for( auto& rPair : rA.data )
+        static const uint32_t aBamOp[ 5 ] = { 7, 7, 8, 1, 2 }; // seed and match "=", missmatch "X", insertion "I", deletion "D"
+        for( const auto& rSection : rA.data )
         {
-            uint32_t uiOperation = 0;
-            switch( rPair.first )
-            {
-                case MatchType::seed:
-                case MatchType::match:
-                    uiOperation = 7;
-                    break;
-                case MatchType::missmatch:
-                    uiOperation = 8;
-                    break;
-                case MatchType::insertion:
-                    uiOperation = 1;
-                    break;
-                case MatchType::deletion:
-                    uiOperation = 2;
-                    break;
-                default:
-                    break;
-            }
-            sTag.append( "," ).append( std::to_string( (uint32_t)( rPair.second << 4 ) | uiOperation ) );
+            sTag.push_back( ',' );
+            appendNumber( sTag, (uint32_t)( rSection.second << 4 ) | ( (unsigned)rSection.first < 5 ? aBamOp[ (unsigned)rSection.first ] : 0 ) );
         }
     }
     return sTag;
@@ -550,47 +542,77 @@ class StringOutStream : public OutStream // convenience for tests and in-memory 
     }
 };
 
-class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::ContainerVector<std::shared_ptr<Alignment>>, Pack>
+namespace sam
 {
-    static const size_t uiMaxCigarLen = 0x10000;
-    void init( const SamOptions& )
-    {}
+// "stdout" or a file (fileWriter.h:385-400)
+inline std::shared_ptr<OutStream> openSink( const std::string& sFileName )
+{
+    if( sFileName == "stdout" )
+        return std::make_shared<StdOutStream>( );
+    return std::make_shared<FileOutStream>( sFileName );
+}
+// @SQ line per contig, then @PG.  (sic) the file-name constructors separate SN and LN by a tab, the stream constructors
+// by a blank (fileWriter.h:385-422,474-511)
+inline void writeHeader( OutStream& rOut, const Pack& rPack, bool bTabBeforeLength )
+{
+    std::string sHeader;
+    for( size_t i = 0; i < rPack.vNames.size( ); i++ )
+    {
+        sHeader += "@SQ\tSN:" + rPack.vNames[ i ];
+        sHeader += bTabBeforeLength ? "\tLN:" : " LN:";
+        appendNumber( sHeader, rPack.vLengths[ i ] );
+        sHeader.push_back( '\n' );
+    }
+    sHeader += "@PG\tID:ma\tPN:ma\tVN:0.1.0\tCL:na\n";
+    rOut << sHeader;
+}
+} // namespace sam
 
+// What the two writers share: the sink, the lock that serialises the records of different graph threads on it (several
+// writers may share both: fileWriter.h:430-436,520-541) and the SAM options of the parameter set.
+class SamSink
+{
   public:
     std::shared_ptr<OutStream> pOut;
     std::shared_ptr<std::mutex> pLock;
     const SamOptions xOptions;
+    static const size_t uiMaxCigarLen = 0x10000; // cigars with more operations go to the CG tag (fileWriter.h:364)
+
+  protected:
+    SamSink( std::shared_ptr<OutStream> pOut, std::shared_ptr<std::mutex> pLock, const SamOptions& rOptions )
+        : pOut( pOut ), pLock( pLock ), xOptions( rOptions )
+    {}
+    // the records of one read (or pair) leave as one block
+    void emit( const std::string& sRecords ) const
+    {
+        if( sRecords.empty( ) )
+            return;
+        std::unique_lock<std::mutex> xTurn( *pLock );
+        pOut->write( sRecords.data( ), sRecords.size( ) );
+    }
+};
+
+class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::ContainerVector<std::shared_ptr<Alignment>>, Pack>,
+                   public SamSink
+{
+  public:
 
     // fileWriter.h:385-400: "stdout" or a file name; header with tab-separated @SQ fields
     FileWriter( const ParameterSetManager& rParameters, std::string sFileName, std::shared_ptr<Pack> pPackContainer )
-        : pLock( new std::mutex ), xOptions( rParameters.xSam )
+        : SamSink( sam::openSink( sFileName ), std::make_shared<std::mutex>( ), rParameters.xSam )
     {
-        init( xOptions );
-        if( sFileName != "stdout" )
-            pOut = std::shared_ptr<OutStream>( new FileOutStream( sFileName ) );
-        else
-            pOut = std::shared_ptr<OutStream>( new StdOutStream( ) );
-        for( size_t i = 0; i < pPackContainer->vNames.size( ); i++ )
-            *pOut << "@SQ\tSN:" << pPackContainer->vNames[ i ] << "\tLN:" << std::to_string( pPackContainer->vLengths[ i ] )
-                  << "\n";
-        *pOut << "@PG\tID:ma\tPN:ma\tVN:0.1.0\tCL:na\n";
+        sam::writeHeader( *pOut, *pPackContainer, true );
     }
     // fileWriter.h:407-422 (sic: a blank, not a tab, before LN)
     FileWriter( const ParameterSetManager& rParameters, std::shared_ptr<OutStream> pOut_, std::shared_ptr<Pack> pPackContainer )
-        : pOut( pOut_ ), pLock( new std::mutex ), xOptions( rParameters.xSam )
+        : SamSink( pOut_, std::make_shared<std::mutex>( ), rParameters.xSam )
     {
-        init( xOptions );
-        for( size_t i = 0; i < pPackContainer->vNames.size( ); i++ )
-            *pOut << "@SQ\tSN:" << pPackContainer->vNames[ i ] << " LN:" << std::to_string( pPackContainer->vLengths[ i ] )
-                  << "\n";
-        *pOut << "@PG\tID:ma\tPN:ma\tVN:0.1.0\tCL:na\n";
+        sam::writeHeader( *pOut, *pPackContainer, false );
     }
     // fileWriter.h:430-436: a second writer on the same stream
     FileWriter( const ParameterSetManager& rParameters, std::shared_ptr<FileWriter> pOther )
-        : pOut( pOther->pOut ), pLock( pOther->pLock ), xOptions( rParameters.xSam )
-    {
-        init( xOptions );
-    }
+        : SamSink( pOther->pOut, pOther->pLock, rParameters.xSam )
+    {}
 
     // fileWriter.cpp:11-158
     virtual std::shared_ptr<libMS::Container>
@@ -668,14 +690,11 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
                 sCombined += sam::computeTag( rA, bLong );
             sCombined.push_back( '\n' );
         }
-        if( pAlignments->size( ) == 0 )
+        if( pAlignments->empty( ) )
             unmapped( "255" );
-        if( sCombined.size( ) == 0 )
+        else if( sCombined.empty( ) ) // every alignment was filtered out
             unmapped( "0" );
-        {
-            std::lock_guard<std::mutex> xGuard( *pLock );
-            *pOut << sCombined;
-        }
+        emit( sCombined );
         return std::make_shared<libMS::Container>( );
     }
     virtual bool requiresLock( ) const
@@ -685,142 +704,135 @@ class FileWriter : public libMS::Module<libMS::Container, false, NucSeq, libMS::
 };
 // PairedFileWriter (fileWriter.h:456-545, fileWriter.cpp:158-380): SAM records of a mate pair
 class PairedFileWriter : public libMS::Module<libMS::Container, false, NucSeq, NucSeq,
-                                              libMS::ContainerVector<std::shared_ptr<Alignment>>, Pack>
+                                              libMS::ContainerVector<std::shared_ptr<Alignment>>, Pack>,
+                         public SamSink
 {
-    static const size_t uiMaxCigarLen = 0x10000;
     void init( const SamOptions& rO )
     {
         if( rO.bEmulateNgmlrTags )
             throw std::runtime_error( "PairedFileWriter: the NGMLR tag emulation is not available in the MI355X host layer" );
     }
-    void header( std::shared_ptr<Pack> pPackContainer, const char* sSep )
-    {
-        for( size_t i = 0; i < pPackContainer->vNames.size( ); i++ )
-            *pOut << "@SQ\tSN:" << pPackContainer->vNames[ i ] << sSep << std::to_string( pPackContainer->vLengths[ i ] ) << "\n";
-        *pOut << "@PG\tID:ma\tPN:ma\tVN:0.1.0\tCL:na\n";
-    }
 
   public:
-    std::shared_ptr<OutStream> pOut;
-    std::shared_ptr<std::mutex> pLock;
-    const SamOptions xOptions;
-
     // fileWriter.h:474-491
     PairedFileWriter( const ParameterSetManager& rParameters, std::string sFileName, std::shared_ptr<Pack> pPackContainer )
-        : pLock( new std::mutex ), xOptions( rParameters.xSam )
+        : SamSink( sam::openSink( sFileName ), std::make_shared<std::mutex>( ), rParameters.xSam )
     {
         init( xOptions );
-        if( sFileName != "stdout" )
-            pOut = std::shared_ptr<OutStream>( new FileOutStream( sFileName ) );
-        else
-            pOut = std::shared_ptr<OutStream>( new StdOutStream( ) );
-        header( pPackContainer, "\tLN:" );
+        sam::writeHeader( *pOut, *pPackContainer, true );
     }
     // fileWriter.h:498-511 (sic: a blank, not a tab, before LN)
     PairedFileWriter( const ParameterSetManager& rParameters, std::shared_ptr<OutStream> pOut_, std::shared_ptr<Pack> pPackContainer )
-        : pOut( pOut_ ), pLock( new std::mutex ), xOptions( rParameters.xSam )
+        : SamSink( pOut_, std::make_shared<std::mutex>( ), rParameters.xSam )
     {
         init( xOptions );
-        header( pPackContainer, " LN:" );
+        sam::writeHeader( *pOut, *pPackContainer, false );
     }
     // fileWriter.h:520-541: further writers on the same stream
     PairedFileWriter( const ParameterSetManager& rParameters, std::shared_ptr<FileWriter> pOther )
-        : pOut( pOther->pOut ), pLock( pOther->pLock ), xOptions( rParameters.xSam )
+        : SamSink( pOther->pOut, pOther->pLock, rParameters.xSam )
     {
         init( xOptions );
     }
     PairedFileWriter( const ParameterSetManager& rParameters, std::shared_ptr<PairedFileWriter> pOther )
-        : pOut( pOther->pOut ), pLock( pOther->pLock ), xOptions( rParameters.xSam )
+        : SamSink( pOther->pOut, pOther->pLock, rParameters.xSam )
     {
         init( xOptions );
     }
 
+    // fileWriter.cpp:158-383.  Every record of the pair goes through ONE emitter (sam::Columns below appends the eleven
+    // mandatory columns to the pair's buffer in order); the three shapes of a record differ only in what the columns hold:
+    //   aligned mate          FLAG = strand | secondary | supplementary | 0x1 | 0x2 | first/last | mate strand, RNEXT / PNEXT = the mate's
+    //                         alignment ("=" on the same contig), CIGAR clipped against the length of the FIRST mate (sic, :191-193)
+    //   pair without any      FLAG = 0x4 | 0x1 | first/last | 0x8, everything else empty, QUAL printed
+    //   one mate unaligned    placed at the first alignment of the list (:348-366), RNEXT "=", QUAL "*"
     virtual std::shared_ptr<libMS::Container>
     execute( std::shared_ptr<NucSeq> pQuery1, std::shared_ptr<NucSeq> pQuery2,
              std::shared_ptr<libMS::ContainerVector<std::shared_ptr<Alignment>>> pAlignments, std::shared_ptr<Pack> pPack ) override
     {
-        std::string sCombined;
-        bool bFirstQueryHasAlignment = false, bSecondQueryHasAlignment = false;
-        for( std::shared_ptr<Alignment> pAlignment : *pAlignments )
+        const NucSeq* const apMate[ 2 ] = { pQuery1.get( ), pQuery2.get( ) };
+        const uint32_t aMateFlag[ 2 ] = { MA_SAM_FIRST_IN_TEMPLATE, MA_SAM_LAST_IN_TEMPLATE };
+        bool aHasRecord[ 2 ] = { false, false };
+        std::string sPair;
+        sPair.reserve( pAlignments->size( ) * ( pQuery1->length( ) + pQuery2->length( ) + 96 ) + 2 * ( pQuery1->length( ) + pQuery2->length( ) ) + 128 );
+        for( const std::shared_ptr<Alignment>& pAlignment : *pAlignments )
         {
-            if( sam::length( *pAlignment ) == 0 )
+            const Alignment& rA = *pAlignment;
+            if( sam::length( rA ) == 0 || ( xOptions.bNoSecondary && rA.bSecondary ) || ( xOptions.bNoSupplementary && rA.bSupplementary ) )
                 continue;
-            if( xOptions.bNoSecondary && pAlignment->bSecondary )
-                continue;
-            if( xOptions.bNoSupplementary && pAlignment->bSupplementary )
-                continue;
-            const bool bFirst = pAlignment->xStats.bFirst;
-            ( bFirst ? bFirstQueryHasAlignment : bSecondQueryHasAlignment ) = true;
-            const NucSeq& rQuery = bFirst ? *pQuery1 : *pQuery2;
-            const bool bLong = xOptions.bCGTag && pAlignment->data.size( ) >= uiMaxCigarLen;
-            std::string sCigar;
-            if( bLong )
-                sCigar = std::to_string( pAlignment->uiEndOnQuery - pAlignment->uiBeginOnQuery ).append( "S" );
-            else // (sic) clipped against the length of the FIRST mate (fileWriter.cpp:191-193)
-                sCigar = sam::cigarString( *pAlignment, *pPack, pQuery1->length( ), xOptions.bSoftClip, xOptions.bOutputMCigar );
-            uint32_t flag = sam::getSamFlag( *pAlignment, *pPack );
-            std::string sContigOther = "*", sPosOther = "0";
-            std::string sSegment;
-            if( xOptions.bSoftClip )
-                sSegment = sam::bPositionIsOnReversStrand( *pPack, pAlignment->uiBeginOnRef )
-                               ? sam::fromToComplement( rQuery, 0, rQuery.length( ) )
-                               : sam::toString( rQuery );
+            const int iMate = rA.xStats.bFirst ? 0 : 1;
+            const NucSeq& rMate = *apMate[ iMate ];
+            aHasRecord[ iMate ] = true;
+            const bool bRev = sam::bPositionIsOnReversStrand( *pPack, rA.uiBeginOnRef );
+            const bool bLong = xOptions.bCGTag && rA.data.size( ) >= uiMaxCigarLen;
+            const size_t uiContig = (size_t)sam::uiSequenceIdForPosition( *pPack, rA.uiBeginOnRef );
+            const std::shared_ptr<Alignment> pPartner = rA.xStats.pOther.lock( );
+            uint32_t uiFlag = sam::getSamFlag( rA, *pPack ) | MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE | MA_SAM_SEGMENT_PROPERLY_ALIGNED | aMateFlag[ iMate ];
+            if( pPartner != nullptr && sam::bPositionIsOnReversStrand( *pPack, pPartner->uiBeginOnRef ) )
+                uiFlag |= MA_SAM_NEXT_REVERSE_COMPLEMENTED;
+            sam::Columns xLine( sPair );
+            xLine.text( rMate.sName ).number( uiFlag ).text( pPack->vNames[ uiContig ] ).number( sam::getSamPosition( rA, *pPack ) );
+            if( std::isnan( rA.fMappingQuality ) )
+                xLine.text( "255" );
             else
-                sSegment = sam::getQuerySequence( *pAlignment, rQuery, *pPack );
-            const std::string sQual = sam::fromToQual( rQuery, pAlignment->uiBeginOnQuery, pAlignment->uiEndOnQuery );
-            flag |= MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE | MA_SAM_SEGMENT_PROPERLY_ALIGNED;
-            flag |= bFirst ? MA_SAM_FIRST_IN_TEMPLATE : MA_SAM_LAST_IN_TEMPLATE;
-            const std::string sRefName = sam::nameOfSequenceForPosition( *pPack, pAlignment->uiBeginOnRef );
-            if( auto pOther = pAlignment->xStats.pOther.lock( ) )
+                xLine.number( (uint64_t)std::min( static_cast<int>( std::ceil( rA.fMappingQuality * 254 ) ), 255 ) );
+            xLine.column( [ & ]( std::string& rOut ) {
+                if( bLong )
+                {
+                    sam::appendNumber( rOut, rA.uiEndOnQuery - rA.uiBeginOnQuery );
+                    rOut.push_back( 'S' );
+                }
+                else
+                    sam::appendCigar( rOut, rA, *pPack, pQuery1->length( ), xOptions.bSoftClip, xOptions.bOutputMCigar );
+            } );
+            if( pPartner != nullptr )
             {
-                if( sam::bPositionIsOnReversStrand( *pPack, pOther->uiBeginOnRef ) )
-                    flag |= MA_SAM_NEXT_REVERSE_COMPLEMENTED;
-                sContigOther = sam::nameOfSequenceForPosition( *pPack, pOther->uiBeginOnRef );
-                if( sContigOther == sRefName )
-                    sContigOther = "=";
-                sPosOther = std::to_string( sam::getSamPosition( *pOther, *pPack ) );
+                const size_t uiPartnerContig = (size_t)sam::uiSequenceIdForPosition( *pPack, pPartner->uiBeginOnRef );
+                xLine.text( pPack->vNames[ uiPartnerContig ] == pPack->vNames[ uiContig ] ? std::string( "=" ) : pPack->vNames[ uiPartnerContig ] );
+                xLine.number( sam::getSamPosition( *pPartner, *pPack ) );
             }
-            const nucSeqIndex uiRefPos = sam::getSamPosition( *pAlignment, *pPack );
-            const std::string sTag = sam::computeTag( *pAlignment, bLong );
-            std::string sMapQual;
-            if( std::isnan( pAlignment->fMappingQuality ) )
-                sMapQual = "255";
             else
-                sMapQual = std::to_string( std::min( static_cast<int>( std::ceil( pAlignment->fMappingQuality * 254 ) ), 255 ) );
-            // the template length is not output by the reference ("0", fileWriter.cpp:317)
-            sCombined += ( bFirst ? pQuery1->sName : pQuery2->sName ) + "\t" + std::to_string( flag ) + "\t" + sRefName + "\t" +
-                         std::to_string( uiRefPos ) + "\t" + sMapQual + "\t" + sCigar + "\t" + sContigOther + "\t" + sPosOther +
-                         "\t0\t" + sSegment + "\t" + sQual + sTag + "\n";
+                xLine.text( "*" ).text( "0" );
+            xLine.text( "0" ); // the template length is not output by the reference (fileWriter.cpp:317)
+            xLine.column( [ & ]( std::string& rOut ) {
+                const nucSeqIndex uiFrom = xOptions.bSoftClip ? 0 : rA.uiBeginOnQuery, uiTo = xOptions.bSoftClip ? rMate.length( ) : rA.uiEndOnQuery;
+                const size_t uiBefore = rOut.size( );
+                if( bRev )
+                    sam::appendFromToComplement( rOut, rMate, uiFrom, uiTo );
+                else
+                    sam::appendFromTo( rOut, rMate, uiFrom, uiTo );
+                if( !xOptions.bSoftClip && rOut.size( ) - uiBefore != rA.uiEndOnQuery - rA.uiBeginOnQuery )
+                    throw std::runtime_error( "Query length is off by " +
+                                              std::to_string( (int64_t)( rOut.size( ) - uiBefore ) - (int64_t)( rA.uiEndOnQuery - rA.uiBeginOnQuery ) ) + "." );
+            } );
+            xLine.column( [ & ]( std::string& rOut ) { sam::appendFromToQual( rOut, rMate, rA.uiBeginOnQuery, rA.uiEndOnQuery ); } );
+            if( bLong )
+                sPair += sam::computeTag( rA, bLong );
+            xLine.end( );
         }
-        if( !bFirstQueryHasAlignment && !bSecondQueryHasAlignment )
+        auto unaligned = [ & ]( int iMate, uint32_t uiExtraFlags, const std::string& sContig, const std::string& sPos, const char* sNext,
+                                bool bWithQuality ) {
+            const NucSeq& rMate = *apMate[ iMate ];
+            sam::Columns xLine( sPair );
+            xLine.text( rMate.sName ).number( MA_SAM_SEGMENT_UNMAPPED | MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE | aMateFlag[ iMate ] | uiExtraFlags );
+            xLine.text( sContig ).text( sPos ).text( "0" ).text( "*" ).text( sNext ).text( sPos ).text( "0" );
+            xLine.column( [ & ]( std::string& rOut ) { sam::appendFromTo( rOut, rMate, 0, rMate.length( ) ); } );
+            if( bWithQuality )
+                xLine.column( [ & ]( std::string& rOut ) { sam::appendFromToQual( rOut, rMate, 0, rMate.length( ) ); } );
+            else
+                xLine.text( "*" );
+            xLine.end( );
+        };
+        if( !aHasRecord[ 0 ] && !aHasRecord[ 1 ] )
+            for( int iMate = 0; iMate < 2; iMate++ )
+                unaligned( iMate, MA_SAM_NEXT_SEGMENT_UNMAPPED, "*", "0", "*", true );
+        else if( aHasRecord[ 0 ] != aHasRecord[ 1 ] )
         {
-            sCombined += pQuery1->sName + "\t" +
-                         std::to_string( MA_SAM_SEGMENT_UNMAPPED | MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE | MA_SAM_FIRST_IN_TEMPLATE |
-                                         MA_SAM_NEXT_SEGMENT_UNMAPPED ) +
-                         "\t*\t0\t0\t*\t*\t0\t0\t" + sam::toString( *pQuery1 ) + "\t" +
-                         sam::fromToQual( *pQuery1, 0, pQuery1->length( ) ) + "\n";
-            sCombined += pQuery2->sName + "\t" +
-                         std::to_string( MA_SAM_SEGMENT_UNMAPPED | MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE | MA_SAM_LAST_IN_TEMPLATE |
-                                         MA_SAM_NEXT_SEGMENT_UNMAPPED ) +
-                         "\t*\t0\t0\t*\t*\t0\t0\t" + sam::toString( *pQuery2 ) + "\t" +
-                         sam::fromToQual( *pQuery2, 0, pQuery2->length( ) ) + "\n";
+            const Alignment& rAnchor = *( *pAlignments )[ 0 ];
+            unaligned( aHasRecord[ 0 ] ? 1 : 0, 0, sam::nameOfSequenceForPosition( *pPack, rAnchor.uiBeginOnRef ),
+                       std::to_string( sam::getSamPosition( rAnchor, *pPack ) ), "=", false );
         }
-        else if( !bFirstQueryHasAlignment || !bSecondQueryHasAlignment )
-        {
-            // the unaligned mate is placed at the first alignment of the list (fileWriter.cpp:348-366)
-            const std::string sPosOther = std::to_string( sam::getSamPosition( *( *pAlignments )[ 0 ], *pPack ) );
-            const std::string sContigOther = sam::nameOfSequenceForPosition( *pPack, ( *pAlignments )[ 0 ]->uiBeginOnRef );
-            sCombined += ( !bFirstQueryHasAlignment ? pQuery1->sName : pQuery2->sName ) + "\t" +
-                         std::to_string( MA_SAM_SEGMENT_UNMAPPED | MA_SAM_MULTIPLE_SEGMENTS_IN_TEMPLATE |
-                                         ( !bFirstQueryHasAlignment ? MA_SAM_FIRST_IN_TEMPLATE : MA_SAM_LAST_IN_TEMPLATE ) ) +
-                         "\t" + sContigOther + "\t" + sPosOther + "\t0\t*\t=\t" + sPosOther + "\t0\t" +
-                         ( !bFirstQueryHasAlignment ? sam::toString( *pQuery1 ) : sam::toString( *pQuery2 ) ) + "\t*\n";
-        }
-        if( sCombined.size( ) > 0 )
-        {
-            std::lock_guard<std::mutex> xGuard( *pLock );
-            *pOut << sCombined;
-        }
+        emit( sPair );
         return std::make_shared<libMS::Container>( );
     }
     virtual bool requiresLock( ) const
@@ -839,63 +851,92 @@ class FileStream : public libMS::Container
     virtual std::string fileName( ) = 0;
     virtual void safeGetLine( std::string& t ) = 0;
 };
-namespace detail
+// Character source over any std::istream, read a block at a time: peek / pop / one line work on memory, so a FASTQ file is
+// scanned at memory speed (the per-character virtual calls and streambuf round trips of a plain istream wrapper cost ~10 ns
+// per byte).  What callers observe is what the reference's StdFileStream / StringStream show them (fileReader.h:100-200):
+//   - "\n", "\r\n" and a lone "\r" end a line; a last line without a line end still counts
+//   - eof() turns true when a peek / pop / line finds nothing left -- not before (the record parser peeks first)
+template <typename SOURCE> class BlockFileStream : public FileStream
 {
-// One text line off a stream buffer; "\n", "\r\n" and a lone "\r" all end a line, and a final line without a line end
-// still counts.  Reaching the end with nothing read marks the stream as exhausted (what FileStream::eof() reports;
-// behaviour of fileReader.h:152-186).
-inline void safeGetLine( std::istream& rIn, std::string& rLine )
-{
-    typedef std::streambuf::traits_type TR;
-    std::streambuf* const pBuf = rIn.rdbuf( );
-    rLine.clear( );
-    for( TR::int_type iNext = pBuf->sbumpc( ); !TR::eq_int_type( iNext, TR::eof( ) ); iNext = pBuf->sbumpc( ) )
+  protected:
+    SOURCE xSource;
+
+  private:
+    std::vector<char> vBlock;
+    size_t uiAt = 0, uiFilled = 0;
+    bool bSawEnd = false;
+
+    bool available( ) // at least one unread character in the block
     {
-        const char cNext = TR::to_char_type( iNext );
-        if( cNext == '\n' )
-            return;
-        if( cNext == '\r' )
-        {
-            if( TR::eq_int_type( pBuf->sgetc( ), TR::to_int_type( '\n' ) ) )
-                pBuf->sbumpc( ); // the second half of a Windows line end
-            return;
-        }
-        rLine.push_back( cNext );
+        if( uiAt < uiFilled )
+            return true;
+        if( vBlock.empty( ) )
+            vBlock.resize( 1u << 20 );
+        xSource.read( vBlock.data( ), (std::streamsize)vBlock.size( ) );
+        uiAt = 0;
+        uiFilled = (size_t)xSource.gcount( );
+        return uiFilled > 0;
     }
-    if( rLine.empty( ) )
-        rIn.setstate( std::ios::eofbit );
-}
-} // namespace detail
-class StdFileStream : public FileStream
-{
-    std::ifstream xStream;
-    const std::string sFileName;
 
   public:
-    StdFileStream( const std::string& sFilename ) : xStream( sFilename ), sFileName( sFilename )
-    {
-        if( !xStream.is_open( ) )
-            throw std::runtime_error( "Unable to open file " + sFilename );
-    }
+    template <typename... ARGS> explicit BlockFileStream( ARGS&&... args ) : xSource( std::forward<ARGS>( args )... )
+    {}
     bool eof( ) const override
     {
-        return !xStream.good( ) || xStream.eof( );
+        return bSawEnd;
     }
     char peek( ) override
     {
-        return (char)xStream.peek( );
+        if( !available( ) )
+        {
+            bSawEnd = true;
+            return (char)std::char_traits<char>::eof( );
+        }
+        return vBlock[ uiAt ];
     }
     char pop( ) override
     {
-        return (char)xStream.get( );
+        const char cNext = peek( );
+        if( !bSawEnd )
+            uiAt++;
+        return cNext;
+    }
+    void safeGetLine( std::string& rLine ) override
+    {
+        rLine.clear( );
+        while( available( ) )
+        {
+            const char* const pFrom = vBlock.data( ) + uiAt;
+            const char* const pEnd = vBlock.data( ) + uiFilled;
+            const char* pStop = pFrom;
+            while( pStop != pEnd && *pStop != '\n' && *pStop != '\r' )
+                pStop++;
+            rLine.append( pFrom, pStop );
+            uiAt += (size_t)( pStop - pFrom );
+            if( pStop == pEnd )
+                continue; // the line goes on in the next block
+            uiAt++; // the line end itself
+            if( *pStop == '\r' && available( ) && vBlock[ uiAt ] == '\n' )
+                uiAt++; // the second half of a Windows line end
+            return;
+        }
+        if( rLine.empty( ) )
+            bSawEnd = true; // nothing was left
+    }
+};
+class StdFileStream : public BlockFileStream<std::ifstream>
+{
+    const std::string sFileName;
+
+  public:
+    StdFileStream( const std::string& sFilename ) : BlockFileStream<std::ifstream>( sFilename ), sFileName( sFilename )
+    {
+        if( !xSource.is_open( ) )
+            throw std::runtime_error( "Unable to open file " + sFilename );
     }
     std::string fileName( ) override
     {
         return sFileName;
-    }
-    void safeGetLine( std::string& t ) override
-    {
-        detail::safeGetLine( xStream, t );
     }
 };
 #ifdef MA_WITH_ZLIB
@@ -904,7 +945,7 @@ class StdFileStream : public FileStream
 class GzFileStream : public FileStream
 {
     gzFile pFile = nullptr;
-    int lastReadReturn = 0; // 1 == last read was ok; 0 == eof; -1 == error
+    int iLastRead = 0; // what the last gzread returned: 1 = a byte, 0 = end of the file, < 0 = failure
     unsigned char cBuff = 0;
     const std::string sFileName;
     void open( )
@@ -912,15 +953,14 @@ class GzFileStream : public FileStream
         if( pFile == nullptr )
         {
             pFile = gzopen( sFileName.c_str( ), "rb" );
-            lastReadReturn = pFile != nullptr ? gzread( pFile, &cBuff, 1 ) : -1;
+            iLastRead = pFile != nullptr ? gzread( pFile, &cBuff, 1 ) : -1;
         }
     }
 
   public:
     GzFileStream( const std::string& sFilename ) : sFileName( sFilename )
     {
-        std::ifstream xFileEnd( sFilename, std::ifstream::ate | std::ifstream::binary );
-        if( !xFileEnd.is_open( ) )
+        if( !std::ifstream( sFilename, std::ios::binary ).is_open( ) ) // the reference probes the file the same way before zlib opens it lazily
             throw std::runtime_error( "Unable to open file " + sFilename );
     }
     ~GzFileStream( )
@@ -930,7 +970,7 @@ class GzFileStream : public FileStream
     }
     bool eof( ) const override
     {
-        return lastReadReturn != 1;
+        return iLastRead != 1;
     }
     char peek( ) override
     {
@@ -957,8 +997,8 @@ class GzFileStream : public FileStream
     {
         open( );
         rLine.clear( );
-        auto have = [ this ]( ) { return lastReadReturn == 1; };
-        auto advance = [ this ]( ) { lastReadReturn = gzread( pFile, &cBuff, 1 ); };
+        auto have = [ this ]( ) { return iLastRead == 1; };
+        auto advance = [ this ]( ) { iLastRead = gzread( pFile, &cBuff, 1 ); };
         while( have( ) )
         {
             if( cBuff == '\r' )
@@ -978,32 +1018,14 @@ class GzFileStream : public FileStream
     }
 };
 #endif
-class StringStream : public FileStream
+class StringStream : public BlockFileStream<std::istringstream>
 {
-    std::stringstream xStream;
-
   public:
-    StringStream( const std::string& sString ) : xStream( sString )
+    StringStream( const std::string& sString ) : BlockFileStream<std::istringstream>( sString )
     {}
-    bool eof( ) const override
-    {
-        return !xStream.good( ) || xStream.eof( );
-    }
-    char peek( ) override
-    {
-        return (char)xStream.peek( );
-    }
-    char pop( ) override
-    {
-        return (char)xStream.get( );
-    }
     std::string fileName( ) override
     {
         return "StringStream";
-    }
-    void safeGetLine( std::string& t ) override
-    {
-        detail::safeGetLine( xStream, t );
     }
 };
 
@@ -1189,21 +1211,21 @@ class PairedFileReader : public libMS::Module<PairedReadsContainer, true, Paired
     {}
     virtual std::shared_ptr<PairedReadsContainer> execute( std::shared_ptr<PairedFileStream> pFileStreamIn ) override
     {
-        auto pRet = std::make_shared<PairedReadsContainer>( );
-        pRet->push_back( xFileReader.execute( pFileStreamIn->first ) );
-        pRet->push_back( xFileReader.execute( pFileStreamIn->second ) );
-        if( ( *pRet )[ 0 ] == nullptr || ( *pRet )[ 1 ] == nullptr )
+        // one record off each file; the pair stream ends with the shorter file (both files are read before the check, like
+        // the reference does: fileReader.h:590-600)
+        const std::shared_ptr<NucSeq> apMate[ 2 ] = { xFileReader.execute( pFileStreamIn->first ), xFileReader.execute( pFileStreamIn->second ) };
+        if( apMate[ 0 ] == nullptr || apMate[ 1 ] == nullptr )
             return nullptr;
         if( bRevCompMate )
         {
             // NucSeq::vReverse (nucSeq.h:373-381, with the qualities) + vSwitchAllBasePairsToComplement (537-543)
-            NucSeq& rMate = *pRet->back( );
+            NucSeq& rMate = *apMate[ 1 ];
             std::reverse( rMate.xCodes.begin( ), rMate.xCodes.end( ) );
             std::reverse( rMate.xQuality.begin( ), rMate.xQuality.end( ) );
             for( uint8_t& c : rMate.xCodes )
                 c = c < 4 ? (uint8_t)( 3 - c ) : (uint8_t)5;
         }
-        return pRet;
+        return std::make_shared<PairedReadsContainer>( std::begin( apMate ), std::end( apMate ) );
     }
 };
 
