@@ -204,6 +204,66 @@ int main( int argc, char** argv )
                       (unsigned long long)pSinkG->uiBytes.load( ) );
             sBatchGraph += buf;
         }
+        // ---- leg 2d: the doAlign shape (execution-context.h:291-406) end to end: FASTQ TEXT -> BatchFileReader -> BatchAlign ->
+        // BatchFileWriter -> SAM bytes, graph threads under simultaneousGet.  The text lives in memory (no disk in the timing).
+        std::string sFastqGraph;
+        {
+            std::string sFastq;
+            sFastq.reserve( n * ( 2 * uiLen + 24 ) );
+            for( size_t i = 0; i < n; i++ )
+            {
+                const NucSeq& rQ = *( *pReads )[ i ];
+                sFastq.push_back( '@' );
+                sFastq += rQ.sName;
+                sFastq.push_back( '\n' );
+                for( uint8_t b : rQ.xCodes )
+                    sFastq.push_back( "ACGTN"[ b < 4 ? b : 4 ] );
+                sFastq += "\n+\n";
+                sFastq.append( rQ.xCodes.size( ), 'F' );
+                sFastq.push_back( '\n' );
+            }
+            for( int iT : { 3, 4, 6 } )
+            {
+                auto pSinkG = std::make_shared<CountingSink>( );
+                auto pStream = std::make_shared<Pledge<FileStream>>( );
+                pStream->set( std::make_shared<StringStream>( sFastq ) );
+                auto pBatchReader = std::make_shared<BatchFileReader>( xParams );
+                pBatchReader->uiBatchReads = 1u << 17;
+                auto pAlign = std::make_shared<BatchAlign>( xParams );
+                auto pBatchWriter = std::make_shared<BatchFileWriter>( xParams, std::static_pointer_cast<OutStream>( pSinkG ), pPack );
+                pBatchWriter->uiFormatThreads = std::min( 16u, uiHw );
+                auto pPackP = std::make_shared<Pledge<Pack>>( );
+                pPackP->set( pPack );
+                auto pFmP = std::make_shared<Pledge<FMIndex>>( );
+                pFmP->set( pFM );
+                std::vector<std::shared_ptr<BasePledge>> vSinks;
+                for( int t = 0; t < iT; t++ )
+                {
+                    auto pBatch = promiseMe( std::make_shared<Lock<ReadVec>>( ), promiseMe( pBatchReader, pStream ) );
+                    auto pAligned = promiseMe( pAlign, pFmP, pBatch );
+                    auto pWritten = promiseMe( pBatchWriter, pBatch, pAligned, pPackP );
+                    vSinks.push_back( promiseMe( std::make_shared<UnLock<Container>>( pBatch ), pWritten ) );
+                }
+                {
+                    std::vector<std::thread> vWarm;
+                    for( int t = 0; t < iT; t++ )
+                        vWarm.emplace_back( [ & ]( ) {
+                            pAlign->execute( pFM, std::make_shared<ReadVec>( pReads->begin( ), pReads->begin( ) + std::min<size_t>( n, 1u << 17 ) ) );
+                        } );
+                    for( auto& rT : vWarm )
+                        rT.join( );
+                    pAlign->uiBatches = 0;
+                }
+                t0 = now( );
+                BasePledge::simultaneousGet( vSinks );
+                const double f = now( ) - t0;
+                char buf[ 384 ];
+                snprintf( buf, sizeof( buf ), "%s\"graph_threads_%d\": {\"reads_per_s\": %.1f, \"wall_s\": %.4f, \"device_batches\": %llu, \"fastq_bytes\": %zu, \"sam_bytes\": %llu}",
+                          sFastqGraph.empty( ) ? "" : ", ", iT, n / f, f, (unsigned long long)pAlign->uiBatches.load( ), sFastq.size( ),
+                          (unsigned long long)pSinkG->uiBytes.load( ) );
+                sFastqGraph += buf;
+            }
+        }
         // ---- leg 2: SAM text of every read
         auto pSink = std::make_shared<CountingSink>( );
         FileWriter xWriter( xParams, std::static_pointer_cast<OutStream>( pSink ), pPack );
@@ -272,6 +332,8 @@ int main( int argc, char** argv )
                 "up to 32 threads into byte arenas, one write per batch\"}, "
                 "\"batch_graph\": {%s, \"what\": \"BatchSource -> BatchAlign -> BatchFileWriter as graph nodes under promiseMe / "
                 "simultaneousGet, 128 k reads per device batch, one device batch in flight per graph thread: reads in host memory -> SAM bytes\"}, "
+                "\"fastq_to_sam_graph\": {%s, \"what\": \"FASTQ text in memory -> BatchFileReader (records cut out of the stream under its lock, "
+                "reads built outside) -> BatchAlign -> BatchFileWriter -> SAM bytes: the shape of ExecutionContext::doAlign as batch graph nodes\"}, "
                 "\"sam\": {\"reads_per_s\": %.1f, \"threads\": %u, \"bytes\": %llu, \"what\": \"FileWriter::execute per read into a "
                 "counting sink\"}, "
                 "\"graph\": {\"reads_per_s\": %.1f, \"graph_threads\": %d, \"device_batches\": %llu, \"mean_reads_per_device_batch\": %.1f, "
@@ -279,7 +341,7 @@ int main( int argc, char** argv )
                 "NeedlemanWunsch -> MappingQuality -> FileWriter) on that many graph threads; per-read execute() calls funnelled into "
                 "device batches\"}}\n",
                 n, uiLen, uiHw, fLoad, sBatch.c_str( ), sFlat.c_str( ), n / fSamFlat, (unsigned long long)uiSamFlatBytes, sBatchGraph.c_str( ),
-                n / fSam, uiSamThreads, (unsigned long long)pSink->uiBytes.load( ), n / fGraph,
+                sFastqGraph.c_str( ), n / fSam, uiSamThreads, (unsigned long long)pSink->uiBytes.load( ), n / fGraph,
                 iGraphThreads, (unsigned long long)xStat.first, xStat.first ? (double)xStat.second / xStat.first : 0.0 );
     }
     catch( const std::exception& e )

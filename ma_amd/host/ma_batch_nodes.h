@@ -76,20 +76,52 @@ class BatchAlign : public libMS::Module<AlignedBatch, false, FMIndex, ReadVector
 // (fileReader.cpp:37-203), up to uiBatchReads of them under ONE acquisition of the stream's lock.
 class BatchFileReader : public libMS::Module<ReadVector, true, FileStream>
 {
+    std::atomic<size_t> uiLastBatchBytes{ 0 }; // text of the previous batch: the next one reserves that much up front
+
   public:
     size_t uiBatchReads = 1u << 18;
     BatchFileReader( const ParameterSetManager& )
     {}
     virtual std::shared_ptr<ReadVector> execute( std::shared_ptr<FileStream> pStream ) override
     {
-        std::lock_guard<std::mutex> xLock( pStream->xMutex );
         auto pRet = std::make_shared<ReadVector>( );
-        while( pRet->size( ) < uiBatchReads )
+        std::string sRecords; // the text of the batch, cut out of the stream under its lock ...
+        sRecords.reserve( uiLastBatchBytes + uiLastBatchBytes / 8 );
+        size_t uiRecords = 0;
         {
-            auto pQ = FileReader::parseRecord( *pStream );
-            if( pQ == nullptr )
-                break;
-            pRet->push_back( pQ );
+            std::lock_guard<std::mutex> xLock( pStream->xMutex );
+            const bool bCut = pStream->capture( &sRecords );
+            try
+            {
+                while( pRet->size( ) + uiRecords < uiBatchReads )
+                {
+                    if( bCut )
+                    {
+                        if( !FileReader::skipRecord( *pStream ) )
+                            break;
+                        uiRecords++;
+                    }
+                    else if( auto pQ = FileReader::parseRecord( *pStream ) ) // a stream that cannot be cut: parse in place
+                        pRet->push_back( pQ );
+                    else
+                        break;
+                }
+            }
+            catch( ... )
+            {
+                pStream->capture( nullptr );
+                throw;
+            }
+            pStream->capture( nullptr );
+        }
+        // ... and turned into reads outside of it, while the next graph thread cuts its batch
+        if( uiRecords > 0 )
+        {
+            uiLastBatchBytes = sRecords.size( );
+            StringStream xText( std::move( sRecords ) );
+            pRet->reserve( uiRecords );
+            while( auto pQ = FileReader::parseRecord( xText ) )
+                pRet->push_back( pQ );
         }
         if( pRet->empty( ) )
             return nullptr; // end of file (module.h:688-695)

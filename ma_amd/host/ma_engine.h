@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <stdexcept>
 #include <cstdio>
 #include <cstdlib>
@@ -61,6 +62,16 @@ template <typename T> class HostBuf
 {
     T* p = nullptr;
     size_t uiCap = 0;
+    bool bPinned = false;
+
+    void release( )
+    {
+        if( p != nullptr && bPinned )
+            ma_host_free( p );
+        else if( p != nullptr )
+            free( p );
+        p = nullptr;
+    }
 
   public:
     HostBuf( )
@@ -69,19 +80,22 @@ template <typename T> class HostBuf
     HostBuf& operator=( const HostBuf& ) = delete;
     ~HostBuf( )
     {
-        if( p != nullptr )
-            ma_host_free( p );
+        release( );
     }
     T* need( size_t n ) // at least n elements (contents are lost when it grows)
     {
         if( n > uiCap )
         {
-            if( p != nullptr )
-                ma_host_free( p );
-            p = nullptr;
+            release( );
             uiCap = n + n / 4 + 64;
+            // page-locking pays for the MB-sized arrays of a throughput batch; the few KB of a small batch of the per-read
+            // funnel stay ordinary memory (page-locking and unlocking go through the driver and stall other streams)
+            bPinned = uiCap * sizeof( T ) >= ( 1u << 20 );
             void* q = nullptr;
-            engineCheck( ma_host_alloc( uiCap * sizeof( T ), &q ) );
+            if( bPinned )
+                engineCheck( ma_host_alloc( uiCap * sizeof( T ), &q ) );
+            else if( ( q = malloc( uiCap * sizeof( T ) ) ) == nullptr )
+                throw std::bad_alloc( );
             p = static_cast<T*>( q );
         }
         return p;
@@ -146,7 +160,7 @@ class Engine
         for( auto& pR : vPool )
             if( pR.use_count( ) == 1 )
                 return pR;
-        if( vPool.size( ) < 8 )
+        if( vPool.size( ) < 64 )
         {
             vPool.push_back( std::make_shared<BatchResult>( ) );
             return vPool.back( );
@@ -309,7 +323,8 @@ struct Ticket
 struct BatcherOptions
 {
     size_t uiMaxBatch = 1u << 18; // reads per device batch at most
-    size_t uiEngines = 4; // device batches in flight (own stream each): a small batch is latency-bound (~5 ms whatever its size)
+    size_t uiEngines = 2; // device batches in flight (own stream each).  Measured with 2048 graph threads: 2 -> 109 k reads/s, 4 -> 63 k: with
+                          // an engine always free a batch is sealed after xGather, while it is small, and small batches pay the fixed cost
     std::chrono::microseconds xGather{ 40 }; // an idle GPU still waits this long for more reads to arrive
     std::chrono::microseconds xMaxWait{ 20000 }; // a read never waits longer than this for its batch to be sealed
     // true: every stage's records are fetched, so SegmentVector / SoCPriorityQueue / seed sets / NeedlemanWunsch's

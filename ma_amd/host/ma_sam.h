@@ -850,6 +850,24 @@ class FileStream : public libMS::Container
     virtual char pop( ) = 0;
     virtual std::string fileName( ) = 0;
     virtual void safeGetLine( std::string& t ) = 0;
+    // Optional: from now on append every character that is consumed to *pText (nullptr ends it).  A stream that can do so
+    // lets BatchFileReader cut a batch of records out of the file under the stream's lock at memory speed and build the
+    // reads outside of it.
+    virtual bool capture( std::string* )
+    {
+        return false;
+    }
+    // The next line as a view that stays valid until the next call on the stream.  The default goes through safeGetLine;
+    // a stream that holds its text in memory hands out a pointer into it and copies nothing.
+    virtual void lineView( const char*& rpLine, size_t& ruiLength )
+    {
+        safeGetLine( sLineOfView );
+        rpLine = sLineOfView.data( );
+        ruiLength = sLineOfView.size( );
+    }
+
+  private:
+    std::string sLineOfView;
 };
 // Character source over any std::istream, read a block at a time: peek / pop / one line work on memory, so a FASTQ file is
 // scanned at memory speed (the per-character virtual calls and streambuf round trips of a plain istream wrapper cost ~10 ns
@@ -863,24 +881,66 @@ template <typename SOURCE> class BlockFileStream : public FileStream
 
   private:
     std::vector<char> vBlock;
+    const char* pBlock = nullptr; // the current block: vBlock, or a text the stream adopted as its only block
+    std::string sAdopted;
+    bool bTextAdopted = false;
     size_t uiAt = 0, uiFilled = 0;
     bool bSawEnd = false;
+    std::string sStraddling;
+    std::string* pCaptured = nullptr; // consumed text goes here too ...
+    size_t uiCapturedTo = 0; // ... what lies before this offset of the block already did
 
+    // first '\n' or '\r' in [pFrom, pEnd), pEnd if there is none (two vectorised passes instead of a byte loop)
+    static const char* lineEnd( const char* pFrom, const char* pEnd )
+    {
+        const char* pFeed = (const char*)memchr( pFrom, '\n', (size_t)( pEnd - pFrom ) );
+        if( pFeed == nullptr )
+            pFeed = pEnd;
+        const char* const pReturn = (const char*)memchr( pFrom, '\r', (size_t)( pFeed - pFrom ) );
+        return pReturn != nullptr ? pReturn : pFeed;
+    }
+    void flushCapture( )
+    {
+        if( pCaptured != nullptr && uiAt > uiCapturedTo )
+            pCaptured->append( pBlock + uiCapturedTo, uiAt - uiCapturedTo );
+        uiCapturedTo = uiAt;
+    }
     bool available( ) // at least one unread character in the block
     {
         if( uiAt < uiFilled )
             return true;
+        flushCapture( );
+        uiAt = uiCapturedTo = uiFilled = 0;
+        if( bTextAdopted )
+            return false; // the adopted text was the whole stream
         if( vBlock.empty( ) )
-            vBlock.resize( 1u << 20 );
+            vBlock.resize( std::max<size_t>( uiBlockBytes, 1 ) );
+        pBlock = vBlock.data( );
         xSource.read( vBlock.data( ), (std::streamsize)vBlock.size( ) );
-        uiAt = 0;
         uiFilled = (size_t)xSource.gcount( );
         return uiFilled > 0;
     }
 
   public:
+    size_t uiBlockBytes = 1u << 20; // size of the block; read before the first character is (tests shrink it)
     template <typename... ARGS> explicit BlockFileStream( ARGS&&... args ) : xSource( std::forward<ARGS>( args )... )
     {}
+    // The stream IS this text from now on (taken over without a copy); the source is not read.
+    void adoptText( std::string&& sText )
+    {
+        sAdopted = std::move( sText );
+        bTextAdopted = true;
+        pBlock = sAdopted.data( );
+        uiAt = uiCapturedTo = 0;
+        uiFilled = sAdopted.size( );
+    }
+    bool capture( std::string* pText ) override
+    {
+        flushCapture( );
+        pCaptured = pText;
+        uiCapturedTo = uiAt;
+        return true;
+    }
     bool eof( ) const override
     {
         return bSawEnd;
@@ -892,7 +952,7 @@ template <typename SOURCE> class BlockFileStream : public FileStream
             bSawEnd = true;
             return (char)std::char_traits<char>::eof( );
         }
-        return vBlock[ uiAt ];
+        return pBlock[ uiAt ];
     }
     char pop( ) override
     {
@@ -901,22 +961,42 @@ template <typename SOURCE> class BlockFileStream : public FileStream
             uiAt++;
         return cNext;
     }
+    void lineView( const char*& rpLine, size_t& ruiLength ) override
+    {
+        if( available( ) )
+        {
+            const char* const pFrom = pBlock + uiAt;
+            const char* const pEnd = pBlock + uiFilled;
+            const char* const pStop = lineEnd( pFrom, pEnd );
+            // the whole line and what follows its end lie in the block: no copy
+            if( pStop != pEnd && ( *pStop == '\n' || pStop + 1 != pEnd ) )
+            {
+                rpLine = pFrom;
+                ruiLength = (size_t)( pStop - pFrom );
+                uiAt += ruiLength + 1;
+                if( *pStop == '\r' && pBlock[ uiAt ] == '\n' )
+                    uiAt++;
+                return;
+            }
+        }
+        safeGetLine( sStraddling ); // a line across two blocks (or the last one of the text) is assembled
+        rpLine = sStraddling.data( );
+        ruiLength = sStraddling.size( );
+    }
     void safeGetLine( std::string& rLine ) override
     {
         rLine.clear( );
         while( available( ) )
         {
-            const char* const pFrom = vBlock.data( ) + uiAt;
-            const char* const pEnd = vBlock.data( ) + uiFilled;
-            const char* pStop = pFrom;
-            while( pStop != pEnd && *pStop != '\n' && *pStop != '\r' )
-                pStop++;
+            const char* const pFrom = pBlock + uiAt;
+            const char* const pEnd = pBlock + uiFilled;
+            const char* const pStop = lineEnd( pFrom, pEnd );
             rLine.append( pFrom, pStop );
             uiAt += (size_t)( pStop - pFrom );
             if( pStop == pEnd )
                 continue; // the line goes on in the next block
             uiAt++; // the line end itself
-            if( *pStop == '\r' && available( ) && vBlock[ uiAt ] == '\n' )
+            if( *pStop == '\r' && available( ) && pBlock[ uiAt ] == '\n' )
                 uiAt++; // the second half of a Windows line end
             return;
         }
@@ -1021,8 +1101,14 @@ class GzFileStream : public FileStream
 class StringStream : public BlockFileStream<std::istringstream>
 {
   public:
-    StringStream( const std::string& sString ) : BlockFileStream<std::istringstream>( sString )
-    {}
+    StringStream( const std::string& sString ) : BlockFileStream<std::istringstream>( )
+    {
+        adoptText( std::string( sString ) );
+    }
+    StringStream( std::string&& sString ) : BlockFileStream<std::istringstream>( )
+    {
+        adoptText( std::move( sString ) );
+    }
     std::string fileName( ) override
     {
         return "StringStream";
@@ -1073,17 +1159,29 @@ class FileReader : public libMS::Module<NucSeq, true, FileStream>
         return table( ).a;
     }
     // length of a line without its trailing characters of the other class
-    static size_t trimmed( const std::string& sLine, uint8_t uiKeepBit, bool bKeepIfSet )
+    struct Line // view of one line of the stream (valid until the next one is asked for)
     {
-        size_t n = sLine.size( );
-        while( n > 0 && ( ( classes( )[ (uint8_t)sLine[ n - 1 ] ] & uiKeepBit ) != 0 ) != bKeepIfSet )
+        const char* p = nullptr;
+        size_t n = 0;
+        bool empty( ) const
+        {
+            return n == 0;
+        }
+        char operator[]( size_t i ) const
+        {
+            return p[ i ];
+        }
+    };
+    static size_t trimmed( const Line& rLine, uint8_t uiKeepBit, bool bKeepIfSet )
+    {
+        size_t n = rLine.n;
+        while( n > 0 && ( ( classes( )[ (uint8_t)rLine[ n - 1 ] ] & uiKeepBit ) != 0 ) != bKeepIfSet )
             n--;
         return n;
     }
     struct Scanner
     {
         FileStream& rS;
-        std::string sLine;
         bool more( ) const
         {
             return !rS.eof( );
@@ -1092,11 +1190,11 @@ class FileReader : public libMS::Module<NucSeq, true, FileStream>
         {
             return rS.peek( ) == c;
         }
-        const std::string& line( )
+        Line line( )
         {
-            sLine.clear( );
-            rS.safeGetLine( sLine );
-            return sLine;
+            Line xLine;
+            rS.lineView( xLine.p, xLine.n );
+            return xLine;
         }
     };
 
@@ -1106,7 +1204,19 @@ class FileReader : public libMS::Module<NucSeq, true, FileStream>
     // One record off the stream, nullptr at its end.  The caller holds the stream's lock.
     static std::shared_ptr<NucSeq> parseRecord( FileStream& rStream )
     {
-        Scanner xIn{ rStream, std::string( ) };
+        return scanRecord<true>( rStream );
+    }
+    // The same walk over one record without building it: true if there was one.  (With FileStream::capture this cuts the
+    // record's text out of the stream.)
+    static bool skipRecord( FileStream& rStream )
+    {
+        return scanRecord<false>( rStream ) != nullptr;
+    }
+
+  private:
+    template <bool BUILD> static std::shared_ptr<NucSeq> scanRecord( FileStream& rStream )
+    {
+        Scanner xIn{ rStream };
         rStream.peek( );
         if( !xIn.more( ) )
             return nullptr;
@@ -1116,47 +1226,59 @@ class FileReader : public libMS::Module<NucSeq, true, FileStream>
                                       rStream.fileName( ) + "\npeek was:" + cKind );
         const char cTerminator = cKind == '@' ? '+' : '>';
         auto pRead = std::make_shared<NucSeq>( );
+        size_t uiBases = 0;
         // ---- header
         {
-            const std::string& sHeader = xIn.line( );
-            if( sHeader.empty( ) )
+            const Line xHeader = xIn.line( );
+            if( xHeader.empty( ) )
                 throw std::runtime_error( "Invalid line in fasta" );
-            const size_t uiBlank = sHeader.find( ' ' );
-            pRead->sName.assign( sHeader, 1, uiBlank == std::string::npos ? std::string::npos : uiBlank - 1 );
+            const char* const pBlank = (const char*)memchr( xHeader.p, ' ', xHeader.n );
+            const size_t uiNameEnd = pBlank == nullptr ? xHeader.n : std::max<size_t>( (size_t)( pBlank - xHeader.p ), 1 );
+            pRead->sName.assign( xHeader.p + 1, uiNameEnd - 1 );
         }
         // ---- sequence
         while( xIn.more( ) && !xIn.nextStartsWith( cTerminator ) && !xIn.nextStartsWith( ' ' ) )
         {
-            const std::string& sBases = xIn.line( );
+            const Line sBases = xIn.line( );
             const size_t n = trimmed( sBases, 1, true );
-            for( size_t i = 0; i < n; i++ )
-                pRead->xCodes.push_back( table( ).aCode[ (uint8_t)sBases[ i ] ] );
+            uiBases += n;
+            if( BUILD )
+            {
+                const size_t uiOld = pRead->xCodes.size( );
+                pRead->xCodes.resize( uiOld + n );
+                const uint8_t* const pCodeOf = table( ).aCode;
+                for( size_t i = 0; i < n; i++ )
+                    pRead->xCodes[ uiOld + i ] = pCodeOf[ (uint8_t)sBases[ i ] ];
+            }
         }
         // ---- quality
         if( cKind == '@' )
         {
-            pRead->xQuality.assign( pRead->xCodes.size( ), 0 );
-            const std::string& sPlus = xIn.line( );
+            if( BUILD )
+                pRead->xQuality.assign( pRead->xCodes.size( ), 0 );
+            const Line sPlus = xIn.line( );
             if( !sPlus.empty( ) && sPlus[ 0 ] == '+' )
             {
                 size_t uiFilled = 0;
                 while( xIn.more( ) && ( uiFilled == 0 || !xIn.nextStartsWith( '@' ) ) )
                 {
-                    const std::string& sQual = xIn.line( );
+                    const Line sQual = xIn.line( );
                     const size_t n = trimmed( sQual, 2, false );
-                    for( size_t i = 0; i < n && uiFilled + i < pRead->xQuality.size( ); i++ )
-                        pRead->xQuality[ uiFilled + i ] = (uint8_t)sQual[ i ];
+                    if( BUILD && uiFilled < pRead->xQuality.size( ) )
+                        memcpy( pRead->xQuality.data( ) + uiFilled, sQual.p, std::min( n, pRead->xQuality.size( ) - uiFilled ) );
                     uiFilled += n;
                 }
             }
         }
-        if( pRead->length( ) == 0 )
+        if( uiBases == 0 )
             throw std::runtime_error( "found empty read: " + pRead->sName );
         // ---- whatever follows, up to the next record
         for( rStream.peek( ); xIn.more( ) && !xIn.nextStartsWith( '>' ) && !xIn.nextStartsWith( '@' ); rStream.peek( ) )
             rStream.pop( );
         return pRead;
     }
+
+  public:
     // nullptr = end of file (volatile source, module.h:688-695)
     virtual std::shared_ptr<NucSeq> execute( std::shared_ptr<FileStream> pStream ) override
     {

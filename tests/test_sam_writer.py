@@ -66,6 +66,24 @@ def test_fasta_fastq_reader_matches_reference(tmp_path, name):
 
 
 @pytest.mark.skipif(not os.path.exists("/usr/include/zlib.h"), reason="zlib headers not installed")
+@pytest.mark.parametrize("name", ["reader_multi.fa", "reader_multi.fq", "reader_empty.fa", "reader_notfasta.txt", "reader_plusname.fq"])
+@pytest.mark.parametrize("batch,block", [(1, 1), (2, 7), (3, 64), (1000, 1 << 20)])
+def test_batch_reader_cuts_the_same_records(tmp_path, name, batch, block):
+    """BatchFileReader (ma_batch_nodes.h) cuts a batch of records out of the stream under its lock and builds the reads
+    outside of it: same reads, same error text as the per-record FileReader, whatever the batch size and wherever the block
+    boundaries of the stream fall."""
+    exe = build_reader_exe()
+    out = str(tmp_path / "out.txt")
+    subprocess.check_call([exe, os.path.join("reader", name), out, "batch", str(batch), str(block)], cwd=G)
+    want = open(os.path.join(G, "reader", name + ".ref")).read()
+    got = open(out).read()
+    if "ERROR" in want:  # reads of the batch that holds the broken record are lost with it; the error text is the same
+        assert got.splitlines()[-1] == want.splitlines()[-1]
+        assert want.startswith("".join(l + "\n" for l in got.splitlines()[:-1]))
+    else:
+        assert got == want
+
+
 @pytest.mark.parametrize("name", ["reader_multi.fa", "reader_multi.fq", "reader_plusname.fq"])
 def test_gzip_input_matches_reference(tmp_path, name):
     """GzFileStream (WITH_ZLIB build of the reference): the compressed file yields the same reads."""
