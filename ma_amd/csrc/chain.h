@@ -282,8 +282,22 @@ struct SeqIdCache
 };
 
 // scratch of the keyed sorts (optional): ki1 / ki2 = n (key, index) pairs each, usable while mm / after mm is filled; tmp = n seeds
+// The sweep in two halves, so that a long read's two big sorts can run between them as wave-cooperative kernels
+// (wave_sort.h, k_sort_seeds_wave): soc_windows = [sort by delta] + window sweep + make_heap + reference rectangles,
+// soc_rebuild = [sort by reference position] + the strips rebuilt over the re-sorted seeds.
+MA_HD u32 soc_windows( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm, ma_seed* tmp,
+                       bool sortedByDelta );
+MA_HD void soc_rebuild( ma_seed* s, u32 n, SoCEntry* mx, const RefMinMax* mm, u32 nmx, KeyIdx* ki2, ma_seed* tmp, bool sortedByRef );
 MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm,
                      KeyIdx* ki2 = nullptr, ma_seed* tmp = nullptr )
+{
+    const u32 nmx = soc_windows( X, P, s, n, qlen, mx, mm, tmp, false );
+    if( n != 0 )
+        soc_rebuild( s, n, mx, mm, nmx, ki2, tmp, false );
+    return nmx;
+}
+MA_HD u32 soc_windows( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm, ma_seed* tmp,
+                       bool sortedByDelta )
 {
     if( n == 0 )
         return 0;
@@ -292,7 +306,9 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
         fMinLen = 0;
     const u64 strip = P.soc_width != 0 ? (u64)P.soc_width : ( (u64)P.match * (u64)qlen - (u64)P.gap ) / (u64)P.extend;
     CH_T( c0 );
-    if( tmp && n >= 64 ) // short reads have a handful of seeds: not worth the two extra passes
+    if( sortedByDelta )
+        ;
+    else if( tmp && n >= 64 ) // short reads have a handful of seeds: not worth the two extra passes
         sort_seeds_by_key( s, n, (KeyIdx*)mm, tmp, []( const ma_seed& x ) { return (u64)x.delta; } ); // mm is free until the rectangles
     else
         ss::sort( s, (i64)n, SeedByDelta( ) );
@@ -340,7 +356,14 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
     }
     CH_T( c3 );
     CH_ADD( 2, c2, c3 );
-    if( tmp && ki2 && n >= 64 )
+    return nmx;
+}
+MA_HD void soc_rebuild( ma_seed* s, u32 n, SoCEntry* mx, const RefMinMax* mm, u32 nmx, KeyIdx* ki2, ma_seed* tmp, bool sortedByRef )
+{
+    CH_T( c3 );
+    if( sortedByRef )
+        ;
+    else if( tmp && ki2 && n >= 64 )
         sort_seeds_by_key( s, n, ki2, tmp, []( const ma_seed& x ) { return (u64)x.r_start; } );
     else
         ss::sort( s, (i64)n, SeedByRef( ) );
@@ -365,7 +388,6 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
     }
     CH_T( c5 );
     CH_ADD( 4, c4, c5 );
-    return nmx;
 }
 
 // The queue alone (SoCPriorityQueue across the boundary): sweep, then pop() until the heap is empty (soc.h:240-284).
@@ -851,12 +873,21 @@ MA_HD u64 bump_alloc( unsigned long long* ctr, u64 n )
 // Harmonization::execute (harmonization.cpp:374-555) for one read. Returns number of sets; err flags.
 // queue / nQueue: the strips were swept elsewhere (ma_batch_set_soc_heap: a SoCPriorityQueue of the reference): C.work holds
 // the seeds as rectangularSoC left them, queue[] the array vMaxima; the sweep is skipped.
+// preSwept: soc_windows already ran for this read (k_soc_windows, between the two wave-cooperative sorts): C.maxima / C.mm
+// hold its result, nPre strips; sortedByRef: C.work is already re-sorted by reference position.
 MA_HD u32 chain_read( const IndexView& X, const ChainParams& P, const ChainScratch& C, u32 nSeeds, u32 qlen,
-                      const ChainOut& O, u32& err, const ma_soc* queue = nullptr, u32 nQueue = 0 )
+                      const ChainOut& O, u32& err, const ma_soc* queue = nullptr, u32 nQueue = 0, bool preSwept = false, u32 nPre = 0,
+                      bool sortedByRef = false )
 {
     CH_T( t0 );
     u32 nmx0;
-    if( queue != nullptr )
+    if( preSwept )
+    {
+        nmx0 = nPre;
+        if( nSeeds != 0 )
+            soc_rebuild( C.work, nSeeds, C.maxima, C.mm, nmx0, (KeyIdx*)C.sh1, C.setA, sortedByRef );
+    }
+    else if( queue != nullptr )
     {
         nmx0 = nQueue < nSeeds ? nQueue : nSeeds; // a strip holds a seed at least: the scratch carved by seed count is enough
         for( u32 k = 0; k < nmx0; k++ )

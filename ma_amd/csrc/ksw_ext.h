@@ -656,10 +656,15 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     ksw_backtrack_ring<RING>( P, cig, J.flag, GLOBAL ? tlen - 1 : ez.max_t, GLOBAL ? qlen - 1 : ez.max_q, nCigar,
                               pathSteps, lds, ldsBytes, qlen, tlen );
 #if defined( MA_KSW_PROF )
-    prof[ GLOBAL ? 8 : 4 ] += tp1 - tp0; // diagonal loop
-    prof[ GLOBAL ? 9 : 5 ] += clock64( ) - tp1; // back-trace
-    prof[ GLOBAL ? 10 : 6 ] += (unsigned long long)nCells;
-    prof[ GLOBAL ? 11 : 7 ] += 1ull;
+    if( !GLOBAL )
+    {
+        prof[ 4 ] += tp1 - tp0; // diagonal loop
+        prof[ 5 ] += clock64( ) - tp1; // back-trace
+        prof[ 6 ] += (unsigned long long)nCells;
+        prof[ 7 ] += 1ull;
+    }
+    else
+        prof[ 8 ] += 1ull;
 #endif
     return true;
 }

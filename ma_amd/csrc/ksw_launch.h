@@ -253,6 +253,22 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( R 
         KSW_PROF_ADD( 1, t1, t2 );
         KSW_PROF_ADD( 2, t2, t3 );
         KSW_PROF_ADD( 3, 0ull, 1ull );
+#if defined( MA_KSW_PROF )
+        // wave time (fetch .. publish) of the jobs that would fit HALF a wavefront (two jobs per wave: qlen + 2 <= 64 cells),
+        // of those that would fit a quarter, and their numbers: the upper bound of what packing several jobs into one
+        // wavefront can save (profiles/r03_ext_pairing_bound.txt)
+        if( J.qlen + 2 <= 64 || J.tlen <= 64 )
+        {
+            prof[ 14 ] += t3 - t0;
+            prof[ 15 ] += 1;
+        }
+        if( J.qlen + 2 <= 32 || J.tlen <= 32 )
+        {
+            prof[ 10 ] += t3 - t0; // (the GLOBAL slots 10 / 11 are re-used: see tools/ksw_prof.py)
+            prof[ 11 ] += 1;
+        }
+        prof[ 9 ] += t3 - t0;
+#endif
     }
     ksw_flush( O, acc );
 #if defined( MA_KSW_PROF )

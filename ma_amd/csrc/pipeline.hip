@@ -3,6 +3,7 @@
 // libMA::setUpCompGraph (libs/ma/src/util/export.cpp:104-108) but over a whole batch of reads resident
 // in HBM.  Every stage is a HIP kernel; there is no host fallback.
 #include "chain.h"
+#include "wave_sort.h"
 #include "ksw_launch.h"
 #include "nw.h"
 #include "seeding.h"
@@ -778,6 +779,10 @@ struct ChainKernelArgs
     // optional: the SoC queues were swept elsewhere (ma_batch_set_soc_heap); carved by seed offset like the scratch
     const ma_soc* queue;
     const u32* queue_cnt;
+    // optional (long reads): the sweep ran as separate kernels around the wave-cooperative sorts (k_sort_seeds_wave,
+    // k_soc_windows): strips per read, and which of a read's two sorts the wave kernel did (bit 0 delta, bit 1 reference)
+    const u32* pre_nmx;
+    const u32* pre_sorted;
 };
 
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4, 4 ) ) ) k_chain( ChainKernelArgs A )
@@ -801,8 +806,9 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4,
     C.med = A.med + 6 * off;
     C.inl = A.inl + 3 * off;
     C.best = A.best + 3 * off;
-    for( u32 i = 0; i < n; i++ )
-        C.work[ i ] = A.seeds[ off + i ];
+    if( A.pre_nmx == nullptr )
+        for( u32 i = 0; i < n; i++ )
+            C.work[ i ] = A.seeds[ off + i ];
     ChainOut O;
     O.pool = A.hpool;
     O.pool_cap = A.hpool_cap;
@@ -813,10 +819,89 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4,
     O.local_cap = 3 * n;
     u32 err = 0;
     const u32 qlen = (u32)( A.roff[ r + 1 ] - A.roff[ r ] );
-    const u32 ns = chain_read( A.X, A.P, C, n, qlen, O, err, A.queue ? A.queue + off : nullptr, A.queue ? A.queue_cnt[ r ] : 0 );
+    const u32 ns = chain_read( A.X, A.P, C, n, qlen, O, err, A.queue ? A.queue + off : nullptr, A.queue ? A.queue_cnt[ r ] : 0,
+                               A.pre_nmx != nullptr, A.pre_nmx ? A.pre_nmx[ r ] : 0, A.pre_sorted ? ( A.pre_sorted[ r ] & 2u ) != 0 : false );
     A.nsets[ r ] = ns < A.set_cap ? ns : A.set_cap;
     if( err )
         atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
+}
+
+// ---- long reads: the two big sorts of the sweep as wave-cooperative kernels (wave_sort.h), the window sweep between them
+struct PackedKeyLess
+{
+    __device__ bool operator( )( u64 a, u64 b ) const
+    {
+        return ( a >> 20 ) < ( b >> 20 );
+    }
+};
+// reads with fewer seeds are sorted by their lane in k_soc_windows / k_chain as before: a wavefront per read pays off when the
+// sort has many large ranges to partition (10 kb reads, ~250 seeds: 28 ms of wave sorts vs 17 ms inside the lane kernels)
+#define MA_WSORT_MIN 768u
+#define MA_WSORT_SMALL 2688u // reads with up to this many seeds: 37 KB of LDS per wavefront
+#define MA_WSORT_LARGE 8192u // up to this many: 100 KB; more -> the lane-serial sort of chain.h
+// One wavefront per read.  mode 0: work = seeds sorted by delta (reads outside [nMin, nMax] of this launch are left alone,
+// reads it owns but cannot sort are copied unsorted); mode 1: work re-sorted by reference position in place (via tmp).
+__global__ void __launch_bounds__( 64 ) k_sort_seeds_wave( u32 n_reads, const u64* seed_off, const u32* seed_cnt, const ma_seed* seeds,
+                                                          ma_seed* work, ma_seed* tmp, u32* sorted, int mode, u32 nMin, u32 nMax,
+                                                          u32 nSortMin, u32 nSortMax )
+{
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[];
+    const u32 r = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    if( r >= n_reads )
+        return;
+    const u32 n = seed_cnt[ r ];
+    if( n < nMin || n > nMax )
+        return;
+    const u64 off = seed_off[ r ];
+    bool doSort = n >= nSortMin && n <= nSortMax;
+    const ma_seed* src = mode == 0 ? seeds + off : work + off;
+    ws::Scratch S = ws::carve( lds, doSort ? n : 1 );
+    if( doSort )
+    {
+        bool wide = false;
+        for( u32 i = lane; i < n; i += 64 )
+        {
+            const u64 key = mode == 0 ? (u64)src[ i ].delta : (u64)src[ i ].r_start;
+            wide = wide || ( key >> 44 ) != 0;
+            S.a[ i ] = ( key << 20 ) | (u64)i;
+        }
+        if( __ballot( wide ) != 0 )
+            doSort = false; // does not pack (never for genomes below 2^44 positions)
+        __syncthreads( );
+    }
+    if( !doSort )
+    {
+        if( mode == 0 )
+            for( u32 i = lane; i < n; i += 64 )
+                work[ off + i ] = src[ i ];
+        return;
+    }
+    ws::wave_std_sort( S, (i32)n, PackedKeyLess( ) );
+    if( mode == 0 )
+        for( u32 i = lane; i < n; i += 64 )
+            work[ off + i ] = src[ (u32)( S.a[ i ] & 0xfffffu ) ];
+    else
+    {
+        for( u32 i = lane; i < n; i += 64 )
+            tmp[ off + i ] = src[ (u32)( S.a[ i ] & 0xfffffu ) ];
+        for( u32 i = lane; i < n; i += 64 ) // every lane copies back what it wrote itself
+            work[ off + i ] = tmp[ off + i ];
+    }
+    if( lane == 0 )
+        sorted[ r ] |= 1u << mode;
+}
+// the sweep between the two sorts, one read per lane (thin waves like k_chain)
+__global__ void __launch_bounds__( 64 ) k_soc_windows( IndexView X, ChainParams P, u32 n_reads, u32 lanes, const u64* roff, const u64* seed_off,
+                                                      const u32* seed_cnt, ma_seed* work, SoCEntry* maxima, RefMinMax* mm, ma_seed* tmp,
+                                                      const u32* sorted, u32* pre_nmx )
+{
+    const u32 r = blockIdx.x * lanes + threadIdx.x;
+    if( threadIdx.x >= lanes || r >= n_reads )
+        return;
+    const u64 off = seed_off[ r ];
+    pre_nmx[ r ] = soc_windows( X, P, work + off, seed_cnt[ r ], (u32)( roff[ r + 1 ] - roff[ r ] ), maxima + off, mm + off, tmp + off,
+                                ( sorted[ r ] & 1u ) != 0 );
 }
 
 // the SoC queue of every read in pop order (ma_batch_get_socs); scratch and output carved by the read's seed offset
@@ -1375,6 +1460,7 @@ struct ma_batch
         hsetFlat, hsetRead;
     u64 hpoolCap = 0, nHsets = 0, nHseeds = 0;
     DevBuf socIn, socInCnt; // SoC queues swept elsewhere (ma_batch_set_soc_heap), carved by seed offset
+    DevBuf preNmx, preSorted; // long reads: strips per read after k_soc_windows, which sorts k_sort_seeds_wave did
     bool socGiven = false;
     // dp
     DevBuf jobs, info, ez, cigOff, cigPool, kswScratch, clsLists, opsCap, opsOff, ops, hdr, order, mqOrder, mqCnt;
@@ -2079,9 +2165,40 @@ int ma_chain_batch( ma_batch* b )
     A.ctr = b->ctr.as<unsigned long long>( );
     A.queue = b->socGiven ? b->socIn.as<ma_soc>( ) : nullptr;
     A.queue_cnt = b->socGiven ? b->socInCnt.as<u32>( ) : nullptr;
+    A.pre_nmx = nullptr;
+    A.pre_sorted = nullptr;
+    // long reads (thousands of seeds per read): the sweep's two std::sort calls run as wave-cooperative kernels on arrays in
+    // LDS, the window sweep between them and the rest of the stage stay one read per lane (MA_CHAIN_WAVE_SORT=0: all in k_chain)
+    static const bool waveSortOn = []( ) {
+        const char* e = getenv( "MA_CHAIN_WAVE_SORT" );
+        return !e || atoi( e ) != 0;
+    }( );
+    const bool waveSort = waveSortOn && !b->socGiven && b->max_qlen > 254 && b->nSeeds >= 64;
     {
         EvTimer t( b, 2 );
         A.lanes = lanes_per_wave( n );
+        if( waveSort )
+        {
+            if( b->preNmx.reserve( ( n + 1 ) * 4 ) || b->preSorted.reserve( ( n + 1 ) * 4 ) )
+                return 1;
+            MA_HIP( hipMemsetAsync( b->preSorted.p, 0, ( n + 1 ) * 4, b->stream ) );
+            const u32 ldsSmall = (u32)ws::scratch_bytes( MA_WSORT_SMALL ), ldsLarge = (u32)ws::scratch_bytes( MA_WSORT_LARGE );
+            MA_HIP( hipFuncSetAttribute( (const void*)k_sort_seeds_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLarge ) );
+            for( int mode = 0; mode < 2; mode++ )
+            {
+                // reads of up to MA_WSORT_SMALL seeds (several wavefronts per CU), then the larger ones (one per CU)
+                hipLaunchKernelGGL( k_sort_seeds_wave, dim3( (unsigned)n ), dim3( 64 ), ldsSmall, b->stream, (u32)n, A.seed_off, A.seed_cnt, A.seeds,
+                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, 0u, MA_WSORT_SMALL, MA_WSORT_MIN, MA_WSORT_SMALL );
+                hipLaunchKernelGGL( k_sort_seeds_wave, dim3( (unsigned)n ), dim3( 64 ), ldsLarge, b->stream, (u32)n, A.seed_off, A.seed_cnt, A.seeds,
+                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, MA_WSORT_SMALL + 1, 0xffffffffu, MA_WSORT_SMALL + 1, MA_WSORT_LARGE );
+                if( mode == 0 )
+                    hipLaunchKernelGGL( k_soc_windows, dim3( (unsigned)( ( n + A.lanes - 1 ) / A.lanes ) ), dim3( 64 ), 0, b->stream, A.X, A.P, (u32)n,
+                                        A.lanes, A.roff, A.seed_off, A.seed_cnt, A.work, A.maxima, A.mm, A.setA, b->preSorted.as<u32>( ),
+                                        b->preNmx.as<u32>( ) );
+            }
+            A.pre_nmx = b->preNmx.as<u32>( );
+            A.pre_sorted = b->preSorted.as<u32>( );
+        }
         hipLaunchKernelGGL( k_chain, dim3( (unsigned)( ( n + A.lanes - 1 ) / A.lanes ) ), dim3( 64 ), 0, b->stream, A );
     }
     MA_HIP( hipGetLastError( ) );

@@ -206,6 +206,39 @@ template <typename T, typename C> MA_HD_OUTLINE void sort( T* a, i64 n, C comp )
         insertion_sort( a, (i64)0, n, comp );
 }
 
+// The part of std::sort that is left of a range [first, last) once __introsort_loop has come down to it with `depth`
+// levels of its budget left -- the rest of the loop on that range, then the final insertion sort's share of it (the blocks
+// the loop leaves are sorted in place, see wave_sort.h) -- by one thread.
+template <typename T, typename C> MA_HD void finish_range( T* a, i64 first, i64 last, i64 depth, C comp )
+{
+    const i64 rangeFirst = first, rangeLast = last;
+    int stF[ 40 ], stL[ 40 ], stD[ 40 ];
+    int sp = 0;
+    while( true )
+    {
+        while( last - first > 16 )
+        {
+            if( depth == 0 || sp == 40 )
+            {
+                heap_sort_range( a, first, last, comp ); // (sp == 40 cannot happen: the budget is 2 * lg n <= 40 levels)
+                break;
+            }
+            --depth;
+            const i64 mid = first + ( last - first ) / 2;
+            move_median_to_first( a, first, first + 1, mid, last - 1, comp );
+            const i64 cut = unguarded_partition( a, first + 1, last, first, comp );
+            stF[ sp ] = (int)cut, stL[ sp ] = (int)last, stD[ sp ] = (int)depth;
+            sp++;
+            last = cut;
+        }
+        if( sp == 0 )
+            break;
+        sp--;
+        first = stF[ sp ], last = stL[ sp ], depth = stD[ sp ];
+    }
+    insertion_sort( a, rangeFirst, rangeLast, comp );
+}
+
 // std::lower_bound
 template <typename T, typename V, typename C> MA_HD i64 lower_bound( const T* a, i64 n, const V& val, C comp )
 {

@@ -30,5 +30,12 @@ finally:
         print("ext  per job: loop %.0f backtrace %.0f cells %.0f" % (v[4] / v[7], v[5] / v[7], v[6] / v[7]))
     if v[7]:
         print("ext  per job: descriptor+query %.0f target+init %.0f" % (v[12] / v[7], v[13] / v[7]))
-    if v[11]:
-        print("glob per job: loop %.0f backtrace %.0f cells %.0f" % (v[8] / v[11], v[9] / v[11], v[10] / v[11]))
+    print("global (cigar-only) jobs: %d" % v[8])
+    if v[9]:
+        print("extension kernel wave time (fetch .. publish): all jobs %d cycles; jobs that fit half a wavefront (qlen + 2 <= 64): "
+              "%d jobs = %.1f %% of the jobs, %.1f %% of the time; jobs that fit a quarter (qlen + 2 <= 32): %d jobs = %.1f %%, %.1f %% of the time" % (
+                  v[9], v[15], 100.0 * v[15] / j, 100.0 * v[14] / v[9], v[11], 100.0 * v[11] / j, 100.0 * v[10] / v[9]))
+        half_only = v[14] - v[10]
+        print("upper bound of packing: two jobs per wave for the half-size ones saves at most %.1f %% of the kernel; four per wave for "
+              "the quarter-size ones on top of that at most %.1f %% more (perfect pairing, no added per-diagonal cost)" % (
+                  50.0 * v[14] / v[9], 25.0 * v[10] / v[9]))
