@@ -568,8 +568,10 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         {
             LP[ 11 + k ] = LP[ k ]; // the huge jobs: what the small tier leaves
             LP[ 11 + k ].tier = 2;
-            if( conc )
-                LP[ 11 + k ].waves = std::min<u32>( LP[ 11 + k ].waves, KSW_SIDE_WAVES );
+            if( conc ) // their region is a fixed quarter of the budget (a region that follows the largest job of every batch
+                       // would be re-allocated -- seconds, device-wide -- whenever a later batch brings a larger one)
+                LP[ 11 + k ].waves = (u32)std::max<u64>( 1, std::min<u64>( std::min<u32>( LP[ 11 + k ].waves, KSW_SIDE_WAVES ),
+                                                                        ( B / 4 ) / std::max<u64>( LP[ 11 + k ].stride, 1 ) ) );
             const u64 cgSmall = splitP ? std::min<u64>( cg, pSmall / 16 + 3 ) : cg;
             LP[ k ] = ksw_plan_launch( pSmall, cgSmall, SZ.cls[ k ], wantOf( k ), budgetOf[ k ] );
             LP[ k ].tier = 1;
@@ -607,11 +609,12 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     // reads: once it is in the GB range take the whole budget so that later batches never re-allocate mid-step
     if( !conc && needLane[ 0 ] > ( 2ull << 30 ) )
         needLane[ 0 ] = std::max<u64>( needLane[ 0 ], B );
-    if( conc && needLane[ 0 ] + needLane[ 1 ] + needLane[ 2 ] > ( 2ull << 30 ) )
+    if( conc && needLane[ 0 ] + needLane[ 1 ] + needLane[ 2 ] + needLane[ 3 ] > ( 2ull << 30 ) )
     {
         needLane[ 0 ] = std::max<u64>( needLane[ 0 ], B / 4 );
         needLane[ 1 ] = std::max<u64>( needLane[ 1 ], 5 * B / 12 );
         needLane[ 2 ] = std::max<u64>( needLane[ 2 ], B / 3 );
+        needLane[ 3 ] = std::max<u64>( needLane[ 3 ], B / 4 );
     }
     u64 laneBase[ 4 ], total = 0;
     for( int l = 0; l < 4; l++ )

@@ -224,6 +224,7 @@ template <typename SINK> struct NwWalk
     const uint8_t* Q; // read codes
     u64 winBegin; // absolute position of window offset 0
     AlnBuilder A; // only used when SINK::STITCH
+    u64 qLenTotal = 0; // length of the read (set by run)
 
     MA_HD u32 qb( u64 i ) const
     {
@@ -233,10 +234,56 @@ template <typename SINK> struct NwWalk
     {
         return text_base( X, winBegin + i );
     }
+    // An M run of a cigar as match / missmatch entries (needlemanWunsch.cpp:573-620 appends base by base; Alignment::append
+    // merges equal neighbours, so appending a whole run of equal bases at once gives the same entries and the same score).
+    // The header and the last op live in global memory: one append per RUN instead of per base, the read through an aligned
+    // 8-byte window and the reference through the pac byte that holds four bases (50 kb reads: this loop was most of k_stitch).
     MA_HD void match_run( u64 qPos, u64 rPos, u32 amount )
     {
+        u32 curType = MT_MATCH;
+        u64 curLen = 0;
+        uintptr_t qWordAt = ~(uintptr_t)0;
+        u64 qWord = 0, pacAt = ~0ull;
+        u32 pacByte = 0;
         for( u32 k = 0; k < amount; k++ )
-            aln_append( P, A, qb( k + qPos ) == rb( k + rPos ) ? MT_MATCH : MT_MISS, 1 );
+        {
+            const uintptr_t qAddr = (uintptr_t)( Q + qPos + k );
+            if( ( qAddr & ~(uintptr_t)7 ) != qWordAt )
+            {
+                qWordAt = qAddr & ~(uintptr_t)7;
+                // the window never starts before the allocation of the reads (allocations are at least 256-byte aligned) but its
+                // end may lie behind the last base of a caller-owned array: then it is put together byte by byte
+                if( qWordAt + 8 <= (uintptr_t)( Q + qLenTotal ) )
+                    qWord = *(const u64*)qWordAt;
+                else
+                {
+                    qWord = 0;
+                    for( uintptr_t a = qAddr; a < (uintptr_t)( Q + qLenTotal ); a++ )
+                        qWord |= (u64)( *(const uint8_t*)a ) << ( 8 * ( a & 7 ) );
+                }
+            }
+            const u32 q = (u32)( qWord >> ( 8 * ( qAddr & 7 ) ) ) & 0xffu;
+            const u64 p = winBegin + rPos + k;
+            const bool comp = p >= X.F;
+            const u64 f = comp ? X.n - 1 - p : p;
+            if( ( f >> 2 ) != pacAt )
+            {
+                pacAt = f >> 2;
+                pacByte = X.pac[ pacAt ];
+            }
+            u32 r = ( pacByte >> ( ( ~(u32)f & 3 ) << 1 ) ) & 3;
+            if( comp )
+                r = 3u - r;
+            const u32 type = q == r ? MT_MATCH : MT_MISS;
+            if( type != curType && curLen != 0 )
+            {
+                aln_append( P, A, curType, curLen );
+                curLen = 0;
+            }
+            curType = type;
+            curLen++;
+        }
+        aln_append( P, A, curType, curLen );
     }
     MA_HD void app( u32 type, u64 size )
     {
@@ -512,6 +559,7 @@ template <typename SINK> struct NwWalk
     // NeedlemanWunsch::execute_one (needlemanWunsch.cpp:625-877) after the window was fixed
     MA_HD void run( const ma_seed* S, u32 n, u64 qlen, const NwWindow& W )
     {
+        qLenTotal = qlen;
         const u64 beginRef = W.begin_ref, endRef = W.end_ref;
         dyn_prg( 0, (u64)S[ 0 ].q_start, 0, (u64)S[ 0 ].r_start - beginRef, true, false );
         u64 endLastQ = (u64)S[ 0 ].q_start + (u64)S[ 0 ].len;

@@ -160,3 +160,24 @@ def test_smem_lists_of_odd_read_lengths(genome_and_index, monkeypatch, length):
     b.sync()
     _same(_all_records(b), want)
     b.close()
+
+
+def test_bench_four_ranks_long_reads_both_scaling_modes(gpu_device):
+    """the multi-rank flow of bench.py with LONG reads -- where every rank's device batch holds GBs of
+    pools and the DP stage runs its kernel classes on side streams -- as four ranks on one device (gloo; the driver's runs
+    use one GPU per rank over RCCL), in both scaling modes.  weak: every rank aligns its own reads, the job aligns four
+    times the reads of one rank; strong: ONE read set cut into four contiguous blocks gives exactly the aligned reads of
+    the single process."""
+    from test_gpu_round2 import _bench
+    common = ["--workload", "10kb", "--genome-scale", "0.02", "--steps", "2", "--warmup", "1", "--reads-per-step", "2000",
+              "--cpu-sample", "0", "--boundary-reads", "0", "--overlap", "0"]
+    one = _bench(common + ["--gpus", "1"])
+    weak = _bench(common + ["--gpus", "4"], nproc=4, env={"MA_BENCH_ONE_DEVICE": "1"})
+    strong = _bench(common + ["--gpus", "4", "--scaling", "strong"], nproc=4, env={"MA_BENCH_ONE_DEVICE": "1"})
+    w1, ww, ws = one["config"]["workloads"][0], weak["config"]["workloads"][0], strong["config"]["workloads"][0]
+    assert weak["n_gpus"] == 4 and strong["n_gpus"] == 4 and weak["scaling"] == "weak" and strong["scaling"] == "strong"
+    assert w1["aligned_reads"] > 0.95 * 4000
+    assert ws["aligned_reads"] == w1["aligned_reads"]
+    assert 3.8 * w1["aligned_reads"] < ww["aligned_reads"] < 4.2 * w1["aligned_reads"]
+    # value is the whole job's rate: reads of all ranks over the slowest rank's time
+    assert ww["value"] > 0 and ws["value"] > 0
