@@ -5,10 +5,11 @@
 #   -> gpurun_out/prof_<tag>_<workload>/{kernel_stats.csv,summary.txt,pmc_counters.csv}, entry added to profiles-style
 #      gpurun_out/prof_<tag>_pmc_traffic.json
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 WL=${2:-150bp}
 PRESET=${3:-default}
 OUT=gpurun_out/prof_${TAG}_$WL
+if [ "$PRESET" != default ]; then OUT=${OUT}_$PRESET; fi
 mkdir -p $OUT
 export TMPDIR=/tmp
 case $WL in 150bp) RL=150; RPS=1000000;; 10kb) RL=10000; RPS=200000;; 50kb) RL=50000; RPS=20000;; esac

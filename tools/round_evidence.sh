@@ -3,20 +3,26 @@
 # the Illumina-preset line, rocprofv3 kernel stats + PMC passes of the four workloads, SQ counters of the 10 kb DP stage,
 # the launch timeline of a 50 kb step.  Copy what is to be judged from gpurun_out/ into profiles/ (profiles/README.md).
 #   usage: bash tools/round_evidence.sh [tag=r02]
-TAG=${1:-r02}
+TAG=${1:-r03}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/${TAG}_gpu_tests.txt
 cat gpurun_out/${TAG}_gpu_tests.txt
+# the PMC passes first: bench.py replays their HBM bytes / VALU instructions (roofline.traffic, wave_insts_per_launch) only
+# when they were collected with the kernel sources the library is built from (kernel_source_hash)
+for wl in 150bp 10kb 50kb; do bash tools/collect_profiles.sh $TAG $wl > gpurun_out/collect_$wl.log 2>&1; done
+bash tools/collect_profiles.sh $TAG 150bp illumina > gpurun_out/collect_illumina.log 2>&1
+cp gpurun_out/prof_${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 python bench.py --workload 150bp --preset illumina --boundary-reads 0 > gpurun_out/${TAG}_bench_illumina.json 2> gpurun_out/${TAG}_bench_illumina.err
-for wl in 150bp 10kb 50kb; do bash tools/collect_profiles.sh $TAG $wl > gpurun_out/collect_$wl.log 2>&1; done
-bash tools/collect_profiles.sh ${TAG}i 150bp illumina > gpurun_out/collect_illumina.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU \
   -d gpurun_out/sq10 -o pmc --output-format csv -- python3 bench.py --workload 10kb --steps 1 --warmup 0 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/sq10.log 2>&1
 python3 tools/pmc_sq.py gpurun_out/sq10 k_ksw > gpurun_out/${TAG}_sq_counters_10kb_dp.txt; rm -rf gpurun_out/sq10
-rocprofv3 --kernel-trace -d gpurun_out/tr_50kb -o tr --output-format csv -- python3 bench.py --workload 50kb --steps 1 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/tr_50kb.log 2>&1
-python3 tools/launch_list.py gpurun_out/tr_50kb k_ksw k_chain k_stitch > gpurun_out/${TAG}_launch_timeline_50kb.txt; rm -rf gpurun_out/tr_50kb
+for wl in 50kb 10kb; do
+rocprofv3 --kernel-trace -d gpurun_out/tr_$wl -o tr --output-format csv -- python3 bench.py --workload $wl --steps 1 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/tr_$wl.log 2>&1
+python3 tools/launch_list.py gpurun_out/tr_$wl k_ksw k_job_cost k_chain k_sort_seeds k_soc_windows k_stitch > gpurun_out/${TAG}_launch_timeline_$wl.txt; rm -rf gpurun_out/tr_$wl
+done
+python3 tools/ksw_prof.py --workload 150bp --boundary-reads 0 --overlap 0 2>&1 | grep -v "^{" | grep -v amdgpu.ids > gpurun_out/${TAG}_ext_pairing_bound.txt
 python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_bench_default.json").read().strip().splitlines()[-1])
