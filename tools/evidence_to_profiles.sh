@@ -1,0 +1,13 @@
+#!/bin/bash
+# Copies what tools/round_evidence.sh left under gpurun_out/ into profiles/ (tracked).  usage: bash tools/evidence_to_profiles.sh [tag=r03]
+TAG=${1:-r03}
+cd "$(dirname "$0")/.."
+for f in bench_default.json bench_illumina.json gpu_tests.txt launch_timeline_50kb.txt launch_timeline_10kb.txt sq_counters_10kb_dp.txt ext_pairing_bound.txt; do
+  [ -s gpurun_out/${TAG}_$f ] && cp gpurun_out/${TAG}_$f profiles/${TAG}_$f
+done
+[ -s gpurun_out/prof_${TAG}_pmc_traffic.json ] && cp gpurun_out/prof_${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
+for d in 150bp 10kb 50kb 150bp_illumina; do
+  [ -s gpurun_out/prof_${TAG}_$d/kernel_stats.csv ] && cp gpurun_out/prof_${TAG}_$d/kernel_stats.csv profiles/${TAG}_kernel_stats_$d.csv
+  [ -s gpurun_out/prof_${TAG}_$d/summary.txt ] && cp gpurun_out/prof_${TAG}_$d/summary.txt profiles/${TAG}_pmc_summary_$d.txt
+done
+ls -la profiles | grep ${TAG}_
