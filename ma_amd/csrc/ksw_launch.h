@@ -453,11 +453,8 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
 // batches take the paths of the large ones -- fewer waves, classes split in two launches, the side stream)
 inline u64 ksw_scratch_budget( )
 {
-    static const u64 budget = []( ) -> u64 {
-        const char* e = getenv( "MA_KSW_SCRATCH_MB" );
-        return e && atoi( e ) > 0 ? (u64)atoi( e ) << 20 : 24ull << 30;
-    }( );
-    return budget;
+    const char* e = getenv( "MA_KSW_SCRATCH_MB" ); // (read on every call: the tests switch it inside one process)
+    return e && atoi( e ) > 0 ? (u64)atoi( e ) << 20 : 24ull << 30;
 }
 #define KSW_SCRATCH_BUDGET ksw_scratch_budget( )
 struct KswLaunchPlan
@@ -522,7 +519,7 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     const u64 resident[ KSW_N_CLASSES ] = { 256 * 24, 256 * 16, 256 * 16, 256 * 16, 0, 256 * 28, 256 * 16 };
     auto wantOf = [ & ]( int k ) { return conc ? std::min<u64>( wantWaves, resident[ k ] ) : wantWaves; };
     // budgets of the scratch regions: lane 0 / 1 / 2 (sequential launches of a lane share its region)
-    const u64 B = KSW_SCRATCH_BUDGET;
+    const u64 B = KSW_SCRATCH_BUDGET; // one reading per call
     const u64 budgetOf[ KSW_N_CLASSES ] = { conc ? B / 3 : B, conc ? B / 3 : B, conc ? B / 3 : B, conc ? 5 * B / 12 : B, B, conc ? B / 4 : B, conc ? B / 4 : B };
     auto ldsOf = []( u64 qBytes ) { return std::max<u32>( (u32)( ( ( std::min<u64>( qBytes, 150000 + 64 ) + 15 ) / 16 ) * 16 ), KSW_REG_LDS ); };
     // pass 0 launches of the register kernels: classes 0..3 (exact), 5 / 6 (extension); [7..10]: classes 0..3 of the

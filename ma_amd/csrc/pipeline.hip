@@ -1698,6 +1698,7 @@ static SeedParams seed_params( const ma_params& P )
     S.genome_size_disable = P.genome_size_disable;
     S.window_begin = S.window_end = nullptr;
     S.smem_compact = 0;
+    S.smem_merge = 0;
     return S;
 }
 // reads that stay in HBM are read through a 16-byte register window (seed_qbyte): the bounds of the reads array
@@ -1949,6 +1950,9 @@ int ma_seed_batch( ma_batch* b )
             A.P.smem_compact = smem && b->max_qlen < 2048 && b->idx->v.n < ( 1ull << 35 ) ? 1 : 0;
             if( const char* e = getenv( "MA_SMEM_COMPACT" ) ) // tuning / test hook
                 A.P.smem_compact = A.P.smem_compact && atoi( e ) != 0 ? 1 : 0;
+            A.P.smem_merge = smem && A.P.min_amb == 0 ? 1 : 0;
+            if( const char* e = getenv( "MA_SMEM_MERGE" ) ) // test hook: 0 = keep every entry like the reference's lists
+                A.P.smem_merge = A.P.smem_merge && atoi( e ) != 0 ? 1 : 0;
             // measured per 1 M x 150 bp reads: maxSpan 8.98 ms (1) / 8.56 (4) / 8.87 (8); SMEMs 114 ms (4) / 96 (8) / 96 (16) / 101 (32)
             A.slow_batch = A.P.technique == 0 ? 4 : 8;
             if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook
@@ -2169,7 +2173,7 @@ int ma_chain_batch( ma_batch* b )
     A.pre_sorted = nullptr;
     // long reads (thousands of seeds per read): the sweep's two std::sort calls run as wave-cooperative kernels on arrays in
     // LDS, the window sweep between them and the rest of the stage stay one read per lane (MA_CHAIN_WAVE_SORT=0: all in k_chain)
-    static const bool waveSortOn = []( ) {
+    const bool waveSortOn = []( ) { // (read on every call: the tests switch it inside one process)
         const char* e = getenv( "MA_CHAIN_WAVE_SORT" );
         return !e || atoi( e ) != 0;
     }( );
@@ -2182,15 +2186,18 @@ int ma_chain_batch( ma_batch* b )
             if( b->preNmx.reserve( ( n + 1 ) * 4 ) || b->preSorted.reserve( ( n + 1 ) * 4 ) )
                 return 1;
             MA_HIP( hipMemsetAsync( b->preSorted.p, 0, ( n + 1 ) * 4, b->stream ) );
-            const u32 ldsSmall = (u32)ws::scratch_bytes( MA_WSORT_SMALL ), ldsLarge = (u32)ws::scratch_bytes( MA_WSORT_LARGE );
+            // test hooks: MA_WSORT_MIN / MA_WSORT_SMALL move the thresholds so that small test reads take both launches
+            const u32 wsMin = []( ) { const char* e = getenv( "MA_WSORT_MIN" ); return e ? (u32)std::max( 17, atoi( e ) ) : MA_WSORT_MIN; }( );
+            const u32 wsSmall = []( ) { const char* e = getenv( "MA_WSORT_SMALL" ); return e ? (u32)std::min<int>( std::max( 17, atoi( e ) ), MA_WSORT_SMALL ) : MA_WSORT_SMALL; }( );
+            const u32 ldsSmall = (u32)ws::scratch_bytes( wsSmall ), ldsLarge = (u32)ws::scratch_bytes( MA_WSORT_LARGE );
             MA_HIP( hipFuncSetAttribute( (const void*)k_sort_seeds_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLarge ) );
             for( int mode = 0; mode < 2; mode++ )
             {
                 // reads of up to MA_WSORT_SMALL seeds (several wavefronts per CU), then the larger ones (one per CU)
                 hipLaunchKernelGGL( k_sort_seeds_wave, dim3( (unsigned)n ), dim3( 64 ), ldsSmall, b->stream, (u32)n, A.seed_off, A.seed_cnt, A.seeds,
-                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, 0u, MA_WSORT_SMALL, MA_WSORT_MIN, MA_WSORT_SMALL );
+                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, 0u, wsSmall, wsMin, wsSmall );
                 hipLaunchKernelGGL( k_sort_seeds_wave, dim3( (unsigned)n ), dim3( 64 ), ldsLarge, b->stream, (u32)n, A.seed_off, A.seed_cnt, A.seeds,
-                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, MA_WSORT_SMALL + 1, 0xffffffffu, MA_WSORT_SMALL + 1, MA_WSORT_LARGE );
+                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, wsSmall + 1, 0xffffffffu, std::max( wsSmall + 1, wsMin ), MA_WSORT_LARGE );
                 if( mode == 0 )
                     hipLaunchKernelGGL( k_soc_windows, dim3( (unsigned)( ( n + A.lanes - 1 ) / A.lanes ) ), dim3( 64 ), 0, b->stream, A.X, A.P, (u32)n,
                                         A.lanes, A.roff, A.seed_off, A.seed_cnt, A.work, A.maxima, A.mm, A.setA, b->preSorted.as<u32>( ),
@@ -2282,11 +2289,8 @@ static bool dp_exclusive( )
 // MA_DP_ONE_STREAM=1: all kernel classes of a DP stage back to back on the batch's stream, as before round 3 (A/B hook)
 static bool dp_one_stream( )
 {
-    static const bool on = []( ) {
-        const char* e = getenv( "MA_DP_ONE_STREAM" );
-        return e && atoi( e ) != 0;
-    }( );
-    return on;
+    const char* e = getenv( "MA_DP_ONE_STREAM" ); // (read on every call: the tests switch it inside one process)
+    return e && atoi( e ) != 0;
 }
 
 int ma_dp_batch( ma_batch* b )

@@ -19,6 +19,7 @@ struct SeedParams
     const uint8_t* window_begin = nullptr; // device kernels whose reads stay in HBM: the reads array, for seed_qbyte's 16-byte window
     const uint8_t* window_end = nullptr; // (null: off)
     u32 smem_compact = 0; // SMEM pending lists hold 16-byte entries (smem_put / smem_get): reads < 2048 bases, text < 2^35
+    u32 smem_merge = 0; // SMEM backward phase: an entry whose interval equals that of the entry pushed before it is not kept (seed_apply)
 };
 
 // Scratch a read needs while it is being seeded (lives in HBM, one slot per resident lane).
@@ -67,6 +68,8 @@ struct SeedLane
     u32 curQStart, curQSize; // prev[jPrev] of the extension in flight (its interval is in ik): read once, in seed_prepare
     u32 bHaveOne, retS, retE;
     u32 flip; // which of smem_a/smem_b is "prev"
+    i64 lastK, lastRc, lastS; // the entry pushed last onto curr (its q_start is the position i it was pushed at):
+    u32 lastQSize; //           twin test of smem_merge, and the register copy seed_try continues with
     // output
     u32 nseg;
     u32 err;
@@ -309,6 +312,29 @@ MA_HD bool seed_stop( const SeedParams& P, const i64 ok[ 3 ], const i64 ik[ 3 ] 
 // bookkeeping of seed_prepare is executed once for many lanes instead of on every step for one or two.)
 template <bool WIN = false> MA_HD bool seed_try( SeedLane& L, const SeedParams& P, u32& c )
 {
+    if( L.phase == PH_SMEM_BWD )
+    {
+        // SMEM backward phase with ONE entry left on the list that was just written (after the twins are gone: nearly
+        // every position of a read): the end-of-position bookkeeping of seed_prepare, with the entry taken from the
+        // registers it was pushed from instead of from the list in HBM -- no batching with other lanes' transitions, no
+        // memory round trip before the extension can start
+        if( L.jPrev == L.nPrev && L.nCurr == 1 && L.i != 0 )
+        {
+            L.flip ^= 1;
+            L.nPrev = 1;
+            L.nCurr = 0;
+            L.jPrev = 0;
+            L.bHaveOne = 0;
+            L.retS = L.i;
+            L.curQStart = L.i;
+            L.curQSize = L.lastQSize;
+            L.ik[ 0 ] = L.lastK, L.ik[ 1 ] = L.lastRc, L.ik[ 2 ] = L.lastS;
+            L.i--;
+            c = seed_qbyte<WIN>( L, P, L.i );
+            return true;
+        }
+        return false;
+    }
     const bool right = L.phase == PH_P1_RIGHT || L.phase == PH_P2_RIGHT || L.phase == PH_SMEM_FWD;
     const bool left = L.phase == PH_P1_LEFT || L.phase == PH_P2_LEFT;
     const bool ok = right ? L.i < L.qlen : ( left && L.i != 0xffffffffu );
@@ -584,11 +610,25 @@ MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, c
             }
             else if( ok[ 2 ] > (i64)P.min_amb || ( ok[ 2 ] > 0 && (u64)s.q_size >= (u64)P.max_amb ) )
             {
-                if( L.nCurr < S.smem_cap )
-                    smem_put( P, curr, L.nCurr, L.i, (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ] );
-                else
-                    L.err |= MA_ERR_SMEM_OVERFLOW;
-                L.nCurr++;
+                // Twins.  The list is ordered by decreasing match length; after a few backward steps most of its entries
+                // have shrunk to the SAME interval (for a unique read: all ~13 of them, the one locus) and differ only in
+                // length.  extend_backward reads start and size only, so twins fail or survive together on every later
+                // position, stay neighbours, and the later one is never emitted: when they fail the earlier one has set
+                // bHaveOne (or found it set), and with uiMinAmbiguity == 0 a failed entry has size 0 and is not pushed
+                // either (binarySeeding.h:380-413); at the start of the query only the front of the list is emitted
+                // (:437-448).  Dropping the later twin here changes no emitted segment and no list's emptiness -- and
+                // takes the backward phase of a 150 bp read from ~13 extensions per position to ~1 (a run-time switch:
+                // with uiMinAmbiguity > 0 a failed twin of sufficient length IS pushed, so the lists stay as they are).
+                const bool twin = P.smem_merge && L.nCurr > 0 && L.lastK == ok[ 0 ] && L.lastS == ok[ 2 ];
+                if( !twin )
+                {
+                    if( L.nCurr < S.smem_cap )
+                        smem_put( P, curr, L.nCurr, L.i, (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ] );
+                    else
+                        L.err |= MA_ERR_SMEM_OVERFLOW;
+                    L.nCurr++;
+                    L.lastK = ok[ 0 ], L.lastRc = ok[ 1 ], L.lastS = ok[ 2 ], L.lastQSize = (u32)s.q_size + 1;
+                }
             }
             L.jPrev++;
             break;

@@ -181,3 +181,73 @@ def test_bench_four_ranks_long_reads_both_scaling_modes(gpu_device):
     assert 3.8 * w1["aligned_reads"] < ww["aligned_reads"] < 4.2 * w1["aligned_reads"]
     # value is the whole job's rate: reads of all ranks over the slowest rank's time
     assert ww["value"] > 0 and ws["value"] > 0
+
+
+@pytest.mark.parametrize("env", [{"MA_CHAIN_WAVE_SORT": "0"}, {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "60"}, {"MA_WSORT_MIN": "100"},
+                                 {"MA_DP_ONE_STREAM": "1"}, {"MA_KSW_SCRATCH_MB": "64"}])
+def test_long_read_stage_variants_give_identical_results(gpu_device, monkeypatch, env):
+    """Round-3 variants of the long-read stages forced through their hooks on one read set with repeats (many equal deltas
+    and reference positions = ties in the sweep's sorts): the sweep's sorts inside the lane kernels / as wave-cooperative
+    kernels with both launch sizes exercised (thresholds moved down to test-sized reads), the DP classes on one stream / on
+    their own streams, a tiny DP scratch budget (every class split into tiers).  Every stage record equals the default's."""
+    import ma_amd
+    g = rand_genome(53, [900000, 400000], repeat_unit=250, repeat_copies=120, repeat_div=0.04)
+    reads = (sample_reads(g, 40, 6000, 91, sub=0.01, ins=0.005, dele=0.005) + sample_reads(g, 6, 20000, 92, sub=0.03, ins=0.03, dele=0.04)
+             + sample_reads(g, 200, 150, 93, sub=0.01) + sample_reads(g, 10, 2500, 94, sub=0.05, ins=0.02, dele=0.02))
+    idx = ma_amd.Index.build(g)
+
+    def run():
+        b = _batch(idx, reads)
+        b.align()
+        b.sync()
+        out = _all_records(b)
+        n_seeds = np.diff(b.seeds()[0].astype(np.int64))
+        b.close()
+        return out, n_seeds
+
+    want, n_seeds = run()
+    assert (n_seeds > 100).sum() >= 3 and (n_seeds > 60).sum() >= 10 and ((n_seeds > 20) & (n_seeds <= 60)).sum() >= 3, \
+        "the read set must reach the sort thresholds of the variants"
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got, _ = run()
+    _same(got, want)
+    idx.close()
+
+
+@pytest.mark.parametrize("min_amb", [0, 2])
+def test_smem_twin_entries_are_dropped_without_changing_the_segments(gpu_device, monkeypatch, min_amb):
+    """The SMEM backward phase drops list entries whose interval equals that of the entry before them (seeding.h,
+    seed_apply); every stage record equals that of the lists kept entry by entry (MA_SMEM_MERGE=0) -- on unique reads,
+    reads out of repeats (many distinct intervals survive for long), reads with Ns and random reads -- and the extension
+    counter shows the saving.  uiMinAmbiguity > 0 keeps the full lists (a failed twin may be pushed there)."""
+    import ma_amd
+    g = rand_genome(67, [600000, 300000], repeat_unit=180, repeat_copies=150, repeat_div=0.03)
+    reads = (sample_reads(g, 1500, 150, 21, sub=0.02) + sample_reads(g, 300, 151, 22, sub=0.05, n_rate=0.02)
+             + sample_reads(g, 200, 100, 23, random_frac=1.0) + sample_reads(g, 40, 1200, 24, sub=0.01, ins=0.005, dele=0.005))
+    idx = ma_amd.Index.build(g)
+
+    def run():
+        P = ma_amd.Params.preset("illumina")
+        P.seeding_technique = 1
+        P.min_ambiguity = min_amb
+        b = ma_amd.Batch(idx, P, len(reads), sum(len(r) for r in reads) + 64)
+        b.set_reads(reads)
+        b.align()
+        b.sync()
+        out = _all_records(b)
+        steps = int(b.counters()[0])  # extend_backward steps
+        b.close()
+        return out, steps
+
+    monkeypatch.setenv("MA_SMEM_MERGE", "0")
+    want, steps_full = run()
+    monkeypatch.delenv("MA_SMEM_MERGE")
+    got, steps = run()
+    _same(got, want)
+    assert len(want[0][1]) > 2000
+    if min_amb == 0:
+        assert steps < 0.6 * steps_full
+    else:
+        assert steps == steps_full
+    idx.close()
