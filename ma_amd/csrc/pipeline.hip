@@ -211,7 +211,7 @@ template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const See
             const unsigned long long sm = __ballot( act && !ext );
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare<LONG, !LONG>( L, A.P, S, A.X, c ); // the K-mer table pays for reads in LDS (150 bp: 8.1 -> 7.5 ms), not here for reads in HBM (10 kb: 145 -> 188 ms)
+                    ext = seed_prepare<LONG, true>( L, A.P, S, A.X, c ); // K-mer table: 150 bp 8.1 -> 7.5 ms; reads in HBM with K byte loads per key 145 -> 188 ms (10 kb), hence seed_jump's block loads
         }
 #if defined( MA_KSW_PROF )
         const unsigned long long tC = clock64( );
@@ -221,6 +221,8 @@ template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const See
         {
             i64 ok[ 3 ];
             u32 nb;
+            if( LONG )
+                seed_prefetch<LONG>( L, A.P );
             extend_backward( A.X, L.ik, c, ok, nb );
             L.steps++;
             L.blocks += nb;
@@ -394,6 +396,7 @@ struct TaskKernelArgs
     u64* pool_key; // read << MA_TASK_KEY_BITS | path
     u64 pool_cap;
     unsigned long long* ctr;
+    u32 slow_batch;
 };
 __global__ void k_task_roots( const u64* roff, u32 n_reads, SeedTask* out, unsigned long long* nOut )
 {
@@ -522,7 +525,7 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
         bool ext = act && seed_try( L, A.P, c );
         {
             const unsigned long long sm = __ballot( act && !ext );
-            if( sm && ( (u32)__popcll( sm ) >= 4 || __ballot( ext ) == 0 ) )
+            if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
                     ext = seed_prepare<false, true>( L, A.P, S, A.X, c );
         }
@@ -1796,6 +1799,9 @@ static int seed_tasks( ma_batch* b )
     TaskKernelArgs A;
     A.X = b->idx->v;
     A.P = seed_params( b->P );
+    A.slow_batch = 4;
+    if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook
+        A.slow_batch = (u32)std::max( 1, atoi( e ) );
     A.reads = b->d_reads;
     A.roff = b->d_roff;
     A.task_cap = taskCap;
@@ -1954,13 +1960,19 @@ int ma_seed_batch( ma_batch* b )
             if( const char* e = getenv( "MA_SMEM_MERGE" ) ) // test hook: 0 = keep every entry like the reference's lists
                 A.P.smem_merge = A.P.smem_merge && atoi( e ) != 0 ? 1 : 0;
             // measured per 1 M x 150 bp reads: maxSpan 8.98 ms (1) / 8.56 (4) / 8.87 (8); SMEMs 114 ms (4) / 96 (8) / 96 (16) / 101 (32)
-            A.slow_batch = A.P.technique == 0 ? 4 : 8;
+            // 200 k x 10 kb reads (k_seed_long: a transition costs several memory round trips in a row): 4: 149 ms, 8: 140, 16: 130, 24: 134, 32: 144
+            A.slow_batch = A.P.technique == 0 ? ( A.q_lds ? 4 : 16 ) : 8;
             if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook
                 A.slow_batch = (u32)std::max( 1, atoi( e ) );
             if( A.q_lds )
                 hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
             else
+            {
+                if( const char* e = getenv( "MA_SEED_LONG_JUMP" ) ) // A/B + test hook: 0 = walk every run step by step
+                    if( atoi( e ) == 0 )
+                        A.X.kmer_k = 0;
                 hipLaunchKernelGGL( k_seed_long, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), 0, b->stream, A );
+            }
         }
         MA_HIP( hipGetLastError( ) );
         // did every read fit its staging area, and all segments the pool?

@@ -90,32 +90,35 @@ struct SeedLane
 // base i of the lane's read.  P.window_begin / window_end (wave-uniform; null = off: the read is in LDS, or host code)
 // delimit the reads array: the 16 bytes are taken aligned, or flush with an end of the array where an aligned block
 // would leave it.
+MA_HD void seed_qwin_load( SeedLane& L, const SeedParams& P, u32 i )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    const uintptr_t a = (uintptr_t)( L.q + i );
+    uintptr_t base = a & ~(uintptr_t)15;
+    uint4 v;
+    if( base + 16 > (uintptr_t)P.window_end || base < (uintptr_t)P.window_begin )
+    {
+        // first / last bytes of the reads array: flush with its end, byte loads
+        if( base + 16 > (uintptr_t)P.window_end )
+            base = (uintptr_t)P.window_end - 16;
+        if( base < (uintptr_t)P.window_begin )
+            base = (uintptr_t)P.window_begin;
+        __builtin_memcpy( &v, (const void*)base, 16 );
+    }
+    else
+        v = *(const uint4*)base; // one global_load_dwordx4
+    L.qw[ 0 ] = v.x, L.qw[ 1 ] = v.y, L.qw[ 2 ] = v.z, L.qw[ 3 ] = v.w;
+    L.qwinLo = i - (u32)( a - base );
+#endif
+}
 template <bool WIN> MA_HD u32 seed_qbyte( SeedLane& L, const SeedParams& P, u32 i )
 {
 #if defined( __HIP_DEVICE_COMPILE__ )
     if( WIN && P.window_end )
     {
-        u32 d = i - L.qwinLo;
-        if( d >= 16u )
-        {
-            const uintptr_t a = (uintptr_t)( L.q + i );
-            uintptr_t base = a & ~(uintptr_t)15;
-            uint4 v;
-            if( base + 16 > (uintptr_t)P.window_end || base < (uintptr_t)P.window_begin )
-            {
-                // first / last bytes of the reads array: flush with its end, byte loads
-                if( base + 16 > (uintptr_t)P.window_end )
-                    base = (uintptr_t)P.window_end - 16;
-                if( base < (uintptr_t)P.window_begin )
-                    base = (uintptr_t)P.window_begin;
-                __builtin_memcpy( &v, (const void*)base, 16 );
-            }
-            else
-                v = *(const uint4*)base; // one global_load_dwordx4
-            L.qw[ 0 ] = v.x, L.qw[ 1 ] = v.y, L.qw[ 2 ] = v.z, L.qw[ 3 ] = v.w;
-            d = (u32)( a - base );
-            L.qwinLo = i - d;
-        }
+        if( i - L.qwinLo >= 16u )
+            seed_qwin_load( L, P, i );
+        const u32 d = i - L.qwinLo;
         const u32 lo = d & 8u ? L.qw[ 2 ] : L.qw[ 0 ], hi = d & 8u ? L.qw[ 3 ] : L.qw[ 1 ]; // selects, not a register index
         return ( ( d & 4u ? hi : lo ) >> ( 8u * ( d & 3u ) ) ) & 0xffu;
     }
@@ -272,19 +275,58 @@ MA_HD void seed_after_center( SeedLane& L, const SeedScratch& S, u32 cS, u32 cN 
 // .. (PH_P2_LEFT).  Valid when the interval after those steps is still larger than min_amb: interval sizes only shrink
 // along a run, so none of the skipped steps would have met the stop rule (binarySeeding.h:109-112).  Returns false (and
 // leaves the lane untouched) when the run has to be walked step by step.
-MA_HD bool seed_jump( SeedLane& L, const SeedParams& P, const IndexView& X, bool right )
+template <bool WIN = false> MA_HD bool seed_jump( SeedLane& L, const SeedParams& P, const IndexView& X, bool right )
 {
 #if defined( __HIP_DEVICE_COMPILE__ )
     const u32 K = X.kmer_k;
     if( K == 0 || ( right ? L.center + K > L.qlen : L.center + 1 < K ) )
         return false;
     u32 key = 0, bad = 0;
-    for( u32 j = 0; j < K; j++ )
+    if( WIN && P.window_end )
     {
-        const u32 b = L.q[ right ? L.center + j : L.center - j ]; // plain loads: K bytes of one or two lines
-        bad |= b >> 2;
-        key = ( key << 2 ) | ( ( right ? 3u - b : b ) & 3u );
+        // reads in HBM: the K <= 14 bases [lo, lo + K) out of two 16-byte blocks (aligned, or flush with an end of the
+        // reads array like seed_qbyte's window) instead of K byte loads, the 2-bit key by bit gathering
+        const uintptr_t a = (uintptr_t)( L.q + ( right ? L.center : L.center + 1 - K ) );
+        uintptr_t base = a & ~(uintptr_t)15;
+        if( base + 32 > (uintptr_t)P.window_end )
+            base = (uintptr_t)P.window_end - 32;
+        if( base < (uintptr_t)P.window_begin )
+            return false; // an array of fewer than 32 bytes
+        u64 w[ 4 ];
+        __builtin_memcpy( w, (const void*)base, 32 ); // (the flush case is unaligned: byte-wise there, two dwordx4 otherwise)
+        const u32 d = (u32)( a - base ); // < 32 - K
+        const u32 sh = 8u * ( d & 7u );
+        const u64 w0 = d & 16u ? w[ 2 ] : w[ 0 ], w1 = d & 16u ? w[ 3 ] : w[ 1 ], w2 = d & 16u ? 0ull : w[ 2 ], w3 = d & 16u ? 0ull : w[ 3 ];
+        const u64 lo8 = d & 8u ? w1 : w0, mid8 = d & 8u ? w2 : w1, hi8 = d & 8u ? w3 : w2;
+        u64 x = sh ? ( lo8 >> sh ) | ( mid8 << ( 64u - sh ) ) : lo8; // bases 0..7 of the span
+        u64 y = sh ? ( mid8 >> sh ) | ( hi8 << ( 64u - sh ) ) : mid8; // bases 8..15
+        if( K < 8 )
+            x &= ( 1ull << ( 8u * K ) ) - 1ull;
+        y = K > 8 ? y & ( ( 1ull << ( 8u * ( K - 8u ) ) ) - 1ull ) : 0ull; // K <= 14
+        bad = ( ( x | y ) & 0xfcfcfcfcfcfcfcfcull ) != 0;
+        auto gather = []( u64 v ) -> u32 { // code of byte j -> bits 2j, 2j+1
+            v = ( v | ( v >> 6 ) ) & 0x000f000f000f000full;
+            v = ( v | ( v >> 12 ) ) & 0x000000ff000000ffull;
+            return (u32)( ( v | ( v >> 24 ) ) & 0xffffull );
+        };
+        const u32 le = gather( x ) | gather( y ) << 16; // base j of the span at bits 2j
+        if( right )
+        {
+            // first base of the span most significant, complemented
+            u32 r = __brev( le ) >> ( 32u - 2u * K );
+            r = ( ( r & 0xaaaaaaaau ) >> 1 ) | ( ( r & 0x55555555u ) << 1 );
+            key = r ^ ( ( 1u << ( 2u * K ) ) - 1u );
+        }
+        else
+            key = le; // q[center] = last base of the span most significant
     }
+    else
+        for( u32 j = 0; j < K; j++ )
+        {
+            const u32 b = L.q[ right ? L.center + j : L.center - j ]; // plain loads: K bytes of one or two lines
+            bad |= b >> 2;
+            key = ( key << 2 ) | ( ( right ? 3u - b : b ) & 3u );
+        }
     if( bad )
         return false; // an N inside the K-mer
     const ulonglong2 e = ( (const ulonglong2*)X.kmer_tab )[ key ];
@@ -346,6 +388,24 @@ template <bool WIN = false> MA_HD bool seed_try( SeedLane& L, const SeedParams& 
     return ok;
 }
 
+// The base of THIS step has been taken out of the 16-byte window (seed_try / seed_prepare returned true); when the run's next
+// base lies outside of it, the next block is requested now, ahead of this step's occ blocks: it arrives while the lane waits
+// for those anyway.  (Loaded on demand at the top of the next step, some lane of the wavefront needs a block on nearly every
+// trip, and every trip became two memory round trips in a row: 7.2 k of 13.7 k cycles per trip of the 10 kb workload.)
+template <bool WIN> MA_HD void seed_prefetch( SeedLane& L, const SeedParams& P )
+{
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( WIN && P.window_end )
+    {
+        const bool right = L.phase == PH_P1_RIGHT || L.phase == PH_P2_RIGHT || L.phase == PH_SMEM_FWD;
+        const bool left = L.phase == PH_P1_LEFT || L.phase == PH_P2_LEFT;
+        const u32 nxt = right ? L.i + 1 : L.i - 1; // L.i == 0 going left: wraps, and fails the test below
+        if( ( right || left ) && nxt < L.qlen && nxt - L.qwinLo >= 16u )
+            seed_qwin_load( L, P, nxt );
+    }
+#endif
+}
+
 // ---- transitions (no index access) ----------------------------------------------------------
 // Runs cheap bookkeeping until the lane either needs an extension (returns true and sets c) or is done.
 // JUMP: use the K-mer table of the index (only the kernel whose register budget has room for it: inlined into the
@@ -377,7 +437,7 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
                     }
                     L.end = L.center;
                     L.i = L.center + 1;
-                    if( JUMP && seed_jump( L, P, X, true ) )
+                    if( JUMP && seed_jump<WIN>( L, P, X, true ) )
                     {
                         L.end = L.center + X.kmer_k - 1;
                         L.i = L.center + X.kmer_k;
@@ -426,7 +486,7 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
                 L.start = L.center;
                 L.phase = PH_P2_LEFT;
                 L.i = L.center > 0 ? L.center - 1 : 0xffffffffu;
-                if( JUMP && seed_jump( L, P, X, false ) )
+                if( JUMP && seed_jump<WIN>( L, P, X, false ) )
                 {
                     L.start = L.center - ( X.kmer_k - 1 );
                     L.i = L.start > 0 ? L.start - 1 : 0xffffffffu;

@@ -251,3 +251,33 @@ def test_smem_twin_entries_are_dropped_without_changing_the_segments(gpu_device,
     else:
         assert steps == steps_full
     idx.close()
+
+
+def test_long_read_seeding_kmer_jump_gives_the_same_segments(gpu_device, monkeypatch):
+    """The read-per-lane kernel for reads in HBM (k_seed_long) takes the first K-1 steps of a run from the K-mer table, the
+    key assembled out of two 16-byte blocks of the reads array (seeding.h, seed_jump): same records as the walk step by
+    step -- with Ns inside K-mers, centres within K bases of the read ends, and reads at both ends of the reads array (where
+    the blocks are taken flush with the array instead of aligned)."""
+    import ma_amd
+    g = rand_genome(71, [800000, 300000], repeat_unit=200, repeat_copies=80, repeat_div=0.05)
+    reads = (sample_reads(g, 3, 40, 31, sub=0.0) + sample_reads(g, 60, 3000, 32, sub=0.01, ins=0.003, dele=0.003)
+             + sample_reads(g, 30, 700, 33, sub=0.03, n_rate=0.01) + sample_reads(g, 200, 150, 34, sub=0.02) + sample_reads(g, 3, 33, 35, sub=0.0))
+    idx = ma_amd.Index.build(g)
+    monkeypatch.setenv("MA_SEED_TASKS", "0")
+
+    def run():
+        b = _batch(idx, reads)
+        b.align()
+        b.sync()
+        out = _all_records(b)
+        steps = int(b.counters()[0])
+        b.close()
+        return out, steps
+
+    monkeypatch.setenv("MA_SEED_LONG_JUMP", "0")
+    want, steps_walk = run()
+    monkeypatch.delenv("MA_SEED_LONG_JUMP")
+    got, steps = run()
+    _same(got, want)
+    assert steps < 0.9 * steps_walk
+    idx.close()
