@@ -448,6 +448,14 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             bool need = hEn0 > (i32)ez.max || __any( laneMax > (i32)ez.max ) != 0;
             if( !need && J.zdrop >= 0 )
                 need = hEn0 < (i32)ez.max - J.zdrop && __any( laneMax >= (i32)ez.max - J.zdrop ) == 0;
+#if defined( MA_EXP_NONEED ) // experiment (timing only, results wrong): what would a deferred exact maximum save?
+            if( need )
+            {
+                max_H = max( hEn0, wave_max_i32( laneMax ) );
+                max_t = en0;
+                need = false;
+            }
+#endif
             if( need )
             {
                 // classes (t - st0) mod HL: a lane's low cells all share one class, its high cells the next one

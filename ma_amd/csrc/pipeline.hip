@@ -90,7 +90,7 @@ static __device__ unsigned long long g_seed_prof[ 8 ];
 // One read per lane at a time; lanes refill from a global queue, so a wavefront keeps stepping 64
 // reads in lockstep through extend_backward until the batch is exhausted.
 // LONG: the reads stay in HBM (longer than 240 bases) and are read through the register window of seed_qbyte.
-template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const SeedKernelArgs& A )
+template <bool LONG, bool SM> __device__ __forceinline__ void seed_kernel_body( const SeedKernelArgs& A )
 {
     const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     SeedScratch S;
@@ -107,7 +107,7 @@ template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const See
     u64 steps = 0, blocks = 0;
     const u32 wl = threadIdx.x & 63;
 #if defined( MA_KSW_PROF )
-    unsigned long long pf[ 6 ] = { 0, 0, 0, 0, 0, 0 };
+    unsigned long long pf[ 7 ] = { 0, 0, 0, 0, 0, 0, 0 };
 #endif
     // the read in flight is staged in LDS (stride = odd number of words: conflict-free): every step of the state
     // machine starts with a query base, and an LDS read is ~20x closer than an HBM one
@@ -205,13 +205,22 @@ template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const See
 #endif
         u32 c = 0;
         const bool act = alive && L.phase != PH_DONE;
-        bool ext = act && seed_try<LONG>( L, A.P, c );
+        bool ext = act && seed_try<LONG, SM>( L, A.P, c );
         {
             // phase transitions are batched like the refills: run them when enough lanes wait for one (or nobody can step)
             const unsigned long long sm = __ballot( act && !ext );
+#if defined( MA_KSW_PROF )
+            const unsigned long long tB1 = clock64( );
+            if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
+                pf[ 5 ] += 1ull << 32, pf[ 0 ] -= tB1; // slow trips in the high word; slow cycles: + tC below
+#endif
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare<LONG, true>( L, A.P, S, A.X, c ); // K-mer table: 150 bp 8.1 -> 7.5 ms; reads in HBM with K byte loads per key 145 -> 188 ms (10 kb), hence seed_jump's block loads
+                    ext = seed_prepare<LONG, true, SM>( L, A.P, S, A.X, c );
+#if defined( MA_KSW_PROF )
+            if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
+                pf[ 0 ] += clock64( );
+#endif // K-mer table: 150 bp 8.1 -> 7.5 ms; reads in HBM with K byte loads per key 145 -> 188 ms (10 kb), hence seed_jump's block loads
         }
 #if defined( MA_KSW_PROF )
         const unsigned long long tC = clock64( );
@@ -226,11 +235,11 @@ template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const See
             extend_backward( A.X, L.ik, c, ok, nb );
             L.steps++;
             L.blocks += nb;
-            seed_apply( L, A.P, S, ok );
+            seed_apply<SM>( L, A.P, S, ok );
         }
 #if defined( MA_KSW_PROF )
         const unsigned long long tD = clock64( );
-        pf[ 0 ] += tB - tA;
+        pf[ 6 ] += tB - tA;
         pf[ 1 ] += tC - tB;
         pf[ 2 ] += tD - tC;
         pf[ 3 ] += 1;
@@ -247,13 +256,13 @@ template <bool LONG> __device__ __forceinline__ void seed_kernel_body( const See
 }
 // Two register budgets: short reads (staged in LDS) run best without spills at 3 waves per SIMD (137 VGPRs: 8.4 vs 9.2 ms
 // per 1 M x 150 bp reads), long reads want the fourth wave more than the 16 spilled dwords hurt (200 k x 10 kb: 155 vs 180 ms).
-__global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
+template <bool SM> __global__ void __launch_bounds__( 256 ) k_seed( SeedKernelArgs A )
 {
-    seed_kernel_body<false>( A );
+    seed_kernel_body<false, SM>( A );
 }
-__global__ void __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( 4 ) ) ) k_seed_long( SeedKernelArgs A )
+template <bool SM> __global__ void __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( 4 ) ) ) k_seed_long( SeedKernelArgs A )
 {
-    seed_kernel_body<true>( A );
+    seed_kernel_body<true, SM>( A );
 }
 
 __device__ __forceinline__ u64 wave_sum_u64( u64 v );
@@ -522,21 +531,22 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
             break;
         u32 c = 0;
         const bool act = alive && L.phase != PH_DONE;
-        bool ext = act && seed_try( L, A.P, c );
+        bool ext = act && seed_try<true, false>( L, A.P, c );
         {
             const unsigned long long sm = __ballot( act && !ext );
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare<false, true>( L, A.P, S, A.X, c );
+                    ext = seed_prepare<true, true, false>( L, A.P, S, A.X, c );
         }
         if( ext )
         {
             i64 ok[ 3 ];
             u32 nb;
+            seed_prefetch<true>( L, A.P );
             extend_backward( A.X, L.ik, c, ok, nb );
             L.steps++;
             L.blocks += nb;
-            seed_apply( L, A.P, S, ok );
+            seed_apply<false>( L, A.P, S, ok );
         }
     }
     steps = wave_sum_u64( steps );
@@ -1799,6 +1809,7 @@ static int seed_tasks( ma_batch* b )
     TaskKernelArgs A;
     A.X = b->idx->v;
     A.P = seed_params( b->P );
+    seed_window( A.P, b, true );
     A.slow_batch = 4;
     if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook
         A.slow_batch = (u32)std::max( 1, atoi( e ) );
@@ -1965,13 +1976,13 @@ int ma_seed_batch( ma_batch* b )
             if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) ) // tuning hook
                 A.slow_batch = (u32)std::max( 1, atoi( e ) );
             if( A.q_lds )
-                hipLaunchKernelGGL( k_seed, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
+                hipLaunchKernelGGL( smem ? k_seed<true> : k_seed<false>, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), A.q_lds * 256, b->stream, A );
             else
             {
                 if( const char* e = getenv( "MA_SEED_LONG_JUMP" ) ) // A/B + test hook: 0 = walk every run step by step
                     if( atoi( e ) == 0 )
                         A.X.kmer_k = 0;
-                hipLaunchKernelGGL( k_seed_long, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), 0, b->stream, A );
+                hipLaunchKernelGGL( smem ? k_seed_long<true> : k_seed_long<false>, dim3( (unsigned)( lanes / 256 ) ), dim3( 256 ), 0, b->stream, A );
             }
         }
         MA_HIP( hipGetLastError( ) );

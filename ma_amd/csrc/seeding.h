@@ -63,6 +63,12 @@ struct SeedLane
     u32 center, i, start, end;
     u32 s1_start, s1_end; // first (right-then-left) segment of the center, for the duplicate test
     i64 ik[ 3 ];
+    // K-mer table entry of the centre's LEFT run (second pass), looked up together with the right run's (seed_center): the
+    // two gathers share one memory round trip.  eL1 == 0: none
+    u64 eL0, eL1;
+    // reads in HBM: the bases around the centre the transitions need -- q[c-K], q[c-1], q[c], q[c+1], q[c+K], 3 bits each,
+    // bit 15 = valid -- out of the block seed_center loaded (otherwise every transition is a memory round trip of its own)
+    u32 cb;
     // SMEM state
     u32 nPrev, nCurr, jPrev; // list sizes / cursor
     u32 curQStart, curQSize; // prev[jPrev] of the extension in flight (its interval is in ik): read once, in seed_prepare
@@ -270,76 +276,155 @@ MA_HD void seed_after_center( SeedLane& L, const SeedScratch& S, u32 cS, u32 cN 
         L.phase = PH_DONE;
 }
 
-// The first K-1 extension steps of a run that starts at the centre with a single-base interval, from the K-mer table of
-// the index: right = true: bases q[centre .. centre+K-1] complemented (the run of PH_P1_RIGHT), else q[centre], q[centre-1],
-// .. (PH_P2_LEFT).  Valid when the interval after those steps is still larger than min_amb: interval sizes only shrink
-// along a run, so none of the skipped steps would have met the stop rule (binarySeeding.h:109-112).  Returns false (and
-// leaves the lane untouched) when the run has to be walked step by step.
-template <bool WIN = false> MA_HD bool seed_jump( SeedLane& L, const SeedParams& P, const IndexView& X, bool right )
+// The first K-1 extension steps of a run that starts at the centre with a single-base interval come from the K-mer table of
+// the index: the right run (PH_P1_RIGHT) of the bases q[centre .. centre+K-1] complemented, the left run (PH_P2_LEFT) of
+// q[centre], q[centre-1], ..  An entry is valid for a run when its interval is still larger than min_amb: interval sizes only
+// shrink along a run, so none of the skipped steps would have met the stop rule (binarySeeding.h:109-112).
+MA_HD bool kmer_decode( const SeedParams& P, u64 x, u64 y, i64 ik[ 3 ] )
 {
-#if defined( __HIP_DEVICE_COMPILE__ )
-    const u32 K = X.kmer_k;
-    if( K == 0 || ( right ? L.center + K > L.qlen : L.center + 1 < K ) )
-        return false;
-    u32 key = 0, bad = 0;
-    if( WIN && P.window_end )
-    {
-        // reads in HBM: the K <= 14 bases [lo, lo + K) out of two 16-byte blocks (aligned, or flush with an end of the
-        // reads array like seed_qbyte's window) instead of K byte loads, the 2-bit key by bit gathering
-        const uintptr_t a = (uintptr_t)( L.q + ( right ? L.center : L.center + 1 - K ) );
-        uintptr_t base = a & ~(uintptr_t)15;
-        if( base + 32 > (uintptr_t)P.window_end )
-            base = (uintptr_t)P.window_end - 32;
-        if( base < (uintptr_t)P.window_begin )
-            return false; // an array of fewer than 32 bytes
-        u64 w[ 4 ];
-        __builtin_memcpy( w, (const void*)base, 32 ); // (the flush case is unaligned: byte-wise there, two dwordx4 otherwise)
-        const u32 d = (u32)( a - base ); // < 32 - K
-        const u32 sh = 8u * ( d & 7u );
-        const u64 w0 = d & 16u ? w[ 2 ] : w[ 0 ], w1 = d & 16u ? w[ 3 ] : w[ 1 ], w2 = d & 16u ? 0ull : w[ 2 ], w3 = d & 16u ? 0ull : w[ 3 ];
-        const u64 lo8 = d & 8u ? w1 : w0, mid8 = d & 8u ? w2 : w1, hi8 = d & 8u ? w3 : w2;
-        u64 x = sh ? ( lo8 >> sh ) | ( mid8 << ( 64u - sh ) ) : lo8; // bases 0..7 of the span
-        u64 y = sh ? ( mid8 >> sh ) | ( hi8 << ( 64u - sh ) ) : mid8; // bases 8..15
-        if( K < 8 )
-            x &= ( 1ull << ( 8u * K ) ) - 1ull;
-        y = K > 8 ? y & ( ( 1ull << ( 8u * ( K - 8u ) ) ) - 1ull ) : 0ull; // K <= 14
-        bad = ( ( x | y ) & 0xfcfcfcfcfcfcfcfcull ) != 0;
-        auto gather = []( u64 v ) -> u32 { // code of byte j -> bits 2j, 2j+1
-            v = ( v | ( v >> 6 ) ) & 0x000f000f000f000full;
-            v = ( v | ( v >> 12 ) ) & 0x000000ff000000ffull;
-            return (u32)( ( v | ( v >> 24 ) ) & 0xffffull );
-        };
-        const u32 le = gather( x ) | gather( y ) << 16; // base j of the span at bits 2j
-        if( right )
-        {
-            // first base of the span most significant, complemented
-            u32 r = __brev( le ) >> ( 32u - 2u * K );
-            r = ( ( r & 0xaaaaaaaau ) >> 1 ) | ( ( r & 0x55555555u ) << 1 );
-            key = r ^ ( ( 1u << ( 2u * K ) ) - 1u );
-        }
-        else
-            key = le; // q[center] = last base of the span most significant
-    }
-    else
-        for( u32 j = 0; j < K; j++ )
-        {
-            const u32 b = L.q[ right ? L.center + j : L.center - j ]; // plain loads: K bytes of one or two lines
-            bad |= b >> 2;
-            key = ( key << 2 ) | ( ( right ? 3u - b : b ) & 3u );
-        }
-    if( bad )
-        return false; // an N inside the K-mer
-    const ulonglong2 e = ( (const ulonglong2*)X.kmer_tab )[ key ];
-    const i64 size = (i64)( ( e.x >> 35 ) | ( ( ( e.y >> 35 ) & 0x3full ) << 29 ) );
+    const i64 size = (i64)( ( x >> 35 ) | ( ( ( y >> 35 ) & 0x3full ) << 29 ) );
     if( size <= (i64)P.min_amb )
         return false;
-    L.ik[ 0 ] = (i64)( e.x & 0x7ffffffffull );
-    L.ik[ 1 ] = (i64)( e.y & 0x7ffffffffull );
-    L.ik[ 2 ] = size;
+    ik[ 0 ] = (i64)( x & 0x7ffffffffull );
+    ik[ 1 ] = (i64)( y & 0x7ffffffffull );
+    ik[ 2 ] = size;
     return true;
+}
+// 2-bit codes of up to 16 bases held one per byte (x: bases 0..7, y: 8..15) -> base j at bits 2j, 2j+1
+MA_HD u32 kmer_gather( u64 x, u64 y )
+{
+    auto g = []( u64 v ) -> u32 {
+        v = ( v | ( v >> 6 ) ) & 0x000f000f000f000full;
+        v = ( v | ( v >> 12 ) ) & 0x000000ff000000ffull;
+        return (u32)( ( v | ( v >> 24 ) ) & 0xffffull );
+    };
+    return g( x ) | g( y ) << 16;
+}
+MA_HD u32 kmer_key_right( u32 le, u32 K ) // first base of the span most significant, complemented
+{
+    u32 r = 0;
+#if defined( __HIP_DEVICE_COMPILE__ )
+    r = __brev( le ) >> ( 32u - 2u * K );
 #else
-    return false;
+    for( u32 j = 0; j < 32; j++ )
+        r |= ( ( le >> j ) & 1u ) << ( 31u - j );
+    r >>= 32u - 2u * K;
 #endif
+    r = ( ( r & 0xaaaaaaaau ) >> 1 ) | ( ( r & 0x55555555u ) << 1 );
+    return r ^ (u32)( ( 1ull << ( 2u * K ) ) - 1ull );
+}
+
+// Start of a centre: its base (returned), and -- when the index has a K-mer table -- the table entries of BOTH runs that
+// start at the centre: eR (returned through eRx / eRy, 0 = none) and the lane's eL.  Reads in HBM (WIN): ONE load of the 48
+// bytes around the centre serves the base, both keys and the bases the later transitions of this centre start with (L.cb);
+// step by step the same costs a window load for the centre, K byte loads per key and a window load per transition, each a
+// memory round trip of its own that the whole wavefront waits for.
+template <bool WIN, bool JUMP, bool SM = true> MA_HD u32 seed_center( SeedLane& L, const SeedParams& P, const IndexView& X, u64& eRx, u64& eRy )
+{
+    const u32 K = JUMP && ( !SM || P.technique == 0 ) ? X.kmer_k : 0, c = L.center;
+    eRx = eRy = 0;
+    L.eL0 = L.eL1 = 0;
+    L.cb = 0;
+    bool vR = K != 0 && c + K <= L.qlen, vL = K != 0 && c + 1 >= K;
+    u32 keyR = 0, keyL = 0, qc;
+#if defined( __HIP_DEVICE_COMPILE__ )
+    const uintptr_t a0 = (uintptr_t)( L.q + c ) - K; // q[c-K] (possibly in front of the read)
+    const uintptr_t base = a0 & ~(uintptr_t)15;
+    if( WIN && K != 0 && P.window_end && base >= (uintptr_t)P.window_begin && base + 48 <= (uintptr_t)P.window_end )
+    {
+        const uint4 b0 = ( (const uint4*)base )[ 0 ], b1 = ( (const uint4*)base )[ 1 ], b2 = ( (const uint4*)base )[ 2 ];
+        const u64 w0 = b0.x | (u64)b0.y << 32, w1 = b0.z | (u64)b0.w << 32, w2 = b1.x | (u64)b1.y << 32, w3 = b1.z | (u64)b1.w << 32,
+                  w4 = b2.x | (u64)b2.y << 32, w5 = b2.z | (u64)b2.w << 32;
+        const u32 d0 = (u32)( a0 - base ), sh = 8u * ( d0 & 7u );
+        const bool t = ( d0 & 8u ) != 0;
+        auto fun = [ & ]( u64 lo, u64 hi ) -> u64 { return sh ? ( lo >> sh ) | ( hi << ( 64u - sh ) ) : lo; };
+        // v[j]: bytes 8j .. 8j+7 of the view that starts at q[c-K]
+        const u64 v0 = fun( t ? w1 : w0, t ? w2 : w1 ), v1 = fun( t ? w2 : w1, t ? w3 : w2 ), v2 = fun( t ? w3 : w2, t ? w4 : w3 ),
+                  v3 = fun( t ? w4 : w3, t ? w5 : w4 );
+        auto at = [ & ]( u32 j ) -> u32 { // j is wave-uniform
+            const u64 v = j < 8 ? v0 : j < 16 ? v1 : j < 24 ? v2 : v3;
+            return (u32)( v >> ( 8u * ( j & 7u ) ) ) & 0xffu;
+        };
+        auto span = [ & ]( u32 j, u64& x, u64& y ) { // K bytes from byte j on
+            const u32 s8 = 8u * ( j & 7u );
+            const u64 p = j < 8 ? v0 : j < 16 ? v1 : v2, q = j < 8 ? v1 : j < 16 ? v2 : v3, r = j < 8 ? v2 : j < 16 ? v3 : 0ull;
+            x = s8 ? ( p >> s8 ) | ( q << ( 64u - s8 ) ) : p;
+            y = s8 ? ( q >> s8 ) | ( r << ( 64u - s8 ) ) : q;
+            if( K < 8 )
+                x &= ( 1ull << ( 8u * K ) ) - 1ull;
+            y = K > 8 ? y & ( ( 1ull << ( 8u * ( K - 8u ) ) ) - 1ull ) : 0ull; // K <= 14
+        };
+        qc = at( K );
+        const u32 qm1 = at( K - 1 ), qp1 = at( K + 1 ), qmK = at( 0 ), qpK = at( 2 * K );
+        if( ( ( qc | qm1 | qp1 | qmK | qpK ) & ~7u ) == 0 )
+            L.cb = qmK | qm1 << 3 | qc << 6 | qp1 << 9 | qpK << 12 | 0x8000u;
+        u64 x, y;
+        span( K, x, y );
+        vR = vR && ( ( x | y ) & 0xfcfcfcfcfcfcfcfcull ) == 0;
+        keyR = kmer_key_right( kmer_gather( x, y ), K );
+        span( 1, x, y );
+        vL = vL && ( ( x | y ) & 0xfcfcfcfcfcfcfcfcull ) == 0;
+        keyL = kmer_gather( x, y ); // q[c] = last base of the span most significant
+    }
+    else
+#endif
+    {
+        qc = seed_qbyte<WIN>( L, P, c );
+        if( qc >= 4 )
+            return qc;
+        u32 bad = 0;
+        for( u32 j = 0; vR && j < K; j++ )
+        {
+            const u32 b = L.q[ c + j ];
+            bad |= b >> 2;
+            keyR = ( keyR << 2 ) | ( ( 3u - b ) & 3u );
+        }
+        vR = vR && !bad;
+        bad = 0;
+        for( u32 j = 0; vL && j < K; j++ )
+        {
+            const u32 b = L.q[ c - j ];
+            bad |= b >> 2;
+            keyL = ( keyL << 2 ) | ( b & 3u );
+        }
+        vL = vL && !bad;
+    }
+    if( qc >= 4 )
+        return qc;
+#if defined( __HIP_DEVICE_COMPILE__ )
+    if( K != 0 )
+    {
+        // both gathers in flight before either entry is looked at
+        ulonglong2 eR = make_ulonglong2( 0, 0 ), eL = make_ulonglong2( 0, 0 );
+        if( vR )
+            eR = ( (const ulonglong2*)X.kmer_tab )[ keyR ];
+        if( vL )
+            eL = ( (const ulonglong2*)X.kmer_tab )[ keyL ];
+        eRx = eR.x, eRy = eR.y;
+        L.eL0 = eL.x, L.eL1 = eL.y;
+    }
+#endif
+    return qc;
+}
+// base i of the read out of the centre's cached bases when it is one of them
+template <bool WIN> MA_HD u32 seed_qbyte_c( SeedLane& L, const SeedParams& P, const IndexView& X, u32 i )
+{
+    if( WIN && ( L.cb & 0x8000u ) )
+    {
+        const u32 K = X.kmer_k;
+        const i32 d = (i32)( i - L.center );
+        if( d == -1 )
+            return ( L.cb >> 3 ) & 7u;
+        if( d == 1 )
+            return ( L.cb >> 9 ) & 7u;
+        if( d == 0 )
+            return ( L.cb >> 6 ) & 7u;
+        if( d == -(i32)K )
+            return L.cb & 7u;
+        if( d == (i32)K )
+            return ( L.cb >> 12 ) & 7u;
+    }
+    return seed_qbyte<WIN>( L, P, i );
 }
 
 MA_HD bool seed_stop( const SeedParams& P, const i64 ok[ 3 ], const i64 ik[ 3 ] ) // binarySeeding.h:109-112
@@ -352,9 +437,10 @@ MA_HD bool seed_stop( const SeedParams& P, const i64 ok[ 3 ], const i64 ik[ 3 ] 
 // Can the lane extend right away, i.e. without any phase transition?  (The kernel batches the transitions of a
 // wavefront: a lane whose transition is due idles for a few steps until enough lanes wait, so that the divergent
 // bookkeeping of seed_prepare is executed once for many lanes instead of on every step for one or two.)
-template <bool WIN = false> MA_HD bool seed_try( SeedLane& L, const SeedParams& P, u32& c )
+// SM = false: the kernel serves maxSpan only (P.technique == 0): the SMEM states and their lane registers are compiled out
+template <bool WIN = false, bool SM = true> MA_HD bool seed_try( SeedLane& L, const SeedParams& P, u32& c )
 {
-    if( L.phase == PH_SMEM_BWD )
+    if( SM && L.phase == PH_SMEM_BWD )
     {
         // SMEM backward phase with ONE entry left on the list that was just written (after the twins are gone: nearly
         // every position of a read): the end-of-position bookkeeping of seed_prepare, with the entry taken from the
@@ -377,7 +463,7 @@ template <bool WIN = false> MA_HD bool seed_try( SeedLane& L, const SeedParams& 
         }
         return false;
     }
-    const bool right = L.phase == PH_P1_RIGHT || L.phase == PH_P2_RIGHT || L.phase == PH_SMEM_FWD;
+    const bool right = L.phase == PH_P1_RIGHT || L.phase == PH_P2_RIGHT || ( SM && L.phase == PH_SMEM_FWD );
     const bool left = L.phase == PH_P1_LEFT || L.phase == PH_P2_LEFT;
     const bool ok = right ? L.i < L.qlen : ( left && L.i != 0xffffffffu );
     if( ok )
@@ -410,7 +496,7 @@ template <bool WIN> MA_HD void seed_prefetch( SeedLane& L, const SeedParams& P )
 // Runs cheap bookkeeping until the lane either needs an extension (returns true and sets c) or is done.
 // JUMP: use the K-mer table of the index (only the kernel whose register budget has room for it: inlined into the
 // read-per-lane kernel it costs a wave of occupancy, 117 -> 138 VGPRs, which eats the gain)
-template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
+template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
 {
     while( true )
     {
@@ -421,14 +507,15 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
             case PH_NEW_CENTER:
             {
                 L.center = L.aS + L.aN / 2;
-                const u32 qc = seed_qbyte<WIN>( L, P, L.center );
+                u64 eRx, eRy;
+                const u32 qc = seed_center<WIN, JUMP, SM>( L, P, X, eRx, eRy );
                 if( qc >= 4 )
                 { // N covers one position (binarySeeding.h:70-72 / 275-277)
                     seed_after_center( L, S, L.center, 1 );
                     break;
                 }
                 init_interval( X, 3 - qc, L.ik );
-                if( P.technique == 0 )
+                if( !SM || P.technique == 0 )
                 {
                     if( L.ik[ 2 ] == 0 )
                     {
@@ -437,7 +524,7 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
                     }
                     L.end = L.center;
                     L.i = L.center + 1;
-                    if( JUMP && seed_jump<WIN>( L, P, X, true ) )
+                    if( JUMP && kmer_decode( P, eRx, eRy, L.ik ) )
                     {
                         L.end = L.center + X.kmer_k - 1;
                         L.i = L.center + X.kmer_k;
@@ -457,7 +544,7 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
             case PH_P1_RIGHT:
                 if( L.i < L.qlen )
                 {
-                    c = comp_base( seed_qbyte<WIN>( L, P, L.i ) );
+                    c = comp_base( seed_qbyte_c<WIN>( L, P, X, L.i ) );
                     return true;
                 }
                 // end of query: switch direction (binarySeeding.h:118-120)
@@ -475,18 +562,18 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
             case PH_P1_LEFT:
                 if( L.i != 0xffffffffu )
                 {
-                    c = seed_qbyte<WIN>( L, P, L.i );
+                    c = seed_qbyte_c<WIN>( L, P, X, L.i );
                     return true;
                 }
                 // record first segment and start the second pass (binarySeeding.h:152-163)
                 seed_emit( L, S, L.start, L.end - L.start, L.ik[ 0 ], L.ik[ 1 ], L.ik[ 2 ] );
                 L.s1_start = L.start;
                 L.s1_end = L.end;
-                init_interval( X, seed_qbyte<WIN>( L, P, L.center ), L.ik );
+                init_interval( X, seed_qbyte_c<WIN>( L, P, X, L.center ), L.ik );
                 L.start = L.center;
                 L.phase = PH_P2_LEFT;
                 L.i = L.center > 0 ? L.center - 1 : 0xffffffffu;
-                if( JUMP && seed_jump<WIN>( L, P, X, false ) )
+                if( JUMP && kmer_decode( P, L.eL0, L.eL1, L.ik ) )
                 {
                     L.start = L.center - ( X.kmer_k - 1 );
                     L.i = L.start > 0 ? L.start - 1 : 0xffffffffu;
@@ -495,7 +582,7 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
             case PH_P2_LEFT:
                 if( L.i != 0xffffffffu )
                 {
-                    c = seed_qbyte<WIN>( L, P, L.i );
+                    c = seed_qbyte_c<WIN>( L, P, X, L.i );
                     return true;
                 }
                 mswap( L.ik[ 0 ], L.ik[ 1 ] );
@@ -506,7 +593,7 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
             case PH_P2_RIGHT:
                 if( L.i < L.qlen )
                 {
-                    c = comp_base( seed_qbyte<WIN>( L, P, L.i ) );
+                    c = comp_base( seed_qbyte_c<WIN>( L, P, X, L.i ) );
                     return true;
                 }
                 {
@@ -523,6 +610,8 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
                 }
                 break;
             case PH_SMEM_FWD:
+                if( !SM )
+                    return false;
                 if( L.i < L.qlen )
                 {
                     c = comp_base( seed_qbyte<WIN>( L, P, L.i ) );
@@ -561,6 +650,8 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
                 break;
             case PH_SMEM_BWD:
             {
+                if( !SM )
+                    return false;
                 ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
                 if( L.jPrev < L.nPrev )
                 {
@@ -608,7 +699,7 @@ template <bool WIN = false, bool JUMP = false> MA_HD bool seed_prepare( SeedLane
 }
 
 // ---- apply the result of the extension requested by seed_prepare --------------------------------
-MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, const i64 ok[ 3 ] )
+template <bool SM = true> MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, const i64 ok[ 3 ] )
 {
     switch( L.phase )
     {
@@ -636,6 +727,8 @@ MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, c
             break;
         case PH_SMEM_FWD:
         { // binarySeeding.h:296-337
+            if( !SM )
+                break;
             ma_segment* cur = S.smem_a;
             auto push = [ & ]( u32 st, u32 sz, i64 a, i64 b, i64 c ) {
                 if( L.nCurr < S.smem_cap )
@@ -660,6 +753,8 @@ MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, c
         }
         case PH_SMEM_BWD:
         { // binarySeeding.h:380-413
+            if( !SM )
+                break;
             ma_segment* curr = L.flip ? S.smem_a : S.smem_b;
             ma_segment s; // = prev[ L.jPrev ], kept in the lane state by seed_prepare (saves a memory round trip per step)
             s.q_start = L.curQStart, s.q_size = L.curQSize, s.sa_start = L.ik[ 0 ], s.sa_start_rc = L.ik[ 1 ], s.sa_size = L.ik[ 2 ];

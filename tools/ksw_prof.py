@@ -20,8 +20,9 @@ finally:
     sp = (C.c_ulonglong * 8)()
     ma_amd.lib().ma_debug_seed_prof(sp)
     sp = list(sp)
-    print("k_seed: refill cycles %d, prepare %d, extend+apply %d, wave trips %d, active lanes/trip %.1f, refill trips %d" % (
-        sp[0], sp[1], sp[2], sp[3], sp[4] / max(sp[3], 1), sp[5]))
+    slow_trips = sp[5] >> 32
+    print("k_seed: slow-path cycles %d in %d slow trips (%.0f each), try+prepare %d, extend+apply %d, wave trips %d, active lanes/trip %.1f, refill trips %d" % (
+        sp[0], slow_trips, sp[0] / max(slow_trips, 1), sp[1], sp[2], sp[3], sp[4] / max(sp[3], 1), sp[5] & 0xffffffff))
     print("k_seed per trip: refill %.0f prepare %.0f extend %.0f" % (sp[0] / max(sp[3], 1), sp[1] / max(sp[3], 1), sp[2] / max(sp[3], 1)))
     print("k_extract: wave cycles in segment search %d, in bwt_sa %d" % (sp[6], sp[7]))
     j = max(v[3], 1)
