@@ -285,6 +285,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( S 
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
     __shared__ u32 sSlot;
     __shared__ unsigned long long sOff;
+    __shared__ int2 sSnap[ 64 * S ]; // the lanes' H of the diagonal that raised ez.max last (ksw_pk.h)
     uint8_t* my = scratch + (u64)blockIdx.x * stride;
     uint8_t* P = my;
     u32* cig = (u32*)( my + p_cap );
@@ -309,7 +310,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( S 
         u64 cells = 0, path = 0;
         auto qf = F.qfetch( slot );
         auto tf = F.tfetch( slot );
-        ksw_pk_core<S, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes );
+        ksw_pk_core<S, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes, sSnap );
         ksw_publish( O, acc, slot, ez, nCig, cells, path, cig, &sOff );
     }
     ksw_flush( O, acc );

@@ -41,7 +41,7 @@ __device__ __forceinline__ i32 pk_hi8( u32 x ) // int8 value of the high half
 template <int R, bool EARLY, typename QF, typename TF>
 __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, uint8_t* qr /*LDS*/,
                              uint8_t* P /*HBM direction bytes*/, u32* cig, KswEz& ez, u32& nCigar, u64& cells,
-                             u64& pathSteps, u32 ldsBytes )
+                             u64& pathSteps, u32 ldsBytes, int2* snap /*LDS, 64 * R entries*/ )
 {
     constexpr i32 RING = 128 * R;
     const int lane = threadIdx.x & 63;
@@ -163,6 +163,94 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         Hlo[ s ] = Hhi[ s ] = NEG;
     }
     i32 last_st = -1, last_en = -1, cur_st = 0;
+    // calcMaxScore (kswcpp_core.h:156-299) of one diagonal: the H of the cells of [st0, en0) as the lanes hold them (hl / hh: the
+    // low / high cell of ring slot s, tts: the low cell's index), H[en0] = hE -> the SSE code's (max_H, max_t)
+    auto exactMax = [ & ]( const i32( &hl )[ R ], const i32( &hh )[ R ], const i32( &tts )[ R ], i32 st0, i32 en0, i32 hE, i32& max_H, i32& max_t ) {
+        const i32 en1 = st0 + ( ( ( en0 - st0 ) >> HLs ) << HLs );
+        // classes (t - st0) mod HL: a lane's low cells all share one class, its high cells the next one
+        i32 bhL = (i32)0x80000000, bkL = 0x7fffffff, bhH = (i32)0x80000000, bkH = 0x7fffffff;
+        i32 tailL = (i32)0x80000000, tailH = (i32)0x80000000; // scalar remainder [en1, en0)
+#pragma unroll
+        for( int s = 0; s < R; s++ )
+        {
+            const i32 tt = tts[ s ];
+            if( tt >= st0 && tt < en0 )
+            {
+                if( tt < en1 )
+                    best_pair( bhL, bkL, hl[ s ], ( tt - st0 ) >> HLs );
+                else
+                    tailL = hl[ s ];
+            }
+            if( tt + 1 >= st0 && tt + 1 < en0 )
+            {
+                if( tt + 1 < en1 )
+                    best_pair( bhH, bkH, hh[ s ], ( tt + 1 - st0 ) >> HLs );
+                else
+                    tailH = hh[ s ];
+            }
+        }
+        // all-reduce over the lanes of one class: lanes with equal (lane mod HL/2)
+        if( HL == 4 )
+        {
+            best_pair( bhL, bkL, dpp_ctrl<0x122>( bhL ), dpp_ctrl<0x122>( bkL ) ); // row_ror:2
+            best_pair( bhH, bkH, dpp_ctrl<0x122>( bhH ), dpp_ctrl<0x122>( bkH ) );
+        }
+        best_pair( bhL, bkL, dpp_ctrl<0x124>( bhL ), dpp_ctrl<0x124>( bkL ) ); // row_ror:4
+        best_pair( bhH, bkH, dpp_ctrl<0x124>( bhH ), dpp_ctrl<0x124>( bkH ) );
+        best_pair( bhL, bkL, dpp_ctrl<0x128>( bhL ), dpp_ctrl<0x128>( bkL ) ); // row_ror:8
+        best_pair( bhH, bkH, dpp_ctrl<0x128>( bhH ), dpp_ctrl<0x128>( bkH ) );
+        best_pair( bhL, bkL, __shfl_xor( bhL, 16, 64 ), __shfl_xor( bkL, 16, 64 ) );
+        best_pair( bhH, bkH, __shfl_xor( bhH, 16, 64 ), __shfl_xor( bkH, 16, 64 ) );
+        best_pair( bhL, bkL, __shfl_xor( bhL, 32, 64 ), __shfl_xor( bkL, 32, 64 ) );
+        best_pair( bhH, bkH, __shfl_xor( bhH, 32, 64 ), __shfl_xor( bkH, 32, 64 ) );
+        // per class: the initial (H[en0], en0) wins ties; then independent horizontal maxima over the classes
+        i32 mh = hE, mt = en0;
+        if( bhL > hE )
+            mh = bhL, mt = st0 + ( bkL << HLs );
+        {
+            const i32 vh = bhH > hE ? bhH : hE, vt = bhH > hE ? st0 + ( bkH << HLs ) : en0;
+            mh = max( mh, vh );
+            mt = max( mt, vt );
+        }
+        mh = max( mh, dpp_ctrl<0xB1>( mh ) ); // quad_perm [1,0,3,2]: the neighbouring lane's two classes
+        mt = max( mt, dpp_ctrl<0xB1>( mt ) );
+        if( HL == 8 )
+        {
+            mh = max( mh, dpp_ctrl<0x4E>( mh ) ); // quad_perm [2,3,0,1]
+            mt = max( mt, dpp_ctrl<0x4E>( mt ) );
+        }
+        max_H = __builtin_amdgcn_readfirstlane( mh );
+        max_t = __builtin_amdgcn_readfirstlane( mt );
+        // scalar remainder [en1, en0): ascending t, strict >
+        for( i32 t = en1; t < en0; ++t )
+        {
+            const i32 h = lane_bcast( ( t & 1 ) ? tailH : tailL, ( t >> 1 ) & 63 );
+            if( h > max_H )
+                max_H = h, max_t = t;
+        }
+    };
+    // pending position of the last diagonal that raised ez.max (the lanes' H of that diagonal are in `snap`)
+    bool pend = false;
+    i32 pSt0 = 0, pEn0 = 0, pR = 0, pCur = 0, pHEn0 = 0;
+    auto resolvePending = [ & ]( ) {
+        if( !pend )
+            return;
+        i32 hl[ R ], hh[ R ], tts[ R ];
+#pragma unroll
+        for( int s = 0; s < R; s++ )
+        {
+            const int2 v = snap[ s * 64 + lane ];
+            hl[ s ] = v.x, hh[ s ] = v.y;
+            // the lane's cell of slot s inside the ring window [pCur, pCur + RING) of that diagonal
+            i32 d = ( 128 * s + 2 * lane - pCur ) % RING;
+            tts[ s ] = pCur + ( d < 0 ? d + RING : d );
+        }
+        i32 mh, mt;
+        exactMax( hl, hh, tts, pSt0, pEn0, pHEn0, mh, mt );
+        ez.max_t = mt;
+        ez.max_q = pR - mt;
+        pend = false;
+    };
     i32 hBelow = NEG; // H[st-1]: the only recycled cell that is read again (as H[en0-1] when en0 == st)
     const i32 nDiag = qlen + tlen - 1;
     bool stop = false;
@@ -382,6 +470,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             __builtin_amdgcn_sched_barrier( 0 );
         }
         i32 max_H, max_t, hEnd, hS;
+        bool raised = false;
         if( r > 0 )
         {
             // H[en0] = en0 > 0 ? Hold[en0-1] + u[en0] : Hold[en0] + v[en0].  Cell en0 - 1 was advanced above when it
@@ -442,83 +531,31 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             }
             hEnd = hEn0;
             hS = st0 == en0 ? hEn0 : pickCell( Hlo, Hhi, st0 );
-            // the exact (max_H, max_t) is only consumed when the diagonal raises ez.max or could z-drop (ksw_reg.h)
+            // The exact (max_H, max_t) -- the class-wise first maxima of the SSE code, ~240 instructions -- is only consumed when
+            // the diagonal raises ez.max or could z-drop (ksw_reg.h).  A diagonal that RAISES ez.max (every other one while
+            // an alignment runs: 17 % of the 10 kb DP stage) needs only the value right away, max( H[en0], the lanes' maxima );
+            // its position max_t is read by the z-drop test and by the caller at the end, and only that of the LAST raise:
+            // the lanes' H go to LDS (one ds_write_b64 per ring slot) and the position is worked out of that snapshot when
+            // somebody asks (resolvePending).
             max_H = (i32)0x80000000;
             max_t = 0;
-            bool need = hEn0 > (i32)ez.max || __any( laneMax > (i32)ez.max ) != 0;
-            if( !need && J.zdrop >= 0 )
-                need = hEn0 < (i32)ez.max - J.zdrop && __any( laneMax >= (i32)ez.max - J.zdrop ) == 0;
-#if defined( MA_EXP_NONEED ) // experiment (timing only, results wrong): what would a deferred exact maximum save?
-            if( need )
+            raised = hEn0 > (i32)ez.max || __any( laneMax > (i32)ez.max ) != 0;
+            bool need = false;
+            if( raised )
             {
-                max_H = max( hEn0, wave_max_i32( laneMax ) );
-                max_t = en0;
-                need = false;
-            }
-#endif
-            if( need )
-            {
-                // classes (t - st0) mod HL: a lane's low cells all share one class, its high cells the next one
-                i32 bhL = (i32)0x80000000, bkL = 0x7fffffff, bhH = (i32)0x80000000, bkH = 0x7fffffff;
-                i32 tailL = (i32)0x80000000, tailH = (i32)0x80000000; // scalar remainder [en1, en0)
+                const i32 m = max( hEn0, wave_max_i32( laneMax ) );
 #pragma unroll
                 for( int s = 0; s < R; s++ )
-                {
-                    const i32 tt = TT[ s ];
-                    if( tt >= st0 && tt < en0 )
-                    {
-                        if( tt < en1 )
-                            best_pair( bhL, bkL, Hlo[ s ], ( tt - st0 ) >> HLs );
-                        else
-                            tailL = Hlo[ s ];
-                    }
-                    if( tt + 1 >= st0 && tt + 1 < en0 )
-                    {
-                        if( tt + 1 < en1 )
-                            best_pair( bhH, bkH, Hhi[ s ], ( tt + 1 - st0 ) >> HLs );
-                        else
-                            tailH = Hhi[ s ];
-                    }
-                }
-                // all-reduce over the lanes of one class: lanes with equal (lane mod HL/2)
-                if( HL == 4 )
-                {
-                    best_pair( bhL, bkL, dpp_ctrl<0x122>( bhL ), dpp_ctrl<0x122>( bkL ) ); // row_ror:2
-                    best_pair( bhH, bkH, dpp_ctrl<0x122>( bhH ), dpp_ctrl<0x122>( bkH ) );
-                }
-                best_pair( bhL, bkL, dpp_ctrl<0x124>( bhL ), dpp_ctrl<0x124>( bkL ) ); // row_ror:4
-                best_pair( bhH, bkH, dpp_ctrl<0x124>( bhH ), dpp_ctrl<0x124>( bkH ) );
-                best_pair( bhL, bkL, dpp_ctrl<0x128>( bhL ), dpp_ctrl<0x128>( bkL ) ); // row_ror:8
-                best_pair( bhH, bkH, dpp_ctrl<0x128>( bhH ), dpp_ctrl<0x128>( bkH ) );
-                best_pair( bhL, bkL, __shfl_xor( bhL, 16, 64 ), __shfl_xor( bkL, 16, 64 ) );
-                best_pair( bhH, bkH, __shfl_xor( bhH, 16, 64 ), __shfl_xor( bkH, 16, 64 ) );
-                best_pair( bhL, bkL, __shfl_xor( bhL, 32, 64 ), __shfl_xor( bkL, 32, 64 ) );
-                best_pair( bhH, bkH, __shfl_xor( bhH, 32, 64 ), __shfl_xor( bkH, 32, 64 ) );
-                // per class: the initial (H[en0], en0) wins ties; then independent horizontal maxima over the classes
-                i32 mh = hEn0, mt = en0;
-                if( bhL > hEn0 )
-                    mh = bhL, mt = st0 + ( bkL << HLs );
-                {
-                    const i32 vh = bhH > hEn0 ? bhH : hEn0, vt = bhH > hEn0 ? st0 + ( bkH << HLs ) : en0;
-                    mh = max( mh, vh );
-                    mt = max( mt, vt );
-                }
-                mh = max( mh, dpp_ctrl<0xB1>( mh ) ); // quad_perm [1,0,3,2]: the neighbouring lane's two classes
-                mt = max( mt, dpp_ctrl<0xB1>( mt ) );
-                if( HL == 8 )
-                {
-                    mh = max( mh, dpp_ctrl<0x4E>( mh ) ); // quad_perm [2,3,0,1]
-                    mt = max( mt, dpp_ctrl<0x4E>( mt ) );
-                }
-                max_H = __builtin_amdgcn_readfirstlane( mh );
-                max_t = __builtin_amdgcn_readfirstlane( mt );
-                // scalar remainder [en1, en0): ascending t, strict >
-                for( i32 t = en1; t < en0; ++t )
-                {
-                    const i32 h = lane_bcast( ( t & 1 ) ? tailH : tailL, ( t >> 1 ) & 63 );
-                    if( h > max_H )
-                        max_H = h, max_t = t;
-                }
+                    snap[ s * 64 + lane ] = make_int2( Hlo[ s ], Hhi[ s ] );
+                pend = true, pSt0 = st0, pEn0 = en0, pR = r, pCur = cur_st, pHEn0 = hEn0;
+                ez.max = (u32)m & 0x7fffffffu;
+            }
+            else if( J.zdrop >= 0 )
+                need = hEn0 < (i32)ez.max - J.zdrop && __any( laneMax >= (i32)ez.max - J.zdrop ) == 0;
+            if( need )
+            {
+                resolvePending( );
+                exactMax( Hlo, Hhi, TT, st0, en0, hEn0, max_H, max_t );
             }
         }
         else
@@ -537,9 +574,11 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         if( r - st0 == qlen - 1 && hS > ez.mqe )
             ez.mqe = hS, ez.mqe_t = st0;
         // ksw_apply_zdrop (kswcpp_core.h:22-44), is_rot = 1
-        if( max_H > (i32)ez.max )
+        if( raised )
+            ; // ez.max is up to date, (max_t, max_q) pending
+        else if( max_H > (i32)ez.max )
         {
-            ez.max = (u32)max_H & 0x7fffffffu;
+            ez.max = (u32)max_H & 0x7fffffffu; // r == 0
             ez.max_t = max_t;
             ez.max_q = r - max_t;
         }
@@ -603,6 +642,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         last_st = st;
         last_en = en;
     }
+    resolvePending( );
     __syncthreads( ); // direction bytes of all lanes visible to the back-trace
     i32 i0 = -1, j0b = -1;
     if( !ez.zdropped && !( J.flag & KSW_EZ_EXTZ_ONLY ) )
