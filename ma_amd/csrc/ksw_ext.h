@@ -213,7 +213,7 @@ __device__ __forceinline__ void ksw_backtrack_ring( const uint8_t* P, u32* cig, 
 template <int R, bool LEFT, bool GLOBAL, typename QF, typename TF>
 __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbase, TF tbase, uint8_t* lds, u32 ldsBytes,
                               uint8_t* P /*HBM direction rows, RING bytes each*/, u32* cig, KswEz& ez, u32& nCigar,
-                              u64& cells, u64& pathSteps
+                              u64& cells, u64& pathSteps, uint2* snap /*LDS, 64 * R entries*/
 #if defined( MA_KSW_PROF )
                               ,
                               unsigned long long* prof
@@ -347,6 +347,94 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     if( !GLOBAL )
         prof[ 13 ] += tp0 - tpB; // target bytes + state initialisation
 #endif
+    // calcMaxScore of one diagonal (kswcpp_core.h:156-299) from the lanes' packed H (Hs) and cell offsets t - st0 (DDs)
+    auto exactMax = [ & ]( const u32( &Hs )[ R ], const u32( &DDs )[ R ], i32 st0, i32 en0, i32& mH, i32& mT ) {
+        // ---- the reference's max_t (kswcpp_core.h:156-299): 8 classes (t - st0) mod 8 over the chunks
+        // [st0, en1), each class keeps its first maximum and the chunk base it came from, the initial
+        // (H[en0], en0) wins ties, max_t is the largest of the classes' values; then [en1, en0) one by one
+        const i32 pe = en0 & ( RING - 1 );
+        u32 hreg = Hs[ 0 ];
+#pragma unroll
+        for( int s = 1; s < R; s++ )
+            if( ( pe >> 7 ) == s )
+                hreg = Hs[ s ];
+        const i32 hEn0 = (i32)( (u32)lane_bcast( (i32)hreg, ( pe & 127 ) >> 1 ) << ( pe & 1 ? 0 : 16 ) ) >> 16;
+        const i32 nS = ( ( en0 - st0 ) / 8 ) * 8; // cells of the 8-lane part
+        i32 kLo = (i32)0x80000000, kHi = (i32)0x80000000;
+#pragma unroll
+        for( int s = 0; s < R; s++ )
+        {
+            const u32 inv = pk_sub( 0xffffffffu, DDs[ s ] ); // 0xffff - (t - st0): earlier chunks win ties
+            const i32 lo = (i32)__builtin_amdgcn_perm( Hs[ s ], inv, 0x05040100u );
+            const i32 hi = (i32)__builtin_amdgcn_perm( Hs[ s ], inv, 0x07060302u );
+            if( ( DDs[ s ] & 0xffffu ) < (u32)nS )
+                kLo = max( kLo, lo );
+            if( ( DDs[ s ] >> 16 ) < (u32)nS )
+                kHi = max( kHi, hi );
+        }
+        // lanes with equal (lane mod 4) hold the same two classes
+        kLo = max( kLo, dpp_ctrl<0x124>( kLo ) );
+        kHi = max( kHi, dpp_ctrl<0x124>( kHi ) );
+        kLo = max( kLo, dpp_ctrl<0x128>( kLo ) );
+        kHi = max( kHi, dpp_ctrl<0x128>( kHi ) );
+        {
+            auto a16 = __builtin_amdgcn_permlane16_swap( (u32)kLo, (u32)kLo, false, false );
+            kLo = max( (i32)a16[ 0 ], (i32)a16[ 1 ] );
+            auto b16 = __builtin_amdgcn_permlane16_swap( (u32)kHi, (u32)kHi, false, false );
+            kHi = max( (i32)b16[ 0 ], (i32)b16[ 1 ] );
+            auto a32 = __builtin_amdgcn_permlane32_swap( (u32)kLo, (u32)kLo, false, false );
+            kLo = max( (i32)a32[ 0 ], (i32)a32[ 1 ] );
+            auto b32 = __builtin_amdgcn_permlane32_swap( (u32)kHi, (u32)kHi, false, false );
+            kHi = max( (i32)b32[ 0 ], (i32)b32[ 1 ] );
+        }
+        mH = hEn0, mT = en0;
+        if( nS > 0 )
+        {
+            const i32 hl = kLo >> 16, hh = kHi >> 16;
+            const i32 tl = hl > hEn0 ? st0 + ( ( 0xffff - ( kLo & 0xffff ) ) & ~7 ) : en0;
+            const i32 th = hh > hEn0 ? st0 + ( ( 0xffff - ( kHi & 0xffff ) ) & ~7 ) : en0;
+            i32 vh = max( max( hl, hh ), hEn0 ), vt = max( tl, th );
+            vh = max( vh, dpp_ctrl<0xB1>( vh ) ); // the four lanes of a quad hold the eight classes
+            vt = max( vt, dpp_ctrl<0xB1>( vt ) );
+            vh = max( vh, dpp_ctrl<0x4E>( vh ) );
+            vt = max( vt, dpp_ctrl<0x4E>( vt ) );
+            mH = __builtin_amdgcn_readfirstlane( vh );
+            mT = __builtin_amdgcn_readfirstlane( vt );
+        }
+        for( i32 t = st0 + nS; t < en0; ++t )
+        {
+            const i32 p = t & ( RING - 1 );
+            u32 hr = Hs[ 0 ];
+#pragma unroll
+            for( int s = 1; s < R; s++ )
+                if( ( p >> 7 ) == s )
+                    hr = Hs[ s ];
+            const i32 h = (i32)( (u32)lane_bcast( (i32)hr, ( p & 127 ) >> 1 ) << ( p & 1 ? 0 : 16 ) ) >> 16;
+            if( h > mH )
+                mH = h, mT = t;
+        }
+    };
+    // A diagonal that raises ez.max needs the new value at once, but its position (max_t, max_q) only when the z-drop test or
+    // the caller reads it -- and only that of the LAST raise: the lanes' H and offsets go to LDS, and the ~90 instructions of the
+    // class-wise reduction run once per job instead of on every other diagonal of a good alignment (150 bp: 21.3 -> 18.9 ms)
+    bool pend = false;
+    i32 pSt0 = 0, pEn0 = 0, pR = 0;
+    auto resolvePending = [ & ]( ) {
+        if( !pend )
+            return;
+        u32 Hs[ R ], DDs[ R ];
+#pragma unroll
+        for( int s = 0; s < R; s++ )
+        {
+            const uint2 v = snap[ s * 64 + lane ];
+            Hs[ s ] = v.x, DDs[ s ] = v.y;
+        }
+        i32 mH, mT;
+        exactMax( Hs, DDs, pSt0, pEn0, mH, mT );
+        ez.max_t = mT;
+        ez.max_q = pR - mT;
+        pend = false;
+    };
     i32 recycled = 0; // cells below this index have been handed to cells RING further up
     // granularity of that hand-over: 16 cells when the ring has room for 15 dead cells beside the live window, else 8, 4 or
     // one lane (2 cells): each hand-over costs the same, so the coarsest one that fits is the cheapest per diagonal
@@ -544,85 +632,36 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
         }
         if( need )
         {
-            // ---- the reference's max_t (kswcpp_core.h:156-299): 8 classes (t - st0) mod 8 over the chunks
-            // [st0, en1), each class keeps its first maximum and the chunk base it came from, the initial
-            // (H[en0], en0) wins ties, max_t is the largest of the classes' values; then [en1, en0) one by one
-            const i32 pe = en0 & ( RING - 1 );
-            u32 hreg = H[ 0 ];
+            if( newMax )
+            {
+                // (the z-drop branch cannot be taken on a raise)
+                ez.max = (u32)wave_max_i32( max( (i32)( hm << 16 ) >> 16, (i32)hm >> 16 ) ) & 0x7fffffffu;
 #pragma unroll
-            for( int s = 1; s < R; s++ )
-                if( ( pe >> 7 ) == s )
-                    hreg = H[ s ];
-            const i32 hEn0 = (i32)( (u32)lane_bcast( (i32)hreg, ( pe & 127 ) >> 1 ) << ( pe & 1 ? 0 : 16 ) ) >> 16;
-            const i32 nS = ( ( en0 - st0 ) / 8 ) * 8; // cells of the 8-lane part
-            i32 kLo = (i32)0x80000000, kHi = (i32)0x80000000;
-#pragma unroll
-            for( int s = 0; s < R; s++ )
-            {
-                const u32 inv = pk_sub( 0xffffffffu, DD[ s ] ); // 0xffff - (t - st0): earlier chunks win ties
-                const i32 lo = (i32)__builtin_amdgcn_perm( H[ s ], inv, 0x05040100u );
-                const i32 hi = (i32)__builtin_amdgcn_perm( H[ s ], inv, 0x07060302u );
-                if( ( DD[ s ] & 0xffffu ) < (u32)nS )
-                    kLo = max( kLo, lo );
-                if( ( DD[ s ] >> 16 ) < (u32)nS )
-                    kHi = max( kHi, hi );
+                for( int s = 0; s < R; s++ )
+                    snap[ s * 64 + lane ] = make_uint2( H[ s ], DD[ s ] );
+                pend = true, pSt0 = st0, pEn0 = en0, pR = r;
             }
-            // lanes with equal (lane mod 4) hold the same two classes
-            kLo = max( kLo, dpp_ctrl<0x124>( kLo ) );
-            kHi = max( kHi, dpp_ctrl<0x124>( kHi ) );
-            kLo = max( kLo, dpp_ctrl<0x128>( kLo ) );
-            kHi = max( kHi, dpp_ctrl<0x128>( kHi ) );
+            else
             {
-                auto a16 = __builtin_amdgcn_permlane16_swap( (u32)kLo, (u32)kLo, false, false );
-                kLo = max( (i32)a16[ 0 ], (i32)a16[ 1 ] );
-                auto b16 = __builtin_amdgcn_permlane16_swap( (u32)kHi, (u32)kHi, false, false );
-                kHi = max( (i32)b16[ 0 ], (i32)b16[ 1 ] );
-                auto a32 = __builtin_amdgcn_permlane32_swap( (u32)kLo, (u32)kLo, false, false );
-                kLo = max( (i32)a32[ 0 ], (i32)a32[ 1 ] );
-                auto b32 = __builtin_amdgcn_permlane32_swap( (u32)kHi, (u32)kHi, false, false );
-                kHi = max( (i32)b32[ 0 ], (i32)b32[ 1 ] );
-            }
-            i32 mH = hEn0, mT = en0;
-            if( nS > 0 )
-            {
-                const i32 hl = kLo >> 16, hh = kHi >> 16;
-                const i32 tl = hl > hEn0 ? st0 + ( ( 0xffff - ( kLo & 0xffff ) ) & ~7 ) : en0;
-                const i32 th = hh > hEn0 ? st0 + ( ( 0xffff - ( kHi & 0xffff ) ) & ~7 ) : en0;
-                i32 vh = max( max( hl, hh ), hEn0 ), vt = max( tl, th );
-                vh = max( vh, dpp_ctrl<0xB1>( vh ) ); // the four lanes of a quad hold the eight classes
-                vt = max( vt, dpp_ctrl<0xB1>( vt ) );
-                vh = max( vh, dpp_ctrl<0x4E>( vh ) );
-                vt = max( vt, dpp_ctrl<0x4E>( vt ) );
-                mH = __builtin_amdgcn_readfirstlane( vh );
-                mT = __builtin_amdgcn_readfirstlane( vt );
-            }
-            for( i32 t = st0 + nS; t < en0; ++t )
-            {
-                const i32 p = t & ( RING - 1 );
-                u32 hr = H[ 0 ];
-#pragma unroll
-                for( int s = 1; s < R; s++ )
-                    if( ( p >> 7 ) == s )
-                        hr = H[ s ];
-                const i32 h = (i32)( (u32)lane_bcast( (i32)hr, ( p & 127 ) >> 1 ) << ( p & 1 ? 0 : 16 ) ) >> 16;
-                if( h > mH )
-                    mH = h, mT = t;
-            }
-            // ksw_apply_zdrop (kswcpp_core.h:22-44), is_rot = 1; mH == max_H
-            if( mH > (i32)ez.max )
-            {
-                ez.max = (u32)mH & 0x7fffffffu;
-                ez.max_t = mT;
-                ez.max_q = r - mT;
-            }
-            else if( mT >= ez.max_t && r - mT >= ez.max_q )
-            {
-                const i32 tl = mT - ez.max_t, ql = ( r - mT ) - ez.max_q;
-                const i32 l = tl > ql ? tl - ql : ql - tl;
-                if( J.zdrop >= 0 && (i32)( ez.max - (u32)mH ) > J.zdrop + l * e2 )
+                i32 mH, mT;
+                exactMax( H, DD, st0, en0, mH, mT );
+                resolvePending( );
+                // ksw_apply_zdrop (kswcpp_core.h:22-44), is_rot = 1; mH == max_H
+                if( mH > (i32)ez.max )
                 {
-                    ez.zdropped = 1;
-                    stop = true;
+                    ez.max = (u32)mH & 0x7fffffffu;
+                    ez.max_t = mT;
+                    ez.max_q = r - mT;
+                }
+                else if( mT >= ez.max_t && r - mT >= ez.max_q )
+                {
+                    const i32 tl = mT - ez.max_t, ql = ( r - mT ) - ez.max_q;
+                    const i32 l = tl > ql ? tl - ql : ql - tl;
+                    if( J.zdrop >= 0 && (i32)( ez.max - (u32)mH ) > J.zdrop + l * e2 )
+                    {
+                        ez.zdropped = 1;
+                        stop = true;
+                    }
                 }
             }
         }
@@ -650,6 +689,8 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
 #if defined( MA_KSW_PROF )
     const unsigned long long tp1 = clock64( );
 #endif
+    if( !GLOBAL )
+        resolvePending( );
     __syncthreads( ); // direction bytes visible to the back-trace
     if( !GLOBAL && ( ez.max_t < 0 || ez.max_q < 0 ) )
         return true;

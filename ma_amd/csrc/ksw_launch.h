@@ -207,6 +207,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( R 
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
     __shared__ u32 sSlot;
     __shared__ unsigned long long sOff;
+    __shared__ uint2 sSnap[ 64 * R ]; // the lanes' H of the diagonal that raised ez.max last (ksw_ext.h)
     uint8_t* my = scratch + (u64)blockIdx.x * stride;
     u32* cig = (u32*)( my + p_cap );
 #if defined( MA_KSW_PROF )
@@ -232,14 +233,14 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( R 
         if( !( J.flag & KSW_EZ_EXTZ_ONLY ) )
         {
             if( J.flag & KSW_EZ_RIGHT )
-                ok = ksw_ext_core<R, false, true>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path KSW_PROF_ARG );
+                ok = ksw_ext_core<R, false, true>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path, sSnap KSW_PROF_ARG );
             else
-                ok = ksw_ext_core<R, true, true>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path KSW_PROF_ARG );
+                ok = ksw_ext_core<R, true, true>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path, sSnap KSW_PROF_ARG );
         }
         else if( J.flag & KSW_EZ_RIGHT )
-            ok = ksw_ext_core<R, false, false>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path KSW_PROF_ARG );
+            ok = ksw_ext_core<R, false, false>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path, sSnap KSW_PROF_ARG );
         else
-            ok = ksw_ext_core<R, true, false>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path KSW_PROF_ARG );
+            ok = ksw_ext_core<R, true, false>( SC, J, qf, tf, (uint8_t*)lds, ldsBytes, my, cig, ez, nCig, cells, path, sSnap KSW_PROF_ARG );
         if( !ok )
         {
             if( threadIdx.x == 0 )

@@ -530,7 +530,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                     }
             }
             hEnd = hEn0;
-            hS = st0 == en0 ? hEn0 : pickCell( Hlo, Hhi, st0 );
+            hS = r - st0 != qlen - 1 ? 0 : st0 == en0 ? hEn0 : pickCell( Hlo, Hhi, st0 ); // only read on the last query row (mqe below)
             // The exact (max_H, max_t) -- the class-wise first maxima of the SSE code, ~240 instructions -- is only consumed when
             // the diagonal raises ez.max or could z-drop (ksw_reg.h).  A diagonal that RAISES ez.max (every other one while
             // an alignment runs: 17 % of the 10 kb DP stage) needs only the value right away, max( H[en0], the lanes' maxima );
