@@ -216,6 +216,16 @@ MA_HD NwWindow nw_window( const IndexView& X, const NwParams& P, const ma_seed* 
     return W;
 }
 
+// SINK::WAVE (device only): ONE alignment per wavefront -- all lanes walk the seeds and cigars in step (the same loads, the
+// same appends), and the base comparisons of an M run, the bulk of a long read's walk, are spread over the lanes (match_run)
+template <typename S, typename = void> struct sink_is_wave
+{
+    static const bool value = false;
+};
+template <typename S> struct sink_is_wave<S, decltype( (void)S::WAVE )>
+{
+    static const bool value = S::WAVE;
+};
 template <typename SINK> struct NwWalk
 {
     const IndexView& X;
@@ -240,6 +250,34 @@ template <typename SINK> struct NwWalk
     // 8-byte window and the reference through the pac byte that holds four bases (50 kb reads: this loop was most of k_stitch).
     MA_HD void match_run( u64 qPos, u64 rPos, u32 amount )
     {
+#if defined( __HIP_DEVICE_COMPILE__ )
+        if( sink_is_wave<SINK>::value )
+        {
+            // 64 bases per trip: one coalesced load of the read and of the packed reference, the mismatches as a ballot, the
+            // runs of equal bits appended one by one (appends of equal neighbours merge: the entries of the serial loop)
+            const u32 lane = threadIdx.x & 63;
+            for( u32 k0 = 0; k0 < amount; k0 += 64 )
+            {
+                const u32 k = k0 + lane, nv = amount - k0 < 64u ? amount - k0 : 64u;
+                bool miss = false;
+                if( k < amount )
+                    miss = qb( qPos + k ) != rb( rPos + k );
+                const unsigned long long mm = __ballot( miss );
+                u32 pos = 0;
+                while( pos < nv )
+                {
+                    const u32 bit = (u32)( mm >> pos ) & 1u;
+                    const unsigned long long other = ( bit ? ~mm : mm ) >> pos; // set where the type changes
+                    u32 len = other ? (u32)__builtin_ctzll( other ) : 64u - pos;
+                    if( len > nv - pos )
+                        len = nv - pos;
+                    aln_append( P, A, bit ? MT_MISS : MT_MATCH, len );
+                    pos += len;
+                }
+            }
+            return;
+        }
+#endif
         u32 curType = MT_MATCH;
         u64 curLen = 0;
         uintptr_t qWordAt = ~(uintptr_t)0;
@@ -444,13 +482,15 @@ template <typename SINK> struct NwWalk
             gapPen += kq + ke * qPosRight - qPos; // (sic) operator precedence, needlemanWunsch.cpp:413-416
         if( rPosRight - rPos > 0 )
             gapPen += kq + ke * rPosRight - rPos;
-        if( mmPen < gapPen )
-            while( qPos < qPosRight && rPos < rPosRight )
-            {
-                app( qb( qPos ) == rb( rPos ) ? MT_MATCH : MT_MISS, 1 );
-                qPos++;
-                rPos++;
-            }
+        if( mmPen < gapPen && qPos < qPosRight && rPos < rPosRight )
+        {
+            // base by base in the reference (needlemanWunsch.cpp:420-427); as runs the entries are the same
+            const u64 m = mmin( qPosRight - qPos, rPosRight - rPos );
+            if( SINK::STITCH )
+                match_run( qPos, rPos, (u32)m );
+            qPos += m;
+            rPos += m;
+        }
         app( MT_INS, qPosRight - qPos );
         app( MT_DEL, rPosRight - rPos );
         if( lastType == MT_MATCH )

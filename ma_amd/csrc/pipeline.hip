@@ -1034,6 +1034,7 @@ struct DpKernelArgs
     u64 list_stride;
     KswScoring SC;
     u32 lanes; // sets per wavefront (lanes_per_wave)
+    u32 wave_split; // long reads: sets that span >= 1024 query bases go to k_stitch_wave
 };
 
 #if defined( __HIPCC__ )
@@ -1322,14 +1323,28 @@ struct StitchKernelArgs
     AlnHeader* hdr;
     unsigned long long* ctr;
     u32 lanes; // sets per wavefront (lanes_per_wave)
+    u32 wave_split; // long reads: sets that span >= 1024 query bases go to k_stitch_wave
 };
 
-__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 ) ) ) k_stitch( StitchKernelArgs A )
+struct StitchSinkWave : StitchSink
 {
-    const u32 s = blockIdx.x * A.lanes + threadIdx.x;
-    u64 nOps = 0;
-    if( threadIdx.x < A.lanes && s < A.n_sets )
-    {
+    static const bool WAVE = true;
+};
+// Sets whose walk is long enough to be worth a wavefront of their own (k_stitch_wave): the seeds span >= 1024 query bases.
+// (A batch of 20 k reads of 50 kb has 2 * 10^5 sets; the ~10 % that span the read are ~all of the bases to compare, and as
+// lanes of the one-set-per-lane kernel each of them kept its wavefront busy for its whole length: 69 ms.)
+__device__ __forceinline__ bool stitch_is_big( const StitchKernelArgs& A, u32 s )
+{
+    if( !A.wave_split )
+        return false;
+    const HSet hs = A.sets[ s ];
+    if( hs.cnt == 0 || !A.info[ s ].valid )
+        return false;
+    const ma_seed first = A.hpool[ hs.off ], last = A.hpool[ hs.off + hs.cnt - 1 ];
+    return (u64)last.q_start + (u64)last.len >= (u64)first.q_start + 1024;
+}
+template <typename SINK> __device__ __forceinline__ u64 stitch_set( const StitchKernelArgs& A, u32 s )
+{
     const HSet hs = A.sets[ s ];
     const u32 rd = A.set_read[ s ];
     const SetInfo I = A.info[ s ];
@@ -1352,20 +1367,39 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 
         W.begin_ref = I.win_begin;
         W.end_ref = I.win_end;
         W.valid = true;
-        StitchSink sink{ A.ez + 2 * hs.off, A.cig_off + 2 * hs.off, A.cig_pool, 0 };
-        NwWalk<StitchSink> walk{ A.X, A.P, sink, A.reads + A.roff[ rd ], I.win_begin,
-                                 AlnBuilder{ &h, A.ops + h.ops_off, &err } };
+        SINK sink;
+        sink.ez = A.ez + 2 * hs.off, sink.cig_off = A.cig_off + 2 * hs.off, sink.cig_pool = A.cig_pool, sink.k = 0;
+        NwWalk<SINK> walk{ A.X, A.P, sink, A.reads + A.roff[ rd ], I.win_begin, AlnBuilder{ &h, A.ops + h.ops_off, &err } };
         walk.run( A.hpool + hs.off, hs.cnt, A.roff[ rd + 1 ] - A.roff[ rd ], W );
     }
-    A.hdr[ s ] = h;
-    if( err )
-        atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
-    nOps = h.n_ops;
+    if( !sink_is_wave<SINK>::value || ( threadIdx.x & 63 ) == 0 )
+    {
+        A.hdr[ s ] = h;
+        if( err )
+            atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
     }
+    return h.n_ops;
+}
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 ) ) ) k_stitch( StitchKernelArgs A )
+{
+    const u32 s = blockIdx.x * A.lanes + threadIdx.x;
+    u64 nOps = 0;
+    if( threadIdx.x < A.lanes && s < A.n_sets && !stitch_is_big( A, s ) )
+        nOps = stitch_set<StitchSink>( A, s );
     // exact size of the ops download (all alignments): one atomic per wave
     const u64 total = wave_sum_u64( nOps );
     if( ( threadIdx.x & 63 ) == 0 && total )
         atomicAdd( &A.ctr[ CTR_OPS_ALL ], (unsigned long long)total );
+}
+// one set per wavefront: the sets k_stitch left out
+__global__ void __launch_bounds__( 64 ) k_stitch_wave( StitchKernelArgs A )
+{
+    const u32 s = blockIdx.x;
+    if( !stitch_is_big( A, s ) )
+        return;
+    const u64 nOps = stitch_set<StitchSinkWave>( A, s );
+    if( threadIdx.x == 0 && nOps )
+        atomicAdd( &A.ctr[ CTR_OPS_ALL ], (unsigned long long)nOps );
 }
 
 // per read: NeedlemanWunsch::execute's final sort + MappingQuality::execute
@@ -2503,7 +2537,12 @@ int ma_dp_batch( ma_batch* b )
         T.hdr = b->hdr.as<AlnHeader>( );
         T.ctr = b->ctr.as<unsigned long long>( );
         T.lanes = lanes_per_wave( nh );
+        T.wave_split = b->max_qlen >= 1024 ? 1 : 0;
+        if( const char* e = getenv( "MA_STITCH_WAVE" ) ) // A/B + test hook
+            T.wave_split = T.wave_split && atoi( e ) != 0 ? 1 : 0;
         hipLaunchKernelGGL( k_stitch, dim3( (unsigned)( ( nh + T.lanes - 1 ) / T.lanes ) ), dim3( 64 ), 0, b->stream, T );
+        if( T.wave_split )
+            hipLaunchKernelGGL( k_stitch_wave, dim3( (unsigned)nh ), dim3( 64 ), 0, b->stream, T );
         hipLaunchKernelGGL( k_finish, dim3( (unsigned)( ( n + 63 ) / 64 ) ), dim3( 64 ), 0, b->stream, NP, (u32)n,
                             b->hsetOff.as<u64>( ), b->d_roff, b->hdr.as<AlnHeader>( ), b->ops.as<u64>( ),
                             b->order.as<u32>( ), b->mqOrder.as<u32>( ), b->mqCnt.as<u32>( ),

@@ -184,12 +184,13 @@ def test_bench_four_ranks_long_reads_both_scaling_modes(gpu_device):
 
 
 @pytest.mark.parametrize("env", [{"MA_CHAIN_WAVE_SORT": "0"}, {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "60"}, {"MA_WSORT_MIN": "100"},
-                                 {"MA_DP_ONE_STREAM": "1"}, {"MA_KSW_SCRATCH_MB": "64"}])
+                                 {"MA_DP_ONE_STREAM": "1"}, {"MA_KSW_SCRATCH_MB": "64"}, {"MA_STITCH_WAVE": "0"}])
 def test_long_read_stage_variants_give_identical_results(gpu_device, monkeypatch, env):
     """Round-3 variants of the long-read stages forced through their hooks on one read set with repeats (many equal deltas
     and reference positions = ties in the sweep's sorts): the sweep's sorts inside the lane kernels / as wave-cooperative
     kernels with both launch sizes exercised (thresholds moved down to test-sized reads), the DP classes on one stream / on
-    their own streams, a tiny DP scratch budget (every class split into tiers).  Every stage record equals the default's."""
+    their own streams, a tiny DP scratch budget (every class split into tiers), the walk of the long alignments by one lane
+    each instead of one wavefront each.  Every stage record equals the default's."""
     import ma_amd
     g = rand_genome(53, [900000, 400000], repeat_unit=250, repeat_copies=120, repeat_div=0.04)
     reads = (sample_reads(g, 40, 6000, 91, sub=0.01, ins=0.005, dele=0.005) + sample_reads(g, 6, 20000, 92, sub=0.03, ins=0.03, dele=0.04)
