@@ -6,6 +6,7 @@
 // removeDangeling / larger / overlap and MappingQuality::execute follow alignment.cpp:10-98,240-296,
 // alignment.h:659-735,819-845 and mappingQuality.cpp:11-131.
 #pragma once
+#include <type_traits>
 #include "fm_device.h"
 #include "stdsort.h"
 
@@ -72,7 +73,16 @@ struct AlnBuilder
     AlnHeader* h;
     u64* ops; // this alignment's region
     u32* err;
+    // the LAST entry (ops[ n_ops - 1 ]) lives here until another one follows it or aln_flush is called: every append looks at
+    // it and most appends change it, and as a read-modify-write of global memory that was a memory round trip per append in
+    // the middle of the walk's dependency chain
+    u64 last = 0;
 };
+MA_HD void aln_flush( AlnBuilder& A )
+{
+    if( A.h->n_ops != 0 )
+        A.ops[ A.h->n_ops - 1 ] = A.last;
+}
 
 MA_HD u64 indel_cost( const NwParams& P, u64 len )
 {
@@ -104,27 +114,31 @@ MA_HD void aln_append( const NwParams& P, AlnBuilder& A, u32 type, u64 size )
             h.end_q += size;
         else
             h.end_ref += size;
-        if( h.n_ops != 0 && op_type( A.ops[ h.n_ops - 1 ] ) == type )
+        if( h.n_ops != 0 && op_type( A.last ) == type )
         {
-            const u64 prev = op_len( A.ops[ h.n_ops - 1 ] );
+            // the reference takes the entry off, adds its length to the new one and puts that back (the entry before it is of
+            // another type: equal neighbours never exist): same thing in place
+            const u64 prev = op_len( A.last );
             size += prev;
-            h.length -= prev;
             h.score += (i64)indel_cost( P, prev );
-            h.n_ops--;
+            h.score -= (i64)indel_cost( P, size );
+            A.last = op_pack( type, size );
+            h.length += size - prev;
+            return;
         }
         h.score -= (i64)indel_cost( P, size );
     }
-    if( h.n_ops != 0 && op_type( A.ops[ h.n_ops - 1 ] ) == type )
-        A.ops[ h.n_ops - 1 ] = op_pack( type, op_len( A.ops[ h.n_ops - 1 ] ) + size );
-    else
+    if( h.n_ops != 0 && op_type( A.last ) == type )
+        A.last = op_pack( type, op_len( A.last ) + size );
+    else if( h.n_ops < h.ops_cap )
     {
-        if( h.n_ops < h.ops_cap )
-            A.ops[ h.n_ops ] = op_pack( type, size );
-        else
-            *A.err |= MA_ERR_OPS_OVERFLOW;
-        if( h.n_ops < h.ops_cap )
-            h.n_ops++;
+        if( h.n_ops != 0 )
+            A.ops[ h.n_ops - 1 ] = A.last;
+        A.last = op_pack( type, size );
+        h.n_ops++;
     }
+    else
+        *A.err |= MA_ERR_OPS_OVERFLOW;
     h.length += size;
 }
 
@@ -167,6 +181,16 @@ struct KswResult
     i32 max_q, max_t;
     const u32* cigar;
     u32 n_cigar;
+    // the one-alignment-per-wavefront kernel hands over the first four entries with the result (most gap fills of a long read
+    // have one to three): read with the job record, 64 jobs at a time, instead of in a memory round trip of their own
+    u32 first[ 4 ];
+    bool cached = false;
+    MA_HD u32 at( u32 i ) const
+    {
+        if( cached && i < 4 )
+            return i < 2 ? ( i == 0 ? first[ 0 ] : first[ 1 ] ) : ( i == 2 ? first[ 2 ] : first[ 3 ] );
+        return cigar[ i ];
+    }
 };
 
 // ---- the walk ---------------------------------------------------------------------------------
@@ -259,6 +283,8 @@ template <typename SINK> struct NwWalk
             for( u32 k0 = 0; k0 < amount; k0 += 64 )
             {
                 const u32 k = k0 + lane, nv = amount - k0 < 64u ? amount - k0 : 64u;
+                // (the bases out of 1 KB windows of the read and the reference in LDS instead of these two loads: measured, slower
+                // -- 34 -> 42 ms for 20 k alignments of 50 kb: the kernel is bound by the instructions of the walk, not by these loads)
                 bool miss = false;
                 if( k < amount )
                     miss = qb( qPos + k ) != rb( rPos + k );
@@ -346,7 +372,7 @@ template <typename SINK> struct NwWalk
         u64 qPos = fromQ, rPos = fromR;
         for( u32 i = 0; i < R.n_cigar; i++ )
         {
-            const u32 sym = R.cigar[ i ] & 0xf, amount = R.cigar[ i ] >> 4;
+            const u32 sym = R.at( i ) & 0xf, amount = R.at( i ) >> 4;
             if( sym == 0 )
             {
                 match_run( qPos, rPos, amount );
@@ -388,8 +414,8 @@ template <typename SINK> struct NwWalk
         if( rPos != rCenter && qPos != qCenter )
             for( u32 i = 0; i < Lz.n_cigar; ++i )
             {
-                const u32 sym = Lz.cigar[ i ] & 0xf;
-                u32 amount = Lz.cigar[ i ] >> 4;
+                const u32 sym = Lz.at( i ) & 0xf;
+                u32 amount = Lz.at( i ) >> 4;
                 if( sym == 0 )
                 {
                     if( qPos + amount > qCenter )
@@ -428,8 +454,8 @@ template <typename SINK> struct NwWalk
         {
             if( rPosRight >= rCenter && qPosRight >= qCenter )
                 break;
-            const u32 sym = Rz.cigar[ i ] & 0xf;
-            u32 amount = Rz.cigar[ i ] >> 4;
+            const u32 sym = Rz.at( i ) & 0xf;
+            u32 amount = Rz.at( i ) >> 4;
             if( sym == 0 )
             {
                 if( rPosRight + amount >= rCenter && qPosRight + amount >= qCenter )
@@ -508,7 +534,7 @@ template <typename SINK> struct NwWalk
             rPosRight += notUnrolled;
         for( ; i < Rz.n_cigar; ++i )
         {
-            const u32 sym = Rz.cigar[ i ] & 0xf, amount = Rz.cigar[ i ] >> 4;
+            const u32 sym = Rz.at( i ) & 0xf, amount = Rz.at( i ) >> 4;
             if( sym == 0 )
             {
                 match_run( qPosRight, rPosRight, amount );
@@ -568,7 +594,7 @@ template <typename SINK> struct NwWalk
         }
         for( u32 i = 0; i < R.n_cigar; i++ )
         {
-            const u32 sym = R.cigar[ i ] & 0xf, amount = R.cigar[ i ] >> 4;
+            const u32 sym = R.at( i ) & 0xf, amount = R.at( i ) >> 4;
             if( sym == 0 )
             {
                 match_run( qPos, rPos, amount );
@@ -597,17 +623,29 @@ template <typename SINK> struct NwWalk
     }
 
     // NeedlemanWunsch::execute_one (needlemanWunsch.cpp:625-877) after the window was fixed
+    // seed k of the set: (q_start, r_start, len)
+    template <typename T = SINK> MA_HD typename std::enable_if<sink_is_wave<T>::value>::type sd( const ma_seed* S, u32 n, u32 k, u64& q, u64& r, u64& l )
+    {
+        sink.seed( S, n, k, q, r, l );
+    }
+    template <typename T = SINK> MA_HD typename std::enable_if<!sink_is_wave<T>::value>::type sd( const ma_seed* S, u32, u32 k, u64& q, u64& r, u64& l )
+    {
+        q = (u64)S[ k ].q_start, r = (u64)S[ k ].r_start, l = (u64)S[ k ].len;
+    }
     MA_HD void run( const ma_seed* S, u32 n, u64 qlen, const NwWindow& W )
     {
         qLenTotal = qlen;
         const u64 beginRef = W.begin_ref, endRef = W.end_ref;
-        dyn_prg( 0, (u64)S[ 0 ].q_start, 0, (u64)S[ 0 ].r_start - beginRef, true, false );
-        u64 endLastQ = (u64)S[ 0 ].q_start + (u64)S[ 0 ].len;
-        u64 endLastR = (u64)S[ 0 ].r_start + (u64)S[ 0 ].len - beginRef;
-        app( MT_SEED, (u64)S[ 0 ].len );
+        u64 q0, r0, l0;
+        sd( S, n, 0, q0, r0, l0 );
+        dyn_prg( 0, q0, 0, r0 - beginRef, true, false );
+        u64 endLastQ = q0 + l0;
+        u64 endLastR = r0 + l0 - beginRef;
+        app( MT_SEED, l0 );
         for( u32 k = 1; k < n; k++ )
         {
-            const u64 sq = (u64)S[ k ].q_start, sr = (u64)S[ k ].r_start, sl = (u64)S[ k ].len;
+            u64 sq, sr, sl;
+            sd( S, n, k, sq, sr, sl );
             if( sl == 0 )
                 continue;
             u64 ovQ = endLastQ - sq;
@@ -634,6 +672,7 @@ template <typename SINK> struct NwWalk
         dyn_prg( endLastQ, qlen - 1, endLastR, endRef - beginRef - 1, false, true );
         if( SINK::STITCH )
         {
+            aln_flush( A );
             const u32 front = aln_remove_dangling( P, A );
             if( front > 0 )
             {

@@ -1326,9 +1326,75 @@ struct StitchKernelArgs
     u32 wave_split; // long reads: sets that span >= 1024 query bases go to k_stitch_wave
 };
 
+// what k_stitch_wave keeps in LDS of the set it walks: the next 64 seeds and the records of the next 64 jobs (with the first
+// four cigar entries of each), loaded by the 64 lanes at once -- step by step each of them is a memory round trip that all
+// lanes wait for (a 50 kb alignment: ~5 k seeds and ~5 k gap fills)
+struct StitchWaveCache
+{
+    u64 sq[ 64 ], sr[ 64 ], sl[ 64 ];
+    i32 jq[ 64 ], jt[ 64 ];
+    u32 jn[ 64 ];
+    u64 joff[ 64 ];
+    uint4 jc[ 64 ];
+};
 struct StitchSinkWave : StitchSink
 {
     static const bool WAVE = true;
+    StitchWaveCache* C;
+    u32 seedBase = 0x80000000u, jobBase = 0x80000000u, nJobs = 0;
+    __device__ void seed( const ma_seed* S, u32 n, u32 kk, u64& q, u64& r, u64& l )
+    {
+        if( kk - seedBase >= 64u )
+        {
+            const u32 lane = threadIdx.x & 63, i = kk + lane;
+            __syncthreads( );
+            if( i < n )
+            {
+                const ma_seed x = S[ i ];
+                C->sq[ lane ] = (u64)x.q_start, C->sr[ lane ] = (u64)x.r_start, C->sl[ lane ] = (u64)x.len;
+            }
+            seedBase = kk;
+            __syncthreads( );
+        }
+        const u32 d = kk - seedBase;
+        q = C->sq[ d ], r = C->sr[ d ], l = C->sl[ d ];
+    }
+    __device__ KswResult next( )
+    {
+        if( k - jobBase >= 64u )
+        {
+            const u32 lane = threadIdx.x & 63, i = k + lane;
+            __syncthreads( );
+            if( i < nJobs )
+            {
+                const ma_ez e = ez[ i ];
+                const u64 off = cig_off[ i ];
+                C->jq[ lane ] = e.max_q, C->jt[ lane ] = e.max_t, C->jn[ lane ] = (u32)e.n_cigar, C->joff[ lane ] = off;
+                uint4 c = make_uint4( 0, 0, 0, 0 );
+                const u32* p = cig_pool + off;
+                if( e.n_cigar > 0 )
+                    c.x = p[ 0 ];
+                if( e.n_cigar > 1 )
+                    c.y = p[ 1 ];
+                if( e.n_cigar > 2 )
+                    c.z = p[ 2 ];
+                if( e.n_cigar > 3 )
+                    c.w = p[ 3 ];
+                C->jc[ lane ] = c;
+            }
+            jobBase = k;
+            __syncthreads( );
+        }
+        const u32 d = k - jobBase;
+        KswResult R;
+        R.max_q = C->jq[ d ], R.max_t = C->jt[ d ], R.n_cigar = C->jn[ d ];
+        R.cigar = cig_pool + C->joff[ d ];
+        const uint4 c = C->jc[ d ];
+        R.first[ 0 ] = c.x, R.first[ 1 ] = c.y, R.first[ 2 ] = c.z, R.first[ 3 ] = c.w;
+        R.cached = true;
+        k++;
+        return R;
+    }
 };
 // Sets whose walk is long enough to be worth a wavefront of their own (k_stitch_wave): the seeds span >= 1024 query bases.
 // (A batch of 20 k reads of 50 kb has 2 * 10^5 sets; the ~10 % that span the read are ~all of the bases to compare, and as
@@ -1343,7 +1409,14 @@ __device__ __forceinline__ bool stitch_is_big( const StitchKernelArgs& A, u32 s 
     const ma_seed first = A.hpool[ hs.off ], last = A.hpool[ hs.off + hs.cnt - 1 ];
     return (u64)last.q_start + (u64)last.len >= (u64)first.q_start + 1024;
 }
-template <typename SINK> __device__ __forceinline__ u64 stitch_set( const StitchKernelArgs& A, u32 s )
+__device__ __forceinline__ void stitch_sink_setup( StitchSink&, const SetInfo&, StitchWaveCache* )
+{}
+__device__ __forceinline__ void stitch_sink_setup( StitchSinkWave& sink, const SetInfo& I, StitchWaveCache* cache )
+{
+    sink.C = cache;
+    sink.nJobs = I.n_jobs;
+}
+template <typename SINK> __device__ __forceinline__ u64 stitch_set( const StitchKernelArgs& A, u32 s, StitchWaveCache* cache )
 {
     const HSet hs = A.sets[ s ];
     const u32 rd = A.set_read[ s ];
@@ -1369,6 +1442,7 @@ template <typename SINK> __device__ __forceinline__ u64 stitch_set( const Stitch
         W.valid = true;
         SINK sink;
         sink.ez = A.ez + 2 * hs.off, sink.cig_off = A.cig_off + 2 * hs.off, sink.cig_pool = A.cig_pool, sink.k = 0;
+        stitch_sink_setup( sink, I, cache );
         NwWalk<SINK> walk{ A.X, A.P, sink, A.reads + A.roff[ rd ], I.win_begin, AlnBuilder{ &h, A.ops + h.ops_off, &err } };
         walk.run( A.hpool + hs.off, hs.cnt, A.roff[ rd + 1 ] - A.roff[ rd ], W );
     }
@@ -1385,7 +1459,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 
     const u32 s = blockIdx.x * A.lanes + threadIdx.x;
     u64 nOps = 0;
     if( threadIdx.x < A.lanes && s < A.n_sets && !stitch_is_big( A, s ) )
-        nOps = stitch_set<StitchSink>( A, s );
+        nOps = stitch_set<StitchSink>( A, s, nullptr );
     // exact size of the ops download (all alignments): one atomic per wave
     const u64 total = wave_sum_u64( nOps );
     if( ( threadIdx.x & 63 ) == 0 && total )
@@ -1397,7 +1471,8 @@ __global__ void __launch_bounds__( 64 ) k_stitch_wave( StitchKernelArgs A )
     const u32 s = blockIdx.x;
     if( !stitch_is_big( A, s ) )
         return;
-    const u64 nOps = stitch_set<StitchSinkWave>( A, s );
+    __shared__ StitchWaveCache cache;
+    const u64 nOps = stitch_set<StitchSinkWave>( A, s, &cache );
     if( threadIdx.x == 0 && nOps )
         atomicAdd( &A.ctr[ CTR_OPS_ALL ], (unsigned long long)nOps );
 }
