@@ -259,6 +259,13 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     // consecutive diagonals out of 16, and only once the band has reached the last target column (before that a cell on
     // the alignment's diagonal always has room left) -- because it costs about as much as 0.15 diagonals.
     const bool early = EARLY && ( J.flag & KSW_EZ_EXTZ_ONLY );
+    // Global jobs of the pipeline (NeedlemanWunsch::ksw, needlemanWunsch.cpp:82-169: the gap fills between seeds): the caller
+    // reads the cigar traced back from the corner and nothing else, so neither the running H of the cells nor any ez field is
+    // needed -- as long as the band cannot run out before the corner (|tlen - qlen| + 2 <= w, checked against the bounds
+    // below for all r; the caller's w is |tlen - qlen| + 10 at least) and no z-drop is asked for.  Per diagonal that is the
+    // H arithmetic of every slot, the pick of H[en0] and the maximum tests: a quarter of the instructions of a one-slot job.
+    const bool noH = EARLY && !( J.flag & KSW_EZ_EXTZ_ONLY ) && J.zdrop < 0 && ( tlen > qlen ? tlen - qlen : qlen - tlen ) + 2 <= w;
+    const int noHU = __builtin_amdgcn_readfirstlane( noH ? 1 : 0 );
     const bool earlySparse = qlen > w + 1;
     const i32 earlyFrom = earlySparse ? w + 3 : qlen; // first diagonal at which B_r and B_{r-1} cover every in-band chain
     i32 topH = 0, boundPrev = 0x7fffffff; // H(r-1,-1) of the first-row boundary; B_{r-1} (ksw_reg.h)
@@ -452,7 +459,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             // (cells of [st0, en0] lie inside [st, en], so nu / nv are the committed values there).  Only the running H
             // of the cells in [st0, en0) is advanced here; H[en0] and H[st0] belong to ONE lane of ONE slot each and
             // are picked out of the registers after the loop with wave-uniform lane reads.
-            if( r > 0 )
+            if( r > 0 && !noHU )
             {
                 const i32 vlo = pk_lo8( nv ), vhi = pk_hi8( nv );
                 if( tt >= st0 && tt < en0 )
@@ -469,9 +476,11 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             // keep the slots' instruction streams apart: interleaving them multiplies the live temporaries by R
             __builtin_amdgcn_sched_barrier( 0 );
         }
-        i32 max_H, max_t, hEnd, hS;
+        i32 max_H = (i32)0x80000000, max_t = 0, hEnd = 0, hS = 0;
         bool raised = false;
-        if( r > 0 )
+        if( noHU )
+            ;
+        else if( r > 0 )
         {
             // H[en0] = en0 > 0 ? Hold[en0-1] + u[en0] : Hold[en0] + v[en0].  Cell en0 - 1 was advanced above when it
             // lies in [st0, en0): its old value is the new one minus this diagonal's v (16-bit wrap-around is a ring
@@ -569,12 +578,14 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             hEnd = h0;
             hS = h0;
         }
-        if( en0 == tlen - 1 && hEnd > ez.mte )
+        if( noHU )
+            ;
+        else if( en0 == tlen - 1 && hEnd > ez.mte )
             ez.mte = hEnd, ez.mte_q = r - en;
-        if( r - st0 == qlen - 1 && hS > ez.mqe )
+        if( !noHU && r - st0 == qlen - 1 && hS > ez.mqe )
             ez.mqe = hS, ez.mqe_t = st0;
         // ksw_apply_zdrop (kswcpp_core.h:22-44), is_rot = 1
-        if( raised )
+        if( raised || noHU )
             ; // ez.max is up to date, (max_t, max_q) pending
         else if( max_H > (i32)ez.max )
         {
@@ -592,7 +603,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                 stop = true;
             }
         }
-        if( !stop && r == qlen + tlen - 2 && en0 == tlen - 1 )
+        if( !noHU && !stop && r == qlen + tlen - 2 && en0 == tlen - 1 )
             ez.score = hEnd;
         if( EARLY && early && r >= earlyFrom - 1 && ( earlySparse ? en0 == tlen - 1 && ( r & 15 ) <= 1 : ( r & 7 ) <= 1 ) )
         {
