@@ -204,8 +204,27 @@ MA_HD void soc_sum( const ma_seed* s, u32 b, u32 e, SoCEntry& o )
     }
 }
 
+// Prefix sums of (len, ambiguity) over the seeds in sweep order: the sums of the reference's loops (soc.h:362-404 re-adds a
+// strip's seeds whenever two strips are cut against each other) as differences -- the same integers.
+struct SoCPrefix
+{
+    const u64* len = nullptr; // n + 1 entries
+    const u32* amb = nullptr;
+};
+MA_HD void soc_sum( const ma_seed* s, const SoCPrefix& pre, u32 b, u32 e, SoCEntry& o )
+{
+    if( pre.len == nullptr || e < b )
+    {
+        soc_sum( s, b, e, o );
+        return;
+    }
+    o.accLen = pre.len[ e ] - pre.len[ b ];
+    o.amb = pre.amb[ e ] - pre.amb[ b ];
+    o.cnt = e - b;
+}
 // push_back_no_overlap (soc.h:362-404)
-MA_HD void soc_push_no_overlap( const ma_seed* s, SoCEntry* mx, u32& nmx, SoCEntry cur, u32 itS, u32 itE, u64 minScore )
+MA_HD void soc_push_no_overlap( const ma_seed* s, SoCEntry* mx, u32& nmx, SoCEntry cur, u32 itS, u32 itE, u64 minScore,
+                                const SoCPrefix& pre = SoCPrefix( ) )
 {
     while( nmx > 0 && mx[ nmx - 1 ].e > itS )
     {
@@ -213,7 +232,7 @@ MA_HD void soc_push_no_overlap( const ma_seed* s, SoCEntry* mx, u32& nmx, SoCEnt
         if( soc_less( back, cur ) )
         {
             const u32 bb = back.b;
-            soc_sum( s, bb, itS, back );
+            soc_sum( s, pre, bb, itS, back );
             back.b = bb;
             back.e = itS;
             if( back.accLen < minScore || back.accLen == 0 )
@@ -222,7 +241,7 @@ MA_HD void soc_push_no_overlap( const ma_seed* s, SoCEntry* mx, u32& nmx, SoCEnt
         else
         {
             const u32 be = back.e;
-            soc_sum( s, be, itE, cur );
+            soc_sum( s, pre, be, itE, cur );
             itS = be;
             if( cur.accLen < minScore || cur.accLen == 0 )
                 return;
@@ -286,7 +305,7 @@ struct SeqIdCache
 // (wave_sort.h, k_sort_seeds_wave): soc_windows = [sort by delta] + window sweep + make_heap + reference rectangles,
 // soc_rebuild = [sort by reference position] + the strips rebuilt over the re-sorted seeds.
 MA_HD u32 soc_windows( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm, ma_seed* tmp,
-                       bool sortedByDelta );
+                       bool sortedByDelta, u64* prefix = nullptr );
 MA_HD void soc_rebuild( ma_seed* s, u32 n, SoCEntry* mx, const RefMinMax* mm, u32 nmx, KeyIdx* ki2, ma_seed* tmp, bool sortedByRef );
 MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm,
                      KeyIdx* ki2 = nullptr, ma_seed* tmp = nullptr )
@@ -296,8 +315,10 @@ MA_HD u32 soc_sweep( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n
         soc_rebuild( s, n, mx, mm, nmx, ki2, tmp, false );
     return nmx;
 }
+// prefix: 12 * (n + 1) bytes of scratch (or null; may be `tmp`, which only the sort uses): the window sums and the re-sums of
+// push_back_no_overlap come out of prefix sums (50 kb reads: k_soc_windows 36.6 -> 19.9 ms)
 MA_HD u32 soc_windows( const IndexView& X, const ChainParams& P, ma_seed* s, u32 n, u32 qlen, SoCEntry* mx, RefMinMax* mm, ma_seed* tmp,
-                       bool sortedByDelta )
+                       bool sortedByDelta, u64* prefix )
 {
     if( n == 0 )
         return 0;
@@ -320,6 +341,38 @@ MA_HD u32 soc_windows( const IndexView& X, const ChainParams& P, ma_seed* s, u32
     u32 S = 0, E = 0;
     SeqIdCache cache; // both ends of the window: they are on the same contig nearly always
     i64 cidE = cache.get( X, (u64)s[ 0 ].r_start );
+    SoCPrefix pre;
+    if( prefix != nullptr ) // (may be the keyed sort's scratch: that sort is over)
+    {
+        u64* pl = prefix;
+        u32* pa = (u32*)( prefix + n + 1 );
+        u64 al = 0;
+        u32 aa = 0;
+        pl[ 0 ] = 0, pa[ 0 ] = 0;
+        for( u32 i = 0; i < n; i++ )
+        {
+            al += (u64)s[ i ].len, aa += s[ i ].ambiguity;
+            pl[ i + 1 ] = al, pa[ i + 1 ] = aa;
+        }
+        pre.len = pl, pre.amb = pa;
+        while( E != n && S != n )
+        {
+            const i64 cidS = cache.get( X, (u64)s[ S ].r_start );
+            const u64 lim = (u64)s[ S ].delta + strip;
+            while( E != n && lim >= (u64)s[ E ].delta && cidS == cidE )
+            {
+                E++;
+                if( E != n )
+                    cidE = cache.get( X, (u64)s[ E ].r_start );
+            }
+            // the window holds seed S at least (E == S passes both tests), so E > S: the running sums of the reference
+            cur.accLen = pl[ E ] - pl[ S ], cur.amb = pa[ E ] - pa[ S ], cur.cnt = E - S;
+            if( (double)cur.accLen >= fMinLen )
+                soc_push_no_overlap( s, mx, nmx, cur, S, E, (u64)fMinLen, pre );
+            S++;
+        }
+    }
+    else
     while( E != n && S != n )
     {
         const i64 cidS = cache.get( X, (u64)s[ S ].r_start );

@@ -913,8 +913,11 @@ __global__ void __launch_bounds__( 64 ) k_soc_windows( IndexView X, ChainParams 
     if( threadIdx.x >= lanes || r >= n_reads )
         return;
     const u64 off = seed_off[ r ];
+    const bool byDelta = ( sorted[ r ] & 1u ) != 0;
+    // (tmp is the keyed sort's scratch, free when the wave-cooperative kernel did the sort: 40 n bytes for the 12 (n + 1) of the prefix
+    // sums.  Reads sorted in here -- 10 kb: ~240 seeds -- gain nothing: building the sums costs what they save, 55.3 vs 57.7 ms)
     pre_nmx[ r ] = soc_windows( X, P, work + off, seed_cnt[ r ], (u32)( roff[ r + 1 ] - roff[ r ] ), maxima + off, mm + off, tmp + off,
-                                ( sorted[ r ] & 1u ) != 0 );
+                                byDelta, byDelta && seed_cnt[ r ] >= 2 ? (u64*)( tmp + off ) : nullptr );
 }
 
 // the SoC queue of every read in pop order (ma_batch_get_socs); scratch and output carved by the read's seed offset
