@@ -448,7 +448,8 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     auto hTopBefore = [ & ]( i32 n ) -> i32 { return hBoundary( n ); }; // H(n-1, -1): only the early stop reads it
     const u32 M_LANE0 = lane == 0 ? 0xffffffffu : 0u;
     const u32 S_X0 = K_X0 << 16, S_X20 = K_X20 << 16; // cell 0's left neighbour never had a gap open
-    i32 boundPrev = 0x7fffffff;
+    i32 boundPrev = 0x7fffffff, nextBound = 0;
+    const i32 boundRate = max( 1, ( -sc_mis + sc_mch + 1 ) / 2 );
     const i32 nDiag = qlen + tlen - 1;
     bool stop = false;
     u32 nCells = 0; // < 2^32: qlen <= 256 cells on at most w + 1 diagonals
@@ -666,7 +667,12 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
             }
         }
         // ---- early stop (ksw_reg.h): no later cell can exceed ez.max
-        if( !newMax && !stop && r >= qlen - 1 && ( r & 2 ) ) // on two of every four diagonals
+        // The bound needs two consecutive diagonals (B_r and B_{r-1}) and costs ~60 instructions each time.  A pair that does not
+        // stop the job tells how far off the stop is: along its diagonal chain a cell loses at most mismatch + match per two
+        // diagonals (z >= the mismatch score, one step less to go), so a bound that exceeds ez.max by g cannot fall to it in fewer
+        // than g / rate diagonals -- the next pair is evaluated then, not two diagonals later (a junk extension: ~6 pairs instead
+        // of ~60; skipping is only ever late, never wrong: the job just runs until a later pair proves the stop)
+        if( !newMax && !stop && r >= qlen - 1 && r >= nextBound )
         {
             const u32 qo = pk_bcast_s( qlen - 1 - r );
             u32 bm = K_NEG;
@@ -678,9 +684,16 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
                 bm = pk_max( bm, pk_bfi( LMs[ s ], bnd, K_NEG ) );
             }
             const i32 bound = wave_max_i32( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
-            if( r >= qlen && max( max( bound, boundPrev ), hTopBefore( r ) + sc_mch * qlen ) <= (i32)ez.max )
+            const i32 all = max( max( bound, boundPrev ), hTopBefore( r ) + sc_mch * qlen );
+            if( r >= qlen && all <= (i32)ez.max )
                 stop = true;
-            boundPrev = bound;
+            else if( boundPrev != 0x7fffffff && r >= qlen )
+            {
+                nextBound = r + 1 + max( 0, ( max( bound, hTopBefore( r ) + sc_mch * qlen ) - (i32)ez.max ) / boundRate - 1 );
+                boundPrev = 0x7fffffff;
+            }
+            else
+                boundPrev = bound;
         }
         else
             boundPrev = 0x7fffffff;
