@@ -12,8 +12,8 @@ import os
 import re
 import sys
 
-GROUPS = [("k_seed", ["k_seed(", "k_seed_long(", "k_seed_tasks", "k_task_", "k_mems"]), ("k_seed_rows+k_lf_walk+k_seed_final", ["k_seed_rows", "k_lf_walk", "k_seed_final"]),
-          ("k_chain", ["k_chain"]), ("k_dp_enum", ["k_dp_enum"]), ("k_ksw_pk", ["k_ksw_pk"]), ("k_ksw (LDS)", ["::k_ksw<"]),
+GROUPS = [("k_seed", ["k_seed(", "k_seed<", "k_seed_long(", "k_seed_long<", "k_seed_tasks", "k_task_", "k_mems"]), ("k_seed_rows+k_lf_walk+k_seed_final", ["k_seed_rows", "k_lf_walk", "k_seed_final"]),
+          ("k_chain", ["k_chain", "k_soc_windows", "k_sort_seeds_wave"]), ("k_dp_enum", ["k_dp_enum"]), ("k_ksw_pk", ["k_ksw_pk"]), ("k_ksw (LDS)", ["::k_ksw<"]),
           ("k_stitch+k_finish", ["k_stitch", "k_finish"])]
 
 
