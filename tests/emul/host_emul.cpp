@@ -71,7 +71,7 @@ int main( int argc, char** argv )
 {
     if( argc < 6 )
     {
-        fprintf( stderr, "usage: host_emul <case> <preset> <srand_seed> <out> <stage: all|sortcheck>\n" );
+        fprintf( stderr, "usage: host_emul <case> <preset> <srand_seed> <out> <stage: all|sortcheck|round3check>\n" );
         return 2;
     }
     if( std::string( argv[ 5 ] ) == "sortcheck" )
@@ -137,6 +137,67 @@ int main( int argc, char** argv )
         printf( "sortcheck ok\n" );
         return 0;
     }
+    if( std::string( argv[ 5 ] ) == "round3check" )
+    {
+        srand( atoi( argv[ 3 ] ) );
+        // (1) K-mer keys by bit gathering (seed_center) == the byte loops they replace
+        for( int it = 0; it < 200000; it++ )
+        {
+            const u32 K = 2 + rand( ) % 13;
+            uint8_t b[ 16 ] = { 0 };
+            for( u32 j = 0; j < K; j++ )
+                b[ j ] = (uint8_t)( rand( ) & 3 );
+            u64 x = 0, y = 0;
+            for( u32 j = 0; j < 8; j++ )
+                x |= (u64)b[ j ] << ( 8 * j ), y |= (u64)b[ 8 + j ] << ( 8 * j );
+            const u32 le = kmer_gather( x, y );
+            u32 keyR = 0, keyL = 0;
+            for( u32 j = 0; j < K; j++ ) // right run: bases 0 .. K-1 complemented, first most significant
+                keyR = ( keyR << 2 ) | ( ( 3u - b[ j ] ) & 3u );
+            for( u32 j = 0; j < K; j++ ) // left run: the span's LAST base is q[centre], most significant
+                keyL = ( keyL << 2 ) | ( b[ K - 1 - j ] & 3u );
+            if( kmer_key_right( le, K ) != keyR || le != keyL )
+            {
+                fprintf( stderr, "kmer key mismatch K=%u\n", K );
+                return 1;
+            }
+        }
+        // (2) the window sweep with prefix sums == the sweep with running sums and re-added strips (ties, repeats, two contigs)
+        IndexView X;
+        u64 cstart[ 2 ] = { 0, 500000 }, clen[ 2 ] = { 500000, 400000 };
+        X.cstart = cstart, X.clen = clen, X.n_contigs = 2, X.F = 900000, X.n = 1800000;
+        ChainParams CP;
+        CP.match = 2, CP.gap = 4, CP.extend = 2, CP.harm_score_min = 18, CP.harm_score_min_rel = 0.002, CP.soc_width = 0, CP.genome_size_disable = 0;
+        for( int it = 0; it < 3000; it++ )
+        {
+            const u32 n = 1 + rand( ) % 400, qlen = 200 + rand( ) % 5000;
+            std::vector<ma_seed> a( n );
+            for( u32 i = 0; i < n; i++ )
+            {
+                a[ i ].q_start = rand( ) % qlen, a[ i ].len = 16 + rand( ) % 40;
+                a[ i ].r_start = ( rand( ) % 3 == 0 ? 499000 : 20000 ) + rand( ) % ( it % 2 ? 3000 : 60000 );
+                a[ i ].delta = a[ i ].r_start + qlen - a[ i ].q_start, a[ i ].ambiguity = 1 + rand( ) % 4, a[ i ].on_forward = 1;
+            }
+            ss::sort( a.data( ), (i64)n, SeedByDelta( ) );
+            std::vector<ma_seed> b = a, tmp( n );
+            std::vector<SoCEntry> m1( n + 1 ), m2( n + 1 );
+            std::vector<RefMinMax> r1( n + 1 ), r2( n + 1 );
+            std::vector<u64> pre( 2 * ( n + 2 ) );
+            const u32 k1 = soc_windows( X, CP, a.data( ), n, qlen, m1.data( ), r1.data( ), tmp.data( ), true, nullptr );
+            const u32 k2 = soc_windows( X, CP, b.data( ), n, qlen, m2.data( ), r2.data( ), tmp.data( ), true, pre.data( ) );
+            bool same = k1 == k2;
+            for( u32 k = 0; same && k < k1; k++ )
+                same = m1[ k ].accLen == m2[ k ].accLen && m1[ k ].amb == m2[ k ].amb && m1[ k ].cnt == m2[ k ].cnt && m1[ k ].b == m2[ k ].b &&
+                       m1[ k ].e == m2[ k ].e && r1[ k ].lo == r2[ k ].lo && r1[ k ].hi == r2[ k ].hi;
+            if( !same )
+            {
+                fprintf( stderr, "soc prefix mismatch n=%u\n", n );
+                return 1;
+            }
+        }
+        printf( "round3check ok\n" );
+        return 0;
+    }
     CaseFile cs = readCase( argv[ 1 ] );
     std::vector<uint64_t> lens;
     std::vector<uint8_t> cat;
@@ -188,6 +249,8 @@ int main( int argc, char** argv )
     SP.disable_heuristics = OP.disable_heuristics;
     SP.rel_min_seed_size_amount = OP.rel_min_seed_size_amount;
     SP.genome_size_disable = OP.genome_size_disable;
+    if( const char* e = getenv( "MA_EMUL_SMEM_MERGE" ) ) // the kernels' default for uiMinAmbiguity == 0: twin list entries are not kept
+        SP.smem_merge = atoi( e ) != 0 && SP.min_amb == 0 ? 1 : 0;
     ChainParams CP;
     CP.max_num_soc = OP.max_num_soc;
     CP.min_num_soc = OP.min_num_soc;

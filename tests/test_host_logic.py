@@ -25,6 +25,13 @@ def emul():
     return EMUL
 
 
+def test_round3_units(emul):
+    """K-mer keys by bit gathering == the byte loops (seeding.h, seed_center); the window sweep with prefix sums == the sweep
+    with running sums and re-added strips (chain.h, soc_windows)."""
+    out = subprocess.check_output([emul, "x", "default", "7", "/dev/null", "round3check"]).decode()
+    assert "round3check ok" in out
+
+
 def test_stdsort_matches_libstdcxx(emul):
     out = subprocess.check_output([emul, "x", "default", "3", "/dev/null", "sortcheck"]).decode()
     assert "sortcheck ok" in out
@@ -37,6 +44,16 @@ def test_stage_logic_vs_reference_golden(emul, tmp_path, preset, name):
     ref = gunzip_to(os.path.join(G, name + ".gz"), str(tmp_path / name))
     out = str(tmp_path / "emul.pipe")
     subprocess.check_call([emul, case, preset, "1", out, "all"])
+    assert first_diff(ref, out) is None
+
+
+def test_smem_twin_merge_vs_reference_golden(emul, tmp_path):
+    """The SMEM state machine with the kernels' default (list entries whose interval equals that of the entry before them are
+    not kept, seeding.h seed_apply) reproduces the compiled reference's dump of the Illumina preset."""
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    ref = gunzip_to(os.path.join(G, "small_ref.illumina.pipe.gz"), str(tmp_path / "ref.pipe"))
+    out = str(tmp_path / "emul.pipe")
+    subprocess.check_call([emul, case, "illumina", "1", out, "all"], env=dict(os.environ, MA_EMUL_SMEM_MERGE="1"))
     assert first_diff(ref, out) is None
 
 
