@@ -90,7 +90,7 @@ static __device__ unsigned long long g_seed_prof[ 8 ];
 // One read per lane at a time; lanes refill from a global queue, so a wavefront keeps stepping 64
 // reads in lockstep through extend_backward until the batch is exhausted.
 // LONG: the reads stay in HBM (longer than 240 bases) and are read through the register window of seed_qbyte.
-template <bool LONG, bool SM> __device__ __forceinline__ void seed_kernel_body( const SeedKernelArgs& A )
+template <bool LONG, bool SM, bool MS = !SM> __device__ __forceinline__ void seed_kernel_body( const SeedKernelArgs& A )
 {
     const u32 lane = blockIdx.x * blockDim.x + threadIdx.x;
     SeedScratch S;
@@ -205,7 +205,7 @@ template <bool LONG, bool SM> __device__ __forceinline__ void seed_kernel_body( 
 #endif
         u32 c = 0;
         const bool act = alive && L.phase != PH_DONE;
-        bool ext = act && seed_try<LONG, SM>( L, A.P, c );
+        bool ext = act && seed_try<LONG, SM, MS>( L, A.P, c, &S );
         {
             // phase transitions are batched like the refills: run them when enough lanes wait for one (or nobody can step)
             const unsigned long long sm = __ballot( act && !ext );
@@ -216,7 +216,7 @@ template <bool LONG, bool SM> __device__ __forceinline__ void seed_kernel_body( 
 #endif
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare<LONG, true, SM>( L, A.P, S, A.X, c );
+                    ext = seed_prepare<LONG, true, SM, MS>( L, A.P, S, A.X, c );
 #if defined( MA_KSW_PROF )
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 pf[ 0 ] += clock64( );
@@ -235,7 +235,7 @@ template <bool LONG, bool SM> __device__ __forceinline__ void seed_kernel_body( 
             extend_backward( A.X, L.ik, c, ok, nb );
             L.steps++;
             L.blocks += nb;
-            seed_apply<SM>( L, A.P, S, ok );
+            seed_apply<SM, MS>( L, A.P, S, ok );
         }
 #if defined( MA_KSW_PROF )
         const unsigned long long tD = clock64( );

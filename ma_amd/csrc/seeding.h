@@ -74,8 +74,10 @@ struct SeedLane
     u32 curQStart, curQSize; // prev[jPrev] of the extension in flight (its interval is in ik): read once, in seed_prepare
     u32 bHaveOne, retS, retE;
     u32 flip; // which of smem_a/smem_b is "prev"
-    i64 lastK, lastRc, lastS; // the entry pushed last onto curr (its q_start is the position i it was pushed at):
-    u32 lastQSize; //           twin test of smem_merge, and the register copy seed_try continues with
+    i64 lastK, lastS; // interval of the entry pushed last onto curr: the twin test of smem_merge
+    u64 first0, first1; // the entry pushed FIRST onto curr (16-byte form): what the next position starts with (seed_try)
+    u64 nxt0, nxt1; // prev[ jPrev ] of the NEXT backward step (16-byte entries only), requested one step ahead: the entry
+    u32 nxtOk; //      arrives while this step's occ blocks are on their way, instead of in a round trip of its own
     // output
     u32 nseg;
     u32 err;
@@ -141,13 +143,18 @@ MA_HD u32 comp_base( u32 c ) // NucSeq::nucleotideComplement (nucSeq.h:524-532)
 // their traffic is as large as that of the occ blocks (Illumina preset: 99 GB of reads and 94 GB of writes per 1 M reads
 // beside 105 GB of occ blocks).  A 40-byte record straddles 64-byte lines; packed into 16 bytes -- three 35-bit interval
 // fields, two 11-bit query fields -- an entry is one aligned dwordx4 and four of them share a line.
+MA_HD void smem_pack( u32 qs, u32 qz, i64 a, i64 b, i64 c, u64& w0, u64& w1 )
+{
+    w0 = (u64)a | ( ( (u64)c & 0x1fffffffull ) << 35 );
+    w1 = (u64)b | ( ( (u64)c >> 29 ) << 35 ) | ( (u64)qs << 41 ) | ( (u64)qz << 52 );
+}
 MA_HD void smem_put( const SeedParams& P, ma_segment* list, u32 idx, u32 qs, u32 qz, i64 a, i64 b, i64 c )
 {
     if( P.smem_compact )
     {
         u64* w = (u64*)list + 2 * (u64)idx;
-        const u64 w0 = (u64)a | ( ( (u64)c & 0x1fffffffull ) << 35 );
-        const u64 w1 = (u64)b | ( ( (u64)c >> 29 ) << 35 ) | ( (u64)qs << 41 ) | ( (u64)qz << 52 );
+        u64 w0, w1;
+        smem_pack( qs, qz, a, b, c, w0, w1 );
 #if defined( __HIP_DEVICE_COMPILE__ )
         *(ulonglong2*)w = make_ulonglong2( w0, w1 );
 #else
@@ -183,6 +190,18 @@ MA_HD ma_segment smem_get( const SeedParams& P, const ma_segment* list, u32 idx 
     return list[ idx ];
 }
 
+MA_HD ma_segment smem_unpack( u64 w0, u64 w1 )
+{
+    ma_segment s;
+    s.sa_start = (i64)( w0 & 0x7ffffffffull );
+    s.sa_start_rc = (i64)( w1 & 0x7ffffffffull );
+    s.sa_size = (i64)( ( w0 >> 35 ) | ( ( ( w1 >> 35 ) & 0x3full ) << 29 ) );
+    s.q_start = (i64)( ( w1 >> 41 ) & 0x7ffull );
+    s.q_size = (i64)( ( w1 >> 52 ) & 0x7ffull );
+    return s;
+}
+// request entry idx of a list of 16-byte entries into the lane's prefetch registers
+MA_HD void smem_prefetch( SeedLane& L, const ma_segment* list, u32 idx );
 MA_HD void seed_emit( SeedLane& L, const SeedScratch& S, u32 start, u32 size, i64 a, i64 b, i64 c )
 {
     if( L.nseg < S.seg_cap )
@@ -202,8 +221,20 @@ MA_HD void seed_emit( SeedLane& L, const SeedScratch& S, u32 start, u32 size, i6
     L.nseg++;
 }
 
+MA_HD void smem_prefetch( SeedLane& L, const ma_segment* list, u32 idx )
+{
+    const u64* w = (const u64*)list + 2 * (u64)idx;
+#if defined( __HIP_DEVICE_COMPILE__ )
+    const ulonglong2 v = *(const ulonglong2*)w;
+    L.nxt0 = v.x, L.nxt1 = v.y;
+#else
+    L.nxt0 = w[ 0 ], L.nxt1 = w[ 1 ];
+#endif
+    L.nxtOk = 1;
+}
 MA_HD void seed_begin_read( SeedLane& L, const uint8_t* q, u32 qlen )
 {
+    L.nxtOk = 0;
     L.q = q;
     L.qlen = qlen;
     L.qwinLo = 0x80000000u; // empty
@@ -319,12 +350,15 @@ MA_HD u32 kmer_key_right( u32 le, u32 K ) // first base of the span most signifi
 // bytes around the centre serves the base, both keys and the bases the later transitions of this centre start with (L.cb);
 // step by step the same costs a window load for the centre, K byte loads per key and a window load per transition, each a
 // memory round trip of its own that the whole wavefront waits for.
-template <bool WIN, bool JUMP, bool SM = true> MA_HD u32 seed_center( SeedLane& L, const SeedParams& P, const IndexView& X, u64& eRx, u64& eRy )
+template <bool WIN, bool JUMP, bool SM = true, bool MS = true> MA_HD u32 seed_center( SeedLane& L, const SeedParams& P, const IndexView& X, u64& eRx, u64& eRy )
 {
-    const u32 K = JUMP && ( !SM || P.technique == 0 ) ? X.kmer_k : 0, c = L.center;
+    const u32 K = JUMP && MS && ( !SM || P.technique == 0 ) ? X.kmer_k : 0, c = L.center;
     eRx = eRy = 0;
-    L.eL0 = L.eL1 = 0;
-    L.cb = 0;
+    if( MS )
+    {
+        L.eL0 = L.eL1 = 0;
+        L.cb = 0;
+    }
     bool vR = K != 0 && c + K <= L.qlen, vL = K != 0 && c + 1 >= K;
     u32 keyR = 0, keyL = 0, qc;
 #if defined( __HIP_DEVICE_COMPILE__ )
@@ -437,34 +471,52 @@ MA_HD bool seed_stop( const SeedParams& P, const i64 ok[ 3 ], const i64 ik[ 3 ] 
 // Can the lane extend right away, i.e. without any phase transition?  (The kernel batches the transitions of a
 // wavefront: a lane whose transition is due idles for a few steps until enough lanes wait, so that the divergent
 // bookkeeping of seed_prepare is executed once for many lanes instead of on every step for one or two.)
-// SM = false: the kernel serves maxSpan only (P.technique == 0): the SMEM states and their lane registers are compiled out
-template <bool WIN = false, bool SM = true> MA_HD bool seed_try( SeedLane& L, const SeedParams& P, u32& c )
+// SM = false: the kernel serves maxSpan only (P.technique == 0): the SMEM states and their lane registers are compiled out;
+// MS = false: SMEMs only (P.technique == 1), the same for the maxSpan states
+template <bool WIN = false, bool SM = true, bool MS = true> MA_HD bool seed_try( SeedLane& L, const SeedParams& P, u32& c, const SeedScratch* S = nullptr )
 {
     if( SM && L.phase == PH_SMEM_BWD )
     {
-        // SMEM backward phase with ONE entry left on the list that was just written (after the twins are gone: nearly
-        // every position of a read): the end-of-position bookkeeping of seed_prepare, with the entry taken from the
-        // registers it was pushed from instead of from the list in HBM -- no batching with other lanes' transitions, no
-        // memory round trip before the extension can start
-        if( L.jPrev == L.nPrev && L.nCurr == 1 && L.i != 0 )
+        // the next entry of the list was requested a step ago (seed_prepare / here): take it, request the one after it
+        if( S != nullptr && L.nxtOk && L.jPrev < L.nPrev )
+        {
+            const ma_segment s = smem_unpack( L.nxt0, L.nxt1 );
+            L.ik[ 0 ] = s.sa_start, L.ik[ 1 ] = s.sa_start_rc, L.ik[ 2 ] = s.sa_size;
+            L.curQStart = (u32)s.q_start, L.curQSize = (u32)s.q_size;
+            if( L.jPrev + 1 < L.nPrev )
+                smem_prefetch( L, L.flip ? S->smem_b : S->smem_a, L.jPrev + 1 );
+            else
+                L.nxtOk = 0;
+            c = seed_qbyte<WIN>( L, P, L.i );
+            return true;
+        }
+        // End of a backward position (the bookkeeping of seed_prepare's PH_SMEM_BWD) without leaving the fast path: the next
+        // position starts with the entry that was pushed FIRST onto the list just written, which is still in registers -- no
+        // list read, no batching with other lanes' transitions; the second entry is requested for the step after this one.
+        // (16-byte entries only: reads < 2048 bases, so the packed q_start / q_size are exact.)
+        if( S != nullptr && P.smem_compact && L.jPrev == L.nPrev && L.nCurr >= 1 && L.i != 0 )
         {
             L.flip ^= 1;
-            L.nPrev = 1;
+            L.nPrev = L.nCurr;
             L.nCurr = 0;
             L.jPrev = 0;
             L.bHaveOne = 0;
             L.retS = L.i;
-            L.curQStart = L.i;
-            L.curQSize = L.lastQSize;
-            L.ik[ 0 ] = L.lastK, L.ik[ 1 ] = L.lastRc, L.ik[ 2 ] = L.lastS;
+            const ma_segment s = smem_unpack( L.first0, L.first1 );
+            L.ik[ 0 ] = s.sa_start, L.ik[ 1 ] = s.sa_start_rc, L.ik[ 2 ] = s.sa_size;
+            L.curQStart = (u32)s.q_start, L.curQSize = (u32)s.q_size;
+            if( L.nPrev > 1 )
+                smem_prefetch( L, L.flip ? S->smem_b : S->smem_a, 1 );
+            else
+                L.nxtOk = 0;
             L.i--;
             c = seed_qbyte<WIN>( L, P, L.i );
             return true;
         }
         return false;
     }
-    const bool right = L.phase == PH_P1_RIGHT || L.phase == PH_P2_RIGHT || ( SM && L.phase == PH_SMEM_FWD );
-    const bool left = L.phase == PH_P1_LEFT || L.phase == PH_P2_LEFT;
+    const bool right = ( MS && ( L.phase == PH_P1_RIGHT || L.phase == PH_P2_RIGHT ) ) || ( SM && L.phase == PH_SMEM_FWD );
+    const bool left = MS && ( L.phase == PH_P1_LEFT || L.phase == PH_P2_LEFT );
     const bool ok = right ? L.i < L.qlen : ( left && L.i != 0xffffffffu );
     if( ok )
     {
@@ -496,7 +548,7 @@ template <bool WIN> MA_HD void seed_prefetch( SeedLane& L, const SeedParams& P )
 // Runs cheap bookkeeping until the lane either needs an extension (returns true and sets c) or is done.
 // JUMP: use the K-mer table of the index (only the kernel whose register budget has room for it: inlined into the
 // read-per-lane kernel it costs a wave of occupancy, 117 -> 138 VGPRs, which eats the gain)
-template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
+template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> MA_HD bool seed_prepare( SeedLane& L, const SeedParams& P, const SeedScratch& S, const IndexView& X, u32& c )
 {
     while( true )
     {
@@ -508,14 +560,14 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
             {
                 L.center = L.aS + L.aN / 2;
                 u64 eRx, eRy;
-                const u32 qc = seed_center<WIN, JUMP, SM>( L, P, X, eRx, eRy );
+                const u32 qc = seed_center<WIN, JUMP, SM, MS>( L, P, X, eRx, eRy );
                 if( qc >= 4 )
                 { // N covers one position (binarySeeding.h:70-72 / 275-277)
                     seed_after_center( L, S, L.center, 1 );
                     break;
                 }
                 init_interval( X, 3 - qc, L.ik );
-                if( !SM || P.technique == 0 )
+                if( MS && ( !SM || P.technique == 0 ) )
                 {
                     if( L.ik[ 2 ] == 0 )
                     {
@@ -531,7 +583,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
                     }
                     L.phase = PH_P1_RIGHT;
                 }
-                else
+                else if( SM )
                 {
                     L.nCurr = 0;
                     L.retS = L.retE = L.center;
@@ -539,9 +591,13 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
                     L.flip = 0;
                     L.phase = PH_SMEM_FWD;
                 }
+                else
+                    L.phase = PH_DONE;
                 break;
             }
             case PH_P1_RIGHT:
+                if( !MS )
+                    return false;
                 if( L.i < L.qlen )
                 {
                     c = comp_base( seed_qbyte_c<WIN>( L, P, X, L.i ) );
@@ -560,6 +616,8 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
                 L.i = 0xffffffffu; // sentinel: left loop skipped
                 break;
             case PH_P1_LEFT:
+                if( !MS )
+                    return false;
                 if( L.i != 0xffffffffu )
                 {
                     c = seed_qbyte_c<WIN>( L, P, X, L.i );
@@ -580,6 +638,8 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
                 }
                 break;
             case PH_P2_LEFT:
+                if( !MS )
+                    return false;
                 if( L.i != 0xffffffffu )
                 {
                     c = seed_qbyte_c<WIN>( L, P, X, L.i );
@@ -591,6 +651,8 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
                 L.phase = PH_P2_RIGHT;
                 break;
             case PH_P2_RIGHT:
+                if( !MS )
+                    return false;
                 if( L.i < L.qlen )
                 {
                     c = comp_base( seed_qbyte_c<WIN>( L, P, X, L.i ) );
@@ -630,6 +692,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
                     L.nCurr = 0;
                     L.flip = 0; // prev = smem_a, curr = smem_b
                     L.jPrev = 0;
+                    L.nxtOk = 0;
                     L.bHaveOne = 0;
                     if( L.center != 0 && L.nPrev > 0 )
                     {
@@ -655,7 +718,11 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
                 ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
                 if( L.jPrev < L.nPrev )
                 {
-                    const ma_segment s = smem_get( P, prev, L.jPrev );
+                    const ma_segment s = L.nxtOk ? smem_unpack( L.nxt0, L.nxt1 ) : smem_get( P, prev, L.jPrev );
+                    if( P.smem_compact && L.jPrev + 1 < L.nPrev )
+                        smem_prefetch( L, prev, L.jPrev + 1 );
+                    else
+                        L.nxtOk = 0;
                     L.ik[ 0 ] = s.sa_start;
                     L.ik[ 1 ] = s.sa_start_rc;
                     L.ik[ 2 ] = s.sa_size;
@@ -665,6 +732,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
                     return true;
                 }
                 // end of one backward position: swap lists (binarySeeding.h:416-433)
+                L.nxtOk = 0;
                 L.flip ^= 1;
                 L.nPrev = L.nCurr;
                 L.nCurr = 0;
@@ -699,12 +767,14 @@ template <bool WIN = false, bool JUMP = false, bool SM = true> MA_HD bool seed_p
 }
 
 // ---- apply the result of the extension requested by seed_prepare --------------------------------
-template <bool SM = true> MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, const i64 ok[ 3 ] )
+template <bool SM = true, bool MS = true> MA_HD void seed_apply( SeedLane& L, const SeedParams& P, const SeedScratch& S, const i64 ok[ 3 ] )
 {
     switch( L.phase )
     {
         case PH_P1_RIGHT:
         case PH_P2_RIGHT:
+            if( !MS )
+                break;
             if( seed_stop( P, ok, L.ik ) )
                 L.i = L.qlen; // leave the loop; seed_prepare performs the transition
             else
@@ -716,6 +786,8 @@ template <bool SM = true> MA_HD void seed_apply( SeedLane& L, const SeedParams& 
             break;
         case PH_P1_LEFT:
         case PH_P2_LEFT:
+            if( !MS )
+                break;
             if( seed_stop( P, ok, L.ik ) )
                 L.i = 0xffffffffu;
             else
@@ -781,8 +853,10 @@ template <bool SM = true> MA_HD void seed_apply( SeedLane& L, const SeedParams& 
                         smem_put( P, curr, L.nCurr, L.i, (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ] );
                     else
                         L.err |= MA_ERR_SMEM_OVERFLOW;
+                    if( L.nCurr == 0 )
+                        smem_pack( L.i, (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ], L.first0, L.first1 );
                     L.nCurr++;
-                    L.lastK = ok[ 0 ], L.lastRc = ok[ 1 ], L.lastS = ok[ 2 ], L.lastQSize = (u32)s.q_size + 1;
+                    L.lastK = ok[ 0 ], L.lastS = ok[ 2 ];
                 }
             }
             L.jPrev++;
