@@ -2036,7 +2036,9 @@ int ma_seed_batch( ma_batch* b )
     MA_HIP( hipMemGetInfo( &freeB, &totalB ) );
     const u64 have = b->stage.cap + b->smemA.cap + b->smemB.cap; // already ours
     const u64 budget = std::max<u64>( 8ull << 30, ( (u64)freeB + have ) / 3 );
-    const u64 want = std::min<u64>( 256ull * 2048, ( n + 255 ) / 256 * 256 );
+    u64 want = std::min<u64>( 256ull * 2048, ( n + 255 ) / 256 * 256 );
+    if( const char* e = getenv( "MA_SEED_LANES" ) ) // tuning hook: resident lanes of the read-per-lane kernels
+        want = std::min<u64>( want, std::max<u64>( 256, (u64)atoll( e ) / 256 * 256 ) );
     u32 seg_cap = worst_cap;
     if( want * ( (u64)worst_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment ) ) > budget )
         seg_cap = std::min<u32>( worst_cap, ( smem ? 3 : 1 ) * ( b->max_qlen / 4 ) + 64 );
