@@ -281,4 +281,9 @@ def test_long_read_seeding_kmer_jump_gives_the_same_segments(gpu_device, monkeyp
     got, steps = run()
     _same(got, want)
     assert steps < 0.9 * steps_walk
+    # 256 resident lanes for 296 reads: the lanes fetch a second read from the queue when their first one is done
+    monkeypatch.setenv("MA_SEED_LANES", "256")
+    got, steps2 = run()
+    _same(got, want)
+    assert steps2 == steps
     idx.close()
