@@ -441,11 +441,36 @@ def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, 
                                                res["ops"][2 * int(oa["ops_off"]):2 * int(oa["ops_off"] + oa["n_ops"])])
             bad += 0 if ok else 1
         bad = max(bad, 1)
+    cpu["cpu_quota_cores"] = cpu_quota_cores()  # what `cores` threads actually get: the container's CFS quota
     cpu["parity_check"] = {"reads": Pn, "alignments": na, "alignment_ops": nops, "mapq_records": nm,
                            "mismatching_reads": bad,
                            "what": "GPU vs oracle on the first reads of step 0: every NeedlemanWunsch alignment (positions, score, "
                                    "ops) and MappingQuality record (flags, mapq bits)"}
     return cpu
+
+
+def cpu_quota_cores():
+    """CPU time the container may use, in cores (cgroup CFS quota), or None: the boxes of the pool show 256 logical CPUs and
+    grant 16 cores' worth of time per 100 ms period -- every host-side figure of this line is measured under that quota."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except Exception:  # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            return None if q <= 0 else round(q / p, 2)
+        except Exception:  # noqa: BLE001
+            return None
+
+
+def cfs_throttle():
+    """(periods in which the container was throttled, seconds its threads spent throttled) so far, or None"""
+    try:
+        d = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines() if len(l.split()) == 2)
+        return int(d["nr_throttled"]), int(d["throttled_usec"]) / 1e6
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def boundary_leg(E, args):
@@ -455,12 +480,21 @@ def boundary_leg(E, args):
     if not os.path.exists(exe):
         return {"error": "examples/ma_boundary_bench not built (run __graft_entry__.build())"}
     try:
+        t0 = cfs_throttle()
         out = subprocess.run([exe, E.reference_index(), str(args.boundary_reads), "150", args.preset, str(E.gpu)],
                              capture_output=True, text=True, timeout=900)
+        t1 = cfs_throttle()
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if out.returncode != 0 or not line:
             return {"error": (out.stderr or out.stdout)[-300:]}
-        return json.loads(line[-1])
+        res = json.loads(line[-1])
+        res["host_cpu_quota_cores"] = cpu_quota_cores()
+        if t0 and t1:
+            res["cfs_throttled"] = {"periods": t1[0] - t0[0], "thread_seconds": round(t1[1] - t0[1], 1),
+                                    "what": "CFS throttling of the container while this leg ran: its host threads (256 workers, 2048 "
+                                            "graph threads in the per-read leg) compete for the quota above, which makes the "
+                                            "thread-heavy legs vary from run to run"}
+        return res
     except Exception as e:  # noqa: BLE001
         return {"error": repr(e)[:300]}
 
