@@ -393,7 +393,9 @@ def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, 
                 return int(m.group(2)) / float(m.group(3)), float(m.group(3))
 
             runs = {}
-            cand = sorted(set([ncores] + ([max(1, ncores // 4)] if args.cpu_threads_sweep else [])))
+            quota = cpu_quota_cores()
+            cand = sorted(set([ncores] + ([max(1, ncores // 4)] if args.cpu_threads_sweep else [])
+                              + ([max(1, int(quota))] if quota and quota < ncores else [])))  # as many threads as the quota grants cores
             for t in cand:
                 runs[t] = timed("reads.case", t)
             best = max(runs, key=lambda t: runs[t][0])
