@@ -490,6 +490,9 @@ def boundary_leg(E, args):
         if out.returncode != 0 or not line:
             return {"error": (out.stderr or out.stdout)[-300:]}
         res = json.loads(line[-1])
+        gl = [l for l in out.stderr.splitlines() if l.startswith("graph leg:")]
+        if gl and isinstance(res.get("graph"), dict):
+            res["graph"]["device_side"] = gl[-1]  # wall of the leg vs the seconds its device batches took, by phase
         res["host_cpu_quota_cores"] = cpu_quota_cores()
         if t0 and t1:
             res["cfs_throttled"] = {"periods": t1[0] - t0[0], "thread_seconds": round(t1[1] - t0[1], 1),
