@@ -327,6 +327,7 @@ struct BatcherOptions
                           // an engine always free a batch is sealed after xGather, while it is small, and small batches pay the fixed cost
     std::chrono::microseconds xGather{ 40 }; // an idle GPU still waits this long for more reads to arrive
     std::chrono::microseconds xMaxWait{ 20000 }; // a read never waits longer than this for its batch to be sealed
+    std::chrono::microseconds xFill{ 3000 }; // while another batch runs, a batch smaller than half the last one waits this long for more
     // true: every stage's records are fetched, so SegmentVector / SoCPriorityQueue / seed sets / NeedlemanWunsch's
     // alignments carry their content (what a graph needs whose nodes are not all MI355X modules).  false: only the
     // MappingQuality-annotated alignments are fetched; the intermediate containers are empty shells that just pass the
@@ -375,7 +376,7 @@ class DeviceBatcher
     std::condition_variable xChanged;
     std::shared_ptr<Slot> pOpen;
     std::vector<std::unique_ptr<Engine>> vIdle; // engines not running a batch
-    size_t uiEnginesMade = 0, uiRunning = 0;
+    size_t uiEnginesMade = 0, uiRunning = 0, uiLastSealed = 0;
     uint64_t uiBatches = 0, uiReadsTotal = 0;
     double fSumH2D = 0, fSumKernels = 0, fSumD2H = 0, fSumRun = 0; // seconds over all batches
     double aSumStageMs[ 4 ] = { 0, 0, 0, 0 };
@@ -451,6 +452,7 @@ class DeviceBatcher
         pSlot->vReads.push_back( rRead );
         auto seal = [ & ]( ) {
             pSlot->bSealed = true;
+            uiLastSealed = pSlot->vReads.size( );
             if( pOpen == pSlot )
                 pOpen = nullptr;
         };
@@ -463,14 +465,19 @@ class DeviceBatcher
         {
             // the first read of a batch leads it: it seals the batch once a device slot is free and the arrivals have had
             // a moment to gather (while all device slots are busy the batch simply keeps growing), or after xMaxWait
+            // While ANOTHER batch is on the device a free engine is no reason to leave with a handful of reads: the readers of
+            // the batch that just finished are only now coming back, and a batch of 30 reads costs the same ~4 ms as one of 600
+            // (measured: the batches alternated between ~1100 and ~40 reads, and less than one of them was in flight on average).
+            // Such a batch waits until it holds half of what the last sealed batch held, or xFill.
             const auto tOpened = std::chrono::steady_clock::now( );
             while( !pSlot->bSealed )
             {
                 const auto tNow = std::chrono::steady_clock::now( );
                 const bool bGathered = tNow - tOpened >= xOpt.xGather;
-                if( ( bGathered && uiRunning < xOpt.uiEngines ) || tNow - tOpened >= xOpt.xMaxWait )
+                const bool bFilled = uiRunning == 0 || pSlot->vReads.size( ) >= uiLastSealed / 2 || tNow - tOpened >= xOpt.xFill;
+                if( ( bGathered && bFilled && uiRunning < xOpt.uiEngines ) || tNow - tOpened >= xOpt.xMaxWait )
                     break;
-                xChanged.wait_for( xLock, bGathered ? std::chrono::microseconds( 500 ) : xOpt.xGather );
+                xChanged.wait_for( xLock, bGathered ? std::chrono::microseconds( 200 ) : xOpt.xGather );
             }
             if( !pSlot->bSealed )
             {
