@@ -10,16 +10,28 @@ GRCh38-sized synthetic genome (24 contigs, 3.09 Gnt, planted repeat families) an
   C3  10 kb CCS-like reads (0.4 / 0.3 / 0.3 % sub / ins / del), 5 steps of 200 k reads = the 1 M reads of configs[2]
   C5  50 kb ONT-like reads (3 / 3 / 4 %), 4 steps of 20 k reads (stress shape)
 
-each with its own timed region (barrier + synchronize on both sides, MAX over ranks), roofline block, CPU baseline (the
-compiled reference on the host cores, N = 1 only) and a parity check of the GPU results against the oracle.  The line's
-top-level value / ms_per_step / roofline are those of ONE leg of C2 (several batches in flight when that is faster, else one
-batch at a time; config.value_is says which), cpu_baseline is C2's; config.workloads[] carries all three workloads.
---workload {150bp,10kb,50kb} or an explicit --read-len runs a single workload.
+plus C2 once more under the Illumina preset (SMEM seeding) and, at N = 1, BASELINE.md section 3's sanity anchor
+on C1 (oracle vs the compiled reference vs the GPU path on `ecoli_like`, 1 k reads).  Every workload runs three legs, each
+with its own timed region (barrier + synchronize on both sides, MAX over ranks):
+
+  single stream      one batch at a time, reads and results resident in HBM: undisturbed launches -> the roofline block,
+                     the CPU baseline (the compiled reference on the host cores, N = 1 only) and the parity check
+  device resident    several batches in flight (own streams + host threads), reads and results resident in HBM
+  host to host       BASELINE.md section 3's region: every step's reads start in page-locked HOST memory, the flat result arrays
+                     (offsets, alignment headers, ops) end in page-locked HOST memory, several batches in flight so that
+                     the copies of one batch hide behind the kernels of another
+
+The line's top-level value / ms_per_step / roofline are those of the HOST-TO-HOST leg of C2 (config.value_is says so);
+value_150bp_device_resident, value_10kb, value_50kb, value_150bp_illumina ... are top-level scalars of the same line; the
+full per-workload blocks (and the boundary leg) go to a side file (config.detail_file) and to stderr, so that the printed
+line stays short.  --workload {150bp,10kb,50kb,illumina} or an explicit --read-len runs a single workload.
 
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL, used only for the barrier and the
 max-over-ranks time); the index is replicated, there is no data-path collective.  --scaling weak (default): every rank
 aligns its own steps x reads_per_step reads; --scaling strong: ONE read set of steps x reads_per_step reads is
-partitioned into contiguous blocks over the ranks.  Prints ONE JSON line on rank 0.
+partitioned into contiguous blocks over the ranks.  Prints ONE JSON line on rank 0.  `--gpus N` without a torchrun
+environment starts the N ranks itself (python -m torch.distributed.run ... bench.py ...) before anything touches a GPU
+and exits with their status; inside a torchrun environment WORLD_SIZE must equal --gpus.
 """
 import argparse
 import ctypes as C
@@ -42,6 +54,8 @@ GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1593
           133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616,
           64444167, 46709983, 50818468, 156040895, 57227415]
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, a wave64 VALU instruction occupies a SIMD for 2 cycles (full-rate ops) at 2.4 GHz
+CHIP_VALU_PEAK_GINST = 256 * 4 * 2.4 / 2
 STAGES = ["k_seed", "k_seed_rows+k_lf_walk+k_seed_final", "k_chain", "k_dp_enum", "k_ksw", "k_stitch+k_finish"]
 
 WORKLOADS = {
@@ -52,6 +66,10 @@ WORKLOADS = {
                  cpu_sample=15360, baseline_config="configs[2] (C3)"),
     "50kb": dict(read_len=50000, sub=0.03, ins=0.03, dele=0.04, seed=13, reads_per_step=20000, steps=4, warmup=1,
                  cpu_sample=2048, baseline_config="configs[4] (C5 shape, one GPU)"),
+    # C2's reads under the Illumina preset (SMEM seeding, parameter.h:1083-1087): SURVEY 8(d) asks for this row beside every
+    # 150 bp table.  Parity sample only (the reference is timed on the Default preset's workloads)
+    "illumina": dict(read_len=150, sub=0.005, ins=0.0, dele=0.0, seed=11, reads_per_step=1000000, steps=10, warmup=1,
+                     cpu_sample=20000, baseline_config="configs[1] (C2), Illumina preset", preset="illumina", reference=False),
 }
 
 
@@ -146,6 +164,7 @@ class Env:
         self.t_index = time.perf_counter() - t0
         self.ref_dir = None  # index files for the compiled reference, written once
         self.live = []  # batch objects of the workload being run
+        self.live_host = []  # its page-locked staging arrays
 
     def chk(self, rc):
         if rc != 0:
@@ -168,7 +187,8 @@ def run_workload(E, name, wl, args):
     from ma_amd.shard import reduce_timing_and_counts, shard_range, weak_shard_first_index
     torch, ma_amd, L, dev, dist = E.torch, E.ma, E.L, E.dev, E.dist
     rank, world = E.rank, E.world
-    read_len, preset = wl["read_len"], args.preset
+    read_len, preset = wl["read_len"], wl.get("preset") or args.preset
+    host_io = bool(args.host_io)
     K, W = wl["steps"], wl["warmup"]
     B_total = wl["reads_per_step"]  # reads per step and GPU (weak) / per step over all GPUs (strong)
     if args.scaling == "strong":
@@ -202,9 +222,43 @@ def run_workload(E, name, wl, args):
     NB = max(1, min(args.inflight, K))
     batches = []
 
+    # ---- host-to-host leg: the reads of every step start in page-locked host memory and the flat
+    # result arrays end in page-locked host memory.  The staging holds the reads of up to `hs` distinct steps (step k uses
+    # slot k mod hs; at most ~6 GB are page-locked), every batch in flight owns one set of result arrays.
+    hcodes = hoffs = None
+    hout = []
+    hs = 0
+    if host_io and n_reads > 0:
+        hs = int(max(1, min(K, 6e9 // max(max_bases, 1))))
+        hstride = max_bases + 64
+        hcodes = ma_amd.HostArray(hs * hstride, np.uint8)
+        hoffs = ma_amd.HostArray(hs * (B + 1), np.uint64)
+        for j in range(hs):
+            a, z = int(offs_h[j * B]), int(offs_h[j * B + B])
+            torch.from_numpy(hcodes.a[j * hstride:j * hstride + (z - a)]).copy_(codes[a:z])
+            hoffs.a[j * (B + 1):(j + 1) * (B + 1)] = offs_h[j * B:j * B + B + 1] - offs_h[j * B]
+        E.live_host += [hcodes, hoffs]
+
+    def grow_out(i, c):
+        for h in hout[i] or ():
+            h.close()
+        hout[i] = (ma_amd.HostArray(B + 1, np.uint64),
+                   ma_amd.HostArray(int(c["alignments"] * 1.25) + 4096, ma_amd.ALIGNMENT_DT),
+                   ma_amd.HostArray(int(2 * c["ops_cap"] * 1.25) + 4096, np.uint64))
+
     def step(i, k):
         bt = batches[i][0]
         lo_r = k * B
+        if host_io:
+            j = k % hs
+            bt.set_reads_flat(hcodes.ptr + j * (max_bases + 64), hoffs.ptr + 8 * j * (B + 1), B)
+            bt.align()
+            bt.sync()
+            if hout[i] is None or bt.mapq_alignments_into(*hout[i]) is None:
+                grow_out(i, bt.counts())  # first step of this batch object, or a step with more output than any before
+                if bt.mapq_alignments_into(*hout[i]) is None:
+                    raise RuntimeError("result arrays too small after growing them")
+            return
         nbases = int(offs_h[lo_r + B] - offs_h[lo_r])
         bt.set_reads_device(codes.data_ptr() + int(offs_h[lo_r]), offs.data_ptr() + 8 * k * (B + 1), B, nbases)
         bt.align()
@@ -218,6 +272,7 @@ def run_workload(E, name, wl, args):
             bt.set_stream(st.cuda_stream)
             bt.enable_timing(True)
             batches.append((bt, st))
+            hout.append(None)
             E.live.append(bt)  # closed by the caller if this workload fails half-way
         for w in range(W):  # warm-up: W steps on every batch object (each sizes its own buffers); untimed
             for i in range(NB):
@@ -308,6 +363,11 @@ def run_workload(E, name, wl, args):
         peak = float(E.cal["valu_mix_peak_ginst"])
         roofline.update({"bound": "valu", "achieved": round(valu / avg_s / 1e9, 1), "peak": peak, "unit": "G wave-inst/s",
                          "frac": round(valu / avg_s / 1e9 / peak, 3), "traffic": traffic,
+                         # the same rate against what the chip can issue at all (full-rate ops: 1024 SIMDs x 2.4 GHz / 2 cycles);
+                         # `peak` is the measured issue rate of THIS kernel's opcode mix (packed 16-bit ops, DPP: ~4 cycles)
+                         "frac_of_chip_valu_peak": round(valu / avg_s / 1e9 / CHIP_VALU_PEAK_GINST, 3),
+                         "chip_valu_peak": CHIP_VALU_PEAK_GINST,
+                         "lane_insts_per_cell": round(valu * 64.0 / max(ctr[4] / Kd, 1.0), 1),
                          "wave_insts_per_launch": valu, "wave_insts_source": src,
                          "peak_source": "profiles/r02_valu_mix.txt (dp_mix, 8 waves/SIMD)", "hbm": hbm})
     else:
@@ -323,13 +383,15 @@ def run_workload(E, name, wl, args):
 
     # ---- CPU baseline (rank 0, N = 1): the compiled reference and the oracle on this host's cores, then parity ---------
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_sample != 0 and n_reads > 0:
+    if rank == 0 and world == 1 and args.cpu_sample != 0 and n_reads > 0 and not host_io:
         cpu = cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, batches, roofline)
 
     res = None
     if rank == 0:
         res = {
-            "name": name, "baseline_config": wl.get("baseline_config"),
+            "name": name, "baseline_config": wl.get("baseline_config"), "batches_in_flight": NB,
+            "io": "host to host (reads from page-locked host memory, flat results into page-locked host memory)" if host_io
+                  else "device resident (reads and results stay in HBM)",
             "workload": "%d x %d bp reads (%.2f%% sub, %.2f%% ins, %.2f%% del), %s preset, %d reads/step %s" % (
                 n_global, read_len, 100 * wl["sub"], 100 * wl["ins"], 100 * wl["dele"], preset, B_total,
                 "per GPU" if args.scaling == "weak" else "over all GPUs"),
@@ -344,6 +406,13 @@ def run_workload(E, name, wl, args):
     for bt, _ in batches:
         bt.close()
     E.live.clear()
+    for hset in hout:
+        for h in hset or ():
+            h.close()
+    for h in (hcodes, hoffs):
+        if h is not None:
+            h.close()
+    E.live_host = []
     del codes, offs
     torch.cuda.empty_cache()
     return res
@@ -356,11 +425,12 @@ def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, 
     read_len = wl["read_len"]
     S = args.cpu_sample if args.cpu_sample > 0 else (wl["cpu_sample"] or min(n_reads, max(2000, int(4000 * ncores * 150 / max(read_len, 1)))))
     S = min(S, n_reads)
+    preset = wl.get("preset") or args.preset
     oidx = OrIndex.from_parts(E.idx.download())
     hb = int(offs_h[S])
     rc = codes[:hb].cpu().numpy()
     reads = [rc[int(offs_h[i]):int(offs_h[i + 1])] for i in range(S)]
-    op = or_params(args.preset, 1)
+    op = or_params(preset, 1)
     t1 = time.perf_counter()
     res = oidx.align(reads, op, threads=ncores)
     tc = time.perf_counter() - t1
@@ -374,7 +444,7 @@ def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, 
     # scales badly over many threads (glibc rand() lock, allocator), so a few thread counts are timed and the best is
     # the baseline; the 1-thread rate is measured on a smaller sample.
     ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
-    if os.path.exists(ref_dump) and not os.environ.get("MA_BENCH_NO_REFERENCE"):
+    if os.path.exists(ref_dump) and not os.environ.get("MA_BENCH_NO_REFERENCE") and wl.get("reference", True):
         td = tempfile.mkdtemp(prefix="ma_reads_")
         try:
             t2 = time.perf_counter()
@@ -385,7 +455,7 @@ def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, 
             write_case(os.path.join(td, "reads1.case"), [], reads[:S1])
 
             def timed(case, threads):
-                out = subprocess.run([ref_dump, "timeidx", prefix, os.path.join(td, case), args.preset, str(threads)],
+                out = subprocess.run([ref_dump, "timeidx", prefix, os.path.join(td, case), preset, str(threads)],
                                      capture_output=True, text=True, timeout=1800)
                 m = re.search(r"(\d+) reads \((\d+) aligned\) in ([0-9.]+) s on (\d+) threads", out.stdout)
                 if out.returncode != 0 or not m:
@@ -504,12 +574,191 @@ def boundary_leg(E, args):
         return {"error": repr(e)[:300]}
 
 
+def self_launch_or_check(args, argv):
+    """`--gpus N` is the contract: outside a torchrun environment N > 1 ranks are started HERE, as a child (one process per
+    GPU, RCCL), before this process has touched a GPU; inside one, WORLD_SIZE must be N (a 1-GPU number must never be printed
+    as an N-GPU one).  The reference's counterpart is one graph copy per thread (export.cpp:99-126, module.h:303-369)."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            print("bench.py: --gpus %d but WORLD_SIZE=%s: refusing to report a %s-rank run as %d GPUs" % (args.gpus, ws, ws, args.gpus),
+                  file=sys.stderr)
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    if os.environ.get("MA_BENCH_ONE_DEVICE") != "1" and os.environ.get("MA_BENCH_DRY_RUN") != "1":
+        import torch  # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print("bench.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, have), file=sys.stderr)
+            sys.exit(2)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.exit(subprocess.call(cmd))
+
+
+def dry_run(args):
+    """MA_BENCH_DRY_RUN=1 (CPU tests of the launch path): the ranks rendezvous over gloo, agree on who is there and rank 0
+    prints the line's launch fields -- no GPU is touched, nothing is measured."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    seen = [rank]
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group(backend="gloo")
+        t = torch.zeros(world, dtype=torch.int64)
+        t[rank] = 1
+        dist.all_reduce(t)
+        seen = [i for i in range(world) if int(t[i]) == 1]
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": seen, "gpus_flag": args.gpus,
+                          "local_rank_env": os.environ.get("LOCAL_RANK")}))
+
+
+def c1_anchor(E, args):
+    """BASELINE.md section 3's sanity anchor on configs[0] (C1): 1 k x 150 bp reads vs `ecoli_like` (one contig of 4 641 652 nt,
+    i.i.d., seed 1; the doubled text of 9.28 Mnt lies just below the 10 Mnt switch, so the drop-all / SoC heuristics are OFF,
+    binarySeeding.cpp:172-175, stripOfConsideration.cpp:21-23).  The oracle is raced against the compiled reference (one thread
+    each, the reference with ITS OWN index builder) and all three -- reference, oracle, GPU path -- must agree record by record."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ma_testlib import OrIndex, or_params, parse_pipe_dump, write_case
+    torch, ma_amd, L = E.torch, E.ma, E.L
+    F, n, rl = 4641652, 1000, 150
+    out = {"config": "configs[0] (C1): %d x %d bp reads vs ecoli_like (%d nt, seed 1), default preset, heuristics off (< 10 Mnt)" % (n, rl, F)}
+    g = torch.empty(F, dtype=torch.uint8, device=E.dev)
+    E.chk(L.ma_synth_genome_device(C.c_uint64(1), C.c_uint64(F), C.c_int32(0), C.c_void_p(g.data_ptr())))
+    idx = ma_amd.Index.build_device(np.array([F], dtype=np.uint64), g.data_ptr())
+    contig = g.cpu().numpy()
+    del g
+    codes = torch.empty(n * (rl + 8) + 1024, dtype=torch.uint8, device=E.dev)
+    offs = torch.empty(n + 2, dtype=torch.int64, device=E.dev)
+    nb = C.c_uint64()
+    E.chk(L.ma_synth_reads_device(idx.h, C.c_uint64(11), C.c_uint64(n), C.c_uint32(rl), C.c_double(0.005), C.c_double(0.0), C.c_double(0.0),
+                                  C.c_uint64(0), C.c_void_p(codes.data_ptr()), C.c_void_p(offs.data_ptr()), C.c_uint64(codes.numel()), C.byref(nb)))
+    oh = offs[:n + 1].cpu().numpy().astype(np.int64)
+    ch = codes.cpu().numpy()
+    reads = [ch[oh[i]:oh[i + 1]] for i in range(n)]
+    P = ma_amd.Params.preset("default")
+    bt = ma_amd.Batch(idx, P, n, int(oh[n]) + 64)
+    try:
+        bt.set_reads(reads)
+        bt.align()
+        bt.sync()
+        goff, galn, gops = bt.alignments()
+        moff, gmq, _ = bt.mapq_alignments()
+        # the oracle on the GPU-built index, one thread, best of three
+        oidx = OrIndex.from_parts(idx.download())
+        op = or_params("default", 1)
+        t_or = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            res = oidx.align(reads, op, threads=1)
+            t_or.append(time.perf_counter() - t0)
+        na = int(res["aln_off"][n])
+        same = (np.array_equal(goff, res["aln_off"][:n + 1]) and galn[:na].tobytes() == res["alns"][:na].tobytes()
+                and np.array_equal(moff, res["mq_off"][:n + 1])
+                and gmq["mapq"][:int(moff[n])].tobytes() == res["mq"]["mapq"][:int(moff[n])].tobytes())
+        out.update({"oracle_reads_per_s_1_thread": round(n / min(t_or), 1), "gpu_vs_oracle_identical": bool(same),
+                    "alignments": na, "aligned_reads": int(res["n_aligned"])})
+        ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+        if os.path.exists(ref_dump) and not os.environ.get("MA_BENCH_NO_REFERENCE"):
+            td = tempfile.mkdtemp(prefix="ma_c1_")
+            try:
+                case = os.path.join(td, "c1.case")
+                write_case(case, [contig], reads)
+                t_ref = []
+                for _ in range(3):  # `time`: the reference builds its own index of the case's contigs, then times its modules
+                    o = subprocess.run([ref_dump, "time", case, "default", "1"], capture_output=True, text=True, timeout=600)
+                    m = re.search(r"(\d+) reads \((\d+) aligned\) in ([0-9.]+) s on (\d+) threads", o.stdout)
+                    if o.returncode != 0 or not m:
+                        raise RuntimeError((o.stderr or o.stdout)[-300:])
+                    t_ref.append(float(m.group(3)))
+                subprocess.check_call([ref_dump, "pipe", case, "default", "1", os.path.join(td, "ref.pipe")], stdout=subprocess.DEVNULL,
+                                      timeout=600)
+                want = parse_pipe_dump(os.path.join(td, "ref.pipe"))
+                bad = 0
+                for r in range(n):
+                    a0, a1 = int(goff[r]), int(goff[r + 1])
+                    w = want[r]["alns"]
+                    ok = len(w) == a1 - a0
+                    for k in range(a1 - a0 if ok else 0):
+                        ga, wa = galn[a0 + k], w[k]
+                        o0 = int(ga["ops_off"])
+                        ok = ok and (int(ga["begin_ref"]), int(ga["end_ref"]), int(ga["begin_q"]), int(ga["end_q"]), int(ga["score"])) == (
+                            wa["bref"], wa["eref"], wa["bq"], wa["eq"], wa["score"])
+                        ok = ok and [(int(gops[2 * (o0 + j)]), int(gops[2 * (o0 + j) + 1])) for j in range(int(ga["n_ops"]))] == wa["ops"]
+                    m0, m1 = int(moff[r]), int(moff[r + 1])
+                    ok = ok and len(want[r]["mq"]) == m1 - m0
+                    for k in range(m1 - m0 if ok else 0):
+                        ok = ok and float("%.17g" % gmq[m0 + k]["mapq"]) == want[r]["mq"][k]["mapq"]
+                    bad += 0 if ok else 1
+                out.update({"reference_reads_per_s_1_thread": round(n / min(t_ref), 1),
+                            "oracle_over_reference": round(min(t_ref) / min(t_or), 3),
+                            "gpu_vs_reference_mismatching_reads": bad,
+                            "what": "the reference builds its own index of ecoli_like (is_bwt path); its alignments and mapping "
+                                    "qualities of all reads are compared with the GPU path's on the GPU-built index"})
+            except Exception as e:  # noqa: BLE001
+                out["reference_error"] = repr(e)[:300]
+            finally:
+                shutil.rmtree(td, ignore_errors=True)
+    finally:
+        bt.close()
+        idx.close()
+    return out
+
+
+def run_legs(E, name, wl, args):
+    """The three legs of one workload (module docstring); returns the single-stream block with the other legs attached."""
+    import copy
+    a1 = copy.copy(args)
+    a1.inflight, a1.host_io = 1, 0
+    r = run_workload(E, name, wl, a1)
+    nfl = args.overlap if wl["read_len"] <= 1000 else min(args.overlap, args.overlap_long)
+    if nfl > 1:
+        wl2 = dict(wl)
+        wl2["steps"] = max(wl["steps"], 2 * nfl)  # every batch object gets at least two timed steps
+        for key, hio in (("overlapped", 0), ("host_to_host", 1)):
+            a2 = copy.copy(args)
+            a2.inflight, a2.cpu_sample, a2.host_io = nfl, 0, hio
+            try:
+                r2, err = run_workload(E, name, wl2, a2), None
+            except RuntimeError as e:  # e.g. not enough HBM for that many long-read batches
+                r2, err = None, str(e)
+                for bt in E.live:
+                    bt.close()
+                E.live.clear()
+                for h in E.live_host:
+                    h.close()
+                E.live_host = []
+                E.torch.cuda.empty_cache()
+            if r is None:
+                continue
+            if r2 is None:
+                r[key] = {"batches_in_flight": nfl, "error": err}
+                continue
+            rf2 = dict(r2["roofline"])
+            rf2["leg"] = ("%d batches in flight, %s: a kernel's launch time includes the share of the chip the other batches' kernels "
+                          "took meanwhile" % (nfl, r2["io"]))
+            r[key] = {"batches_in_flight": nfl, "io": r2["io"], "value": r2["value"], "unit": r2["unit"], "steps": r2["steps"],
+                      "ms_per_step": r2["ms_per_step"], "step_ms_min": r2["step_ms_min"], "step_ms_max": r2["step_ms_max"],
+                      "gbases_per_s": r2["gbases_per_s"], "aligned_reads": r2["aligned_reads"],
+                      "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"], "roofline": rf2}
+    return r
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="all", choices=["all", "150bp", "10kb", "50kb"])
+    ap.add_argument("--workload", default="all", choices=["all", "150bp", "10kb", "50kb", "illumina"])
     ap.add_argument("--reads-per-step", type=int, default=0, help="override the workload's reads per step")
     ap.add_argument("--read-len", type=int, default=0, help="custom single workload with --sub/--ins/--dele")
     ap.add_argument("--sub", type=float, default=0.005)
@@ -519,15 +768,19 @@ def main():
     ap.add_argument("--preset", default="default")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--cpu-sample", type=int, default=-1, help="reads for the CPU baseline (-1 per workload, 0 off)")
-    ap.add_argument("--cpu-threads-sweep", type=int, default=1, help="also time the reference on a quarter of the threads")
+    ap.add_argument("--cpu-threads-sweep", type=int, default=0, help="also time the reference on a quarter of the threads")
     ap.add_argument("--boundary-reads", type=int, default=1000000, help="reads of the host-fed boundary leg (0 off)")
     ap.add_argument("--no-repeats", action="store_true")
-    ap.add_argument("--overlap", type=int, default=3, help="batches in flight of the additional overlapped leg (0/1 off)")
+    ap.add_argument("--overlap", type=int, default=3, help="batches in flight of the overlapped legs (0/1: single-stream leg only)")
     ap.add_argument("--overlap-long", type=int, default=2, help="the same for reads longer than 1 kb (a batch holds ~110 GB of HBM)")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="batches in flight per GPU (own stream + host thread each): while one batch is in its "
-                         "VALU-bound DP kernels another runs its memory-bound seeding / chaining")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="run ONE leg only, with this many batches in flight per GPU (own stream + host thread each; profiling runs)")
+    ap.add_argument("--host-io", type=int, default=0, help="with --inflight: that leg host to host (1) or device resident (0)")
+    ap.add_argument("--detail-file", default="", help="where the per-workload blocks go (default: gpurun_out/bench_detail.json)")
     args = ap.parse_args()
+    self_launch_or_check(args, sys.argv[1:])
+    if os.environ.get("MA_BENCH_DRY_RUN") == "1":
+        return dry_run(args)
 
     E = Env(args)
     wls = []
@@ -538,83 +791,135 @@ def main():
                                    reads_per_step=B, steps=args.steps, warmup=args.warmup, cpu_sample=None,
                                    baseline_config=None)))
     else:
-        for name in (["150bp", "10kb", "50kb"] if args.workload == "all" else [args.workload]):
+        for name in (["150bp", "10kb", "50kb", "illumina"] if args.workload == "all" else [args.workload]):
             wl = dict(WORKLOADS[name])
             if wl["steps"] is None or args.workload != "all":
                 wl["steps"], wl["warmup"] = args.steps, args.warmup
-            if args.reads_per_step > 0 and (name == "150bp" or args.workload != "all"):
+            if args.reads_per_step > 0 and (wl["read_len"] <= 1000 or args.workload != "all"):
                 wl["reads_per_step"] = args.reads_per_step
             wls.append((name, wl))
     results = []
     for name, wl in wls:
-        r = run_workload(E, name, wl, args)
-        # the same workload once more with several batches in flight (own streams and host threads): the memory-bound
-        # stages of one batch overlap the issue-bound DP kernels of another.  Reported beside the single-stream numbers,
-        # whose per-kernel times stay those of undisturbed launches.
-        nfl = args.overlap if wl["read_len"] <= 1000 else min(args.overlap, args.overlap_long)
-        if nfl > 1 and args.inflight == 1:
-            import copy
-            a2 = copy.copy(args)
-            a2.inflight, a2.cpu_sample = nfl, 0
-            wl2 = dict(wl)
-            wl2["steps"] = max(wl["steps"], 2 * nfl)  # every batch object gets at least two timed steps
-            try:
-                r2 = run_workload(E, name, wl2, a2)
-                err = None
-            except RuntimeError as e:  # e.g. not enough HBM for that many long-read batches
-                r2, err = None, str(e)
-                for bt in E.live:
-                    bt.close()
-                E.live.clear()
-                E.torch.cuda.empty_cache()
-            if r is not None:
-                if r2 is not None:
-                    rf2 = dict(r2["roofline"])
-                    rf2["leg"] = ("%d batches in flight: a kernel's launch time includes the share of the chip the other batches' "
-                                  "kernels took meanwhile" % nfl)
-                    r["overlapped"] = {"batches_in_flight": nfl, "value": r2["value"], "unit": r2["unit"], "steps": r2["steps"],
-                                       "ms_per_step": r2["ms_per_step"], "step_ms_min": r2["step_ms_min"], "step_ms_max": r2["step_ms_max"],
-                                       "gbases_per_s": r2["gbases_per_s"], "aligned_reads": r2["aligned_reads"],
-                                       "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"], "roofline": rf2}
-                else:
-                    r["overlapped"] = {"batches_in_flight": nfl, "error": err}
+        if args.inflight > 0:  # one explicit leg (what a rocprofv3 run of a single leg uses)
+            r = run_workload(E, name, wl, args)
+        else:
+            r = run_legs(E, name, wl, args)
         if r is not None:
             results.append(r)
-    boundary = None
-    if E.rank == 0 and E.world == 1 and args.boundary_reads > 0 and args.cpu_sample != 0 and args.read_len == 0:
+    boundary = anchor = None
+    full = E.rank == 0 and E.world == 1 and args.cpu_sample != 0 and args.read_len == 0 and args.inflight == 0
+    if full and args.workload == "all":
+        try:
+            anchor = c1_anchor(E, args)
+        except Exception as e:  # noqa: BLE001
+            anchor = {"error": repr(e)[:300]}
+    if full and args.boundary_reads > 0:
         boundary = boundary_leg(E, args)
     if E.rank == 0:
-        head = results[0]
-        # The headline is the throughput of the job as a production run schedules it (BatchAligner: several device batches
-        # in flight per GPU, ma_engine.h) when that leg ran and is faster; the single-stream leg -- whose undisturbed
-        # launches the roofline block is measured on -- stays in workloads[0].value / ms_per_step.
-        ov = head.get("overlapped") or {}
-        use_ov = "value" in ov and ov["value"] > head["value"]
-        top = ov if use_ov else head
-        out = {
-            "metric": "aligned reads/sec (whole node), 150bp & 10kb synthetic vs GRCh38",
-            "value": top["value"], "unit": "aligned reads/s", "n_gpus": E.world, "steps": top["steps"], "warmup": head["warmup"],
-            "ms_per_step": top["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "u8/int8 (2-bit BWT ranks, int8 DP differences, int16/32 scores)",
-            "data": "synthetic",
-            "config": {"workload": head["workload"] + " vs GRCh38-like synthetic genome (%d contigs, %d nt%s)" % (
-                           len(E.lens), E.F, "" if args.no_repeats else ", planted repeats"),
-                       "value_is": "workload '%s' (%s), %s" % (
-                           head["name"], head["baseline_config"],
-                           "%d batches in flight per GPU (workloads[0].overlapped); one batch at a time: workloads[0].value = %.1f"
-                           % (ov["batches_in_flight"], head["value"]) if use_ov else "one batch at a time"),
-                       "reads_per_s_total": head["reads_per_s_total"], "index_build_s": round(E.t_index, 2),
-                       "parallelism": "reads partitioned over %d GPU(s) (%s scaling), index replicated, no collective; %d "
-                                      "batch(es) in flight per GPU" % (E.world, args.scaling,
-                                                                      ov["batches_in_flight"] if use_ov else max(1, args.inflight)),
-                       "workloads": results, "boundary": boundary},
-            # of the leg `value` comes from; the undisturbed one-batch-at-a-time launches are in workloads[0].roofline
-            "roofline": ov["roofline"] if use_ov else head["roofline"], "cpu_baseline": head["cpu_baseline"],
-        }
-        print(json.dumps(out))
+        print(compose_line(E, args, results, boundary, anchor))
     E.close()
     if E.dist is not None:
         E.dist.destroy_process_group()
+
+
+def leg_of(block, key):
+    """(value, ms_per_step, batches in flight) of a workload's leg, or Nones"""
+    leg = block if key is None else (block.get(key) or {})
+    return leg.get("value"), leg.get("ms_per_step"), leg.get("batches_in_flight")
+
+
+def compose_line(E, args, results, boundary, anchor):
+    """The ONE line of rank 0: top-level scalars for every workload (the driver keeps the tail of stdout and the scalar fields
+    of the line), the roofline and CPU baseline of the leg `value` comes from; everything else goes to the detail file."""
+    head = results[0]
+    # headline = the host-to-host leg (BASELINE.md section 3: first read in host memory -> last alignment record in host memory)
+    key = "host_to_host" if "value" in (head.get("host_to_host") or {}) else ("overlapped" if "value" in (head.get("overlapped") or {}) else None)
+    top = head if key is None else head[key]
+    detail = {"workloads": results, "boundary": boundary, "c1_anchor": anchor, "kernel_source_hash": kernel_source_hash()}
+    dpath = args.detail_file or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(dpath), exist_ok=True)
+        with open(dpath, "w") as f:
+            json.dump(detail, f)
+    except OSError as e:
+        dpath = "not written (%s)" % e
+    print("bench detail: " + json.dumps(detail), file=sys.stderr, flush=True)
+    out = {
+        "metric": "aligned reads/sec (whole node), 150bp & 10kb synthetic vs GRCh38",
+        "value": top["value"], "unit": "aligned reads/s", "n_gpus": E.world, "steps": top["steps"], "warmup": head["warmup"],
+        "ms_per_step": top["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
+        "vs_baseline": None, "dtype": "u8/int8 (2-bit BWT ranks, int8 DP differences, int16/32 scores)",
+        "data": "synthetic",
+    }
+    # every workload as top-level scalars: host to host (the timed region of BASELINE.md section 3), device resident with the same
+    # batches in flight, and one batch at a time (the leg the per-kernel roofline is measured on)
+    for r in results:
+        n = {"150bp": "150bp", "10kb": "10kb", "50kb": "50kb", "illumina": "150bp_illumina"}.get(r["name"], r["name"])
+        v, ms, nb = leg_of(r, "host_to_host")
+        if v is not None:
+            out["value_%s" % n], out["ms_per_step_%s" % n], out["batches_in_flight_%s" % n] = v, ms, nb
+        v2, ms2, _ = leg_of(r, "overlapped")
+        if v2 is not None:
+            out["value_%s_device_resident" % n], out["ms_per_step_%s_device_resident" % n] = v2, ms2
+        out["value_%s_single_stream" % n], out["ms_per_step_%s_single_stream" % n] = r["value"], r["ms_per_step"]
+        if v is None and v2 is None:
+            out["value_%s" % n], out["ms_per_step_%s" % n], out["batches_in_flight_%s" % n] = r["value"], r["ms_per_step"], r.get("batches_in_flight")
+        cb = r.get("cpu_baseline") or {}
+        if cb.get("value") is not None and cb.get("kind") == "reference":
+            out["cpu_reference_%s" % n] = cb["value"]
+            out["cpu_reference_threads_%s" % n] = cb.get("cores")
+        pc = cb.get("parity_check")
+        if pc:
+            out["parity_%s" % n] = "%d mismatching of %d reads (%d alignments, %d ops) vs oracle" % (
+                pc["mismatching_reads"], pc["reads"], pc["alignments"], pc["alignment_ops"])
+        rf = r.get("roofline") or {}
+        if rf.get("kernel"):
+            out["roofline_%s" % n] = "%s %.2f ms/launch: %s frac %s of %s %s%s; hbm frac %s" % (
+                rf["kernel"], rf["avg_launch_ms"], rf.get("bound"), rf.get("frac"), rf.get("peak"), rf.get("unit"),
+                ", %s of the chip's VALU issue peak, %s lane-instructions per cell" % (rf.get("frac_of_chip_valu_peak"), rf.get("lane_insts_per_cell"))
+                if rf.get("bound") == "valu" else "", (rf.get("hbm") or rf).get("frac"))
+    if anchor:
+        out["c1_anchor"] = ("error: " + anchor["error"]) if "error" in anchor else (
+            "oracle %s reads/s vs reference %s reads/s (1 thread each, %s); GPU vs reference: %s mismatching of 1000 reads; GPU vs oracle identical: %s" % (
+                anchor.get("oracle_reads_per_s_1_thread"), anchor.get("reference_reads_per_s_1_thread"), "ecoli_like 4 641 652 nt",
+                anchor.get("gpu_vs_reference_mismatching_reads", anchor.get("reference_error", "reference not on this box")),
+                anchor.get("gpu_vs_oracle_identical")))
+    if isinstance(boundary, dict) and "error" not in boundary:
+        g = boundary.get("graph") or {}
+        if g.get("reads_per_s") is not None:
+            out["dropin_graph_reads_per_s"] = g.get("reads_per_s")
+            out["dropin_graph_threads"] = g.get("threads")
+    out["config"] = {
+        "workload": head["workload"] + " vs GRCh38-like synthetic genome (%d contigs, %d nt%s)" % (
+            len(E.lens), E.F, "" if args.no_repeats else ", planted repeats"),
+        "value_is": "workload '%s' (%s), %s" % (
+            head["name"], head["baseline_config"],
+            "one batch at a time, device resident" if key is None else
+            "%d batches in flight per GPU, %s; the same batches with reads and results resident in HBM: value_150bp_device_resident" % (
+                top["batches_in_flight"], top.get("io", ""))),
+        "reads_per_s_total": head["reads_per_s_total"], "index_build_s": round(E.t_index, 2),
+        "parallelism": "reads partitioned over %d GPU(s) (%s scaling), index replicated, no collective; %s batch(es) in flight per GPU" % (
+            E.world, args.scaling, top.get("batches_in_flight", 1)),
+        "detail_file": os.path.relpath(dpath, ROOT) if os.path.isabs(dpath) else dpath,
+        "kernel_source_hash": kernel_source_hash(),
+    }
+    # of the leg `value` comes from (under overlap a kernel's launch time includes the share of the chip the other batches'
+    # kernels took); the undisturbed one-batch-at-a-time launches: roofline_150bp above and the detail file
+    rf = dict(top["roofline"])
+    rf.pop("kernel_ms_per_step", None)
+    hb = rf.get("hbm")
+    if isinstance(hb, dict):
+        hb.pop("pmc_replay_refused", None)
+    out["roofline"] = rf
+    cb = dict(head.get("cpu_baseline") or {})
+    cb.pop("port", None)
+    if "sample" in cb:
+        cb["sample"] = cb["sample"][:160]
+    pc = cb.get("parity_check")
+    if isinstance(pc, dict):
+        pc.pop("what", None)
+    out["cpu_baseline"] = cb or None
+    return json.dumps(out)
 
 
 if __name__ == "__main__":

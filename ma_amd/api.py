@@ -99,6 +99,30 @@ def set_device(d):
     _chk(lib().ma_set_device(C.c_int(d)))
 
 
+class HostArray:
+    """Page-locked host memory (ma_host_alloc) as a numpy array: uploads from it and downloads into it are DMA transfers
+    that run asynchronously on the batch's stream, so the copies of one batch hide behind the kernels of another."""
+
+    def __init__(self, n, dtype):
+        self.dtype = np.dtype(dtype)
+        self.n = int(n)
+        self.p = C.c_void_p()
+        nbytes = max(self.n * self.dtype.itemsize, 64)
+        _chk(lib().ma_host_alloc(C.c_uint64(nbytes), C.byref(self.p)))
+        buf = (C.c_char * nbytes).from_address(self.p.value)
+        self.a = np.frombuffer(buf, dtype=self.dtype, count=self.n)
+
+    @property
+    def ptr(self):
+        return self.p.value
+
+    def close(self):
+        if self.p:
+            self.a = None
+            lib().ma_host_free(self.p)
+            self.p = None
+
+
 class Index:
     """Device-resident FMD-index + pack (ma_index*)."""
 
@@ -276,6 +300,11 @@ class Batch:
         _chk(lib().ma_batch_set_reads(self.h, _ptr(cat), _ptr(off), C.c_uint64(len(reads))))
         self.n = len(reads)
 
+    def set_reads_flat(self, codes_ptr, offsets_ptr, n_reads):
+        """reads that already are one host array of codes + CSR offsets (n + 1 u64, starting at 0), e.g. in page-locked memory"""
+        _chk(lib().ma_batch_set_reads(self.h, C.c_void_p(int(codes_ptr)), C.c_void_p(int(offsets_ptr)), C.c_uint64(n_reads)))
+        self.n = n_reads
+
     def set_reads_device(self, d_codes_ptr, d_offsets_ptr, n_reads, n_bases):
         _chk(lib().ma_batch_set_reads_device(self.h, C.c_void_p(int(d_codes_ptr)), C.c_void_p(int(d_offsets_ptr)),
                                              C.c_uint64(n_reads), C.c_uint64(n_bases)))
@@ -395,6 +424,15 @@ class Batch:
 
     def mapq_alignments(self):
         return self._alns(lib().ma_batch_get_mapq_alignments)
+
+    def mapq_alignments_into(self, off, alns, ops):
+        """The MappingQuality records into caller-owned host arrays (HostArray: u64[n + 1], ALIGNMENT_DT[>= alignments],
+        u64[>= 2 * ops_cap + 2]); returns None when they are too small (the caller grows them), else the counts."""
+        c = self.counts()
+        if off.n < self.n + 1 or alns.n < c["alignments"] + 1 or ops.n < 2 * c["ops_cap"] + 2:
+            return None
+        _chk(lib().ma_batch_get_mapq_alignments(self.h, C.c_void_p(off.ptr), C.c_void_p(alns.ptr), C.c_void_p(ops.ptr)))
+        return c
 
     def close(self):
         if self.h:

@@ -279,8 +279,11 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( R 
 #endif
 }
 
+#if !defined( MA_PK5_WAVES )
+#define MA_PK5_WAVES 4
+#endif
 template <typename FETCH, int S>
-__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( S >= 5 ? 4 : 3 ) ) ) k_ksw_pk( FETCH F, KswScoring SC, KswJobs JB, unsigned int* nextSlot,
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( S >= 5 ? MA_PK5_WAVES : 3 ) ) ) k_ksw_pk( FETCH F, KswScoring SC, KswJobs JB, unsigned int* nextSlot,
                                                   uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];

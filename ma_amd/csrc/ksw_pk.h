@@ -15,6 +15,15 @@
 #if defined( __HIPCC__ )
 namespace ma
 {
+#if defined( MA_KSW_PROF )
+// diagnostics build only: wave cycles of the phases of one diagonal of ksw_pk_core, summed over all jobs (tools/pk_prof.py)
+static __device__ unsigned long long g_pk_prof[ 16 ];
+#define PK_PROF_T( v ) const unsigned long long v = clock64( )
+#define PK_PROF_ADD( i, a, b ) pkp[ i ] += ( b ) - ( a )
+#else
+#define PK_PROF_T( v )
+#define PK_PROF_ADD( i, a, b )
+#endif
 // ring slots (128 cells each) a job needs here: the touched range of a diagonal is [st, st + m + 29]
 MA_HD i32 ksw_pk_slots( i32 qlen, i32 tlen, i32 w )
 {
@@ -97,18 +106,23 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     };
     // tags (ksw_ext.h): LEFT keeps the first maximum of (s, a, b, a2, b2): d = 4 - tag; RIGHT the last of (s, a, b, a2)
     const u32 tS = LEFT ? 4 : 0, tX = LEFT ? 3 : 1, tY = 2, tX2 = LEFT ? 1 : 3, tY2 = 0;
+#if defined( MA_PK_KV )
+#define PK_K( x ) pk_opaque( x ) // experiment: the slot body's constants in VGPRs (for builds with fewer waves per SIMD)
+#else
+#define PK_K( x ) ( x )
+#endif
     const u32 K_X0 = pk_val( -q - e, tX ), K_Y0 = pk_val( -q - e, tY ), K_X20 = pk_val( -q2 - e2, tX2 ),
               K_Y20 = pk_val( -q2 - e2, tY2 ), K_V0 = pk_val( -q - e, 0 ), K_S0 = pk_val( 0, tS );
-    const u32 K_TX = pk_val( 0, tX ), K_TY = pk_val( 0, tY ), K_TX2 = pk_val( 0, tX2 ), K_TY2 = pk_val( 0, tY2 );
-    const u32 K_Q = pk_val( q, 0 ), K_Q2 = pk_val( q2, 0 ), K_QE = pk_val( q + e, 0 ), K_QE2 = pk_val( q2 + e2, 0 );
-    const u32 K_MCH = pk_val( sc_mch, tS ), K_NDIFF = pk_val( sc_mis - sc_mch, 0 ), K_NADJ = pk_val( -e2 - sc_mis, 0 );
-    const u32 K_CLIP = pk_val( sc_mch, 0xff );
+    const u32 K_TX = PK_K( pk_val( 0, tX ) ), K_TY = pk_val( 0, tY ), K_TX2 = PK_K( pk_val( 0, tX2 ) ), K_TY2 = pk_val( 0, tY2 );
+    const u32 K_Q = PK_K( pk_val( q, 0 ) ), K_Q2 = PK_K( pk_val( q2, 0 ) ), K_QE = PK_K( pk_val( q + e, 0 ) ), K_QE2 = PK_K( pk_val( q2 + e2, 0 ) );
+    const u32 K_MCH = PK_K( pk_val( sc_mch, tS ) ), K_NDIFF = PK_K( pk_val( sc_mis - sc_mch, 0 ) ), K_NADJ = pk_val( -e2 - sc_mis, 0 );
+    const u32 K_CLIP = PK_K( pk_val( sc_mch, 0xff ) );
     // lane 0 continues lane 63 of the previous ring slot: a bit mask for ONE v_bitop3 per neighbour view (written as
     // lane == 0 ? px[sp] : px[s] the compiler indexes the register array dynamically: 4 v_cndmask per view for R = 5)
     const u32 M_LANE0 = pk_opaque( lane == 0 ? 0xffffffffu : 0u );
     const u32 M_LEFT = pk_opaque( LEFT ? 0xffffffffu : 0u ), K_DX = pk_opaque( LEFT ? 0x00070007u : 0u ), K_DS = pk_opaque( LEFT ? 0x00030003u : 0u );
-    const u32 K_FX = pk_sub( K_TX, LEFT ? 0u : 0x00010001u ), K_FY = pk_sub( K_TY, LEFT ? 0u : 0x00010001u ),
-              K_FX2 = pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ), K_FY2 = pk_sub( K_TY2, LEFT ? 0u : 0x00010001u );
+    const u32 K_FX = PK_K( pk_sub( K_TX, LEFT ? 0u : 0x00010001u ) ), K_FY = PK_K( pk_sub( K_TY, LEFT ? 0u : 0x00010001u ) ),
+              K_FX2 = PK_K( pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ) ), K_FY2 = PK_K( pk_sub( K_TY2, LEFT ? 0u : 0x00010001u ) );
     const u32 K_ONES = pk_opaque( 0x00010001u );
 
     // The reversed query in LDS.  A diagonal r reads the bases r - t of its cells, and the loop below ends after
@@ -121,14 +135,29 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         return lo > 64 ? ( lo & ~15 ) : 0;
     }( );
     const uint8_t* qrT = qLo ? qr + 64 - qLo : qr;
+    // Bases >= 4 (N) anywhere in what this job can read switch the score profile to its general form; without them (the
+    // pack holds no N, reads rarely do) match / mismatch is all there is: three instructions per slot instead of seven.
+    u32 nAcc = 0;
     if( qLo == 0 )
         for( i32 t = lane; t < qrBytes; t += 64 )
-            qr[ t ] = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
+        {
+            const uint8_t b = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
+            qr[ t ] = b;
+            nAcc |= b;
+        }
     else
     {
-        qr[ lane ] = lane < qlen ? (uint8_t)qbase( qlen - 1 - lane ) : (uint8_t)0;
+        {
+            const uint8_t b = lane < qlen ? (uint8_t)qbase( qlen - 1 - lane ) : (uint8_t)0;
+            qr[ lane ] = b;
+            nAcc |= b;
+        }
         for( i32 t = qLo + lane; t < qrBytes; t += 64 )
-            qr[ 64 + t - qLo ] = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
+        {
+            const uint8_t b = t < qlen ? (uint8_t)qbase( qlen - 1 - t ) : (uint8_t)0;
+            qr[ 64 + t - qLo ] = b;
+            nAcc |= b;
+        }
     }
     __syncthreads( );
 
@@ -160,8 +189,10 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         Y2[ s ] = K_Y20;
         Sp[ s ] = K_S0;
         T[ s ] = tgtAt( TT[ s ] ) | tgtAt( TT[ s ] + 1 ) << 16;
+        nAcc |= T[ s ];
         Hlo[ s ] = Hhi[ s ] = NEG;
     }
+    int hasN = __any( ( nAcc & 0x00fc00fcu ) != 0 ) ? 1 : 0; // wave-uniform; a recycled ring slot can still set it
     i32 last_st = -1, last_en = -1, cur_st = 0;
     // calcMaxScore (kswcpp_core.h:156-299) of one diagonal: the H of the cells of [st0, en0) as the lanes hold them (hl / hh: the
     // low / high cell of ring slot s, tts: the low cell's index), H[en0] = hE -> the SSE code's (max_H, max_t)
@@ -270,15 +301,19 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     const i32 earlyFrom = earlySparse ? w + 3 : qlen; // first diagonal at which B_r and B_{r-1} cover every in-band chain
     i32 topH = 0, boundPrev = 0x7fffffff; // H(r-1,-1) of the first-row boundary; B_{r-1} (ksw_reg.h)
     uint8_t* prow = P; // direction row of the current diagonal
+#if defined( MA_KSW_PROF )
+    unsigned long long pkp[ 12 ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
     for( i32 r = 0; r < nDiag && !stop; ++r )
     {
+        PK_PROF_T( tp0 );
         // ---- bounds (kswcpp_core.h:541-559)
         i32 st0 = 0, en0 = tlen - 1;
         st0 = max( st0, r - qlen + 1 );
         en0 = min( en0, r );
         st0 = max( st0, ( r - w + 1 ) >> 1 );
         en0 = min( en0, ( r + w ) >> 1 );
-        if( st0 > en0 )
+        if( __builtin_expect( st0 > en0, 0 ) )
         {
             ez.zdropped = 1;
             break;
@@ -288,7 +323,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         u32 x1 = K_X0 & 0xffffu, x21 = K_X20 & 0xffffu, v1 = K_V0 & 0xffffu; // one 16-bit half each
         if( st == 0 )
             v1 = ( (u32)initOf( r ) & 0xffu ) << 8;
-        if( st != cur_st )
+        if( __builtin_expect( st != cur_st, 0 ) ) // every 32nd diagonal
         {
             const int jOld = ( cur_st >> 7 ) % R; // slot that holds [cur_st, cur_st + 16)
             const int src = ( ( st - 1 ) >> 1 ) & 63; // cell st-1 is the HIGH half of this lane
@@ -318,6 +353,8 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                         Hlo[ s ] = Hhi[ s ] = NEG;
                         T[ s ] = tgtAt( TT[ s ] ) | tgtAt( TT[ s ] + 1 ) << 16;
                     }
+                    if( !hasN && __any( ( T[ s ] & 0x00fc00fcu ) != 0 ) )
+                        hasN = 1;
                 }
             cur_st = st;
         }
@@ -332,6 +369,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         cells += (u64)( en - st + 1 );
         const i32 hi = max( en, pEnd - 1 );
         const i32 en1 = st0 + ( ( ( en0 - st0 ) >> HLs ) << HLs );
+        const u32 hLen = (u32)( en0 - st0 );
         const int b0 = st >> 7, j0 = __builtin_amdgcn_readfirstlane( b0 % R );
         const int nAct = __builtin_amdgcn_readfirstlane( ( hi >> 7 ) - b0 + 1 ); // ring slots from j0 on that hold touched cells
         // wave-uniform access to ONE cell of the ring (t in [st, st + RING)): slot, then a lane read
@@ -358,6 +396,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             return ( t & 1 ) ? pk_hi8( v ) : pk_lo8( v );
         };
         const int stLane = ( st >> 1 ) & 63; // cell st = low half of this lane of slot j0
+        PK_PROF_T( tp1 );
         // previous-lane views (lane i <- lane i-1; lane 0 continues lane 63 of the previous slot of the ring)
         u32 px[ R ], pv[ R ], px2[ R ];
 #pragma unroll
@@ -374,7 +413,9 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
 #pragma unroll
         for( int s = 0; s < R; s++ )
             QB[ s ] = (u32)qrT[ qoff + TT[ s ] ] | (u32)qrT[ qoff + TT[ s ] + 1 ] << 16;
+        const int hasNU = __builtin_amdgcn_readfirstlane( hasN );
         __builtin_amdgcn_sched_barrier( 0 );
+        PK_PROF_T( tp2 );
 #pragma unroll
         for( int s = 0; s < R; s++ )
         {
@@ -389,14 +430,16 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             u32 x2t1 = cells_shift1( X2[ s ], R == 1 ? px2[ s ] : pk_bfi( M_LANE0, px2[ sp ], px2[ s ] ) );
             if( s == j0 )
             {
-                // cell st takes the carry-in
+                // cell st takes the carry-in.  A real scalar branch: if-converted (the compiler's choice for three selects) EVERY
+                // slot pays three v_bitop3 and three v_cndmask for the one slot that has the cell
+                asm volatile( "" );
                 const u32 m = lane == stLane ? 0x0000ffffu : 0u;
                 xt1 = pk_bfi( m, x1, xt1 );
                 vt1 = pk_bfi( m, v1, vt1 );
                 x2t1 = pk_bfi( m, x21, x2t1 );
             }
             // first row / column initialisation of cell r
-            if( initRowU )
+            if( __builtin_expect( initRowU != 0, 0 ) )
             {
                 // cell r = half (r - tt) of the lane with tt <= r <= tt + 1
                 const u32 m = pk_opaque( tt == r ? 0x0000ffffu : ( tt + 1 == r ? 0xffff0000u : 0u ) );
@@ -407,10 +450,16 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             // score profile of the cells in [st0, pEnd): match / mismatch, -e2 when either base is N
             {
                 const u32 b = QB[ s ];
-                const u32 isN = pk_lshr( T[ s ] | b, 2 );
-                const u32 differ = pk_min1( ( T[ s ] ^ b ) | isN, K_ONES );
-                u32 val = pk_mad( differ, K_NDIFF, K_MCH );
-                val = pk_mad( isN, K_NADJ, val );
+                u32 val;
+                if( __builtin_expect( hasNU != 0, 0 ) )
+                {
+                    const u32 isN = pk_lshr( T[ s ] | b, 2 );
+                    const u32 differ = pk_min1( ( T[ s ] ^ b ) | isN, K_ONES );
+                    val = pk_mad( differ, K_NDIFF, K_MCH );
+                    val = pk_mad( isN, K_NADJ, val );
+                }
+                else
+                    val = pk_mad( pk_min1( T[ s ] ^ b, K_ONES ), K_NDIFF, K_MCH );
                 // cells in [st0, pEnd): (t - st0) mod 2^16 < pEnd - st0, per half (the window is < 2^15 cells wide)
                 const u32 inProf = pk_nonzero15( pk_subsatu( profLen, pk_sub( PT[ s ], profSt ) ) );
                 Sp[ s ] = pk_bfi( inProf, val, Sp[ s ] );
@@ -461,21 +510,23 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             // are picked out of the registers after the loop with wave-uniform lane reads.
             if( r > 0 && !noHU )
             {
+                // cells of [st0, en0): one unsigned compare per half, (t - st0) < en0 - st0
                 const i32 vlo = pk_lo8( nv ), vhi = pk_hi8( nv );
-                if( tt >= st0 && tt < en0 )
-                {
-                    Hlo[ s ] = TH( Hlo[ s ] + vlo );
-                    laneMax = max( laneMax, Hlo[ s ] );
-                }
-                if( tt + 1 >= st0 && tt + 1 < en0 )
-                {
-                    Hhi[ s ] = TH( Hhi[ s ] + vhi );
-                    laneMax = max( laneMax, Hhi[ s ] );
-                }
+                const u32 d0 = (u32)( tt - st0 );
+                const bool inLo = d0 < hLen, inHi = d0 + 1u < hLen;
+                const i32 nlo = TH( Hlo[ s ] + vlo ), nhi = TH( Hhi[ s ] + vhi );
+                Hlo[ s ] = inLo ? nlo : Hlo[ s ];
+                Hhi[ s ] = inHi ? nhi : Hhi[ s ];
+                laneMax = max( laneMax, max( inLo ? nlo : (i32)0x80000000, inHi ? nhi : (i32)0x80000000 ) );
             }
             // keep the slots' instruction streams apart: interleaving them multiplies the live temporaries by R
             __builtin_amdgcn_sched_barrier( 0 );
         }
+        PK_PROF_T( tp3 );
+#if defined( MA_KSW_PROF )
+        pkp[ 7 ] += (unsigned long long)nAct;
+        unsigned long long tp4 = tp3;
+#endif
         i32 max_H = (i32)0x80000000, max_t = 0, hEnd = 0, hS = 0;
         bool raised = false;
         if( noHU )
@@ -487,7 +538,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             // homomorphism, so TH commutes); below st it has left the ring and is the carry-in hBelow.
             i32 hEn0;
             const int sE = slotOf( en0 ), lE = ( en0 >> 1 ) & 63;
-            if( ( en0 & 127 ) != 0 && en0 - 1 >= st )
+            if( __builtin_expect( ( en0 & 127 ) != 0 && en0 - 1 >= st, 1 ) )
             {
                 // the usual case: cells en0 - 1 and en0 sit in the same ring slot -- one pass over the slots reads the three
                 // registers involved and puts H[en0] in place (each separate pick is an R-way chain of scalar branches)
@@ -539,6 +590,9 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
                     }
             }
             hEnd = hEn0;
+#if defined( MA_KSW_PROF )
+            tp4 = clock64( );
+#endif
             hS = r - st0 != qlen - 1 ? 0 : st0 == en0 ? hEn0 : pickCell( Hlo, Hhi, st0 ); // only read on the last query row (mqe below)
             // The exact (max_H, max_t) -- the class-wise first maxima of the SSE code, ~240 instructions -- is only consumed when
             // the diagonal raises ez.max or could z-drop (ksw_reg.h).  A diagonal that RAISES ez.max (every other one while
@@ -552,7 +606,23 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             bool need = false;
             if( raised )
             {
-                const i32 m = max( hEn0, wave_max_i32( laneMax ) );
+                // the new ez.max = the largest H of the diagonal.  While an alignment runs, ONE lane is above the old maximum
+                // (the cell on the alignment's diagonal): its value is a lane read; the reduction over the lanes (12 DPP steps)
+                // only runs when several are
+                const unsigned long long above = __ballot( laneMax > (i32)ez.max );
+                i32 m = hEn0;
+                if( above != 0 )
+                {
+                    i32 mm;
+                    if( ( above & ( above - 1 ) ) == 0 )
+                        mm = __builtin_amdgcn_readlane( laneMax, (int)__builtin_ctzll( above ) );
+                    else
+                    {
+                        asm volatile( "" ); // keeps the reduction on its own side of the branch
+                        mm = wave_max_i32( laneMax );
+                    }
+                    m = max( m, mm );
+                }
 #pragma unroll
                 for( int s = 0; s < R; s++ )
                     snap[ s * 64 + lane ] = make_int2( Hlo[ s ], Hhi[ s ] );
@@ -561,11 +631,15 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             }
             else if( J.zdrop >= 0 )
                 need = hEn0 < (i32)ez.max - J.zdrop && __any( laneMax >= (i32)ez.max - J.zdrop ) == 0;
-            if( need )
+            if( __builtin_expect( need, 0 ) )
             {
                 resolvePending( );
                 exactMax( Hlo, Hhi, TT, st0, en0, hEn0, max_H, max_t );
             }
+#if defined( MA_KSW_PROF )
+            pkp[ 8 ] += raised ? 1 : 0;
+            pkp[ 9 ] += need ? 1 : 0;
+#endif
         }
         else
         {
@@ -578,6 +652,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
             hEnd = h0;
             hS = h0;
         }
+        PK_PROF_T( tp5 );
         if( noHU )
             ;
         else if( en0 == tlen - 1 && hEnd > ez.mte )
@@ -605,7 +680,7 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         }
         if( !noHU && !stop && r == qlen + tlen - 2 && en0 == tlen - 1 )
             ez.score = hEnd;
-        if( EARLY && early && r >= earlyFrom - 1 && ( earlySparse ? en0 == tlen - 1 && ( r & 15 ) <= 1 : ( r & 7 ) <= 1 ) )
+        if( EARLY && __builtin_expect( early && r >= earlyFrom - 1 && ( earlySparse ? en0 == tlen - 1 && ( r & 15 ) <= 1 : ( r & 7 ) <= 1 ), 0 ) )
         {
             // early stop of pipeline extensions (proof in ksw_reg.h)
             i32 bnd = (i32)0x80000000;
@@ -652,7 +727,24 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
         topH += uInit; // H(r,-1)
         last_st = st;
         last_en = en;
+        PK_PROF_T( tp6 );
+        PK_PROF_ADD( 0, tp0, tp1 );
+        PK_PROF_ADD( 1, tp1, tp2 );
+        PK_PROF_ADD( 2, tp2, tp3 );
+        PK_PROF_ADD( 3, tp3, tp4 );
+        PK_PROF_ADD( 4, tp4, tp5 );
+        PK_PROF_ADD( 5, tp5, tp6 );
+        PK_PROF_ADD( 6, 0ull, 1ull );
     }
+#if defined( MA_KSW_PROF )
+    if( lane == 0 && R == 5 )
+    {
+        for( int i = 0; i < 10; i++ )
+            atomicAdd( &g_pk_prof[ i ], pkp[ i ] );
+        atomicAdd( &g_pk_prof[ 10 ], 1ull );
+    }
+    const unsigned long long tpE = clock64( );
+#endif
     resolvePending( );
     __syncthreads( ); // direction bytes of all lanes visible to the back-trace
     i32 i0 = -1, j0b = -1;
@@ -668,6 +760,10 @@ __device__ void ksw_pk_core( const KswScoring& SC, const KswJobView& J, QF qbase
     else
         return;
     ksw_backtrack_lane0( P, cig, (i64)n_col, qlen, tlen, w, J.flag, i0, j0b, nCigar, pathSteps, qr, ldsBytes );
+#if defined( MA_KSW_PROF )
+    if( lane == 0 && R == 5 )
+        atomicAdd( &g_pk_prof[ 11 ], clock64( ) - tpE );
+#endif
 }
 } // namespace ma
 #endif

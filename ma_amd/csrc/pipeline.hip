@@ -2416,11 +2416,8 @@ static std::mutex& dp_turn( int device )
 }
 static bool dp_exclusive( )
 {
-    static const bool on = []( ) {
-        const char* e = getenv( "MA_DP_EXCLUSIVE" );
-        return e && atoi( e ) != 0;
-    }( );
-    return on;
+    const char* e = getenv( "MA_DP_EXCLUSIVE" ); // (read on every call: tools/overlap_matrix.py switches it inside one process)
+    return e && atoi( e ) != 0;
 }
 
 // MA_DP_ONE_STREAM=1: all kernel classes of a DP stage back to back on the batch's stream, as before round 3 (A/B hook)
@@ -3284,6 +3281,11 @@ int ma_debug_chain_prof( unsigned long long* out )
 int ma_debug_ksw_prof( unsigned long long* out )
 {
     MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_ksw_prof ), 16 * 8 ) );
+    return 0;
+}
+int ma_debug_pk_prof( unsigned long long* out )
+{
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_pk_prof ), 16 * 8 ) );
     return 0;
 }
 int ma_debug_seed_prof( unsigned long long* out )

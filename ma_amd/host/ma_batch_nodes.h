@@ -24,7 +24,10 @@ class BatchAlign : public libMS::Module<AlignedBatch, false, FMIndex, ReadVector
 {
     const ma_params xP;
     std::mutex xMutex;
-    std::vector<std::unique_ptr<detail::Engine>> vIdle; // engines whose graph thread is between two batches
+    // engines whose graph thread is between two batches, with the index they are bound to (an engine's ma_batch belongs to ONE
+    // ma_index: reusing it for another genome would align against the first one)
+    std::vector<std::pair<const ma_index*, std::unique_ptr<detail::Engine>>> vIdle;
+    std::mutex xPrimeMutex; // first batches of new engines run one at a time (they allocate GBs and page-lock memory)
 
   public:
     // seconds summed over all batches (phases of different batches overlap when several graph threads are at work)
@@ -39,33 +42,47 @@ class BatchAlign : public libMS::Module<AlignedBatch, false, FMIndex, ReadVector
         auto pRet = std::make_shared<AlignedBatch>( );
         pRet->pReads = pReads;
         pRet->uiFirst = 0;
+        const ma_index* pIndex = pFM_index->pDev->p;
         std::unique_ptr<detail::Engine> pEngine;
         {
             std::lock_guard<std::mutex> xGuard( xMutex );
-            if( !vIdle.empty( ) )
-            {
-                pEngine = std::move( vIdle.back( ) );
-                vIdle.pop_back( );
-            }
+            for( size_t k = 0; k < vIdle.size( ); k++ )
+                if( vIdle[ k ].first == pIndex )
+                {
+                    pEngine = std::move( vIdle[ k ].second );
+                    vIdle.erase( vIdle.begin( ) + k );
+                    break;
+                }
         }
-        if( pEngine == nullptr )
-            pEngine.reset( new detail::Engine( pFM_index->pDev->p, xP ) );
         std::vector<detail::ReadRef> vRefs;
         vRefs.reserve( pReads->size( ) );
         for( const auto& pQ : *pReads )
             vRefs.emplace_back( pQ->xCodes );
         try
         {
-            pRet->pResult = pEngine->run( vRefs, false );
+            if( pEngine == nullptr || !pEngine->primed( vRefs.size( ) ) )
+            {
+                // engines before admission: the graph threads all arrive at once at the start of a run; their engines are
+                // created and run their first batch one after the other instead of racing for the allocator and the page-locker
+                std::lock_guard<std::mutex> xPrime( xPrimeMutex );
+                if( pEngine == nullptr )
+                    pEngine.reset( new detail::Engine( pIndex, xP ) );
+                pRet->pResult = pEngine->run( vRefs, false );
+            }
+            else
+                pRet->pResult = pEngine->run( vRefs, false );
         }
         catch( ... )
         {
-            std::lock_guard<std::mutex> xGuard( xMutex );
-            vIdle.push_back( std::move( pEngine ) );
+            if( pEngine != nullptr )
+            {
+                std::lock_guard<std::mutex> xGuard( xMutex );
+                vIdle.emplace_back( pIndex, std::move( pEngine ) );
+            }
             throw;
         }
         std::lock_guard<std::mutex> xGuard( xMutex );
-        vIdle.push_back( std::move( pEngine ) );
+        vIdle.emplace_back( pIndex, std::move( pEngine ) );
         uiBatches++, uiReads += pReads->size( ), uiAligned += pRet->pResult->uiAlignedReads;
         fPack += pRet->pResult->fPack, fH2D += pRet->pResult->fH2D, fKernels += pRet->pResult->fKernels, fD2H += pRet->pResult->fD2H;
         return pRet;

@@ -71,6 +71,7 @@ template <typename T> class HostBuf
         else if( p != nullptr )
             free( p );
         p = nullptr;
+        uiCap = 0;
     }
 
   public:
@@ -86,17 +87,21 @@ template <typename T> class HostBuf
     {
         if( n > uiCap )
         {
-            release( );
-            uiCap = n + n / 4 + 64;
+            // the new block first, into locals: a failed (page-locked) allocation throws and must leave the buffer as it was,
+            // not with p == nullptr and the new capacity (the engine is reused after a failed batch)
+            const size_t uiNewCap = n + n / 4 + 64;
             // page-locking pays for the MB-sized arrays of a throughput batch; the few KB of a small batch of the per-read
             // funnel stay ordinary memory (page-locking and unlocking go through the driver and stall other streams)
-            bPinned = uiCap * sizeof( T ) >= ( 1u << 20 );
+            const bool bNewPinned = uiNewCap * sizeof( T ) >= ( 1u << 20 );
             void* q = nullptr;
-            if( bPinned )
-                engineCheck( ma_host_alloc( uiCap * sizeof( T ), &q ) );
-            else if( ( q = malloc( uiCap * sizeof( T ) ) ) == nullptr )
+            if( bNewPinned )
+                engineCheck( ma_host_alloc( uiNewCap * sizeof( T ), &q ) );
+            else if( ( q = malloc( uiNewCap * sizeof( T ) ) ) == nullptr )
                 throw std::bad_alloc( );
+            release( );
             p = static_cast<T*>( q );
+            uiCap = uiNewCap;
+            bPinned = bNewPinned;
         }
         return p;
     }
@@ -170,6 +175,14 @@ class Engine
 
   public:
     bool bFetchSocQueues = false; // run(): with bStages also fetch every read's SoC queue (one extra kernel per batch)
+    // batches this engine has completed.  Its FIRST batch allocates the device pools (GBs) and page-locks the staging
+    // arrays, which stalls every stream of the process: callers run first batches one at a time, before they admit
+    // concurrent work (primed( ), BatchAligner::alignRange, BatchAlign::execute, DeviceBatcher's constructor)
+    uint64_t uiRuns = 0;
+    bool primed( uint64_t uiReads ) const
+    {
+        return uiRuns != 0 && pBatch != nullptr && uiReads <= uiCapReads;
+    }
 
   private:
     void fit( uint64_t uiReads, uint64_t uiBases )
@@ -198,6 +211,12 @@ class Engine
         if( pBatch != nullptr )
             ma_batch_destroy( pBatch );
         ma_stream_destroy( pIndex, pStream );
+    }
+
+    // device batch and pools for batches of up to that size, now (instead of inside the first run)
+    void reserve( uint64_t uiReads, uint64_t uiBases )
+    {
+        fit( uiReads, uiBases );
     }
 
     // vReads[i] = codes of read i (A0 C1 G2 T3 N4).  bStages: also fetch the records of the intermediate stages.
@@ -302,6 +321,7 @@ class Engine
             R.uiMqOps = rLast.ops_off + rLast.n_ops;
         }
         R.fD2H = secondsSince( t0 );
+        uiRuns++;
         if( getenv( "MA_ENGINE_TRACE" ) ) // diagnostics: the phases of every device batch
             fprintf( stderr, "engine %p: %zu reads, h2d %.4f s, stages %.4f s (seed %.1f extract %.1f chain %.1f dp %.1f ms), d2h %.4f s\n",
                      (void*)this, n, R.fH2D, R.fKernels, R.aStageMs[ 0 ], R.aStageMs[ 1 ], R.aStageMs[ 2 ], R.aStageMs[ 3 ], R.fD2H );
@@ -431,9 +451,21 @@ class DeviceBatcher
     }
 
   public:
+    // Engines before admission: all uiEngines engines (stream + device batch sized for the batches a funnel sees) exist when
+    // the constructor returns; none is created while reads are being aligned.
     DeviceBatcher( const ma_index* pIndex, const ma_params& rP, const BatcherOptions& rOpt = BatcherOptions( ) )
         : pIndex( pIndex ), xP( rP ), xOpt( rOpt )
-    {}
+    {
+        const uint64_t uiReads = std::min<uint64_t>( std::max<uint64_t>( xOpt.uiMaxBatch, 1 ), 4096 );
+        for( size_t k = 0; k < xOpt.uiEngines; k++ )
+        {
+            std::unique_ptr<Engine> pEngine( new Engine( pIndex, xP, true ) );
+            pEngine->bFetchSocQueues = xOpt.bSocQueues;
+            pEngine->reserve( uiReads, uiReads * 512 );
+            vIdle.push_back( std::move( pEngine ) );
+            uiEnginesMade++;
+        }
+    }
     DeviceBatcher( const DeviceBatcher& ) = delete;
 
     // Blocks until the batch that contains this read has been through all stages.  rCodes must stay alive meanwhile

@@ -1432,12 +1432,59 @@ class BatchAligner
         const size_t uiFlatBase = pFlat ? pFlat->size( ) : 0;
         if( pFlat )
             pFlat->resize( uiFlatBase + ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) );
-        auto worker = [ & ]( ) {
-            std::unique_ptr<detail::Engine> pEngine;
+        // one device batch [lo, hi) through an engine; results into pFlat / pOut, phase times into rT
+        auto runBatch = [ & ]( detail::Engine& xEngine, size_t lo, size_t hi ) {
+            std::vector<detail::ReadRef> vReads;
+            vReads.reserve( hi - lo );
+            for( size_t i = lo; i < hi; i++ )
+                vReads.emplace_back( rQueries[ i ]->xCodes );
+            auto pRes = xEngine.run( vReads, false );
+            const auto t0 = std::chrono::steady_clock::now( );
+            if( pFlat )
+            {
+                auto pB = std::make_shared<AlignedBatch>( );
+                pB->pReads = pReadsOfFlat;
+                pB->uiFirst = lo;
+                pB->pResult = pRes;
+                ( *pFlat )[ uiFlatBase + ( lo - uiFrom ) / uiBatchReads ] = pB;
+            }
+            if( pOut )
+                for( size_t i = lo; i < hi; i++ )
+                {
+                    auto pV = std::make_shared<AlignmentVector>( );
+                    detail::appendAlignments( pRes->vMq.data( ), pRes->vMqOps.data( ), pRes->vMqOff[ i - lo ], pRes->vMqOff[ i - lo + 1 ], true, *pV );
+                    ( *pOut )[ i ] = pV;
+                }
+            const double fContainers = detail::secondsSince( t0 );
+            std::lock_guard<std::mutex> xGuard( xNext );
+            rT.fPack += pRes->fPack, rT.fH2D += pRes->fH2D, rT.fKernels += pRes->fKernels, rT.fD2H += pRes->fD2H, rT.fContainers += fContainers;
+            rT.uiBatches++, rT.uiReads += hi - lo, rT.uiAlignedReads += pRes->uiAlignedReads;
+        };
+        const size_t uiWorkers = std::max<size_t>( 1, std::min( uiInflight, ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) ) );
+        // Engines before admission: every worker's engine exists before the first worker starts, and an engine that has not
+        // run a batch of this size yet runs its first one HERE, alone -- the first batch of an engine allocates GBs of device
+        // pools and page-locks its staging arrays, which stalls every other stream of the process (0.3-0.8 s each; with four
+        // new engines racing inside a timed leg the driver's run of round 3 measured 0.35 M reads/s instead of 19 M).
+        std::vector<std::unique_ptr<detail::Engine>> vEngines;
+        for( size_t k = 0; k < uiWorkers; k++ )
+            vEngines.push_back( takeEngine( pIndex ) );
+        try
+        {
+            for( auto& pEngine : vEngines )
+                if( !pEngine->primed( std::min( uiBatchReads, uiTo - uiFrom ) ) && uiNext < uiTo )
+                {
+                    const size_t lo = uiNext, hi = uiNext = std::min( uiTo, uiNext + uiBatchReads );
+                    runBatch( *pEngine, lo, hi );
+                }
+        }
+        catch( const std::exception& rE )
+        {
+            sFailure = rE.what( );
+        }
+        auto worker = [ & ]( size_t uiMe ) {
             try
             {
-                pEngine = takeEngine( pIndex );
-                detail::Engine& xEngine = *pEngine;
+                detail::Engine& xEngine = *vEngines[ uiMe ];
                 for( ;; )
                 {
                     size_t lo, hi;
@@ -1448,31 +1495,7 @@ class BatchAligner
                         lo = uiNext;
                         hi = uiNext = std::min( uiTo, uiNext + uiBatchReads );
                     }
-                    std::vector<detail::ReadRef> vReads;
-                    vReads.reserve( hi - lo );
-                    for( size_t i = lo; i < hi; i++ )
-                        vReads.emplace_back( rQueries[ i ]->xCodes );
-                    auto pRes = xEngine.run( vReads, false );
-                    const auto t0 = std::chrono::steady_clock::now( );
-                    if( pFlat )
-                    {
-                        auto pB = std::make_shared<AlignedBatch>( );
-                        pB->pReads = pReadsOfFlat;
-                        pB->uiFirst = lo;
-                        pB->pResult = pRes;
-                        ( *pFlat )[ uiFlatBase + ( lo - uiFrom ) / uiBatchReads ] = pB;
-                    }
-                    if( pOut )
-                        for( size_t i = lo; i < hi; i++ )
-                        {
-                            auto pV = std::make_shared<AlignmentVector>( );
-                            detail::appendAlignments( pRes->vMq.data( ), pRes->vMqOps.data( ), pRes->vMqOff[ i - lo ], pRes->vMqOff[ i - lo + 1 ], true, *pV );
-                            ( *pOut )[ i ] = pV;
-                        }
-                    const double fContainers = detail::secondsSince( t0 );
-                    std::lock_guard<std::mutex> xGuard( xNext );
-                    rT.fPack += pRes->fPack, rT.fH2D += pRes->fH2D, rT.fKernels += pRes->fKernels, rT.fD2H += pRes->fD2H, rT.fContainers += fContainers;
-                    rT.uiBatches++, rT.uiReads += hi - lo, rT.uiAlignedReads += pRes->uiAlignedReads;
+                    runBatch( xEngine, lo, hi );
                 }
             }
             catch( const std::exception& rE )
@@ -1481,18 +1504,38 @@ class BatchAligner
                 if( sFailure.empty( ) )
                     sFailure = rE.what( );
             }
-            if( pEngine != nullptr )
-                giveEngine( pIndex, std::move( pEngine ) );
         };
-        const size_t uiWorkers = std::max<size_t>( 1, std::min( uiInflight, ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) ) );
         std::vector<std::thread> vWorkers;
         for( size_t k = 1; k < uiWorkers; k++ )
-            vWorkers.emplace_back( worker );
-        worker( );
+            vWorkers.emplace_back( worker, k );
+        worker( 0 );
         for( auto& rW : vWorkers )
             rW.join( );
+        for( auto& pEngine : vEngines )
+            giveEngine( pIndex, std::move( pEngine ) );
         if( !sFailure.empty( ) )
             throw std::runtime_error( sFailure );
+    }
+
+    // Creates the uiInflight engines of this aligner for pFM_index and runs one batch through each, one after the other
+    // (results discarded): after it, execute / executeFlat on batches of up to that size allocate nothing.
+    void warmUp( std::shared_ptr<FMIndex> pFM_index, std::shared_ptr<ReadVector> pSample )
+    {
+        if( pSample == nullptr || pSample->empty( ) )
+            return;
+        const ma_index* pIndex = pFM_index->pDev->p;
+        std::vector<std::unique_ptr<detail::Engine>> vEngines;
+        for( size_t k = 0; k < std::max<size_t>( uiInflight, 1 ); k++ )
+            vEngines.push_back( takeEngine( pIndex ) );
+        const size_t n = std::min( pSample->size( ), uiBatchReads );
+        std::vector<detail::ReadRef> vReads;
+        for( size_t i = 0; i < n; i++ )
+            vReads.emplace_back( ( *pSample )[ i ]->xCodes );
+        for( auto& pEngine : vEngines )
+            if( !pEngine->primed( n ) )
+                pEngine->run( vReads, false );
+        for( auto& pEngine : vEngines )
+            giveEngine( pIndex, std::move( pEngine ) );
     }
 
     virtual std::shared_ptr<TP_RESULT> execute( std::shared_ptr<FMIndex> pFM_index,

@@ -272,15 +272,28 @@ def test_unknown_seeding_technique_is_rejected(gpu_device, tmp_path):
     idx.close()
 
 
-def _bench(args, nproc=1, env=None):
+def _bench(args, nproc=1, env=None, self_launch=False):
+    """Runs bench.py and returns its line with the per-workload blocks of the detail file put back under config.workloads.
+    nproc > 1: under an outer torchrun as the driver starts it -- or, self_launch, by bench.py's own --gpus N."""
     import sys
+    import tempfile
     e = dict(os.environ, **(env or {}))
     base = [sys.executable]
-    if nproc > 1:
+    if nproc > 1 and not self_launch:
         base += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
                  "--master-port", "29617"]
-    out = subprocess.check_output(base + [os.path.join(ROOT, "bench.py")] + args, env=e, stderr=subprocess.DEVNULL).decode()
-    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        e.pop("WORLD_SIZE", None)
+    with tempfile.TemporaryDirectory() as td:
+        detail = os.path.join(td, "detail.json")
+        out = subprocess.check_output(base + [os.path.join(ROOT, "bench.py")] + args + ["--detail-file", detail], env=e,
+                                      stderr=subprocess.DEVNULL).decode()
+        line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        with open(detail) as f:
+            d = json.load(f)
+    line["config"]["workloads"] = d["workloads"]
+    line["config"]["boundary"] = d["boundary"]
+    line["c1_anchor_detail"] = d["c1_anchor"]
+    return line
 
 
 def test_bench_two_ranks_partition_one_read_set(gpu_device):
@@ -299,6 +312,28 @@ def test_bench_two_ranks_partition_one_read_set(gpu_device):
     assert ws["aligned_reads"] == w1["aligned_reads"]
     # weak: rank 0 repeats the single process' reads, rank 1 adds as many others
     assert 1.9 * w1["aligned_reads"] < ww["aligned_reads"] < 2.1 * w1["aligned_reads"]
+    # every leg of the line: one batch at a time, batches in flight, host to host (reads from / results into page-locked host
+    # memory) -- the same reads, so the same number of aligned reads per step
+    for key in ("overlapped", "host_to_host"):  # (these legs run more steps, of other reads of the same kind)
+        assert abs(w1[key]["aligned_reads"] / w1[key]["steps"] - w1["aligned_reads"] / w1["steps"]) < 0.01 * 30000, key
+        assert ww[key]["value"] > 0
+    assert w1["host_to_host"]["aligned_reads"] == w1["overlapped"]["aligned_reads"]  # the same reads through both I/O paths
+    assert one["value"] == w1["host_to_host"]["value"] and "host to host" in one["config"]["value_is"]
+    assert one["value_150bp_device_resident"] == w1["overlapped"]["value"] and one["value_150bp_single_stream"] == w1["value"]
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself(gpu_device):
+    """`bench.py --gpus 2` WITHOUT an outer torchrun starts its two ranks itself (here both on GPU 0 over
+    gloo) and reports n_gpus = 2; with a torchrun environment of another size it refuses instead of printing a 1-rank number."""
+    common = ["--workload", "150bp", "--genome-scale", "0.01", "--steps", "2", "--warmup", "1", "--reads-per-step", "20000",
+              "--cpu-sample", "0", "--boundary-reads", "0", "--overlap", "0"]
+    two = _bench(common + ["--gpus", "2"], nproc=2, env={"MA_BENCH_ONE_DEVICE": "1"}, self_launch=True)
+    assert two["n_gpus"] == 2
+    assert two["config"]["workloads"][0]["aligned_reads"] > 0.95 * 2 * 40000
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--gpus", "4"],
+                       env=dict(os.environ, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True)
+    assert r.returncode != 0 and "refusing" in r.stderr
 
 
 def band_cut_extension_cases(n, seed):

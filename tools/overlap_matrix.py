@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Overlap matrix on one workload, ONE process (the index is built once): batches in flight x DP turn-taking
+(MA_DP_EXCLUSIVE: one DP stage at a time per device) x resident DP waves per CU (MA_KSW_WAVES_PER_CU: fewer persistent DP
+waves leave register file and wave slots to the memory-bound kernels of the other batches).
+usage: python tools/overlap_matrix.py [--workload 150bp] [--steps 12] [--host-io 0] > gpurun_out/overlap_matrix.txt"""
+import argparse
+import copy
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="150bp")
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--host-io", type=int, default=0)
+    ap.add_argument("--inflight", default="1,2,3")
+    ap.add_argument("--waves", default="0,12,16,20,24")
+    ap.add_argument("--exclusive", default="0,1")
+    a = ap.parse_args()
+    sys.argv = ["bench.py", "--workload", a.workload, "--cpu-sample", "0", "--boundary-reads", "0"]
+    pa = argparse.ArgumentParser()
+    # the defaults of bench.main's parser, by running its own parser on an empty command line
+    import io, contextlib
+    args = None
+
+    def grab(E, name, wl, ar):
+        raise RuntimeError("unused")
+    # build the argument namespace the way bench.main does
+    real_env = bench.Env
+
+    class Stop(Exception):
+        pass
+
+    def fake_env(ar):
+        nonlocal args
+        args = ar
+        raise Stop()
+    bench.Env = fake_env
+    try:
+        bench.main()
+    except Stop:
+        pass
+    bench.Env = real_env
+    E = bench.Env(args)
+    wl = dict(bench.WORKLOADS[a.workload])
+    wl["warmup"] = 1
+    print("workload %s, %d steps per point, host_io %d; columns: reads/s, ms per step, k_ksw ms per step under that overlap" % (
+        a.workload, a.steps, a.host_io), flush=True)
+    for nfl in [int(x) for x in a.inflight.split(",")]:
+        for ex in [int(x) for x in a.exclusive.split(",")]:
+            if nfl == 1 and ex == 1:
+                continue
+            for wv in [int(x) for x in a.waves.split(",")]:
+                os.environ["MA_DP_EXCLUSIVE"] = str(ex)
+                if wv:
+                    os.environ["MA_KSW_WAVES_PER_CU"] = str(wv)
+                else:
+                    os.environ.pop("MA_KSW_WAVES_PER_CU", None)
+                a2 = copy.copy(args)
+                a2.inflight, a2.host_io, a2.cpu_sample = nfl, a.host_io, 0
+                w2 = dict(wl)
+                w2["steps"] = max(a.steps, 3 * nfl)
+                r = bench.run_workload(E, a.workload, w2, a2)
+                k = r["roofline"]["kernel_ms_per_step"]
+                print("inflight=%d dp_exclusive=%d dp_waves_per_cu=%s  %12.1f  %8.3f  k_ksw %.2f k_seed %.2f k_chain %.2f" % (
+                    nfl, ex, wv or "default", r["value"], r["ms_per_step"], k["k_ksw"], k["k_seed"], k["k_chain"]), flush=True)
+    E.close()
+
+
+if __name__ == "__main__":
+    main()
