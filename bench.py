@@ -93,7 +93,8 @@ def pmc_replay(read_len, reads_per_step, preset, genome_scale, stage):
     the pass was collected with other kernel sources than the ones libma_amd.so is built from now."""
     cur = kernel_source_hash()
     reason = "no PMC pass of this workload under profiles/"
-    for src in (os.path.join("profiles", "r03_pmc_traffic.json"), os.path.join("profiles", "r02_pmc_traffic.json")):
+    for src in (os.path.join("profiles", "r04_pmc_traffic.json"), os.path.join("profiles", "r03_pmc_traffic.json"),
+                os.path.join("profiles", "r02_pmc_traffic.json")):
         try:
             with open(os.path.join(ROOT, src)) as f:
                 doc = json.load(f)
@@ -656,16 +657,18 @@ def c1_anchor(E, args):
         # the oracle on the GPU-built index, one thread, best of three
         oidx = OrIndex.from_parts(idx.download())
         op = or_params("default", 1)
+        REP = 20  # the race is timed on 20 x the 1 000 reads (a 1 000-read run of the reference takes 25 ms)
         t_or = []
         for _ in range(3):
             t0 = time.perf_counter()
-            res = oidx.align(reads, op, threads=1)
+            oidx.align(reads * REP, op, threads=1)
             t_or.append(time.perf_counter() - t0)
+        res = oidx.align(reads, op, threads=1)
         na = int(res["aln_off"][n])
         same = (np.array_equal(goff, res["aln_off"][:n + 1]) and galn[:na].tobytes() == res["alns"][:na].tobytes()
                 and np.array_equal(moff, res["mq_off"][:n + 1])
                 and gmq["mapq"][:int(moff[n])].tobytes() == res["mq"]["mapq"][:int(moff[n])].tobytes())
-        out.update({"oracle_reads_per_s_1_thread": round(n / min(t_or), 1), "gpu_vs_oracle_identical": bool(same),
+        out.update({"oracle_reads_per_s_1_thread": round(REP * n / min(t_or), 1), "gpu_vs_oracle_identical": bool(same),
                     "alignments": na, "aligned_reads": int(res["n_aligned"])})
         ref_dump = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
         if os.path.exists(ref_dump) and not os.environ.get("MA_BENCH_NO_REFERENCE"):
@@ -673,9 +676,11 @@ def c1_anchor(E, args):
             try:
                 case = os.path.join(td, "c1.case")
                 write_case(case, [contig], reads)
+                case_t = os.path.join(td, "c1x.case")
+                write_case(case_t, [contig], reads * REP)
                 t_ref = []
                 for _ in range(3):  # `time`: the reference builds its own index of the case's contigs, then times its modules
-                    o = subprocess.run([ref_dump, "time", case, "default", "1"], capture_output=True, text=True, timeout=600)
+                    o = subprocess.run([ref_dump, "time", case_t, "default", "1"], capture_output=True, text=True, timeout=600)
                     m = re.search(r"(\d+) reads \((\d+) aligned\) in ([0-9.]+) s on (\d+) threads", o.stdout)
                     if o.returncode != 0 or not m:
                         raise RuntimeError((o.stderr or o.stdout)[-300:])
@@ -699,7 +704,7 @@ def c1_anchor(E, args):
                     for k in range(m1 - m0 if ok else 0):
                         ok = ok and float("%.17g" % gmq[m0 + k]["mapq"]) == want[r]["mq"][k]["mapq"]
                     bad += 0 if ok else 1
-                out.update({"reference_reads_per_s_1_thread": round(n / min(t_ref), 1),
+                out.update({"reference_reads_per_s_1_thread": round(REP * n / min(t_ref), 1),
                             "oracle_over_reference": round(min(t_ref) / min(t_or), 3),
                             "gpu_vs_reference_mismatching_reads": bad,
                             "what": "the reference builds its own index of ecoli_like (is_bwt path); its alignments and mapping "

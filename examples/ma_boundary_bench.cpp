@@ -53,6 +53,150 @@ class VecReader : public Module<NucSeq, true>
     }
 };
 
+// execute( ) of a module, timed (thread time summed over all graph threads): where the host side of the per-read graph goes
+template <class TP_MODULE> struct Timed : public TP_MODULE
+{
+    std::atomic<uint64_t> uiNs{ 0 }, uiCalls{ 0 };
+    template <typename... A> Timed( A&&... a ) : TP_MODULE( std::forward<A>( a )... )
+    {}
+    template <typename F> auto timed( F&& f ) -> decltype( f( ) )
+    {
+        const auto t0 = std::chrono::steady_clock::now( );
+        auto r = f( );
+        uiNs += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>( std::chrono::steady_clock::now( ) - t0 ).count( );
+        uiCalls++;
+        return r;
+    }
+    double usPerCall( ) const
+    {
+        return uiCalls ? uiNs / 1e3 / uiCalls : 0.0;
+    }
+};
+struct TReader : public Timed<PrefetchReader<>>
+{
+    using Timed<PrefetchReader<>>::Timed;
+    std::shared_ptr<NucSeq> execute( ) override
+    {
+        return timed( [ & ]( ) { return PrefetchReader<>::execute( ); } );
+    }
+};
+struct TSeeding : public Timed<BinarySeeding>
+{
+    using Timed<BinarySeeding>::Timed;
+    std::shared_ptr<SegmentVector> execute( std::shared_ptr<SuffixArrayInterface> a, std::shared_ptr<NucSeq> b ) override
+    {
+        return timed( [ & ]( ) { return BinarySeeding::execute( a, b ); } );
+    }
+};
+struct TSoc : public Timed<StripOfConsideration>
+{
+    using Timed<StripOfConsideration>::Timed;
+    std::shared_ptr<SoCPriorityQueue> execute( std::shared_ptr<SegmentVector> a, std::shared_ptr<NucSeq> b, std::shared_ptr<Pack> c,
+                                               std::shared_ptr<FMIndex> d ) override
+    {
+        return timed( [ & ]( ) { return StripOfConsideration::execute( a, b, c, d ); } );
+    }
+};
+struct THarm : public Timed<Harmonization>
+{
+    using Timed<Harmonization>::Timed;
+    std::shared_ptr<SeedsSetVector> execute( std::shared_ptr<SoCPriorityQueue> a, std::shared_ptr<NucSeq> b, std::shared_ptr<FMIndex> c ) override
+    {
+        return timed( [ & ]( ) { return Harmonization::execute( a, b, c ); } );
+    }
+};
+typedef libMS::ContainerVector<std::shared_ptr<Alignment>> AlnVec;
+struct TDp : public Timed<NeedlemanWunsch>
+{
+    using Timed<NeedlemanWunsch>::Timed;
+    std::shared_ptr<AlnVec> execute( std::shared_ptr<SeedsSetVector> a, std::shared_ptr<NucSeq> b, std::shared_ptr<Pack> c ) override
+    {
+        return timed( [ & ]( ) { return NeedlemanWunsch::execute( a, b, c ); } );
+    }
+};
+struct TMq : public Timed<MappingQuality>
+{
+    using Timed<MappingQuality>::Timed;
+    std::shared_ptr<AlnVec> execute( std::shared_ptr<NucSeq> a, std::shared_ptr<AlnVec> b ) override
+    {
+        return timed( [ & ]( ) { return MappingQuality::execute( a, b ); } );
+    }
+};
+struct TWriter : public Timed<FileWriter>
+{
+    using Timed<FileWriter>::Timed;
+    std::shared_ptr<libMS::Container> execute( std::shared_ptr<NucSeq> a, std::shared_ptr<AlnVec> b, std::shared_ptr<Pack> c ) override
+    {
+        return timed( [ & ]( ) { return FileWriter::execute( a, b, c ); } );
+    }
+};
+
+// ---- leg 4: the per-read graph of export.cpp:99-126 with the reader node wrapped into a PrefetchReader: reads are pulled ahead
+// a device batch at a time and every graph thread gets reads that are already aligned -- a few dozen graph threads
+static std::string prefetchLeg( const ParameterSetManager& xParams, std::shared_ptr<ReadVec> pReads, std::shared_ptr<FMIndex> pFM,
+                                std::shared_ptr<Pack> pPack, uint64_t uiExpectedSamBytes, double& fPrefetchBest, int& iPrefetchBestThreads )
+{
+    const size_t n = pReads->size( );
+    auto now = []( ) { return std::chrono::duration<double>( std::chrono::steady_clock::now( ).time_since_epoch( ) ).count( ); };
+    auto pPackP = std::make_shared<Pledge<Pack>>( );
+    pPackP->set( pPack );
+    auto pFmP = std::make_shared<Pledge<FMIndex>>( );
+    pFmP->set( pFM );
+    auto pSai = std::make_shared<Pledge<SuffixArrayInterface>>( );
+    pSai->set( pFM );
+    double t0 = 0;
+    std::string sPrefetch;
+    for( int iT : { 8, 16, 32, 64 } )
+    {
+        detail::PrefetchOptions xPO;
+        xPO.uiBatchReads = 1u << 16;
+        xPO.uiDepth = 2;
+        auto pSource = std::make_shared<VecReader>( *pReads );
+        auto pAhead = std::make_shared<TReader>( xParams, pSource, pFM, xPO );
+        auto pSeeding4 = std::make_shared<TSeeding>( xParams );
+        auto pSoc4 = std::make_shared<TSoc>( xParams );
+        auto pHarm4 = std::make_shared<THarm>( xParams );
+        auto pDp4 = std::make_shared<TDp>( xParams );
+        auto pMq4 = std::make_shared<TMq>( xParams );
+        auto pSink4 = std::make_shared<CountingSink>( );
+        auto pWriter4 = std::make_shared<TWriter>( xParams, std::static_pointer_cast<OutStream>( pSink4 ), pPack );
+        std::vector<std::shared_ptr<BasePledge>> vSinks4;
+        for( int t = 0; t < iT; t++ )
+        {
+            auto pQuery = promiseMe( std::make_shared<Lock<NucSeq>>( ), promiseMe( std::static_pointer_cast<PrefetchReader<>>( pAhead ) ) );
+            auto pSeeds = promiseMe( std::static_pointer_cast<BinarySeeding>( pSeeding4 ), pSai, pQuery );
+            auto pSOCs = promiseMe( std::static_pointer_cast<StripOfConsideration>( pSoc4 ), pSeeds, pQuery, pPackP, pFmP );
+            auto pHarmonized = promiseMe( std::static_pointer_cast<Harmonization>( pHarm4 ), pSOCs, pQuery, pFmP );
+            auto pAlignments = promiseMe( std::static_pointer_cast<NeedlemanWunsch>( pDp4 ), pHarmonized, pQuery, pPackP );
+            auto pWithQuality = promiseMe( std::static_pointer_cast<MappingQuality>( pMq4 ), pQuery, pAlignments );
+            auto pWritten = promiseMe( std::static_pointer_cast<FileWriter>( pWriter4 ), pQuery, pWithQuality, pPackP );
+            vSinks4.push_back( promiseMe( std::make_shared<UnLock<Container>>( pQuery ), pWritten ) );
+        }
+        t0 = now( );
+        BasePledge::simultaneousGet( vSinks4 );
+        const double f4 = now( ) - t0;
+        uint64_t uiB = 0, uiR = 0;
+        double fRun4 = 0, fPull4 = 0;
+        pAhead->stats( uiB, uiR, fRun4, fPull4 );
+        if( pSeeding4->batcher( ) != nullptr )
+            throw std::runtime_error( "prefetch leg: a read went through the per-read funnel" );
+        char buf[ 640 ];
+        snprintf( buf, sizeof( buf ), "%s\"graph_threads_%d\": {\"reads_per_s\": %.1f, \"wall_s\": %.4f, \"device_batches\": %llu, "
+                                      "\"device_batch_s\": %.4f, \"pull_s\": %.4f, \"sam_bytes\": %llu, \"us_per_read\": {\"thread_time\": %.2f, "
+                                      "\"reader\": %.2f, \"seeding\": %.2f, \"soc\": %.2f, \"harmonization\": %.2f, \"dp\": %.2f, \"mapping_quality\": %.2f, "
+                                      "\"writer\": %.2f}}",
+                  sPrefetch.empty( ) ? "" : ", ", iT, n / f4, f4, (unsigned long long)uiB, fRun4, fPull4, (unsigned long long)pSink4->uiBytes.load( ),
+                  f4 * iT * 1e6 / n, pAhead->usPerCall( ), pSeeding4->usPerCall( ), pSoc4->usPerCall( ), pHarm4->usPerCall( ), pDp4->usPerCall( ),
+                  pMq4->usPerCall( ), pWriter4->usPerCall( ) );
+        sPrefetch += buf;
+        if( uiExpectedSamBytes != 0 && pSink4->uiBytes.load( ) != uiExpectedSamBytes )
+            throw std::runtime_error( "prefetch leg: SAM bytes differ from the funnel leg's" );
+        if( n / f4 > fPrefetchBest )
+            fPrefetchBest = n / f4, iPrefetchBestThreads = iT;
+    }
+    return sPrefetch;
+}
+
 int main( int argc, char** argv )
 {
     if( argc < 6 )
@@ -108,6 +252,15 @@ int main( int argc, char** argv )
             pReads->push_back( pQ );
         }
         std::vector<uint8_t>( ).swap( vPac );
+        if( getenv( "MA_BOUNDARY_ONLY_GRAPH" ) ) // diagnostics: the per-read graph with the prefetching reader alone
+        {
+            defaultBatcherOptions( ).bStages = false;
+            double fBest = 0;
+            int iBest = 0;
+            const std::string sOnly = prefetchLeg( xParams, pReads, pFM, pPack, 0, fBest, iBest );
+            printf( "{\"graph\": {\"reads_per_s\": %.1f, \"threads\": %d, %s}}\n", fBest, iBest, sOnly.c_str( ) );
+            return 0;
+        }
         // ---- leg 1: BatchAligner
         std::string sBatch;
         std::shared_ptr<BatchAligner::TP_RESULT> pRes;
@@ -323,6 +476,9 @@ int main( int argc, char** argv )
             pSeeding->batcher( )->stageSeconds( aStage );
         fprintf( stderr, "graph leg: %.3f s wall; device batches: run %.3f s (h2d %.3f, kernels %.3f = seed %.3f + extract %.3f + chain %.3f + dp %.3f, d2h %.3f) summed over %llu batches\n",
                  fGraph, fRun, fUp, fKern, aStage[ 0 ], aStage[ 1 ], aStage[ 2 ], aStage[ 3 ], fDown, (unsigned long long)xStat.first );
+        double fPrefetchBest = 0;
+        int iPrefetchBestThreads = 0;
+        const std::string sPrefetch = prefetchLeg( xParams, pReads, pFM, pPack, pSink2->uiBytes.load( ), fPrefetchBest, iPrefetchBestThreads );
         printf( "{\"reads\": %zu, \"read_len\": %zu, \"host_threads\": %u, \"index_load_s\": %.2f, "
                 "\"batch_aligner\": {%s, \"what\": \"reads in host memory -> BatchAligner::execute (H2D, all stages, D2H, Alignment "
                 "containers); 256 k reads per device batch; phase times summed over the batches\"}, "
@@ -336,13 +492,16 @@ int main( int argc, char** argv )
                 "reads built outside) -> BatchAlign -> BatchFileWriter -> SAM bytes: the shape of ExecutionContext::doAlign as batch graph nodes\"}, "
                 "\"sam\": {\"reads_per_s\": %.1f, \"threads\": %u, \"bytes\": %llu, \"what\": \"FileWriter::execute per read into a "
                 "counting sink\"}, "
-                "\"graph\": {\"reads_per_s\": %.1f, \"graph_threads\": %d, \"device_batches\": %llu, \"mean_reads_per_device_batch\": %.1f, "
-                "\"what\": \"the unchanged per-read graph (reader -> BinarySeeding -> StripOfConsideration -> Harmonization -> "
-                "NeedlemanWunsch -> MappingQuality -> FileWriter) on that many graph threads; per-read execute() calls funnelled into "
-                "device batches\"}}\n",
+                "\"graph\": {\"reads_per_s\": %.1f, \"threads\": %d, %s, \"what\": \"the per-read graph of export.cpp:99-126 (reader -> "
+                "BinarySeeding -> StripOfConsideration -> Harmonization -> NeedlemanWunsch -> MappingQuality -> FileWriter), the reader "
+                "node wrapped into PrefetchReader: it pulls 64 k reads ahead, sends them through all stages on the GPU and hands "
+                "every graph thread reads that are aligned already; reads_per_s = the best of the thread counts\"}, "
+                "\"graph_funnel\": {\"reads_per_s\": %.1f, \"graph_threads\": %d, \"device_batches\": %llu, \"mean_reads_per_device_batch\": %.1f, "
+                "\"what\": \"the same graph with the plain reader: per-read execute() calls of that many graph threads funnelled into "
+                "device batches (DeviceBatcher)\"}}\n",
                 n, uiLen, uiHw, fLoad, sBatch.c_str( ), sFlat.c_str( ), n / fSamFlat, (unsigned long long)uiSamFlatBytes, sBatchGraph.c_str( ),
-                sFastqGraph.c_str( ), n / fSam, uiSamThreads, (unsigned long long)pSink->uiBytes.load( ), n / fGraph,
-                iGraphThreads, (unsigned long long)xStat.first, xStat.first ? (double)xStat.second / xStat.first : 0.0 );
+                sFastqGraph.c_str( ), n / fSam, uiSamThreads, (unsigned long long)pSink->uiBytes.load( ), fPrefetchBest, iPrefetchBestThreads,
+                sPrefetch.c_str( ), n / fGraph, iGraphThreads, (unsigned long long)xStat.first, xStat.first ? (double)xStat.second / xStat.first : 0.0 );
     }
     catch( const std::exception& e )
     {

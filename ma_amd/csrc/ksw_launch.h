@@ -455,7 +455,10 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
 #define KSW_REG_LDS 6144u // per-wave LDS of the exact register kernels: reversed query, later the back-trace staging block
 #define KSW_EXT_LDS 4096u // extension kernel: back-trace staging only (8 waves per SIMD fit)
 // per-wave scratch of all resident waves of a launch may take this much HBM (MA_KSW_SCRATCH_MB: test hook that makes small
-// batches take the paths of the large ones -- fewer waves, classes split in two launches, the side stream)
+// batches take the paths of the large ones -- fewer waves, classes split in two launches, the side stream).
+// B bounds ONE launch.  With the kernel classes on their own streams (the default for batches with job lists) four lanes of
+// launches run side by side, each in its own region of B/4, 5B/12, B/3 and B/4 bytes: a batch whose DP stage needs more than
+// 2 GB of scratch then holds 1.25 B (30 GB at the default), once per batch in flight -- DESIGN.md section 2 counts it that way.
 inline u64 ksw_scratch_budget( )
 {
     const char* e = getenv( "MA_KSW_SCRATCH_MB" ); // (read on every call: the tests switch it inside one process)

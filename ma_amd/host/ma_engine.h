@@ -1,6 +1,10 @@
 // ma_engine.h -- the host-side machinery between MA's per-read Module graph and the batch-oriented C ABI:
 //   Engine        one device batch (ma_batch) + one HIP stream on the device of its index: reads in host memory ->
 //                 H2D -> all four stages -> D2H of every stage's records (BatchResult), with the time of each phase
+//   PrefetchQueue the funnel turned round (round 4): a volatile SOURCE of the graph reads AHEAD -- it pulls a device batch
+//                 worth of reads from the reader it wraps, sends them through all stages and hands every graph thread one
+//                 read of a FINISHED batch with its ticket, so that no graph thread ever blocks per read and a few dozen
+//                 graph threads keep the GPU busy (the per-read funnel needs a thousand)
 //   DeviceBatcher thread-safe funnel: the graph threads of libMA::setUpCompGraph (export.cpp:84-126, one graph copy per
 //                 thread, every copy calling BinarySeeding::execute concurrently and lock-free, module.h:303-369) hand in
 //                 ONE read each and block; the reads that arrive while the GPU is busy form the next device batch, whose
@@ -545,6 +549,190 @@ class DeviceBatcher
         std::lock_guard<std::mutex> xLock( xMutex );
         for( int k = 0; k < 4; k++ )
             aOut[ k ] = aSumStageMs[ k ] / 1e3;
+    }
+};
+
+struct PrefetchOptions
+{
+    size_t uiBatchReads = 1u << 16; // reads per device batch pulled ahead
+    size_t uiDepth = 2; // device batches ahead of the graph threads (in flight or finished and not yet handed out): one engine each
+    // reads of a finished batch a graph thread takes at a time: the queue's lock is taken once per slice, not once per read
+    // (with more graph threads than the host grants cores, a thread that is descheduled while it holds a lock stalls them all)
+    size_t uiSlice = 128;
+    bool bStages = false, bSocQueues = false; // as in BatcherOptions
+};
+
+// Reads pulled AHEAD of the graph threads.  TP_ITEM is the read handle of the host layer (shared_ptr to its NucSeq type).
+//   next( out, pull, ref ): the next read of a finished device batch with its ticket; false = the source is exhausted and
+//   everything pulled has been handed out.  `pull` returns the next read of the wrapped source or an empty handle at its
+//   end; it is called by ONE thread at a time (the wrapped reader need not be re-entrant).  A caller that finds fewer than
+//   uiDepth batches ahead pulls and runs the next batch itself (it blocks for one device batch, the others keep being
+//   served from the finished ones), so there is no thread of our own and nothing runs when nobody asks.
+// Order: reads are handed out batch by batch in pull order, within a batch in pull order; which graph thread gets which
+// read is as arbitrary as in the reference (every graph thread takes the next read from the shared reader, export.cpp:99-126).
+template <typename TP_ITEM> class PrefetchQueue
+{
+    struct Batch
+    {
+        std::vector<TP_ITEM> vItems;
+        std::shared_ptr<const BatchResult> pResult;
+        size_t uiNext = 0;
+    };
+    const ma_index* pIndex;
+    const ma_params xP;
+    const PrefetchOptions xOpt;
+    std::mutex xMutex; // state below
+    std::condition_variable xChanged;
+    std::vector<std::shared_ptr<Batch>> vReady; // finished batches, oldest first
+    std::vector<std::unique_ptr<Engine>> vIdle;
+    size_t uiLoading = 0; // batches being pulled or on the device
+    bool bEof = false;
+    std::string sError;
+    std::mutex xPullMutex; // the wrapped source is read by one thread at a time, batches are pulled in order
+    uint64_t uiBatches = 0, uiReadsTotal = 0;
+    double fSumRun = 0, fSumPull = 0;
+
+  public:
+    PrefetchQueue( const ma_index* pIndex, const ma_params& rP, const PrefetchOptions& rOpt = PrefetchOptions( ) )
+        : pIndex( pIndex ), xP( rP ), xOpt( rOpt )
+    {
+        // engines before admission: streams and device batches exist before the first read is asked for
+        for( size_t k = 0; k < std::max<size_t>( xOpt.uiDepth, 1 ); k++ )
+        {
+            std::unique_ptr<Engine> pEngine( new Engine( pIndex, xP, true ) );
+            pEngine->bFetchSocQueues = xOpt.bSocQueues;
+            pEngine->reserve( xOpt.uiBatchReads, xOpt.uiBatchReads * 256 );
+            vIdle.push_back( std::move( pEngine ) );
+        }
+    }
+    PrefetchQueue( const PrefetchQueue& ) = delete;
+
+    // the calling thread's slice of a finished batch (thread-local: no lock while it lasts)
+    struct Slice
+    {
+        const void* pOwner = nullptr;
+        std::shared_ptr<Batch> pBatch;
+        size_t uiNext = 0, uiEnd = 0;
+    };
+    static Slice& mySlice( )
+    {
+        static thread_local Slice xSlice;
+        return xSlice;
+    }
+
+    template <typename TP_PULL, typename TP_REF> bool next( TP_ITEM& rItem, Ticket& rTicket, TP_PULL&& fPull, TP_REF&& fRef )
+    {
+        Slice& rMine = mySlice( );
+        if( rMine.pOwner == this && rMine.uiNext < rMine.uiEnd )
+        {
+            const size_t k = rMine.uiNext++;
+            rItem = rMine.pBatch->vItems[ k ];
+            rTicket.pResult = rMine.pBatch->pResult;
+            rTicket.uiRead = k;
+            if( rMine.uiNext >= rMine.uiEnd )
+                rMine.pBatch.reset( );
+            return true;
+        }
+        std::unique_lock<std::mutex> xLock( xMutex );
+        for( ;; )
+        {
+            if( !sError.empty( ) )
+                throw std::runtime_error( sError );
+            // keep uiDepth batches ahead: this caller pulls and runs the next one, the others are served meanwhile
+            if( !bEof && uiLoading + vReady.size( ) < std::max<size_t>( xOpt.uiDepth, 1 ) && !vIdle.empty( ) )
+            {
+                uiLoading++;
+                std::unique_ptr<Engine> pEngine = std::move( vIdle.back( ) );
+                vIdle.pop_back( );
+                xLock.unlock( );
+                auto pBatch = std::make_shared<Batch>( );
+                std::string sFailed;
+                bool bEnd = false;
+                const auto tPull = std::chrono::steady_clock::now( );
+                double fPullS = 0, fRun = 0;
+                try
+                {
+                    {
+                        std::lock_guard<std::mutex> xPull( xPullMutex );
+                        pBatch->vItems.reserve( xOpt.uiBatchReads );
+                        while( pBatch->vItems.size( ) < xOpt.uiBatchReads )
+                        {
+                            TP_ITEM xItem = fPull( );
+                            if( !xItem )
+                            {
+                                bEnd = true;
+                                break;
+                            }
+                            pBatch->vItems.push_back( std::move( xItem ) );
+                        }
+                    }
+                    fPullS = secondsSince( tPull );
+                    if( !pBatch->vItems.empty( ) )
+                    {
+                        const auto tRun = std::chrono::steady_clock::now( );
+                        std::vector<ReadRef> vRefs;
+                        vRefs.reserve( pBatch->vItems.size( ) );
+                        for( const TP_ITEM& rI : pBatch->vItems )
+                            vRefs.push_back( fRef( rI ) );
+                        pBatch->pResult = pEngine->run( vRefs, xOpt.bStages );
+                        fRun = secondsSince( tRun );
+                    }
+                }
+                catch( const std::exception& rE )
+                {
+                    sFailed = rE.what( );
+                    if( sFailed.empty( ) )
+                        sFailed = "device batch failed";
+                }
+                xLock.lock( );
+                vIdle.push_back( std::move( pEngine ) );
+                uiLoading--;
+                if( bEnd )
+                    bEof = true;
+                if( !sFailed.empty( ) )
+                {
+                    bEof = true;
+                    if( sError.empty( ) )
+                        sError = sFailed;
+                }
+                else if( !pBatch->vItems.empty( ) )
+                {
+                    // (with several batches ahead they may finish, and are handed out, in another order than they were pulled)
+                    vReady.push_back( pBatch );
+                    uiBatches++, uiReadsTotal += pBatch->vItems.size( );
+                    fSumRun += fRun, fSumPull += fPullS;
+                }
+                xChanged.notify_all( );
+                continue;
+            }
+            if( !vReady.empty( ) )
+            {
+                std::shared_ptr<Batch> pB = vReady.front( );
+                const size_t k = pB->uiNext;
+                pB->uiNext = std::min( pB->vItems.size( ), k + std::max<size_t>( xOpt.uiSlice, 1 ) );
+                rMine.pOwner = this, rMine.pBatch = pB, rMine.uiNext = k + 1, rMine.uiEnd = pB->uiNext;
+                if( pB->uiNext >= pB->vItems.size( ) )
+                {
+                    vReady.erase( vReady.begin( ) );
+                    xChanged.notify_all( ); // room for another batch ahead
+                }
+                xLock.unlock( );
+                rItem = pB->vItems[ k ];
+                rTicket.pResult = pB->pResult;
+                rTicket.uiRead = k;
+                if( rMine.uiNext >= rMine.uiEnd )
+                    rMine.pBatch.reset( );
+                return true;
+            }
+            if( bEof && uiLoading == 0 )
+                return false;
+            xChanged.wait( xLock );
+        }
+    }
+    void stats( uint64_t& rBatches, uint64_t& rReads, double& rRunSeconds, double& rPullSeconds )
+    {
+        std::lock_guard<std::mutex> xLock( xMutex );
+        rBatches = uiBatches, rReads = uiReadsTotal, rRunSeconds = fSumRun, rPullSeconds = fSumPull;
     }
 };
 } // namespace engine

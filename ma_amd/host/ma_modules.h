@@ -105,6 +105,9 @@ class NucSeq : public libMS::Container // nucSeq.h:61-160: codes A0 C1 G2 T3 N4
     std::vector<uint8_t> xCodes;
     std::vector<uint8_t> xQuality; // FASTQ quality characters (empty = none, nucSeq.h:105-108)
     std::string sName = "unknown";
+    // set by PrefetchReader: this read already went through all stages on the GPU as read uiRead of that device batch
+    // (the binding on the reference's own NucSeq carries it in a subclass, ma_ref_binding.h)
+    detail::Ticket xTicket;
     NucSeq( )
     {}
     NucSeq( const std::string& sText )
@@ -809,7 +812,8 @@ class BinarySeeding : public libMS::Module<SegmentVector, false, SuffixArrayInte
         auto pRet = std::make_shared<SegmentVector>( );
         if( pQuerySeq == nullptr )
             return pRet;
-        pRet->xTicket = batcherFor( pFM_index->pDev )->align( pQuerySeq->xCodes );
+        // a read that came through PrefetchReader has been aligned already; otherwise it joins the funnel and this thread waits
+        pRet->xTicket = pQuerySeq->xTicket ? pQuerySeq->xTicket : batcherFor( pFM_index->pDev )->align( pQuerySeq->xCodes );
         const detail::BatchResult& R = *pRet->xTicket.pResult;
         for( uint64_t i = R.bStages ? R.vSegOff[ pRet->xTicket.uiRead ] : 0; R.bStages && i < R.vSegOff[ pRet->xTicket.uiRead + 1 ]; i++ )
         {
@@ -836,6 +840,45 @@ class BinarySeeding : public libMS::Module<SegmentVector, false, SuffixArrayInte
         if( pBatcher != nullptr )
             pBatcher->stats( b, r );
         return std::make_pair( b, r );
+    }
+};
+
+// The funnel turned round: a volatile source with the signature of the reader it wraps
+// (fileReader.h:475: FileReader : Module<NucSeq, true, FileStream>; here any Module<NucSeq, true, TP_ARGS...>).  It reads
+// AHEAD: a device batch worth of reads is pulled from the wrapped reader, goes through ALL stages on the GPU, and every
+// execute( ) hands the calling graph thread one read of a FINISHED batch with its ticket.  The five modules downstream find
+// the ticket on the query and only pick their slices, so no graph thread ever waits for the GPU per read: the graph of
+// export.cpp:99-126 stays as it is -- only the reader node is wrapped -- and runs with a few dozen threads instead of the
+// thousand the per-read funnel (DeviceBatcher) needs to fill a device batch.
+//     auto pReader = std::make_shared<PrefetchReader<FileStream>>( rParameters, std::make_shared<FileReader>( rParameters ), pFMDIndex );
+template <typename... TP_ARGS> class PrefetchReader : public libMS::Module<NucSeq, true, TP_ARGS...>
+{
+    typedef libMS::Module<NucSeq, true, TP_ARGS...> TP_SOURCE;
+    std::shared_ptr<TP_SOURCE> pSource;
+    detail::PrefetchQueue<std::shared_ptr<NucSeq>> xQueue;
+
+  public:
+    PrefetchReader( const ParameterSetManager& rParameters, std::shared_ptr<TP_SOURCE> pSource, std::shared_ptr<FMIndex> pFM_index,
+                    const detail::PrefetchOptions& rOpt = detail::PrefetchOptions( ) )
+        : pSource( pSource ), xQueue( pFM_index->pDev->p, *rParameters.getSelected( ), rOpt )
+    {}
+    // nullptr = the wrapped reader is exhausted and every read it gave has been handed out (module.h:688-695)
+    virtual std::shared_ptr<NucSeq> execute( std::shared_ptr<TP_ARGS>... pArgs ) override
+    {
+        std::shared_ptr<NucSeq> pQuery;
+        detail::Ticket xTicket;
+        if( !xQueue.next(
+                pQuery, xTicket, [ & ]( ) { return pSource->execute( pArgs... ); },
+                []( const std::shared_ptr<NucSeq>& pQ ) { return detail::ReadRef( pQ->xCodes ); } ) )
+            return nullptr;
+        // a copy carries the ticket: it dies with this read's chain, and the device batch's result can be recycled
+        auto pOut = std::make_shared<NucSeq>( *pQuery );
+        pOut->xTicket = xTicket;
+        return pOut;
+    }
+    void stats( uint64_t& rBatches, uint64_t& rReads, double& rRunSeconds, double& rPullSeconds )
+    {
+        xQueue.stats( rBatches, rReads, rRunSeconds, rPullSeconds );
     }
 };
 

@@ -67,6 +67,7 @@ struct BindingOptions
     // caller does the same
     unsigned int uiRansacSeed = 1;
     engine::BatcherOptions xBatcher; // funnel of the per-read execute() calls (ma_engine.h)
+    engine::PrefetchOptions xPrefetch; // PrefetchReader: reads pulled ahead of the graph threads, a device batch at a time
 };
 inline BindingOptions& options( )
 {
@@ -175,10 +176,33 @@ struct FMIndexAccess : public libMA::FMIndex
     }
 };
 
+// One registered container: the device copy it maps to and a weak reference to the container itself.  The registry is
+// keyed by raw addresses; the weak reference tells a LIVE container from a new one that the allocator happened to put at
+// the address of a genome that was unloaded without detachIndex (whose entry is then dropped instead of being served).
+struct RegistryEntry
+{
+    std::shared_ptr<DeviceIndex> pDev;
+    std::weak_ptr<const void> pOwner;
+    uint64_t uiForwardLength = 0; // of the pair the device copy was made from (Pack: uiUnpackedSizeForwardStrand)
+};
 struct Registry
 {
     std::mutex xMutex;
-    std::map<const void*, std::shared_ptr<DeviceIndex>> xByObject; // keyed by the Pack's AND the FMIndex's address
+    std::map<const void*, RegistryEntry> xByObject; // keyed by the Pack's AND the FMIndex's address
+    // entry of a live container, or nullptr (an entry whose container died is erased: its device copy goes with the last module
+    // that still holds it)
+    RegistryEntry* find( const void* pKey )
+    {
+        auto xIt = xByObject.find( pKey );
+        if( xIt == xByObject.end( ) )
+            return nullptr;
+        if( xIt->second.pOwner.expired( ) )
+        {
+            xByObject.erase( xIt );
+            return nullptr;
+        }
+        return &xIt->second;
+    }
 };
 inline Registry& registry( )
 {
@@ -195,19 +219,22 @@ inline std::shared_ptr<DeviceIndex> attachIndex( const std::shared_ptr<libMA::Pa
 {
     if( pPack == nullptr || pFM == nullptr )
         throw std::runtime_error( "ma_amd::attachIndex: null container" );
+    const uint64_t uiN = pFM->getRefSeqLength( ), uiF = pPack->uiUnpackedSizeForwardStrand;
+    if( uiN != 2 * uiF ) // on the cached path too: any Pack could be bound to an FMIndex that is registered already
+        throw std::runtime_error( "ma_amd::attachIndex: Pack and FMIndex do not belong together" );
     auto& rReg = detail::registry( );
     std::lock_guard<std::mutex> xGuard( rReg.xMutex );
-    auto xIt = rReg.xByObject.find( pFM.get( ) );
-    if( xIt != rReg.xByObject.end( ) )
+    if( detail::RegistryEntry* pHave = rReg.find( pFM.get( ) ) )
     {
-        rReg.xByObject[ pPack.get( ) ] = xIt->second;
-        return xIt->second;
+        if( pHave->uiForwardLength != uiF )
+            throw std::runtime_error( "ma_amd::attachIndex: this FMIndex is attached with another Pack" );
+        detail::RegistryEntry xForPack = *pHave;
+        xForPack.pOwner = std::shared_ptr<const void>( pPack, pPack.get( ) );
+        rReg.xByObject[ pPack.get( ) ] = xForPack;
+        return xForPack.pDev;
     }
     const std::vector<uint32_t>& rBwt = detail::FMIndexAccess::bwtOf( *pFM );
     const std::vector<int64_t>& rSa = detail::FMIndexAccess::saOf( *pFM );
-    const uint64_t uiN = pFM->getRefSeqLength( ), uiF = pPack->uiUnpackedSizeForwardStrand;
-    if( uiN != 2 * uiF )
-        throw std::runtime_error( "ma_amd::attachIndex: Pack and FMIndex do not belong together" );
     if( detail::FMIndexAccess::saIntervalOf( *pFM ) != 32 )
         throw std::runtime_error( "ma_amd::attachIndex: suffix array sampling interval must be 32" );
     uint64_t aL2[ 5 ];
@@ -226,11 +253,17 @@ inline std::shared_ptr<DeviceIndex> attachIndex( const std::shared_ptr<libMA::Pa
     auto pDev = std::make_shared<DeviceIndex>( );
     check( ma_index_create( rBwt.data( ), rBwt.size( ), rSa.data( ), rSa.size( ), aL2, pFM->primary, uiN, vPac.data( ),
                             (int32_t)vStarts.size( ), vStarts.data( ), vLens.data( ), &pDev->p ) );
-    rReg.xByObject[ pFM.get( ) ] = pDev;
-    rReg.xByObject[ pPack.get( ) ] = pDev;
+    detail::RegistryEntry xEntry;
+    xEntry.pDev = pDev;
+    xEntry.uiForwardLength = uiF;
+    xEntry.pOwner = std::shared_ptr<const void>( pFM, pFM.get( ) );
+    rReg.xByObject[ pFM.get( ) ] = xEntry;
+    xEntry.pOwner = std::shared_ptr<const void>( pPack, pPack.get( ) );
+    rReg.xByObject[ pPack.get( ) ] = xEntry;
     return pDev;
 }
-// Frees the device copy once the last module that holds it lets go (call when the genome is unloaded).
+// Frees the device copy once the last module that holds it lets go (call when the genome is unloaded; a genome that is
+// unloaded without it is dropped from the registry the next time its address is looked up or reused).
 inline void detachIndex( const std::shared_ptr<libMA::Pack>& pPack, const std::shared_ptr<libMA::FMIndex>& pFM )
 {
     auto& rReg = detail::registry( );
@@ -242,11 +275,11 @@ inline std::shared_ptr<DeviceIndex> deviceIndexOf( const void* pPackOrFMIndex )
 {
     auto& rReg = detail::registry( );
     std::lock_guard<std::mutex> xGuard( rReg.xMutex );
-    auto xIt = rReg.xByObject.find( pPackOrFMIndex );
-    if( xIt == rReg.xByObject.end( ) )
+    detail::RegistryEntry* pHave = rReg.find( pPackOrFMIndex );
+    if( pHave == nullptr )
         throw std::runtime_error( "ma_amd: this index was not uploaded; call ma_amd::attachIndex( pPack, pFMIndex ) where the "
                                   "genome is loaded" );
-    return xIt->second;
+    return pHave->pDev;
 }
 
 // ---- containers: the reference's own, plus the ticket of the device batch the read went through -------------------------
@@ -256,6 +289,25 @@ inline std::shared_ptr<DeviceIndex> deviceIndexOf( const void* pPackOrFMIndex )
 struct TicketedSegments : public libMA::SegmentVector
 {
     engine::Ticket xTicket;
+};
+// a query PrefetchReader hands out: the read went through all stages already, as read uiRead of that device batch
+struct TicketedQuery : public libMA::NucSeq
+{
+    engine::Ticket xTicket;
+    explicit TicketedQuery( const libMA::NucSeq& rOther )
+    {
+        sName = rOther.sName;
+        iId = rOther.iId;
+#if WITH_QUALITY
+        if( rOther.bHasQuality( ) )
+        {
+            addQuality( );
+            vAppend( rOther.pGetSequenceRef( ), rOther.pxQualityRef, rOther.length( ) );
+        }
+        else
+#endif
+            vAppend( rOther.pGetSequenceRef( ), rOther.length( ) );
+    }
 };
 struct TicketedSoCs : public libMA::SoCPriorityQueue
 {
@@ -424,8 +476,14 @@ class BinarySeeding : public libMS::Module<libMA::SegmentVector, false, libMA::S
         auto pRet = std::make_shared<TicketedSegments>( );
         if( pQuerySeq == nullptr )
             return pRet;
-        const auto pDev = deviceIndexOf( pFM_index.get( ) );
-        pRet->xTicket = batcherFor( pDev )->align( engine::ReadRef( pQuerySeq->pGetSequenceRef( ), pQuerySeq->length( ) ) );
+        // a read that came through PrefetchReader has been aligned already; otherwise it joins the funnel and this thread waits
+        if( const TicketedQuery* pAhead = dynamic_cast<const TicketedQuery*>( pQuerySeq.get( ) ) )
+            pRet->xTicket = pAhead->xTicket;
+        else
+        {
+            const auto pDev = deviceIndexOf( pFM_index.get( ) );
+            pRet->xTicket = batcherFor( pDev )->align( engine::ReadRef( pQuerySeq->pGetSequenceRef( ), pQuerySeq->length( ) ) );
+        }
         const engine::BatchResult& R = *pRet->xTicket.pResult;
         if( R.bStages )
         {
@@ -445,6 +503,53 @@ class BinarySeeding : public libMS::Module<libMA::SegmentVector, false, libMA::S
         uint64_t uiBatches = 0, uiReads = 0;
         if( pBatcher != nullptr )
             pBatcher->stats( uiBatches, uiReads );
+        return std::make_pair( uiBatches, uiReads );
+    }
+};
+
+// ---- PrefetchReader: the funnel turned round ---------------------------------------------------------------------------
+// A volatile source with the signature of the reader it wraps (fileReader.h:475: FileReader : Module<NucSeq, true, FileStream>;
+// any Module<NucSeq, true, TP_ARGS...>).  It reads AHEAD: a device batch worth of reads is pulled from the wrapped reader
+// (one caller at a time), goes through ALL stages on the GPU, and every execute( ) hands the calling graph thread one read of
+// a FINISHED batch, as a TicketedQuery.  The five modules above find the ticket and only pick their slices: no graph thread
+// waits for the GPU per read, so the graph of export.cpp:99-126 -- unchanged but for this one node --
+//     auto pFileReader = std::make_shared<ma_amd::PrefetchReader<FileStream>>( rParameters, std::make_shared<FileReader>( rParameters ), pFMIndex );
+// keeps the GPU busy with a few dozen threads (the per-read funnel behind BinarySeeding needs a thousand).
+template <typename... TP_ARGS> class PrefetchReader : public libMS::Module<libMA::NucSeq, true, TP_ARGS...>
+{
+    typedef libMS::Module<libMA::NucSeq, true, TP_ARGS...> TP_SOURCE;
+    std::shared_ptr<TP_SOURCE> pSource;
+    std::shared_ptr<DeviceIndex> pDev; // keeps the device copy alive
+    engine::PrefetchQueue<std::shared_ptr<libMA::NucSeq>> xQueue;
+
+    static engine::PrefetchOptions withQueues( engine::PrefetchOptions xOpt )
+    {
+        xOpt.bSocQueues = xOpt.bStages; // as for the funnel: the reference's SoCPriorityQueue is filled eagerly
+        return xOpt;
+    }
+
+  public:
+    PrefetchReader( const ::ParameterSetManager& rParameters, std::shared_ptr<TP_SOURCE> pSource, std::shared_ptr<libMA::FMIndex> pFMIndex )
+        : pSource( pSource ), pDev( deviceIndexOf( pFMIndex.get( ) ) ), xQueue( pDev->p, paramsOf( rParameters ), withQueues( options( ).xPrefetch ) )
+    {}
+    // nullptr = the wrapped reader is exhausted and every read it gave has been handed out (module.h:688-695)
+    virtual std::shared_ptr<libMA::NucSeq> execute( std::shared_ptr<TP_ARGS>... pArgs ) override
+    {
+        std::shared_ptr<libMA::NucSeq> pQuery;
+        engine::Ticket xTicket;
+        if( !xQueue.next(
+                pQuery, xTicket, [ & ]( ) { return pSource->execute( pArgs... ); },
+                []( const std::shared_ptr<libMA::NucSeq>& pQ ) { return engine::ReadRef( pQ->pGetSequenceRef( ), pQ->length( ) ); } ) )
+            return nullptr;
+        auto pOut = std::make_shared<TicketedQuery>( *pQuery );
+        pOut->xTicket = xTicket;
+        return pOut;
+    }
+    std::pair<uint64_t, uint64_t> batchStatistics( )
+    {
+        uint64_t uiBatches = 0, uiReads = 0;
+        double fRun = 0, fPull = 0;
+        xQueue.stats( uiBatches, uiReads, fRun, fPull );
         return std::make_pair( uiBatches, uiReads );
     }
 };
@@ -719,9 +824,10 @@ class MappingQuality : public libMS::Module<Alignments, false, libMA::NucSeq, Al
     {
         auto& rReg = detail::registry( );
         std::lock_guard<std::mutex> xGuard( rReg.xMutex );
-        if( rReg.xByObject.empty( ) )
-            throw std::runtime_error( "ma_amd::MappingQuality: no index attached (ma_amd::attachIndex)" );
-        return rReg.xByObject.begin( )->second;
+        for( auto& rKV : rReg.xByObject )
+            if( !rKV.second.pOwner.expired( ) )
+                return rKV.second.pDev;
+        throw std::runtime_error( "ma_amd::MappingQuality: no index attached (ma_amd::attachIndex)" );
     }
 };
 } // namespace ma_amd

@@ -308,8 +308,21 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     pFMDIndex->set( idx.pFM );
     std::vector<std::shared_ptr<BasePledge>> aSinks;
     auto pLock = std::make_shared<Lock<NucSeq>>( xParams );
+    // option 8: the reader node wrapped into ma_amd::PrefetchReader (reads pulled ahead MA_PREFETCH_BATCH at a time and aligned
+    // before any graph thread sees them); the rest of the graph is the same
+    std::shared_ptr<libMS::Module<NucSeq, true>> pReaderNode = pSource;
+    std::shared_ptr<ma_amd::PrefetchReader<>> pAhead;
+    if( ( iOptions & 8 ) != 0 )
+    {
+        if( xGpu.size( ) != 5 )
+            throw std::runtime_error( "the prefetching reader needs all five stages on the GPU" );
+        ma_amd::options( ).xPrefetch.uiBatchReads = getenv( "MA_PREFETCH_BATCH" ) ? (size_t)atoi( getenv( "MA_PREFETCH_BATCH" ) ) : 64;
+        ma_amd::options( ).xPrefetch.bStages = false;
+        pAhead = std::make_shared<ma_amd::PrefetchReader<>>( xParams, pSource, idx.pFM );
+        pReaderNode = pAhead;
+    }
     BasePledge::parallelGraph( uiThreads, [ & ]( ) {
-        auto pQuery_ = promiseMe( pSource ); // volatile source, then the Lock / UnLock pair of export.cpp:101-124
+        auto pQuery_ = promiseMe( pReaderNode ); // volatile source, then the Lock / UnLock pair of export.cpp:101-124
         auto pQuery = promiseMe( pLock, pQuery_ );
         auto pSeeds = promiseMe( S.pSeeding, promiseMe( pCast, pFMDIndex ), pQuery );
         auto pSOCs = promiseMe( S.pSoc, pSeeds, pQuery, pPack, pFMDIndex );
@@ -324,8 +337,12 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     uint64_t uiBatches = 0, uiReads = 0;
     if( S.pGpuSeeding != nullptr )
         std::tie( uiBatches, uiReads ) = S.pGpuSeeding->batchStatistics( );
-    printf( "{\"threads\": %u, \"reads\": %zu, \"device_batches\": %llu, \"reads_in_batches\": %llu}\n", uiThreads, c.reads.size( ),
-            (unsigned long long)uiBatches, (unsigned long long)uiReads );
+    uint64_t uiAheadBatches = 0, uiAheadReads = 0;
+    if( pAhead != nullptr )
+        std::tie( uiAheadBatches, uiAheadReads ) = pAhead->batchStatistics( );
+    printf( "{\"threads\": %u, \"reads\": %zu, \"device_batches\": %llu, \"reads_in_batches\": %llu, \"prefetched_batches\": %llu, "
+            "\"prefetched_reads\": %llu}\n", uiThreads, c.reads.size( ),
+            (unsigned long long)uiBatches, (unsigned long long)uiReads, (unsigned long long)uiAheadBatches, (unsigned long long)uiAheadReads );
     return 0;
 }
 

@@ -185,7 +185,7 @@ static void writeRecords( FILE* f, size_t n, const NucSeq& rQ, const ContainerVe
 
 // N graph copies over one shared reader (export.cpp:84-126: parallelGraph + simultaneousGet)
 static int runThreads( const CaseFile& c, const ParameterSetManager& xParams, std::shared_ptr<Pack> pPackC, std::shared_ptr<FMIndex> pFmC,
-                       const char* sOut, int iThreads, int iRepeat )
+                       const char* sOut, int iThreads, int iRepeat, size_t uiPrefetchBatch = 0 )
 {
     auto pPack = std::make_shared<Pledge<Pack>>( );
     pPack->set( pPackC );
@@ -193,7 +193,21 @@ static int runThreads( const CaseFile& c, const ParameterSetManager& xParams, st
     pFMDIndex->set( pFmC );
     auto pSai = std::make_shared<Pledge<SuffixArrayInterface>>( );
     pSai->set( pFmC );
-    auto pReader = std::make_shared<Reader>( c, iRepeat > 0 ? (size_t)iRepeat : 1 );
+    auto pPlainReader = std::make_shared<Reader>( c, iRepeat > 0 ? (size_t)iRepeat : 1 );
+    // mode "prefetch": the reader node wrapped into a PrefetchReader (reads pulled ahead uiPrefetchBatch at a time, through all
+    // stages on the GPU before any graph thread sees them); the rest of the graph is the same
+    std::shared_ptr<libMS::Module<NucSeq, true>> pReader = pPlainReader;
+    std::shared_ptr<PrefetchReader<>> pAhead;
+    if( uiPrefetchBatch != 0 )
+    {
+        detail::PrefetchOptions xPO;
+        xPO.uiBatchReads = uiPrefetchBatch;
+        xPO.uiDepth = 2;
+        xPO.bStages = defaultBatcherOptions( ).bStages;
+        xPO.bSocQueues = defaultBatcherOptions( ).bSocQueues;
+        pAhead = std::make_shared<PrefetchReader<>>( xParams, pPlainReader, pFmC, xPO );
+        pReader = pAhead;
+    }
     auto pSeeding = std::make_shared<BinarySeeding>( xParams );
     auto pSOC = std::make_shared<StripOfConsideration>( xParams );
     auto pHarmonization = std::make_shared<Harmonization>( xParams );
@@ -218,6 +232,17 @@ static int runThreads( const CaseFile& c, const ParameterSetManager& xParams, st
     BasePledge::simultaneousGet( vSinks );
     const double fSec = std::chrono::duration<double>( std::chrono::steady_clock::now( ) - t0 ).count( );
     auto xStat = pSeeding->batchStatistics( );
+    const unsigned long long uiFunnelled = xStat.second;
+    if( pAhead != nullptr )
+    {
+        double fRun = 0, fPull = 0;
+        pAhead->stats( xStat.first, xStat.second, fRun, fPull );
+        if( uiFunnelled != 0 )
+        {
+            fprintf( stderr, "prefetch mode: %llu reads went through the per-read funnel\n", uiFunnelled );
+            return 1;
+        }
+    }
     printf( "{\"graph_threads\": %d, \"reads\": %zu, \"aligned_reads\": %zu, \"seconds\": %.4f, \"reads_per_s\": %.1f, "
             "\"device_batches\": %llu, \"mean_reads_per_device_batch\": %.1f}\n",
             iThreads, pCollector->uiSeen.load( ), pCollector->uiAligned.load( ), fSec, pCollector->uiSeen.load( ) / fSec,
@@ -380,6 +405,8 @@ int main( int argc, char** argv )
     {
         if( sMode == "threads" )
             return runThreads( c, xParams, pPackC, pFmC, argv[ 3 ], argc >= 6 ? atoi( argv[ 5 ] ) : 8, argc >= 7 ? atoi( argv[ 6 ] ) : 0 );
+        if( sMode == "prefetch" ) // prefetch <threads> <reads per device batch pulled ahead>
+            return runThreads( c, xParams, pPackC, pFmC, argv[ 3 ], argc >= 6 ? atoi( argv[ 5 ] ) : 8, 0, argc >= 7 ? (size_t)atoi( argv[ 6 ] ) : 64 );
         if( sMode == "socs" )
             return runSocs( c, xParams, pPackC, pFmC, argv[ 3 ] );
         if( sMode == "multi" )

@@ -92,6 +92,26 @@ def test_unchanged_graph_with_many_threads_funnels_into_device_batches(tmp_path,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("preset,name", [("default", "small_ref.default.pipe"), ("illumina", "small_ref.illumina.pipe")])
+@pytest.mark.parametrize("threads,batch", [(4, 37), (16, 64), (3, 100000)])
+def test_graph_with_prefetching_reader_needs_no_funnel(tmp_path, gpu_device, preset, name, threads, batch):
+    """the same per-read graph with ONLY the reader node wrapped (PrefetchReader pulls `batch` reads ahead,
+    sends them through all stages on the GPU and hands the graph threads reads that carry their ticket): a handful of graph
+    threads, no read goes through the per-read funnel (the executable fails if one does), every read gets exactly the
+    reference's records; batches smaller than, and larger than, the read set; end of input with reads still being handed out."""
+    import json
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    out = str(tmp_path / "graph.out")
+    line = subprocess.check_output([exe, case, preset, out, "prefetch", str(threads), str(batch)]).decode().strip().splitlines()[-1]
+    info = json.loads(line)
+    want = parse_pipe_dump(os.path.join(G, name + ".gz"))
+    assert info["reads"] == len(want)
+    assert info["device_batches"] == (len(want) + batch - 1) // batch, info
+    _same_alns_and_mq(parse_pipe_dump(out), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("preset,name", [("default", "small_ref.default.pipe"), ("illumina", "small_ref.illumina.pipe")])
 def test_modules_take_over_mid_chain_from_plain_containers(tmp_path, gpu_device, preset, name):
     """Drop-in one stage at a time: every module is fed a container that does NOT come from the preceding MI355X module
     (rebuilt field by field, as the reference's modules would hand it over); each stage then runs on its own through

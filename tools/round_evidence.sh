@@ -3,7 +3,7 @@
 # the Illumina-preset line, rocprofv3 kernel stats + PMC passes of the four workloads, SQ counters of the 10 kb DP stage,
 # the launch timeline of a 50 kb step.  Copy what is to be judged from gpurun_out/ into profiles/ (profiles/README.md).
 #   usage: bash tools/round_evidence.sh [tag=r02]
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/${TAG}_gpu_tests.txt
@@ -13,8 +13,16 @@ cat gpurun_out/${TAG}_gpu_tests.txt
 for wl in 150bp 10kb 50kb; do bash tools/collect_profiles.sh $TAG $wl > gpurun_out/collect_$wl.log 2>&1; done
 bash tools/collect_profiles.sh $TAG 150bp illumina > gpurun_out/collect_illumina.log 2>&1
 cp gpurun_out/prof_${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
-python bench.py > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
-python bench.py --workload 150bp --preset illumina --boundary-reads 0 > gpurun_out/${TAG}_bench_illumina.json 2> gpurun_out/${TAG}_bench_illumina.err
+# the driver's line (all workloads incl. the Illumina preset and the C1 anchor); its per-workload blocks go to the detail file
+python bench.py --detail-file gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
+# the leg `value` comes from -- 150 bp, 3 batches in flight, host to host -- under rocprofv3 (program directly after --):
+# kernel trace -> concurrency timeline, and the same command's --stats summary
+rocprofv3 --kernel-trace --stats -d gpurun_out/tr_h2h -o tr --output-format csv -- python3 bench.py --workload 150bp --inflight 3 --host-io 1 --steps 9 --warmup 1 --cpu-sample 0 --boundary-reads 0 > gpurun_out/tr_h2h.log 2>&1
+python3 tools/overlap_timeline.py $(find gpurun_out/tr_h2h -name "*kernel_trace.csv" | head -1) 3 1 > gpurun_out/${TAG}_overlap_timeline_150bp_h2h.txt
+find gpurun_out/tr_h2h -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_150bp_h2h_inflight3.csv \;
+grep "^{" gpurun_out/tr_h2h.log | tail -1 > gpurun_out/${TAG}_bench_150bp_h2h_inflight3_under_rocprof.json; rm -rf gpurun_out/tr_h2h
+python3 tools/overlap_matrix.py --workload 150bp --steps 12 --inflight 1,2,3 --waves 0,12,16,20 > gpurun_out/${TAG}_overlap_matrix_150bp.txt 2>/dev/null
+python3 tools/pk_prof.py --workload 10kb 2>&1 | grep -v "^{" | grep -v amdgpu.ids > gpurun_out/${TAG}_pk_phase_profile_10kb.txt
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU \
   -d gpurun_out/sq10 -o pmc --output-format csv -- python3 bench.py --workload 10kb --steps 1 --warmup 0 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/sq10.log 2>&1
 python3 tools/pmc_sq.py gpurun_out/sq10 k_ksw > gpurun_out/${TAG}_sq_counters_10kb_dp.txt; rm -rf gpurun_out/sq10
@@ -26,10 +34,8 @@ python3 tools/ksw_prof.py --workload 150bp --boundary-reads 0 --overlap 0 2>&1 |
 python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_bench_default.json").read().strip().splitlines()[-1])
-print("value", d["value"], d["ms_per_step"])
-for w in d["config"]["workloads"]:
-    o = w.get("overlapped") or {}
-    c = (w.get("cpu_baseline") or {})
-    print(w["name"], w["value"], w["ms_per_step"], "overlapped", o.get("value"), "reference", c.get("value"),
-          "mismatching reads", (c.get("parity_check") or {}).get("mismatching_reads"), "of", (c.get("parity_check") or {}).get("reads"))
+print("value", d["value"], d["ms_per_step"], d["config"]["value_is"])
+for k in sorted(d):
+    if k.startswith(("value_", "parity_", "c1_", "cpu_reference_", "dropin_", "roofline_")):
+        print(k, d[k])
 PY
