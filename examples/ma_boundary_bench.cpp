@@ -53,6 +53,21 @@ class VecReader : public Module<NucSeq, true>
     }
 };
 
+// volatile source that hands out a NEW NucSeq per call, as a file reader does (FileReader::execute, fileReader.cpp:37-203)
+class FreshReader : public Module<NucSeq, true>
+{
+  public:
+    const ReadVec& r;
+    std::atomic<size_t> i{ 0 };
+    FreshReader( const ReadVec& r ) : r( r )
+    {}
+    std::shared_ptr<NucSeq> execute( ) override
+    {
+        const size_t k = i++;
+        return k < r.size( ) ? std::make_shared<NucSeq>( *r[ k ] ) : nullptr;
+    }
+};
+
 // execute( ) of a module, timed (thread time summed over all graph threads): where the host side of the per-read graph goes
 template <class TP_MODULE> struct Timed : public TP_MODULE
 {
@@ -138,12 +153,13 @@ static std::string prefetchLeg( const ParameterSetManager& xParams, std::shared_
 {
     const size_t n = pReads->size( );
     auto now = []( ) { return std::chrono::duration<double>( std::chrono::steady_clock::now( ).time_since_epoch( ) ).count( ); };
-    auto pPackP = std::make_shared<Pledge<Pack>>( );
-    pPackP->set( pPack );
-    auto pFmP = std::make_shared<Pledge<FMIndex>>( );
-    pFmP->set( pFM );
-    auto pSai = std::make_shared<Pledge<SuffixArrayInterface>>( );
-    pSai->set( pFM );
+    // Every graph copy gets its own handles of the shared constants (Pack, FMIndex): same objects, but behind a control block
+    // of the copy's own.  A constant pledge hands out a shared_ptr copy per get( ) -- six per read -- and with ONE control block
+    // for all threads those reference counts bounce a cache line between the cores (measured: ~15 us of thread time per read).
+    auto own = []( auto p ) {
+        typedef typename decltype( p )::element_type T;
+        return std::shared_ptr<T>( p.get( ), [ p ]( T* ) {} );
+    };
     double t0 = 0;
     std::string sPrefetch;
     for( int iT : { 8, 16, 32, 64 } )
@@ -151,7 +167,14 @@ static std::string prefetchLeg( const ParameterSetManager& xParams, std::shared_
         detail::PrefetchOptions xPO;
         xPO.uiBatchReads = 1u << 16;
         xPO.uiDepth = 2;
-        auto pSource = std::make_shared<VecReader>( *pReads );
+        // (MA_BOUNDARY_SHARED_READS=1: the source hands out the caller's own objects, which PrefetchReader then has to copy)
+        std::shared_ptr<Module<NucSeq, true>> pSource;
+        if( getenv( "MA_BOUNDARY_SHARED_READS" ) )
+            pSource = std::make_shared<VecReader>( *pReads );
+        else
+            pSource = std::make_shared<FreshReader>( *pReads );
+        if( getenv( "MA_PREFETCH_BATCH" ) )
+            xPO.uiBatchReads = (size_t)atoi( getenv( "MA_PREFETCH_BATCH" ) );
         auto pAhead = std::make_shared<TReader>( xParams, pSource, pFM, xPO );
         auto pSeeding4 = std::make_shared<TSeeding>( xParams );
         auto pSoc4 = std::make_shared<TSoc>( xParams );
@@ -163,6 +186,12 @@ static std::string prefetchLeg( const ParameterSetManager& xParams, std::shared_
         std::vector<std::shared_ptr<BasePledge>> vSinks4;
         for( int t = 0; t < iT; t++ )
         {
+            auto pPackP = std::make_shared<Pledge<Pack>>( );
+            pPackP->set( own( pPack ) );
+            auto pFmP = std::make_shared<Pledge<FMIndex>>( );
+            pFmP->set( own( pFM ) );
+            auto pSai = std::make_shared<Pledge<SuffixArrayInterface>>( );
+            pSai->set( own( std::static_pointer_cast<SuffixArrayInterface>( pFM ) ) );
             auto pQuery = promiseMe( std::make_shared<Lock<NucSeq>>( ), promiseMe( std::static_pointer_cast<PrefetchReader<>>( pAhead ) ) );
             auto pSeeds = promiseMe( std::static_pointer_cast<BinarySeeding>( pSeeding4 ), pSai, pQuery );
             auto pSOCs = promiseMe( std::static_pointer_cast<StripOfConsideration>( pSoc4 ), pSeeds, pQuery, pPackP, pFmP );

@@ -1,0 +1,217 @@
+// stage_chain.h -- kernels of the SoC sweep and Harmonization (stripOfConsideration.cpp:12-161, harmonization.cpp:14-555): k_chain,
+// the wave-cooperative sorts and the window sweep of long reads (k_sort_seeds_wave, k_soc_windows), k_soc_dump, and the
+// compaction of the harmonized sets (k_hseed_counts, k_hset_flatten).  Textually part of pipeline.hip.
+struct ChainKernelArgs
+{
+    IndexView X;
+    ChainParams P;
+    u32 n_reads;
+    const u64* roff;
+    const u64* seed_off;
+    const u32* seed_cnt;
+    const ma_seed* seeds;
+    // scratch carved by seed offset
+    ma_seed* work;
+    SoCEntry* maxima;
+    RefMinMax* mm;
+    ma_seed* setA;
+    ma_seed* setB;
+    ma_seed* outA;
+    Shadow* sh1;
+    Shadow* sh2;
+    double* vX;
+    double* vY;
+    double* med;
+    i32* inl;
+    i32* best;
+    // output
+    ma_seed* hpool; // shared overflow pool (atomic bump pointer CTR_HSEED_USED)
+    u64 hpool_cap;
+    ma_seed* hlocal; // private regions: read r owns [3 * seed_off[r], + 3 * seed_cnt[r])
+    HSet* sets; // n_reads * set_cap
+    u32 set_cap;
+    u32* nsets; // per read
+    unsigned long long* ctr;
+    u32 lanes; // reads per wavefront (lanes_per_wave)
+    // optional: the SoC queues were swept elsewhere (ma_batch_set_soc_heap); carved by seed offset like the scratch
+    const ma_soc* queue;
+    const u32* queue_cnt;
+    // optional (long reads): the sweep ran as separate kernels around the wave-cooperative sorts (k_sort_seeds_wave,
+    // k_soc_windows): strips per read, and which of a read's two sorts the wave kernel did (bit 0 delta, bit 1 reference)
+    const u32* pre_nmx;
+    const u32* pre_sorted;
+};
+
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4, 4 ) ) ) k_chain( ChainKernelArgs A )
+{
+    const u32 r = blockIdx.x * A.lanes + threadIdx.x;
+    if( threadIdx.x >= A.lanes || r >= A.n_reads )
+        return;
+    const u64 off = A.seed_off[ r ];
+    const u32 n = A.seed_cnt[ r ];
+    ChainScratch C;
+    C.work = A.work + off;
+    C.maxima = A.maxima + off;
+    C.mm = A.mm + off;
+    C.setA = A.setA + off;
+    C.setB = A.setB + off;
+    C.outA = A.outA + off;
+    C.sh1 = A.sh1 + off;
+    C.sh2 = A.sh2 + off;
+    C.vX = A.vX + 3 * off;
+    C.vY = A.vY + 3 * off;
+    C.med = A.med + 6 * off;
+    C.inl = A.inl + 3 * off;
+    C.best = A.best + 3 * off;
+    if( A.pre_nmx == nullptr )
+        for( u32 i = 0; i < n; i++ )
+            C.work[ i ] = A.seeds[ off + i ];
+    ChainOut O;
+    O.pool = A.hpool;
+    O.pool_cap = A.hpool_cap;
+    O.pool_used = &A.ctr[ CTR_HSEED_USED ];
+    O.sets = A.sets + (u64)r * A.set_cap;
+    O.set_cap = A.set_cap;
+    O.local = A.hlocal + 3 * off; // seed ranges of different reads are disjoint (but not ordered by read)
+    O.local_cap = 3 * n;
+    u32 err = 0;
+    const u32 qlen = (u32)( A.roff[ r + 1 ] - A.roff[ r ] );
+    const u32 ns = chain_read( A.X, A.P, C, n, qlen, O, err, A.queue ? A.queue + off : nullptr, A.queue ? A.queue_cnt[ r ] : 0,
+                               A.pre_nmx != nullptr, A.pre_nmx ? A.pre_nmx[ r ] : 0, A.pre_sorted ? ( A.pre_sorted[ r ] & 2u ) != 0 : false );
+    A.nsets[ r ] = ns < A.set_cap ? ns : A.set_cap;
+    if( err )
+        atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
+}
+
+// ---- long reads: the two big sorts of the sweep as wave-cooperative kernels (wave_sort.h), the window sweep between them
+struct PackedKeyLess
+{
+    __device__ bool operator( )( u64 a, u64 b ) const
+    {
+        return ( a >> 20 ) < ( b >> 20 );
+    }
+};
+// reads with fewer seeds are sorted by their lane in k_soc_windows / k_chain as before: a wavefront per read pays off when the
+// sort has many large ranges to partition (10 kb reads, ~250 seeds: 28 ms of wave sorts vs 17 ms inside the lane kernels)
+#define MA_WSORT_MIN 768u
+#define MA_WSORT_SMALL 2688u // reads with up to this many seeds: 37 KB of LDS per wavefront
+#define MA_WSORT_LARGE 8192u // up to this many: 100 KB; more -> the lane-serial sort of chain.h
+// One wavefront per read.  mode 0: work = seeds sorted by delta (reads outside [nMin, nMax] of this launch are left alone,
+// reads it owns but cannot sort are copied unsorted); mode 1: work re-sorted by reference position in place (via tmp).
+__global__ void __launch_bounds__( 64 ) k_sort_seeds_wave( u32 n_reads, const u64* seed_off, const u32* seed_cnt, const ma_seed* seeds,
+                                                          ma_seed* work, ma_seed* tmp, u32* sorted, int mode, u32 nMin, u32 nMax,
+                                                          u32 nSortMin, u32 nSortMax )
+{
+    extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[];
+    const u32 r = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    if( r >= n_reads )
+        return;
+    const u32 n = seed_cnt[ r ];
+    if( n < nMin || n > nMax )
+        return;
+    const u64 off = seed_off[ r ];
+    bool doSort = n >= nSortMin && n <= nSortMax;
+    const ma_seed* src = mode == 0 ? seeds + off : work + off;
+    ws::Scratch S = ws::carve( lds, doSort ? n : 1 );
+    if( doSort )
+    {
+        bool wide = false;
+        for( u32 i = lane; i < n; i += 64 )
+        {
+            const u64 key = mode == 0 ? (u64)src[ i ].delta : (u64)src[ i ].r_start;
+            wide = wide || ( key >> 44 ) != 0;
+            S.a[ i ] = ( key << 20 ) | (u64)i;
+        }
+        if( __ballot( wide ) != 0 )
+            doSort = false; // does not pack (never for genomes below 2^44 positions)
+        __syncthreads( );
+    }
+    if( !doSort )
+    {
+        if( mode == 0 )
+            for( u32 i = lane; i < n; i += 64 )
+                work[ off + i ] = src[ i ];
+        return;
+    }
+    ws::wave_std_sort( S, (i32)n, PackedKeyLess( ) );
+    if( mode == 0 )
+        for( u32 i = lane; i < n; i += 64 )
+            work[ off + i ] = src[ (u32)( S.a[ i ] & 0xfffffu ) ];
+    else
+    {
+        for( u32 i = lane; i < n; i += 64 )
+            tmp[ off + i ] = src[ (u32)( S.a[ i ] & 0xfffffu ) ];
+        for( u32 i = lane; i < n; i += 64 ) // every lane copies back what it wrote itself
+            work[ off + i ] = tmp[ off + i ];
+    }
+    if( lane == 0 )
+        sorted[ r ] |= 1u << mode;
+}
+// the sweep between the two sorts, one read per lane (thin waves like k_chain)
+__global__ void __launch_bounds__( 64 ) k_soc_windows( IndexView X, ChainParams P, u32 n_reads, u32 lanes, const u64* roff, const u64* seed_off,
+                                                      const u32* seed_cnt, ma_seed* work, SoCEntry* maxima, RefMinMax* mm, ma_seed* tmp,
+                                                      const u32* sorted, u32* pre_nmx )
+{
+    const u32 r = blockIdx.x * lanes + threadIdx.x;
+    if( threadIdx.x >= lanes || r >= n_reads )
+        return;
+    const u64 off = seed_off[ r ];
+    const bool byDelta = ( sorted[ r ] & 1u ) != 0;
+    // (tmp is the keyed sort's scratch, free when the wave-cooperative kernel did the sort: 40 n bytes for the 12 (n + 1) of the prefix
+    // sums.  Reads sorted in here -- 10 kb: ~240 seeds -- gain nothing: building the sums costs what they save, 55.3 vs 57.7 ms)
+    pre_nmx[ r ] = soc_windows( X, P, work + off, seed_cnt[ r ], (u32)( roff[ r + 1 ] - roff[ r ] ), maxima + off, mm + off, tmp + off,
+                                byDelta, byDelta && seed_cnt[ r ] >= 2 ? (u64*)( tmp + off ) : nullptr );
+}
+
+// the SoC queue of every read in pop order (ma_batch_get_socs); scratch and output carved by the read's seed offset
+__global__ void __launch_bounds__( 64 ) k_soc_dump( IndexView X, ChainParams P, u32 n_reads, const u64* roff, const u64* seed_off,
+                                                   const u32* seed_cnt, const ma_seed* seeds, ma_seed* work, SoCEntry* maxima,
+                                                   RefMinMax* mm, ma_soc* socs, u32* nsocs, int heap_layout )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    const u64 off = seed_off[ r ];
+    const u32 n = seed_cnt[ r ];
+    for( u32 i = 0; i < n; i++ )
+        work[ off + i ] = seeds[ off + i ];
+    nsocs[ r ] = soc_dump_read( X, P, work + off, n, (u32)( roff[ r + 1 ] - roff[ r ] ), maxima + off, mm + off, socs + off, heap_layout != 0 );
+}
+
+// harmonized seeds of a read (sum of its sets' sizes), input of the scan that lays out the dense pool
+__global__ void k_hseed_counts( const HSet* sets, u32 set_cap, const u32* nsets, u32 n_reads, u64* cnt )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    u64 c = 0;
+    for( u32 k = 0; k < nsets[ r ]; k++ )
+        c += sets[ (u64)r * set_cap + k ].cnt;
+    cnt[ r ] = c;
+}
+
+// flatten the per-read set tables into CSR order (hset_off from an exclusive scan of nsets) and compact the seeds of
+// the sets (private regions / overflow pool) into one dense pool in read order (hseed_off from a scan of the counts)
+__global__ void k_hset_flatten( const HSet* sets, u32 set_cap, const u32* nsets, const u64* hset_off, u32 n_reads,
+                                const u64* hseed_off, const u64* seed_off, const ma_seed* hlocal, const ma_seed* hovf,
+                                ma_seed* dense, HSet* flat, u32* flat_read )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    if( r >= n_reads )
+        return;
+    const u64 o = hset_off[ r ];
+    u64 d = hseed_off[ r ];
+    const ma_seed* mine = hlocal + 3 * seed_off[ r ];
+    for( u32 k = 0; k < nsets[ r ]; k++ )
+    {
+        HSet h = sets[ (u64)r * set_cap + k ];
+        const ma_seed* src = ( h.off & MA_HSET_LOCAL ) ? mine + ( h.off & ~MA_HSET_LOCAL ) : hovf + h.off;
+        for( u32 i = 0; i < h.cnt; i++ )
+            dense[ d + i ] = src[ i ];
+        h.off = d;
+        d += h.cnt;
+        flat[ o + k ] = h;
+        flat_read[ o + k ] = r;
+    }
+}

@@ -1,0 +1,536 @@
+// stage_dp.h -- kernels of the NeedlemanWunsch stage around the kswcpp kernels of ksw_launch.h (needlemanWunsch.cpp:82-877,
+// mappingQuality.cpp:11-131): k_dp_enum (job enumeration), k_job_cost, k_ops_caps, k_stitch / k_stitch_wave (the walk that
+// assembles the alignments), k_finish (sort + MappingQuality).  Textually part of pipeline.hip.
+struct SetInfo // per harmonized set, filled by the enumeration pass
+{
+    u64 win_begin, win_end;
+    u32 valid;
+    u32 n_jobs;
+};
+
+struct EnumSink
+{
+    static const bool STITCH = false;
+    DpJob* jobs; // slots of this set
+    u32 n;
+    u32 cap;
+    u32 slot0; // global index of jobs[0]
+    u64 win_begin, read_off;
+    // sizing of the ksw launches, accumulated per lane and reduced once per wave by the kernel
+    u64 mx_state = 0, mx_h = 0, mx_p = 0, mx_cig = 0, mx_qlen = 0, n_jobs = 0, seq_bytes = 0;
+    MA_HD void job( u32 qf, u32 qt, u32 rf, u32 rt, i32 w, i32 zdrop, i32 flag, u32 rev )
+    {
+        if( n < cap )
+        {
+            DpJob j;
+            j.win_begin = win_begin;
+            j.read_off = read_off;
+            j.q_from = qf, j.q_to = qt, j.r_from = rf, j.r_to = rt;
+            j.w = w, j.zdrop = zdrop, j.flag = flag, j.rev = rev;
+            jobs[ n ] = j;
+#if defined( __HIP_DEVICE_COMPILE__ )
+            const i32 ql = (i32)( qt - qf ), tl = (i32)( rt - rf );
+            const u64 L = (u64)( ( tl + 15 ) / 16 ) * 16;
+            const u64 p = (u64)( (i64)ql + tl - 1 ) * (u64)( ksw_ncol( ql, tl, w ) * 16 ) + 16;
+            mx_state = mmax( mx_state, ksw_state_bytes( ql, tl ) );
+            mx_h = mmax( mx_h, L * 4 );
+            mx_p = mmax( mx_p, p );
+            mx_cig = mmax( mx_cig, (u64)ql + tl + 2 );
+            mx_qlen = mmax( mx_qlen, (u64)ql );
+            n_jobs++;
+            seq_bytes += (u64)( ql + tl );
+#endif
+        }
+        n++;
+    }
+    MA_HD KswResult next( )
+    {
+        return KswResult{ -1, -1, nullptr, 0 };
+    }
+};
+
+struct DpKernelArgs
+{
+    IndexView X;
+    NwParams P;
+    u32 n_sets;
+    const HSet* sets;
+    const u32* set_read;
+    const ma_seed* hpool;
+    const uint8_t* reads;
+    const u64* roff;
+    DpJob* jobs; // 2 slots per pooled harmonized seed: slots of set s start at 2*sets[s].off
+    SetInfo* info;
+    unsigned long long* ctr;
+    u32* lists;
+    u64 list_stride;
+    KswScoring SC;
+    u32 lanes; // sets per wavefront (lanes_per_wave)
+    u32 wave_split; // long reads: sets that span >= 1024 query bases go to k_stitch_wave
+};
+
+#if defined( __HIPCC__ )
+__device__ __forceinline__ u64 wave_max_u64( u64 v )
+{
+    for( int m = 32; m; m >>= 1 )
+    {
+        const u64 o = ( (u64)(u32)__shfl_xor( (int)( v >> 32 ), m, 64 ) << 32 ) | (u32)__shfl_xor( (int)(u32)v, m, 64 );
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ u64 wave_sum_u64( u64 v )
+{
+    for( int m = 32; m; m >>= 1 )
+        v += ( (u64)(u32)__shfl_xor( (int)( v >> 32 ), m, 64 ) << 32 ) | (u32)__shfl_xor( (int)(u32)v, m, 64 );
+    return v;
+}
+#endif
+
+__device__ void dp_enum_one( const DpKernelArgs& A, u32 s, EnumSink& sink )
+{
+    const HSet hs = A.sets[ s ];
+    const ma_seed* S = A.hpool + hs.off;
+    const u32 rd = A.set_read[ s ];
+    const u64 qlen = A.roff[ rd + 1 ] - A.roff[ rd ];
+    SetInfo I;
+    const NwWindow W = nw_window( A.X, A.P, S, hs.cnt );
+    I.win_begin = W.begin_ref;
+    I.win_end = W.end_ref;
+    I.valid = W.valid ? 1 : 0;
+    I.n_jobs = 0;
+    if( W.valid )
+    {
+        sink.jobs = A.jobs + 2 * hs.off;
+        sink.slot0 = (u32)( 2 * hs.off );
+        sink.n = 0;
+        sink.cap = 2 * hs.cnt;
+        sink.win_begin = W.begin_ref;
+        sink.read_off = A.roff[ rd ];
+        NwWalk<EnumSink> walk{ A.X, A.P, sink, A.reads + A.roff[ rd ], W.begin_ref, AlnBuilder{ nullptr, nullptr, nullptr } };
+        walk.run( S, hs.cnt, qlen, W );
+        I.n_jobs = sink.n < sink.cap ? sink.n : sink.cap;
+        if( sink.n > sink.cap )
+            atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)MA_ERR_SCRATCH_OVERFLOW );
+    }
+    A.info[ s ] = I;
+}
+
+__global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
+{
+    const u32 s = blockIdx.x * A.lanes + threadIdx.x;
+    EnumSink sink;
+    sink.n = 0;
+    sink.cap = 0;
+    sink.slot0 = 0;
+    if( threadIdx.x < A.lanes && s < A.n_sets )
+        dp_enum_one( A, s, sink );
+    u32 pcl[ KSW_N_CLASSES ], cgl[ KSW_N_CLASSES ], pRedo = 0, cgRedo = 0;
+    // append the jobs to the per-class lists: one atomic per wave, class and round instead of one per job
+    {
+        const u32 mine = sink.n < sink.cap ? sink.n : sink.cap;
+        const u32 rounds = (u32)wave_max_u64( mine );
+        const int lane = threadIdx.x & 63;
+        // scratch per wave of each class's launch: the classes differ by orders of magnitude (a 50 kb end extension
+        // needs 27 MB of direction bytes, a gap between two seeds a few KB), and a launch sized for the largest job of
+        // the whole batch would leave most of the machine without waves
+#pragma unroll
+        for( int c = 0; c < KSW_N_CLASSES; c++ )
+            pcl[ c ] = cgl[ c ] = 0;
+        for( u32 k = 0; k < rounds; k++ )
+        {
+            int cls = -1;
+            u32 pj = 0, cj = 0;
+            if( k < mine )
+            {
+                const DpJob& j = A.jobs[ sink.slot0 + k ];
+                const i32 ql = (i32)( j.q_to - j.q_from ), tl = (i32)( j.r_to - j.r_from );
+                cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
+                const u64 pk = ksw_p_bytes( ql, tl, j.w );
+                pj = (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 ); // 256-byte units
+                cj = (u32)( ql + tl + 2 );
+                if( cls >= 5 )
+                {
+                    pRedo = max( pRedo, (u32)( ( pk + 255 ) >> 8 ) );
+                    cgRedo = max( cgRedo, cj );
+                }
+            }
+#pragma unroll
+            for( int c = 0; c < KSW_N_CLASSES; c++ )
+            {
+                if( cls == c )
+                {
+                    pcl[ c ] = max( pcl[ c ], pj );
+                    cgl[ c ] = max( cgl[ c ], cj );
+                }
+                const unsigned long long m = __ballot( cls == c );
+                if( m == 0 )
+                    continue;
+                const int leader = __ffsll( (long long)m ) - 1;
+                unsigned long long base = 0;
+                if( lane == leader )
+                    base = atomicAdd( &A.ctr[ CTR_CLS0 + c ], (unsigned long long)__popcll( m ) );
+                base = ( (u64)(u32)__shfl( (int)( base >> 32 ), leader, 64 ) << 32 ) | (u32)__shfl( (int)(u32)base, leader, 64 );
+                if( cls == c )
+                    A.lists[ (u64)c * A.list_stride + base + __popcll( m & ( ( 1ull << lane ) - 1 ) ) ] = sink.slot0 + k;
+            }
+        }
+    }
+    // one atomic per wave and quantity instead of eight per job
+    const u64 st = wave_max_u64( sink.mx_state ), h = wave_max_u64( sink.mx_h ), p = wave_max_u64( sink.mx_p );
+    const u64 cg = wave_max_u64( sink.mx_cig ), ql = wave_max_u64( sink.mx_qlen );
+    const u64 nj = wave_sum_u64( sink.n_jobs ), sb = wave_sum_u64( sink.seq_bytes );
+    u64 pcW[ KSW_N_CLASSES ], cgW[ KSW_N_CLASSES ];
+#pragma unroll
+    for( int c = 0; c < KSW_N_CLASSES; c++ )
+    {
+        pcW[ c ] = wave_max_u64( pcl[ c ] );
+        cgW[ c ] = wave_max_u64( cgl[ c ] );
+    }
+    const u64 pRedoW = wave_max_u64( pRedo ), cgRedoW = wave_max_u64( cgRedo );
+    if( ( threadIdx.x & 63 ) == 0 && nj )
+    {
+        atomicMax( &A.ctr[ CTR_MAX_STATE ], (unsigned long long)st );
+        atomicMax( &A.ctr[ CTR_MAX_H ], (unsigned long long)h );
+        atomicMax( &A.ctr[ CTR_MAX_P ], (unsigned long long)p );
+        atomicMax( &A.ctr[ CTR_MAX_CIG ], (unsigned long long)cg );
+        atomicMax( &A.ctr[ CTR_MAX_QLEN ], (unsigned long long)ql );
+#pragma unroll
+        for( int c = 0; c < KSW_N_CLASSES; c++ )
+        {
+            if( pcW[ c ] )
+                atomicMax( &A.ctr[ CTR_MAX_PC0 + c ], (unsigned long long)pcW[ c ] << 8 );
+            if( cgW[ c ] )
+                atomicMax( &A.ctr[ CTR_MAX_CIGC0 + c ], (unsigned long long)cgW[ c ] );
+        }
+        if( pRedoW )
+        {
+            atomicMax( &A.ctr[ CTR_MAX_P_REDO ], (unsigned long long)pRedoW << 8 );
+            atomicMax( &A.ctr[ CTR_MAX_CIG_REDO ], (unsigned long long)cgRedoW );
+        }
+        atomicAdd( &A.ctr[ CTR_N_JOBS ], (unsigned long long)nj );
+        atomicAdd( &A.ctr[ CTR_SEQ_BYTES ], (unsigned long long)sb );
+    }
+}
+
+namespace
+{
+struct PipeFetch
+{
+    static const bool EARLY = true; // the stitch pass reads only max_q, max_t and the cigar (ksw_reg.h)
+    IndexView X;
+    const DpJob* jobs;
+    const uint8_t* reads;
+    __device__ bool valid( u32 s ) const
+    {
+        return jobs[ s ].q_to > jobs[ s ].q_from; // slots are zero-filled before enumeration
+    }
+    __device__ KswJobView view( u32 s ) const
+    {
+        const DpJob& j = jobs[ s ];
+        KswJobView v;
+        v.qlen = (i32)( j.q_to - j.q_from );
+        v.tlen = (i32)( j.r_to - j.r_from );
+        v.w = j.w;
+        v.zdrop = j.zdrop;
+        v.flag = j.flag;
+        return v;
+    }
+    struct Q
+    {
+        const uint8_t* q;
+        u32 from, to, rev;
+        __device__ u32 operator( )( i32 i ) const
+        {
+            return rev ? q[ to - 1 - (u32)i ] : q[ from + (u32)i ];
+        }
+    };
+    struct T
+    {
+        IndexView X;
+        u64 base;
+        u32 from, to, rev;
+        __device__ u32 operator( )( i32 i ) const
+        {
+            return text_base( X, base + ( rev ? to - 1 - (u32)i : from + (u32)i ) );
+        }
+        // bases of cells i and i + 1 (low / high half) with one address computation; i < to - from; the high half repeats
+        // cell i when i + 1 is past the window (the caller masks it).  A DP window never bridges the two strands.
+        static const bool CLEAN = true; // codes 0..3 only (2-bit pack): no N to recode
+        __device__ u32 pair( i32 i ) const
+        {
+            // the window lies on one strand, so strand and step direction are wave-uniform: forward position of cell i =
+            // fFirst + sgn * i
+            const u64 pFirst = base + ( rev ? to - 1 : from );
+            const bool comp = pFirst >= X.F;
+            const i32 sgn = ( rev != 0 ) != comp ? -1 : 1;
+            const u64 fFirst = comp ? X.n - 1 - pFirst : pFirst;
+            const u64 f0 = fFirst + (u64)(i64)( sgn * i );
+            const u64 f1 = f0 + (u64)(i64)( (u32)i + 1 < to - from ? sgn : 0 );
+            u32 b0 = ( (u32)X.pac[ f0 >> 2 ] >> ( ( ~(u32)f0 & 3 ) << 1 ) ) & 3;
+            u32 b1 = ( (u32)X.pac[ f1 >> 2 ] >> ( ( ~(u32)f1 & 3 ) << 1 ) ) & 3;
+            const u32 flip = comp ? 0x00030003u : 0u; // complement of a 2-bit code = code ^ 3
+            return ( b0 | b1 << 16 ) ^ flip;
+        }
+    };
+    __device__ Q qfetch( u32 s ) const
+    {
+        const DpJob& j = jobs[ s ];
+        return Q{ reads + j.read_off, j.q_from, j.q_to, j.rev };
+    }
+    __device__ T tfetch( u32 s ) const
+    {
+        const DpJob& j = jobs[ s ];
+        return T{ X, j.win_begin, j.r_from, j.r_to, j.rev };
+    }
+};
+} // namespace
+
+// Longest jobs first: a persistent launch whose waves pull jobs from a queue ends when its LAST job ends, and a long job
+// taken late is a tail with one busy wave.  The lists of the exact register kernels (long-read batches: 10^4..10^6 jobs of
+// 10^3..10^8 cells) are therefore sorted by descending direction-matrix size before the launch (LPT rule).
+__global__ void k_job_cost( PipeFetch F, const u32* list, u32 n, u32* key )
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i >= n )
+        return;
+    const KswJobView J = F.view( list[ i ] );
+    const u64 c = ksw_p_bytes( J.qlen, J.tlen, J.w ) >> 6;
+    key[ i ] = c > 0xffffffffull ? 0xffffffffu : (u32)c;
+}
+
+// ops capacity of a set: |Q| + sum of its jobs' cigar lengths + 8 * seeds + 16 (see nw.h)
+__global__ void k_ops_caps( const HSet* sets, const SetInfo* info, const u32* set_read, const u64* roff,
+                            const ma_ez* ez, u32 n_sets, u64* caps )
+{
+    const u32 s = blockIdx.x * blockDim.x + threadIdx.x;
+    if( s >= n_sets )
+        return;
+    const HSet hs = sets[ s ];
+    const u32 rd = set_read[ s ];
+    u64 c = ( roff[ rd + 1 ] - roff[ rd ] ) + 8ull * hs.cnt + 16;
+    for( u32 k = 0; k < info[ s ].n_jobs; k++ )
+        c += (u64)ez[ 2 * hs.off + k ].n_cigar;
+    caps[ s ] = info[ s ].valid ? c : 0;
+}
+
+struct StitchSink
+{
+    static const bool STITCH = true;
+    const ma_ez* ez;
+    const u64* cig_off;
+    const u32* cig_pool;
+    u32 k;
+    MA_HD void job( u32, u32, u32, u32, i32, i32, i32, u32 )
+    {}
+    MA_HD KswResult next( )
+    {
+        KswResult R;
+        R.max_q = ez[ k ].max_q;
+        R.max_t = ez[ k ].max_t;
+        R.n_cigar = (u32)ez[ k ].n_cigar;
+        R.cigar = cig_pool + cig_off[ k ];
+        k++;
+        return R;
+    }
+};
+
+struct StitchKernelArgs
+{
+    IndexView X;
+    NwParams P;
+    u32 n_sets;
+    const HSet* sets;
+    const u32* set_read;
+    const SetInfo* info;
+    const ma_seed* hpool;
+    const uint8_t* reads;
+    const u64* roff;
+    const ma_ez* ez;
+    const u64* cig_off;
+    const u32* cig_pool;
+    const u64* ops_off; // exclusive scan of caps
+    const u64* ops_cap;
+    u64* ops;
+    AlnHeader* hdr;
+    unsigned long long* ctr;
+    u32 lanes; // sets per wavefront (lanes_per_wave)
+    u32 wave_split; // long reads: sets that span >= 1024 query bases go to k_stitch_wave
+};
+
+// what k_stitch_wave keeps in LDS of the set it walks: the next 64 seeds and the records of the next 64 jobs (with the first
+// four cigar entries of each), loaded by the 64 lanes at once -- step by step each of them is a memory round trip that all
+// lanes wait for (a 50 kb alignment: ~5 k seeds and ~5 k gap fills)
+struct StitchWaveCache
+{
+    u64 sq[ 64 ], sr[ 64 ], sl[ 64 ];
+    i32 jq[ 64 ], jt[ 64 ];
+    u32 jn[ 64 ];
+    u64 joff[ 64 ];
+    uint4 jc[ 64 ];
+};
+struct StitchSinkWave : StitchSink
+{
+    static const bool WAVE = true;
+    StitchWaveCache* C;
+    u32 seedBase = 0x80000000u, jobBase = 0x80000000u, nJobs = 0;
+    __device__ void seed( const ma_seed* S, u32 n, u32 kk, u64& q, u64& r, u64& l )
+    {
+        if( kk - seedBase >= 64u )
+        {
+            const u32 lane = threadIdx.x & 63, i = kk + lane;
+            __syncthreads( );
+            if( i < n )
+            {
+                const ma_seed x = S[ i ];
+                C->sq[ lane ] = (u64)x.q_start, C->sr[ lane ] = (u64)x.r_start, C->sl[ lane ] = (u64)x.len;
+            }
+            seedBase = kk;
+            __syncthreads( );
+        }
+        const u32 d = kk - seedBase;
+        q = C->sq[ d ], r = C->sr[ d ], l = C->sl[ d ];
+    }
+    __device__ KswResult next( )
+    {
+        if( k - jobBase >= 64u )
+        {
+            const u32 lane = threadIdx.x & 63, i = k + lane;
+            __syncthreads( );
+            if( i < nJobs )
+            {
+                const ma_ez e = ez[ i ];
+                const u64 off = cig_off[ i ];
+                C->jq[ lane ] = e.max_q, C->jt[ lane ] = e.max_t, C->jn[ lane ] = (u32)e.n_cigar, C->joff[ lane ] = off;
+                uint4 c = make_uint4( 0, 0, 0, 0 );
+                const u32* p = cig_pool + off;
+                if( e.n_cigar > 0 )
+                    c.x = p[ 0 ];
+                if( e.n_cigar > 1 )
+                    c.y = p[ 1 ];
+                if( e.n_cigar > 2 )
+                    c.z = p[ 2 ];
+                if( e.n_cigar > 3 )
+                    c.w = p[ 3 ];
+                C->jc[ lane ] = c;
+            }
+            jobBase = k;
+            __syncthreads( );
+        }
+        const u32 d = k - jobBase;
+        KswResult R;
+        R.max_q = C->jq[ d ], R.max_t = C->jt[ d ], R.n_cigar = C->jn[ d ];
+        R.cigar = cig_pool + C->joff[ d ];
+        const uint4 c = C->jc[ d ];
+        R.first[ 0 ] = c.x, R.first[ 1 ] = c.y, R.first[ 2 ] = c.z, R.first[ 3 ] = c.w;
+        R.cached = true;
+        k++;
+        return R;
+    }
+};
+// Sets whose walk is long enough to be worth a wavefront of their own (k_stitch_wave): the seeds span >= 1024 query bases.
+// (A batch of 20 k reads of 50 kb has 2 * 10^5 sets; the ~10 % that span the read are ~all of the bases to compare, and as
+// lanes of the one-set-per-lane kernel each of them kept its wavefront busy for its whole length: 69 ms.)
+__device__ __forceinline__ bool stitch_is_big( const StitchKernelArgs& A, u32 s )
+{
+    if( !A.wave_split )
+        return false;
+    const HSet hs = A.sets[ s ];
+    if( hs.cnt == 0 || !A.info[ s ].valid )
+        return false;
+    const ma_seed first = A.hpool[ hs.off ], last = A.hpool[ hs.off + hs.cnt - 1 ];
+    return (u64)last.q_start + (u64)last.len >= (u64)first.q_start + 1024;
+}
+__device__ __forceinline__ void stitch_sink_setup( StitchSink&, const SetInfo&, StitchWaveCache* )
+{}
+__device__ __forceinline__ void stitch_sink_setup( StitchSinkWave& sink, const SetInfo& I, StitchWaveCache* cache )
+{
+    sink.C = cache;
+    sink.nJobs = I.n_jobs;
+}
+template <typename SINK> __device__ __forceinline__ u64 stitch_set( const StitchKernelArgs& A, u32 s, StitchWaveCache* cache )
+{
+    const HSet hs = A.sets[ s ];
+    const u32 rd = A.set_read[ s ];
+    const SetInfo I = A.info[ s ];
+    AlnHeader h;
+    h.begin_ref = h.end_ref = 0;
+    h.begin_q = h.end_q = 0;
+    h.score = 0;
+    h.length = 0;
+    h.ops_off = A.ops_off[ s ];
+    h.n_ops = 0;
+    h.ops_cap = (u32)A.ops_cap[ s ];
+    h.soc_index = hs.soc;
+    h.secondary = h.supplementary = 0;
+    h.mapq = NAN;
+    u32 err = 0;
+    if( I.valid )
+    {
+        h.begin_ref = h.end_ref = I.win_begin;
+        NwWindow W;
+        W.begin_ref = I.win_begin;
+        W.end_ref = I.win_end;
+        W.valid = true;
+        SINK sink;
+        sink.ez = A.ez + 2 * hs.off, sink.cig_off = A.cig_off + 2 * hs.off, sink.cig_pool = A.cig_pool, sink.k = 0;
+        stitch_sink_setup( sink, I, cache );
+        NwWalk<SINK> walk{ A.X, A.P, sink, A.reads + A.roff[ rd ], I.win_begin, AlnBuilder{ &h, A.ops + h.ops_off, &err } };
+        walk.run( A.hpool + hs.off, hs.cnt, A.roff[ rd + 1 ] - A.roff[ rd ], W );
+    }
+    if( !sink_is_wave<SINK>::value || ( threadIdx.x & 63 ) == 0 )
+    {
+        A.hdr[ s ] = h;
+        if( err )
+            atomicOr( (unsigned long long*)&A.ctr[ CTR_ERR ], (unsigned long long)err );
+    }
+    return h.n_ops;
+}
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 6 ) ) ) k_stitch( StitchKernelArgs A )
+{
+    const u32 s = blockIdx.x * A.lanes + threadIdx.x;
+    u64 nOps = 0;
+    if( threadIdx.x < A.lanes && s < A.n_sets && !stitch_is_big( A, s ) )
+        nOps = stitch_set<StitchSink>( A, s, nullptr );
+    // exact size of the ops download (all alignments): one atomic per wave
+    const u64 total = wave_sum_u64( nOps );
+    if( ( threadIdx.x & 63 ) == 0 && total )
+        atomicAdd( &A.ctr[ CTR_OPS_ALL ], (unsigned long long)total );
+}
+// one set per wavefront: the sets k_stitch left out
+__global__ void __launch_bounds__( 64 ) k_stitch_wave( StitchKernelArgs A )
+{
+    const u32 s = blockIdx.x;
+    if( !stitch_is_big( A, s ) )
+        return;
+    __shared__ StitchWaveCache cache;
+    const u64 nOps = stitch_set<StitchSinkWave>( A, s, &cache );
+    if( threadIdx.x == 0 && nOps )
+        atomicAdd( &A.ctr[ CTR_OPS_ALL ], (unsigned long long)nOps );
+}
+
+// per read: NeedlemanWunsch::execute's final sort + MappingQuality::execute
+__global__ void k_finish( NwParams P, u32 n_reads, const u64* hset_off, const u64* roff, AlnHeader* hdr, const u64* ops,
+                          u32* order, u32* mq_order, u32* mq_cnt, unsigned long long* ctr, int nw_sort )
+{
+    const u32 r = blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 b = r < n_reads ? hset_off[ r ] : 0;
+    const u32 n = r < n_reads ? (u32)( hset_off[ r + 1 ] - b ) : 0;
+    u32 m = 0;
+    u64 opsMq = 0;
+    if( r < n_reads )
+    {
+        m = finish_read( P, hdr + b, ops, n, roff[ r + 1 ] - roff[ r ], order + b, mq_order + b, nw_sort != 0 );
+        mq_cnt[ r ] = m;
+        for( u32 k = 0; k < m; k++ )
+            opsMq += hdr[ b + mq_order[ b + k ] ].n_ops;
+    }
+    // one atomic per wave and quantity
+    const u64 al = wave_sum_u64( m ? 1 : 0 ), am = wave_sum_u64( m ), om = wave_sum_u64( opsMq );
+    if( ( threadIdx.x & 63 ) == 0 && al )
+    {
+        atomicAdd( &ctr[ CTR_N_ALIGNED ], (unsigned long long)al );
+        atomicAdd( &ctr[ CTR_OPS_MQ ], (unsigned long long)om );
+        atomicAdd( &ctr[ CTR_ALN_MQ ], (unsigned long long)am );
+    }
+}

@@ -612,7 +612,22 @@ template <typename TP_ITEM> class PrefetchQueue
     {
         const void* pOwner = nullptr;
         std::shared_ptr<Batch> pBatch;
+        // the batch's result behind a control block of THIS thread's own: the tickets of a slice are copied a dozen times per
+        // read (query -> segments -> ... -> alignments), and reference counts that 16 threads keep bumping on ONE control
+        // block bounce its cache line between the cores (measured: half of a graph thread's time per read)
+        std::shared_ptr<const BatchResult> pResult;
         size_t uiNext = 0, uiEnd = 0;
+        void take( const std::shared_ptr<Batch>& pB, size_t uiFrom, size_t uiTo, const void* pQueue )
+        {
+            pOwner = pQueue, pBatch = pB, uiNext = uiFrom, uiEnd = uiTo;
+            std::shared_ptr<const BatchResult> pKeep = pB->pResult;
+            pResult = std::shared_ptr<const BatchResult>( pKeep.get( ), [ pKeep ]( const BatchResult* ) {} );
+        }
+        void drop( )
+        {
+            pBatch.reset( );
+            pResult.reset( );
+        }
     };
     static Slice& mySlice( )
     {
@@ -626,11 +641,11 @@ template <typename TP_ITEM> class PrefetchQueue
         if( rMine.pOwner == this && rMine.uiNext < rMine.uiEnd )
         {
             const size_t k = rMine.uiNext++;
-            rItem = rMine.pBatch->vItems[ k ];
-            rTicket.pResult = rMine.pBatch->pResult;
+            rItem = std::move( rMine.pBatch->vItems[ k ] ); // (every read is handed out once)
+            rTicket.pResult = rMine.pResult;
             rTicket.uiRead = k;
             if( rMine.uiNext >= rMine.uiEnd )
-                rMine.pBatch.reset( );
+                rMine.drop( );
             return true;
         }
         std::unique_lock<std::mutex> xLock( xMutex );
@@ -710,18 +725,19 @@ template <typename TP_ITEM> class PrefetchQueue
                 std::shared_ptr<Batch> pB = vReady.front( );
                 const size_t k = pB->uiNext;
                 pB->uiNext = std::min( pB->vItems.size( ), k + std::max<size_t>( xOpt.uiSlice, 1 ) );
-                rMine.pOwner = this, rMine.pBatch = pB, rMine.uiNext = k + 1, rMine.uiEnd = pB->uiNext;
+                const size_t uiEnd = pB->uiNext;
                 if( pB->uiNext >= pB->vItems.size( ) )
                 {
                     vReady.erase( vReady.begin( ) );
                     xChanged.notify_all( ); // room for another batch ahead
                 }
                 xLock.unlock( );
-                rItem = pB->vItems[ k ];
-                rTicket.pResult = pB->pResult;
+                rMine.take( pB, k + 1, uiEnd, this );
+                rItem = std::move( pB->vItems[ k ] );
+                rTicket.pResult = rMine.pResult;
                 rTicket.uiRead = k;
                 if( rMine.uiNext >= rMine.uiEnd )
-                    rMine.pBatch.reset( );
+                    rMine.drop( );
                 return true;
             }
             if( bEof && uiLoading == 0 )

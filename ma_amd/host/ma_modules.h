@@ -549,9 +549,9 @@ class SoCPriorityQueue : public libMS::Container
         bHaveQueue = true;
         if( pSeeds == nullptr || pSeeds->empty( ) )
             return;
-        if( pIndex == nullptr || pQuery == nullptr )
+        if( pFmIndex == nullptr || pQuery == nullptr )
             throw std::runtime_error( "SoCPriorityQueue: the queue was not produced by StripOfConsideration" );
-        detail::SingleRead xB( pIndex->p, xP, *pQuery );
+        detail::SingleRead xB( pFmIndex->pDev->p, xP, *pQuery );
         std::vector<ma_seed> v;
         for( const Seed& s : *pSeeds )
             v.push_back( detail::fromSeed( s ) );
@@ -569,7 +569,7 @@ class SoCPriorityQueue : public libMS::Container
   public:
     detail::Ticket xTicket;
     std::shared_ptr<Seeds> pSeeds; // seeds after ExtractSeeds (read-only view)
-    std::shared_ptr<DeviceIndex> pIndex;
+    std::shared_ptr<FMIndex> pFmIndex; // (the handle StripOfConsideration was called with: copying it touches the caller's control block)
     std::shared_ptr<NucSeq> pQuery;
     ma_params xP;
     bool empty( )
@@ -871,7 +871,13 @@ template <typename... TP_ARGS> class PrefetchReader : public libMS::Module<NucSe
                 pQuery, xTicket, [ & ]( ) { return pSource->execute( pArgs... ); },
                 []( const std::shared_ptr<NucSeq>& pQ ) { return detail::ReadRef( pQ->xCodes ); } ) )
             return nullptr;
-        // a copy carries the ticket: it dies with this read's chain, and the device batch's result can be recycled
+        // The ticket must die with this read's chain (the device batch's result is recycled then).  A read nobody else holds --
+        // what a file reader returns -- carries it itself; one the wrapped source still shares is copied.
+        if( pQuery.use_count( ) == 1 )
+        {
+            pQuery->xTicket = xTicket;
+            return pQuery;
+        }
         auto pOut = std::make_shared<NucSeq>( *pQuery );
         pOut->xTicket = xTicket;
         return pOut;
@@ -896,7 +902,7 @@ class StripOfConsideration : public libMS::Module<SoCPriorityQueue, false, Segme
     {
         auto pRet = std::make_shared<SoCPriorityQueue>( );
         pRet->pSeeds = std::make_shared<Seeds>( );
-        pRet->pIndex = pFM_index->pDev;
+        pRet->pFmIndex = pFM_index;
         pRet->pQuery = pQuery;
         pRet->xP = xP;
         if( pSegments->xTicket )
