@@ -162,7 +162,7 @@ static std::string prefetchLeg( const ParameterSetManager& xParams, std::shared_
     };
     double t0 = 0;
     std::string sPrefetch;
-    for( int iT : { 8, 16, 32, 64 } )
+    for( int iT : { 8, 16, 32 } )
     {
         detail::PrefetchOptions xPO;
         xPO.uiBatchReads = 1u << 16;

@@ -568,6 +568,10 @@ struct PrefetchOptions
 //   end; it is called by ONE thread at a time (the wrapped reader need not be re-entrant).  A caller that finds fewer than
 //   uiDepth batches ahead pulls and runs the next batch itself (it blocks for one device batch, the others keep being
 //   served from the finished ones), so there is no thread of our own and nothing runs when nobody asks.
+// The reads a batch pulled stay with the batch until its last slice is done and are then released together by ONE thread: the
+// host layer hands the graph threads COPIES (made, and later freed, by the consuming thread).  Handing out the pulled objects
+// themselves was measured at a third of the rate: they are allocated by the thread that pulled the batch and would be freed
+// by 8-16 others, all contending for that one thread's malloc arena (13.4 vs 5.1 us of thread time per read).
 // Order: reads are handed out batch by batch in pull order, within a batch in pull order; which graph thread gets which
 // read is as arbitrary as in the reference (every graph thread takes the next read from the shared reader, export.cpp:99-126).
 template <typename TP_ITEM> class PrefetchQueue
@@ -641,7 +645,7 @@ template <typename TP_ITEM> class PrefetchQueue
         if( rMine.pOwner == this && rMine.uiNext < rMine.uiEnd )
         {
             const size_t k = rMine.uiNext++;
-            rItem = std::move( rMine.pBatch->vItems[ k ] ); // (every read is handed out once)
+            rItem = rMine.pBatch->vItems[ k ];
             rTicket.pResult = rMine.pResult;
             rTicket.uiRead = k;
             if( rMine.uiNext >= rMine.uiEnd )
@@ -733,7 +737,7 @@ template <typename TP_ITEM> class PrefetchQueue
                 }
                 xLock.unlock( );
                 rMine.take( pB, k + 1, uiEnd, this );
-                rItem = std::move( pB->vItems[ k ] );
+                rItem = pB->vItems[ k ];
                 rTicket.pResult = rMine.pResult;
                 rTicket.uiRead = k;
                 if( rMine.uiNext >= rMine.uiEnd )

@@ -871,13 +871,8 @@ template <typename... TP_ARGS> class PrefetchReader : public libMS::Module<NucSe
                 pQuery, xTicket, [ & ]( ) { return pSource->execute( pArgs... ); },
                 []( const std::shared_ptr<NucSeq>& pQ ) { return detail::ReadRef( pQ->xCodes ); } ) )
             return nullptr;
-        // The ticket must die with this read's chain (the device batch's result is recycled then).  A read nobody else holds --
-        // what a file reader returns -- carries it itself; one the wrapped source still shares is copied.
-        if( pQuery.use_count( ) == 1 )
-        {
-            pQuery->xTicket = xTicket;
-            return pQuery;
-        }
+        // a copy carries the ticket: it dies with this read's chain (the device batch's result is recycled then), and it is
+        // allocated and freed by THIS thread (PrefetchQueue: why the pulled object itself is not handed out)
         auto pOut = std::make_shared<NucSeq>( *pQuery );
         pOut->xTicket = xTicket;
         return pOut;

@@ -22,7 +22,7 @@ python3 tools/overlap_timeline.py $(find gpurun_out/tr_h2h -name "*kernel_trace.
 find gpurun_out/tr_h2h -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_150bp_h2h_inflight3.csv \;
 grep "^{" gpurun_out/tr_h2h.log | tail -1 > gpurun_out/${TAG}_bench_150bp_h2h_inflight3_under_rocprof.json; rm -rf gpurun_out/tr_h2h
 python3 tools/overlap_matrix.py --workload 150bp --steps 12 --inflight 1,2,3 --waves 0,12,16,20 > gpurun_out/${TAG}_overlap_matrix_150bp.txt 2>/dev/null
-python3 tools/pk_prof.py --workload 10kb 2>&1 | grep -v "^{" | grep -v amdgpu.ids > gpurun_out/${TAG}_pk_phase_profile_10kb.txt
+python3 tools/pk_prof.py --workload 10kb 2>&1 | grep -v "^{" | grep -v "^bench detail:" | grep -v amdgpu.ids > gpurun_out/${TAG}_pk_phase_profile_10kb.txt
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU \
   -d gpurun_out/sq10 -o pmc --output-format csv -- python3 bench.py --workload 10kb --steps 1 --warmup 0 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/sq10.log 2>&1
 python3 tools/pmc_sq.py gpurun_out/sq10 k_ksw > gpurun_out/${TAG}_sq_counters_10kb_dp.txt; rm -rf gpurun_out/sq10
@@ -30,7 +30,7 @@ for wl in 50kb 10kb; do
 rocprofv3 --kernel-trace -d gpurun_out/tr_$wl -o tr --output-format csv -- python3 bench.py --workload $wl --steps 1 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/tr_$wl.log 2>&1
 python3 tools/launch_list.py gpurun_out/tr_$wl k_ksw k_job_cost k_chain k_sort_seeds k_soc_windows k_stitch > gpurun_out/${TAG}_launch_timeline_$wl.txt; rm -rf gpurun_out/tr_$wl
 done
-python3 tools/ksw_prof.py --workload 150bp --boundary-reads 0 --overlap 0 2>&1 | grep -v "^{" | grep -v amdgpu.ids > gpurun_out/${TAG}_ext_pairing_bound.txt
+python3 tools/ksw_prof.py --workload 150bp --boundary-reads 0 --overlap 0 2>&1 | grep -v "^{" | grep -v "^bench detail:" | grep -v amdgpu.ids > gpurun_out/${TAG}_ext_pairing_bound.txt
 python3 - <<PY
 import json
 d = json.loads(open("gpurun_out/${TAG}_bench_default.json").read().strip().splitlines()[-1])
