@@ -183,6 +183,8 @@ static std::string prefetchLeg( const ParameterSetManager& xParams, std::shared_
         auto pMq4 = std::make_shared<TMq>( xParams );
         auto pSink4 = std::make_shared<CountingSink>( );
         auto pWriter4 = std::make_shared<TWriter>( xParams, std::static_pointer_cast<OutStream>( pSink4 ), pPack );
+        if( !getenv( "MA_BOUNDARY_WRITER_UNBUFFERED" ) )
+            pWriter4->uiBufferBytes = 1u << 16; // per-thread buffers: the writer's lock once per 64 KB instead of once per read
         std::vector<std::shared_ptr<BasePledge>> vSinks4;
         for( int t = 0; t < iT; t++ )
         {
@@ -203,6 +205,7 @@ static std::string prefetchLeg( const ParameterSetManager& xParams, std::shared_
         }
         t0 = now( );
         BasePledge::simultaneousGet( vSinks4 );
+        pWriter4->flush( );
         const double f4 = now( ) - t0;
         uint64_t uiB = 0, uiR = 0;
         double fRun4 = 0, fPull4 = 0;
@@ -321,10 +324,13 @@ int main( int argc, char** argv )
             char buf[ 512 ];
             snprintf( buf, sizeof( buf ),
                       "%s\"inflight_%zu\": {\"reads_per_s\": %.1f, \"wall_s\": %.4f, \"gather_s\": %.4f, \"h2d_s\": %.4f, \"kernels_s\": %.4f, "
-                      "\"d2h_s\": %.4f, \"device_batches\": %llu, \"aligned_reads\": %llu}",
+                      "\"d2h_s\": %.4f, \"device_batches\": %llu, \"aligned_reads\": %llu, \"slowest_batch_over_median\": %.2f}",
                       sFlat.empty( ) ? "" : ", ", uiInflight, n / T.fWall, T.fWall, T.fPack, T.fH2D, T.fKernels, T.fD2H,
-                      (unsigned long long)T.uiBatches, (unsigned long long)T.uiAlignedReads );
+                      (unsigned long long)T.uiBatches, (unsigned long long)T.uiAlignedReads, T.maxOverMedian( ) );
             sFlat += buf;
+            // engines before admission: no batch of a timed leg may pay an engine's allocations (round 3: 2.9 s inside a 0.06 s leg)
+            if( T.maxOverMedian( ) > 3.0 )
+                fprintf( stderr, "WARNING: flat leg with %zu in flight: slowest device batch %.1fx the median\n", uiInflight, T.maxOverMedian( ) );
         }
         // ---- leg 2b: SAM text of the flat batches (BatchFileWriter: arenas, one write per batch)
         double fSamFlat = 0;

@@ -593,6 +593,12 @@ template <typename TP_ITEM> class PrefetchQueue
     bool bEof = false;
     std::string sError;
     std::mutex xPullMutex; // the wrapped source is read by one thread at a time, batches are pulled in order
+    static uint64_t nextId( )
+    {
+        static std::atomic<uint64_t> uiNext{ 1 };
+        return uiNext++;
+    }
+    const uint64_t uiId = nextId( ); // what a thread's slice remembers of its queue
     uint64_t uiBatches = 0, uiReadsTotal = 0;
     double fSumRun = 0, fSumPull = 0;
 
@@ -614,16 +620,16 @@ template <typename TP_ITEM> class PrefetchQueue
     // the calling thread's slice of a finished batch (thread-local: no lock while it lasts)
     struct Slice
     {
-        const void* pOwner = nullptr;
+        uint64_t uiOwner = 0; // id of the queue the slice belongs to (not its address: a later queue may be allocated there)
         std::shared_ptr<Batch> pBatch;
         // the batch's result behind a control block of THIS thread's own: the tickets of a slice are copied a dozen times per
         // read (query -> segments -> ... -> alignments), and reference counts that 16 threads keep bumping on ONE control
         // block bounce its cache line between the cores (measured: half of a graph thread's time per read)
         std::shared_ptr<const BatchResult> pResult;
         size_t uiNext = 0, uiEnd = 0;
-        void take( const std::shared_ptr<Batch>& pB, size_t uiFrom, size_t uiTo, const void* pQueue )
+        void take( const std::shared_ptr<Batch>& pB, size_t uiFrom, size_t uiTo, uint64_t uiQueue )
         {
-            pOwner = pQueue, pBatch = pB, uiNext = uiFrom, uiEnd = uiTo;
+            uiOwner = uiQueue, pBatch = pB, uiNext = uiFrom, uiEnd = uiTo;
             std::shared_ptr<const BatchResult> pKeep = pB->pResult;
             pResult = std::shared_ptr<const BatchResult>( pKeep.get( ), [ pKeep ]( const BatchResult* ) {} );
         }
@@ -642,7 +648,7 @@ template <typename TP_ITEM> class PrefetchQueue
     template <typename TP_PULL, typename TP_REF> bool next( TP_ITEM& rItem, Ticket& rTicket, TP_PULL&& fPull, TP_REF&& fRef )
     {
         Slice& rMine = mySlice( );
-        if( rMine.pOwner == this && rMine.uiNext < rMine.uiEnd )
+        if( rMine.uiOwner == uiId && rMine.uiNext < rMine.uiEnd )
         {
             const size_t k = rMine.uiNext++;
             rItem = rMine.pBatch->vItems[ k ];
@@ -736,7 +742,7 @@ template <typename TP_ITEM> class PrefetchQueue
                     xChanged.notify_all( ); // room for another batch ahead
                 }
                 xLock.unlock( );
-                rMine.take( pB, k + 1, uiEnd, this );
+                rMine.take( pB, k + 1, uiEnd, uiId );
                 rItem = pB->vItems[ k ];
                 rTicket.pResult = rMine.pResult;
                 rTicket.uiRead = k;

@@ -1417,6 +1417,17 @@ struct AlignerTiming
 {
     double fWall = 0, fPack = 0, fH2D = 0, fKernels = 0, fD2H = 0, fContainers = 0;
     uint64_t uiReads = 0, uiBatches = 0, uiAlignedReads = 0;
+    std::vector<double> vBatchSeconds; // gather + upload + stages + download of every device batch (one slow one = an engine that allocated)
+    // slowest batch over the median batch: a steady-state leg stays below ~3 (the boundary benchmark reports it)
+    double maxOverMedian( ) const
+    {
+        if( vBatchSeconds.empty( ) )
+            return 0;
+        std::vector<double> v( vBatchSeconds );
+        std::sort( v.begin( ), v.end( ) );
+        const double fMedian = v[ v.size( ) / 2 ];
+        return fMedian > 0 ? v.back( ) / fMedian : 0;
+    }
 };
 
 // Throughput API, one GPU: reads in host memory -> device batches of uiBatchReads reads, uiInflight of them in flight
@@ -1503,6 +1514,7 @@ class BatchAligner
             std::lock_guard<std::mutex> xGuard( xNext );
             rT.fPack += pRes->fPack, rT.fH2D += pRes->fH2D, rT.fKernels += pRes->fKernels, rT.fD2H += pRes->fD2H, rT.fContainers += fContainers;
             rT.uiBatches++, rT.uiReads += hi - lo, rT.uiAlignedReads += pRes->uiAlignedReads;
+            rT.vBatchSeconds.push_back( pRes->fPack + pRes->fH2D + pRes->fKernels + pRes->fD2H );
         };
         const size_t uiWorkers = std::max<size_t>( 1, std::min( uiInflight, ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) ) );
         // Engines before admission: every worker's engine exists before the first worker starts, and an engine that has not

@@ -26,6 +26,7 @@
 #include "ms/module/splitter.h"
 #include "dump_format.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -322,6 +323,12 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
         pReaderNode = pAhead;
     }
     BasePledge::parallelGraph( uiThreads, [ & ]( ) {
+        // every graph copy its own handle of the shared constants (same objects behind a control block of the copy's own): a
+        // constant pledge hands out a shared_ptr copy per get( ), and one control block for all threads is a contended cache line
+        auto pPack = std::make_shared<Pledge<Pack>>( );
+        pPack->set( std::shared_ptr<Pack>( idx.pPack.get( ), [ keep = idx.pPack ]( Pack* ) {} ) );
+        auto pFMDIndex = std::make_shared<Pledge<FMIndex>>( );
+        pFMDIndex->set( std::shared_ptr<FMIndex>( idx.pFM.get( ), [ keep = idx.pFM ]( FMIndex* ) {} ) );
         auto pQuery_ = promiseMe( pReaderNode ); // volatile source, then the Lock / UnLock pair of export.cpp:101-124
         auto pQuery = promiseMe( pLock, pQuery_ );
         auto pSeeds = promiseMe( S.pSeeding, promiseMe( pCast, pFMDIndex ), pQuery );
@@ -332,7 +339,9 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
         auto pEmptyContainer = promiseMe( pWriter, pQuery, pAlignmentsWQuality, pPack ); // export.cpp:120
         aSinks.push_back( promiseMe( std::make_shared<UnLock<libMS::Container>>( xParams, pQuery ), pEmptyContainer ) ); // :122-124
     } );
+    const auto tGraph = std::chrono::steady_clock::now( );
     BasePledge::simultaneousGet( aSinks, []( ) { return true; }, uiThreads );
+    const double fGraphSeconds = std::chrono::duration<double>( std::chrono::steady_clock::now( ) - tGraph ).count( );
     fclose( f );
     uint64_t uiBatches = 0, uiReads = 0;
     if( S.pGpuSeeding != nullptr )
@@ -341,8 +350,9 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     if( pAhead != nullptr )
         std::tie( uiAheadBatches, uiAheadReads ) = pAhead->batchStatistics( );
     printf( "{\"threads\": %u, \"reads\": %zu, \"device_batches\": %llu, \"reads_in_batches\": %llu, \"prefetched_batches\": %llu, "
-            "\"prefetched_reads\": %llu}\n", uiThreads, c.reads.size( ),
-            (unsigned long long)uiBatches, (unsigned long long)uiReads, (unsigned long long)uiAheadBatches, (unsigned long long)uiAheadReads );
+            "\"prefetched_reads\": %llu, \"graph_seconds\": %.4f, \"reads_per_s\": %.1f}\n", uiThreads, c.reads.size( ),
+            (unsigned long long)uiBatches, (unsigned long long)uiReads, (unsigned long long)uiAheadBatches, (unsigned long long)uiAheadReads,
+            fGraphSeconds, c.reads.size( ) / fGraphSeconds );
     return 0;
 }
 

@@ -45,6 +45,8 @@ int main( int argc, char** argv )
     }
     auto pStream = std::make_shared<StringOutStream>( );
     FileWriter xWriter( xParams, std::static_pointer_cast<OutStream>( pStream ), pPack );
+    if( iOptions & 8 ) // per-thread buffering of the writer: the same bytes once flush( ) has run
+        xWriter.uiBufferBytes = 4096;
     std::vector<std::shared_ptr<NucSeq>> vFileReads;
     if( argc >= 6 )
     {
@@ -132,6 +134,7 @@ int main( int argc, char** argv )
         }
     }
     flush( );
+    xWriter.flush( );
     FILE* o = fopen( argv[ 3 ], "w" );
     fputs( pStream->sText.c_str( ), o );
     fclose( o );

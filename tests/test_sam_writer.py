@@ -38,6 +38,17 @@ def test_sam_text_matches_reference_filewriter(tmp_path, preset, opt):
         assert a == b, "SAM line %d differs" % i
 
 
+def test_buffered_writer_writes_the_same_bytes(tmp_path):
+    """FileWriter::uiBufferBytes > 0 (per-thread buffers, the lock once per 4 KB instead of once per read): after flush( ) the
+    stream holds the bytes of the reference's FileWriter (one thread: even the order)."""
+    exe = build_exe()
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    pipe = gunzip_to(os.path.join(G, "small_ref.default.pipe.gz"), str(tmp_path / "p.pipe"))
+    out = str(tmp_path / "o.sam")
+    subprocess.check_call([exe, case, pipe, out, str(8 | 1)])
+    assert open(out).read() == gzip.open(os.path.join(G, "small_ref.default.opt1.sam.gz"), "rt").read()
+
+
 READER_EXE = os.path.join(ROOT, "tests", "emul", "reader_test")
 
 
