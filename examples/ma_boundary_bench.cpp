@@ -175,6 +175,8 @@ static std::string prefetchLeg( const ParameterSetManager& xParams, std::shared_
             pSource = std::make_shared<FreshReader>( *pReads );
         if( getenv( "MA_PREFETCH_BATCH" ) )
             xPO.uiBatchReads = (size_t)atoi( getenv( "MA_PREFETCH_BATCH" ) );
+        if( getenv( "MA_PREFETCH_DEPTH" ) )
+            xPO.uiDepth = (size_t)atoi( getenv( "MA_PREFETCH_DEPTH" ) );
         auto pAhead = std::make_shared<TReader>( xParams, pSource, pFM, xPO );
         auto pSeeding4 = std::make_shared<TSeeding>( xParams );
         auto pSoc4 = std::make_shared<TSoc>( xParams );
