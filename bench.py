@@ -758,7 +758,7 @@ def run_legs(E, name, wl, args):
     return r
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -782,7 +782,11 @@ def main():
                     help="run ONE leg only, with this many batches in flight per GPU (own stream + host thread each; profiling runs)")
     ap.add_argument("--host-io", type=int, default=0, help="with --inflight: that leg host to host (1) or device resident (0)")
     ap.add_argument("--detail-file", default="", help="where the per-workload blocks go (default: gpurun_out/bench_detail.json)")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = build_parser().parse_args()
     self_launch_or_check(args, sys.argv[1:])
     if os.environ.get("MA_BENCH_DRY_RUN") == "1":
         return dry_run(args)

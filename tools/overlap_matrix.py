@@ -22,30 +22,7 @@ def main():
     ap.add_argument("--waves", default="0,12,16,20,24")
     ap.add_argument("--exclusive", default="0,1")
     a = ap.parse_args()
-    sys.argv = ["bench.py", "--workload", a.workload, "--cpu-sample", "0", "--boundary-reads", "0"]
-    pa = argparse.ArgumentParser()
-    # the defaults of bench.main's parser, by running its own parser on an empty command line
-    import io, contextlib
-    args = None
-
-    def grab(E, name, wl, ar):
-        raise RuntimeError("unused")
-    # build the argument namespace the way bench.main does
-    real_env = bench.Env
-
-    class Stop(Exception):
-        pass
-
-    def fake_env(ar):
-        nonlocal args
-        args = ar
-        raise Stop()
-    bench.Env = fake_env
-    try:
-        bench.main()
-    except Stop:
-        pass
-    bench.Env = real_env
+    args = bench.build_parser().parse_args(["--workload", a.workload, "--cpu-sample", "0", "--boundary-reads", "0"])
     E = bench.Env(args)
     wl = dict(bench.WORKLOADS[a.workload])
     wl["warmup"] = 1
