@@ -18,6 +18,7 @@
 #include "ma_ref_binding.h"
 
 #include "ma/module/binarySeeding.h"
+#include "ma/module/fileReader.h"
 #include "ma/module/fileWriter.h"
 #include "ma/module/harmonization.h"
 #include "ma/module/mappingQuality.h"
@@ -282,7 +283,7 @@ struct CaseSource : public Module<NucSeq, true>
 };
 
 static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, const char* sOut, const char* sStages, unsigned uiThreads,
-                   int iOptions )
+                   int iOptions, const char* sReadsFile = nullptr )
 {
     const CaseFile c = readCase( sCase );
     const RefIndex idx = buildIndex( c );
@@ -322,6 +323,20 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
         pAhead = std::make_shared<ma_amd::PrefetchReader<>>( xParams, pSource, idx.pFM );
         pReaderNode = pAhead;
     }
+    // option 16: the reads come from a FASTA / FASTQ file through the reference's OWN FileReader (fileReader.cpp:37-203), wrapped
+    // into ma_amd::PrefetchReader<FileStream> -- the line INTEGRATION.md adds at export.cpp:83
+    std::shared_ptr<Pledge<FileStream>> pStreamPledge;
+    std::shared_ptr<ma_amd::PrefetchReader<FileStream>> pAheadFile;
+    if( ( iOptions & 16 ) != 0 )
+    {
+        if( xGpu.size( ) != 5 || sReadsFile == nullptr )
+            throw std::runtime_error( "option 16 needs all five stages on the GPU and a reads file" );
+        ma_amd::options( ).xPrefetch.uiBatchReads = getenv( "MA_PREFETCH_BATCH" ) ? (size_t)atoi( getenv( "MA_PREFETCH_BATCH" ) ) : 64;
+        ma_amd::options( ).xPrefetch.bStages = false;
+        pStreamPledge = std::make_shared<Pledge<FileStream>>( );
+        pStreamPledge->set( std::make_shared<FileStreamFromPath>( std::string( sReadsFile ) ) );
+        pAheadFile = std::make_shared<ma_amd::PrefetchReader<FileStream>>( xParams, std::make_shared<FileReader>( xParams ), idx.pFM );
+    }
     BasePledge::parallelGraph( uiThreads, [ & ]( ) {
         // every graph copy its own handle of the shared constants (same objects behind a control block of the copy's own): a
         // constant pledge hands out a shared_ptr copy per get( ), and one control block for all threads is a contended cache line
@@ -329,15 +344,21 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
         pPack->set( std::shared_ptr<Pack>( idx.pPack.get( ), [ keep = idx.pPack ]( Pack* ) {} ) );
         auto pFMDIndex = std::make_shared<Pledge<FMIndex>>( );
         pFMDIndex->set( std::shared_ptr<FMIndex>( idx.pFM.get( ), [ keep = idx.pFM ]( FMIndex* ) {} ) );
-        auto pQuery_ = promiseMe( pReaderNode ); // volatile source, then the Lock / UnLock pair of export.cpp:101-124
-        auto pQuery = promiseMe( pLock, pQuery_ );
-        auto pSeeds = promiseMe( S.pSeeding, promiseMe( pCast, pFMDIndex ), pQuery );
-        auto pSOCs = promiseMe( S.pSoc, pSeeds, pQuery, pPack, pFMDIndex );
-        auto pHarmonized = promiseMe( S.pHarm, pSOCs, pQuery, pFMDIndex );
-        auto pAlignments = promiseMe( S.pDp, pHarmonized, pQuery, pPack );
-        auto pAlignmentsWQuality = promiseMe( S.pMq, pQuery, pAlignments );
-        auto pEmptyContainer = promiseMe( pWriter, pQuery, pAlignmentsWQuality, pPack ); // export.cpp:120
-        aSinks.push_back( promiseMe( std::make_shared<UnLock<libMS::Container>>( xParams, pQuery ), pEmptyContainer ) ); // :122-124
+        // the chain behind the reader node: export.cpp:102-124, whatever the reader node is
+        auto chain = [ & ]( auto pQuery_ ) {
+            auto pQuery = promiseMe( pLock, pQuery_ ); // the Lock / UnLock pair of export.cpp:101-124
+            auto pSeeds = promiseMe( S.pSeeding, promiseMe( pCast, pFMDIndex ), pQuery );
+            auto pSOCs = promiseMe( S.pSoc, pSeeds, pQuery, pPack, pFMDIndex );
+            auto pHarmonized = promiseMe( S.pHarm, pSOCs, pQuery, pFMDIndex );
+            auto pAlignments = promiseMe( S.pDp, pHarmonized, pQuery, pPack );
+            auto pAlignmentsWQuality = promiseMe( S.pMq, pQuery, pAlignments );
+            auto pEmptyContainer = promiseMe( pWriter, pQuery, pAlignmentsWQuality, pPack ); // export.cpp:120
+            aSinks.push_back( promiseMe( std::make_shared<UnLock<libMS::Container>>( xParams, pQuery ), pEmptyContainer ) ); // :122-124
+        };
+        if( pAheadFile != nullptr )
+            chain( promiseMe( pAheadFile, pStreamPledge ) ); // the reference's FileReader behind the prefetching reader
+        else
+            chain( promiseMe( pReaderNode ) ); // volatile source over the case's reads (plain, or wrapped: option 8)
     } );
     const auto tGraph = std::chrono::steady_clock::now( );
     BasePledge::simultaneousGet( aSinks, []( ) { return true; }, uiThreads );
@@ -349,6 +370,8 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     uint64_t uiAheadBatches = 0, uiAheadReads = 0;
     if( pAhead != nullptr )
         std::tie( uiAheadBatches, uiAheadReads ) = pAhead->batchStatistics( );
+    if( pAheadFile != nullptr )
+        std::tie( uiAheadBatches, uiAheadReads ) = pAheadFile->batchStatistics( );
     printf( "{\"threads\": %u, \"reads\": %zu, \"device_batches\": %llu, \"reads_in_batches\": %llu, \"prefetched_batches\": %llu, "
             "\"prefetched_reads\": %llu, \"graph_seconds\": %.4f, \"reads_per_s\": %.1f}\n", uiThreads, c.reads.size( ),
             (unsigned long long)uiBatches, (unsigned long long)uiReads, (unsigned long long)uiAheadBatches, (unsigned long long)uiAheadReads,
@@ -385,7 +408,7 @@ int main( int argc, char** argv )
             return cmdPipe( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ], argv[ 6 ] );
         if( argc >= 8 && !strcmp( argv[ 1 ], "sam" ) )
             return cmdSam( argv[ 2 ], argv[ 3 ], (unsigned)atoi( argv[ 4 ] ), argv[ 5 ], argv[ 6 ], (unsigned)atoi( argv[ 7 ] ),
-                           argc > 8 ? atoi( argv[ 8 ] ) : 0 );
+                           argc > 8 ? atoi( argv[ 8 ] ) : 0, argc > 9 ? argv[ 9 ] : nullptr );
         if( argc >= 3 && !strcmp( argv[ 1 ], "nogpu" ) )
             return cmdNoGpu( argv[ 2 ] );
     }

@@ -151,6 +151,31 @@ def test_prefetching_reader_in_the_reference_graph_writes_the_reference_sam(tmp_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("threads,batch", [(1, 50), (8, 100000)])
+def test_prefetching_reader_around_the_references_own_filereader(tmp_path, gpu_device, threads, batch):
+    """The line INTEGRATION.md adds at export.cpp:83, literally: ma_amd::PrefetchReader<FileStream> around the reference's OWN
+    FileReader (fileReader.cpp:37-203) over a FASTA file, its own FileWriter as sink: the goldens' SAM bytes."""
+    from ma_testlib import read_case
+    exe = build_exe()
+    case = small_case(tmp_path)
+    _, reads, _ = read_case(case)
+    fa = str(tmp_path / "reads.fa")
+    with open(fa, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(">r%d\n%s\n" % (i, "".join("ACGTN"[min(int(b), 4)] for b in r)))
+    sam = str(tmp_path / "file.sam")
+    env = dict(os.environ, MA_PREFETCH_BATCH=str(batch))
+    stats = json.loads(subprocess.check_output([exe, "sam", case, "default", "1", sam, "all", str(threads), "16", fa], env=env).decode())
+    want = gzip.open(os.path.join(G, "small_ref.default.opt0.sam.gz"), "rt").read()
+    got = open(sam).read()
+    if threads == 1:
+        assert got == want
+    else:
+        assert sorted(got.splitlines()) == sorted(want.splitlines())
+    assert stats["device_batches"] == 0 and stats["prefetched_reads"] == len(reads)
+
+
+@pytest.mark.gpu
 def test_mixed_graph_writes_the_reference_sam(tmp_path, gpu_device):
     exe = build_exe()
     for stages in ("dp", "seeding,soc", "harm,dp,mq"):
