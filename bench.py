@@ -870,7 +870,8 @@ def compose_line(E, args, results, boundary, anchor):
         v2, ms2, _ = leg_of(r, "overlapped")
         if v2 is not None:
             out["value_%s_device_resident" % n], out["ms_per_step_%s_device_resident" % n] = v2, ms2
-        out["value_%s_single_stream" % n], out["ms_per_step_%s_single_stream" % n] = r["value"], r["ms_per_step"]
+        if r.get("batches_in_flight", 1) == 1 and r.get("io", "device").startswith("device"):
+            out["value_%s_single_stream" % n], out["ms_per_step_%s_single_stream" % n] = r["value"], r["ms_per_step"]
         if v is None and v2 is None:
             out["value_%s" % n], out["ms_per_step_%s" % n], out["batches_in_flight_%s" % n] = r["value"], r["ms_per_step"], r.get("batches_in_flight")
         cb = r.get("cpu_baseline") or {}
@@ -903,7 +904,8 @@ def compose_line(E, args, results, boundary, anchor):
             len(E.lens), E.F, "" if args.no_repeats else ", planted repeats"),
         "value_is": "workload '%s' (%s), %s" % (
             head["name"], head["baseline_config"],
-            "one batch at a time, device resident" if key is None else
+            "%d batch(es) in flight per GPU, %s (the one leg --inflight / --host-io asked for)" % (head.get("batches_in_flight", 1), head.get("io", ""))
+            if key is None else
             "%d batches in flight per GPU, %s; the same batches with reads and results resident in HBM: value_150bp_device_resident" % (
                 top["batches_in_flight"], top.get("io", ""))),
         "reads_per_s_total": head["reads_per_s_total"], "index_build_s": round(E.t_index, 2),
