@@ -904,7 +904,8 @@ def compose_line(E, args, results, boundary, anchor):
             len(E.lens), E.F, "" if args.no_repeats else ", planted repeats"),
         "value_is": "workload '%s' (%s), %s" % (
             head["name"], head["baseline_config"],
-            "%d batch(es) in flight per GPU, %s (the one leg --inflight / --host-io asked for)" % (head.get("batches_in_flight", 1), head.get("io", ""))
+            ( "%d batch(es) in flight per GPU, %s (the one leg --inflight / --host-io asked for)" % (head.get("batches_in_flight", 1), head.get("io", ""))
+              if args.inflight > 0 else "one batch at a time, device resident (no overlapped leg ran)" )
             if key is None else
             "%d batches in flight per GPU, %s; the same batches with reads and results resident in HBM: value_150bp_device_resident" % (
                 top["batches_in_flight"], top.get("io", ""))),
