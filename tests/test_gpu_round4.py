@@ -226,3 +226,55 @@ def test_c1_ecoli_like_vs_compiled_reference(gpu_device, tmp_path):
         compare_reads(got, want)
         assert counts["aligned_reads"] == sum(1 for w in want if w["mq"]) >= 990
     idx.close()
+
+
+def test_host_to_host_io_through_page_locked_arrays(gpu_device):
+    """The I/O path of bench.py's headline leg: reads handed over as ONE page-locked host array + CSR offsets
+    (Batch.set_reads_flat over ma_host_alloc memory), the MappingQuality records downloaded into caller-owned page-locked arrays
+    (mapq_alignments_into) -- identical to the list-of-reads / numpy path, too small result arrays are reported (None), and
+    the same batch object serves a second, different read set."""
+    import ma_amd
+    from ma_testlib import rand_genome, sample_reads
+    g = rand_genome(77, [300000, 200000], repeat_unit=200, repeat_copies=40, repeat_div=0.05)
+    idx = ma_amd.Index.build(g)
+    P = ma_amd.Params.preset("default")
+    sets = [sample_reads(g, 3000, 150, 5, sub=0.01) + sample_reads(g, 20, 3000, 6, sub=0.02, ins=0.01, dele=0.01),
+            sample_reads(g, 1000, 100, 7, sub=0.03, n_rate=0.01) + [np.zeros(0, dtype=np.uint8)]]
+    nb = max(sum(len(r) for r in s) for s in sets)
+    nr = max(len(s) for s in sets)
+    b1 = ma_amd.Batch(idx, P, nr, nb + 64)
+    b2 = ma_amd.Batch(idx, P, nr, nb + 64)
+    codes = ma_amd.HostArray(nb + 64, np.uint8)
+    offs = ma_amd.HostArray(nr + 1, np.uint64)
+    out_off = ma_amd.HostArray(nr + 1, np.uint64)
+    small = (ma_amd.HostArray(nr + 1, np.uint64), ma_amd.HostArray(8, ma_amd.ALIGNMENT_DT), ma_amd.HostArray(8, np.uint64))
+    for reads in sets:
+        b1.set_reads(reads)
+        b1.align()
+        b1.sync()
+        woff, walns, wops = b1.mapq_alignments()
+        n = len(reads)
+        o = np.zeros(n + 1, dtype=np.uint64)
+        o[1:] = np.cumsum([len(r) for r in reads])
+        codes.a[: int(o[n])] = np.concatenate([np.asarray(r, dtype=np.uint8) for r in reads]) if int(o[n]) else []
+        offs.a[: n + 1] = o
+        b2.set_reads_flat(codes.ptr, offs.ptr, n)
+        b2.align()
+        b2.sync()
+        assert b2.mapq_alignments_into(*small) is None  # too small: nothing is written, the caller grows its arrays
+        c = b2.counts()
+        out_alns = ma_amd.HostArray(c["alignments"] + 1, ma_amd.ALIGNMENT_DT)
+        out_ops = ma_amd.HostArray(2 * c["ops_cap"] + 2, np.uint64)
+        assert b2.mapq_alignments_into(out_off, out_alns, out_ops) == c
+        na = int(woff[n])
+        assert np.array_equal(out_off.a[: n + 1], woff)
+        assert out_alns.a[:na].tobytes() == walns[:na].tobytes()
+        nops = int(walns["ops_off"][na - 1] + walns["n_ops"][na - 1]) if na else 0
+        assert np.array_equal(out_ops.a[: 2 * nops], wops[: 2 * nops])
+        out_alns.close()
+        out_ops.close()
+    for h in (codes, offs, out_off) + small:
+        h.close()
+    b1.close()
+    b2.close()
+    idx.close()
