@@ -1,8 +1,10 @@
 #!/bin/bash
-# Everything the round's committed numbers come from, in one GPU call (≈30 min): parity tests, the driver's bench line and
-# the Illumina-preset line, rocprofv3 kernel stats + PMC passes of the four workloads, SQ counters of the 10 kb DP stage,
-# the launch timeline of a 50 kb step.  Copy what is to be judged from gpurun_out/ into profiles/ (profiles/README.md).
-#   usage: bash tools/round_evidence.sh [tag=r02]
+# Everything the round's committed numbers come from, in one GPU call (≈16 min of box time in round 4): parity tests, rocprofv3
+# kernel stats + PMC passes of the four workloads, the bench line (all workloads, three legs each, C1 anchor, boundary), the
+# kernel trace of the leg `value` comes from and its concurrency timeline, the overlap matrix, the phase profile of
+# k_ksw_pk<5>, SQ counters of the 10 kb DP stage, launch timelines.  tools/evidence_to_profiles.sh copies what is to be judged
+# from gpurun_out/ into profiles/ (profiles/README.md).
+#   usage: bash tools/round_evidence.sh [tag=r04]
 TAG=${1:-r04}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
