@@ -71,9 +71,18 @@ typedef struct
     double paired_bonus; /* 1.25                                 xPairedBonus */
 } ma_params;
 
-/* ParameterSetManager presets (parameter.h:1079-1087) */
+/* ParameterSetManager presets (parameter.h:1079-1104): "default" 1081, "illumina" 1083-1087, "illuminapaired" 1089-1094,
+ * "pacbio" 1096-1098, "nanopore" 1101-1104. */
 void ma_params_default( ma_params* p );
 void ma_params_illumina( ma_params* p );
+void ma_params_illuminapaired( ma_params* p ); /* illumina + xUsePairedReads (read by the host module PairedReads) */
+void ma_params_pacbio( ma_params* p ); /* default + xMaxSupplementaryPerPrim 100, xMinNumSoC 5 */
+void ma_params_nanopore( ma_params* p ); /* pacbio + SMEM seeding */
+/* ParameterSetManager::setSelected (parameter.h:1163-1170) by key, case-insensitive like the reference's map keys are
+ * lower case: 0 on success; an unknown key fails with the reference's text ("The presetting '<key>' can not be found."),
+ * "sv-illumina" / "sv-pacbio" (1106-1128) fail as not implemented: they switch xRectangularSoc off
+ * (stripOfConsideration.h:41-53), which the device path does not have. */
+int ma_params_preset( const char* key, ma_params* p );
 
 /* Records (same layout as the oracle's records so parity tests compare raw arrays) */
 typedef struct

@@ -36,11 +36,9 @@ class Params(C.Structure):
 
     @staticmethod
     def preset(name="default"):
+        """ParameterSetManager::setSelected (parameter.h:1163-1170): default, illumina, illuminapaired, pacbio, nanopore."""
         p = Params()
-        if name.lower() == "illumina":
-            lib().ma_params_illumina(C.byref(p))
-        else:
-            lib().ma_params_default(C.byref(p))
+        _chk(lib().ma_params_preset(name.encode(), C.byref(p)))
         return p
 
 

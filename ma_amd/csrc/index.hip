@@ -146,6 +146,45 @@ void ma_params_illumina( ma_params* p )
     p->min_num_soc = 10;
     p->max_num_soc = 20;
 }
+void ma_params_illuminapaired( ma_params* p )
+{
+    ma_params_illumina( p ); // parameter.h:1089-1094
+    p->use_paired_reads = 1;
+}
+void ma_params_pacbio( ma_params* p )
+{
+    ma_params_default( p ); // parameter.h:1096-1098
+    p->max_supplementary = 100;
+    p->min_num_soc = 5;
+}
+void ma_params_nanopore( ma_params* p )
+{
+    ma_params_pacbio( p ); // parameter.h:1101-1104
+    p->seeding_technique = 1;
+}
+int ma_params_preset( const char* key, ma_params* p )
+{
+    if( !key || !p )
+        return ma::fail( "ma_params_preset: null argument" );
+    std::string k;
+    for( const char* c = key; *c; ++c )
+        k += (char)tolower( (unsigned char)*c );
+    if( k == "default" )
+        ma_params_default( p );
+    else if( k == "illumina" )
+        ma_params_illumina( p );
+    else if( k == "illuminapaired" )
+        ma_params_illuminapaired( p );
+    else if( k == "pacbio" )
+        ma_params_pacbio( p );
+    else if( k == "nanopore" )
+        ma_params_nanopore( p );
+    else if( k == "sv-illumina" || k == "sv-pacbio" )
+        return ma::fail( "ma_params_preset: the presetting '" + k + "' is not implemented on the device ('Rectangular SoC' = false)" );
+    else
+        return ma::fail( "The presetting '" + std::string( key ) + "' can not be found." );
+    return 0;
+}
 
 extern "C++" {
 // Dense SA sample (every 2^shift-th row) out of the reference's every-32nd one: each dense row that is not in

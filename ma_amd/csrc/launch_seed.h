@@ -229,18 +229,22 @@ int ma_seed_batch( ma_batch* b )
     u64 want = std::min<u64>( 256ull * 2048, ( n + 255 ) / 256 * 256 );
     if( const char* e = getenv( "MA_SEED_LANES" ) ) // tuning hook: resident lanes of the read-per-lane kernels
         want = std::min<u64>( want, std::max<u64>( 256, (u64)atoll( e ) / 256 * 256 ) );
+    // SMEM pending lists as 16-byte entries (seeding.h: smem_pack) unless the text or a read is too long for the packed fields
+    u32 smem_compact = smem && b->max_qlen < ( 1u << MA_SMEM_QZ_BITS ) && b->idx->v.n < ( 1ull << 35 ) ? 1 : 0;
+    if( const char* e = getenv( "MA_SMEM_COMPACT" ) ) // tuning / test hook
+        smem_compact = smem_compact && atoi( e ) != 0 ? 1 : 0;
+    const u64 smem_entry = smem_compact ? 16 : sizeof( ma_segment );
     u32 seg_cap = worst_cap;
-    if( want * ( (u64)worst_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment ) ) > budget )
+    if( want * ( (u64)worst_cap * sizeof( ma_segment ) + 2ull * smem_cap * smem_entry ) > budget )
         seg_cap = std::min<u32>( worst_cap, ( smem ? 3 : 1 ) * ( b->max_qlen / 4 ) + 64 );
     if( const char* e = getenv( "MA_SEED_STAGE_CAP" ) ) // test hook: force a (too) small first attempt
         seg_cap = std::min<u32>( worst_cap, (u32)std::max( 1, atoi( e ) ) );
     for( int attempt = 0; attempt < 3; attempt++ )
     {
-        const u64 lane_bytes = (u64)seg_cap * sizeof( ma_segment ) + 2ull * smem_cap * sizeof( ma_segment );
+        const u64 lane_bytes = (u64)seg_cap * sizeof( ma_segment ) + 2ull * smem_cap * smem_entry;
         const u64 lanes = std::min<u64>( want, std::max<u64>( 256, ( budget / lane_bytes ) / 256 * 256 ) );
         if( b->stage.reserve( lanes * seg_cap * sizeof( ma_segment ) ) ||
-            ( smem && ( b->smemA.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ||
-                        b->smemB.reserve( lanes * smem_cap * sizeof( ma_segment ) ) ) ) ||
+            ( smem && ( b->smemA.reserve( lanes * smem_cap * smem_entry ) || b->smemB.reserve( lanes * smem_cap * smem_entry ) ) ) ||
             b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
             b->segOff.reserve( n * 8 ) || b->segCnt.reserve( n * 4 ) || b->seedStack.reserve( lanes * 2 * MA_SEED_STACK * 4 ) )
             return 1;
@@ -268,9 +272,7 @@ int ma_seed_batch( ma_batch* b )
             const u32 qb = (u32)( ( b->max_qlen + 7 ) / 8 * 8 + 4 );
             A.q_lds = qb * 256 <= 64 * 1024 ? qb : 0;
             seed_window( A.P, b, A.q_lds == 0 );
-            A.P.smem_compact = smem && b->max_qlen < 2048 && b->idx->v.n < ( 1ull << 35 ) ? 1 : 0;
-            if( const char* e = getenv( "MA_SMEM_COMPACT" ) ) // tuning / test hook
-                A.P.smem_compact = A.P.smem_compact && atoi( e ) != 0 ? 1 : 0;
+            A.P.smem_compact = smem_compact;
             A.P.smem_merge = smem && A.P.min_amb == 0 ? 1 : 0;
             if( const char* e = getenv( "MA_SMEM_MERGE" ) ) // test hook: 0 = keep every entry like the reference's lists
                 A.P.smem_merge = A.P.smem_merge && atoi( e ) != 0 ? 1 : 0;

@@ -18,7 +18,7 @@ struct SeedParams
     u64 genome_size_disable;
     const uint8_t* window_begin = nullptr; // device kernels whose reads stay in HBM: the reads array, for seed_qbyte's 16-byte window
     const uint8_t* window_end = nullptr; // (null: off)
-    u32 smem_compact = 0; // SMEM pending lists hold 16-byte entries (smem_put / smem_get): reads < 2048 bases, text < 2^35
+    u32 smem_compact = 0; // SMEM pending lists hold 16-byte entries (smem_put / smem_get): reads < 2^22 bases, text < 2^35
     u32 smem_merge = 0; // SMEM backward phase: an entry whose interval equals that of the entry pushed before it is not kept (seed_apply)
 };
 
@@ -142,11 +142,27 @@ MA_HD u32 comp_base( u32 c ) // NucSeq::nucleotideComplement (nucSeq.h:524-532)
 // Entries of the SMEM pending lists (binarySeeding.h:296-433).  The lists live in HBM, one pair per resident lane, and
 // their traffic is as large as that of the occ blocks (Illumina preset: 99 GB of reads and 94 GB of writes per 1 M reads
 // beside 105 GB of occ blocks).  A 40-byte record straddles 64-byte lines; packed into 16 bytes -- three 35-bit interval
-// fields, two 11-bit query fields -- an entry is one aligned dwordx4 and four of them share a line.
-MA_HD void smem_pack( u32 qs, u32 qz, i64 a, i64 b, i64 c, u64& w0, u64& w1 )
+// fields and ONE 22-bit query field -- an entry is one aligned dwordx4 and four of them share a line.
+// The start of the match is not stored: all entries of one list share it.  The forward phase pushes (center, ...)
+// (binarySeeding.h:296-337), a backward position i pushes (i, ...) (:380-413), so the entries a backward position i reads were
+// pushed at i + 1 (or by the forward phase with center = i + 1) and the caller names the start when it unpacks (`qs`);
+// the 40-byte form keeps its own copy, and the host emulation checks that both agree.  (Round 4 stored two 11-bit query
+// fields, which kept reads of 2048 bases and more -- the Nanopore preset's -- on the 40-byte records.)
+#define MA_SMEM_QZ_BITS 22
+MA_HD void smem_pack( u32 qz, i64 a, i64 b, i64 c, u64& w0, u64& w1 )
 {
     w0 = (u64)a | ( ( (u64)c & 0x1fffffffull ) << 35 );
-    w1 = (u64)b | ( ( (u64)c >> 29 ) << 35 ) | ( (u64)qs << 41 ) | ( (u64)qz << 52 );
+    w1 = (u64)b | ( ( (u64)c >> 29 ) << 35 ) | ( (u64)qz << 41 );
+}
+MA_HD ma_segment smem_unpack( u64 w0, u64 w1, u32 qs )
+{
+    ma_segment s;
+    s.sa_start = (i64)( w0 & 0x7ffffffffull );
+    s.sa_start_rc = (i64)( w1 & 0x7ffffffffull );
+    s.sa_size = (i64)( ( w0 >> 35 ) | ( ( ( w1 >> 35 ) & 0x3full ) << 29 ) );
+    s.q_start = (i64)qs;
+    s.q_size = (i64)( ( w1 >> 41 ) & ( ( 1ull << MA_SMEM_QZ_BITS ) - 1 ) );
+    return s;
 }
 MA_HD void smem_put( const SeedParams& P, ma_segment* list, u32 idx, u32 qs, u32 qz, i64 a, i64 b, i64 c )
 {
@@ -154,7 +170,7 @@ MA_HD void smem_put( const SeedParams& P, ma_segment* list, u32 idx, u32 qs, u32
     {
         u64* w = (u64*)list + 2 * (u64)idx;
         u64 w0, w1;
-        smem_pack( qs, qz, a, b, c, w0, w1 );
+        smem_pack( qz, a, b, c, w0, w1 );
 #if defined( __HIP_DEVICE_COMPILE__ )
         *(ulonglong2*)w = make_ulonglong2( w0, w1 );
 #else
@@ -168,7 +184,8 @@ MA_HD void smem_put( const SeedParams& P, ma_segment* list, u32 idx, u32 qs, u32
         list[ idx ] = s;
     }
 }
-MA_HD ma_segment smem_get( const SeedParams& P, const ma_segment* list, u32 idx )
+// qs: the start all entries of this list share (see above)
+MA_HD ma_segment smem_get( const SeedParams& P, const ma_segment* list, u32 idx, u32 qs )
 {
     if( P.smem_compact )
     {
@@ -179,27 +196,15 @@ MA_HD ma_segment smem_get( const SeedParams& P, const ma_segment* list, u32 idx 
 #else
         const u64 w0 = w[ 0 ], w1 = w[ 1 ];
 #endif
-        ma_segment s;
-        s.sa_start = (i64)( w0 & 0x7ffffffffull );
-        s.sa_start_rc = (i64)( w1 & 0x7ffffffffull );
-        s.sa_size = (i64)( ( w0 >> 35 ) | ( ( ( w1 >> 35 ) & 0x3full ) << 29 ) );
-        s.q_start = (i64)( ( w1 >> 41 ) & 0x7ffull );
-        s.q_size = (i64)( ( w1 >> 52 ) & 0x7ffull );
-        return s;
+        return smem_unpack( w0, w1, qs );
     }
+#if !defined( __HIP_DEVICE_COMPILE__ )
+    if( (u64)list[ idx ].q_start != (u64)qs )
+        abort( ); // host emulation only: the shared start the compact form relies on
+#endif
     return list[ idx ];
 }
 
-MA_HD ma_segment smem_unpack( u64 w0, u64 w1 )
-{
-    ma_segment s;
-    s.sa_start = (i64)( w0 & 0x7ffffffffull );
-    s.sa_start_rc = (i64)( w1 & 0x7ffffffffull );
-    s.sa_size = (i64)( ( w0 >> 35 ) | ( ( ( w1 >> 35 ) & 0x3full ) << 29 ) );
-    s.q_start = (i64)( ( w1 >> 41 ) & 0x7ffull );
-    s.q_size = (i64)( ( w1 >> 52 ) & 0x7ffull );
-    return s;
-}
 // request entry idx of a list of 16-byte entries into the lane's prefetch registers
 MA_HD void smem_prefetch( SeedLane& L, const ma_segment* list, u32 idx );
 MA_HD void seed_emit( SeedLane& L, const SeedScratch& S, u32 start, u32 size, i64 a, i64 b, i64 c )
@@ -480,7 +485,7 @@ template <bool WIN = false, bool SM = true, bool MS = true> MA_HD bool seed_try(
         // the next entry of the list was requested a step ago (seed_prepare / here): take it, request the one after it
         if( S != nullptr && L.nxtOk && L.jPrev < L.nPrev )
         {
-            const ma_segment s = smem_unpack( L.nxt0, L.nxt1 );
+            const ma_segment s = smem_unpack( L.nxt0, L.nxt1, L.i + 1 );
             L.ik[ 0 ] = s.sa_start, L.ik[ 1 ] = s.sa_start_rc, L.ik[ 2 ] = s.sa_size;
             L.curQStart = (u32)s.q_start, L.curQSize = (u32)s.q_size;
             if( L.jPrev + 1 < L.nPrev )
@@ -493,7 +498,7 @@ template <bool WIN = false, bool SM = true, bool MS = true> MA_HD bool seed_try(
         // End of a backward position (the bookkeeping of seed_prepare's PH_SMEM_BWD) without leaving the fast path: the next
         // position starts with the entry that was pushed FIRST onto the list just written, which is still in registers -- no
         // list read, no batching with other lanes' transitions; the second entry is requested for the step after this one.
-        // (16-byte entries only: reads < 2048 bases, so the packed q_start / q_size are exact.)
+        // (16-byte entries only.)  The entry was pushed at position L.i, which is the start it carries.
         if( S != nullptr && P.smem_compact && L.jPrev == L.nPrev && L.nCurr >= 1 && L.i != 0 )
         {
             L.flip ^= 1;
@@ -502,7 +507,7 @@ template <bool WIN = false, bool SM = true, bool MS = true> MA_HD bool seed_try(
             L.jPrev = 0;
             L.bHaveOne = 0;
             L.retS = L.i;
-            const ma_segment s = smem_unpack( L.first0, L.first1 );
+            const ma_segment s = smem_unpack( L.first0, L.first1, L.i );
             L.ik[ 0 ] = s.sa_start, L.ik[ 1 ] = s.sa_start_rc, L.ik[ 2 ] = s.sa_size;
             L.curQStart = (u32)s.q_start, L.curQSize = (u32)s.q_size;
             if( L.nPrev > 1 )
@@ -684,7 +689,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> M
                     ma_segment* cur = S.smem_a;
                     for( u32 a = 0, b = L.nCurr; a + 1 < b; a++, b-- )
                     {
-                        const ma_segment t = smem_get( P, cur, a ), u = smem_get( P, cur, b - 1 );
+                        const ma_segment t = smem_get( P, cur, a, L.center ), u = smem_get( P, cur, b - 1, L.center );
                         smem_put( P, cur, a, (u32)u.q_start, (u32)u.q_size, u.sa_start, u.sa_start_rc, u.sa_size );
                         smem_put( P, cur, b - 1, (u32)t.q_start, (u32)t.q_size, t.sa_start, t.sa_start_rc, t.sa_size );
                     }
@@ -704,7 +709,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> M
                         // cannot extend backwards at all (binarySeeding.h:354, 437-448)
                         if( L.nPrev > 0 )
                         {
-                            const ma_segment f = smem_get( P, S.smem_a, 0 );
+                            const ma_segment f = smem_get( P, S.smem_a, 0, L.center );
                             seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
                         }
                         seed_after_center( L, S, L.retS, L.retE - L.retS );
@@ -718,7 +723,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> M
                 ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
                 if( L.jPrev < L.nPrev )
                 {
-                    const ma_segment s = L.nxtOk ? smem_unpack( L.nxt0, L.nxt1 ) : smem_get( P, prev, L.jPrev );
+                    const ma_segment s = L.nxtOk ? smem_unpack( L.nxt0, L.nxt1, L.i + 1 ) : smem_get( P, prev, L.jPrev, L.i + 1 );
                     if( P.smem_compact && L.jPrev + 1 < L.nPrev )
                         smem_prefetch( L, prev, L.jPrev + 1 );
                     else
@@ -753,7 +758,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> M
                 {
                     if( L.nPrev > 0 )
                     {
-                        const ma_segment f = smem_get( P, L.flip ? S.smem_b : S.smem_a, 0 );
+                        const ma_segment f = smem_get( P, L.flip ? S.smem_b : S.smem_a, 0, L.i );
                         seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
                     }
                     seed_after_center( L, S, L.retS, L.retE - L.retS );
@@ -854,7 +859,7 @@ template <bool SM = true, bool MS = true> MA_HD void seed_apply( SeedLane& L, co
                     else
                         L.err |= MA_ERR_SMEM_OVERFLOW;
                     if( L.nCurr == 0 )
-                        smem_pack( L.i, (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ], L.first0, L.first1 );
+                        smem_pack( (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ], L.first0, L.first1 );
                     L.nCurr++;
                     L.lastK = ok[ 0 ], L.lastS = ok[ 2 ];
                 }

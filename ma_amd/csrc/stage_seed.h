@@ -36,8 +36,10 @@ template <bool LONG, bool SM, bool MS = !SM> __device__ __forceinline__ void see
     SeedScratch S;
     S.stage = A.stage + (u64)lane * A.seg_cap;
     S.seg_cap = A.seg_cap;
-    S.smem_a = A.smem_a ? A.smem_a + (u64)lane * A.smem_cap : nullptr;
-    S.smem_b = A.smem_b ? A.smem_b + (u64)lane * A.smem_cap : nullptr;
+    // a lane's list: smem_cap entries of 16 bytes (compact) or 40 bytes
+    const u64 smemWords = (u64)A.smem_cap * ( A.P.smem_compact ? 2u : 5u );
+    S.smem_a = A.smem_a ? (ma_segment*)( (u64*)A.smem_a + (u64)lane * smemWords ) : nullptr;
+    S.smem_b = A.smem_b ? (ma_segment*)( (u64*)A.smem_b + (u64)lane * smemWords ) : nullptr;
     S.smem_cap = A.smem_cap;
     S.stack = A.stack + (u64)lane * ( 2 * MA_SEED_STACK );
     S.drop_div = A.P.min_seed_size_drop;

@@ -65,28 +65,9 @@ class ParameterSetManager
     }
     void setSelected( const std::string& sKey )
     {
-        std::string k;
-        for( char c : sKey )
-            k += (char)tolower( c );
-        if( k == "default" )
-            ma_params_default( &xSelected );
-        else if( k == "illumina" )
-            ma_params_illumina( &xSelected );
-        else if( k == "illuminapaired" ) // parameter.h:1089-1094
-        {
-            ma_params_illumina( &xSelected );
-            xSelected.use_paired_reads = 1;
-        }
-        else if( k == "pacbio" || k == "nanopore" ) // parameter.h:1096-1104
-        {
-            ma_params_default( &xSelected );
-            xSelected.max_supplementary = 100;
-            xSelected.min_num_soc = 5;
-            if( k == "nanopore" )
-                xSelected.seeding_technique = 1;
-        }
-        else
-            throw std::runtime_error( "The presetting '" + sKey + "' can not be found." );
+        // the C ABI holds the preset table (parameter.h:1079-1104); an unknown key fails with the reference's text
+        if( ma_params_preset( sKey.c_str( ), &xSelected ) != 0 )
+            throw std::runtime_error( ma_last_error( ) );
     }
     const ma_params* getSelected( ) const
     {

@@ -81,6 +81,19 @@ extern "C" void ma_or_params_illumina( ma_or_params* p )
     p->max_num_soc = 20;
 }
 
+extern "C" void ma_or_params_pacbio( ma_or_params* p )
+{
+    ma_or_params_default( p ); // parameter.h:1096-1098
+    p->max_supplementary = 100;
+    p->min_num_soc = 5;
+}
+
+extern "C" void ma_or_params_nanopore( ma_or_params* p )
+{
+    ma_or_params_pacbio( p ); // parameter.h:1101-1104
+    p->seeding_technique = 1;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Index: fMIndex.h:195-230 (data), fMIndex.cpp:152-314 (construction), pack.h:586-698 (2-bit pack)
 // ---------------------------------------------------------------------------------------------

@@ -251,6 +251,8 @@ int main( int argc, char** argv )
     SP.genome_size_disable = OP.genome_size_disable;
     if( const char* e = getenv( "MA_EMUL_SMEM_MERGE" ) ) // the kernels' default for uiMinAmbiguity == 0: twin list entries are not kept
         SP.smem_merge = atoi( e ) != 0 && SP.min_amb == 0 ? 1 : 0;
+    if( const char* e = getenv( "MA_EMUL_SMEM_COMPACT" ) ) // the kernels' 16-byte list entries (one 22-bit length, the start shared by the list)
+        SP.smem_compact = atoi( e ) != 0 ? 1 : 0;
     ChainParams CP;
     CP.max_num_soc = OP.max_num_soc;
     CP.min_num_soc = OP.min_num_soc;

@@ -390,6 +390,10 @@ def or_params(preset="default", seed=1):
     p = OrParams()
     if preset.startswith("illumina"):
         orlib().ma_or_params_illumina(C.byref(p))
+    elif preset.startswith("pacbio"):
+        orlib().ma_or_params_pacbio(C.byref(p))
+    elif preset.startswith("nanopore"):
+        orlib().ma_or_params_nanopore(C.byref(p))
     else:
         orlib().ma_or_params_default(C.byref(p))
     if preset.endswith("+mems"):  # the MEMs seeding technique (binarySeeding.h:460-537), selected by no preset

@@ -1,0 +1,170 @@
+"""Round 5: full-size NOISY-read parity inside `pytest -m gpu`: the GRCh38-size index of bench.py, reads
+with the error profiles of BASELINE.json's configs, every alignment op and the mapq bits against the oracle, under the
+Default, PacBio and Nanopore parameter sets (parameter.h:1081-1104); the presets of the C ABI; SMEM seeding of long reads
+on the 16-byte list entries."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ma_testlib import OrIndex, or_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717,
+          133797422, 135086622, 133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616,
+          64444167, 46709983, 50818468, 156040895, 57227415]
+
+
+@pytest.fixture(scope="module")
+def gpu_device():
+    import ma_amd
+    if ma_amd.device_count() < 1:
+        pytest.skip("no HIP device")
+    ma_amd.set_device(0)
+    return 0
+
+
+@pytest.fixture(scope="module")
+def grch38(gpu_device):
+    """bench.py's genome (24 contigs of GRCh38's lengths, seed 2, planted repeat families), its index on the device and the
+    same index bytes in the oracle."""
+    import torch
+    import ma_amd
+    L = ma_amd.lib()
+    lens = np.array(GRCH38, dtype=np.uint64)
+    F = int(lens.sum())
+    g = torch.empty(F, dtype=torch.uint8, device="cuda")
+    assert L.ma_synth_genome_device(C.c_uint64(2), C.c_uint64(F), C.c_int32(1), C.c_void_p(g.data_ptr())) == 0
+    idx = ma_amd.Index.build_device(lens, g.data_ptr())
+    del g
+    torch.cuda.empty_cache()
+    oidx = OrIndex.from_parts(idx.download())
+    yield idx, oidx
+    idx.close()
+
+
+def synth_reads(idx, seed, n, rl, sub=0.0, ins=0.0, dele=0.0):
+    import torch
+    import ma_amd
+    L = ma_amd.lib()
+    cap = int(n * (rl * (1 + 2 * ins) + 8)) + 1024
+    codes = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    offs = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    nb = C.c_uint64()
+    assert L.ma_synth_reads_device(idx.h, C.c_uint64(seed), C.c_uint64(n), C.c_uint32(rl), C.c_double(sub), C.c_double(ins),
+                                   C.c_double(dele), C.c_uint64(0), C.c_void_p(codes.data_ptr()), C.c_void_p(offs.data_ptr()),
+                                   C.c_uint64(cap), C.byref(nb)) == 0
+    return codes, offs, int(nb.value)
+
+
+def assert_same_as_oracle(bt, res, n, what):
+    """every NeedlemanWunsch alignment (positions, score, SoC index, every op) and every MappingQuality record (flags, the bits
+    of the mapq double) of the first n reads"""
+    goff, galn, gops = bt.alignments()
+    moff, mq, _ = bt.mapq_alignments()
+    na, nm = int(res["aln_off"][n]), int(res["mq_off"][n])
+    assert np.array_equal(goff[:n + 1], res["aln_off"][:n + 1]), what + ": alignments per read"
+    nops = int(res["alns"]["ops_off"][na - 1] + res["alns"]["n_ops"][na - 1]) if na else 0
+    if galn[:na].tobytes() != res["alns"][:na].tobytes():
+        for f in res["alns"].dtype.names:
+            bad = np.nonzero(galn[f][:na] != res["alns"][f][:na])[0]
+            assert len(bad) == 0, "%s: alignment field %s differs first at alignment %d" % (what, f, int(bad[0]))
+    assert np.array_equal(gops[:2 * nops], res["ops"][:2 * nops]), what + ": alignment ops"
+    assert np.array_equal(moff[:n + 1], res["mq_off"][:n + 1]), what + ": mapq records per read"
+    for f in ("begin_ref", "end_ref", "begin_q", "end_q", "score", "soc_index", "n_ops", "secondary", "supplementary"):
+        assert np.array_equal(mq[f][:nm], res["mq"][f][:nm]), what + ": mapq record field " + f
+    assert mq["mapq"][:nm].tobytes() == res["mq"]["mapq"][:nm].tobytes(), what + ": mapq bits"
+    return na, nops, nm
+
+
+# (workload, reads, read length, sub / ins / del rates of BASELINE.json's configs, read seed, presets)
+SCALE_CASES = [
+    ("150bp", 100000, 150, 0.005, 0.0, 0.0, 11, ("default", "illumina")),
+    ("10kb", 2000, 10000, 0.004, 0.003, 0.003, 12, ("default", "pacbio", "nanopore")),
+    ("50kb", 256, 50000, 0.03, 0.03, 0.04, 13, ("default", "pacbio", "nanopore")),
+]
+
+
+@pytest.mark.parametrize("case", SCALE_CASES, ids=[c[0] for c in SCALE_CASES])
+def test_noisy_reads_at_grch38_scale_vs_oracle(grch38, case):
+    """configs[1] / [2] / [4] at the genome size they are quoted on: noisy synthetic reads against the 6.2 Gnt index (positions
+    above 2^32, drop-all heuristic and SoC score threshold ON, the repeat families' ambiguity), compared with the oracle record
+    by record.  The oracle runs on the index bytes the GPU builder produced (pinned at this scale by
+    test_gpu_round4.py::test_index_pinned_at_grch38_scale)."""
+    import ma_amd
+    idx, oidx = grch38
+    name, n, rl, sub, ins, dele, seed, presets = case
+    codes, offs, nb = synth_reads(idx, seed, n, rl, sub, ins, dele)
+    oh = offs.cpu().numpy()
+    ch = codes[:nb].cpu().numpy()
+    reads = [ch[int(oh[i]):int(oh[i + 1])] for i in range(n)]
+    threads = min(16, os.cpu_count() or 1)
+    for preset in presets:
+        bt = ma_amd.Batch(idx, ma_amd.Params.preset(preset), n, nb + 64)
+        bt.set_reads_device(codes.data_ptr(), offs.data_ptr(), n, nb)
+        bt.align()
+        bt.sync()
+        res = oidx.align(reads, or_params(preset, 1), threads=threads)
+        na, nops, nm = assert_same_as_oracle(bt, res, n, "%s/%s" % (name, preset))
+        aligned = bt.counts()["aligned_reads"]
+        assert aligned == res["n_aligned"] and aligned >= 0.97 * n, (name, preset, aligned)
+        assert na >= n * 0.97 and nops > na
+        if preset in ("pacbio", "nanopore"):
+            # xMaxSupplementaryPerPrim = 100 (parameter.h:1097,1103): the selection differs from the Default set's
+            assert ma_amd.Params.preset(preset).max_supplementary == 100
+        print("%s %s: %d reads, %d alignments, %d ops, %d mapq records identical" % (name, preset, n, na, nops, nm))
+        bt.close()
+
+
+def test_presets_of_the_c_abi(gpu_device):
+    """ma_params_preset = ParameterSetManager::setSelected over the sets of parameter.h:1081-1104; unknown keys fail with the
+    reference's text, the sv-* sets (non-rectangular SoC) are refused."""
+    import ma_amd
+    d, i, ip, pb, on = (ma_amd.Params.preset(k) for k in ("default", "Illumina", "illuminapaired", "pacbio", "NANOPORE"))
+    assert (d.seeding_technique, d.max_ambiguity, d.min_num_soc, d.max_num_soc, d.max_supplementary) == (0, 100, 1, 30, 1)
+    assert (i.seeding_technique, i.max_ambiguity, i.min_num_soc, i.max_num_soc, i.use_paired_reads) == (1, 500, 10, 20, 0)
+    assert (ip.seeding_technique, ip.max_ambiguity, ip.min_num_soc, ip.max_num_soc, ip.use_paired_reads) == (1, 500, 10, 20, 1)
+    assert (pb.seeding_technique, pb.max_supplementary, pb.min_num_soc, pb.max_num_soc) == (0, 100, 5, 30)
+    assert (on.seeding_technique, on.max_supplementary, on.min_num_soc, on.max_ambiguity) == (1, 100, 5, 100)
+    with pytest.raises(RuntimeError, match="can not be found"):
+        ma_amd.Params.preset("no-such-set")
+    with pytest.raises(RuntimeError, match="not implemented"):
+        ma_amd.Params.preset("sv-pacbio")
+
+
+def test_smem_seeding_of_long_reads_on_compact_entries(gpu_device):
+    """Nanopore preset = SMEM seeding of long reads (parameter.h:1101-1104).  The pending lists of binarySeeding.h:296-433 are
+    16-byte entries for reads below 2^22 bases (one 22-bit length; the start is shared by a list's entries); MA_SMEM_COMPACT=0
+    keeps the 40-byte records.  Both give the oracle's segments, also with uiMinAmbiguity > 0 (no twin merging) and Ns."""
+    import ma_amd
+    from ma_testlib import rand_genome, sample_reads
+    g = rand_genome(55, [400000, 250000], repeat_unit=300, repeat_copies=60, repeat_div=0.08)
+    idx = ma_amd.Index.build(g)
+    oidx = OrIndex.from_parts(idx.download())
+    reads = (sample_reads(g, 40, 2047, 3, sub=0.03, ins=0.03, dele=0.04) + sample_reads(g, 40, 2048, 4, sub=0.03, ins=0.02, dele=0.02)
+             + sample_reads(g, 24, 12000, 5, sub=0.03, ins=0.03, dele=0.04, n_rate=0.002) + sample_reads(g, 6, 60000, 6, sub=0.02, ins=0.02, dele=0.02))
+    nb = sum(len(r) for r in reads)
+    for min_amb in (0, 2):
+        op = or_params("nanopore", 1)
+        op.min_ambiguity = min_amb
+        res = oidx.align(reads, op, threads=8)
+        for compact in ("1", "0"):
+            os.environ["MA_SMEM_COMPACT"] = compact
+            try:
+                P = ma_amd.Params.preset("nanopore")
+                P.min_ambiguity = min_amb
+                bt = ma_amd.Batch(idx, P, len(reads), nb + 64)
+                bt.set_reads(reads)
+                bt.align()
+                bt.sync()
+                soff, segs = bt.segments()
+                assert np.array_equal(soff, res["seg_off"]), (min_amb, compact)
+                assert segs.tobytes() == res["segs"].tobytes(), (min_amb, compact)
+                assert_same_as_oracle(bt, res, len(reads), "nanopore min_amb=%d compact=%s" % (min_amb, compact))
+                bt.close()
+            finally:
+                del os.environ["MA_SMEM_COMPACT"]
+    idx.close()
