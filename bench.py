@@ -114,13 +114,19 @@ def pmc_replay(read_len, reads_per_step, preset, genome_scale, stage):
 
 
 def load_calibration():
-    """profiles/r02_calibration.json: the measured ceilings the roofline fractions are quoted against (tools/calibrate.sh)."""
-    cal = {"gather_ceiling_gblocks": 50.59, "valu_mix_peak_ginst": 576.9, "source": "built-in (profiles/r02_calibration.json missing)"}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_calibration.json")) as f:
-            cal.update(json.load(f))
-    except (OSError, ValueError):
-        pass
+    """The measured ceilings the roofline fractions are quoted against (tools/calibrate.sh): the newest
+    profiles/rNN_calibration.json; its `kernel_source_hash` (if any) says which build's opcode mix was measured."""
+    import glob
+    cal = {"gather_ceiling_gblocks": 50.59, "valu_mix_peak_ginst": 576.9, "source": "built-in (no profiles/r*_calibration.json)"}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_calibration.json")))
+    if files:
+        try:
+            with open(files[-1]) as f:
+                cal.update(json.load(f))
+            cal["source"] = "profiles/" + os.path.basename(files[-1]) + (
+                " (measured on kernel sources %s)" % cal["kernel_source_hash"] if cal.get("kernel_source_hash") else "")
+        except (OSError, ValueError):
+            pass
     return cal
 
 
@@ -265,12 +271,22 @@ def run_workload(E, name, wl, args):
         bt.align()
         bt.sync()
 
+    # Waits.  Every batch thread waits for its stream; the runtime's default wait SPINS.  With more waiting threads on the host
+    # than the container's CPU quota grants cores (8 ranks x 3 batches in flight = 24 spinners under a 16-core CFS quota) the
+    # spinners burn the quota and the whole process group is throttled (that is what bounded the per-read
+    # funnel); then the waits sleep on an interrupt-driven event instead (ma_batch_set_blocking_sync).  MA_BENCH_BLOCKING_SYNC=0/1 forces it.
+    quota = cpu_quota_cores()
+    cores = min(os.cpu_count() or 1, quota) if quota else (os.cpu_count() or 1)
+    blocking = world * NB > cores
+    if os.environ.get("MA_BENCH_BLOCKING_SYNC") in ("0", "1"):
+        blocking = os.environ["MA_BENCH_BLOCKING_SYNC"] == "1"
     setup_err = None
     try:
         for i in range(NB):
             bt = ma_amd.Batch(E.idx, P, max(B, 1), max_bases + 64)
             st = torch.cuda.current_stream() if NB == 1 else torch.cuda.Stream()
             bt.set_stream(st.cuda_stream)
+            bt.set_blocking_sync(blocking)
             bt.enable_timing(True)
             batches.append((bt, st))
             hout.append(None)
@@ -288,7 +304,7 @@ def run_workload(E, name, wl, args):
         raise RuntimeError("setting up %d batch(es) of workload %s failed on %s: %s" % (
             NB, name, "this rank" if setup_err is not None else "another rank", setup_err))
 
-    acc = [dict(kms=np.zeros(8), ctr=np.zeros(8), segs=0, aligned=0, err=None, wall=[]) for _ in range(NB)]
+    acc = [dict(kms=np.zeros(8), ctr=np.zeros(8), segs=0, aligned=0, err=None, wall=[], last=None) for _ in range(NB)]
 
     def worker(i):
         try:
@@ -308,12 +324,14 @@ def run_workload(E, name, wl, args):
                 c = bt.counts()
                 a["aligned"] += c["aligned_reads"]
                 a["segs"] += c["segments"]
+                a["last"] = k
         except Exception as e:  # surfaced after the join
             acc[i]["err"] = e
 
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    thr0 = cfs_throttle()
     t0 = time.perf_counter()
     if NB == 1:
         worker(0)
@@ -327,9 +345,17 @@ def run_workload(E, name, wl, args):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    thr1 = cfs_throttle()
     for a in acc:
         if a["err"] is not None:
             raise a["err"]
+    # ---- the results of a leg with several batches in flight (and of the host-to-host leg) against the same steps run ALONE,
+    # one batch at a time, device resident -- after the timed region.  The single-stream path is what the oracle check of
+    # cpu_baseline_and_parity covers; this ties the overlapped / host-to-host records to it byte for byte (a race between
+    # concurrent batches -- shared DP scratch, result arrays re-allocated mid-run -- would show here).
+    xleg = None
+    if (NB > 1 or host_io) and n_reads > 0 and not os.environ.get("MA_BENCH_NO_XLEG"):
+        xleg = cross_leg_parity(batches, hout, acc, host_io, hs, B, K, codes, offs, offs_h)
     kms = sum(a["kms"] for a in acc)
     walls = [w for a in acc for w in a["wall"]]
     ctr = sum(a["ctr"] for a in acc)
@@ -361,16 +387,17 @@ def run_workload(E, name, wl, args):
     if dom == 4 and valu and avg_s > 0:
         # the DP kernels are bound by VALU issue, not by HBM: wave-level VALU instructions of the committed PMC pass over
         # the live launch time, against the MEASURED issue rate of the kernel's instruction mix (tools/valu_mix.hip)
-        peak = float(E.cal["valu_mix_peak_ginst"])
-        roofline.update({"bound": "valu", "achieved": round(valu / avg_s / 1e9, 1), "peak": peak, "unit": "G wave-inst/s",
-                         "frac": round(valu / avg_s / 1e9 / peak, 3), "traffic": traffic,
-                         # the same rate against what the chip can issue at all (full-rate ops: 1024 SIMDs x 2.4 GHz / 2 cycles);
-                         # `peak` is the measured issue rate of THIS kernel's opcode mix (packed 16-bit ops, DPP: ~4 cycles)
+        # `peak` = what the chip can issue at all (full-rate ops: 1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction, MI355X_MICROARCH.md);
+        # the measured issue rate of THIS kernel's opcode mix (packed 16-bit ops and DPP moves issue at ~4 cycles: tools/valu_mix.hip,
+        # re-run by tools/calibrate.sh) is the secondary `mix_ceiling`
+        mix = float(E.cal["valu_mix_peak_ginst"])
+        roofline.update({"bound": "valu", "achieved": round(valu / avg_s / 1e9, 1), "peak": CHIP_VALU_PEAK_GINST, "unit": "G wave-inst/s",
+                         "frac": round(valu / avg_s / 1e9 / CHIP_VALU_PEAK_GINST, 3), "traffic": traffic,
                          "frac_of_chip_valu_peak": round(valu / avg_s / 1e9 / CHIP_VALU_PEAK_GINST, 3),
-                         "chip_valu_peak": CHIP_VALU_PEAK_GINST,
+                         "mix_ceiling": {"peak": mix, "frac": round(valu / avg_s / 1e9 / mix, 3),
+                                         "source": E.cal.get("source", "profiles/r02_valu_mix.txt (dp_mix, 8 waves/SIMD)")},
                          "lane_insts_per_cell": round(valu * 64.0 / max(ctr[4] / Kd, 1.0), 1),
-                         "wave_insts_per_launch": valu, "wave_insts_source": src,
-                         "peak_source": "profiles/r02_valu_mix.txt (dp_mix, 8 waves/SIMD)", "hbm": hbm})
+                         "wave_insts_per_launch": valu, "wave_insts_source": src, "hbm": hbm})
     else:
         roofline.update({"bound": "hbm"})
         roofline.update(hbm)
@@ -403,7 +430,12 @@ def run_workload(E, name, wl, args):
             "reads_per_s_total": round(n_global / dt, 1),
             "gbases_per_s": round(total_bases * (world if args.scaling == "weak" else 1) / dt / 1e9, 3),
             "roofline": roofline, "cpu_baseline": cpu,
+            "stream_waits": "blocking (event)" if blocking else "spinning (runtime default)",
+            "cfs_throttled": None if thr0 is None or thr1 is None else {"periods": thr1[0] - thr0[0], "thread_seconds": round(thr1[1] - thr0[1], 3)},
+            "host_cores": cores, "cross_leg_parity": xleg,
         }
+        if host_io and hs < K:
+            res["io"] += "; the page-locked staging holds the reads of %d steps: step k re-uses the reads of step k mod %d" % (hs, hs)
     for bt, _ in batches:
         bt.close()
     E.live.clear()
@@ -417,6 +449,49 @@ def run_workload(E, name, wl, args):
     del codes, offs
     torch.cuda.empty_cache()
     return res
+
+
+def cross_leg_parity(batches, hout, acc, host_io, hs, B, K, codes, offs, offs_h):
+    """The MappingQuality records (offsets, every header byte, every op) of the LAST step each batch object ran inside the timed
+    region -- with the other batches in flight beside it, host to host or device resident -- against the same reads aligned
+    again with nothing else running (device resident, on batch object 0)."""
+    got = []
+    for i, (bt, _) in enumerate(batches):
+        k = acc[i]["last"]
+        if k is None:
+            continue
+        if host_io:
+            ho, ha, hp = hout[i]
+            off = ho.a[:B + 1].copy()
+            na = int(off[B])
+            al = ha.a[:na].copy()
+            nops = int(al["ops_off"][na - 1] + al["n_ops"][na - 1]) if na else 0
+            ops = hp.a[:2 * nops].copy()
+            k_reads = k % hs
+        else:
+            off, al, ops = bt.mapq_alignments()
+            na = int(off[B])
+            al = al[:na]
+            nops = int(al["ops_off"][na - 1] + al["n_ops"][na - 1]) if na else 0
+            ops = ops[:2 * nops]
+            k_reads = k
+        got.append((k, k_reads, off, al, ops, na, nops))
+    bad_steps, n_al, n_ops = 0, 0, 0
+    bt0 = batches[0][0]
+    for k, kr, off, al, ops, na, nops in got:
+        lo_r = kr * B
+        bt0.set_reads_device(codes.data_ptr() + int(offs_h[lo_r]), offs.data_ptr() + 8 * kr * (B + 1), B, int(offs_h[lo_r + B] - offs_h[lo_r]))
+        bt0.align()
+        bt0.sync()
+        woff, wal, wops = bt0.mapq_alignments()
+        same = (np.array_equal(off[:B + 1], woff[:B + 1]) and al.tobytes() == wal[:na].tobytes()
+                and np.array_equal(ops, wops[:2 * nops]))
+        bad_steps += 0 if same else 1
+        n_al += na
+        n_ops += nops
+    return {"steps_compared": len(got), "reads": len(got) * B, "alignments": n_al, "ops": n_ops, "mismatching_steps": bad_steps,
+            "what": "the last step of every batch in flight vs the same reads aligned alone (single stream, device resident): MappingQuality "
+                    "records byte for byte"}
 
 
 def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, batches, roofline):
@@ -754,7 +829,9 @@ def run_legs(E, name, wl, args):
             r[key] = {"batches_in_flight": nfl, "io": r2["io"], "value": r2["value"], "unit": r2["unit"], "steps": r2["steps"],
                       "ms_per_step": r2["ms_per_step"], "step_ms_min": r2["step_ms_min"], "step_ms_max": r2["step_ms_max"],
                       "gbases_per_s": r2["gbases_per_s"], "aligned_reads": r2["aligned_reads"],
-                      "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"], "roofline": rf2}
+                      "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"], "roofline": rf2,
+                      "cross_leg_parity": r2.get("cross_leg_parity"), "stream_waits": r2.get("stream_waits"),
+                      "cfs_throttled": r2.get("cfs_throttled")}
     return r
 
 
@@ -870,6 +947,17 @@ def compose_line(E, args, results, boundary, anchor):
         v2, ms2, _ = leg_of(r, "overlapped")
         if v2 is not None:
             out["value_%s_device_resident" % n], out["ms_per_step_%s_device_resident" % n] = v2, ms2
+        if v is not None and v2:
+            out["h2h_over_device_resident_%s" % n] = round(v / v2, 3)
+        for key2, tag in (("host_to_host", "h2h"), ("overlapped", "overlapped")):
+            xp = (r.get(key2) or {}).get("cross_leg_parity")
+            if xp:
+                out["parity_%s_%s" % (n, tag)] = "%d mismatching of %d steps (%d reads, %d alignments, %d ops) vs the same steps run alone" % (
+                    xp["mismatching_steps"], xp["steps_compared"], xp["reads"], xp["alignments"], xp["ops"])
+        if E.world > 1:  # N > 1: what the container's CPU quota did to the ranks' host threads during the leg `value` comes from
+            lg = r.get("host_to_host") or r.get("overlapped") or r
+            out["stream_waits_%s" % n] = lg.get("stream_waits")
+            out["cfs_throttled_%s" % n] = lg.get("cfs_throttled")
         if r.get("batches_in_flight", 1) == 1 and r.get("io", "device").startswith("device"):
             out["value_%s_single_stream" % n], out["ms_per_step_%s_single_stream" % n] = r["value"], r["ms_per_step"]
         if v is None and v2 is None:
@@ -886,7 +974,8 @@ def compose_line(E, args, results, boundary, anchor):
         if rf.get("kernel"):
             out["roofline_%s" % n] = "%s %.2f ms/launch: %s frac %s of %s %s%s; hbm frac %s" % (
                 rf["kernel"], rf["avg_launch_ms"], rf.get("bound"), rf.get("frac"), rf.get("peak"), rf.get("unit"),
-                ", %s of the chip's VALU issue peak, %s lane-instructions per cell" % (rf.get("frac_of_chip_valu_peak"), rf.get("lane_insts_per_cell"))
+                " (the chip's issue peak; %s of the kernel's measured mix ceiling), %s lane-instructions per cell" % (
+                    (rf.get("mix_ceiling") or {}).get("frac"), rf.get("lane_insts_per_cell"))
                 if rf.get("bound") == "valu" else "", (rf.get("hbm") or rf).get("frac"))
     if anchor:
         out["c1_anchor"] = ("error: " + anchor["error"]) if "error" in anchor else (
@@ -915,9 +1004,12 @@ def compose_line(E, args, results, boundary, anchor):
         "detail_file": os.path.relpath(dpath, ROOT) if os.path.isabs(dpath) else dpath,
         "kernel_source_hash": kernel_source_hash(),
     }
-    # of the leg `value` comes from (under overlap a kernel's launch time includes the share of the chip the other batches'
-    # kernels took); the undisturbed one-batch-at-a-time launches: roofline_150bp above and the detail file
-    rf = dict(top["roofline"])
+    # The top-level roofline is the SINGLE-STREAM leg's (one batch at a time: a launch's duration is the kernel's own, and
+    # avg_launch_ms <= that leg's ms_per_step); under overlap a kernel's launch time includes the share of the chip the other
+    # batches' kernels took, which says nothing about the kernel -- that leg's figures are in the detail file.
+    rf = dict(head["roofline"])
+    rf["leg"] = "one batch at a time, device resident: value_%s_single_stream, %s ms per step" % (
+        {"150bp": "150bp", "10kb": "10kb", "50kb": "50kb", "illumina": "150bp_illumina"}.get(head["name"], head["name"]), head["ms_per_step"])
     rf.pop("kernel_ms_per_step", None)
     hb = rf.get("hbm")
     if isinstance(hb, dict):

@@ -334,6 +334,43 @@ int main( int argc, char** argv )
             if( T.maxOverMedian( ) > 3.0 )
                 fprintf( stderr, "WARNING: flat leg with %zu in flight: slowest device batch %.1fx the median\n", uiInflight, T.maxOverMedian( ) );
         }
+        // ---- leg 1c: ONE process, several index replicas: MultiDeviceAligner::executeFlat with persistent engines.
+        // On a node every replica is another GPU; on a one-GPU box the second replica is a "virtual shard" on the same device,
+        // which must cost nothing: 2 replicas x 2 batches in flight against 1 replica x 4 in flight.
+        std::string sMulti;
+        {
+            int nDev = 1;
+            maCheck( ma_device_count( &nDev ) );
+            const int iHere = atoi( argv[ 5 ] );
+            double fOne = 0;
+            for( int iReplicas : { 1, 2 } )
+            {
+                std::vector<int> vDevices;
+                for( int g = 0; g < iReplicas; g++ )
+                    vDevices.push_back( nDev >= iReplicas ? ( iHere + g ) % nDev : iHere );
+                auto vReplicas = MultiDeviceAligner::replicate( pFM, vDevices, iHere );
+                MultiDeviceAligner xMulti( xParams, vReplicas );
+                xMulti.uiInflight = iReplicas == 1 ? 4 : 2;
+                xMulti.warmUp( pReads );
+                xMulti.executeFlat( pReads );
+                const uint64_t uiEngines = detail::Engine::created( ).load( );
+                auto pOut = xMulti.executeFlat( pReads );
+                const AlignerTiming& T = xMulti.xLast;
+                if( iReplicas == 1 )
+                    fOne = n / T.fWall;
+                char buf[ 512 ];
+                snprintf( buf, sizeof( buf ),
+                          "%s\"replicas_%d\": {\"reads_per_s\": %.1f, \"wall_s\": %.4f, \"inflight_per_replica\": %zu, \"devices\": \"%s\", "
+                          "\"device_batches\": %llu, \"batches_of_last_replica\": %llu, \"engines_created_by_the_timed_run\": %llu, "
+                          "\"over_one_replica\": %.3f, \"slowest_batch_over_median\": %.2f}",
+                          sMulti.empty( ) ? "" : ", ", iReplicas, n / T.fWall, T.fWall, xMulti.uiInflight,
+                          nDev >= iReplicas ? "distinct" : "virtual shards on one device", (unsigned long long)T.uiBatches,
+                          (unsigned long long)xMulti.vLast.back( ).uiBatches,
+                          (unsigned long long)( detail::Engine::created( ).load( ) - uiEngines ), fOne > 0 ? ( n / T.fWall ) / fOne : 0.0,
+                          T.maxOverMedian( ) );
+                sMulti += buf;
+            }
+        }
         // ---- leg 2b: SAM text of the flat batches (BatchFileWriter: arenas, one write per batch)
         double fSamFlat = 0;
         uint64_t uiSamFlatBytes = 0;
@@ -521,6 +558,8 @@ int main( int argc, char** argv )
                 "containers); 256 k reads per device batch; phase times summed over the batches\"}, "
                 "\"batch_aligner_flat\": {%s, \"what\": \"BatchAligner::executeFlat: the same without Alignment containers -- the result "
                 "of a device batch stays one header array + one ops array in page-locked memory\"}, "
+                "\"multi_device_flat\": {%s, \"what\": \"MultiDeviceAligner::executeFlat: one process, device batches rotating over the "
+                "replicas of the index, engines persistent (second run timed)\"}, "
                 "\"sam_flat\": {\"reads_per_s\": %.1f, \"bytes\": %llu, \"what\": \"BatchFileWriter::execute on the flat batches: formatted by "
                 "up to 32 threads into byte arenas, one write per batch\"}, "
                 "\"batch_graph\": {%s, \"what\": \"BatchSource -> BatchAlign -> BatchFileWriter as graph nodes under promiseMe / "
@@ -536,7 +575,7 @@ int main( int argc, char** argv )
                 "\"graph_funnel\": {\"reads_per_s\": %.1f, \"graph_threads\": %d, \"device_batches\": %llu, \"mean_reads_per_device_batch\": %.1f, "
                 "\"what\": \"the same graph with the plain reader: per-read execute() calls of that many graph threads funnelled into "
                 "device batches (DeviceBatcher)\"}}\n",
-                n, uiLen, uiHw, fLoad, sBatch.c_str( ), sFlat.c_str( ), n / fSamFlat, (unsigned long long)uiSamFlatBytes, sBatchGraph.c_str( ),
+                n, uiLen, uiHw, fLoad, sBatch.c_str( ), sFlat.c_str( ), sMulti.c_str( ), n / fSamFlat, (unsigned long long)uiSamFlatBytes, sBatchGraph.c_str( ),
                 sFastqGraph.c_str( ), n / fSam, uiSamThreads, (unsigned long long)pSink->uiBytes.load( ), fPrefetchBest, iPrefetchBestThreads,
                 sPrefetch.c_str( ), n / fGraph, iGraphThreads, (unsigned long long)xStat.first, xStat.first ? (double)xStat.second / xStat.first : 0.0 );
     }

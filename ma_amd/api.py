@@ -283,6 +283,10 @@ class Batch:
     def set_stream(self, stream_ptr):
         _chk(lib().ma_batch_set_stream(self.h, C.c_void_p(int(stream_ptr))))
 
+    def set_blocking_sync(self, on=True):
+        """waits of this batch sleep on an interrupt-driven event instead of spinning (hosts with more waiting threads than cores)"""
+        _chk(lib().ma_batch_set_blocking_sync(self.h, C.c_int(1 if on else 0)))
+
     def enable_timing(self, on=True):
         _chk(lib().ma_batch_enable_timing(self.h, C.c_int(1 if on else 0)))
 

@@ -28,6 +28,7 @@ class BatchAlign : public libMS::Module<AlignedBatch, false, FMIndex, ReadVector
     // ma_index: reusing it for another genome would align against the first one)
     std::vector<std::pair<const ma_index*, std::unique_ptr<detail::Engine>>> vIdle;
     std::mutex xPrimeMutex; // first batches of new engines run one at a time (they allocate GBs and page-lock memory)
+    std::atomic<size_t> uiTurn{ 0 }; // which replica of the index takes the next batch
 
   public:
     // seconds summed over all batches (phases of different batches overlap when several graph threads are at work)
@@ -42,7 +43,15 @@ class BatchAlign : public libMS::Module<AlignedBatch, false, FMIndex, ReadVector
         auto pRet = std::make_shared<AlignedBatch>( );
         pRet->pReads = pReads;
         pRet->uiFirst = 0;
+        // device batches rotate over the replicas of the index (DeviceIndex::vReplicas: one per GPU of the node):
+        // the graph of reader -> BatchAlign -> writer stays as it is and feeds all of them
         const ma_index* pIndex = pFM_index->pDev->p;
+        if( !pFM_index->pDev->vReplicas.empty( ) )
+        {
+            const size_t k = uiTurn.fetch_add( 1 ) % ( pFM_index->pDev->vReplicas.size( ) + 1 );
+            if( k > 0 )
+                pIndex = pFM_index->pDev->vReplicas[ k - 1 ]->p;
+        }
         std::unique_ptr<detail::Engine> pEngine;
         {
             std::lock_guard<std::mutex> xGuard( xMutex );

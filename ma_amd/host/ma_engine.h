@@ -60,6 +60,46 @@ inline double secondsSince( const std::chrono::steady_clock::time_point& t0 )
     return std::chrono::duration<double>( std::chrono::steady_clock::now( ) - t0 ).count( );
 }
 
+// Copies of an index on the devices of vDevices (the index is replicated per GPU, 11.9 GB of 288 GB; the arrays are
+// downloaded once and uploaded per device, each upload on a thread bound to its device).  The caller owns the handles
+// (ma_index_destroy).  A device may be named more than once and may be the original's own ("virtual shards" in tests).
+inline std::vector<ma_index*> replicateOnDevices( const ma_index* pOriginal, const std::vector<int>& vDevices )
+{
+    std::vector<ma_index*> vNew;
+    if( vDevices.empty( ) )
+        return vNew;
+    uint64_t nWords = 0, nSa = 0, uiN = 0;
+    int32_t nContigs = 0;
+    engineCheck( ma_index_sizes( pOriginal, &nWords, &nSa, &uiN, &nContigs ) );
+    std::vector<uint32_t> vBwt( nWords );
+    std::vector<int64_t> vSa( nSa );
+    std::vector<uint8_t> vPac( ( uiN / 2 + 3 ) / 4 + 1 );
+    std::vector<uint64_t> vStarts( nContigs ), vLens( nContigs );
+    uint64_t L2[ 5 ];
+    int64_t primary = 0;
+    engineCheck( ma_index_download( pOriginal, vBwt.data( ), vSa.data( ), L2, &primary, vPac.data( ), vStarts.data( ), vLens.data( ) ) );
+    for( int iDev : vDevices )
+    {
+        ma_index* pCopy = nullptr;
+        std::string sFailure;
+        std::thread xCreator( [ & ]( ) { // the upload binds its own thread to the target device
+            if( ma_set_device( iDev ) != 0 ||
+                ma_index_create( vBwt.data( ), nWords, vSa.data( ), nSa, L2, primary, uiN, vPac.data( ), nContigs, vStarts.data( ),
+                                 vLens.data( ), &pCopy ) != 0 )
+                sFailure = ma_last_error( );
+        } );
+        xCreator.join( );
+        if( !sFailure.empty( ) )
+        {
+            for( ma_index* p : vNew )
+                ma_index_destroy( p );
+            throw std::runtime_error( "replicateOnDevices: device " + std::to_string( iDev ) + ": " + sFailure );
+        }
+        vNew.push_back( pCopy );
+    }
+    return vNew;
+}
+
 // Page-locked host array that only grows (ma_host_alloc): the arrays a device batch is uploaded from and downloaded into.
 // Not value-initialised: a download overwrites what it needs.
 template <typename T> class HostBuf
@@ -207,6 +247,17 @@ class Engine
     Engine( const ma_index* pIndex, const ma_params& rP, bool bBlocking = false ) : pIndex( pIndex ), xP( rP ), bBlocking( bBlocking )
     {
         engineCheck( ma_stream_create( pIndex, &pStream ) );
+        created( )++;
+    }
+    // engines constructed by this process so far (tests: a second run of a persistent aligner must not create any)
+    static std::atomic<uint64_t>& created( )
+    {
+        static std::atomic<uint64_t> uiCreated{ 0 };
+        return uiCreated;
+    }
+    const ma_index* index( ) const
+    {
+        return pIndex;
     }
     Engine( const Engine& ) = delete;
     Engine& operator=( const Engine& ) = delete;
@@ -360,6 +411,9 @@ struct BatcherOptions
     // with bStages: also fetch every read's SoC queue (needed by bindings whose SoCPriorityQueue is the reference's own
     // type and must therefore be filled eagerly; the mirror types of ma_modules.h compute it on demand)
     bool bSocQueues = false;
+    // bases per read the engines' device pools are sized for when the batcher is constructed (a funnel batch holds at most
+    // min( uiMaxBatch, 4096 ) reads); a long-read graph sets its expected read length
+    size_t uiReserveBasesPerRead = 512;
 };
 
 // One-shot gate many threads sleep at until it opens.  A condition variable makes every woken thread re-acquire the mutex it
@@ -456,18 +510,29 @@ class DeviceBatcher
 
   public:
     // Engines before admission: all uiEngines engines (stream + device batch sized for the batches a funnel sees) exist when
-    // the constructor returns; none is created while reads are being aligned.
+    // the constructor returns; none is created while reads are being aligned.  Constructing a batcher therefore allocates
+    // device memory and streams even if no read ever arrives (the per-read modules construct theirs on the first execute( ) of a
+    // graph thread, BinarySeeding::batcherFor); a device that is short of memory fails HERE, with a message that says so.
     DeviceBatcher( const ma_index* pIndex, const ma_params& rP, const BatcherOptions& rOpt = BatcherOptions( ) )
         : pIndex( pIndex ), xP( rP ), xOpt( rOpt )
     {
         const uint64_t uiReads = std::min<uint64_t>( std::max<uint64_t>( xOpt.uiMaxBatch, 1 ), 4096 );
         for( size_t k = 0; k < xOpt.uiEngines; k++ )
         {
-            std::unique_ptr<Engine> pEngine( new Engine( pIndex, xP, true ) );
-            pEngine->bFetchSocQueues = xOpt.bSocQueues;
-            pEngine->reserve( uiReads, uiReads * 512 );
-            vIdle.push_back( std::move( pEngine ) );
-            uiEnginesMade++;
+            try
+            {
+                std::unique_ptr<Engine> pEngine( new Engine( pIndex, xP, true ) );
+                pEngine->bFetchSocQueues = xOpt.bSocQueues;
+                pEngine->reserve( uiReads, uiReads * std::max<size_t>( xOpt.uiReserveBasesPerRead, 1 ) );
+                vIdle.push_back( std::move( pEngine ) );
+                uiEnginesMade++;
+            }
+            catch( const std::exception& rE )
+            {
+                throw std::runtime_error( "DeviceBatcher: engine " + std::to_string( k ) + " of " + std::to_string( xOpt.uiEngines ) + " (" +
+                                          std::to_string( uiReads ) + " reads x " + std::to_string( xOpt.uiReserveBasesPerRead ) +
+                                          " bases): " + rE.what( ) );
+            }
         }
     }
     DeviceBatcher( const DeviceBatcher& ) = delete;
@@ -560,6 +625,9 @@ struct PrefetchOptions
     // (with more graph threads than the host grants cores, a thread that is descheduled while it holds a lock stalls them all)
     size_t uiSlice = 128;
     bool bStages = false, bSocQueues = false; // as in BatcherOptions
+    // bases per read the engines' device pools and staging arrays are sized for up front (short reads: 256; a long-read graph
+    // sets its expected read length, otherwise the first batch re-allocates inside the run)
+    size_t uiReserveBasesPerRead = 256;
 };
 
 // Reads pulled AHEAD of the graph threads.  TP_ITEM is the read handle of the host layer (shared_ptr to its NucSeq type).
@@ -574,7 +642,8 @@ struct PrefetchOptions
 // by 8-16 others, all contending for that one thread's malloc arena (13.4 vs 5.1 us of thread time per read).
 // Order: reads are handed out batch by batch in pull order, within a batch in pull order; which graph thread gets which
 // read is as arbitrary as in the reference (every graph thread takes the next read from the shared reader, export.cpp:99-126).
-template <typename TP_ITEM> class PrefetchQueue
+// TP_ENGINE: Engine; the CPU test of the queue's bookkeeping (tests/emul/prefetch_queue_test.cpp) puts a stand-in there.
+template <typename TP_ITEM, typename TP_ENGINE = Engine> class PrefetchQueue
 {
     struct Batch
     {
@@ -582,17 +651,25 @@ template <typename TP_ITEM> class PrefetchQueue
         std::shared_ptr<const BatchResult> pResult;
         size_t uiNext = 0;
     };
-    const ma_index* pIndex;
     const ma_params xP;
     const PrefetchOptions xOpt;
     std::mutex xMutex; // state below
     std::condition_variable xChanged;
     std::vector<std::shared_ptr<Batch>> vReady; // finished batches, oldest first
-    std::vector<std::unique_ptr<Engine>> vIdle;
+    // engines not running a batch.  With several index replicas (one per GPU of the node) every replica has uiDepth
+    // engines of its own and the device batches rotate over them: whoever pulls the next batch takes the engine that has been
+    // idle longest, so G GPUs are fed by the unchanged graph of export.cpp:99-126 -- tickets carry their batch's result, the
+    // modules downstream never ask which device computed it
+    std::vector<std::unique_ptr<TP_ENGINE>> vIdle;
+    size_t uiDepthTotal = 1; // uiDepth per replica
     size_t uiLoading = 0; // batches being pulled or on the device
     bool bEof = false;
     std::string sError;
     std::mutex xPullMutex; // the wrapped source is read by one thread at a time, batches are pulled in order
+    bool bSourceEnded = false; // (under xPullMutex) the source has returned its end marker: it is not asked again
+    // what a thread's unfinished slice checks before it touches its queue's batch: a queue that was destroyed (an aborted
+    // graph) leaves stale slices behind in the threads that served it; they are dropped the next time the thread looks
+    const std::shared_ptr<int> pAlive = std::make_shared<int>( 0 );
     static uint64_t nextId( )
     {
         static std::atomic<uint64_t> uiNext{ 1 };
@@ -603,33 +680,54 @@ template <typename TP_ITEM> class PrefetchQueue
     double fSumRun = 0, fSumPull = 0;
 
   public:
-    PrefetchQueue( const ma_index* pIndex, const ma_params& rP, const PrefetchOptions& rOpt = PrefetchOptions( ) )
-        : pIndex( pIndex ), xP( rP ), xOpt( rOpt )
+    // Constructing a queue creates uiDepth engines per index replica -- a stream, device pools for uiBatchReads reads of
+    // uiReserveBasesPerRead bases (GBs for long reads) and page-locked staging each: before the first read is asked for, not
+    // inside the first timed batch.  A device that is short of memory makes the constructor throw (with the replica's number).
+    PrefetchQueue( const std::vector<const ma_index*>& vIndices, const ma_params& rP, const PrefetchOptions& rOpt = PrefetchOptions( ) )
+        : xP( rP ), xOpt( rOpt )
     {
-        // engines before admission: streams and device batches exist before the first read is asked for
+        if( vIndices.empty( ) )
+            throw std::runtime_error( "PrefetchQueue: no index" );
+        uiDepthTotal = std::max<size_t>( xOpt.uiDepth, 1 ) * vIndices.size( );
+        // round k holds the k-th engine of every replica: vIdle is served from its front, so consecutive batches go to
+        // different devices
         for( size_t k = 0; k < std::max<size_t>( xOpt.uiDepth, 1 ); k++ )
-        {
-            std::unique_ptr<Engine> pEngine( new Engine( pIndex, xP, true ) );
-            pEngine->bFetchSocQueues = xOpt.bSocQueues;
-            pEngine->reserve( xOpt.uiBatchReads, xOpt.uiBatchReads * 256 );
-            vIdle.push_back( std::move( pEngine ) );
-        }
+            for( size_t g = 0; g < vIndices.size( ); g++ )
+            {
+                try
+                {
+                    std::unique_ptr<TP_ENGINE> pEngine( new TP_ENGINE( vIndices[ g ], xP, true ) );
+                    pEngine->bFetchSocQueues = xOpt.bSocQueues;
+                    pEngine->reserve( xOpt.uiBatchReads, xOpt.uiBatchReads * std::max<size_t>( xOpt.uiReserveBasesPerRead, 1 ) );
+                    vIdle.push_back( std::move( pEngine ) );
+                }
+                catch( const std::exception& rE )
+                {
+                    throw std::runtime_error( "PrefetchQueue: engine " + std::to_string( k ) + " of index replica " + std::to_string( g ) +
+                                              " (" + std::to_string( xOpt.uiBatchReads ) + " reads x " +
+                                              std::to_string( xOpt.uiReserveBasesPerRead ) + " bases): " + rE.what( ) );
+                }
+            }
     }
+    PrefetchQueue( const ma_index* pIndex, const ma_params& rP, const PrefetchOptions& rOpt = PrefetchOptions( ) )
+        : PrefetchQueue( std::vector<const ma_index*>( 1, pIndex ), rP, rOpt )
+    {}
     PrefetchQueue( const PrefetchQueue& ) = delete;
 
     // the calling thread's slice of a finished batch (thread-local: no lock while it lasts)
     struct Slice
     {
         uint64_t uiOwner = 0; // id of the queue the slice belongs to (not its address: a later queue may be allocated there)
+        std::weak_ptr<int> pOwnerAlive;
         std::shared_ptr<Batch> pBatch;
         // the batch's result behind a control block of THIS thread's own: the tickets of a slice are copied a dozen times per
         // read (query -> segments -> ... -> alignments), and reference counts that 16 threads keep bumping on ONE control
         // block bounce its cache line between the cores (measured: half of a graph thread's time per read)
         std::shared_ptr<const BatchResult> pResult;
         size_t uiNext = 0, uiEnd = 0;
-        void take( const std::shared_ptr<Batch>& pB, size_t uiFrom, size_t uiTo, uint64_t uiQueue )
+        void take( const std::shared_ptr<Batch>& pB, size_t uiFrom, size_t uiTo, uint64_t uiQueue, const std::shared_ptr<int>& pAliveOfQueue )
         {
-            uiOwner = uiQueue, pBatch = pB, uiNext = uiFrom, uiEnd = uiTo;
+            uiOwner = uiQueue, pOwnerAlive = pAliveOfQueue, pBatch = pB, uiNext = uiFrom, uiEnd = uiTo;
             std::shared_ptr<const BatchResult> pKeep = pB->pResult;
             pResult = std::shared_ptr<const BatchResult>( pKeep.get( ), [ pKeep ]( const BatchResult* ) {} );
         }
@@ -637,18 +735,46 @@ template <typename TP_ITEM> class PrefetchQueue
         {
             pBatch.reset( );
             pResult.reset( );
+            uiNext = uiEnd = 0;
+        }
+        bool empty( ) const
+        {
+            return uiNext >= uiEnd;
         }
     };
-    static Slice& mySlice( )
+    // One slice PER QUEUE the thread serves: a graph thread that alternates between two PrefetchReaders -- two
+    // wrapped files, two aligners in one process -- keeps its unfinished slice of queue A while it takes reads of queue B; with
+    // one slice per thread the reads of A's slice, already taken out of A's batch, were lost.  Finished slices and slices of
+    // queues that no longer exist are removed on the way.
+    static Slice& mySlice( uint64_t uiQueue )
     {
-        static thread_local Slice xSlice;
-        return xSlice;
+        static thread_local std::vector<Slice> vSlices;
+        Slice* pFound = nullptr;
+        for( size_t k = 0; k < vSlices.size( ); )
+        {
+            if( vSlices[ k ].uiOwner == uiQueue )
+                pFound = &vSlices[ k ];
+            else if( vSlices[ k ].empty( ) || vSlices[ k ].pOwnerAlive.expired( ) )
+            {
+                if( pFound == &vSlices.back( ) )
+                    pFound = &vSlices[ k ];
+                vSlices[ k ] = std::move( vSlices.back( ) );
+                vSlices.pop_back( );
+                continue;
+            }
+            k++;
+        }
+        if( pFound != nullptr )
+            return *pFound;
+        vSlices.emplace_back( );
+        vSlices.back( ).uiOwner = uiQueue;
+        return vSlices.back( );
     }
 
     template <typename TP_PULL, typename TP_REF> bool next( TP_ITEM& rItem, Ticket& rTicket, TP_PULL&& fPull, TP_REF&& fRef )
     {
-        Slice& rMine = mySlice( );
-        if( rMine.uiOwner == uiId && rMine.uiNext < rMine.uiEnd )
+        Slice& rMine = mySlice( uiId );
+        if( rMine.uiNext < rMine.uiEnd )
         {
             const size_t k = rMine.uiNext++;
             rItem = rMine.pBatch->vItems[ k ];
@@ -664,11 +790,11 @@ template <typename TP_ITEM> class PrefetchQueue
             if( !sError.empty( ) )
                 throw std::runtime_error( sError );
             // keep uiDepth batches ahead: this caller pulls and runs the next one, the others are served meanwhile
-            if( !bEof && uiLoading + vReady.size( ) < std::max<size_t>( xOpt.uiDepth, 1 ) && !vIdle.empty( ) )
+            if( !bEof && uiLoading + vReady.size( ) < uiDepthTotal && !vIdle.empty( ) )
             {
                 uiLoading++;
-                std::unique_ptr<Engine> pEngine = std::move( vIdle.back( ) );
-                vIdle.pop_back( );
+                std::unique_ptr<TP_ENGINE> pEngine = std::move( vIdle.front( ) ); // idle longest: batches rotate over the replicas
+                vIdle.erase( vIdle.begin( ) );
                 xLock.unlock( );
                 auto pBatch = std::make_shared<Batch>( );
                 std::string sFailed;
@@ -679,16 +805,18 @@ template <typename TP_ITEM> class PrefetchQueue
                 {
                     {
                         std::lock_guard<std::mutex> xPull( xPullMutex );
-                        pBatch->vItems.reserve( xOpt.uiBatchReads );
-                        while( pBatch->vItems.size( ) < xOpt.uiBatchReads )
+                        // a source that has ended is not asked again (it need not be idempotent at its end): a second puller
+                        // may have been waiting for this lock while the first one met the end
+                        bEnd = bSourceEnded;
+                        if( !bEnd )
+                            pBatch->vItems.reserve( xOpt.uiBatchReads );
+                        while( !bEnd && pBatch->vItems.size( ) < xOpt.uiBatchReads )
                         {
                             TP_ITEM xItem = fPull( );
                             if( !xItem )
-                            {
-                                bEnd = true;
-                                break;
-                            }
-                            pBatch->vItems.push_back( std::move( xItem ) );
+                                bEnd = bSourceEnded = true;
+                            else
+                                pBatch->vItems.push_back( std::move( xItem ) );
                         }
                     }
                     fPullS = secondsSince( tPull );
@@ -708,6 +836,10 @@ template <typename TP_ITEM> class PrefetchQueue
                     sFailed = rE.what( );
                     if( sFailed.empty( ) )
                         sFailed = "device batch failed";
+                }
+                catch( ... ) // whatever the wrapped source throws: the queue's state is restored and every waiter sees the failure
+                {
+                    sFailed = "PrefetchQueue: the wrapped source or the device batch threw an exception that is not a std::exception";
                 }
                 xLock.lock( );
                 vIdle.push_back( std::move( pEngine ) );
@@ -742,7 +874,7 @@ template <typename TP_ITEM> class PrefetchQueue
                     xChanged.notify_all( ); // room for another batch ahead
                 }
                 xLock.unlock( );
-                rMine.take( pB, k + 1, uiEnd, uiId );
+                rMine.take( pB, k + 1, uiEnd, uiId, pAlive );
                 rItem = pB->vItems[ k ];
                 rTicket.pResult = rMine.pResult;
                 rTicket.uiRead = k;

@@ -104,13 +104,24 @@ class NucSeq : public libMS::Container // nucSeq.h:61-160: codes A0 C1 G2 T3 N4
 };
 
 // One device-resident index shared by the Pack and FMIndex views (both are read-only after load).
+// vReplicas: copies of the same index on OTHER devices of the node (replicateIndex below).  The throughput forms --
+// PrefetchReader, BatchAlign, BatchAligner -- rotate their device batches over p and the replicas, so the one FMIndex / Pack
+// pledge of the graph (export.cpp:99-126) feeds all GPUs; everything else (single-stage calls, pack extraction) uses p.
 struct DeviceIndex
 {
     ma_index* p = nullptr;
+    std::vector<std::shared_ptr<DeviceIndex>> vReplicas;
     ~DeviceIndex( )
     {
         if( p )
             ma_index_destroy( p );
+    }
+    std::vector<const ma_index*> all( ) const
+    {
+        std::vector<const ma_index*> v( 1, p );
+        for( const auto& pR : vReplicas )
+            v.push_back( pR->p );
+        return v;
     }
 };
 
@@ -205,6 +216,23 @@ class Pack : public libMS::Container
         return n;
     }
 };
+
+// One copy of pDev's index on every device of vDevices (the index is replicated, 11.9 GB of 288 GB per GPU; the
+// arrays are downloaded once and uploaded per device, each upload on a thread bound to its device).  The copies are attached
+// to pDev (DeviceIndex::vReplicas) and returned.  A device may be named more than once and may be the original's own: tests
+// on a one-GPU box run "virtual shards" on device 0.
+inline std::vector<std::shared_ptr<DeviceIndex>> replicateIndex( const std::shared_ptr<DeviceIndex>& pDev, const std::vector<int>& vDevices )
+{
+    std::vector<std::shared_ptr<DeviceIndex>> vNew;
+    for( ma_index* pCopy : detail::replicateOnDevices( pDev->p, vDevices ) )
+    {
+        vNew.push_back( std::make_shared<DeviceIndex>( ) );
+        vNew.back( )->p = pCopy;
+    }
+    for( const auto& pCopy : vNew )
+        pDev->vReplicas.push_back( pCopy );
+    return vNew;
+}
 
 // Loads the reference's own index files <prefix>.bwt/.sa/.pac/.ann (fMIndex.h:555-663, pack.h:271-470)
 // and uploads them; replaces `makePledge<Pack>(prefix)` / `makePledge<FMIndex>(prefix)` of
@@ -841,7 +869,7 @@ template <typename... TP_ARGS> class PrefetchReader : public libMS::Module<NucSe
   public:
     PrefetchReader( const ParameterSetManager& rParameters, std::shared_ptr<TP_SOURCE> pSource, std::shared_ptr<FMIndex> pFM_index,
                     const detail::PrefetchOptions& rOpt = detail::PrefetchOptions( ) )
-        : pSource( pSource ), xQueue( pFM_index->pDev->p, *rParameters.getSelected( ), rOpt )
+        : pSource( pSource ), xQueue( pFM_index->pDev->all( ), *rParameters.getSelected( ), rOpt ) // every replica of the index gets its engines
     {}
     // nullptr = the wrapped reader is exhausted and every read it gave has been handed out (module.h:688-695)
     virtual std::shared_ptr<NucSeq> execute( std::shared_ptr<TP_ARGS>... pArgs ) override
@@ -1450,26 +1478,37 @@ class BatchAligner
     size_t uiBatchReads = 1u << 18;
     size_t uiInflight = 2;
     AlignerTiming xLast; // of the last execute()
+    std::vector<AlignerTiming> vLastPerIndex; // the same per replica of the index (one entry without replicas)
 
     BatchAligner( const ParameterSetManager& rParameters ) : xP( *rParameters.getSelected( ) ), xParams( rParameters )
     {}
 
     typedef libMS::ContainerVector<std::shared_ptr<AlignedBatch>> TP_FLAT;
 
-    // Aligns reads [uiFrom, uiTo) of rQueries on the device of pIndex.  pFlat: one AlignedBatch per device batch (in input
-    // order; entry k covers reads [uiFrom + k * uiBatchReads, ...)); pOut: per read its Alignment containers (rOut[ i ]).
-    void alignRange( const ma_index* pIndex, const libMS::ContainerVector<std::shared_ptr<NucSeq>>& rQueries, size_t uiFrom,
-                     size_t uiTo, TP_RESULT* pOut, AlignerTiming& rT, TP_FLAT* pFlat = nullptr,
-                     std::shared_ptr<ReadVector> pReadsOfFlat = nullptr ) const
+    // Aligns reads [uiFrom, uiTo) of rQueries on the devices of vIndices (replicas of ONE index; one entry = one GPU, or a
+    // "virtual shard" on the same GPU).  The range is cut into device batches of uiBatchReads reads; every replica has uiInflight
+    // workers (host thread + engine: stream, device pools, page-locked staging), and all workers take the next batch from ONE
+    // counter, so the replicas share the work by batches -- no collective, no inter-GPU traffic.  pFlat: one
+    // AlignedBatch per device batch in input order (entry k covers reads [uiFrom + k * uiBatchReads, ...)); pOut: per read its
+    // Alignment containers (rOut[ i ]).  pPerIndex: phase times per replica.
+    void alignRangeOn( const std::vector<const ma_index*>& vIndices, const libMS::ContainerVector<std::shared_ptr<NucSeq>>& rQueries,
+                       size_t uiFrom, size_t uiTo, TP_RESULT* pOut, AlignerTiming& rT, TP_FLAT* pFlat = nullptr,
+                       std::shared_ptr<ReadVector> pReadsOfFlat = nullptr, std::vector<AlignerTiming>* pPerIndex = nullptr ) const
     {
+        if( vIndices.empty( ) )
+            throw std::runtime_error( "BatchAligner: no index" );
         std::mutex xNext;
         size_t uiNext = uiFrom;
         std::string sFailure;
+        const size_t uiBatch = std::max<size_t>( uiBatchReads, 1 );
+        const size_t uiBatchesAll = ( uiTo - uiFrom + uiBatch - 1 ) / uiBatch;
         const size_t uiFlatBase = pFlat ? pFlat->size( ) : 0;
         if( pFlat )
-            pFlat->resize( uiFlatBase + ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) );
+            pFlat->resize( uiFlatBase + uiBatchesAll );
+        if( pPerIndex )
+            pPerIndex->assign( vIndices.size( ), AlignerTiming( ) );
         // one device batch [lo, hi) through an engine; results into pFlat / pOut, phase times into rT
-        auto runBatch = [ & ]( detail::Engine& xEngine, size_t lo, size_t hi ) {
+        auto runBatch = [ & ]( detail::Engine& xEngine, size_t uiOfIndex, size_t lo, size_t hi ) {
             std::vector<detail::ReadRef> vReads;
             vReads.reserve( hi - lo );
             for( size_t i = lo; i < hi; i++ )
@@ -1482,7 +1521,7 @@ class BatchAligner
                 pB->pReads = pReadsOfFlat;
                 pB->uiFirst = lo;
                 pB->pResult = pRes;
-                ( *pFlat )[ uiFlatBase + ( lo - uiFrom ) / uiBatchReads ] = pB;
+                ( *pFlat )[ uiFlatBase + ( lo - uiFrom ) / uiBatch ] = pB;
             }
             if( pOut )
                 for( size_t i = lo; i < hi; i++ )
@@ -1493,25 +1532,36 @@ class BatchAligner
                 }
             const double fContainers = detail::secondsSince( t0 );
             std::lock_guard<std::mutex> xGuard( xNext );
-            rT.fPack += pRes->fPack, rT.fH2D += pRes->fH2D, rT.fKernels += pRes->fKernels, rT.fD2H += pRes->fD2H, rT.fContainers += fContainers;
-            rT.uiBatches++, rT.uiReads += hi - lo, rT.uiAlignedReads += pRes->uiAlignedReads;
-            rT.vBatchSeconds.push_back( pRes->fPack + pRes->fH2D + pRes->fKernels + pRes->fD2H );
+            auto account = [ & ]( AlignerTiming& rA ) {
+                rA.fPack += pRes->fPack, rA.fH2D += pRes->fH2D, rA.fKernels += pRes->fKernels, rA.fD2H += pRes->fD2H, rA.fContainers += fContainers;
+                rA.uiBatches++, rA.uiReads += hi - lo, rA.uiAlignedReads += pRes->uiAlignedReads;
+                rA.vBatchSeconds.push_back( pRes->fPack + pRes->fH2D + pRes->fKernels + pRes->fD2H );
+            };
+            account( rT );
+            if( pPerIndex )
+                account( ( *pPerIndex )[ uiOfIndex ] );
         };
-        const size_t uiWorkers = std::max<size_t>( 1, std::min( uiInflight, ( uiTo - uiFrom + uiBatchReads - 1 ) / std::max<size_t>( uiBatchReads, 1 ) ) );
+        // workers: uiInflight per replica, but no more than there are batches (replica-major order would leave the last
+        // replicas without a worker when there are few batches: round k holds the k-th worker of every replica)
+        std::vector<size_t> vIndexOfWorker;
+        for( size_t k = 0; k < std::max<size_t>( uiInflight, 1 ); k++ )
+            for( size_t g = 0; g < vIndices.size( ) && vIndexOfWorker.size( ) < std::max<size_t>( uiBatchesAll, 1 ); g++ )
+                vIndexOfWorker.push_back( g );
+        const size_t uiWorkers = vIndexOfWorker.size( );
         // Engines before admission: every worker's engine exists before the first worker starts, and an engine that has not
         // run a batch of this size yet runs its first one HERE, alone -- the first batch of an engine allocates GBs of device
         // pools and page-locks its staging arrays, which stalls every other stream of the process (0.3-0.8 s each; with four
         // new engines racing inside a timed leg the driver's run of round 3 measured 0.35 M reads/s instead of 19 M).
         std::vector<std::unique_ptr<detail::Engine>> vEngines;
         for( size_t k = 0; k < uiWorkers; k++ )
-            vEngines.push_back( takeEngine( pIndex ) );
+            vEngines.push_back( takeEngine( vIndices[ vIndexOfWorker[ k ] ] ) );
         try
         {
-            for( auto& pEngine : vEngines )
-                if( !pEngine->primed( std::min( uiBatchReads, uiTo - uiFrom ) ) && uiNext < uiTo )
+            for( size_t k = 0; k < uiWorkers; k++ )
+                if( !vEngines[ k ]->primed( std::min( uiBatch, uiTo - uiFrom ) ) && uiNext < uiTo )
                 {
-                    const size_t lo = uiNext, hi = uiNext = std::min( uiTo, uiNext + uiBatchReads );
-                    runBatch( *pEngine, lo, hi );
+                    const size_t lo = uiNext, hi = uiNext = std::min( uiTo, uiNext + uiBatch );
+                    runBatch( *vEngines[ k ], vIndexOfWorker[ k ], lo, hi );
                 }
         }
         catch( const std::exception& rE )
@@ -1530,9 +1580,9 @@ class BatchAligner
                         if( uiNext >= uiTo || !sFailure.empty( ) )
                             break;
                         lo = uiNext;
-                        hi = uiNext = std::min( uiTo, uiNext + uiBatchReads );
+                        hi = uiNext = std::min( uiTo, uiNext + uiBatch );
                     }
-                    runBatch( xEngine, lo, hi );
+                    runBatch( xEngine, vIndexOfWorker[ uiMe ], lo, hi );
                 }
             }
             catch( const std::exception& rE )
@@ -1548,10 +1598,16 @@ class BatchAligner
         worker( 0 );
         for( auto& rW : vWorkers )
             rW.join( );
-        for( auto& pEngine : vEngines )
-            giveEngine( pIndex, std::move( pEngine ) );
+        for( size_t k = 0; k < uiWorkers; k++ )
+            giveEngine( vIndices[ vIndexOfWorker[ k ] ], std::move( vEngines[ k ] ) );
         if( !sFailure.empty( ) )
             throw std::runtime_error( sFailure );
+    }
+    void alignRange( const ma_index* pIndex, const libMS::ContainerVector<std::shared_ptr<NucSeq>>& rQueries, size_t uiFrom,
+                     size_t uiTo, TP_RESULT* pOut, AlignerTiming& rT, TP_FLAT* pFlat = nullptr,
+                     std::shared_ptr<ReadVector> pReadsOfFlat = nullptr ) const
+    {
+        alignRangeOn( std::vector<const ma_index*>( 1, pIndex ), rQueries, uiFrom, uiTo, pOut, rT, pFlat, pReadsOfFlat );
     }
 
     // Creates the uiInflight engines of this aligner for pFM_index and runs one batch through each, one after the other
@@ -1560,19 +1616,21 @@ class BatchAligner
     {
         if( pSample == nullptr || pSample->empty( ) )
             return;
-        const ma_index* pIndex = pFM_index->pDev->p;
-        std::vector<std::unique_ptr<detail::Engine>> vEngines;
-        for( size_t k = 0; k < std::max<size_t>( uiInflight, 1 ); k++ )
-            vEngines.push_back( takeEngine( pIndex ) );
         const size_t n = std::min( pSample->size( ), uiBatchReads );
         std::vector<detail::ReadRef> vReads;
         for( size_t i = 0; i < n; i++ )
             vReads.emplace_back( ( *pSample )[ i ]->xCodes );
-        for( auto& pEngine : vEngines )
-            if( !pEngine->primed( n ) )
-                pEngine->run( vReads, false );
-        for( auto& pEngine : vEngines )
-            giveEngine( pIndex, std::move( pEngine ) );
+        for( const ma_index* pIndex : pFM_index->pDev->all( ) ) // every replica of the index (one per GPU)
+        {
+            std::vector<std::unique_ptr<detail::Engine>> vEngines;
+            for( size_t k = 0; k < std::max<size_t>( uiInflight, 1 ); k++ )
+                vEngines.push_back( takeEngine( pIndex ) );
+            for( auto& pEngine : vEngines )
+                if( !pEngine->primed( n ) )
+                    pEngine->run( vReads, false );
+            for( auto& pEngine : vEngines )
+                giveEngine( pIndex, std::move( pEngine ) );
+        }
     }
 
     virtual std::shared_ptr<TP_RESULT> execute( std::shared_ptr<FMIndex> pFM_index,
@@ -1582,8 +1640,8 @@ class BatchAligner
         pRet->resize( pQueries->size( ) );
         xLast = AlignerTiming( );
         const auto t0 = std::chrono::steady_clock::now( );
-        if( !pQueries->empty( ) )
-            alignRange( pFM_index->pDev->p, *pQueries, 0, pQueries->size( ), pRet.get( ), xLast );
+        if( !pQueries->empty( ) ) // on every replica of the index (DeviceIndex::vReplicas: one per GPU)
+            alignRangeOn( pFM_index->pDev->all( ), *pQueries, 0, pQueries->size( ), pRet.get( ), xLast, nullptr, nullptr, &vLastPerIndex );
         // "Detect Small Inversions" (export.cpp:118-121): all reads' inversion DP in one more GPU launch
         if( xP.search_inversions )
         {
@@ -1617,7 +1675,7 @@ class BatchAligner
         xLast = AlignerTiming( );
         const auto t0 = std::chrono::steady_clock::now( );
         if( !pQueries->empty( ) )
-            alignRange( pFM_index->pDev->p, *pQueries, 0, pQueries->size( ), nullptr, xLast, pRet.get( ), pQueries );
+            alignRangeOn( pFM_index->pDev->all( ), *pQueries, 0, pQueries->size( ), nullptr, xLast, pRet.get( ), pQueries, &vLastPerIndex );
         xLast.fWall = detail::secondsSince( t0 );
         return pRet;
     }
@@ -1647,44 +1705,73 @@ class BatchAligner
     }
 };
 
-// Throughput API, several GPUs of one node: reads are independent, so the read set is cut into one
-// contiguous block per index replica (the shares differ by at most one read), every replica's block is aligned by its own
-// host thread on the replica's device with BatchAligner's double-buffered batches, and the results land at the reads'
-// input positions.  No collective, no inter-GPU traffic; the only shared state is the output vector (disjoint slots).
-// Replicas may live on the same device (tests on a one-GPU box use two "virtual shards" on device 0).
+// Throughput API, several GPUs of one node: reads are independent, the index is replicated, the device batches
+// of a read set rotate over the replicas (BatchAligner::alignRangeOn: uiInflight workers per replica, one shared batch
+// counter), and the results land at the reads' input positions.  No collective, no inter-GPU traffic.  The aligner and its
+// engines PERSIST: a second execute( ) / executeFlat( ) creates no engine, allocates nothing and page-locks nothing (round 4
+// built a new BatchAligner per replica inside every execute( )).  Replicas may live on the same device (tests on a one-GPU
+// box use "virtual shards" on device 0).
 class MultiDeviceAligner
 {
     ParameterSetManager xParams;
     std::vector<std::shared_ptr<FMIndex>> vReplicas;
+    std::vector<const ma_index*> vIndices;
+    BatchAligner xAligner;
+
+    void configure( )
+    {
+        xAligner.uiBatchReads = uiBatchReads;
+        xAligner.uiInflight = uiInflight;
+    }
 
   public:
     size_t uiBatchReads = 1u << 18;
-    size_t uiInflight = 2;
+    size_t uiInflight = 2; // device batches in flight PER replica
     std::vector<AlignerTiming> vLast; // per replica, of the last execute()
+    AlignerTiming xLast; // all replicas together
 
     MultiDeviceAligner( const ParameterSetManager& rParameters, const std::vector<std::shared_ptr<FMIndex>>& vReplicas )
-        : xParams( rParameters ), vReplicas( vReplicas )
+        : xParams( rParameters ), vReplicas( vReplicas ), xAligner( rParameters )
     {
         if( vReplicas.empty( ) )
             throw std::runtime_error( "MultiDeviceAligner: no index replica" );
+        for( const auto& pFM : vReplicas )
+            for( const ma_index* pIndex : pFM->pDev->all( ) )
+                vIndices.push_back( pIndex );
     }
 
-    // One replica of pFM's index on every device of vDevices (the arrays are downloaded once and uploaded per device;
-    // a device that already holds pFM's index reuses it).
+    // One replica of pFM's index on every device of vDevices, each as an FMIndex of its own (a device that already holds
+    // pFM's index reuses it).  (replicateIndex attaches replicas to ONE FMIndex instead: what the graph forms use.)
     static std::vector<std::shared_ptr<FMIndex>> replicate( const std::shared_ptr<FMIndex>& pFM, const std::vector<int>& vDevices,
                                                             int iDeviceOfOriginal = 0 )
     {
-        uint64_t nWords = 0, nSa = 0, uiN = 0;
-        int32_t nContigs = 0;
-        maCheck( ma_index_sizes( pFM->pDev->p, &nWords, &nSa, &uiN, &nContigs ) );
-        std::vector<uint32_t> vBwt;
-        std::vector<int64_t> vSa;
-        std::vector<uint8_t> vPac;
-        std::vector<uint64_t> vStarts( nContigs ), vLens( nContigs );
-        uint64_t L2[ 5 ];
-        int64_t primary = 0;
-        std::vector<std::shared_ptr<FMIndex>> vRet;
+        std::vector<int> vOthers;
         bool bUsedOriginal = false;
+        for( int iDev : vDevices )
+        {
+            if( iDev == iDeviceOfOriginal && !bUsedOriginal )
+                bUsedOriginal = true;
+            else
+                vOthers.push_back( iDev );
+        }
+        // copies that are NOT attached to pFM: this aligner addresses every replica itself
+        auto pScratch = std::make_shared<DeviceIndex>( );
+        pScratch->p = pFM->pDev->p;
+        std::vector<std::shared_ptr<DeviceIndex>> vCopies;
+        try
+        {
+            vCopies = replicateIndex( pScratch, vOthers );
+        }
+        catch( ... )
+        {
+            pScratch->p = nullptr;
+            throw;
+        }
+        pScratch->p = nullptr; // (borrowed)
+        pScratch->vReplicas.clear( );
+        std::vector<std::shared_ptr<FMIndex>> vRet;
+        size_t uiCopy = 0;
+        bUsedOriginal = false;
         for( int iDev : vDevices )
         {
             if( iDev == iDeviceOfOriginal && !bUsedOriginal )
@@ -1693,64 +1780,50 @@ class MultiDeviceAligner
                 bUsedOriginal = true;
                 continue;
             }
-            if( vBwt.empty( ) )
-            {
-                vBwt.resize( nWords );
-                vSa.resize( nSa );
-                vPac.resize( ( uiN / 2 + 3 ) / 4 + 1 );
-                maCheck( ma_index_download( pFM->pDev->p, vBwt.data( ), vSa.data( ), L2, &primary, vPac.data( ), vStarts.data( ),
-                                            vLens.data( ) ) );
-            }
-            auto pDev = std::make_shared<DeviceIndex>( );
-            std::string sFailure;
-            std::thread xCreator( [ & ]( ) { // the upload binds its own thread to the target device
-                if( ma_set_device( iDev ) != 0 ||
-                    ma_index_create( vBwt.data( ), nWords, vSa.data( ), nSa, L2, primary, uiN, vPac.data( ), nContigs, vStarts.data( ),
-                                     vLens.data( ), &pDev->p ) != 0 )
-                    sFailure = ma_last_error( );
-            } );
-            xCreator.join( );
-            if( !sFailure.empty( ) )
-                throw std::runtime_error( sFailure );
             auto pCopy = std::make_shared<FMIndex>( );
-            pCopy->pDev = pDev;
+            pCopy->pDev = vCopies[ uiCopy++ ];
             vRet.push_back( pCopy );
         }
         return vRet;
     }
 
+    // engines of every replica created and primed with a batch of pSample (after it nothing is allocated inside execute)
+    void warmUp( std::shared_ptr<ReadVector> pSample )
+    {
+        configure( );
+        for( const auto& pFM : vReplicas )
+            xAligner.warmUp( pFM, pSample );
+    }
+
     std::shared_ptr<BatchAligner::TP_RESULT> execute( std::shared_ptr<libMS::ContainerVector<std::shared_ptr<NucSeq>>> pQueries )
     {
+        configure( );
         auto pRet = std::make_shared<BatchAligner::TP_RESULT>( );
         pRet->resize( pQueries->size( ) );
-        const size_t uiG = vReplicas.size( ), n = pQueries->size( );
-        vLast.assign( uiG, AlignerTiming( ) );
-        std::vector<std::string> vFailure( uiG );
-        std::vector<std::thread> vWorkers;
-        for( size_t g = 0; g < uiG; g++ )
-            vWorkers.emplace_back( [ &, g ]( ) {
-                const size_t uiBase = n / uiG, uiRem = n % uiG;
-                const size_t lo = g * uiBase + std::min( g, uiRem ), hi = lo + uiBase + ( g < uiRem ? 1 : 0 );
-                try
-                {
-                    BatchAligner xAligner( xParams );
-                    xAligner.uiBatchReads = uiBatchReads;
-                    xAligner.uiInflight = uiInflight;
-                    const auto t0 = std::chrono::steady_clock::now( );
-                    if( hi > lo )
-                        xAligner.alignRange( vReplicas[ g ]->pDev->p, *pQueries, lo, hi, pRet.get( ), vLast[ g ] );
-                    vLast[ g ].fWall = detail::secondsSince( t0 );
-                }
-                catch( const std::exception& rE )
-                {
-                    vFailure[ g ] = rE.what( );
-                }
-            } );
-        for( auto& rW : vWorkers )
-            rW.join( );
-        for( const std::string& sF : vFailure )
-            if( !sF.empty( ) )
-                throw std::runtime_error( sF );
+        xLast = AlignerTiming( );
+        vLast.assign( vIndices.size( ), AlignerTiming( ) );
+        const auto t0 = std::chrono::steady_clock::now( );
+        if( !pQueries->empty( ) )
+            xAligner.alignRangeOn( vIndices, *pQueries, 0, pQueries->size( ), pRet.get( ), xLast, nullptr, nullptr, &vLast );
+        xLast.fWall = detail::secondsSince( t0 );
+        for( auto& rT : vLast )
+            rT.fWall = xLast.fWall;
+        return pRet;
+    }
+
+    // The same run with the results left FLAT: one AlignedBatch per device batch, in input order, whichever replica ran it.
+    std::shared_ptr<BatchAligner::TP_FLAT> executeFlat( std::shared_ptr<ReadVector> pQueries )
+    {
+        configure( );
+        auto pRet = std::make_shared<BatchAligner::TP_FLAT>( );
+        xLast = AlignerTiming( );
+        vLast.assign( vIndices.size( ), AlignerTiming( ) );
+        const auto t0 = std::chrono::steady_clock::now( );
+        if( !pQueries->empty( ) )
+            xAligner.alignRangeOn( vIndices, *pQueries, 0, pQueries->size( ), nullptr, xLast, pRet.get( ), pQueries, &vLast );
+        xLast.fWall = detail::secondsSince( t0 );
+        for( auto& rT : vLast )
+            rT.fWall = xLast.fWall;
         return pRet;
     }
 };

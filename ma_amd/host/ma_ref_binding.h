@@ -143,9 +143,12 @@ inline ma_params paramsOf( const ::ParameterSetManager& rParameters )
 }
 
 // ---- the device-resident copy of a (Pack, FMIndex) pair ----------------------------------------------------------------
+// vReplicas: copies of the same index on other devices of the node (replicateIndex); PrefetchReader rotates its device batches
+// over p and the replicas, everything else uses p.
 struct DeviceIndex
 {
     ma_index* p = nullptr;
+    std::vector<std::shared_ptr<DeviceIndex>> vReplicas;
     DeviceIndex( )
     {}
     DeviceIndex( const DeviceIndex& ) = delete;
@@ -153,6 +156,13 @@ struct DeviceIndex
     {
         if( p != nullptr )
             ma_index_destroy( p );
+    }
+    std::vector<const ma_index*> all( ) const
+    {
+        std::vector<const ma_index*> v( 1, p );
+        for( const auto& pR : vReplicas )
+            v.push_back( pR->p );
+        return v;
     }
 };
 
@@ -261,6 +271,19 @@ inline std::shared_ptr<DeviceIndex> attachIndex( const std::shared_ptr<libMA::Pa
     xEntry.pOwner = std::shared_ptr<const void>( pPack, pPack.get( ) );
     rReg.xByObject[ pPack.get( ) ] = xEntry;
     return pDev;
+}
+// One more copy of an attached index on every device of vDevices (one process drives all GPUs of the node; the
+// reference's graph copies use the whole node the same way, export.cpp:99-126, module.h:303-369).  Call it after attachIndex,
+// before the PrefetchReader is constructed:
+//     ma_amd::replicateIndex( ma_amd::attachIndex( pPack, pFMIndex ), { 1, 2, 3, 4, 5, 6, 7 } );
+inline void replicateIndex( const std::shared_ptr<DeviceIndex>& pDev, const std::vector<int>& vDevices )
+{
+    for( ma_index* pCopy : engine::replicateOnDevices( pDev->p, vDevices ) )
+    {
+        auto pNew = std::make_shared<DeviceIndex>( );
+        pNew->p = pCopy;
+        pDev->vReplicas.push_back( pNew );
+    }
 }
 // Frees the device copy once the last module that holds it lets go (call when the genome is unloaded; a genome that is
 // unloaded without it is dropped from the registry the next time its address is looked up or reused).
@@ -530,7 +553,7 @@ template <typename... TP_ARGS> class PrefetchReader : public libMS::Module<libMA
 
   public:
     PrefetchReader( const ::ParameterSetManager& rParameters, std::shared_ptr<TP_SOURCE> pSource, std::shared_ptr<libMA::FMIndex> pFMIndex )
-        : pSource( pSource ), pDev( deviceIndexOf( pFMIndex.get( ) ) ), xQueue( pDev->p, paramsOf( rParameters ), withQueues( options( ).xPrefetch ) )
+        : pSource( pSource ), pDev( deviceIndexOf( pFMIndex.get( ) ) ), xQueue( pDev->all( ), paramsOf( rParameters ), withQueues( options( ).xPrefetch ) )
     {}
     // nullptr = the wrapped reader is exhausted and every read it gave has been handed out (module.h:688-695)
     virtual std::shared_ptr<libMA::NucSeq> execute( std::shared_ptr<TP_ARGS>... pArgs ) override

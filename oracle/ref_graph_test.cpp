@@ -294,7 +294,13 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     xParams.getSelected( )->xEmulateNgmlrTags->set( ( iOptions & 4 ) != 0 );
     const auto xGpu = parseStages( sStages );
     if( !xGpu.empty( ) )
-        ma_amd::attachIndex( idx.pPack, idx.pFM );
+    {
+        auto pDev = ma_amd::attachIndex( idx.pPack, idx.pFM );
+        // MA_TEST_REPLICAS=<n>: n - 1 further copies of the index ("virtual shards" on device 0); the prefetching reader
+        // rotates its device batches over them, the graph is the same
+        if( getenv( "MA_TEST_REPLICAS" ) && atoi( getenv( "MA_TEST_REPLICAS" ) ) > 1 && pDev->vReplicas.empty( ) )
+            ma_amd::replicateIndex( pDev, std::vector<int>( (size_t)atoi( getenv( "MA_TEST_REPLICAS" ) ) - 1, 0 ) );
+    }
     // all five on the GPU: the intermediate containers only pass the ticket on; a mixed chain needs their content
     ma_amd::options( ).xBatcher.bStages = xGpu.size( ) != 5;
     Stages S( xParams, xGpu, uiSeed );

@@ -12,6 +12,11 @@
 //                         the reference's modules one at a time
 //   socs                  pops every read's SoC queue and writes the SOC records of the common dump format
 //   multi <shards>        MultiDeviceAligner over <shards> index replicas on device 0 (virtual shards)
+//   multiflat <shards>    MultiDeviceAligner::executeFlat over <shards> virtual shards, run TWICE: the second run must not
+//                         create an engine (persistent engines) and must give the same records
+// MA_TEST_REPLICAS=<n>: n - 1 further copies of the index are attached to the FMIndex / Pack of the graph
+// (libMA::replicateIndex, "virtual shards" on device 0): prefetch, batchgraph and the BatchAligner forms then rotate their
+// device batches over n replicas while the graph stays as it is.
 #include "../../ma_amd/host/ma_batch_nodes.h"
 #include "../../oracle/dump_format.h"
 #include <atomic>
@@ -306,12 +311,57 @@ static int runMulti( const CaseFile& c, const ParameterSetManager& xParams, std:
     for( size_t i = 0; i < c.reads.size( ); i++ )
         writeRecords( f, i, *( *pQueries )[ i ], *( *pRes )[ i ], nullptr );
     fclose( f );
-    size_t uiReads = 0;
+    size_t uiReads = 0, uiBatches = 0, uiShardsUsed = 0;
     for( auto& t : xAligner.vLast )
-        uiReads += t.uiReads;
-    printf( "{\"shards\": %d, \"reads\": %zu, \"device_batches_shard0\": %llu}\n", iShards, uiReads,
-            (unsigned long long)xAligner.vLast[ 0 ].uiBatches );
+        uiReads += t.uiReads, uiBatches += t.uiBatches, uiShardsUsed += t.uiBatches != 0;
+    printf( "{\"shards\": %d, \"reads\": %zu, \"device_batches\": %zu, \"shards_used\": %zu}\n", iShards, uiReads, uiBatches, uiShardsUsed );
     return 0;
+}
+
+// MultiDeviceAligner::executeFlat (persistent engines): two runs, records of the second one
+static int runMultiFlat( const CaseFile& c, const ParameterSetManager& xParams, std::shared_ptr<Pack> pPackC, std::shared_ptr<FMIndex> pFmC,
+                         const char* sOut, int iShards )
+{
+    auto vReplicas = MultiDeviceAligner::replicate( pFmC, std::vector<int>( (size_t)iShards, 0 ), 0 );
+    MultiDeviceAligner xAligner( xParams, vReplicas );
+    xAligner.uiBatchReads = 37;
+    xAligner.uiInflight = 2;
+    auto pQueries = std::make_shared<ReadVector>( );
+    for( size_t i = 0; i < c.reads.size( ); i++ )
+    {
+        auto pQ = std::make_shared<NucSeq>( );
+        pQ->xCodes = c.reads[ i ];
+        pQ->sName = "r" + std::to_string( i );
+        pQueries->push_back( pQ );
+    }
+    auto pFirst = xAligner.executeFlat( pQueries );
+    const uint64_t uiEnginesAfterFirst = detail::Engine::created( ).load( );
+    const size_t uiBatchesFirst = pFirst->size( );
+    pFirst.reset( );
+    auto pFlat = xAligner.executeFlat( pQueries );
+    const uint64_t uiEnginesAfterSecond = detail::Engine::created( ).load( );
+    FILE* f = fopen( sOut, "w" );
+    size_t uiAt = 0;
+    for( const auto& pBatch : *pFlat )
+    {
+        if( pBatch == nullptr || pBatch->uiFirst != uiAt )
+        {
+            fprintf( stderr, "multiflat: the flat batches are not in input order\n" );
+            return 1;
+        }
+        for( size_t i = 0; i < pBatch->size( ); i++ )
+            writeRecords( f, uiAt + i, *pBatch->read( i ), *pBatch->alignmentsOf( i ), nullptr );
+        uiAt += pBatch->size( );
+    }
+    fclose( f );
+    size_t uiShardsUsed = 0;
+    for( auto& t : xAligner.vLast )
+        uiShardsUsed += t.uiBatches != 0;
+    printf( "{\"shards\": %d, \"reads\": %zu, \"device_batches\": %zu, \"device_batches_first_run\": %zu, \"shards_used\": %zu, "
+            "\"engines_after_first_run\": %llu, \"engines_after_second_run\": %llu}\n",
+            iShards, uiAt, pFlat->size( ), uiBatchesFirst, uiShardsUsed, (unsigned long long)uiEnginesAfterFirst,
+            (unsigned long long)uiEnginesAfterSecond );
+    return uiAt == c.reads.size( ) && uiEnginesAfterFirst == uiEnginesAfterSecond ? 0 : 1;
 }
 
 // The throughput form as graph nodes (ma_batch_nodes.h): BatchFileReader (a FASTQ text of the case's reads on an in-memory
@@ -395,6 +445,9 @@ int main( int argc, char** argv )
         fprintf( stderr, "error: %s\n", e.what( ) );
         return 1;
     }
+    if( const char* e = getenv( "MA_TEST_REPLICAS" ) ) // virtual shards attached to the graph's one index (see the header)
+        if( atoi( e ) > 1 )
+            replicateIndex( pFmC->pDev, std::vector<int>( (size_t)atoi( e ) - 1, 0 ) );
     const std::string sMode = argc >= 5 ? argv[ 4 ] : "";
     if( sMode == "nogpu" )
     {
@@ -411,6 +464,8 @@ int main( int argc, char** argv )
             return runSocs( c, xParams, pPackC, pFmC, argv[ 3 ] );
         if( sMode == "multi" )
             return runMulti( c, xParams, pPackC, pFmC, argv[ 3 ], argc >= 6 ? atoi( argv[ 5 ] ) : 2 );
+        if( sMode == "multiflat" )
+            return runMultiFlat( c, xParams, pPackC, pFmC, argv[ 3 ], argc >= 6 ? atoi( argv[ 5 ] ) : 2 );
         if( sMode == "batchgraph" )
             return runBatchGraph( c, xParams, pPackC, pFmC, argv[ 3 ], argc >= 6 ? atoi( argv[ 5 ] ) : 2, argc >= 7 ? (size_t)atoi( argv[ 6 ] ) : 50,
                                   argc >= 8 ? atoi( argv[ 7 ] ) : 0 );

@@ -151,6 +151,21 @@ def test_prefetching_reader_in_the_reference_graph_writes_the_reference_sam(tmp_
 
 
 @pytest.mark.gpu
+def test_prefetching_reader_over_index_replicas_in_the_reference_graph(tmp_path, gpu_device):
+    """VERDICT r4 item 1(b) on the reference's REAL types: ma_amd::replicateIndex attaches two more copies of the index (virtual
+    shards on device 0; one per GPU on a node) to the attached Pack / FMIndex pair, the prefetching reader rotates its device
+    batches over the three, the reference's graph, modules' wiring and FileWriter are untouched: the reference's SAM records."""
+    exe = build_exe()
+    sam = str(tmp_path / "ahead.sam")
+    env = dict(os.environ, MA_PREFETCH_BATCH="23", MA_TEST_REPLICAS="3")
+    stats = json.loads(subprocess.check_output([exe, "sam", small_case(tmp_path), "default", "1", sam, "all", "6", "8"], env=env).decode())
+    want = gzip.open(os.path.join(G, "small_ref.default.opt0.sam.gz"), "rt").read()
+    assert sorted(open(sam).read().splitlines()) == sorted(want.splitlines())
+    assert stats["device_batches"] == 0 and stats["prefetched_reads"] == stats["reads"]
+    assert stats["prefetched_batches"] == (stats["reads"] + 22) // 23
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("threads,batch", [(1, 50), (8, 100000)])
 def test_prefetching_reader_around_the_references_own_filereader(tmp_path, gpu_device, threads, batch):
     """The line INTEGRATION.md adds at export.cpp:83, literally: ma_amd::PrefetchReader<FileStream> around the reference's OWN
