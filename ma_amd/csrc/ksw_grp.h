@@ -1,0 +1,603 @@
+// ksw_grp.h -- SEVERAL short extension jobs per wavefront (round 5).
+//
+// The extension kernel of ksw_ext.h gives every job a whole wavefront: 128 cells per diagonal, of which a job with a query
+// of q bases uses at most q.  68 % of the extension jobs of a 150 bp batch have q + 2 <= 64 (the read ends a seed left over),
+// and for those most of the per-job cost is not even the diagonals but the job itself: descriptor, sequences, state
+// initialisation, back-trace, result record (profiles/r04_ext_pairing_bound.txt: 25.7 % of the kernel's time).  Here a
+// wavefront takes G = 2 or 4 jobs at once -- a GROUP of 64 / G lanes (= 128 / G cells) each -- and runs them in lock-step:
+// the diagonal number r is wave-uniform, everything else that belongs to a job lives in VGPRs, equal in all lanes of its group.
+//
+// Layout.  ksw_ext.h keeps the TARGET position t of a cell fixed in its lane and lets the query flow through the lanes, which
+// needs a ring (cells that left the band are recycled for cells further up the target).  A short job knows its live cells in
+// advance: the band never cuts the rectangle (qlen <= w + 1), so on diagonal r the live cells are the query rows
+// j = 0 .. qlen-1 with 0 <= t = r - j <= tlen - 1.  Cell (t, j) therefore lives in half (j & 1) of lane (j >> 1) of its group
+// for the whole job: the QUERY stays put, the target flows through the lanes, and nothing is ever recycled.
+// In kswcpp's arrays (indexed by t) cell (t, j) reads x, v, x2 of cell (t-1, j) -- the SAME lane here -- and u, y, y2 of cell
+// (t, j-1) -- the previous lane: three DPP shifts (+ the target base) per diagonal instead of five, none of them circular.
+//   first row (j = -1):    the group's first lane takes u = first-row initialisation of cell t = r, y = -q-e, y2 = -q2-e2
+//                          (kswcpp_core.h:562-585) and target base r out of a 2 x CJ byte ring in LDS
+//   first column (t = -1): v = first-column initialisation of row j, x = -q-e, x2 = -q2-e2 and the boundary score H(-1, j) are
+//                          the lanes' initial state and stay until the cell is born (commit under the live mask)
+// H(t, j) = H(t-1, j) + u(t, j) needs no shift at all.
+//
+// What is computed is what ksw_ext.h computes (its header: the callers read max, max_q, max_t and the cigar only; every cell
+// of the regime is a true DP cell; early stop of ksw_reg.h), with the same packed int8-in-int16 arithmetic and tags.  The
+// position of a maximum follows calcMaxScore (kswcpp_core.h:156-299) class by class, evaluated lazily on the lanes' H of the
+// last raise, which stays in a register per lane.  A job that would leave the regime (r > w), or whose cigar outgrows its LDS
+// buffer, is handed back to the exact kernel like ksw_ext.h does.
+#pragma once
+#include "ksw_ext.h"
+
+#if defined( __HIPCC__ )
+namespace ma
+{
+#define KSW_GRP_STAGE_ROWS 32 // direction rows (128 B each) the back-trace stages in LDS at a time
+#define KSW_GRP_CIG_WORDS 256 // cigar words in LDS per wavefront (shared by its G groups)
+#define KSW_GRP_ROWS 516 // direction rows of a wavefront's scratch: a job leaves the regime at r > w, w <= 512
+#define KSW_GRP_LDS ( KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4 + 256 + 64 )
+
+// cells of a job's group for G jobs per wavefront
+MA_HD i32 ksw_grp_cells( int G )
+{
+    return 128 / G;
+}
+// jobs per wavefront this job can share a wavefront with (0: not a job for this kernel).  Same regime as ksw_ext_slots,
+// extension jobs only (a global job's time is its set-up, and its callers read another cell).
+MA_HD int ksw_grp_size( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag )
+{
+    if( !( flag & KSW_EZ_EXTZ_ONLY ) || w > 512 || ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag ) != 1 )
+        return 0;
+    if( zdrop > 16000 )
+        return 0; // the z-drop threshold is kept as a packed int16
+    return qlen <= 32 ? 4 : ( qlen <= 64 ? 2 : 0 );
+}
+
+template <int LANES> __device__ __forceinline__ i32 grp_max_i32( i32 v ) // maximum over the 64 / G lanes of a group, in every lane
+{
+    v = max( v, dpp_ctrl<0x121>( v ) ); // row_ror:1
+    v = max( v, dpp_ctrl<0x122>( v ) );
+    v = max( v, dpp_ctrl<0x124>( v ) );
+    v = max( v, dpp_ctrl<0x128>( v ) );
+    if( LANES == 32 )
+    {
+        auto a = __builtin_amdgcn_permlane16_swap( (u32)v, (u32)v, false, false );
+        v = max( (i32)a[ 0 ], (i32)a[ 1 ] );
+    }
+    return v;
+}
+
+// calcMaxScore (kswcpp_core.h:156-299) of diagonal rr of every group at once, from the lanes' packed H (half lo: row j = 2 l,
+// half hi: row 2 l + 1): the 8 classes (t - st0) mod 8 over the chunks [st0, st0 + nS) keep their first maximum and the chunk
+// base it came from, (H[en0], en0) wins ties, max_t is the largest of the classes' positions (independent horizontal
+// maxima, sic); then the cells [st0 + nS, en0) one by one.  All values are per lane and equal within a group.
+template <int LANES>
+__device__ __forceinline__ void grp_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qlen, i32 tlen, int lane, int l, i32& mH, i32& mT )
+{
+    const i32 st0 = max( 0, rr - qlen + 1 ), en0 = min( rr, tlen - 1 );
+    const u32 ddpk = pk_sub( pk_bcast( rr - st0 ), Jpk ); // t - st0 of the lane's two cells (mod 2^16; dead cells: >= 0x8000 or > en0 - st0)
+    const i32 j0 = rr - en0; // row of cell en0
+    const i32 hv = __builtin_amdgcn_ds_bpermute( ( ( lane - l ) + ( j0 >> 1 ) ) << 2, (i32)Hs );
+    const i32 hEn0 = ( j0 & 1 ) ? ( hv >> 16 ) : ( (i32)( (u32)hv << 16 ) >> 16 );
+    const i32 span = en0 - st0, nS = ( span / 8 ) * 8;
+    const u32 inv = pk_sub( 0xffffffffu, ddpk ); // 0xffff - (t - st0): earlier chunks win ties
+    const i32 lo = (i32)__builtin_amdgcn_perm( Hs, inv, 0x05040100u );
+    const i32 hi = (i32)__builtin_amdgcn_perm( Hs, inv, 0x07060302u );
+    const u32 dLo = ddpk & 0xffffu, dHi = ddpk >> 16;
+    const i32 NONE = (i32)0x80000000;
+    i32 kLo = dLo < (u32)nS ? lo : NONE, kHi = dHi < (u32)nS ? hi : NONE;
+    // lanes with equal (l mod 4) hold the same two classes
+    kLo = max( kLo, dpp_ctrl<0x124>( kLo ) );
+    kHi = max( kHi, dpp_ctrl<0x124>( kHi ) );
+    kLo = max( kLo, dpp_ctrl<0x128>( kLo ) );
+    kHi = max( kHi, dpp_ctrl<0x128>( kHi ) );
+    if( LANES == 32 )
+    {
+        auto a16 = __builtin_amdgcn_permlane16_swap( (u32)kLo, (u32)kLo, false, false );
+        kLo = max( (i32)a16[ 0 ], (i32)a16[ 1 ] );
+        auto b16 = __builtin_amdgcn_permlane16_swap( (u32)kHi, (u32)kHi, false, false );
+        kHi = max( (i32)b16[ 0 ], (i32)b16[ 1 ] );
+    }
+    mH = hEn0, mT = en0;
+    {
+        const i32 hl = kLo >> 16, hh = kHi >> 16;
+        const i32 tl = ( kLo != NONE && hl > hEn0 ) ? st0 + ( ( 0xffff - ( kLo & 0xffff ) ) & ~7 ) : en0;
+        const i32 th = ( kHi != NONE && hh > hEn0 ) ? st0 + ( ( 0xffff - ( kHi & 0xffff ) ) & ~7 ) : en0;
+        i32 vh = max( max( kLo != NONE ? hl : hEn0, kHi != NONE ? hh : hEn0 ), hEn0 ), vt = max( tl, th );
+        vh = max( vh, dpp_ctrl<0xB1>( vh ) ); // the four lanes of a quad hold the eight classes
+        vt = max( vt, dpp_ctrl<0xB1>( vt ) );
+        vh = max( vh, dpp_ctrl<0x4E>( vh ) );
+        vt = max( vt, dpp_ctrl<0x4E>( vt ) );
+        if( nS > 0 )
+            mH = vh, mT = vt;
+    }
+    // the cells after the 8-lane part, in the order the reference visits them: the first of the largest wins, if it is larger
+    const i32 tLo = ( dLo >= (u32)nS && dLo < (u32)span ) ? lo : NONE, tHi = ( dHi >= (u32)nS && dHi < (u32)span ) ? hi : NONE;
+    const i32 tk = grp_max_i32<LANES>( max( tLo, tHi ) );
+    if( tk != NONE && ( tk >> 16 ) > mH )
+    {
+        mH = tk >> 16;
+        mT = st0 + ( 0xffff - ( tk & 0xffff ) );
+    }
+}
+
+// One set of up to G jobs (queue entries [at0, min(at0 + G, n))), all of them left- (LEFT) or right-aligned extensions.
+// redo / nRedo: the hand-back list of the extension kernels.
+template <int G, bool LEFT, typename FETCH>
+__device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* list, u32 n, u32 at0, uint8_t* P /*KSW_GRP_ROWS x 128 B*/,
+                             uint8_t* lds, const KswOut& O, KswWaveAcc& acc, u32* redo, unsigned int* nRedo, unsigned long long* sOff )
+{
+    constexpr int LANES = 64 / G, CJ = 128 / G;
+    const int lane = threadIdx.x & 63, g = lane / LANES, l = lane % LANES;
+    uint8_t* stage = lds; // KSW_GRP_STAGE_ROWS x 128
+    u32* cigLds = (u32*)( lds + KSW_GRP_STAGE_ROWS * 128 ); // KSW_GRP_CIG_WORDS, CIGCAP per group
+    uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // G x 2 CJ bytes = 256
+    i32* gflag = (i32*)( tring + 256 ); // per group: scratch words
+    constexpr u32 CIGCAP = KSW_GRP_CIG_WORDS / G;
+    // ---- the group's job
+    const bool has = at0 + (u32)g < n;
+    const u32 slot = list[ has ? at0 + g : at0 ];
+    const KswJobView J = F.view( slot );
+    const i32 qlen = J.qlen, tlen = J.tlen, w = J.w, zdrop = J.zdrop;
+    auto qf = F.qfetch( slot );
+    auto tf = F.tfetch( slot );
+    typedef decltype( tf ) TF;
+    // ---- scoring (as ksw_ext_core)
+    int8_t q = (int8_t)SC.q, e = (int8_t)SC.e, q2 = (int8_t)SC.q2, e2 = (int8_t)SC.e2;
+    const i32 sc_mch = (int8_t)( SC.match < 0 ? -SC.match : SC.match );
+    const i32 sc_mis = (int8_t)( SC.mismatch > 0 ? -SC.mismatch : SC.mismatch );
+    const i32 qe0 = q + e;
+    if( q2 + e2 < q + e )
+    {
+        int8_t t = q;
+        q = q2;
+        q2 = t;
+        t = e;
+        e = e2;
+        e2 = t;
+    }
+    const bool untouched = -( sc_mis < 0 ? sc_mis : 0 ) > 2 * ( q + e ); // kswcpp returns an untouched ez (kswcpp_core.h:340-341)
+    i32 long_thres = e != e2 ? ( q2 - q ) / ( e - e2 ) - 1 : 0;
+    if( q2 + e2 + long_thres * e2 > q + e + long_thres * e )
+        ++long_thres;
+    const i32 long_diff = long_thres * ( e - e2 ) - ( q2 - q ) - e2;
+    auto initOf = [ & ]( i32 r ) -> i32 {
+        return (int8_t)( r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2 );
+    };
+    auto hBoundary = [ & ]( i32 nn ) -> i32 { // H(nn-1, -1) = H(-1, nn-1) (ksw_ext.h)
+        const i32 a = max( 0, min( nn, long_thres ) - 1 );
+        const i32 hs = long_thres >= 1 && long_thres < nn ? 1 : 0;
+        const i32 rest = ( nn - 1 ) - a - hs;
+        return ( q + e ) - qe0 + ( nn < 1 ? 0 : -( q + e ) - e * a + ( hs ? long_diff : 0 ) - e2 * rest );
+    };
+    constexpr u32 tS = LEFT ? 4 : 0, tX = LEFT ? 3 : 1, tY = 2, tX2 = LEFT ? 1 : 3, tY2 = 0;
+    const u32 K_X0 = pk_val( -q - e, tX ), K_Y0 = pk_val( -q - e, tY ), K_X20 = pk_val( -q2 - e2, tX2 ), K_Y20 = pk_val( -q2 - e2, tY2 );
+    const u32 K_TX = pk_val( 0, tX ), K_TY = pk_val( 0, tY ), K_TX2 = pk_val( 0, tX2 ), K_TY2 = pk_val( 0, tY2 );
+    const u32 K_FX = pk_sub( K_TX, LEFT ? 0u : 0x00010001u ), K_FY = pk_sub( K_TY, LEFT ? 0u : 0x00010001u ),
+              K_FX2 = pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ), K_FY2 = pk_sub( K_TY2, LEFT ? 0u : 0x00010001u );
+    const u32 K_NEG = 0x80008000u, K_MATCH = pk_bcast( sc_mch );
+    const u32 V_CLIP = pk_opaque( pk_val( sc_mch, 0xff ) );
+    const u32 V_SCLO = pk_opaque( ( (u32)sc_mch & 0xffu ) | ( ( (u32)sc_mis & 0xffu ) * 0x01010100u ) );
+    const u32 V_SCHI = pk_opaque( ( (u32)( -e2 ) & 0xffu ) | tS << 8 );
+    const u32 V_Q = pk_opaque( pk_val( q, 0 ) ), V_Q2 = pk_opaque( pk_val( q2, 0 ) ), V_QE = pk_opaque( pk_val( q + e, 0 ) ),
+              V_QE2 = pk_opaque( pk_val( q2 + e2, 0 ) );
+    const u32 M_LEADLO = l == 0 ? 0x0000ffffu : 0u; // the cell that takes the first-row boundary: row 0 of the group
+    // ---- static per lane: rows j = 2 l, 2 l + 1
+    const i32 j0 = 2 * l, j1 = 2 * l + 1;
+    const u32 Jpk = (u32)j0 | (u32)j1 << 16;
+    u32 Jmask = ( has && !untouched && j0 < qlen ? 0x0000ffffu : 0u ) | ( has && !untouched && j1 < qlen ? 0xffff0000u : 0u ); // rows of the job (cleared when it ends)
+    const u32 QLpk = pk_sub( pk_bcast( qlen - 1 ), Jpk ); // rows left below the cell
+    u32 Qb = ( j0 < qlen ? (u32)qf( j0 ) & 0xffu : 4u ) | ( j1 < qlen ? (u32)qf( j1 ) & 0xffu : 4u ) << 16;
+    auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t + 1 (codes as in ksw_ext.h: an N of the target is 12)
+        if( t >= tlen )
+            return 0u;
+        u32 ab = tf.pair( t ) & ( t + 1 < tlen ? 0x00ff00ffu : 0x000000ffu );
+        if( TF::CLEAN )
+            return ab;
+        const u32 nn = pk_lshr( ab, 2 );
+        return pk_bfi( pk_sub( 0u, pk_minu( nn, 0x00010001u ) ), 0x000c000cu, ab );
+    };
+    // the group's target ring: bytes t mod 2 CJ; all of it now, CJ bytes more every CJ diagonals
+    uint8_t* myRing = tring + g * ( 2 * CJ );
+    auto fillRing = [ & ]( i32 tFrom ) { // cells tFrom + 2 l, tFrom + 2 l + 1
+        const i32 t = tFrom + 2 * l;
+        const u32 ab = has ? tgt2( t ) : 0u;
+        *(uint16_t*)( myRing + ( t & ( 2 * CJ - 1 ) ) ) = (uint16_t)( ( ab & 0xffu ) | ( ab >> 8 & 0xff00u ) );
+    };
+    fillRing( 0 );
+    fillRing( CJ );
+    u32 V = ( ( (u32)initOf( j0 ) & 0xffu ) << 8 ) | ( ( (u32)initOf( j1 ) & 0xffu ) << 24 ); // first-column v of the rows
+    u32 X = K_X0, X2 = K_X20, U = 0, Y = K_Y0, Y2 = K_Y20, T = 0;
+    u32 H = ( (u32)hBoundary( j0 + 1 ) & 0xffffu ) | (u32)hBoundary( j1 + 1 ) << 16; // H(-1, j)
+    u32 Tpk = pk_sub( 0u, Jpk ); // t = r - j of the lane's cells
+    const u32 tlenpk = pk_bcast( tlen );
+    // ---- per group (equal in all lanes of the group)
+    i32 ezmax = 0, maxT = -1, maxQ = -1, pR = 0, zdropped = 0;
+    u32 snapH = 0;
+    bool pend = false, handBack = false;
+    bool active = has && !untouched;
+    i32 boundPrev = 0x7fffffff, nextBound = 0;
+    const i32 boundRate = max( 1, ( -sc_mis + sc_mch + 1 ) / 2 );
+    const i32 nDiag = qlen + tlen - 1;
+    i32 rLast = -1; // last diagonal the job computed
+    const bool zd = zdrop >= 0;
+    uint8_t* prow = P + g * CJ + 2 * l;
+    i32 uInS = initOf( 0 ); // first-row initialisation of cell t = r (wave-uniform: the scoring is)
+    __syncthreads( );
+    i32 r = 0;
+    for( ; __any( active ); ++r )
+    {
+        // ---- a job ends before this diagonal: all diagonals done, or it leaves the regime and is handed back
+        if( active && ( r >= nDiag || r > w ) )
+        {
+            handBack = r < nDiag;
+            rLast = r - 1;
+            active = false;
+            Jmask = 0;
+        }
+        if( !__any( active ) ) // (wave-uniform: no lane leaves the loop before the others)
+            break;
+        if( __builtin_expect( r <= long_thres + 1, 0 ) )
+            uInS = initOf( r );
+        if( __builtin_expect( r != 0 && ( r & ( CJ - 1 ) ) == 0, 0 ) )
+        {
+            fillRing( r + CJ );
+            __syncthreads( );
+        }
+        // ---- neighbours: u, y, y2 and the target base come from row j - 1
+        const u32 tIn = (u32)myRing[ r & ( 2 * CJ - 1 ) ];
+        u32 ut = cells_shift1( U, (u32)dpp_wave_shr1( (i32)U ) );
+        u32 yt = cells_shift1( Y, (u32)dpp_wave_shr1( (i32)Y ) );
+        u32 y2t = cells_shift1( Y2, (u32)dpp_wave_shr1( (i32)Y2 ) );
+        u32 tt = cells_shift1( T, (u32)dpp_wave_shr1( (i32)T ) );
+        ut = pk_bfi( M_LEADLO, ( (u32)uInS & 0xffu ) << 8, ut );
+        yt = pk_bfi( M_LEADLO, K_Y0, yt );
+        y2t = pk_bfi( M_LEADLO, K_Y20, y2t );
+        tt = pk_bfi( M_LEADLO, tIn, tt );
+        // ---- live cells: 0 <= t <= tlen - 1 on a row of the job
+        const u32 LM = pk_opaque( pk_nonzero15( pk_subsatu( tlenpk, Tpk ) ) & Jmask );
+        // ---- score and DP cell (kswcpp_core.h:598-766; ksw_ext.h)
+        const u32 sel = ( pk_minu( tt ^ Qb, 0x00040004u ) << 8 ) | 0x00050005u;
+        u32 z = __builtin_amdgcn_perm( V_SCHI, V_SCLO, sel );
+        u32 a = pk_add( X, V );
+        u32 b = pk_add( yt, ut );
+        u32 a2 = pk_add( X2, V );
+        u32 b2 = pk_add( y2t, ut );
+        u32 d;
+        if( LEFT )
+        {
+            z = pk_max( pk_max( z, a ), pk_max( pk_max( b, a2 ), b2 ) );
+            d = pk_sub( 0x00040004u, z & 0x00070007u );
+        }
+        else
+        {
+            z = pk_max( pk_max( z, a ), pk_max( b, a2 ) );
+            d = z & 0x00070007u;
+            z = pk_max( z, b2 );
+        }
+        const u32 zc = pk_min( z, V_CLIP ) & 0xff00ff00u;
+        const u32 nu = pk_sub( zc, V ), nv = pk_sub( zc, ut );
+        u32 tmp = pk_sub( zc, V_Q );
+        a = pk_sub( a, tmp );
+        b = pk_sub( b, tmp );
+        tmp = pk_sub( zc, V_Q2 );
+        a2 = pk_sub( a2, tmp );
+        b2 = pk_sub( b2, tmp );
+        const u32 nx = pk_sub( pk_max( a, K_TX ), V_QE ), ny = pk_sub( pk_max( b, K_TY ), V_QE );
+        const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), V_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), V_QE2 );
+        const u32 fa = pk_sub( K_FX, a ), fb = pk_sub( K_FY, b ), fa2 = pk_sub( K_FX2, a2 ), fb2 = pk_sub( K_FY2, b2 );
+        d = and_or( fa >> 12, 0x00080008u, and_or( fb >> 11, 0x00100010u, and_or( fa2 >> 10, 0x00200020u, and_or( fb2 >> 9, 0x00400040u, d ) ) ) );
+        // ---- commit: the row's own v, x, x2 keep their first-column initialisation until the cell is born
+        U = nu;
+        Y = ny;
+        Y2 = ny2;
+        T = tt;
+        V = pk_bfi( LM, nv, V );
+        X = pk_bfi( LM, nx, X );
+        X2 = pk_bfi( LM, nx2, X2 );
+        if( LM )
+            *(uint16_t*)( prow + (size_t)r * 128 ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
+        // ---- H(t, j) = H(t-1, j) + u(t, j)
+        const u32 hn = pk_add( H, pk_ashr8( nu ) );
+        H = pk_bfi( LM, hn, H );
+        const u32 Hm = pk_bfi( LM, hn, K_NEG );
+        Tpk = pk_add( Tpk, 0x00010001u );
+        // ---- a larger maximum: the value now, its position when somebody asks (ksw_ext.h)
+        const u32 ezpk = pk_bcast( ezmax );
+        const bool above = pk_max( Hm, ezpk ) != ezpk;
+        bool raise = false;
+        if( __any( above ) )
+        {
+            const i32 gm = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
+            raise = gm > ezmax;
+            if( raise )
+            {
+                ezmax = gm;
+                snapH = H;
+                pR = r;
+                pend = true;
+            }
+        }
+        // ---- z-drop candidates: every cell below ez.max - zdrop - 1 (kswcpp_core.h:22-44); rare
+        if( zd )
+        {
+            const u32 tpk = pk_bcast( ezmax - zdrop - 1 );
+            const unsigned long long m = __ballot( pk_max( Hm, tpk ) != tpk );
+            const bool cand = active && !raise && ( ( m >> ( g * LANES ) ) & ( LANES == 32 ? 0xffffffffull : 0xffffull ) ) == 0;
+            if( __builtin_expect( __any( cand ) != 0, 0 ) )
+            {
+                i32 mH, mT;
+                grp_exact_max<LANES>( H, Jpk, r, qlen, tlen, lane, l, mH, mT );
+                i32 pH, pT;
+                grp_exact_max<LANES>( snapH, Jpk, pR, qlen, tlen, lane, l, pH, pT );
+                if( pend && cand )
+                {
+                    maxT = pT;
+                    maxQ = pR - pT;
+                    pend = false;
+                }
+                if( cand && mT >= maxT && r - mT >= maxQ )
+                {
+                    const i32 tl = mT - maxT, ql = ( r - mT ) - maxQ;
+                    const i32 dl = tl > ql ? tl - ql : ql - tl;
+                    if( ezmax - mH > zdrop + dl * e2 )
+                    {
+                        zdropped = 1;
+                        rLast = r;
+                        active = false;
+                        Jmask = 0;
+                    }
+                }
+            }
+        }
+        // ---- early stop (ksw_reg.h; schedule as in ksw_ext.h, evaluated for every job that may whenever one is due)
+        const bool mayBound = active && !raise && r >= qlen - 1;
+        if( __any( mayBound && r >= nextBound ) )
+        {
+            const u32 pot = pk_min( QLpk, pk_sub( tlenpk, Tpk ) ); // min( rows left, columns left ): Tpk is t + 1 by now
+            const u32 bnd = pk_mad( pot, K_MATCH, H );
+            const u32 bm = pk_bfi( LM, bnd, K_NEG );
+            const i32 bound = grp_max_i32<LANES>( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
+            const i32 top = hBoundary( r ) + sc_mch * qlen;
+            if( mayBound )
+            {
+                const i32 all = max( max( bound, boundPrev ), top );
+                if( r >= qlen && all <= ezmax )
+                {
+                    rLast = r;
+                    active = false;
+                    Jmask = 0;
+                }
+                else if( boundPrev != 0x7fffffff && r >= qlen )
+                {
+                    nextBound = r + 1 + max( 0, ( max( bound, top ) - ezmax ) / boundRate - 1 );
+                    boundPrev = 0x7fffffff;
+                }
+                else
+                    boundPrev = bound;
+            }
+            else
+                boundPrev = 0x7fffffff;
+        }
+        else
+            boundPrev = 0x7fffffff;
+    }
+    if( active )
+        rLast = r - 1;
+    // ---- position of the last raise
+    {
+        i32 pH, pT;
+        grp_exact_max<LANES>( snapH, Jpk, pR, qlen, tlen, lane, l, pH, pT );
+        if( pend )
+        {
+            maxT = pT;
+            maxQ = pR - pT;
+        }
+    }
+    __syncthreads( ); // direction bytes visible to the back-trace
+    // ---- back-trace (ksw_backtrack__, kswcpp_core.h:76-150; inside the regime the path stays in the rectangle): one lane per
+    // job walks, all lanes stage the rows it is about to cross into LDS.  Cell (t, j) of diagonal r = t + j: byte g CJ + j of row r.
+    const bool leader = l == 0 && has && !handBack && !untouched && maxT >= 0 && maxQ >= 0;
+    u32* myCig = cigLds + g * CIGCAP;
+    u32 nCig = 0, curOp = 3, curLen = 0, steps = 0;
+    bool cigOver = false;
+    i32 bi = leader ? maxT : -1, bj = leader ? maxQ : -1, state = 0;
+    auto pushRun = [ & ]( u32 op, u32 len ) {
+        if( op == curOp )
+            curLen += len;
+        else
+        {
+            if( curLen )
+            {
+                if( nCig < CIGCAP )
+                    myCig[ nCig ] = curLen << 4 | curOp;
+                else
+                    cigOver = true;
+                nCig++;
+            }
+            curOp = op;
+            curLen = len;
+        }
+    };
+    while( true )
+    {
+        const bool walking = bi >= 0 && bj >= 0;
+        if( !__any( walking ) )
+            break;
+        // rows [rlo, rhi]: the highest diagonal any walker stands on, KSW_GRP_STAGE_ROWS rows down
+        i32 rhi = walking ? bi + bj : -1;
+        rhi = wave_max_i32( rhi );
+        const i32 rlo = max( 0, rhi - KSW_GRP_STAGE_ROWS + 1 );
+        __syncthreads( );
+        for( i32 k = lane * 16; k < ( rhi - rlo + 1 ) * 128; k += 1024 )
+            *(uint4*)( stage + k ) = *(const uint4*)( P + (size_t)rlo * 128 + k );
+        __syncthreads( );
+        while( bi >= 0 && bj >= 0 && bi + bj >= rlo )
+        {
+            const u32 tb = stage[ ( bi + bj - rlo ) * 128 + g * CJ + bj ];
+            if( state != 0 && !( ( tb >> ( state + 2 ) ) & 1 ) )
+                state = 0;
+            if( state == 0 )
+                state = tb & 7;
+            const u32 op = state == 0 ? 0u : ( ( state == 1 || state == 3 ) ? 2u : 1u );
+            steps++;
+            pushRun( op, 1 );
+            bi -= op != 1u ? 1 : 0;
+            bj -= op != 2u ? 1 : 0;
+        }
+    }
+    if( leader )
+    {
+        if( bi >= 0 )
+            pushRun( 2, (u32)( bi + 1 ) );
+        if( bj >= 0 )
+            pushRun( 1, (u32)( bj + 1 ) );
+        if( curLen )
+        {
+            if( nCig < CIGCAP )
+                myCig[ nCig ] = curLen << 4 | curOp;
+            else
+                cigOver = true;
+            nCig++;
+        }
+    }
+    // ---- publish: one pool reservation for the set, every group copies its cigar
+    // (leader's values -> all lanes of the group)
+    gflag[ g ] = 0;
+    __syncthreads( );
+    if( l == 0 )
+        gflag[ g ] = (i32)( cigOver ? 0x40000000u : nCig );
+    __syncthreads( );
+    const u32 gw = (u32)gflag[ g ];
+    const bool over = ( gw & 0x40000000u ) != 0;
+    const u32 myN = over ? 0u : gw;
+    const bool publish = has && !handBack && !over;
+    u32 total = 0, before = 0;
+#pragma unroll
+    for( int k = 0; k < G; k++ )
+    {
+        const u32 v = (u32)gflag[ k ];
+        const u32 c = ( v & 0x40000000u ) ? 0u : v;
+        const bool pub = (u32)__builtin_amdgcn_readlane( (i32)( publish ? 1 : 0 ), k * LANES ) != 0;
+        if( k < g )
+            before += pub ? c : 0u;
+        total += pub ? c : 0u;
+    }
+    total = (u32)__builtin_amdgcn_readfirstlane( (i32)total );
+    u64 off0;
+    if( O.cig_chunk == 0 || total > O.cig_chunk )
+    {
+        if( threadIdx.x == 0 )
+            *sOff = atomicAdd( O.cig_used, (unsigned long long)total );
+        __syncthreads( );
+        off0 = *sOff;
+        __syncthreads( );
+    }
+    else
+    {
+        if( total > acc.chunk_left )
+        {
+            if( threadIdx.x == 0 )
+                *sOff = atomicAdd( O.cig_used, (unsigned long long)O.cig_chunk );
+            __syncthreads( );
+            acc.chunk_off = *sOff;
+            acc.chunk_left = O.cig_chunk;
+            __syncthreads( );
+        }
+        off0 = acc.chunk_off;
+        acc.chunk_off += total;
+        acc.chunk_left -= total;
+    }
+    const u64 off = off0 + before;
+    const bool fits = off + myN <= O.cig_pool_cap;
+    // cells the job computed: sum over r = 0 .. rLast of min( r, tlen - 1 ) - max( 0, r - qlen + 1 ) + 1
+    u64 cellsJob = 0;
+    if( has && rLast >= 0 )
+    {
+        const i64 R = rLast, a = tlen - 1, bq = qlen - 1;
+        const i64 s1 = R <= a ? R * ( R + 1 ) / 2 : a * ( a + 1 ) / 2 + ( R - a ) * a;
+        const i64 s2 = R <= bq ? 0 : ( R - bq ) * ( R - bq + 1 ) / 2;
+        cellsJob = (u64)( s1 - s2 + R + 1 );
+    }
+    if( l == 0 && publish )
+    {
+        ma_ez rz;
+        rz.max = untouched ? 0 : ( ezmax & 0x7fffffff );
+        rz.zdropped = zdropped;
+        rz.max_q = maxQ;
+        rz.max_t = maxT;
+        rz.mqe = (i32)0x80000000;
+        rz.mqe_t = -1;
+        rz.mte = (i32)0x80000000;
+        rz.mte_q = -1;
+        rz.score = (i32)0x80000000;
+        rz.reach_end = 0;
+        rz.n_cigar = (i32)myN;
+        O.ez[ slot ] = rz;
+        O.cig_off[ slot ] = off;
+        if( !fits )
+            atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
+    }
+    if( l == 0 && has && ( handBack || over ) )
+        redo[ atomicAdd( nRedo, 1u ) ] = slot;
+    if( publish && fits )
+        for( u32 i = (u32)l; i < myN; i += LANES ) // the walk leaves the cigar reversed (kswcpp_core.h:146-149)
+            O.cig_pool[ off + i ] = ( J.flag & KSW_EZ_REV_CIGAR ) ? myCig[ i ] : myCig[ myN - 1 - i ];
+    // totals of the set -> the wave's accumulators (lane 0 flushes them)
+    {
+        u64 c = l == 0 && publish ? cellsJob : 0, p = l == 0 && publish ? (u64)steps : 0, nj = l == 0 && publish ? 1 : 0, cw = l == 0 && publish ? myN : 0;
+#pragma unroll
+        for( int k = 0; k < G; k++ )
+        {
+            acc.cells += ( (u64)(u32)__builtin_amdgcn_readlane( (i32)( c >> 32 ), k * LANES ) << 32 ) | (u32)__builtin_amdgcn_readlane( (i32)(u32)c, k * LANES );
+            acc.path += (u32)__builtin_amdgcn_readlane( (i32)(u32)p, k * LANES );
+            acc.njobs += (u32)__builtin_amdgcn_readlane( (i32)(u32)nj, k * LANES );
+            acc.cig_words += (u32)__builtin_amdgcn_readlane( (i32)(u32)cw, k * LANES );
+        }
+    }
+    __syncthreads( ); // LDS and the scratch rows are free for the next set
+}
+
+// lists: four consecutive job lists -- G = 2 left / right, G = 4 left / right -- with n[0..3] entries at lists + k * stride;
+// next: four zeroed queue counters.  Every persistent wave works through the lists in this order, a set of G jobs at a time.
+struct KswGrpLists
+{
+    const u32* list[ 4 ];
+    u32 n[ 4 ];
+};
+template <typename FETCH>
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 5 ) ) )
+k_ksw_grp( FETCH F, KswScoring SC, KswGrpLists L, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* redo, unsigned int* nRedo )
+{
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[ KSW_GRP_LDS ];
+    __shared__ u32 sSet;
+    __shared__ unsigned long long sOff;
+    uint8_t* P = scratch + (u64)blockIdx.x * stride;
+    KswWaveAcc acc;
+#pragma unroll
+    for( int k = 0; k < 4; k++ )
+    {
+        const u32 G = k < 2 ? 2u : 4u;
+        const u32 n = L.n[ k ];
+        while( true )
+        {
+            if( threadIdx.x == 0 )
+                sSet = atomicAdd( next + k, G );
+            __syncthreads( );
+            const u32 at0 = sSet;
+            __syncthreads( );
+            if( at0 >= n )
+                break;
+            if( k == 0 )
+                ksw_grp_set<2, true>( F, SC, L.list[ 0 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+            else if( k == 1 )
+                ksw_grp_set<2, false>( F, SC, L.list[ 1 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+            else if( k == 2 )
+                ksw_grp_set<4, true>( F, SC, L.list[ 2 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+            else
+                ksw_grp_set<4, false>( F, SC, L.list[ 3 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+        }
+    }
+    ksw_flush( O, acc );
+}
+} // namespace ma
+#endif

@@ -54,7 +54,9 @@ struct KswWaveAcc
 #define KSW_S1 2
 #define KSW_S2 3
 #define KSW_S3 5
-#define KSW_N_CLASSES 7 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots
+#define KSW_N_CLASSES 11 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots,
+                         // 7..10 short extensions that share a wavefront (ksw_grp.h): 2 per wave left / right, 4 per wave left / right
+#define KSW_CLS_GRP0 7
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
     if( qlen > 150000 )
@@ -62,13 +64,6 @@ MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
     const i32 n = ksw_pk_slots( qlen, tlen, w ); // 128-cell slots of the two-cells-per-lane kernel (ksw_pk.h)
     return n <= KSW_S0 ? 0 : ( n <= KSW_S1 ? 1 : ( n <= KSW_S2 ? 2 : ( n <= KSW_S3 ? 3 : 4 ) ) );
 }
-// pipeline mode: extensions whose callers read only max_q / max_t / cigar go to the extension kernel
-MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag )
-{
-    const int e = ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag );
-    return e ? 4 + e : ksw_job_class( qlen, tlen, w );
-}
-
 // per-wave scratch of one job: direction bytes of the exact kernels (n_col bytes per diagonal) / of the extension kernel
 // (one ring row per diagonal)
 MA_HD u64 ksw_p_bytes( i32 qlen, i32 tlen, i32 w )
@@ -165,6 +160,23 @@ __device__ __forceinline__ bool ksw_next( unsigned int* nextSlot, u32 n, u32& cu
     }
     at = cur++;
     return true;
+}
+
+} // namespace ma
+#include "ksw_grp.h"
+namespace ma
+{
+// MA_KSW_GRP=0 (A/B and test hook) keeps the short extensions on the one-job-per-wavefront kernel.  The switch travels in
+// KswScoring (a kernel argument of everything that classifies jobs), so host and device classify alike.
+#define ksw_grp_enabled( ) ( SC.grp != 0 )
+// pipeline mode: extensions whose callers read only max_q / max_t / cigar go to the extension kernel
+MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag )
+{
+    const int e = ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag );
+    if( e == 1 && ksw_grp_enabled( ) )
+        if( const int G = ksw_grp_size( SC, qlen, tlen, w, zdrop, flag ) )
+            return KSW_CLS_GRP0 + ( G == 4 ? 2 : 0 ) + ( ( flag & KSW_EZ_RIGHT ) ? 1 : 0 );
+    return e ? 4 + e : ksw_job_class( qlen, tlen, w );
 }
 
 // job source of a launch: mode 0 = list[0..n), 1 = every slot 0..n that is valid and of class cls,
@@ -376,14 +388,19 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, KswJobs J
     ksw_flush( O, acc );
 }
 
+inline i32 ksw_grp_env( ) // KswScoring::grp (read on every call: the tests switch it inside one process)
+{
+    const char* e = getenv( "MA_KSW_GRP" );
+    return e ? ( atoi( e ) != 0 ? 1 : 0 ) : 1;
+}
 // sizes for a job population (host side)
 struct KswSizing
 {
     u64 state = 0, h = 0, p = 0, cig = 0;
     u64 qlen = 0; // longest query (LDS bytes of the register kernels)
-    u64 cls[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0 }; // jobs per class
-    u64 pc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0 }; // largest direction-byte scratch of a job, per class (0: use p)
-    u64 cigc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0 }; // largest cigar scratch in words, per class (0: use cig)
+    u64 cls[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // jobs per class
+    u64 pc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // largest direction-byte scratch of a job, per class (0: use p)
+    u64 cigc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // largest cigar scratch in words, per class (0: use cig)
     u64 pRedo = 0, cigRedo = 0; // the same for jobs the extension kernel hands back to the exact kernels (0: use p / cig)
 };
 inline void ksw_size_job( KswSizing& S, i32 qlen, i32 tlen, i32 w )
@@ -441,7 +458,8 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
     return P;
 }
 
-// Launches every class that has jobs.  `next` = 12 zeroed counters (one per launch), `nextBig` = 4 more.  `lists`
+// Launches every class that has jobs.  `next` = 16 zeroed counters (one per launch; [11..14]: the four lists of k_ksw_grp),
+// `nextBig` = 4 more.  `lists`
 // (device, or null) holds the job slots of class k at lists + k * list_stride, SZ.cls[k] entries, and room for the jobs
 // the extension kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every
 // launch scans nSlots and there are no extension-kernel classes.
@@ -515,7 +533,8 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         nJobs += SZ.cls[ k ];
     if( nJobs == 0 )
         return 0;
-    const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ];
+    const u64 nGrp = SZ.cls[ 7 ] + SZ.cls[ 8 ] + SZ.cls[ 9 ] + SZ.cls[ 10 ];
+    const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ] + nGrp;
     const bool conc = side && side->ready( ) && lists; // classes on their own streams
     u64 perCu = 32; // waves per CU of the persistent ksw launches (MA_KSW_WAVES_PER_CU: tuning hook)
     if( const char* e = getenv( "MA_KSW_WAVES_PER_CU" ) )
@@ -524,17 +543,24 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     // Concurrent launches each own a scratch region, so each asks only for the waves that can be RESIDENT (registers:
     // k_ksw_pk<1> 74 VGPRs = 6 waves per SIMD, <2> 99, <3> 122, <5> 128 = 4; the extension kernels 7 / 4): a persistent wave
     // beyond that would only start when another one retires and its scratch would sit idle until then.
-    const u64 resident[ KSW_N_CLASSES ] = { 256 * 24, 256 * 16, 256 * 16, 256 * 16, 0, 256 * 28, 256 * 16 };
+    const u64 resident[ 7 ] = { 256 * 24, 256 * 16, 256 * 16, 256 * 16, 0, 256 * 28, 256 * 16 };
     auto wantOf = [ & ]( int k ) { return conc ? std::min<u64>( wantWaves, resident[ k ] ) : wantWaves; };
     // budgets of the scratch regions: lane 0 / 1 / 2 (sequential launches of a lane share its region)
     const u64 B = KSW_SCRATCH_BUDGET; // one reading per call
-    const u64 budgetOf[ KSW_N_CLASSES ] = { conc ? B / 3 : B, conc ? B / 3 : B, conc ? B / 3 : B, conc ? 5 * B / 12 : B, B, conc ? B / 4 : B, conc ? B / 4 : B };
+    const u64 budgetOf[ 7 ] = { conc ? B / 3 : B, conc ? B / 3 : B, conc ? B / 3 : B, conc ? 5 * B / 12 : B, B, conc ? B / 4 : B, conc ? B / 4 : B };
     auto ldsOf = []( u64 qBytes ) { return std::max<u32>( (u32)( ( ( std::min<u64>( qBytes, 150000 + 64 ) + 15 ) / 16 ) * 16 ), KSW_REG_LDS ); };
     // pass 0 launches of the register kernels: classes 0..3 (exact), 5 / 6 (extension); [7..10]: classes 0..3 of the
     // second pass (jobs handed back), [11..14]: the huge tier of classes 0..3
     KswLaunchPlan LP[ 15 ];
     u64 pSplit[ 4 ] = { 0, 0, 0, 0 };
-    for( int k = 0; k < KSW_N_CLASSES; k++ )
+    // k_ksw_grp: fixed scratch per wave (KSW_GRP_ROWS direction rows; the cigars stay in LDS), 5 waves per SIMD
+    KswLaunchPlan LG;
+    if( nGrp )
+    {
+        const u64 sets = ( SZ.cls[ 7 ] + 1 ) / 2 + ( SZ.cls[ 8 ] + 1 ) / 2 + ( SZ.cls[ 9 ] + 3 ) / 4 + ( SZ.cls[ 10 ] + 3 ) / 4;
+        LG = ksw_plan_launch( (u64)KSW_GRP_ROWS * 128, 0, sets, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
+    }
+    for( int k = 0; k < 7; k++ )
     {
         if( k == 4 || SZ.cls[ k ] == 0 )
             continue;
@@ -606,7 +632,7 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
             return 2;
         return 0;
     };
-    u64 needLane[ 4 ] = { SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0, 0, 0, 0 };
+    u64 needLane[ 4 ] = { std::max<u64>( SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0, LG.stride * LG.waves ), 0, 0, 0 };
     for( int i = 0; i < 15; i++ )
         if( LP[ i ].waves )
             needLane[ laneOf( i ) ] = std::max<u64>( needLane[ laneOf( i ) ], LP[ i ].stride * LP[ i ].waves );
@@ -696,6 +722,17 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( conc )
         for( int k = 3; k >= 0; k-- )
             launchPk( 0, k );
+    if( nGrp ) // the short extensions, several per wavefront (lane 0 of the streams, like the other extension kernels)
+    {
+        KswGrpLists GL;
+        for( int k = 0; k < 4; k++ )
+        {
+            GL.list[ k ] = lists + (u64)( KSW_CLS_GRP0 + k ) * list_stride;
+            GL.n[ k ] = (u32)SZ.cls[ KSW_CLS_GRP0 + k ];
+        }
+        hipLaunchKernelGGL( ( k_ksw_grp<FETCH> ), dim3( LG.waves ), dim3( 64 ), 0, stream, F, SC, GL, next + 11, base + laneBase[ 0 ], LG.stride, O, redo,
+                            nRedo );
+    }
     if( SZ.cls[ 5 ] )
         hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), dim3( LP[ 5 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
                             lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base + laneBase[ 0 ], LP[ 5 ].stride, LP[ 5 ].p_cap, KSW_EXT_LDS,

@@ -26,6 +26,7 @@ static __device__ unsigned long long g_ksw_prof[ 16 ]; // phase cycle counters (
 struct KswScoring
 {
     i32 match, mismatch, q, e, q2, e2; // KswCppParam<5> (kswcpp.h:44-129)
+    i32 grp = 1; // not a score: short extensions may share a wavefront (ksw_grp.h; ksw_job_class_pipe); MA_KSW_GRP=0 clears it
 };
 
 // Working storage of one job (flat pointers: LDS or HBM)

@@ -88,6 +88,7 @@ int ma_dp_batch( ma_batch* b )
     D.lists = b->clsLists.as<u32>( );
     D.list_stride = nSlots;
     D.SC = KswScoring{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
+    D.SC.grp = ksw_grp_env( );
     {
         EvTimer t( b, 3 );
         // zero-fill: a slot is a job iff q_to > q_from (pool regions of dropped sets stay empty)
@@ -122,7 +123,7 @@ int ma_dp_batch( ma_batch* b )
         if( const char* e = getenv( "MA_CIG_POOL_CAP" ) ) // test hook: force a (too) small pool on the first attempt
             if( b->cigPoolMin == 0 )
                 b->cigPoolCap = (u64)std::max( 1, atoi( e ) );
-        KswScoring SC{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
+        const KswScoring SC = D.SC;
         unsigned long long* c = b->ctr.as<unsigned long long>( );
         PipeFetch F{ b->idx->v, b->jobs.as<DpJob>( ), b->d_reads };
         std::unique_lock<std::mutex> xTurn( dp_turn( b->device ), std::defer_lock );

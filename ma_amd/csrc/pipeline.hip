@@ -41,21 +41,21 @@ enum : int
     CTR_N_ALIGNED = 17,
     CTR_SEQ_BYTES = 18, // sum of qlen+tlen over DP jobs
     CTR_PATH_BYTES = 19, // back-trace steps (direction bytes read back)
-    CTR_CLS0 = 20, // DP jobs per kernel class (KSW_N_CLASSES = 7 consecutive words)
-    CTR_MAX_QLEN = 27,
-    CTR_NEXT_SLOTS = 28, // 12 x u32 job queues of the ksw launches (6 words)
-    CTR_N_REDO = 34, // u32: jobs the extension kernel handed back
-    CTR_CIG_WORDS = 35, // cigar words written (CTR_CIG_USED counts pool words reserved)
-    CTR_NEXT_SEED = 36, // queue of k_lf_walk
-    CTR_OPS_ALL = 37, // alignment ops of all alignments / of the MappingQuality selection (exact sizes of the downloads)
-    CTR_OPS_MQ = 38,
-    CTR_ALN_MQ = 39, // alignments MappingQuality keeps
-    CTR_MAX_PC0 = 40, // per kernel class: largest direction-byte scratch of a job (7 words) ...
-    CTR_MAX_CIGC0 = 47, // ... and largest cigar scratch in words (7 words)
-    CTR_MAX_P_REDO = 54, // the same two for the extension kernel's jobs if they are handed back to the exact kernel
-    CTR_MAX_CIG_REDO = 55,
-    CTR_NEXT_BIG = 56, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
-    CTR_COUNT = 58
+    CTR_CLS0 = 20, // DP jobs per kernel class (KSW_N_CLASSES = 11 consecutive words)
+    CTR_MAX_QLEN = 31,
+    CTR_NEXT_SLOTS = 32, // 16 x u32 job queues of the ksw launches (8 words)
+    CTR_N_REDO = 40, // u32: jobs the extension kernels handed back
+    CTR_CIG_WORDS = 41, // cigar words written (CTR_CIG_USED counts pool words reserved)
+    CTR_NEXT_SEED = 42, // queue of k_lf_walk
+    CTR_OPS_ALL = 43, // alignment ops of all alignments / of the MappingQuality selection (exact sizes of the downloads)
+    CTR_OPS_MQ = 44,
+    CTR_ALN_MQ = 45, // alignments MappingQuality keeps
+    CTR_MAX_PC0 = 46, // per kernel class: largest direction-byte scratch of a job (11 words) ...
+    CTR_MAX_CIGC0 = 57, // ... and largest cigar scratch in words (11 words)
+    CTR_MAX_P_REDO = 68, // the same two for the extension kernels' jobs if they are handed back to the exact kernel
+    CTR_MAX_CIG_REDO = 69,
+    CTR_NEXT_BIG = 70, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
+    CTR_COUNT = 72
 };
 
 // ------------------------------------------------------------------------------------------------

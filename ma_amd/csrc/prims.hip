@@ -127,6 +127,7 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     if( n == 0 )
         return 0;
     KswScoring SC{ P->match, P->mismatch, P->gap, P->extend, P->gap2, P->extend2 };
+    SC.grp = ksw_grp_env( );
     KswSizing S;
     for( uint64_t i = 0; i < n; i++ )
         ksw_size_job( S, jobs[ i ].qlen, jobs[ i ].tlen, jobs[ i ].w );
@@ -146,7 +147,7 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
             const int c = ksw_job_class_pipe( SC, ql, tl, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
             lists[ (size_t)c * n + S.cls[ c ]++ ] = (u32)i;
             const u64 pk = ksw_p_bytes( ql, tl, jobs[ i ].w ), cg = (u64)ql + tl + 2;
-            S.pc[ c ] = std::max( S.pc[ c ], c >= 5 ? ksw_ext_p_bytes( ql, tl, c - 4 ) : pk );
+            S.pc[ c ] = std::max( S.pc[ c ], c >= KSW_CLS_GRP0 ? 0 : ( c >= 5 ? ksw_ext_p_bytes( ql, tl, c - 4 ) : pk ) );
             S.cigc[ c ] = std::max( S.cigc[ c ], cg );
             if( c >= 5 )
             {
@@ -161,12 +162,12 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     DevBuf dj, dq, dt, dez, doff, dpool, dscr, dctr;
     if( dj.reserve( n * sizeof( ma_ksw_job ) ) || dq.reserve( q_len + 16 ) || dt.reserve( t_len + 16 ) ||
         dez.reserve( n * sizeof( ma_ez ) ) || doff.reserve( ( n + 1 ) * 8 ) || dpool.reserve( cigar_cap * 4 + 16 ) ||
-        dctr.reserve( 128 ) )
+        dctr.reserve( 256 ) )
         return 1;
     MA_HIP( hipMemcpy( dj.p, jobs, n * sizeof( ma_ksw_job ), hipMemcpyHostToDevice ) );
     MA_HIP( hipMemcpy( dq.p, q_bytes, q_len, hipMemcpyHostToDevice ) );
     MA_HIP( hipMemcpy( dt.p, t_bytes, t_len, hipMemcpyHostToDevice ) );
-    MA_HIP( hipMemset( dctr.p, 0, 128 ) );
+    MA_HIP( hipMemset( dctr.p, 0, 256 ) );
     MA_HIP( hipMemset( dez.p, 0, n * sizeof( ma_ez ) ) );
     MA_HIP( hipMemset( doff.p, 0, ( n + 1 ) * 8 ) );
     KswOut O;
@@ -182,13 +183,13 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     O.path = nullptr;
     O.cig_words = nullptr;
     O.cig_chunk = 0; // dense pool: cigar_off[n] is the total
-    unsigned int* next = (unsigned int*)( ctr + 4 ); // 4 x u32 launch queues
+    unsigned int* next = (unsigned int*)( ctr + 4 ); // 16 x u32 launch queues (ctr[4..11])
     FETCH F;
     F.jobs = dj.as<ma_ksw_job>( );
     F.qb = dq.as<uint8_t>( );
     F.tb = dt.as<uint8_t>( );
     if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0, FETCH::EARLY ? dlists.as<u32>( ) : nullptr, n,
-                     (unsigned int*)( ctr + 11 ), (unsigned int*)( ctr + 12 ) ) )
+                     (unsigned int*)( ctr + 12 ), (unsigned int*)( ctr + 13 ) ) )
         return 1;
     MA_HIP( hipDeviceSynchronize( ) );
     unsigned long long h[ 8 ];

@@ -147,7 +147,8 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                 const i32 ql = (i32)( j.q_to - j.q_from ), tl = (i32)( j.r_to - j.r_from );
                 cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
                 const u64 pk = ksw_p_bytes( ql, tl, j.w );
-                pj = (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 ); // 256-byte units
+                // 256-byte units (the wavefront-sharing classes 7..10 have a fixed scratch per wave: ksw_grp.h)
+                pj = cls >= KSW_CLS_GRP0 ? 0u : (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 );
                 cj = (u32)( ql + tl + 2 );
                 if( cls >= 5 )
                 {

@@ -209,3 +209,71 @@ def test_eight_ranks_share_one_device_without_starving_the_host(gpu_device):
         one["value"], eight["value"], w8["host_to_host"]["stream_waits"], eight.get("cfs_throttled_150bp")))
     assert eight["value"] >= one["value"] / 1.2, (one["value"], eight["value"])
     assert eight["parity_150bp_h2h"].startswith("0 mismatching")
+
+
+def short_extension_cases(n, seed):
+    """Extension jobs as the pipeline emits them for read ends and dual extensions (needlemanWunsch.cpp:239-622): queries of
+    1..64 bases (the kernel that runs several jobs per wavefront, ksw_grp.h, takes qlen <= 64), targets from shorter than the
+    query to query + 1000 padded bases, band 512, z-drop 200 (or small: it must fire), left-aligned or right-aligned with a
+    reversed cigar; the query is a noisy copy of the target's head, a copy with a gap, junk, a tandem repeat, or holds Ns."""
+    from ma_testlib import KSW_EXTZ, KSW_REV, KSW_RIGHT
+    rng = np.random.default_rng(seed)
+    cases = []
+    for k in range(n):
+        ql = int(rng.choice([1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64])) if rng.random() < 0.3 else int(rng.integers(1, 65))
+        kind = rng.random()
+        tl = int(rng.choice([1, 2, ql, ql + 1, max(1, ql - 3), ql + 40, ql + 500, ql + 1000]))
+        t = rng.integers(0, 4, size=tl, dtype=np.uint8)
+        if kind < 0.12:  # tandem repeat: late maxima are plausible
+            unit = rng.integers(0, 4, size=int(rng.integers(1, 7)), dtype=np.uint8)
+            t = np.tile(unit, tl // len(unit) + 1)[:tl].copy()
+        if kind < 0.75:
+            q = np.resize(t, ql).copy() if tl < ql else t[:ql].copy()
+            er = rng.choice([0.0, 0.02, 0.08, 0.2, 0.4])
+            mut = rng.random(ql) < er
+            q[mut] = (q[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) % 4
+            if rng.random() < 0.4 and ql > 8:  # an indel
+                p = int(rng.integers(2, ql - 2))
+                g = int(rng.integers(1, 12))
+                q = np.concatenate([q[:p], q[p + g:]]) if rng.random() < 0.5 else np.concatenate([q[:p], rng.integers(0, 4, size=g, dtype=np.uint8), q[p:]])
+                q = q[:64] if len(q) else t[:1].copy()
+            if rng.random() < 0.3:  # the match starts after a bad first base (a seed ended there)
+                q[0] = (q[0] + 1) % 4
+        else:
+            q = rng.integers(0, 4, size=ql, dtype=np.uint8)  # junk: lives until the early stop proves it dead
+        if rng.random() < 0.1:
+            q = q.copy()
+            q[rng.random(len(q)) < 0.2] = 4  # N
+        zd = int(rng.choice([200, 200, 200, 30, 10, 3]))
+        fl = KSW_EXTZ if rng.random() < 0.5 else (KSW_EXTZ | KSW_RIGHT | KSW_REV)
+        cases.append((np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(t, dtype=np.uint8), 512, zd, fl))
+    return cases
+
+
+@pytest.mark.parametrize("scoring", [None, (3, 5, 6, 3, 30, 2), (1, 3, 5, 2, 24, 1), (2, 4, 12, 1, 6, 3)])
+def test_short_extensions_that_share_a_wavefront(gpu_device, scoring, monkeypatch):
+    """ksw_grp.h: 2 or 4 short extension jobs per wavefront.  What the callers read -- max, max_q, max_t
+    and the cigar (needlemanWunsch.cpp:239-622) -- against the oracle's kswcpp (every diagonal, kswcpp_core.h:308-879) and
+    against the one-job-per-wavefront kernels (MA_KSW_GRP=0), incl. z-drops, Ns, ragged last sets and a swapped gap model."""
+    import ma_amd
+    from ma_testlib import or_ksw
+    P = ma_amd.Params.preset("default")
+    op = or_params("default", 1)
+    if scoring is not None:
+        for prm in (P, op):
+            prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
+    for n, seed in ((3001, 5), (7, 6), (1, 7), (2, 8)):
+        cases = short_extension_cases(n, seed + (0 if scoring is None else scoring[0]))
+        monkeypatch.setenv("MA_KSW_GRP", "1")
+        ez, cigs = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
+        monkeypatch.setenv("MA_KSW_GRP", "0")
+        ez0, cigs0 = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
+        for i, (q, t, w, zd, fl) in enumerate(cases):
+            oez, ocig = or_ksw(op, q, t, w, zd, fl)
+            what = "case %d (qlen %d tlen %d zdrop %d flag %#x)" % (i, len(q), len(t), zd, fl)
+            for f in ("max", "max_q", "max_t"):
+                assert int(ez[f][i]) == int(oez[f]), "%s: %s = %d, oracle %d, one job per wave %d" % (what, f, int(ez[f][i]), int(oez[f]), int(ez0[f][i]))
+                assert int(ez0[f][i]) == int(oez[f]), what
+            assert np.array_equal(cigs[i], ocig), "%s: cigar %s, oracle %s" % (what, cigs[i].tolist(), ocig.tolist())
+            assert np.array_equal(cigs0[i], ocig), what
+    monkeypatch.delenv("MA_KSW_GRP")
