@@ -349,16 +349,17 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
                 }
             }
         }
-        // ---- early stop (ksw_reg.h; schedule as in ksw_ext.h, evaluated for every job that may whenever one is due)
-        const bool mayBound = active && !raise && r >= qlen - 1;
-        if( __any( mayBound && r >= nextBound ) )
+        // ---- early stop (ksw_reg.h; every job on the schedule of ksw_ext.h -- its OWN schedule: evaluating a job whenever a
+        // neighbour is due would be as exact, but a job's executed cells would then depend on the jobs it shares a wave with)
+        const bool due = active && !raise && r >= qlen - 1 && r >= nextBound;
+        if( __any( due ) )
         {
             const u32 pot = pk_min( QLpk, pk_sub( tlenpk, Tpk ) ); // min( rows left, columns left ): Tpk is t + 1 by now
             const u32 bnd = pk_mad( pot, K_MATCH, H );
             const u32 bm = pk_bfi( LM, bnd, K_NEG );
             const i32 bound = grp_max_i32<LANES>( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
             const i32 top = hBoundary( r ) + sc_mch * qlen;
-            if( mayBound )
+            if( due )
             {
                 const i32 all = max( max( bound, boundPrev ), top );
                 if( r >= qlen && all <= ezmax )

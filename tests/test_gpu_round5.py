@@ -277,3 +277,44 @@ def test_short_extensions_that_share_a_wavefront(gpu_device, scoring, monkeypatc
             assert np.array_equal(cigs[i], ocig), "%s: cigar %s, oracle %s" % (what, cigs[i].tolist(), ocig.tolist())
             assert np.array_equal(cigs0[i], ocig), what
     monkeypatch.delenv("MA_KSW_GRP")
+
+
+@pytest.mark.parametrize("slots", [1, 2, 3, 5])
+def test_a_late_n_switches_the_score_profile_of_the_exact_kernel(gpu_device, slots):
+    """ksw_pk.h scores with three instructions per slot while neither sequence holds an N and re-checks the
+    target bases whenever a ring slot is recycled (hasN).  Deterministic cases for the LATE flip: exactly one N in the target
+    beyond the first ring (R x 128 cells), exactly one N in the query's tail, an N at the very last base of either -- for every
+    ring size of k_ksw_pk<1|2|3|5>, left- and right-aligned: every ez field and the cigar against the oracle."""
+    import ma_amd
+    from ma_testlib import KSW_EXTZ, KSW_REV, KSW_RIGHT, or_ksw
+    P = ma_amd.Params.preset("default")
+    op = or_params("default", 1)
+    rng = np.random.default_rng(900 + slots)
+    m = {1: 90, 2: 200, 3: 330, 5: 560}[slots]  # ksw_pk_slots = ceil((min(qlen, tlen, w + 1) + 30) / 128)
+    ring = 128 * slots
+    cases = []
+    for fl in (KSW_EXTZ, KSW_EXTZ | KSW_RIGHT | KSW_REV, 0):
+        for where in ("target_beyond_ring", "query_tail", "target_last", "query_last", "none"):
+            tl = ring + 300 + int(rng.integers(0, 40))
+            t = rng.integers(0, 4, size=tl, dtype=np.uint8)
+            ql = m if fl else tl - int(rng.integers(0, 6))  # global jobs: near-square (the band must reach the corner)
+            q = t[:ql].copy() if ql <= tl else np.resize(t, ql).copy()
+            mut = rng.random(ql) < 0.03
+            q[mut] = (q[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) % 4
+            if where == "target_beyond_ring":
+                t[ring + 17] = 4
+            elif where == "query_tail":
+                q[ql - 7] = 4
+            elif where == "target_last":
+                t[tl - 1] = 4
+            elif where == "query_last":
+                q[ql - 1] = 4
+            w = 512 if fl else max(20, abs(tl - ql) + 10)
+            cases.append((q, t, w, 200 if fl else -1, fl))
+    ez, cigs = ma_amd.ksw_batch(P, cases)
+    for i, (q, t, w, zd, fl) in enumerate(cases):
+        oez, ocig = or_ksw(op, q, t, w, zd, fl)
+        for f in oez.dtype.names:
+            assert int(ez[f][i]) == int(oez[f]), "case %d (qlen %d tlen %d w %d flag %#x) field %s: %d vs oracle %d" % (
+                i, len(q), len(t), w, fl, f, int(ez[f][i]), int(oez[f]))
+        assert np.array_equal(cigs[i], ocig), "case %d cigar" % i
