@@ -28,6 +28,7 @@
 // the reference's namespaces for builds that do not have the reference tree; the two cannot share a translation unit.)
 #pragma once
 #include "ma/container/alignment.h"
+#include "ma/module/fileWriter.h"
 #include "ma/container/fMIndex.h"
 #include "ma/container/nucSeq.h"
 #include "ma/container/pack.h"
@@ -41,6 +42,7 @@
 #include "ma_amd.h"
 #include "ma_engine.h"
 
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -851,6 +853,100 @@ class MappingQuality : public libMS::Module<Alignments, false, libMA::NucSeq, Al
             if( !rKV.second.pOwner.expired( ) )
                 return rKV.second.pDev;
         throw std::runtime_error( "ma_amd::MappingQuality: no index attached (ma_amd::attachIndex)" );
+    }
+};
+// ---- BufferedFileWriter: the reference's FileWriter, its lock taken once per 64 KB instead of once per read ----------------
+// FileWriter::execute formats a read's SAM records outside its lock and appends them under it (fileWriter.cpp:141-145), and
+// its FileOutStream flushes on every append.  With the GPU modules in front of it that lock is what bounds the graph
+// (profiles/r04_binding_graph_rate.txt: 0.8 M reads/s): a graph thread that is descheduled while it holds the lock stalls all
+// the others, and every read pays a write( ).  This subclass keeps the reference's formatter -- every calling thread owns a
+// PRIVATE libMA::FileWriter on an in-memory stream, so the bytes of a read's records are the reference's by construction --
+// and forwards a thread's text to the shared stream under the shared lock when it has uiBufferBytes of it; flush( ) (or the
+// destructor) writes what is left.  The records of one read stay together, the order between threads is as arbitrary as in
+// the reference.  Same template signature and constructors as FileWriter: `std::make_shared<ma_amd::BufferedFileWriter>( rParameters,
+// sFileName, pPack )` replaces `std::make_shared<FileWriter>( ... )` at export.cpp:109.  rParameters must outlive the writer.
+class BufferedFileWriter : public libMA::FileWriter
+{
+    struct Collect : public libMA::OutStream
+    {
+        std::string sText;
+        Collect& operator<<( std::string s ) override
+        {
+            sText += s;
+            return *this;
+        }
+    };
+    struct PerThread
+    {
+        std::shared_ptr<Collect> pText;
+        std::unique_ptr<libMA::FileWriter> pFormatter;
+    };
+    const ::ParameterSetManager& rParameters;
+    std::shared_ptr<libMA::Pack> pPackOfHeader;
+    std::mutex xThreadsMutex;
+    std::vector<std::unique_ptr<PerThread>> vThreads; // one per thread that ever called execute( ) on this writer
+    const uint64_t uiId = nextId( );
+    static uint64_t nextId( )
+    {
+        static std::atomic<uint64_t> uiNext{ 1 };
+        return uiNext++;
+    }
+    PerThread& mine( )
+    {
+        static thread_local std::vector<std::pair<uint64_t, PerThread*>> vMine; // by writer id (ids are never reused)
+        for( auto& rEntry : vMine )
+            if( rEntry.first == uiId )
+                return *rEntry.second;
+        std::unique_ptr<PerThread> pNew( new PerThread( ) );
+        pNew->pText = std::make_shared<Collect>( );
+        pNew->pFormatter.reset( new libMA::FileWriter( rParameters, std::static_pointer_cast<libMA::OutStream>( pNew->pText ), pPackOfHeader ) );
+        pNew->pText->sText.clear( ); // the private writer's header: the shared stream has the one the base class wrote
+        std::lock_guard<std::mutex> xGuard( xThreadsMutex );
+        vThreads.push_back( std::move( pNew ) );
+        vMine.emplace_back( uiId, vThreads.back( ).get( ) );
+        return *vThreads.back( );
+    }
+    void forward( std::string& rText )
+    {
+        if( rText.empty( ) )
+            return;
+        {
+            std::lock_guard<std::mutex> xGuard( *pLock );
+            *pOut << rText;
+        }
+        rText.clear( );
+    }
+
+  public:
+    size_t uiBufferBytes = 1u << 16;
+
+    BufferedFileWriter( const ::ParameterSetManager& rParameters, std::string sFileName, std::shared_ptr<libMA::Pack> pPackContainer )
+        : libMA::FileWriter( rParameters, sFileName, pPackContainer ), rParameters( rParameters ), pPackOfHeader( pPackContainer )
+    {}
+    BufferedFileWriter( const ::ParameterSetManager& rParameters, std::shared_ptr<libMA::OutStream> pOut,
+                        std::shared_ptr<libMA::Pack> pPackContainer )
+        : libMA::FileWriter( rParameters, pOut, pPackContainer ), rParameters( rParameters ), pPackOfHeader( pPackContainer )
+    {}
+    ~BufferedFileWriter( )
+    {
+        flush( );
+    }
+    virtual std::shared_ptr<libMS::Container> execute( std::shared_ptr<libMA::NucSeq> pQuery, std::shared_ptr<Alignments> pAlignments,
+                                                       std::shared_ptr<libMA::Pack> pPack ) override
+    {
+        PerThread& rMine = mine( );
+        auto pRet = rMine.pFormatter->execute( pQuery, pAlignments, pPack ); // the reference's formatting, into this thread's text
+        if( rMine.pText->sText.size( ) >= uiBufferBytes )
+            forward( rMine.pText->sText );
+        return pRet;
+    }
+    // writes what the threads' buffers still hold; call it (from one thread) when the graph threads are done and before the
+    // stream is read or closed
+    void flush( )
+    {
+        std::lock_guard<std::mutex> xGuard( xThreadsMutex );
+        for( auto& pThread : vThreads )
+            forward( pThread->pText->sText );
     }
 };
 } // namespace ma_amd

@@ -307,7 +307,13 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     if( xGpu.count( "harm" ) == 0 && uiThreads > 1 )
         throw std::runtime_error( "the reference's Harmonization draws from the process-wide rand(): one thread only" );
     FILE* f = fopen( sOut, "w" );
-    auto pWriter = std::make_shared<FileWriter>( xParams, std::make_shared<CaptureStream>( f ), idx.pPack );
+    // option 16: the reference's FileWriter with its lock taken once per 64 KB (ma_amd::BufferedFileWriter); same bytes per read
+    std::shared_ptr<FileWriter> pWriter;
+    std::shared_ptr<ma_amd::BufferedFileWriter> pBuffered;
+    if( ( iOptions & 16 ) != 0 )
+        pWriter = pBuffered = std::make_shared<ma_amd::BufferedFileWriter>( xParams, std::make_shared<CaptureStream>( f ), idx.pPack );
+    else
+        pWriter = std::make_shared<FileWriter>( xParams, std::make_shared<CaptureStream>( f ), idx.pPack );
     auto pSource = std::make_shared<CaseSource>( c );
     auto pCast = std::make_shared<Cast<SuffixArrayInterface, FMIndex>>( xParams );
     auto pPack = std::make_shared<Pledge<Pack>>( );
@@ -368,6 +374,8 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     } );
     const auto tGraph = std::chrono::steady_clock::now( );
     BasePledge::simultaneousGet( aSinks, []( ) { return true; }, uiThreads );
+    if( pBuffered != nullptr )
+        pBuffered->flush( ); // (inside the timed region: what the threads' buffers still hold)
     const double fGraphSeconds = std::chrono::duration<double>( std::chrono::steady_clock::now( ) - tGraph ).count( );
     fclose( f );
     uint64_t uiBatches = 0, uiReads = 0;
