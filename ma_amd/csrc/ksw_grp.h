@@ -31,6 +31,15 @@
 #if defined( __HIPCC__ )
 namespace ma
 {
+#if defined( MA_KSW_PROF )
+// diagnostics build: wave cycles per phase of k_ksw_grp, by jobs per wave G (index 8 * log2 G + phase): 0 set-up (descriptors,
+// sequences, state), 1 diagonal loop, 2 position + back-trace, 3 publish, 4 diagonals run, 5 sets, 6 jobs, 7 sum of the jobs'
+// OWN diagonals (what the loop would run with perfectly matched sets = phase 4 x G)
+static __device__ unsigned long long g_grp_prof[ 24 ];
+#define GRP_PROF_T( v ) const unsigned long long v = clock64( )
+#else
+#define GRP_PROF_T( v )
+#endif
 #define KSW_GRP_STAGE_ROWS 32 // direction rows (128 B each) the back-trace stages in LDS at a time
 #define KSW_GRP_CIG_WORDS 256 // cigar words in LDS per wavefront (shared by its G groups)
 #define KSW_GRP_ROWS 516 // direction rows of a wavefront's scratch: a job leaves the regime at r > w, w <= 512
@@ -49,7 +58,7 @@ MA_HD int ksw_grp_size( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdr
         return 0;
     if( zdrop > 16000 )
         return 0; // the z-drop threshold is kept as a packed int16
-    return qlen <= 32 ? 4 : ( qlen <= 64 ? 2 : 0 );
+    return qlen <= 32 ? 4 : ( qlen <= 64 ? 2 : ( qlen <= 128 && SC.grp >= 2 ? 1 : 0 ) ); // (one job per wave in this layout: MA_KSW_GRP=2, A/B)
 }
 
 template <int LANES> __device__ __forceinline__ i32 grp_max_i32( i32 v ) // maximum over the 64 / G lanes of a group, in every lane
@@ -58,9 +67,14 @@ template <int LANES> __device__ __forceinline__ i32 grp_max_i32( i32 v ) // maxi
     v = max( v, dpp_ctrl<0x122>( v ) );
     v = max( v, dpp_ctrl<0x124>( v ) );
     v = max( v, dpp_ctrl<0x128>( v ) );
-    if( LANES == 32 )
+    if( LANES >= 32 )
     {
         auto a = __builtin_amdgcn_permlane16_swap( (u32)v, (u32)v, false, false );
+        v = max( (i32)a[ 0 ], (i32)a[ 1 ] );
+    }
+    if( LANES == 64 )
+    {
+        auto a = __builtin_amdgcn_permlane32_swap( (u32)v, (u32)v, false, false );
         v = max( (i32)a[ 0 ], (i32)a[ 1 ] );
     }
     return v;
@@ -90,12 +104,19 @@ __device__ __forceinline__ void grp_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qlen
     kHi = max( kHi, dpp_ctrl<0x124>( kHi ) );
     kLo = max( kLo, dpp_ctrl<0x128>( kLo ) );
     kHi = max( kHi, dpp_ctrl<0x128>( kHi ) );
-    if( LANES == 32 )
+    if( LANES >= 32 )
     {
         auto a16 = __builtin_amdgcn_permlane16_swap( (u32)kLo, (u32)kLo, false, false );
         kLo = max( (i32)a16[ 0 ], (i32)a16[ 1 ] );
         auto b16 = __builtin_amdgcn_permlane16_swap( (u32)kHi, (u32)kHi, false, false );
         kHi = max( (i32)b16[ 0 ], (i32)b16[ 1 ] );
+    }
+    if( LANES == 64 )
+    {
+        auto a32 = __builtin_amdgcn_permlane32_swap( (u32)kLo, (u32)kLo, false, false );
+        kLo = max( (i32)a32[ 0 ], (i32)a32[ 1 ] );
+        auto b32 = __builtin_amdgcn_permlane32_swap( (u32)kHi, (u32)kHi, false, false );
+        kHi = max( (i32)b32[ 0 ], (i32)b32[ 1 ] );
     }
     mH = hEn0, mT = en0;
     {
@@ -128,6 +149,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
 {
     constexpr int LANES = 64 / G, CJ = 128 / G;
     const int lane = threadIdx.x & 63, g = lane / LANES, l = lane % LANES;
+    GRP_PROF_T( tp0 );
     uint8_t* stage = lds; // KSW_GRP_STAGE_ROWS x 128
     u32* cigLds = (u32*)( lds + KSW_GRP_STAGE_ROWS * 128 ); // KSW_GRP_CIG_WORDS, CIGCAP per group
     uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // G x 2 CJ bytes = 256
@@ -223,6 +245,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     uint8_t* prow = P + g * CJ + 2 * l;
     i32 uInS = initOf( 0 ); // first-row initialisation of cell t = r (wave-uniform: the scoring is)
     __syncthreads( );
+    GRP_PROF_T( tp1 );
     i32 r = 0;
     for( ; __any( active ); ++r )
     {
@@ -322,7 +345,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         {
             const u32 tpk = pk_bcast( ezmax - zdrop - 1 );
             const unsigned long long m = __ballot( pk_max( Hm, tpk ) != tpk );
-            const bool cand = active && !raise && ( ( m >> ( g * LANES ) ) & ( LANES == 32 ? 0xffffffffull : 0xffffull ) ) == 0;
+            const bool cand = active && !raise && ( ( m >> ( ( g * LANES ) & 63 ) ) & ( LANES == 64 ? ~0ull : ( ( 1ull << ( LANES & 63 ) ) - 1 ) ) ) == 0;
             if( __builtin_expect( __any( cand ) != 0, 0 ) )
             {
                 i32 mH, mT;
@@ -384,6 +407,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     }
     if( active )
         rLast = r - 1;
+    GRP_PROF_T( tp2 );
     // ---- position of the last raise
     {
         i32 pH, pT;
@@ -461,6 +485,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             nCig++;
         }
     }
+    GRP_PROF_T( tp3 );
     // ---- publish: one pool reservation for the set, every group copies its cigar
     // (leader's values -> all lanes of the group)
     gflag[ g ] = 0;
@@ -556,14 +581,39 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         }
     }
     __syncthreads( ); // LDS and the scratch rows are free for the next set
+#if defined( MA_KSW_PROF )
+    {
+        const unsigned long long tp4 = clock64( );
+        u32 own = l == 0 && has ? (u32)( rLast + 1 ) : 0u, nj = l == 0 && has ? 1u : 0u, ownAll = 0, njAll = 0;
+        for( int k = 0; k < G; k++ )
+        {
+            ownAll += (u32)__builtin_amdgcn_readlane( (i32)own, k * LANES );
+            njAll += (u32)__builtin_amdgcn_readlane( (i32)nj, k * LANES );
+        }
+        if( threadIdx.x == 0 )
+        {
+            unsigned long long* pf = g_grp_prof + 8 * ( G == 1 ? 0 : ( G == 2 ? 1 : 2 ) );
+            atomicAdd( pf + 0, tp1 - tp0 );
+            atomicAdd( pf + 1, tp2 - tp1 );
+            atomicAdd( pf + 2, tp3 - tp2 );
+            atomicAdd( pf + 3, tp4 - tp3 );
+            atomicAdd( pf + 4, (unsigned long long)r );
+            atomicAdd( pf + 5, 1ull );
+            atomicAdd( pf + 6, (unsigned long long)njAll );
+            atomicAdd( pf + 7, (unsigned long long)ownAll );
+        }
+    }
+#endif
 }
 
-// lists: four consecutive job lists -- G = 2 left / right, G = 4 left / right -- with n[0..3] entries at lists + k * stride;
-// next: four zeroed queue counters.  Every persistent wave works through the lists in this order, a set of G jobs at a time.
+// lists: six consecutive job lists -- G = 1 left / right (MA_KSW_GRP=2 only), G = 2 left / right, G = 4 left / right -- with
+// n[0..5] entries; next: six zeroed queue counters.  Every persistent wave works through the lists in this order (longest jobs
+// first), a set of G jobs at a time.
+#define KSW_GRP_LISTS 6
 struct KswGrpLists
 {
-    const u32* list[ 4 ];
-    u32 n[ 4 ];
+    const u32* list[ KSW_GRP_LISTS ];
+    u32 n[ KSW_GRP_LISTS ];
 };
 template <typename FETCH>
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 5 ) ) )
@@ -575,9 +625,9 @@ k_ksw_grp( FETCH F, KswScoring SC, KswGrpLists L, unsigned int* next, uint8_t* s
     uint8_t* P = scratch + (u64)blockIdx.x * stride;
     KswWaveAcc acc;
 #pragma unroll
-    for( int k = 0; k < 4; k++ )
+    for( int k = 0; k < KSW_GRP_LISTS; k++ )
     {
-        const u32 G = k < 2 ? 2u : 4u;
+        const u32 G = k < 2 ? 1u : ( k < 4 ? 2u : 4u );
         const u32 n = L.n[ k ];
         while( true )
         {
@@ -589,13 +639,17 @@ k_ksw_grp( FETCH F, KswScoring SC, KswGrpLists L, unsigned int* next, uint8_t* s
             if( at0 >= n )
                 break;
             if( k == 0 )
-                ksw_grp_set<2, true>( F, SC, L.list[ 0 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+                ksw_grp_set<1, true>( F, SC, L.list[ 0 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
             else if( k == 1 )
-                ksw_grp_set<2, false>( F, SC, L.list[ 1 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+                ksw_grp_set<1, false>( F, SC, L.list[ 1 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
             else if( k == 2 )
-                ksw_grp_set<4, true>( F, SC, L.list[ 2 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+                ksw_grp_set<2, true>( F, SC, L.list[ 2 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+            else if( k == 3 )
+                ksw_grp_set<2, false>( F, SC, L.list[ 3 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+            else if( k == 4 )
+                ksw_grp_set<4, true>( F, SC, L.list[ 4 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
             else
-                ksw_grp_set<4, false>( F, SC, L.list[ 3 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+                ksw_grp_set<4, false>( F, SC, L.list[ 5 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
         }
     }
     ksw_flush( O, acc );

@@ -54,8 +54,8 @@ struct KswWaveAcc
 #define KSW_S1 2
 #define KSW_S2 3
 #define KSW_S3 5
-#define KSW_N_CLASSES 11 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots,
-                         // 7..10 short extensions that share a wavefront (ksw_grp.h): 2 per wave left / right, 4 per wave left / right
+#define KSW_N_CLASSES 13 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots,
+                         // 7..12 the query-stationary extension kernel (ksw_grp.h): 1 (MA_KSW_GRP=2 only) / 2 / 4 jobs per wave, left / right
 #define KSW_CLS_GRP0 7
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
@@ -175,7 +175,7 @@ MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i
     const int e = ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag );
     if( e == 1 && ksw_grp_enabled( ) )
         if( const int G = ksw_grp_size( SC, qlen, tlen, w, zdrop, flag ) )
-            return KSW_CLS_GRP0 + ( G == 4 ? 2 : 0 ) + ( ( flag & KSW_EZ_RIGHT ) ? 1 : 0 );
+            return KSW_CLS_GRP0 + ( G == 4 ? 4 : ( G == 2 ? 2 : 0 ) ) + ( ( flag & KSW_EZ_RIGHT ) ? 1 : 0 );
     return e ? 4 + e : ksw_job_class( qlen, tlen, w );
 }
 
@@ -391,16 +391,16 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, KswJobs J
 inline i32 ksw_grp_env( ) // KswScoring::grp (read on every call: the tests switch it inside one process)
 {
     const char* e = getenv( "MA_KSW_GRP" );
-    return e ? ( atoi( e ) != 0 ? 1 : 0 ) : 1;
+    return e ? std::max( 0, std::min( 2, atoi( e ) ) ) : 1; // 2: also the jobs of 65..128 query bases, one per wave (A/B)
 }
 // sizes for a job population (host side)
 struct KswSizing
 {
     u64 state = 0, h = 0, p = 0, cig = 0;
     u64 qlen = 0; // longest query (LDS bytes of the register kernels)
-    u64 cls[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // jobs per class
-    u64 pc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // largest direction-byte scratch of a job, per class (0: use p)
-    u64 cigc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // largest cigar scratch in words, per class (0: use cig)
+    u64 cls[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // jobs per class
+    u64 pc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // largest direction-byte scratch of a job, per class (0: use p)
+    u64 cigc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // largest cigar scratch in words, per class (0: use cig)
     u64 pRedo = 0, cigRedo = 0; // the same for jobs the extension kernel hands back to the exact kernels (0: use p / cig)
 };
 inline void ksw_size_job( KswSizing& S, i32 qlen, i32 tlen, i32 w )
@@ -458,7 +458,7 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
     return P;
 }
 
-// Launches every class that has jobs.  `next` = 16 zeroed counters (one per launch; [11..14]: the four lists of k_ksw_grp),
+// Launches every class that has jobs.  `next` = 20 zeroed counters (one per launch; [11..16]: the six lists of k_ksw_grp),
 // `nextBig` = 4 more.  `lists`
 // (device, or null) holds the job slots of class k at lists + k * list_stride, SZ.cls[k] entries, and room for the jobs
 // the extension kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every
@@ -533,7 +533,7 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         nJobs += SZ.cls[ k ];
     if( nJobs == 0 )
         return 0;
-    const u64 nGrp = SZ.cls[ 7 ] + SZ.cls[ 8 ] + SZ.cls[ 9 ] + SZ.cls[ 10 ];
+    const u64 nGrp = SZ.cls[ 7 ] + SZ.cls[ 8 ] + SZ.cls[ 9 ] + SZ.cls[ 10 ] + SZ.cls[ 11 ] + SZ.cls[ 12 ];
     const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ] + nGrp;
     const bool conc = side && side->ready( ) && lists; // classes on their own streams
     u64 perCu = 32; // waves per CU of the persistent ksw launches (MA_KSW_WAVES_PER_CU: tuning hook)
@@ -557,7 +557,7 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     KswLaunchPlan LG;
     if( nGrp )
     {
-        const u64 sets = ( SZ.cls[ 7 ] + 1 ) / 2 + ( SZ.cls[ 8 ] + 1 ) / 2 + ( SZ.cls[ 9 ] + 3 ) / 4 + ( SZ.cls[ 10 ] + 3 ) / 4;
+        const u64 sets = SZ.cls[ 7 ] + SZ.cls[ 8 ] + ( SZ.cls[ 9 ] + 1 ) / 2 + ( SZ.cls[ 10 ] + 1 ) / 2 + ( SZ.cls[ 11 ] + 3 ) / 4 + ( SZ.cls[ 12 ] + 3 ) / 4;
         LG = ksw_plan_launch( (u64)KSW_GRP_ROWS * 128, 0, sets, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
     }
     for( int k = 0; k < 7; k++ )
@@ -725,7 +725,7 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( nGrp ) // the short extensions, several per wavefront (lane 0 of the streams, like the other extension kernels)
     {
         KswGrpLists GL;
-        for( int k = 0; k < 4; k++ )
+        for( int k = 0; k < KSW_GRP_LISTS; k++ )
         {
             GL.list[ k ] = lists + (u64)( KSW_CLS_GRP0 + k ) * list_stride;
             GL.n[ k ] = (u32)SZ.cls[ KSW_CLS_GRP0 + k ];

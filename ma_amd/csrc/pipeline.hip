@@ -41,21 +41,21 @@ enum : int
     CTR_N_ALIGNED = 17,
     CTR_SEQ_BYTES = 18, // sum of qlen+tlen over DP jobs
     CTR_PATH_BYTES = 19, // back-trace steps (direction bytes read back)
-    CTR_CLS0 = 20, // DP jobs per kernel class (KSW_N_CLASSES = 11 consecutive words)
-    CTR_MAX_QLEN = 31,
-    CTR_NEXT_SLOTS = 32, // 16 x u32 job queues of the ksw launches (8 words)
-    CTR_N_REDO = 40, // u32: jobs the extension kernels handed back
-    CTR_CIG_WORDS = 41, // cigar words written (CTR_CIG_USED counts pool words reserved)
-    CTR_NEXT_SEED = 42, // queue of k_lf_walk
-    CTR_OPS_ALL = 43, // alignment ops of all alignments / of the MappingQuality selection (exact sizes of the downloads)
-    CTR_OPS_MQ = 44,
-    CTR_ALN_MQ = 45, // alignments MappingQuality keeps
-    CTR_MAX_PC0 = 46, // per kernel class: largest direction-byte scratch of a job (11 words) ...
-    CTR_MAX_CIGC0 = 57, // ... and largest cigar scratch in words (11 words)
-    CTR_MAX_P_REDO = 68, // the same two for the extension kernels' jobs if they are handed back to the exact kernel
-    CTR_MAX_CIG_REDO = 69,
-    CTR_NEXT_BIG = 70, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
-    CTR_COUNT = 72
+    CTR_CLS0 = 20, // DP jobs per kernel class (KSW_N_CLASSES = 13 consecutive words)
+    CTR_MAX_QLEN = 33,
+    CTR_NEXT_SLOTS = 34, // 20 x u32 job queues of the ksw launches (10 words)
+    CTR_N_REDO = 44, // u32: jobs the extension kernels handed back
+    CTR_CIG_WORDS = 45, // cigar words written (CTR_CIG_USED counts pool words reserved)
+    CTR_NEXT_SEED = 46, // queue of k_lf_walk
+    CTR_OPS_ALL = 47, // alignment ops of all alignments / of the MappingQuality selection (exact sizes of the downloads)
+    CTR_OPS_MQ = 48,
+    CTR_ALN_MQ = 49, // alignments MappingQuality keeps
+    CTR_MAX_PC0 = 50, // per kernel class: largest direction-byte scratch of a job (13 words) ...
+    CTR_MAX_CIGC0 = 63, // ... and largest cigar scratch in words (13 words)
+    CTR_MAX_P_REDO = 76, // the same two for the extension kernels' jobs if they are handed back to the exact kernel
+    CTR_MAX_CIG_REDO = 77,
+    CTR_NEXT_BIG = 78, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
+    CTR_COUNT = 80
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -296,11 +296,16 @@ int ma_batch_set_reads( ma_batch* b, const uint8_t* codes, const uint64_t* offse
     return 0;
 }
 
+// longest read of the batch: one atomic per wavefront (a million same-address atomics serialise in L2: 182 us per 1 M reads
+// in profiles/r05_step_timeline_150bp.txt, a per-wave maximum first: a few us)
 __global__ void k_max_qlen( const u64* roff, u64 n, unsigned long long* out )
 {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if( i < n )
-        atomicMax( out, (unsigned long long)( roff[ i + 1 ] - roff[ i ] ) );
+    u32 v = i < n ? (u32)std::min<u64>( roff[ i + 1 ] - roff[ i ], 0xffffffffull ) : 0u;
+    for( int m = 32; m; m >>= 1 )
+        v = max( v, (u32)__shfl_xor( (int)v, m, 64 ) );
+    if( ( threadIdx.x & 63 ) == 0 && v )
+        atomicMax( out, (unsigned long long)v );
 }
 
 int ma_batch_set_reads_device( ma_batch* b, const void* d_codes, const void* d_offsets, uint64_t n, uint64_t n_bases )
@@ -920,6 +925,11 @@ int ma_debug_ksw_prof( unsigned long long* out )
 int ma_debug_pk_prof( unsigned long long* out )
 {
     MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_pk_prof ), 16 * 8 ) );
+    return 0;
+}
+int ma_debug_grp_prof( unsigned long long* out ) // 24 words (ksw_grp.h)
+{
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_grp_prof ), 24 * 8 ) );
     return 0;
 }
 int ma_debug_seed_prof( unsigned long long* out )

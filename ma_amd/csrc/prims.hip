@@ -183,13 +183,13 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     O.path = nullptr;
     O.cig_words = nullptr;
     O.cig_chunk = 0; // dense pool: cigar_off[n] is the total
-    unsigned int* next = (unsigned int*)( ctr + 4 ); // 16 x u32 launch queues (ctr[4..11])
+    unsigned int* next = (unsigned int*)( ctr + 4 ); // 20 x u32 launch queues (ctr[4..13])
     FETCH F;
     F.jobs = dj.as<ma_ksw_job>( );
     F.qb = dq.as<uint8_t>( );
     F.tb = dt.as<uint8_t>( );
     if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0, FETCH::EARLY ? dlists.as<u32>( ) : nullptr, n,
-                     (unsigned int*)( ctr + 12 ), (unsigned int*)( ctr + 13 ) ) )
+                     (unsigned int*)( ctr + 14 ), (unsigned int*)( ctr + 15 ) ) )
         return 1;
     MA_HIP( hipDeviceSynchronize( ) );
     unsigned long long h[ 8 ];

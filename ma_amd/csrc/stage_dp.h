@@ -125,7 +125,9 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
     sink.slot0 = 0;
     if( threadIdx.x < A.lanes && s < A.n_sets )
         dp_enum_one( A, s, sink );
-    u32 pcl[ KSW_N_CLASSES ], cgl[ KSW_N_CLASSES ], pRedo = 0, cgRedo = 0;
+    // per-class scratch sizes: only the classes whose launches are sized by their jobs (the query-stationary classes from
+    // KSW_CLS_GRP0 on have a fixed scratch per wave)
+    u32 pcl[ KSW_CLS_GRP0 ], cgl[ KSW_CLS_GRP0 ], pRedo = 0, cgRedo = 0;
     // append the jobs to the per-class lists: one atomic per wave, class and round instead of one per job
     {
         const u32 mine = sink.n < sink.cap ? sink.n : sink.cap;
@@ -135,7 +137,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
         // needs 27 MB of direction bytes, a gap between two seeds a few KB), and a launch sized for the largest job of
         // the whole batch would leave most of the machine without waves
 #pragma unroll
-        for( int c = 0; c < KSW_N_CLASSES; c++ )
+        for( int c = 0; c < KSW_CLS_GRP0; c++ )
             pcl[ c ] = cgl[ c ] = 0;
         for( u32 k = 0; k < rounds; k++ )
         {
@@ -157,16 +159,20 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                 }
             }
 #pragma unroll
-            for( int c = 0; c < KSW_N_CLASSES; c++ )
-            {
+            for( int c = 0; c < KSW_CLS_GRP0; c++ )
                 if( cls == c )
                 {
                     pcl[ c ] = max( pcl[ c ], pj );
                     cgl[ c ] = max( cgl[ c ], cj );
                 }
+            // one list append per class PRESENT in this round (a wave holds two or three of the 13 classes; a pass over all
+            // of them cost k_dp_enum 1.5 of 2.9 ms when the wavefront-sharing classes were added)
+            unsigned long long todo = __ballot( cls >= 0 );
+            while( todo )
+            {
+                const int c = __builtin_amdgcn_readlane( cls, __ffsll( (long long)todo ) - 1 );
                 const unsigned long long m = __ballot( cls == c );
-                if( m == 0 )
-                    continue;
+                todo &= ~m;
                 const int leader = __ffsll( (long long)m ) - 1;
                 unsigned long long base = 0;
                 if( lane == leader )
@@ -181,9 +187,9 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
     const u64 st = wave_max_u64( sink.mx_state ), h = wave_max_u64( sink.mx_h ), p = wave_max_u64( sink.mx_p );
     const u64 cg = wave_max_u64( sink.mx_cig ), ql = wave_max_u64( sink.mx_qlen );
     const u64 nj = wave_sum_u64( sink.n_jobs ), sb = wave_sum_u64( sink.seq_bytes );
-    u64 pcW[ KSW_N_CLASSES ], cgW[ KSW_N_CLASSES ];
+    u64 pcW[ KSW_CLS_GRP0 ], cgW[ KSW_CLS_GRP0 ];
 #pragma unroll
-    for( int c = 0; c < KSW_N_CLASSES; c++ )
+    for( int c = 0; c < KSW_CLS_GRP0; c++ )
     {
         pcW[ c ] = wave_max_u64( pcl[ c ] );
         cgW[ c ] = wave_max_u64( cgl[ c ] );
@@ -197,7 +203,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
         atomicMax( &A.ctr[ CTR_MAX_CIG ], (unsigned long long)cg );
         atomicMax( &A.ctr[ CTR_MAX_QLEN ], (unsigned long long)ql );
 #pragma unroll
-        for( int c = 0; c < KSW_N_CLASSES; c++ )
+        for( int c = 0; c < KSW_CLS_GRP0; c++ )
         {
             if( pcW[ c ] )
                 atomicMax( &A.ctr[ CTR_MAX_PC0 + c ], (unsigned long long)pcW[ c ] << 8 );

@@ -307,10 +307,10 @@ static int cmdSam( const char* sCase, const char* sPreset, unsigned uiSeed, cons
     if( xGpu.count( "harm" ) == 0 && uiThreads > 1 )
         throw std::runtime_error( "the reference's Harmonization draws from the process-wide rand(): one thread only" );
     FILE* f = fopen( sOut, "w" );
-    // option 16: the reference's FileWriter with its lock taken once per 64 KB (ma_amd::BufferedFileWriter); same bytes per read
+    // option 32: the reference's FileWriter with its lock taken once per 64 KB (ma_amd::BufferedFileWriter); same bytes per read
     std::shared_ptr<FileWriter> pWriter;
     std::shared_ptr<ma_amd::BufferedFileWriter> pBuffered;
-    if( ( iOptions & 16 ) != 0 )
+    if( ( iOptions & 32 ) != 0 )
         pWriter = pBuffered = std::make_shared<ma_amd::BufferedFileWriter>( xParams, std::make_shared<CaptureStream>( f ), idx.pPack );
     else
         pWriter = std::make_shared<FileWriter>( xParams, std::make_shared<CaptureStream>( f ), idx.pPack );

@@ -160,7 +160,7 @@ def test_buffered_file_writer_on_the_references_types_writes_the_reference_sam(t
     exe = build_exe()
     sam = str(tmp_path / "buffered.sam")
     env = dict(os.environ, MA_PREFETCH_BATCH="37")
-    stats = json.loads(subprocess.check_output([exe, "sam", small_case(tmp_path), preset, "1", sam, "all", str(threads), str(8 | 16 | options)], env=env).decode())
+    stats = json.loads(subprocess.check_output([exe, "sam", small_case(tmp_path), preset, "1", sam, "all", str(threads), str(8 | 32 | options)], env=env).decode())
     want = gzip.open(os.path.join(G, "small_ref.%s.opt%d.sam.gz" % (preset, options)), "rt").read()
     got = open(sam).read()
     if threads == 1:

@@ -40,7 +40,7 @@ def main():
             print("ma_amd:: modules + PrefetchReader, %2d graph threads: %10.0f reads/s (%d device batches, %d reads through the funnel)" % (
                 threads, r["reads_per_s"], r["prefetched_batches"], r["reads_in_batches"]))
         for threads in (8, 16, 32):  # the same graph with ma_amd::BufferedFileWriter (the reference's formatter, its lock once per 64 KB)
-            r = run(case, out, "all", threads, 8 | 16, {"MA_PREFETCH_BATCH": "65536"})
+            r = run(case, out, "all", threads, 8 | 32, {"MA_PREFETCH_BATCH": "65536"})
             assert sorted(open(out).read().splitlines()) == want
             print("ma_amd:: modules + PrefetchReader + BufferedFileWriter, %2d graph threads: %10.0f reads/s" % (threads, r["reads_per_s"]))
         for threads in (256, 1024):
