@@ -158,8 +158,13 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     // ---- the group's job
     const bool has = at0 + (u32)g < n;
     const u32 slot = list[ has ? at0 + g : at0 ];
-    const KswJobView J = F.view( slot );
-    const i32 qlen = J.qlen, tlen = J.tlen, w = J.w, zdrop = J.zdrop;
+    i32 qlen, tlen, rEnd, nDiag, zdrop;
+    {
+        const KswJobView J = F.view( slot );
+        qlen = J.qlen, tlen = J.tlen, zdrop = J.zdrop;
+        nDiag = qlen + tlen - 1;
+        rEnd = min( nDiag, J.w + 1 ); // the job ends BEFORE diagonal rEnd: all diagonals done, or r > w (handed back)
+    }
     auto qf = F.qfetch( slot );
     auto tf = F.tfetch( slot );
     typedef decltype( tf ) TF;
@@ -192,22 +197,22 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         return ( q + e ) - qe0 + ( nn < 1 ? 0 : -( q + e ) - e * a + ( hs ? long_diff : 0 ) - e2 * rest );
     };
     constexpr u32 tS = LEFT ? 4 : 0, tX = LEFT ? 3 : 1, tY = 2, tX2 = LEFT ? 1 : 3, tY2 = 0;
+    // (wave-uniform constants: the scoring is the launch's)
     const u32 K_X0 = pk_val( -q - e, tX ), K_Y0 = pk_val( -q - e, tY ), K_X20 = pk_val( -q2 - e2, tX2 ), K_Y20 = pk_val( -q2 - e2, tY2 );
     const u32 K_TX = pk_val( 0, tX ), K_TY = pk_val( 0, tY ), K_TX2 = pk_val( 0, tX2 ), K_TY2 = pk_val( 0, tY2 );
     const u32 K_FX = pk_sub( K_TX, LEFT ? 0u : 0x00010001u ), K_FY = pk_sub( K_TY, LEFT ? 0u : 0x00010001u ),
               K_FX2 = pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ), K_FY2 = pk_sub( K_TY2, LEFT ? 0u : 0x00010001u );
     const u32 K_NEG = 0x80008000u, K_MATCH = pk_bcast( sc_mch );
-    const u32 V_CLIP = pk_opaque( pk_val( sc_mch, 0xff ) );
-    const u32 V_SCLO = pk_opaque( ( (u32)sc_mch & 0xffu ) | ( ( (u32)sc_mis & 0xffu ) * 0x01010100u ) );
-    const u32 V_SCHI = pk_opaque( ( (u32)( -e2 ) & 0xffu ) | tS << 8 );
-    const u32 V_Q = pk_opaque( pk_val( q, 0 ) ), V_Q2 = pk_opaque( pk_val( q2, 0 ) ), V_QE = pk_opaque( pk_val( q + e, 0 ) ),
-              V_QE2 = pk_opaque( pk_val( q2 + e2, 0 ) );
+    const u32 V_CLIP = pk_val( sc_mch, 0xff );
+    const u32 V_SCLO = ( (u32)sc_mch & 0xffu ) | ( ( (u32)sc_mis & 0xffu ) * 0x01010100u );
+    const u32 V_SCHI = ( (u32)( -e2 ) & 0xffu ) | tS << 8;
+    const u32 V_Q = pk_val( q, 0 ), V_Q2 = pk_val( q2, 0 ), V_QE = pk_val( q + e, 0 ), V_QE2 = pk_val( q2 + e2, 0 );
     const u32 M_LEADLO = l == 0 ? 0x0000ffffu : 0u; // the cell that takes the first-row boundary: row 0 of the group
     // ---- static per lane: rows j = 2 l, 2 l + 1
     const i32 j0 = 2 * l, j1 = 2 * l + 1;
     const u32 Jpk = (u32)j0 | (u32)j1 << 16;
-    u32 Jmask = ( has && !untouched && j0 < qlen ? 0x0000ffffu : 0u ) | ( has && !untouched && j1 < qlen ? 0xffff0000u : 0u ); // rows of the job (cleared when it ends)
-    const u32 QLpk = pk_sub( pk_bcast( qlen - 1 ), Jpk ); // rows left below the cell
+    // rows of the job (cleared when it ends: a finished job's cells are dead)
+    u32 Jmask = ( has && !untouched && j0 < qlen ? 0x0000ffffu : 0u ) | ( has && !untouched && j1 < qlen ? 0xffff0000u : 0u );
     u32 Qb = ( j0 < qlen ? (u32)qf( j0 ) & 0xffu : 4u ) | ( j1 < qlen ? (u32)qf( j1 ) & 0xffu : 4u ) << 16;
     auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t + 1 (codes as in ksw_ext.h: an N of the target is 12)
         if( t >= tlen )
@@ -232,32 +237,36 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     u32 H = ( (u32)hBoundary( j0 + 1 ) & 0xffffu ) | (u32)hBoundary( j1 + 1 ) << 16; // H(-1, j)
     u32 Tpk = pk_sub( 0u, Jpk ); // t = r - j of the lane's cells
     const u32 tlenpk = pk_bcast( tlen );
-    // ---- per group (equal in all lanes of the group)
-    i32 ezmax = 0, maxT = -1, maxQ = -1, pR = 0, zdropped = 0;
-    u32 snapH = 0;
-    bool pend = false, handBack = false;
-    bool active = has && !untouched;
+    // ---- per group, equal in all lanes of the group.  Flags are 0 / -1 words, not bools: a bool that lives across the loop is
+    // an exec-style mask pair in SGPRs, and the scalar file is full of the kernel's arguments.
+    i32 ezmax = 0, maxT = -1, maxQ = -1, pR = 0;
+    u32 ezpk = 0, snapH = 0;
+    i32 act = has && !untouched ? -1 : 0, handBack = 0, pend = 0, zdropped = 0;
     i32 boundPrev = 0x7fffffff, nextBound = 0;
     const i32 boundRate = max( 1, ( -sc_mis + sc_mch + 1 ) / 2 );
-    const i32 nDiag = qlen + tlen - 1;
+    const i32 qe = q + e; // the cheaper gap model's opening cost (after the swap): a diagonal's maximum falls by at most this per diagonal
     i32 rLast = -1; // last diagonal the job computed
-    const bool zd = zdrop >= 0;
-    uint8_t* prow = P + g * CJ + 2 * l;
+    // z-drop (kswcpp_core.h:22-44) needs a diagonal whose maximum lies more than zdrop below ez.max.  The maximum of diagonal
+    // r + 1 is at least that of diagonal r minus (q + e): the best cell's right or lower neighbour can always open a gap from it
+    // (the clip of z is an upper bound only).  So after a diagonal with maximum m the test cannot pass for
+    // ( m - (ez.max - zdrop - 1) ) / (q + e) diagonals: a job's next test is scheduled like its next bound evaluation.
+    i32 zNext = zdrop >= 0 ? 0 : 0x7fffffff;
+    const u32 laneOff = (u32)( g * CJ + 2 * l ); // the lane's two bytes of a direction row
     i32 uInS = initOf( 0 ); // first-row initialisation of cell t = r (wave-uniform: the scoring is)
     __syncthreads( );
     GRP_PROF_T( tp1 );
     i32 r = 0;
-    for( ; __any( active ); ++r )
+    for( ;; ++r )
     {
         // ---- a job ends before this diagonal: all diagonals done, or it leaves the regime and is handed back
-        if( active && ( r >= nDiag || r > w ) )
         {
-            handBack = r < nDiag;
-            rLast = r - 1;
-            active = false;
-            Jmask = 0;
+            const i32 ends = r >= rEnd ? act : 0;
+            handBack |= rEnd < nDiag ? ends : 0;
+            rLast = ends ? r - 1 : rLast;
+            act &= ~ends;
+            Jmask &= (u32)~ends;
         }
-        if( !__any( active ) ) // (wave-uniform: no lane leaves the loop before the others)
+        if( !__any( act != 0 ) ) // (wave-uniform: no lane leaves the loop before the others)
             break;
         if( __builtin_expect( r <= long_thres + 1, 0 ) )
             uInS = initOf( r );
@@ -317,36 +326,37 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         V = pk_bfi( LM, nv, V );
         X = pk_bfi( LM, nx, X );
         X2 = pk_bfi( LM, nx2, X2 );
-        if( LM )
-            *(uint16_t*)( prow + (size_t)r * 128 ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
+        if( LM ) // (scalar row base + the lane's constant offset: no 64-bit address per lane)
+            *(uint16_t*)( P + (size_t)r * 128 + laneOff ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
         // ---- H(t, j) = H(t-1, j) + u(t, j)
         const u32 hn = pk_add( H, pk_ashr8( nu ) );
         H = pk_bfi( LM, hn, H );
         const u32 Hm = pk_bfi( LM, hn, K_NEG );
         Tpk = pk_add( Tpk, 0x00010001u );
         // ---- a larger maximum: the value now, its position when somebody asks (ksw_ext.h)
-        const u32 ezpk = pk_bcast( ezmax );
-        const bool above = pk_max( Hm, ezpk ) != ezpk;
-        bool raise = false;
-        if( __any( above ) )
+        i32 raise = 0;
+        if( __any( pk_max( Hm, ezpk ) != ezpk ) )
         {
             const i32 gm = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
-            raise = gm > ezmax;
-            if( raise )
-            {
-                ezmax = gm;
-                snapH = H;
-                pR = r;
-                pend = true;
-            }
+            raise = gm > ezmax ? -1 : 0;
+            ezmax = raise ? gm : ezmax;
+            ezpk = raise ? pk_bcast( gm ) : ezpk;
+            snapH = raise ? H : snapH;
+            pR = raise ? r : pR;
+            pend |= raise;
+            // (the diagonal's maximum IS ez.max now: no z-drop before it has fallen by zdrop + 1)
+            zNext = raise && zdrop >= 0 ? r + ( zdrop + qe ) / qe : zNext;
         }
-        // ---- z-drop candidates: every cell below ez.max - zdrop - 1 (kswcpp_core.h:22-44); rare
-        if( zd )
+        // ---- z-drop, on the job's schedule: rare
+        if( __builtin_expect( __any( ( act & ~raise ) != 0 && r >= zNext ) != 0, 0 ) )
         {
-            const u32 tpk = pk_bcast( ezmax - zdrop - 1 );
-            const unsigned long long m = __ballot( pk_max( Hm, tpk ) != tpk );
-            const bool cand = active && !raise && ( ( m >> ( ( g * LANES ) & 63 ) ) & ( LANES == 64 ? ~0ull : ( ( 1ull << ( LANES & 63 ) ) - 1 ) ) ) == 0;
-            if( __builtin_expect( __any( cand ) != 0, 0 ) )
+            const i32 thr = ezmax - zdrop - 1; // candidates: every cell at or below it
+            const i32 gm = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
+            const bool mine = ( act & ~raise ) != 0 && r >= zNext;
+            const bool cand = mine && gm <= thr;
+            if( mine && !cand )
+                zNext = r + ( gm - thr + qe - 1 ) / qe; // >= r + 1
+            if( __any( cand ) )
             {
                 i32 mH, mT;
                 grp_exact_max<LANES>( H, Jpk, r, qlen, tlen, lane, l, mH, mT );
@@ -356,7 +366,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
                 {
                     maxT = pT;
                     maxQ = pR - pT;
-                    pend = false;
+                    pend = 0;
                 }
                 if( cand && mT >= maxT && r - mT >= maxQ )
                 {
@@ -366,17 +376,20 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
                     {
                         zdropped = 1;
                         rLast = r;
-                        active = false;
+                        act = 0;
                         Jmask = 0;
                     }
                 }
+                if( cand && act )
+                    zNext = r + 1; // every cell is below the threshold already: the test is due on every diagonal from here on
             }
         }
         // ---- early stop (ksw_reg.h; every job on the schedule of ksw_ext.h -- its OWN schedule: evaluating a job whenever a
         // neighbour is due would be as exact, but a job's executed cells would then depend on the jobs it shares a wave with)
-        const bool due = active && !raise && r >= qlen - 1 && r >= nextBound;
+        const bool due = ( act & ~raise ) != 0 && r >= qlen - 1 && r >= nextBound;
         if( __any( due ) )
         {
+            const u32 QLpk = pk_sub( pk_bcast( qlen - 1 ), Jpk ); // rows left below the cell
             const u32 pot = pk_min( QLpk, pk_sub( tlenpk, Tpk ) ); // min( rows left, columns left ): Tpk is t + 1 by now
             const u32 bnd = pk_mad( pot, K_MATCH, H );
             const u32 bm = pk_bfi( LM, bnd, K_NEG );
@@ -388,7 +401,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
                 if( r >= qlen && all <= ezmax )
                 {
                     rLast = r;
-                    active = false;
+                    act = 0;
                     Jmask = 0;
                 }
                 else if( boundPrev != 0x7fffffff && r >= qlen )
@@ -405,8 +418,6 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         else
             boundPrev = 0x7fffffff;
     }
-    if( active )
-        rLast = r - 1;
     GRP_PROF_T( tp2 );
     // ---- position of the last raise
     {
@@ -422,6 +433,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     // ---- back-trace (ksw_backtrack__, kswcpp_core.h:76-150; inside the regime the path stays in the rectangle): one lane per
     // job walks, all lanes stage the rows it is about to cross into LDS.  Cell (t, j) of diagonal r = t + j: byte g CJ + j of row r.
     const bool leader = l == 0 && has && !handBack && !untouched && maxT >= 0 && maxQ >= 0;
+    const i32 revCigar = F.view( slot ).flag & KSW_EZ_REV_CIGAR;
     u32* myCig = cigLds + g * CIGCAP;
     u32 nCig = 0, curOp = 3, curLen = 0, steps = 0;
     bool cigOver = false;
@@ -567,7 +579,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         redo[ atomicAdd( nRedo, 1u ) ] = slot;
     if( publish && fits )
         for( u32 i = (u32)l; i < myN; i += LANES ) // the walk leaves the cigar reversed (kswcpp_core.h:146-149)
-            O.cig_pool[ off + i ] = ( J.flag & KSW_EZ_REV_CIGAR ) ? myCig[ i ] : myCig[ myN - 1 - i ];
+            O.cig_pool[ off + i ] = revCigar ? myCig[ i ] : myCig[ myN - 1 - i ];
     // totals of the set -> the wave's accumulators (lane 0 flushes them)
     {
         u64 c = l == 0 && publish ? cellsJob : 0, p = l == 0 && publish ? (u64)steps : 0, nj = l == 0 && publish ? 1 : 0, cw = l == 0 && publish ? myN : 0;
@@ -606,51 +618,29 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
 #endif
 }
 
-// lists: six consecutive job lists -- G = 1 left / right (MA_KSW_GRP=2 only), G = 2 left / right, G = 4 left / right -- with
-// n[0..5] entries; next: six zeroed queue counters.  Every persistent wave works through the lists in this order (longest jobs
-// first), a set of G jobs at a time.
+// six job lists: G = 1 left / right (MA_KSW_GRP=2 only), G = 2 left / right, G = 4 left / right
 #define KSW_GRP_LISTS 6
-struct KswGrpLists
-{
-    const u32* list[ KSW_GRP_LISTS ];
-    u32 n[ KSW_GRP_LISTS ];
-};
-template <typename FETCH>
-__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 5 ) ) )
-k_ksw_grp( FETCH F, KswScoring SC, KswGrpLists L, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* redo, unsigned int* nRedo )
+// One kernel per (G, direction): a single instantiation of ksw_grp_set per kernel keeps the register allocation of each below
+// the budget (all six in one kernel: 128 VGPRs and scratch traffic inside the diagonal loop).
+template <typename FETCH, int G, bool LEFT>
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4, 5 ) ) )
+k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* redo, unsigned int* nRedo )
 {
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[ KSW_GRP_LDS ];
     __shared__ u32 sSet;
     __shared__ unsigned long long sOff;
     uint8_t* P = scratch + (u64)blockIdx.x * stride;
     KswWaveAcc acc;
-#pragma unroll
-    for( int k = 0; k < KSW_GRP_LISTS; k++ )
+    while( true )
     {
-        const u32 G = k < 2 ? 1u : ( k < 4 ? 2u : 4u );
-        const u32 n = L.n[ k ];
-        while( true )
-        {
-            if( threadIdx.x == 0 )
-                sSet = atomicAdd( next + k, G );
-            __syncthreads( );
-            const u32 at0 = sSet;
-            __syncthreads( );
-            if( at0 >= n )
-                break;
-            if( k == 0 )
-                ksw_grp_set<1, true>( F, SC, L.list[ 0 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
-            else if( k == 1 )
-                ksw_grp_set<1, false>( F, SC, L.list[ 1 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
-            else if( k == 2 )
-                ksw_grp_set<2, true>( F, SC, L.list[ 2 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
-            else if( k == 3 )
-                ksw_grp_set<2, false>( F, SC, L.list[ 3 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
-            else if( k == 4 )
-                ksw_grp_set<4, true>( F, SC, L.list[ 4 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
-            else
-                ksw_grp_set<4, false>( F, SC, L.list[ 5 ], n, at0, P, lds, O, acc, redo, nRedo, &sOff );
-        }
+        if( threadIdx.x == 0 )
+            sSet = atomicAdd( next, (unsigned int)G );
+        __syncthreads( );
+        const u32 at0 = sSet;
+        __syncthreads( );
+        if( at0 >= n )
+            break;
+        ksw_grp_set<G, LEFT>( F, SC, list, n, at0, P, lds, O, acc, redo, nRedo, &sOff );
     }
     ksw_flush( O, acc );
 }

@@ -722,17 +722,37 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( conc )
         for( int k = 3; k >= 0; k-- )
             launchPk( 0, k );
-    if( nGrp ) // the short extensions, several per wavefront (lane 0 of the streams, like the other extension kernels)
-    {
-        KswGrpLists GL;
+    if( nGrp ) // the short extensions, several per wavefront (lane 0 of the streams, like the other extension kernels); longest first
         for( int k = 0; k < KSW_GRP_LISTS; k++ )
         {
-            GL.list[ k ] = lists + (u64)( KSW_CLS_GRP0 + k ) * list_stride;
-            GL.n[ k ] = (u32)SZ.cls[ KSW_CLS_GRP0 + k ];
+            const u32 nk = (u32)SZ.cls[ KSW_CLS_GRP0 + k ];
+            if( nk == 0 )
+                continue;
+            const u32* lk = lists + (u64)( KSW_CLS_GRP0 + k ) * list_stride;
+            const u32 Gk = k < 2 ? 1u : ( k < 4 ? 2u : 4u );
+            const u32 waves = (u32)std::max<u64>( 1, std::min<u64>( LG.waves, ( nk + Gk - 1 ) / Gk ) );
+            uint8_t* sb = base + laneBase[ 0 ];
+            switch( k )
+            {
+            case 0:
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 1, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                break;
+            case 1:
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 1, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                break;
+            case 2:
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                break;
+            case 3:
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                break;
+            case 4:
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 4, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                break;
+            default:
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 4, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+            }
         }
-        hipLaunchKernelGGL( ( k_ksw_grp<FETCH> ), dim3( LG.waves ), dim3( 64 ), 0, stream, F, SC, GL, next + 11, base + laneBase[ 0 ], LG.stride, O, redo,
-                            nRedo );
-    }
     if( SZ.cls[ 5 ] )
         hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), dim3( LP[ 5 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
                             lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base + laneBase[ 0 ], LP[ 5 ].stride, LP[ 5 ].p_cap, KSW_EXT_LDS,

@@ -128,7 +128,10 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
     // per-class scratch sizes: only the classes whose launches are sized by their jobs (the query-stationary classes from
     // KSW_CLS_GRP0 on have a fixed scratch per wave)
     u32 pcl[ KSW_CLS_GRP0 ], cgl[ KSW_CLS_GRP0 ], pRedo = 0, cgRedo = 0;
-    // append the jobs to the per-class lists: one atomic per wave, class and round instead of one per job
+    // Append the jobs to the per-class lists with ONE round trip to the list counters per wave: a first pass over the lanes'
+    // jobs counts the wave's jobs per class (lane c holds class c's count), lane c reserves class c's list space, a second
+    // pass writes the entries.  (A reservation per class and round -- each waiting for its atomic's return -- made the kernel
+    // latency-bound when the classes went from 7 to 13: 1.35 -> 2.4 ms per 1 M reads.)
     {
         const u32 mine = sink.n < sink.cap ? sink.n : sink.cap;
         const u32 rounds = (u32)wave_max_u64( mine );
@@ -139,22 +142,28 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
 #pragma unroll
         for( int c = 0; c < KSW_CLS_GRP0; c++ )
             pcl[ c ] = cgl[ c ] = 0;
+        auto classOf = [ & ]( u32 k, u32& pj, u32& cj, u32& pk8 ) -> int {
+            const DpJob& j = A.jobs[ sink.slot0 + k ];
+            const i32 ql = (i32)( j.q_to - j.q_from ), tl = (i32)( j.r_to - j.r_from );
+            const int cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
+            const u64 pk = ksw_p_bytes( ql, tl, j.w );
+            // 256-byte units (the query-stationary classes from KSW_CLS_GRP0 on have a fixed scratch per wave: ksw_grp.h)
+            pj = cls >= KSW_CLS_GRP0 ? 0u : (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 );
+            cj = (u32)( ql + tl + 2 );
+            pk8 = (u32)( ( pk + 255 ) >> 8 );
+            return cls;
+        };
+        u32 cntV = 0; // lane c: jobs of class c among this wave's
         for( u32 k = 0; k < rounds; k++ )
         {
             int cls = -1;
-            u32 pj = 0, cj = 0;
+            u32 pj = 0, cj = 0, pk8 = 0;
             if( k < mine )
             {
-                const DpJob& j = A.jobs[ sink.slot0 + k ];
-                const i32 ql = (i32)( j.q_to - j.q_from ), tl = (i32)( j.r_to - j.r_from );
-                cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
-                const u64 pk = ksw_p_bytes( ql, tl, j.w );
-                // 256-byte units (the wavefront-sharing classes 7..10 have a fixed scratch per wave: ksw_grp.h)
-                pj = cls >= KSW_CLS_GRP0 ? 0u : (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 );
-                cj = (u32)( ql + tl + 2 );
+                cls = classOf( k, pj, cj, pk8 );
                 if( cls >= 5 )
                 {
-                    pRedo = max( pRedo, (u32)( ( pk + 255 ) >> 8 ) );
+                    pRedo = max( pRedo, pk8 );
                     cgRedo = max( cgRedo, cj );
                 }
             }
@@ -165,21 +174,38 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                     pcl[ c ] = max( pcl[ c ], pj );
                     cgl[ c ] = max( cgl[ c ], cj );
                 }
-            // one list append per class PRESENT in this round (a wave holds two or three of the 13 classes; a pass over all
-            // of them cost k_dp_enum 1.5 of 2.9 ms when the wavefront-sharing classes were added)
             unsigned long long todo = __ballot( cls >= 0 );
             while( todo )
             {
                 const int c = __builtin_amdgcn_readlane( cls, __ffsll( (long long)todo ) - 1 );
                 const unsigned long long m = __ballot( cls == c );
                 todo &= ~m;
-                const int leader = __ffsll( (long long)m ) - 1;
-                unsigned long long base = 0;
-                if( lane == leader )
-                    base = atomicAdd( &A.ctr[ CTR_CLS0 + c ], (unsigned long long)__popcll( m ) );
-                base = ( (u64)(u32)__shfl( (int)( base >> 32 ), leader, 64 ) << 32 ) | (u32)__shfl( (int)(u32)base, leader, 64 );
+                if( lane == c )
+                    cntV += (u32)__popcll( m );
+            }
+        }
+        unsigned long long baseV = 0;
+        if( lane < KSW_N_CLASSES && cntV )
+            baseV = atomicAdd( &A.ctr[ CTR_CLS0 + lane ], (unsigned long long)cntV );
+        u32 runV = 0; // lane c: entries of class c written so far
+        for( u32 k = 0; k < rounds; k++ )
+        {
+            int cls = -1;
+            u32 pj, cj, pk8;
+            if( k < mine )
+                cls = classOf( k, pj, cj, pk8 );
+            unsigned long long todo = __ballot( cls >= 0 );
+            while( todo )
+            {
+                const int c = __builtin_amdgcn_readlane( cls, __ffsll( (long long)todo ) - 1 );
+                const unsigned long long m = __ballot( cls == c );
+                todo &= ~m;
+                const u64 base = ( (u64)(u32)__builtin_amdgcn_readlane( (int)( baseV >> 32 ), c ) << 32 ) | (u32)__builtin_amdgcn_readlane( (int)(u32)baseV, c );
+                const u32 run = (u32)__builtin_amdgcn_readlane( (int)runV, c );
                 if( cls == c )
-                    A.lists[ (u64)c * A.list_stride + base + __popcll( m & ( ( 1ull << lane ) - 1 ) ) ] = sink.slot0 + k;
+                    A.lists[ (u64)c * A.list_stride + base + run + __popcll( m & ( ( 1ull << lane ) - 1 ) ) ] = sink.slot0 + k;
+                if( lane == c )
+                    runV += (u32)__popcll( m );
             }
         }
     }
