@@ -40,7 +40,7 @@ static __device__ unsigned long long g_grp_prof[ 24 ];
 #else
 #define GRP_PROF_T( v )
 #endif
-#define KSW_GRP_STAGE_ROWS 32 // direction rows (128 B each) the back-trace stages in LDS at a time
+#define KSW_GRP_STAGE_ROWS 64 // direction rows (128 B each) of the LDS ring: the last 33..64 diagonals of a set never leave the CU
 #define KSW_GRP_CIG_WORDS 256 // cigar words in LDS per wavefront (shared by its G groups)
 #define KSW_GRP_ROWS 516 // direction rows of a wavefront's scratch: a job leaves the regime at r > w, w <= 512
 #define KSW_GRP_LDS ( KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4 + 256 + 64 )
@@ -150,6 +150,10 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     constexpr int LANES = 64 / G, CJ = 128 / G;
     const int lane = threadIdx.x & 63, g = lane / LANES, l = lane % LANES;
     GRP_PROF_T( tp0 );
+    // Direction bytes: row r of the set (128 B: the G jobs' cells side by side) lives at ring slot r mod 64 in LDS.  Every 32
+    // diagonals the 32 rows that the next 32 diagonals will overwrite are copied to the wave's HBM scratch, so at the end the
+    // ring holds the last 33..64 rows and HBM the older ones.  A set of up to 64 diagonals -- most sets of four jobs -- writes no
+    // direction byte to HBM at all and its back-trace starts at once (round 4: 1 B per cell to HBM, 2.3x the algorithmic traffic).
     uint8_t* stage = lds; // KSW_GRP_STAGE_ROWS x 128
     u32* cigLds = (u32*)( lds + KSW_GRP_STAGE_ROWS * 128 ); // KSW_GRP_CIG_WORDS, CIGCAP per group
     uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // G x 2 CJ bytes = 256
@@ -253,6 +257,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     i32 zNext = zdrop >= 0 ? 0 : 0x7fffffff;
     const u32 laneOff = (u32)( g * CJ + 2 * l ); // the lane's two bytes of a direction row
     i32 uInS = initOf( 0 ); // first-row initialisation of cell t = r (wave-uniform: the scoring is)
+    i32 ringLo = 0; // rows below it have been copied to HBM (wave-uniform)
     __syncthreads( );
     GRP_PROF_T( tp1 );
     i32 r = 0;
@@ -274,6 +279,17 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         {
             fillRing( r + CJ );
             __syncthreads( );
+        }
+        if( __builtin_expect( r >= KSW_GRP_STAGE_ROWS && ( r & 31 ) == 0, 0 ) )
+        {
+            // rows [r - 64, r - 32) -> HBM: their ring slots are the ones rows r .. r + 31 take (64 B per lane)
+            __syncthreads( );
+            const uint4* src = (const uint4*)( stage + ( ( r - KSW_GRP_STAGE_ROWS ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 );
+            uint4* dst = (uint4*)( P + (size_t)( r - KSW_GRP_STAGE_ROWS ) * 128 );
+#pragma unroll
+            for( int k = 0; k < 4; k++ )
+                dst[ lane + 64 * k ] = src[ lane + 64 * k ];
+            ringLo = r - 32;
         }
         // ---- neighbours: u, y, y2 and the target base come from row j - 1
         const u32 tIn = (u32)myRing[ r & ( 2 * CJ - 1 ) ];
@@ -326,8 +342,8 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         V = pk_bfi( LM, nv, V );
         X = pk_bfi( LM, nx, X );
         X2 = pk_bfi( LM, nx2, X2 );
-        if( LM ) // (scalar row base + the lane's constant offset: no 64-bit address per lane)
-            *(uint16_t*)( P + (size_t)r * 128 + laneOff ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
+        if( LM ) // the lane's two bytes of row r of the ring
+            *(uint16_t*)( stage + ( r & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + laneOff ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
         // ---- H(t, j) = H(t-1, j) + u(t, j)
         const u32 hn = pk_add( H, pk_ashr8( nu ) );
         H = pk_bfi( LM, hn, H );
@@ -429,7 +445,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             maxQ = pR - pT;
         }
     }
-    __syncthreads( ); // direction bytes visible to the back-trace
+    __syncthreads( ); // direction bytes (LDS, and the rows that went to HBM) visible to the back-trace
     // ---- back-trace (ksw_backtrack__, kswcpp_core.h:76-150; inside the regime the path stays in the rectangle): one lane per
     // job walks, all lanes stage the rows it is about to cross into LDS.  Cell (t, j) of diagonal r = t + j: byte g CJ + j of row r.
     const bool leader = l == 0 && has && !handBack && !untouched && maxT >= 0 && maxQ >= 0;
@@ -455,22 +471,13 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             curLen = len;
         }
     };
+    // rows [winLo, ...] are in the ring (slot r mod 64): first the ones the loop left there, then 64-row windows out of HBM
+    i32 winLo = ringLo;
     while( true )
     {
-        const bool walking = bi >= 0 && bj >= 0;
-        if( !__any( walking ) )
-            break;
-        // rows [rlo, rhi]: the highest diagonal any walker stands on, KSW_GRP_STAGE_ROWS rows down
-        i32 rhi = walking ? bi + bj : -1;
-        rhi = wave_max_i32( rhi );
-        const i32 rlo = max( 0, rhi - KSW_GRP_STAGE_ROWS + 1 );
-        __syncthreads( );
-        for( i32 k = lane * 16; k < ( rhi - rlo + 1 ) * 128; k += 1024 )
-            *(uint4*)( stage + k ) = *(const uint4*)( P + (size_t)rlo * 128 + k );
-        __syncthreads( );
-        while( bi >= 0 && bj >= 0 && bi + bj >= rlo )
+        while( bi >= 0 && bj >= 0 && bi + bj >= winLo )
         {
-            const u32 tb = stage[ ( bi + bj - rlo ) * 128 + g * CJ + bj ];
+            const u32 tb = stage[ ( ( bi + bj ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + g * CJ + bj ];
             if( state != 0 && !( ( tb >> ( state + 2 ) ) & 1 ) )
                 state = 0;
             if( state == 0 )
@@ -481,6 +488,19 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             bi -= op != 1u ? 1 : 0;
             bj -= op != 2u ? 1 : 0;
         }
+        const bool walking = bi >= 0 && bj >= 0;
+        if( !__any( walking ) )
+            break;
+        // the highest diagonal any walker stands on (below winLo: those rows went to HBM), 64 rows down
+        const i32 rhi = wave_max_i32( walking ? bi + bj : -1 );
+        winLo = max( 0, rhi - KSW_GRP_STAGE_ROWS + 1 );
+        __syncthreads( );
+        for( i32 k = lane; k < ( rhi - winLo + 1 ) * 8; k += 64 ) // 16 bytes each: 8 per row
+        {
+            const i32 row = winLo + ( k >> 3 );
+            *(uint4*)( stage + ( row & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + ( k & 7 ) * 16 ) = *(const uint4*)( P + (size_t)row * 128 + ( k & 7 ) * 16 );
+        }
+        __syncthreads( );
     }
     if( leader )
     {
@@ -631,16 +651,22 @@ k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, u
     __shared__ unsigned long long sOff;
     uint8_t* P = scratch + (u64)blockIdx.x * stride;
     KswWaveAcc acc;
+    u32 cur = 0, end = 0; // four sets per queue atomic (a set's time is mostly latency: one round trip less)
     while( true )
     {
-        if( threadIdx.x == 0 )
-            sSet = atomicAdd( next, (unsigned int)G );
-        __syncthreads( );
-        const u32 at0 = sSet;
-        __syncthreads( );
-        if( at0 >= n )
-            break;
-        ksw_grp_set<G, LEFT>( F, SC, list, n, at0, P, lds, O, acc, redo, nRedo, &sOff );
+        if( cur >= end )
+        {
+            if( threadIdx.x == 0 )
+                sSet = atomicAdd( next, (unsigned int)( 4 * G ) );
+            __syncthreads( );
+            cur = sSet;
+            __syncthreads( );
+            if( cur >= n )
+                break;
+            end = cur + 4 * G < n ? cur + 4 * G : n;
+        }
+        ksw_grp_set<G, LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff );
+        cur += G;
     }
     ksw_flush( O, acc );
 }

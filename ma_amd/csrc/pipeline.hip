@@ -296,12 +296,14 @@ int ma_batch_set_reads( ma_batch* b, const uint8_t* codes, const uint64_t* offse
     return 0;
 }
 
-// longest read of the batch: one atomic per wavefront (a million same-address atomics serialise in L2: 182 us per 1 M reads
-// in profiles/r05_step_timeline_150bp.txt, a per-wave maximum first: a few us)
+// longest read of the batch.  A million same-address atomics serialise in L2 (182 us per 1 M reads in
+// profiles/r05_step_timeline_150bp.txt; one per wavefront: still 16 k of them, 180 us): a fixed grid strides over the reads and
+// every wavefront issues ONE atomic (1 024 in all).
 __global__ void k_max_qlen( const u64* roff, u64 n, unsigned long long* out )
 {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u32 v = i < n ? (u32)std::min<u64>( roff[ i + 1 ] - roff[ i ], 0xffffffffull ) : 0u;
+    u32 v = 0;
+    for( u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x )
+        v = max( v, (u32)std::min<u64>( roff[ i + 1 ] - roff[ i ], 0xffffffffull ) );
     for( int m = 32; m; m >>= 1 )
         v = max( v, (u32)__shfl_xor( (int)v, m, 64 ) );
     if( ( threadIdx.x & 63 ) == 0 && v )
@@ -320,7 +322,7 @@ int ma_batch_set_reads_device( ma_batch* b, const void* d_codes, const void* d_o
     b->reads_external = true;
     MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
     if( n )
-        hipLaunchKernelGGL( k_max_qlen, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->d_roff, n,
+        hipLaunchKernelGGL( k_max_qlen, dim3( (unsigned)std::min<u64>( 256, ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->d_roff, n,
                             b->ctr.as<unsigned long long>( ) );
     if( read_ctr( b ) )
         return 1;
