@@ -40,7 +40,7 @@ static __device__ unsigned long long g_grp_prof[ 24 ];
 #else
 #define GRP_PROF_T( v )
 #endif
-#define KSW_GRP_STAGE_ROWS 64 // direction rows (128 B each) of the LDS ring: the last 33..64 diagonals of a set never leave the CU
+#define KSW_GRP_STAGE_ROWS 32 // direction rows (128 B each) of the LDS ring: the last 17..32 diagonals of a set never leave the CU
 #define KSW_GRP_CIG_WORDS 256 // cigar words in LDS per wavefront (shared by its G groups)
 #define KSW_GRP_ROWS 516 // direction rows of a wavefront's scratch: a job leaves the regime at r > w, w <= 512
 #define KSW_GRP_LDS ( KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4 + 256 + 64 )
@@ -145,15 +145,20 @@ __device__ __forceinline__ void grp_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qlen
 // redo / nRedo: the hand-back list of the extension kernels.
 template <int G, bool LEFT, typename FETCH>
 __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* list, u32 n, u32 at0, uint8_t* P /*KSW_GRP_ROWS x 128 B*/,
-                             uint8_t* lds, const KswOut& O, KswWaveAcc& acc, u32* redo, unsigned int* nRedo, unsigned long long* sOff )
+                             uint8_t* lds, const KswOut& O, KswWaveAcc& acc, u32* redo, unsigned int* nRedo, unsigned long long* sOff
+#if defined( MA_KSW_PROF )
+                             ,
+                             unsigned long long* pf
+#endif
+)
 {
     constexpr int LANES = 64 / G, CJ = 128 / G;
     const int lane = threadIdx.x & 63, g = lane / LANES, l = lane % LANES;
     GRP_PROF_T( tp0 );
-    // Direction bytes: row r of the set (128 B: the G jobs' cells side by side) lives at ring slot r mod 64 in LDS.  Every 32
-    // diagonals the 32 rows that the next 32 diagonals will overwrite are copied to the wave's HBM scratch, so at the end the
-    // ring holds the last 33..64 rows and HBM the older ones.  A set of up to 64 diagonals -- most sets of four jobs -- writes no
-    // direction byte to HBM at all and its back-trace starts at once (round 4: 1 B per cell to HBM, 2.3x the algorithmic traffic).
+    // Direction bytes: row r of the set (128 B: the G jobs' cells side by side) lives at ring slot r mod 32 in LDS.  Every 16
+    // diagonals the 16 rows that the next 16 diagonals will overwrite are copied to the wave's HBM scratch (one coalesced 2 KB
+    // copy), so at the end the ring holds the last 17..32 rows and HBM the older ones: the loop itself never stores to global
+    // memory, and the back-trace starts on rows that never left the CU.
     uint8_t* stage = lds; // KSW_GRP_STAGE_ROWS x 128
     u32* cigLds = (u32*)( lds + KSW_GRP_STAGE_ROWS * 128 ); // KSW_GRP_CIG_WORDS, CIGCAP per group
     uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // G x 2 CJ bytes = 256
@@ -255,6 +260,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     // (the clip of z is an upper bound only).  So after a diagonal with maximum m the test cannot pass for
     // ( m - (ez.max - zdrop - 1) ) / (q + e) diagonals: a job's next test is scheduled like its next bound evaluation.
     i32 zNext = zdrop >= 0 ? 0 : 0x7fffffff;
+    const i32 zStep = zdrop >= 0 ? ( zdrop + qe ) / qe : 0x3fffffff; // diagonals after a raise before the test can pass
     const u32 laneOff = (u32)( g * CJ + 2 * l ); // the lane's two bytes of a direction row
     i32 uInS = initOf( 0 ); // first-row initialisation of cell t = r (wave-uniform: the scoring is)
     i32 ringLo = 0; // rows below it have been copied to HBM (wave-uniform)
@@ -280,16 +286,16 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             fillRing( r + CJ );
             __syncthreads( );
         }
-        if( __builtin_expect( r >= KSW_GRP_STAGE_ROWS && ( r & 31 ) == 0, 0 ) )
+        if( __builtin_expect( r >= KSW_GRP_STAGE_ROWS && ( r & ( KSW_GRP_STAGE_ROWS / 2 - 1 ) ) == 0, 0 ) )
         {
-            // rows [r - 64, r - 32) -> HBM: their ring slots are the ones rows r .. r + 31 take (64 B per lane)
+            // rows [r - 32, r - 16) -> HBM: their ring slots are the ones rows r .. r + 15 take (32 B per lane)
             __syncthreads( );
             const uint4* src = (const uint4*)( stage + ( ( r - KSW_GRP_STAGE_ROWS ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 );
             uint4* dst = (uint4*)( P + (size_t)( r - KSW_GRP_STAGE_ROWS ) * 128 );
 #pragma unroll
-            for( int k = 0; k < 4; k++ )
+            for( int k = 0; k < KSW_GRP_STAGE_ROWS / 16; k++ )
                 dst[ lane + 64 * k ] = src[ lane + 64 * k ];
-            ringLo = r - 32;
+            ringLo = r - KSW_GRP_STAGE_ROWS / 2;
         }
         // ---- neighbours: u, y, y2 and the target base come from row j - 1
         const u32 tIn = (u32)myRing[ r & ( 2 * CJ - 1 ) ];
@@ -361,7 +367,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             pR = raise ? r : pR;
             pend |= raise;
             // (the diagonal's maximum IS ez.max now: no z-drop before it has fallen by zdrop + 1)
-            zNext = raise && zdrop >= 0 ? r + ( zdrop + qe ) / qe : zNext;
+            zNext = raise ? r + zStep : zNext;
         }
         // ---- z-drop, on the job's schedule: rare
         if( __builtin_expect( __any( ( act & ~raise ) != 0 && r >= zNext ) != 0, 0 ) )
@@ -471,7 +477,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             curLen = len;
         }
     };
-    // rows [winLo, ...] are in the ring (slot r mod 64): first the ones the loop left there, then 64-row windows out of HBM
+    // rows [winLo, ...] are in the ring (slot r mod 32): first the ones the loop left there, then 32-row windows out of HBM
     i32 winLo = ringLo;
     while( true )
     {
@@ -491,7 +497,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         const bool walking = bi >= 0 && bj >= 0;
         if( !__any( walking ) )
             break;
-        // the highest diagonal any walker stands on (below winLo: those rows went to HBM), 64 rows down
+        // the highest diagonal any walker stands on (below winLo: those rows went to HBM), 32 rows down
         const i32 rhi = wave_max_i32( walking ? bi + bj : -1 );
         winLo = max( 0, rhi - KSW_GRP_STAGE_ROWS + 1 );
         __syncthreads( );
@@ -622,18 +628,8 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             ownAll += (u32)__builtin_amdgcn_readlane( (i32)own, k * LANES );
             njAll += (u32)__builtin_amdgcn_readlane( (i32)nj, k * LANES );
         }
-        if( threadIdx.x == 0 )
-        {
-            unsigned long long* pf = g_grp_prof + 8 * ( G == 1 ? 0 : ( G == 2 ? 1 : 2 ) );
-            atomicAdd( pf + 0, tp1 - tp0 );
-            atomicAdd( pf + 1, tp2 - tp1 );
-            atomicAdd( pf + 2, tp3 - tp2 );
-            atomicAdd( pf + 3, tp4 - tp3 );
-            atomicAdd( pf + 4, (unsigned long long)r );
-            atomicAdd( pf + 5, 1ull );
-            atomicAdd( pf + 6, (unsigned long long)njAll );
-            atomicAdd( pf + 7, (unsigned long long)ownAll );
-        }
+        pf[ 0 ] += tp1 - tp0, pf[ 1 ] += tp2 - tp1, pf[ 2 ] += tp3 - tp2, pf[ 3 ] += tp4 - tp3; // (the wave's own totals: flushed at its end)
+        pf[ 4 ] += (unsigned long long)r, pf[ 5 ] += 1ull, pf[ 6 ] += (unsigned long long)njAll, pf[ 7 ] += (unsigned long long)ownAll;
     }
 #endif
 }
@@ -643,7 +639,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
 // One kernel per (G, direction): a single instantiation of ksw_grp_set per kernel keeps the register allocation of each below
 // the budget (all six in one kernel: 128 VGPRs and scratch traffic inside the diagonal loop).
 template <typename FETCH, int G, bool LEFT>
-__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 4, 5 ) ) )
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 5, 5 ) ) )
 k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* redo, unsigned int* nRedo )
 {
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[ KSW_GRP_LDS ];
@@ -651,6 +647,9 @@ k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, u
     __shared__ unsigned long long sOff;
     uint8_t* P = scratch + (u64)blockIdx.x * stride;
     KswWaveAcc acc;
+#if defined( MA_KSW_PROF )
+    unsigned long long prof[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#endif
     u32 cur = 0, end = 0; // four sets per queue atomic (a set's time is mostly latency: one round trip less)
     while( true )
     {
@@ -665,10 +664,19 @@ k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, u
                 break;
             end = cur + 4 * G < n ? cur + 4 * G : n;
         }
+#if defined( MA_KSW_PROF )
+        ksw_grp_set<G, LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff, prof );
+#else
         ksw_grp_set<G, LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff );
+#endif
         cur += G;
     }
     ksw_flush( O, acc );
+#if defined( MA_KSW_PROF )
+    if( threadIdx.x == 0 )
+        for( int i = 0; i < 8; i++ )
+            atomicAdd( g_grp_prof + 8 * ( G == 1 ? 0 : ( G == 2 ? 1 : 2 ) ) + i, prof[ i ] );
+#endif
 }
 } // namespace ma
 #endif

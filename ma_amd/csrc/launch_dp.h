@@ -89,6 +89,19 @@ int ma_dp_batch( ma_batch* b )
     D.list_stride = nSlots;
     D.SC = KswScoring{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
     D.SC.grp = ksw_grp_env( );
+    D.ez = b->ez.as<ma_ez>( );
+    D.cig_off = b->cigOff.as<u64>( );
+    {
+        // 1 x 1 gap fills are answered by the enumeration when the worst score cannot lose to a gap (stage_dp.h); MA_DP_1X1=0: A/B hook
+        int8_t q = (int8_t)b->P.gap, e = (int8_t)b->P.extend, q2 = (int8_t)b->P.gap2, e2 = (int8_t)b->P.extend2;
+        if( q2 + e2 < q + e )
+            std::swap( q, q2 ), std::swap( e, e2 );
+        const int mis = -std::abs( (int)(int8_t)b->P.mismatch ), worst = std::min( mis, -(int)e2 );
+        const int alt = std::max( -2 * ( q + e ), -( q2 + e2 ) - ( q + e ) );
+        const bool untouched = -std::min( mis, 0 ) > 2 * ( q + e ); // kswcpp returns at once (kswcpp_core.h:340-341)
+        const char* env = getenv( "MA_DP_1X1" );
+        D.one_by_one = ( !env || atoi( env ) != 0 ) && !untouched && worst >= alt && q >= 0 && e >= 1 && q2 >= 0 && e2 >= 1 ? 1u : 0u;
+    }
     {
         EvTimer t( b, 3 );
         // zero-fill: a slot is a job iff q_to > q_from (pool regions of dropped sets stay empty)
@@ -134,6 +147,9 @@ int ma_dp_batch( ma_batch* b )
         {
             if( b->cigPool.reserve( b->cigPoolCap * 4 ) )
                 return 1;
+            // pool word 0 = the cigar 1M of the 1 x 1 gap fills the enumeration answered; the kernels' reservations start at 1
+            MA_HIP( hipMemsetD32Async( (hipDeviceptr_t)b->cigPool.p, (int)( 1u << 4 ), 1, b->stream ) );
+            MA_HIP( hipMemsetD32Async( (hipDeviceptr_t)( c + CTR_CIG_USED ), 1, 1, b->stream ) );
             KswOut O;
             O.ez = b->ez.as<ma_ez>( );
             O.cig_off = b->cigOff.as<u64>( );
@@ -177,6 +193,27 @@ int ma_dp_batch( ma_batch* b )
                             return 1;
                         MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( b->cubTmp.p, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
                                                                               b->sortVal2.as<u32>( ), (int)nk, 0, 32, b->stream ) );
+                        MA_HIP( hipMemcpyAsync( list, b->sortVal2.p, nk * 4, hipMemcpyDeviceToDevice, b->stream ) );
+                    }
+                // the wavefront-sharing classes: sets of about equally long jobs (MA_KSW_GRP_SORT=0: A/B hook)
+                if( []( ) { const char* e = getenv( "MA_KSW_GRP_SORT" ); return !e || atoi( e ) != 0; }( ) )
+                    for( int k = KSW_CLS_GRP0 + 2; k < KSW_N_CLASSES; k++ )
+                    {
+                        const u64 nk = S.cls[ k ];
+                        if( nk < 8192 )
+                            continue;
+                        u32* list = b->clsLists.as<u32>( ) + (u64)k * nSlots;
+                        if( b->sortKey.reserve( nk * 4 ) || b->sortKey2.reserve( nk * 4 ) || b->sortVal2.reserve( nk * 4 ) )
+                            return 1;
+                        hipLaunchKernelGGL( k_job_qlen, dim3( (unsigned)( ( nk + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, F, list, (u32)nk,
+                                            b->sortKey.as<u32>( ) );
+                        size_t tb = 0;
+                        MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( nullptr, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
+                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 8, b->stream ) );
+                        if( b->cubTmp.reserve( tb + 256 ) )
+                            return 1;
+                        MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( b->cubTmp.p, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
+                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 8, b->stream ) );
                         MA_HIP( hipMemcpyAsync( list, b->sortVal2.p, nk * 4, hipMemcpyDeviceToDevice, b->stream ) );
                     }
                 if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,

@@ -55,7 +55,8 @@ enum : int
     CTR_MAX_P_REDO = 76, // the same two for the extension kernels' jobs if they are handed back to the exact kernel
     CTR_MAX_CIG_REDO = 77,
     CTR_NEXT_BIG = 78, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
-    CTR_COUNT = 80
+    CTR_N_1X1 = 80, // 1 x 1 gap fills answered by k_dp_enum itself (counted as ksw calls of one cell each)
+    CTR_COUNT = 82
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -681,8 +682,8 @@ int ma_batch_counters( ma_batch* b, uint64_t out[ 8 ] )
     out[ 1 ] = b->hctr[ CTR_BLOCKS ];
     out[ 2 ] = b->hctr[ CTR_LF_STEPS ];
     out[ 3 ] = b->nSeeds;
-    out[ 4 ] = b->hctr[ CTR_CELLS ];
-    out[ 5 ] = b->hctr[ CTR_KSW_JOBS ];
+    out[ 4 ] = b->hctr[ CTR_CELLS ] + b->hctr[ CTR_N_1X1 ];
+    out[ 5 ] = b->hctr[ CTR_KSW_JOBS ] + b->hctr[ CTR_N_1X1 ];
     out[ 6 ] = b->hctr[ CTR_SEQ_BYTES ];
     out[ 7 ] = b->hctr[ CTR_PATH_BYTES ] + 4 * b->hctr[ CTR_CIG_WORDS ];
     return 0;

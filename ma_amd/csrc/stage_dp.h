@@ -67,6 +67,16 @@ struct DpKernelArgs
     KswScoring SC;
     u32 lanes; // sets per wavefront (lanes_per_wave)
     u32 wave_split; // long reads: sets that span >= 1024 query bases go to k_stitch_wave
+    // 1 x 1 gap fills (a single mismatch between two seeds: 30 % of the DP calls of a 150 bp batch).  NeedlemanWunsch::ksw
+    // (needlemanWunsch.cpp:82-169) runs kswcpp on them globally and reads the cigar only; for a 1 x 1 matrix kswcpp's first cell
+    // compares the score s with the four gap terms -2(q+e), -(q2+e2)-(q+e) (x, y, x2, y2 initialised to -q-e / -q2-e2 plus the
+    // first-row / first-column u, v = -q-e, kswcpp_core.h:562-585,653-699) and the left-aligned variant keeps s on ties: whenever
+    // the WORST score (mismatch, or -e2 for an N) is not below them the back-trace is one M, whatever the bases.  one_by_one = that
+    // holds for the scoring in use: the enumeration writes the result (ez as kswcpp leaves it for a global call, the cigar word
+    // 1M = pool word 0, which the DP stage reserves) and lists no job.
+    u32 one_by_one;
+    ma_ez* ez;
+    u64* cig_off;
 };
 
 #if defined( __HIPCC__ )
@@ -145,6 +155,9 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
         auto classOf = [ & ]( u32 k, u32& pj, u32& cj, u32& pk8 ) -> int {
             const DpJob& j = A.jobs[ sink.slot0 + k ];
             const i32 ql = (i32)( j.q_to - j.q_from ), tl = (i32)( j.r_to - j.r_from );
+            pj = cj = pk8 = 0;
+            if( A.one_by_one && ql == 1 && tl == 1 && j.flag == 0 && j.zdrop < 0 )
+                return -2; // answered here (first pass)
             const int cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
             const u64 pk = ksw_p_bytes( ql, tl, j.w );
             // 256-byte units (the query-stationary classes from KSW_CLS_GRP0 on have a fixed scratch per wave: ksw_grp.h)
@@ -154,6 +167,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
             return cls;
         };
         u32 cntV = 0; // lane c: jobs of class c among this wave's
+        u32 n11 = 0; // this lane's 1 x 1 gap fills
         for( u32 k = 0; k < rounds; k++ )
         {
             int cls = -1;
@@ -165,6 +179,16 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                 {
                     pRedo = max( pRedo, pk8 );
                     cgRedo = max( cgRedo, cj );
+                }
+                if( cls == -2 )
+                {
+                    ma_ez rz; // what a global kswcpp call leaves (kswcpp_core.h:328-338, 796-835): only the cigar is set
+                    rz.max = 0, rz.zdropped = 0, rz.max_q = rz.max_t = rz.mqe_t = rz.mte_q = -1;
+                    rz.mqe = rz.mte = rz.score = (i32)0x80000000;
+                    rz.reach_end = 0, rz.n_cigar = 1;
+                    A.ez[ sink.slot0 + k ] = rz;
+                    A.cig_off[ sink.slot0 + k ] = 0; // pool word 0 = 1M
+                    n11++;
                 }
             }
 #pragma unroll
@@ -183,6 +207,11 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                 if( lane == c )
                     cntV += (u32)__popcll( m );
             }
+        }
+        {
+            const u64 all11 = wave_sum_u64( n11 );
+            if( lane == 0 && all11 )
+                atomicAdd( &A.ctr[ CTR_N_1X1 ], (unsigned long long)all11 );
         }
         unsigned long long baseV = 0;
         if( lane < KSW_N_CLASSES && cntV )
@@ -332,6 +361,15 @@ __global__ void k_job_cost( PipeFetch F, const u32* list, u32 n, u32* key )
     key[ i ] = c > 0xffffffffull ? 0xffffffffu : (u32)c;
 }
 
+// Jobs that share a wavefront run in lock-step until the longest of them is done (ksw_grp.h): the lists of those classes are
+// sorted by query length, so that the jobs of a set are about equally long (unsorted: 1.7x the diagonals four jobs need).
+__global__ void k_job_qlen( PipeFetch F, const u32* list, u32 n, u32* key )
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if( i < n )
+        key[ i ] = (u32)F.view( list[ i ] ).qlen;
+}
+
 // ops capacity of a set: |Q| + sum of its jobs' cigar lengths + 8 * seeds + 16 (see nw.h)
 __global__ void k_ops_caps( const HSet* sets, const SetInfo* info, const u32* set_read, const u64* roff,
                             const ma_ez* ez, u32 n_sets, u64* caps )
@@ -389,6 +427,16 @@ struct StitchKernelArgs
     unsigned long long* ctr;
     u32 lanes; // sets per wavefront (lanes_per_wave)
     u32 wave_split; // long reads: sets that span >= 1024 query bases go to k_stitch_wave
+    // 1 x 1 gap fills (a single mismatch between two seeds: 30 % of the DP calls of a 150 bp batch).  NeedlemanWunsch::ksw
+    // (needlemanWunsch.cpp:82-169) runs kswcpp on them globally and reads the cigar only; for a 1 x 1 matrix kswcpp's first cell
+    // compares the score s with the four gap terms -2(q+e), -(q2+e2)-(q+e) (x, y, x2, y2 initialised to -q-e / -q2-e2 plus the
+    // first-row / first-column u, v = -q-e, kswcpp_core.h:562-585,653-699) and the left-aligned variant keeps s on ties: whenever
+    // the WORST score (mismatch, or -e2 for an N) is not below them the back-trace is one M, whatever the bases.  one_by_one = that
+    // holds for the scoring in use: the enumeration writes the result (ez as kswcpp leaves it for a global call, the cigar word
+    // 1M = pool word 0, which the DP stage reserves) and lists no job.
+    u32 one_by_one;
+    ma_ez* ez;
+    u64* cig_off;
 };
 
 // what k_stitch_wave keeps in LDS of the set it walks: the next 64 seeds and the records of the next 64 jobs (with the first
