@@ -427,16 +427,6 @@ struct StitchKernelArgs
     unsigned long long* ctr;
     u32 lanes; // sets per wavefront (lanes_per_wave)
     u32 wave_split; // long reads: sets that span >= 1024 query bases go to k_stitch_wave
-    // 1 x 1 gap fills (a single mismatch between two seeds: 30 % of the DP calls of a 150 bp batch).  NeedlemanWunsch::ksw
-    // (needlemanWunsch.cpp:82-169) runs kswcpp on them globally and reads the cigar only; for a 1 x 1 matrix kswcpp's first cell
-    // compares the score s with the four gap terms -2(q+e), -(q2+e2)-(q+e) (x, y, x2, y2 initialised to -q-e / -q2-e2 plus the
-    // first-row / first-column u, v = -q-e, kswcpp_core.h:562-585,653-699) and the left-aligned variant keeps s on ties: whenever
-    // the WORST score (mismatch, or -e2 for an N) is not below them the back-trace is one M, whatever the bases.  one_by_one = that
-    // holds for the scoring in use: the enumeration writes the result (ez as kswcpp leaves it for a global call, the cigar word
-    // 1M = pool word 0, which the DP stage reserves) and lists no job.
-    u32 one_by_one;
-    ma_ez* ez;
-    u64* cig_off;
 };
 
 // what k_stitch_wave keeps in LDS of the set it walks: the next 64 seeds and the records of the next 64 jobs (with the first

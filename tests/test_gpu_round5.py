@@ -264,8 +264,11 @@ def test_short_extensions_that_share_a_wavefront(gpu_device, scoring, monkeypatc
             prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
     for n, seed in ((3001, 5), (7, 6), (1, 7), (2, 8)):
         cases = short_extension_cases(n, seed + (0 if scoring is None else scoring[0]))
+        long_cases = [(np.concatenate([q, q[::-1], q])[:int(65 + (i * 7) % 64)], t, w, zd, fl) for i, (q, t, w, zd, fl) in enumerate(cases[:400]) if len(q) >= 33]
         monkeypatch.setenv("MA_KSW_GRP", "1")
         ez, cigs = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
+        monkeypatch.setenv("MA_KSW_GRP", "2")  # the same kernel with ONE job per wavefront for queries of 65..128 bases (A/B mode)
+        ez2, cigs2 = ma_amd.ksw_batch(P, cases + long_cases, pipeline_semantics=True)
         monkeypatch.setenv("MA_KSW_GRP", "0")
         ez0, cigs0 = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
         for i, (q, t, w, zd, fl) in enumerate(cases):
@@ -276,6 +279,12 @@ def test_short_extensions_that_share_a_wavefront(gpu_device, scoring, monkeypatc
                 assert int(ez0[f][i]) == int(oez[f]), what
             assert np.array_equal(cigs[i], ocig), "%s: cigar %s, oracle %s" % (what, cigs[i].tolist(), ocig.tolist())
             assert np.array_equal(cigs0[i], ocig), what
+            assert all(int(ez2[f][i]) == int(oez[f]) for f in ("max", "max_q", "max_t")) and np.array_equal(cigs2[i], ocig), what + " (MA_KSW_GRP=2)"
+        for k, (q, t, w, zd, fl) in enumerate(long_cases):
+            i = len(cases) + k
+            oez, ocig = or_ksw(op, q, t, w, zd, fl)
+            assert all(int(ez2[f][i]) == int(oez[f]) for f in ("max", "max_q", "max_t")) and np.array_equal(cigs2[i], ocig), (
+                "one job per wave, qlen %d tlen %d flag %#x" % (len(q), len(t), fl))
     monkeypatch.delenv("MA_KSW_GRP")
 
 
@@ -318,3 +327,50 @@ def test_a_late_n_switches_the_score_profile_of_the_exact_kernel(gpu_device, slo
             assert int(ez[f][i]) == int(oez[f]), "case %d (qlen %d tlen %d w %d flag %#x) field %s: %d vs oracle %d" % (
                 i, len(q), len(t), w, fl, f, int(ez[f][i]), int(oez[f]))
         assert np.array_equal(cigs[i], ocig), "case %d cigar" % i
+
+
+def test_one_by_one_gap_fills_are_answered_by_the_enumeration(gpu_device, monkeypatch):
+    """A single mismatch between two seeds is a 1 x 1 global kswcpp call (NeedlemanWunsch::ksw, needlemanWunsch.cpp:82-169; 30 % of
+    the DP calls of a 150 bp batch).  k_dp_enum writes its result itself -- one M, whatever the bases, as long as the worst
+    score cannot lose to a gap (stage_dp.h) -- and lists no job.  Same alignments, ops, mapq bits and counters as with the
+    shortcut off (MA_DP_1X1=0) and as the oracle, reads with Ns in the gap included; under a scoring where a gap CAN win the
+    shortcut must switch itself off."""
+    import ma_amd
+    from ma_testlib import rand_genome
+    g = rand_genome(31, [300000, 150000], repeat_unit=200, repeat_copies=30, repeat_div=0.06)
+    rng = np.random.default_rng(5)
+    reads = []
+    for i in range(4000):  # 150 bp reads with 1..3 isolated substitutions (or Ns) far from the ends: 1 x 1 gaps between seeds
+        c = g[i % 2]
+        p = int(rng.integers(0, len(c) - 150))
+        r = c[p:p + 150].copy()
+        for pos in rng.choice(np.arange(25, 125), size=int(rng.integers(1, 4)), replace=False):
+            r[pos] = 4 if rng.random() < 0.1 else (r[pos] + int(rng.integers(1, 4))) % 4
+        reads.append(r if i % 3 else (3 - r[::-1]).astype(np.uint8) if r.max() < 4 else r)
+    idx = ma_amd.Index.build(g)
+    oidx = OrIndex.from_parts(idx.download())
+    nb = sum(len(r) for r in reads)
+    for scoring in (None, (2, 13, 4, 2, 24, 1)):  # the second: a mismatch costs more than two gap openings -- kswcpp returns at once (kswcpp_core.h:340-341)
+        P = ma_amd.Params.preset("default")
+        op = or_params("default", 1)
+        if scoring is not None:
+            for prm in (P, op):
+                prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
+        res = oidx.align(reads, op, threads=8)
+        out = {}
+        for on in ("1", "0"):
+            monkeypatch.setenv("MA_DP_1X1", on)
+            bt = ma_amd.Batch(idx, P, len(reads), nb + 64)
+            bt.set_reads(reads)
+            bt.align()
+            bt.sync()
+            assert_same_as_oracle(bt, res, len(reads), "1x1 shortcut %s, scoring %s" % (on, scoring))
+            jobs = bt.dp_jobs()
+            out[on] = (bt.counters().copy(), int(((jobs[:, 0] == 1) & (jobs[:, 1] == 1) & (jobs[:, 4] == 0)).sum()))
+            bt.close()
+        assert np.array_equal(out["1"][0], out["0"][0]), "work counters must not depend on who answers the 1 x 1 jobs"
+        assert int(out["1"][0][5]) == int(res["counters"][5])  # ksw calls as the oracle counts them
+        if scoring is None:
+            assert out["1"][1] > 2000  # there ARE such jobs in this read set
+    monkeypatch.delenv("MA_DP_1X1")
+    idx.close()
