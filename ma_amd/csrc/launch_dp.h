@@ -231,7 +231,8 @@ int ma_dp_batch( ma_batch* b )
             MA_HIP( hipMemsetAsync( c + CTR_PATH_BYTES, 0, 8, b->stream ) );
             MA_HIP( hipMemsetAsync( c + CTR_NEXT_SLOTS, 0, ( CTR_NEXT_SEED - CTR_NEXT_SLOTS ) * 8, b->stream ) ); // queues, N_REDO, CIG_WORDS
             MA_HIP( hipMemsetAsync( c + CTR_NEXT_BIG, 0, 16, b->stream ) );
-            MA_HIP( hipMemsetAsync( b->ez.p, 0, ( nSlots + 2 ) * sizeof( ma_ez ), b->stream ) );
+            // (the result records are NOT cleared: every listed job writes its own again, and the records of the 1 x 1 gap
+            // fills, which the enumeration wrote, must stay)
         }
         if( check_err( b, "ma_dp_batch(ksw)" ) )
             return 1;

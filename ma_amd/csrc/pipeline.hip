@@ -685,7 +685,7 @@ int ma_batch_counters( ma_batch* b, uint64_t out[ 8 ] )
     out[ 4 ] = b->hctr[ CTR_CELLS ] + b->hctr[ CTR_N_1X1 ];
     out[ 5 ] = b->hctr[ CTR_KSW_JOBS ] + b->hctr[ CTR_N_1X1 ];
     out[ 6 ] = b->hctr[ CTR_SEQ_BYTES ];
-    out[ 7 ] = b->hctr[ CTR_PATH_BYTES ] + 4 * b->hctr[ CTR_CIG_WORDS ];
+    out[ 7 ] = b->hctr[ CTR_PATH_BYTES ] + 4 * b->hctr[ CTR_CIG_WORDS ] + 5 * b->hctr[ CTR_N_1X1 ]; // (a 1 x 1 job: one back-trace step, one cigar word)
     return 0;
 }
 
