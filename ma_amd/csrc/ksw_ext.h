@@ -452,6 +452,13 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
     const i32 boundRate = max( 1, ( -sc_mis + sc_mch + 1 ) / 2 );
     const i32 nDiag = qlen + tlen - 1;
     bool stop = false;
+    // z-drop schedule.  The maximum of diagonal r + 1 is at least that of diagonal r minus (q + e) of the cheaper gap model: the
+    // best cell's right or lower neighbour can always open a gap from it (z is only ever clipped from above, and one of the two
+    // neighbours exists until the last cell of the rectangle).  After a diagonal with maximum m the test -- every cell at or
+    // below ez.max - zdrop - 1 -- can therefore not pass for ( m - (ez.max - zdrop - 1) ) / (q + e) diagonals.
+    const i32 qeDrop = max( 1, (i32)q + (i32)e );
+    const i32 zStep = J.zdrop >= 0 ? ( J.zdrop + qeDrop ) / qeDrop : 0x3fffffff;
+    i32 zNext = J.zdrop >= 0 ? 0 : 0x7fffffff;
     u32 nCells = 0; // < 2^32: qlen <= 256 cells on at most w + 1 diagonals
     for( i32 r = 0; r < nDiag && !stop; ++r )
     {
@@ -621,29 +628,32 @@ __device__ bool ksw_ext_core( const KswScoring& SC, const KswJobView& J, QF qbas
 #pragma unroll
         for( int s = 1; s < R; s++ )
             hm = pk_max( hm, Hm[ s ] );
-        // cheap wave-uniform tests instead of a full reduction: does any cell exceed ez.max, and (z-drop candidate)
-        // are all cells below ez.max - zdrop?  Only then the exact (max_H, max_t) of the diagonal is needed.
+        // a cheap wave-uniform test instead of a full reduction: does any cell exceed ez.max?
         const u32 ezpk = pk_bcast_s( (i32)ez.max );
         const bool newMax = __any( pk_max( hm, ezpk ) != ezpk ) != 0;
-        bool need = newMax;
-        if( !need && J.zdrop >= 0 && (i32)ez.max - J.zdrop - 1 >= -32768 )
+        if( newMax )
         {
-            const u32 tpk = pk_bcast_s( (i32)ez.max - J.zdrop - 1 );
-            need = __any( pk_max( hm, tpk ) != tpk ) == 0;
-        }
-        if( need )
-        {
-            if( newMax )
-            {
-                // (the z-drop branch cannot be taken on a raise)
-                ez.max = (u32)wave_max_i32( max( (i32)( hm << 16 ) >> 16, (i32)hm >> 16 ) ) & 0x7fffffffu;
+            // (the z-drop branch cannot be taken on a raise)
+            ez.max = (u32)wave_max_i32( max( (i32)( hm << 16 ) >> 16, (i32)hm >> 16 ) ) & 0x7fffffffu;
 #pragma unroll
-                for( int s = 0; s < R; s++ )
-                    snap[ s * 64 + lane ] = make_uint2( H[ s ], DD[ s ] );
-                pend = true, pSt0 = st0, pEn0 = en0, pR = r;
-            }
+            for( int s = 0; s < R; s++ )
+                snap[ s * 64 + lane ] = make_uint2( H[ s ], DD[ s ] );
+            pend = true, pSt0 = st0, pEn0 = en0, pR = r;
+            zNext = r + zStep; // this diagonal's maximum IS ez.max: see zStep
+        }
+        else if( __builtin_expect( r >= zNext, 0 ) )
+        {
+            // ---- z-drop (kswcpp_core.h:22-44) needs a diagonal whose maximum lies more than zdrop below ez.max; on the job's
+            // schedule (zStep below), not on every diagonal (round 4: a packed compare, a ballot and ~10 scalar instructions each)
+            const i32 thr = (i32)ez.max - J.zdrop - 1; // candidates: every cell at or below it
+            const i32 gm = wave_max_i32( max( (i32)( hm << 16 ) >> 16, (i32)hm >> 16 ) );
+            if( thr < -32768 )
+                zNext = r + 1; // (packed int16 cells cannot say: as before, no test while the threshold is out of range)
+            else if( gm > thr )
+                zNext = r + ( gm - thr + qeDrop - 1 ) / qeDrop; // >= r + 1
             else
             {
+                zNext = r + 1; // every cell is below the threshold: the test is due on every diagonal from here on
                 i32 mH, mT;
                 exactMax( H, DD, st0, en0, mH, mT );
                 resolvePending( );
