@@ -164,6 +164,26 @@ int ma_dp_batch( ma_batch* b )
             O.cig_words = c + CTR_CIG_WORDS;
             {
                 EvTimer t( b, 4 );
+                // (experiment MA_CU_SPLIT: the DP kernels on the batch's second stream, masked to the other CUs)
+                hipStream_t dpStream = b->cuDp ? b->cuDp : b->stream;
+                if( dpStream != b->stream )
+                {
+                    MA_HIP( hipEventRecord( b->cuFork, b->stream ) );
+                    MA_HIP( hipStreamWaitEvent( dpStream, b->cuFork, 0 ) );
+                }
+                struct Rejoin // the batch's stream continues when the DP kernels are done, whichever way this block is left
+                {
+                    ma_batch* b;
+                    hipStream_t dp;
+                    ~Rejoin( )
+                    {
+                        if( dp != b->stream )
+                        {
+                            (void)hipEventRecord( b->cuJoin, dp );
+                            (void)hipStreamWaitEvent( b->stream, b->cuJoin, 0 );
+                        }
+                    }
+                } xRejoin{ b, dpStream };
                 // long reads: every kernel class on its own stream (ksw_launch.h), longest jobs first
                 const bool longReads = b->max_qlen > 254 && !dp_one_stream( );
                 if( longReads && !b->kswSide.ready( ) )
@@ -184,16 +204,16 @@ int ma_dp_batch( ma_batch* b )
                         u32* list = b->clsLists.as<u32>( ) + (u64)k * nSlots;
                         if( b->sortKey.reserve( nk * 4 ) || b->sortKey2.reserve( nk * 4 ) || b->sortVal2.reserve( nk * 4 ) )
                             return 1;
-                        hipLaunchKernelGGL( k_job_cost, dim3( (unsigned)( ( nk + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, F, list, (u32)nk,
+                        hipLaunchKernelGGL( k_job_cost, dim3( (unsigned)( ( nk + 255 ) / 256 ) ), dim3( 256 ), 0, dpStream, F, list, (u32)nk,
                                             b->sortKey.as<u32>( ) );
                         size_t tb = 0;
                         MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( nullptr, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
-                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 32, b->stream ) );
+                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 32, dpStream ) );
                         if( b->cubTmp.reserve( tb + 256 ) )
                             return 1;
                         MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( b->cubTmp.p, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
-                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 32, b->stream ) );
-                        MA_HIP( hipMemcpyAsync( list, b->sortVal2.p, nk * 4, hipMemcpyDeviceToDevice, b->stream ) );
+                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 32, dpStream ) );
+                        MA_HIP( hipMemcpyAsync( list, b->sortVal2.p, nk * 4, hipMemcpyDeviceToDevice, dpStream ) );
                     }
                 // the wavefront-sharing classes: sets of about equally long jobs (MA_KSW_GRP_SORT=0: A/B hook)
                 if( []( ) { const char* e = getenv( "MA_KSW_GRP_SORT" ); return !e || atoi( e ) != 0; }( ) )
@@ -205,18 +225,18 @@ int ma_dp_batch( ma_batch* b )
                         u32* list = b->clsLists.as<u32>( ) + (u64)k * nSlots;
                         if( b->sortKey.reserve( nk * 4 ) || b->sortKey2.reserve( nk * 4 ) || b->sortVal2.reserve( nk * 4 ) )
                             return 1;
-                        hipLaunchKernelGGL( k_job_qlen, dim3( (unsigned)( ( nk + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, F, list, (u32)nk,
+                        hipLaunchKernelGGL( k_job_qlen, dim3( (unsigned)( ( nk + 255 ) / 256 ) ), dim3( 256 ), 0, dpStream, F, list, (u32)nk,
                                             b->sortKey.as<u32>( ) );
                         size_t tb = 0;
                         MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( nullptr, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
-                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 8, b->stream ) );
+                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 8, dpStream ) );
                         if( b->cubTmp.reserve( tb + 256 ) )
                             return 1;
                         MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( b->cubTmp.p, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
-                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 8, b->stream ) );
-                        MA_HIP( hipMemcpyAsync( list, b->sortVal2.p, nk * 4, hipMemcpyDeviceToDevice, b->stream ) );
+                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 8, dpStream ) );
+                        MA_HIP( hipMemcpyAsync( list, b->sortVal2.p, nk * 4, hipMemcpyDeviceToDevice, dpStream ) );
                     }
-                if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, b->stream,
+                if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, dpStream,
                                  b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ), (unsigned int*)( c + CTR_NEXT_BIG ),
                                  longReads ? &b->kswSide : nullptr ) )
                     return 1;

@@ -108,6 +108,10 @@ struct ma_batch
     DevBuf sortKey, sortKey2, sortVal2; // longest-job-first order of the DP job lists
     u64 cigPoolCap = 0, cigPoolMin = 0, nOpsCap = 0, nJobSlots = 0;
     KswSide kswSide; // created on first use
+    // MA_CU_SPLIT=<n> (experiment, tools/overlap_matrix.py): the batch's kernels run on a stream masked to CUs [0, n) -- the
+    // memory-bound front end -- and its DP kernels on one masked to CUs [n, 256)
+    hipStream_t cuFront = nullptr, cuDp = nullptr;
+    hipEvent_t cuFork = nullptr, cuJoin = nullptr;
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
     bool timing = false;
     bool blocking = false; // batch_wait: sleep on an event instead of spinning
@@ -226,6 +230,13 @@ int ma_batch_destroy( ma_batch* b )
             (void)hipEventDestroy( b->ev[ i ] );
     if( b->waitEv )
         (void)hipEventDestroy( b->waitEv );
+    if( b->cuFront )
+    {
+        (void)hipStreamDestroy( b->cuFront );
+        (void)hipStreamDestroy( b->cuDp );
+        (void)hipEventDestroy( b->cuFork );
+        (void)hipEventDestroy( b->cuJoin );
+    }
     if( b->kswSide.fork )
     {
         (void)hipEventDestroy( b->kswSide.fork );
@@ -246,6 +257,25 @@ int ma_batch_set_stream( ma_batch* b, void* s )
     if( !b )
         return fail( "ma_batch_set_stream: null batch" );
     b->stream = (hipStream_t)s;
+    // The CU-partition experiment: instead of the caller's stream the batch uses two streams of its own,
+    // masked to disjoint sets of CUs (hipExtStreamCreateWithCUMask; bit i = CU i as the runtime numbers them)
+    if( const char* e = getenv( "MA_CU_SPLIT" ) )
+    {
+        const int n = atoi( e );
+        if( n > 0 && n < 256 && !b->cuFront )
+        {
+            MA_BIND_DEVICE( b->device );
+            uint32_t front[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dp[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+            for( int i = 0; i < 256; i++ )
+                ( i < n ? front : dp )[ i >> 5 ] |= 1u << ( i & 31 );
+            MA_HIP( hipExtStreamCreateWithCUMask( &b->cuFront, 8, front ) );
+            MA_HIP( hipExtStreamCreateWithCUMask( &b->cuDp, 8, dp ) );
+            MA_HIP( hipEventCreateWithFlags( &b->cuFork, hipEventDisableTiming ) );
+            MA_HIP( hipEventCreateWithFlags( &b->cuJoin, hipEventDisableTiming ) );
+        }
+        if( b->cuFront )
+            b->stream = b->cuFront;
+    }
     return 0;
 }
 
