@@ -93,8 +93,8 @@ def pmc_replay(read_len, reads_per_step, preset, genome_scale, stage):
     the pass was collected with other kernel sources than the ones libma_amd.so is built from now."""
     cur = kernel_source_hash()
     reason = "no PMC pass of this workload under profiles/"
-    for src in (os.path.join("profiles", "r04_pmc_traffic.json"), os.path.join("profiles", "r03_pmc_traffic.json"),
-                os.path.join("profiles", "r02_pmc_traffic.json")):
+    for src in (os.path.join("profiles", "r05_pmc_traffic.json"), os.path.join("profiles", "r04_pmc_traffic.json"),
+                os.path.join("profiles", "r03_pmc_traffic.json"), os.path.join("profiles", "r02_pmc_traffic.json")):
         try:
             with open(os.path.join(ROOT, src)) as f:
                 doc = json.load(f)

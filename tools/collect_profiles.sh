@@ -5,7 +5,7 @@
 #   -> gpurun_out/prof_<tag>_<workload>/{kernel_stats.csv,summary.txt,pmc_counters.csv}, entry added to profiles-style
 #      gpurun_out/prof_<tag>_pmc_traffic.json
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 WL=${2:-150bp}
 PRESET=${3:-default}
 OUT=gpurun_out/prof_${TAG}_$WL

@@ -21,6 +21,9 @@ def group_of(name):
     m = re.search(r"k_ksw_ext<.*?, (\d)>\(", name)
     if m:
         return "k_ksw_ext<%s>" % m.group(1)
+    m = re.search(r"k_ksw_grp<.*?, (\d), (true|false)>\(", name)
+    if m:
+        return "k_ksw_grp<%s>" % m.group(1)  # (several short extension jobs per wavefront: ksw_grp.h)
     for g, pats in GROUPS:
         if any(p in name for p in pats):
             return g

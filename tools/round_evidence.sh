@@ -5,7 +5,7 @@
 # k_ksw_pk<5>, SQ counters of the 10 kb DP stage, launch timelines.  tools/evidence_to_profiles.sh copies what is to be judged
 # from gpurun_out/ into profiles/ (profiles/README.md).
 #   usage: bash tools/round_evidence.sh [tag=r04]
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/${TAG}_gpu_tests.txt
