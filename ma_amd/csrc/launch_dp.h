@@ -217,25 +217,34 @@ int ma_dp_batch( ma_batch* b )
                     }
                 // the wavefront-sharing classes: sets of about equally long jobs (MA_KSW_GRP_SORT=0: A/B hook)
                 if( []( ) { const char* e = getenv( "MA_KSW_GRP_SORT" ); return !e || atoi( e ) != 0; }( ) )
-                    for( int k = KSW_CLS_GRP0 + 2; k < KSW_N_CLASSES; k++ )
+                {
+                    GrpSortArgs G;
+                    u64 most = 0, all = 0;
+                    for( int k = 0; k < KSW_GRP_SORT_LISTS; k++ ) // (qlen <= 64 here: the lengths fit the 128 bins)
                     {
-                        const u64 nk = S.cls[ k ];
-                        if( nk < 8192 )
-                            continue;
-                        u32* list = b->clsLists.as<u32>( ) + (u64)k * nSlots;
-                        if( b->sortKey.reserve( nk * 4 ) || b->sortKey2.reserve( nk * 4 ) || b->sortVal2.reserve( nk * 4 ) )
-                            return 1;
-                        hipLaunchKernelGGL( k_job_qlen, dim3( (unsigned)( ( nk + 255 ) / 256 ) ), dim3( 256 ), 0, dpStream, F, list, (u32)nk,
-                                            b->sortKey.as<u32>( ) );
-                        size_t tb = 0;
-                        MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( nullptr, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
-                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 8, dpStream ) );
-                        if( b->cubTmp.reserve( tb + 256 ) )
-                            return 1;
-                        MA_HIP( hipcub::DeviceRadixSort::SortPairsDescending( b->cubTmp.p, tb, b->sortKey.as<u32>( ), b->sortKey2.as<u32>( ), list,
-                                                                              b->sortVal2.as<u32>( ), (int)nk, 0, 8, dpStream ) );
-                        MA_HIP( hipMemcpyAsync( list, b->sortVal2.p, nk * 4, hipMemcpyDeviceToDevice, dpStream ) );
+                        const int cls = KSW_CLS_GRP0 + 2 + k;
+                        G.n[ k ] = (u32)S.cls[ cls ];
+                        G.list[ k ] = b->clsLists.as<u32>( ) + (u64)cls * nSlots;
+                        most = std::max<u64>( most, S.cls[ cls ] );
+                        all += S.cls[ cls ];
                     }
+                    if( all >= 8192 )
+                    {
+                        if( b->sortVal2.reserve( all * 4 + 64 ) || b->sortKey.reserve( KSW_GRP_SORT_LISTS * 2 * 128 * 4 ) )
+                            return 1;
+                        u64 at = 0;
+                        for( int k = 0; k < KSW_GRP_SORT_LISTS; k++ )
+                        {
+                            G.tmp[ k ] = b->sortVal2.as<u32>( ) + at;
+                            at += G.n[ k ];
+                        }
+                        G.hist = b->sortKey.as<u32>( );
+                        MA_HIP( hipMemsetAsync( G.hist, 0, KSW_GRP_SORT_LISTS * 2 * 128 * 4, dpStream ) );
+                        const dim3 grid( (unsigned)std::min<u64>( 1024, ( most + 255 ) / 256 ), KSW_GRP_SORT_LISTS );
+                        hipLaunchKernelGGL( k_grp_hist, grid, dim3( 256 ), 0, dpStream, F, G );
+                        hipLaunchKernelGGL( k_grp_scatter, grid, dim3( 256 ), 0, dpStream, F, G );
+                    }
+                }
                 if( ksw_run_all( F, SC, (u32)nSlots, S, b->kswScratch, (unsigned int*)( c + CTR_NEXT_SLOTS ), O, dpStream,
                                  b->clsLists.as<u32>( ), nSlots, (unsigned int*)( c + CTR_N_REDO ), (unsigned int*)( c + CTR_NEXT_BIG ),
                                  longReads ? &b->kswSide : nullptr ) )

@@ -362,12 +362,64 @@ __global__ void k_job_cost( PipeFetch F, const u32* list, u32 n, u32* key )
 }
 
 // Jobs that share a wavefront run in lock-step until the longest of them is done (ksw_grp.h): the lists of those classes are
-// sorted by query length, so that the jobs of a set are about equally long (unsorted: 1.7x the diagonals four jobs need).
-__global__ void k_job_qlen( PipeFetch F, const u32* list, u32 n, u32* key )
+// ordered by query length, longest first, so that the jobs of a set are about equally long (unsorted: 1.7x the diagonals four
+// jobs need).  A counting sort over the <= 128 possible lengths, all lists in two launches (a radix sort per list was 45
+// launches per step): k_grp_hist copies every list aside and counts its lengths, k_grp_scatter puts the entries back at
+// start-of-its-length + a running index.  The order among jobs of equal length is arbitrary; no result depends on it.
+#define KSW_GRP_SORT_LISTS 4
+struct GrpSortArgs
 {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if( i < n )
-        key[ i ] = (u32)F.view( list[ i ] ).qlen;
+    u32* list[ KSW_GRP_SORT_LISTS ]; // in place
+    u32* tmp[ KSW_GRP_SORT_LISTS ];
+    u32 n[ KSW_GRP_SORT_LISTS ];
+    u32* hist; // KSW_GRP_SORT_LISTS x 2 x 128 words, zeroed: [l][0][len] = jobs of that length, [l][1][len] = running index
+};
+// (same-address device atomics serialise in L2 at ~9 ns each: a block counts in LDS and touches every global counter once)
+__global__ void k_grp_hist( PipeFetch F, GrpSortArgs A )
+{
+    const int l = blockIdx.y;
+    __shared__ u32 h[ 128 ];
+    if( threadIdx.x < 128 )
+        h[ threadIdx.x ] = 0;
+    __syncthreads( );
+    for( u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n[ l ]; i += gridDim.x * blockDim.x )
+    {
+        const u32 slot = A.list[ l ][ i ];
+        A.tmp[ l ][ i ] = slot;
+        atomicAdd( &h[ (u32)F.view( slot ).qlen & 127u ], 1u );
+    }
+    __syncthreads( );
+    if( threadIdx.x < 128 && h[ threadIdx.x ] )
+        atomicAdd( A.hist + ( l * 2 + 0 ) * 128 + threadIdx.x, h[ threadIdx.x ] );
+}
+__global__ void k_grp_scatter( PipeFetch F, GrpSortArgs A )
+{
+    const int l = blockIdx.y;
+    __shared__ u32 start[ 128 ]; // where this block's entries of each length go: start of the length (longest first) + the block's reservation
+    __shared__ u32 h[ 128 ];
+    if( threadIdx.x < 128 )
+        h[ threadIdx.x ] = 0;
+    __syncthreads( );
+    for( u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n[ l ]; i += gridDim.x * blockDim.x )
+        atomicAdd( &h[ (u32)F.view( A.tmp[ l ][ i ] ).qlen & 127u ], 1u );
+    __syncthreads( );
+    if( threadIdx.x < 128 )
+    {
+        u32 before = 0;
+        for( u32 k = 127; k > threadIdx.x; k-- )
+            before += A.hist[ ( l * 2 + 0 ) * 128 + k ];
+        start[ threadIdx.x ] = before + ( h[ threadIdx.x ] ? atomicAdd( A.hist + ( l * 2 + 1 ) * 128 + threadIdx.x, h[ threadIdx.x ] ) : 0u );
+    }
+    __syncthreads( );
+    if( threadIdx.x < 128 )
+        h[ threadIdx.x ] = 0;
+    __syncthreads( );
+    for( u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n[ l ]; i += gridDim.x * blockDim.x )
+    {
+        const u32 slot = A.tmp[ l ][ i ];
+        const u32 len = (u32)F.view( slot ).qlen & 127u;
+        A.list[ l ][ start[ len ] + atomicAdd( &h[ len ], 1u ) ] = slot;
+    }
 }
 
 // ops capacity of a set: |Q| + sum of its jobs' cigar lengths + 8 * seeds + 16 (see nw.h)
