@@ -70,6 +70,15 @@ WORKLOADS = {
     # 150 bp table.  Parity sample only (the reference is timed on the Default preset's workloads)
     "illumina": dict(read_len=150, sub=0.005, ins=0.0, dele=0.0, seed=11, reads_per_step=1000000, steps=10, warmup=1,
                      cpu_sample=20000, baseline_config="configs[1] (C2), Illumina preset", preset="illumina", reference=False),
+    # configs[2] / configs[4] name "PacBio-CCS-like" and "ONT-like" reads: the same reads under the reference's PacBio and
+    # Nanopore parameter sets (parameter.h:1096-1104: >= 5 strips per read, up to 100 supplementary alignments; Nanopore: SMEM
+    # seeding).  One batch at a time, half a step's reads, a parity sample against the oracle; the CPU reference is timed on the
+    # Default set's workloads above.
+    "10kb_pacbio": dict(read_len=10000, sub=0.004, ins=0.003, dele=0.003, seed=12, reads_per_step=100000, steps=2, warmup=1,
+                        cpu_sample=2048, baseline_config="configs[2] (C3), PacBio preset", preset="pacbio", reference=False, single_only=True),
+    "50kb_nanopore": dict(read_len=50000, sub=0.03, ins=0.03, dele=0.04, seed=13, reads_per_step=10000, steps=2, warmup=1,
+                          cpu_sample=512, baseline_config="configs[4] (C5 shape, one GPU), Nanopore preset", preset="nanopore", reference=False,
+                          single_only=True),
 }
 
 
@@ -801,7 +810,7 @@ def run_legs(E, name, wl, args):
     a1.inflight, a1.host_io = 1, 0
     r = run_workload(E, name, wl, a1)
     nfl = args.overlap if wl["read_len"] <= 1000 else min(args.overlap, args.overlap_long)
-    if nfl > 1:
+    if nfl > 1 and not wl.get("single_only"):
         wl2 = dict(wl)
         wl2["steps"] = max(wl["steps"], 2 * nfl)  # every batch object gets at least two timed steps
         for key, hio in (("overlapped", 0), ("host_to_host", 1)):
@@ -840,7 +849,7 @@ def build_parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="all", choices=["all", "150bp", "10kb", "50kb", "illumina"])
+    ap.add_argument("--workload", default="all", choices=["all", "150bp", "10kb", "50kb", "illumina", "10kb_pacbio", "50kb_nanopore"])
     ap.add_argument("--reads-per-step", type=int, default=0, help="override the workload's reads per step")
     ap.add_argument("--read-len", type=int, default=0, help="custom single workload with --sub/--ins/--dele")
     ap.add_argument("--sub", type=float, default=0.005)
@@ -877,7 +886,7 @@ def main():
                                    reads_per_step=B, steps=args.steps, warmup=args.warmup, cpu_sample=None,
                                    baseline_config=None)))
     else:
-        for name in (["150bp", "10kb", "50kb", "illumina"] if args.workload == "all" else [args.workload]):
+        for name in (["150bp", "10kb", "50kb", "illumina", "10kb_pacbio", "50kb_nanopore"] if args.workload == "all" else [args.workload]):
             wl = dict(WORKLOADS[name])
             if wl["steps"] is None or args.workload != "all":
                 wl["steps"], wl["warmup"] = args.steps, args.warmup
@@ -940,7 +949,7 @@ def compose_line(E, args, results, boundary, anchor):
     # every workload as top-level scalars: host to host (the timed region of BASELINE.md section 3), device resident with the same
     # batches in flight, and one batch at a time (the leg the per-kernel roofline is measured on)
     for r in results:
-        n = {"150bp": "150bp", "10kb": "10kb", "50kb": "50kb", "illumina": "150bp_illumina"}.get(r["name"], r["name"])
+        n = {"150bp": "150bp", "10kb": "10kb", "50kb": "50kb", "illumina": "150bp_illumina"}.get(r["name"], r["name"])  # (+ 10kb_pacbio, 50kb_nanopore)
         v, ms, nb = leg_of(r, "host_to_host")
         if v is not None:
             out["value_%s" % n], out["ms_per_step_%s" % n], out["batches_in_flight_%s" % n] = v, ms, nb

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the round's committed numbers come from, in one GPU call (≈16 min of box time in round 4): parity tests, rocprofv3
+# Everything the round's committed numbers come from, in one GPU call (≈20 min of box time in round 5): parity tests, rocprofv3
 # kernel stats + PMC passes of the four workloads, the bench line (all workloads, three legs each, C1 anchor, boundary), the
 # kernel trace of the leg `value` comes from and its concurrency timeline, the overlap matrix, the phase profile of
 # k_ksw_pk<5>, SQ counters of the 10 kb DP stage, launch timelines.  tools/evidence_to_profiles.sh copies what is to be judged
@@ -15,6 +15,12 @@ cat gpurun_out/${TAG}_gpu_tests.txt
 for wl in 150bp 10kb 50kb; do bash tools/collect_profiles.sh $TAG $wl > gpurun_out/collect_$wl.log 2>&1; done
 bash tools/collect_profiles.sh $TAG 150bp illumina > gpurun_out/collect_illumina.log 2>&1
 cp gpurun_out/prof_${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
+# the ceilings the roofline fractions are quoted against, re-measured beside this build (tools/calibrate.sh without its PMC passes)
+mkdir -p gpurun_out/calib_$TAG tools/_prof
+hipcc --offload-arch=gfx950 -O3 tools/valu_mix.hip -o tools/_prof/valu_mix 2>/dev/null; hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -Wno-unused-result tools/gups.hip -o tools/_prof/gups 2>/dev/null
+tools/_prof/valu_mix > gpurun_out/calib_$TAG/valu_mix.txt 2>&1; tools/_prof/gups > gpurun_out/calib_$TAG/gups.txt 2>&1
+python3 tools/calibration_json.py gpurun_out/calib_$TAG > gpurun_out/${TAG}_calibration.json
+cp gpurun_out/${TAG}_calibration.json profiles/${TAG}_calibration.json
 # the driver's line (all workloads incl. the Illumina preset and the C1 anchor); its per-workload blocks go to the detail file
 python bench.py --detail-file gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 # the leg `value` comes from -- 150 bp, 3 batches in flight, host to host -- under rocprofv3 (program directly after --):
@@ -23,7 +29,12 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/tr_h2h -o tr --output-format csv 
 python3 tools/overlap_timeline.py $(find gpurun_out/tr_h2h -name "*kernel_trace.csv" | head -1) 3 1 > gpurun_out/${TAG}_overlap_timeline_150bp_h2h.txt
 find gpurun_out/tr_h2h -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_150bp_h2h_inflight3.csv \;
 grep "^{" gpurun_out/tr_h2h.log | tail -1 > gpurun_out/${TAG}_bench_150bp_h2h_inflight3_under_rocprof.json; rm -rf gpurun_out/tr_h2h
-python3 tools/overlap_matrix.py --workload 150bp --steps 12 --inflight 1,2,3 --waves 0,12,16,20 > gpurun_out/${TAG}_overlap_matrix_150bp.txt 2>/dev/null
+python3 tools/overlap_matrix.py --workload 150bp --steps 12 --inflight 1,3 --waves 0 --exclusive 0 --cu-split 0,64,96,128,160 > gpurun_out/${TAG}_overlap_matrix_150bp_cu_split.txt 2>/dev/null
+# the single-stream step launch by launch, and the phase profile of the kernel that runs several short extensions per wavefront
+rocprofv3 --kernel-trace -d gpurun_out/tr150 -o tr --output-format csv -- python3 bench.py --workload 150bp --steps 3 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/tr150.log 2>&1
+python3 tools/step_timeline.py gpurun_out/tr150 > gpurun_out/${TAG}_step_timeline_150bp.txt; rm -rf gpurun_out/tr150
+python3 tools/grp_prof.py --workload 150bp --overlap 0 --boundary-reads 0 2>/dev/null | grep "^G =" > gpurun_out/${TAG}_grp_phase_profile_150bp.txt
+python3 tools/binding_graph_rate.py > gpurun_out/${TAG}_binding_graph_rate.txt 2>&1
 python3 tools/pk_prof.py --workload 10kb 2>&1 | grep -v "^{" | grep -v "^bench detail:" | grep -v amdgpu.ids > gpurun_out/${TAG}_pk_phase_profile_10kb.txt
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU \
   -d gpurun_out/sq10 -o pmc --output-format csv -- python3 bench.py --workload 10kb --steps 1 --warmup 0 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/sq10.log 2>&1
