@@ -163,6 +163,11 @@ class Env:
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.gpu))
         torch.cuda.set_device(self.gpu)
         ma_amd.set_device(self.gpu)
+        # host threads next to the GPU: on the two-socket boxes of the pool the host-to-host leg runs ~10 % slower when the
+        # scheduler happens to place this process on the other socket; MA_BENCH_BIND=none / remote: A/B hooks
+        bind = os.environ.get("MA_BENCH_BIND", "local")
+        self.bound_cpus = ma_amd.bind_host_thread(self.gpu, 1 if bind == "remote" else 0) if bind != "none" else 0
+        self.bind = bind if self.bound_cpus else "none"
         self.dev = torch.device("cuda", self.gpu)
         self.L = ma_amd.lib()
         self.cal = load_calibration()
@@ -262,18 +267,30 @@ def run_workload(E, name, wl, args):
                    ma_amd.HostArray(int(c["alignments"] * 1.25) + 4096, ma_amd.ALIGNMENT_DT),
                    ma_amd.HostArray(int(2 * c["ops_cap"] * 1.25) + 4096, np.uint64))
 
+    h2h_only = os.environ.get("MA_BENCH_H2H", "")
+    phases = [np.zeros(4) for _ in range(NB)]  # host-to-host leg: seconds in upload / align + wait / download, steps
+
     def step(i, k):
         bt = batches[i][0]
         lo_r = k * B
         if host_io:
             j = k % hs
-            bt.set_reads_flat(hcodes.ptr + j * (max_bases + 64), hoffs.ptr + 8 * j * (B + 1), B)
+            t_a = time.perf_counter()
+            if h2h_only == "down":  # diagnostic (MA_BENCH_H2H=down): reads from HBM, results into host memory
+                bt.set_reads_device(codes.data_ptr() + int(offs_h[lo_r]), offs.data_ptr() + 8 * k * (B + 1), B, int(offs_h[lo_r + B] - offs_h[lo_r]))
+            else:
+                bt.set_reads_flat(hcodes.ptr + j * (max_bases + 64), hoffs.ptr + 8 * j * (B + 1), B)
+            t_b = time.perf_counter()
             bt.align()
             bt.sync()
-            if hout[i] is None or bt.mapq_alignments_into(*hout[i]) is None:
-                grow_out(i, bt.counts())  # first step of this batch object, or a step with more output than any before
-                if bt.mapq_alignments_into(*hout[i]) is None:
-                    raise RuntimeError("result arrays too small after growing them")
+            t_c = time.perf_counter()
+            if h2h_only != "up":  # diagnostic (MA_BENCH_H2H=up): reads from host memory, results stay in HBM
+                if hout[i] is None or bt.mapq_alignments_into(*hout[i]) is None:
+                    grow_out(i, bt.counts())  # first step of this batch object, or a step with more output than any before
+                    if bt.mapq_alignments_into(*hout[i]) is None:
+                        raise RuntimeError("result arrays too small after growing them")
+            t_d = time.perf_counter()
+            phases[i] += np.array([t_b - t_a, t_c - t_b, t_d - t_c, 1.0])
             return
         nbases = int(offs_h[lo_r + B] - offs_h[lo_r])
         bt.set_reads_device(codes.data_ptr() + int(offs_h[lo_r]), offs.data_ptr() + 8 * k * (B + 1), B, nbases)
@@ -315,13 +332,46 @@ def run_workload(E, name, wl, args):
 
     acc = [dict(kms=np.zeros(8), ctr=np.zeros(8), segs=0, aligned=0, err=None, wall=[], last=None) for _ in range(NB)]
 
+    # host-to-host leg, double-buffered (ma_batch_stage_reads ...): the reads of a batch object's NEXT step are uploaded and the
+    # results of its LAST step downloaded on the object's I/O stream while its kernels run; MA_BENCH_H2H_SERIAL=1: upload, kernels
+    # and download of a batch object one after the other (ma_batch_set_reads / ma_batch_get_mapq_alignments), the form of rounds 3-4
+    pipelined = bool(host_io) and n_reads > 0 and not h2h_only and os.environ.get("MA_BENCH_H2H_SERIAL") != "1"
+
+    def stage(i, k):
+        j = k % hs
+        batches[i][0].stage_reads_flat(hcodes.ptr + j * (max_bases + 64), hoffs.ptr + 8 * j * (B + 1), B)
+
+    def step_pipelined(i, k, k_next):
+        bt = batches[i][0]
+        t_a = time.perf_counter()
+        bt.use_staged_reads()
+        if k_next is not None:
+            stage(i, k_next)
+        t_b = time.perf_counter()
+        bt.align()
+        bt.sync()
+        t_c = time.perf_counter()
+        bt.finish_download()  # of the step before (its arrays are re-used)
+        if hout[i] is None or bt.start_mapq_download(*hout[i]) is None:
+            grow_out(i, bt.counts())
+            if bt.start_mapq_download(*hout[i]) is None:
+                raise RuntimeError("result arrays too small after growing them")
+        t_d = time.perf_counter()
+        phases[i] += np.array([t_b - t_a, t_c - t_b, t_d - t_c, 1.0])
+
     def worker(i):
         try:
             torch.cuda.set_device(E.gpu)
             a = acc[i]
-            for k in range(i, K, NB):
+            mine = list(range(i, K, NB))
+            if pipelined and mine:
+                stage(i, mine[0])
+            for at, k in enumerate(mine):
                 tk = time.perf_counter()
-                step(i, k)
+                if pipelined:
+                    step_pipelined(i, k, mine[at + 1] if at + 1 < len(mine) else None)
+                else:
+                    step(i, k)
                 bt = batches[i][0]
                 km = bt.kernel_ms().astype(np.float64)
                 a["wall"].append((time.perf_counter() - tk) * 1e3)
@@ -334,12 +384,16 @@ def run_workload(E, name, wl, args):
                 a["aligned"] += c["aligned_reads"]
                 a["segs"] += c["segments"]
                 a["last"] = k
+            if pipelined:
+                batches[i][0].finish_download()
         except Exception as e:  # surfaced after the join
             acc[i]["err"] = e
 
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    for ph in phases:
+        ph[:] = 0
     thr0 = cfs_throttle()
     t0 = time.perf_counter()
     if NB == 1:
@@ -363,7 +417,7 @@ def run_workload(E, name, wl, args):
     # cpu_baseline_and_parity covers; this ties the overlapped / host-to-host records to it byte for byte (a race between
     # concurrent batches -- shared DP scratch, result arrays re-allocated mid-run -- would show here).
     xleg = None
-    if (NB > 1 or host_io) and n_reads > 0 and not os.environ.get("MA_BENCH_NO_XLEG"):
+    if (NB > 1 or host_io) and n_reads > 0 and not os.environ.get("MA_BENCH_NO_XLEG") and not h2h_only:
         xleg = cross_leg_parity(batches, hout, acc, host_io, hs, B, K, codes, offs, offs_h)
     kms = sum(a["kms"] for a in acc)
     walls = [w for a in acc for w in a["wall"]]
@@ -427,7 +481,8 @@ def run_workload(E, name, wl, args):
     if rank == 0:
         res = {
             "name": name, "baseline_config": wl.get("baseline_config"), "batches_in_flight": NB,
-            "io": "host to host (reads from page-locked host memory, flat results into page-locked host memory)" if host_io
+            "io": ("host to host (reads from page-locked host memory, flat results into page-locked host memory%s)" % (
+                       "; a batch object's next upload and last download run beside its kernels" if pipelined else "")) if host_io
                   else "device resident (reads and results stay in HBM)",
             "workload": "%d x %d bp reads (%.2f%% sub, %.2f%% ins, %.2f%% del), %s preset, %d reads/step %s" % (
                 n_global, read_len, 100 * wl["sub"], 100 * wl["ins"], 100 * wl["dele"], preset, B_total,
@@ -442,7 +497,16 @@ def run_workload(E, name, wl, args):
             "stream_waits": "blocking (event)" if blocking else "spinning (runtime default)",
             "cfs_throttled": None if thr0 is None or thr1 is None else {"periods": thr1[0] - thr0[0], "thread_seconds": round(thr1[1] - thr0[1], 3)},
             "host_cores": cores, "cross_leg_parity": xleg,
+            "host_threads": ("pinned to the %d CPUs %s the GPU (ma_host_bind_thread)" % (E.bound_cpus, "next to" if E.bind == "local" else "AWAY from")
+                             if E.bound_cpus else "not pinned"),
         }
+        if host_io:
+            ph = sum(phases)
+            if ph[3] > 0:  # wall time of a batch thread per step, by phase (the threads of the other batches run meanwhile)
+                res["host_phases_ms_per_step"] = {"upload": round(ph[0] / ph[3] * 1e3, 3), "align_and_wait": round(ph[1] / ph[3] * 1e3, 3),
+                                                  "download": round(ph[2] / ph[3] * 1e3, 3)}
+            if h2h_only:
+                res["io"] += "; MA_BENCH_H2H=%s (diagnostic: one direction only)" % h2h_only
         if host_io and hs < K:
             res["io"] += "; the page-locked staging holds the reads of %d steps: step k re-uses the reads of step k mod %d" % (hs, hs)
     for bt, _ in batches:
@@ -841,6 +905,8 @@ def run_legs(E, name, wl, args):
                       "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"], "roofline": rf2,
                       "cross_leg_parity": r2.get("cross_leg_parity"), "stream_waits": r2.get("stream_waits"),
                       "cfs_throttled": r2.get("cfs_throttled")}
+            if r2.get("host_phases_ms_per_step"):
+                r[key]["host_phases_ms_per_step"] = r2["host_phases_ms_per_step"]
     return r
 
 

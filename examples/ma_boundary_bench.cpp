@@ -244,6 +244,7 @@ int main( int argc, char** argv )
         ParameterSetManager xParams;
         xParams.setSelected( argv[ 4 ] );
         maCheck( ma_set_device( atoi( argv[ 5 ] ) ) );
+        maCheck( ma_host_bind_thread( atoi( argv[ 5 ] ), 0, nullptr ) ); // this thread and all it starts: the CPUs next to the GPU
         const unsigned uiHw = std::max( 1u, std::thread::hardware_concurrency( ) );
         const int iGraphThreads = argc >= 7 ? atoi( argv[ 6 ] ) : (int)std::min( 2048u, 8 * uiHw );
         std::shared_ptr<Pack> pPack;

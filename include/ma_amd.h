@@ -130,6 +130,14 @@ int ma_set_device( int device );
  * live in host memory only; this is what NucSeq / Alignment storage becomes on the way to and from the device.) */
 int ma_host_alloc( uint64_t bytes, void** out );
 int ma_host_free( void* p );
+/* Pins the CALLING host thread (and the threads it starts afterwards) to the CPUs next to GPU `device` -- the local_cpulist of
+ * its PCI function in sysfs.  On a two-socket node the threads that feed a device (launches, size read-backs, stream waits,
+ * the copies out of and into page-locked memory) run up to 12 % slower from the other socket, and where the scheduler puts them
+ * differs from run to run.  mode 0: the GPU's CPUs; 1: the OTHER CPUs (the experiment that shows the
+ * cost); -1: every CPU again.  *n_cpus (optional) = CPUs of the new mask, 0 when the mask was left alone (no topology
+ * information, a one-node host).  Fails only for a bad argument.  (No counterpart in the reference: its worker threads are
+ * placed by the OS, module.h:303-369.) */
+int ma_host_bind_thread( int device, int mode, int* n_cpus );
 
 /* ---- index: replaces FMIndex(std::string) / Pack(std::string) loading (fMIndex.h:952-955, pack.h:513-525) ---- */
 /* Upload an index whose arrays were read from the reference's own .bwt/.sa/.pac files. */
@@ -143,6 +151,7 @@ int ma_index_build( int32_t n_contigs, const uint64_t* contig_lens, const uint8_
 /* Same, for a genome that already lives in device memory as 1 byte/base codes. */
 int ma_index_build_device( int32_t n_contigs, const uint64_t* contig_lens, const void* d_codes, ma_index** out );
 int ma_index_destroy( ma_index* );
+int ma_index_device( const ma_index*, int* device ); /* the GPU the index lives on (every call on it binds to that device) */
 int ma_index_sizes( const ma_index*, uint64_t* n_words, uint64_t* n_sa, uint64_t* ref_len, int32_t* n_contigs );
 /* Download (for FMIndex::vStoreFMIndex-compatible files and for tests); any pointer may be NULL. */
 int ma_index_download( const ma_index*, uint32_t* bwt_words, int64_t* sa, uint64_t L2[ 5 ], int64_t* primary,
@@ -238,6 +247,25 @@ int ma_batch_get_hsets( ma_batch*, uint64_t* hset_off /*n+1*/, uint64_t* hseed_o
                         ma_seed* hseeds );
 int ma_batch_get_alignments( ma_batch*, uint64_t* aln_off /*n+1*/, ma_alignment* alns, uint64_t* ops /*2*n_ops*/ );
 int ma_batch_get_mapq_alignments( ma_batch*, uint64_t* aln_off /*n+1*/, ma_alignment* alns, uint64_t* ops );
+
+/* ---- double-buffered I/O of a batch object (the throughput form of the host-to-host path) ----
+ * ma_batch_set_reads / ma_batch_get_mapq_alignments put the upload before and the download after a batch's kernels: with B
+ * batch objects in flight every object spends that time with nothing of its own on the device.  These four calls move both
+ * onto an I/O stream of the batch object, beside its kernels:
+ *   ma_batch_stage_reads         starts the upload of the NEXT reads into the object's second read buffer and returns; the kernels
+ *                                of the current reads may be running.  `codes` / `offsets` must stay untouched until
+ *   ma_batch_use_staged_reads    has returned: it waits for that upload and makes the staged reads the object's reads (what
+ *                                ma_batch_set_reads does in one step).
+ *   ma_batch_start_mapq_download after ma_align_batch + ma_batch_sync: packs the MappingQuality records (the arrays of
+ *                                ma_batch_get_mapq_alignments, same capacities) on the batch's stream and starts their download
+ *                                on the I/O stream; returns at once, the next reads may be aligned on the same object meanwhile.
+ *   ma_batch_finish_download     waits for it (no-op when none is pending); the host arrays are complete after it.
+ * One staged upload and one download can be pending per object.  (No counterpart in the reference, whose containers never
+ * leave host memory; the closest is its reader module pulling the next reads while the graph works, module.h:303-369.) */
+int ma_batch_stage_reads( ma_batch*, const uint8_t* codes, const uint64_t* offsets, uint64_t n_reads );
+int ma_batch_use_staged_reads( ma_batch* );
+int ma_batch_start_mapq_download( ma_batch*, uint64_t* aln_off /*n+1*/, ma_alignment* alns, uint64_t* ops );
+int ma_batch_finish_download( ma_batch* );
 /* work counters for the roofline model (same meaning as the oracle's): [0] extend_backward steps,
  * [1] distinct occ blocks touched, [2] bwt_sa LF steps, [3] SA rows, [4] DP band cells, [5] ksw jobs */
 int ma_batch_counters( ma_batch*, uint64_t out[ 8 ] );

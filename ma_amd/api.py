@@ -97,6 +97,14 @@ def set_device(d):
     _chk(lib().ma_set_device(C.c_int(d)))
 
 
+def bind_host_thread(device, mode=0):
+    """Pins the calling thread (and the threads it starts later) to the CPUs next to GPU `device` (ma_host_bind_thread); mode 1:
+    to the other CPUs, -1: to all again.  Returns the CPUs of the new mask, 0 when it was left alone."""
+    n = C.c_int(0)
+    _chk(lib().ma_host_bind_thread(C.c_int(device), C.c_int(mode), C.byref(n)))
+    return n.value
+
+
 class HostArray:
     """Page-locked host memory (ma_host_alloc) as a numpy array: uploads from it and downloads into it are DMA transfers
     that run asynchronously on the batch's stream, so the copies of one batch hide behind the kernels of another."""
@@ -435,6 +443,27 @@ class Batch:
             return None
         _chk(lib().ma_batch_get_mapq_alignments(self.h, C.c_void_p(off.ptr), C.c_void_p(alns.ptr), C.c_void_p(ops.ptr)))
         return c
+
+    # ---- double-buffered I/O (ma_batch_stage_reads ...): upload of the next reads and download of the last results beside the kernels
+    def stage_reads_flat(self, codes_ptr, offsets_ptr, n_reads):
+        _chk(lib().ma_batch_stage_reads(self.h, C.c_void_p(int(codes_ptr)), C.c_void_p(int(offsets_ptr)), C.c_uint64(n_reads)))
+        self._staged_n = n_reads
+
+    def use_staged_reads(self):
+        _chk(lib().ma_batch_use_staged_reads(self.h))
+        self.n = self._staged_n
+
+    def start_mapq_download(self, off, alns, ops):
+        """mapq_alignments_into without the wait: returns None when the arrays are too small, else the counts; the arrays are
+        complete after finish_download()."""
+        c = self.counts()
+        if off.n < self.n + 1 or alns.n < c["alignments"] + 1 or ops.n < 2 * c["ops_cap"] + 2:
+            return None
+        _chk(lib().ma_batch_start_mapq_download(self.h, C.c_void_p(off.ptr), C.c_void_p(alns.ptr), C.c_void_p(ops.ptr)))
+        return c
+
+    def finish_download(self):
+        _chk(lib().ma_batch_finish_download(self.h))
 
     def close(self):
         if self.h:

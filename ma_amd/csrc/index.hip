@@ -3,9 +3,13 @@
 #include "internal.h"
 #include "fm_device.h"
 #include <algorithm>
+#include <cctype>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <sched.h>
+#include <unistd.h>
 
 namespace ma
 {
@@ -88,6 +92,66 @@ int ma_host_free( void* p )
 {
     if( p )
         MA_HIP( hipHostFree( p ) );
+    return 0;
+}
+
+// The CPUs next to a GPU: /sys/bus/pci/devices/<domain:bus:device.function>/local_cpulist, e.g. "64-127,192-255".
+int ma_host_bind_thread( int device, int mode, int* n_cpus )
+{
+    if( n_cpus )
+        *n_cpus = 0;
+    if( mode < -1 || mode > 1 )
+        return fail( "ma_host_bind_thread: mode must be -1, 0 or 1" );
+    const long nConf = sysconf( _SC_NPROCESSORS_CONF );
+    if( nConf <= 0 || nConf > CPU_SETSIZE )
+        return 0;
+    cpu_set_t local, want;
+    CPU_ZERO( &local );
+    CPU_ZERO( &want );
+    if( mode >= 0 )
+    {
+        char bdf[ 64 ] = { 0 };
+        MA_HIP( hipDeviceGetPCIBusId( bdf, (int)sizeof( bdf ) - 1, device ) );
+        for( char* c = bdf; *c; ++c )
+            *c = (char)tolower( (unsigned char)*c );
+        char path[ 160 ];
+        snprintf( path, sizeof( path ), "/sys/bus/pci/devices/%s/local_cpulist", bdf );
+        FILE* f = fopen( path, "r" );
+        if( !f )
+            return 0; // no topology information: leave the thread where it is
+        char line[ 1024 ] = { 0 };
+        const bool got = fgets( line, (int)sizeof( line ) - 1, f ) != nullptr;
+        fclose( f );
+        if( !got )
+            return 0;
+        for( const char* c = line; *c; )
+        {
+            if( *c < '0' || *c > '9' )
+            {
+                ++c;
+                continue;
+            }
+            char* e = nullptr;
+            long a = strtol( c, &e, 10 ), z = a;
+            if( *e == '-' )
+                z = strtol( e + 1, &e, 10 );
+            for( long i = a; i <= z && i < nConf; i++ )
+                CPU_SET( (int)i, &local );
+            c = e;
+        }
+        if( CPU_COUNT( &local ) == 0 || CPU_COUNT( &local ) >= nConf )
+            return 0; // one node: nothing to choose
+    }
+    for( long i = 0; i < nConf; i++ )
+        if( mode < 0 || ( CPU_ISSET( (int)i, &local ) != 0 ) == ( mode == 0 ) )
+            CPU_SET( (int)i, &want );
+    // only CPUs the process may use at all (a cpuset of the container): the kernel intersects, and refuses an empty set
+    if( sched_setaffinity( 0, sizeof( want ), &want ) != 0 )
+        return 0;
+    cpu_set_t have;
+    CPU_ZERO( &have );
+    if( n_cpus && sched_getaffinity( 0, sizeof( have ), &have ) == 0 )
+        *n_cpus = CPU_COUNT( &have );
     return 0;
 }
 
@@ -327,6 +391,14 @@ int ma_index_destroy( ma_index* x )
     x->cstart.release( );
     x->clen.release( );
     delete x;
+    return 0;
+}
+
+int ma_index_device( const ma_index* x, int* device )
+{
+    if( !x || !device )
+        return fail( "ma_index_device: null argument" );
+    *device = x->device;
     return 0;
 }
 

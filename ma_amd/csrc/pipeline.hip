@@ -112,6 +112,14 @@ struct ma_batch
     // memory-bound front end -- and its DP kernels on one masked to CUs [n, 256)
     hipStream_t cuFront = nullptr, cuDp = nullptr;
     hipEvent_t cuFork = nullptr, cuJoin = nullptr;
+    // double-buffered I/O (ma_batch_stage_reads / ma_batch_start_mapq_download): the next reads are uploaded into reads2 / roff2
+    // and the packed results of the last step downloaded on ioStream while the batch's own stream runs kernels
+    DevBuf reads2, roff2;
+    hipStream_t ioStream = nullptr;
+    hipEvent_t evReadsFree = nullptr, evStaged = nullptr, evPacked = nullptr, evDown = nullptr;
+    bool stagedPending = false, downPending = false;
+    u64 stN = 0, stBases = 0;
+    u32 stMaxQ = 0;
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
     bool timing = false;
     bool blocking = false; // batch_wait: sleep on an event instead of spinning
@@ -230,6 +238,14 @@ int ma_batch_destroy( ma_batch* b )
             (void)hipEventDestroy( b->ev[ i ] );
     if( b->waitEv )
         (void)hipEventDestroy( b->waitEv );
+    if( b->ioStream )
+    {
+        (void)hipStreamSynchronize( b->ioStream );
+        (void)hipStreamDestroy( b->ioStream );
+        for( hipEvent_t e : { b->evReadsFree, b->evStaged, b->evPacked, b->evDown } )
+            if( e )
+                (void)hipEventDestroy( e );
+    }
     if( b->cuFront )
     {
         (void)hipStreamDestroy( b->cuFront );
@@ -299,6 +315,69 @@ int ma_batch_enable_timing( ma_batch* b, int on )
         b->evInit = true;
     }
     b->timing = on != 0;
+    return 0;
+}
+
+// ---- double-buffered I/O ------------------------------------------------------------------------------------------------
+static int io_init( ma_batch* b )
+{
+    if( b->ioStream )
+        return 0;
+    MA_HIP( hipStreamCreateWithFlags( &b->ioStream, hipStreamNonBlocking ) );
+    const unsigned fl = hipEventDisableTiming | ( b->blocking ? hipEventBlockingSync : 0u );
+    MA_HIP( hipEventCreateWithFlags( &b->evReadsFree, hipEventDisableTiming ) );
+    MA_HIP( hipEventCreateWithFlags( &b->evStaged, fl ) );
+    MA_HIP( hipEventCreateWithFlags( &b->evPacked, hipEventDisableTiming ) );
+    MA_HIP( hipEventCreateWithFlags( &b->evDown, fl ) );
+    return 0;
+}
+
+int ma_batch_stage_reads( ma_batch* b, const uint8_t* codes, const uint64_t* offsets, uint64_t n )
+{
+    if( !b || !offsets || ( n && !codes ) )
+        return fail( "ma_batch_stage_reads: null argument" );
+    MA_BIND_DEVICE( b->device );
+    if( n > b->max_reads || offsets[ n ] > b->max_bases )
+        return fail( "ma_batch_stage_reads: batch capacity exceeded" );
+    if( b->stagedPending )
+        return fail( "ma_batch_stage_reads: the reads staged before were not taken (ma_batch_use_staged_reads)" );
+    if( io_init( b ) || b->reads2.reserve( b->max_bases + 64 ) || b->roff2.reserve( ( b->max_reads + 1 ) * 8 ) )
+        return 1;
+    u32 mq = 0;
+    for( u64 i = 0; i < n; i++ )
+        mq = std::max<u32>( mq, (u32)( offsets[ i + 1 ] - offsets[ i ] ) );
+    b->stN = n, b->stBases = offsets[ n ], b->stMaxQ = mq;
+    // the second buffer held the reads of the step before the current one: everything that was enqueued on the batch's stream
+    // up to the last swap may still read it
+    if( b->evReadsFree )
+        MA_HIP( hipStreamWaitEvent( b->ioStream, b->evReadsFree, 0 ) );
+    if( b->stBases )
+        MA_HIP( hipMemcpyAsync( b->reads2.p, codes, b->stBases, hipMemcpyHostToDevice, b->ioStream ) );
+    MA_HIP( hipMemcpyAsync( b->roff2.p, offsets, ( n + 1 ) * 8, hipMemcpyHostToDevice, b->ioStream ) );
+    MA_HIP( hipEventRecord( b->evStaged, b->ioStream ) );
+    b->stagedPending = true;
+    return 0;
+}
+
+int ma_batch_use_staged_reads( ma_batch* b )
+{
+    if( !b )
+        return fail( "ma_batch_use_staged_reads: null batch" );
+    if( !b->stagedPending )
+        return fail( "ma_batch_use_staged_reads: no reads staged (ma_batch_stage_reads)" );
+    MA_BIND_DEVICE( b->device );
+    MA_HIP( hipEventSynchronize( b->evStaged ) );
+    MA_HIP( hipEventRecord( b->evReadsFree, b->stream ) ); // what runs on the stream now is the last reader of the old buffer
+    std::swap( b->reads, b->reads2 );
+    std::swap( b->roff, b->roff2 );
+    b->n_reads = b->stN;
+    b->n_bases = b->stBases;
+    b->max_qlen = b->stMaxQ;
+    b->d_reads = b->reads.as<uint8_t>( );
+    b->d_roff = b->roff.as<u64>( );
+    b->reads_external = false;
+    b->stage_done = 0;
+    b->stagedPending = false;
     return 0;
 }
 
@@ -845,12 +924,23 @@ int ma_batch_get_hsets( ma_batch* b, uint64_t* hset_off, uint64_t* hseed_off, ui
     return 0;
 }
 
-static int get_alns( ma_batch* b, bool mq, uint64_t* aln_off, ma_alignment* alns, uint64_t* ops )
+// async = the double-buffered form: the copies go to the I/O stream behind the pack kernels and nobody waits here
+static int get_alns( ma_batch* b, bool mq, uint64_t* aln_off, ma_alignment* alns, uint64_t* ops, bool async = false )
 {
     if( !b || b->stage_done < 4 )
         return fail( "ma_batch_get_alignments: stage not run" );
     MA_BIND_DEVICE( b->device );
     if( ma_batch_sync( b ) )
+        return 1;
+    if( b->downPending )
+    {
+        // the packed arrays are still being downloaded: nothing may overwrite them before that
+        if( async )
+            return fail( "ma_batch_start_mapq_download: the download started before was not finished (ma_batch_finish_download)" );
+        MA_HIP( hipEventSynchronize( b->evDown ) );
+        b->downPending = false;
+    }
+    if( async && io_init( b ) )
         return 1;
     const u64 n = b->n_reads, nh = b->nHsets;
     if( aln_off )
@@ -881,14 +971,44 @@ static int get_alns( ma_batch* b, bool mq, uint64_t* aln_off, ma_alignment* alns
                         b->ops.as<u64>( ), mq ? 1 : 0, b->outAlnOff.as<u64>( ), b->outOpsOff.as<u64>( ), b->outAlns.as<ma_alignment>( ),
                         b->outOpsPairs.as<u64>( ) );
     MA_HIP( hipGetLastError( ) );
+    hipStream_t cs = b->stream;
+    if( async )
+    {
+        cs = b->ioStream;
+        MA_HIP( hipEventRecord( b->evPacked, b->stream ) );
+        MA_HIP( hipStreamWaitEvent( cs, b->evPacked, 0 ) );
+    }
     if( aln_off )
-        MA_HIP( hipMemcpyAsync( aln_off, b->outAlnOff.p, ( n + 1 ) * 8, hipMemcpyDeviceToHost, b->stream ) );
+        MA_HIP( hipMemcpyAsync( aln_off, b->outAlnOff.p, ( n + 1 ) * 8, hipMemcpyDeviceToHost, cs ) );
     if( alns && totalA )
-        MA_HIP( hipMemcpyAsync( alns, b->outAlns.p, totalA * sizeof( ma_alignment ), hipMemcpyDeviceToHost, b->stream ) );
+        MA_HIP( hipMemcpyAsync( alns, b->outAlns.p, totalA * sizeof( ma_alignment ), hipMemcpyDeviceToHost, cs ) );
     if( ops && totalO )
-        MA_HIP( hipMemcpyAsync( ops, b->outOpsPairs.p, totalO * 16, hipMemcpyDeviceToHost, b->stream ) );
+        MA_HIP( hipMemcpyAsync( ops, b->outOpsPairs.p, totalO * 16, hipMemcpyDeviceToHost, cs ) );
+    if( async )
+    {
+        MA_HIP( hipEventRecord( b->evDown, cs ) );
+        b->downPending = true;
+        return 0;
+    }
     if( batch_wait( b ) )
         return 1;
+    return 0;
+}
+
+int ma_batch_start_mapq_download( ma_batch* b, uint64_t* aln_off, ma_alignment* alns, uint64_t* ops )
+{
+    return get_alns( b, true, aln_off, alns, ops, true );
+}
+
+int ma_batch_finish_download( ma_batch* b )
+{
+    if( !b )
+        return fail( "ma_batch_finish_download: null batch" );
+    if( !b->downPending )
+        return 0;
+    MA_BIND_DEVICE( b->device );
+    MA_HIP( hipEventSynchronize( b->evDown ) );
+    b->downPending = false;
     return 0;
 }
 

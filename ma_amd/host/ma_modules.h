@@ -1571,6 +1571,11 @@ class BatchAligner
         auto worker = [ & ]( size_t uiMe ) {
             try
             {
+                // threads this call starts itself run on the CPUs next to their replica's GPU (ma_host_bind_thread); worker 0 is
+                // the caller's thread and stays where the caller put it
+                int iDevice = 0;
+                if( uiMe != 0 && ma_index_device( vIndices[ vIndexOfWorker[ uiMe ] ], &iDevice ) == 0 )
+                    ma_host_bind_thread( iDevice, 0, nullptr );
                 detail::Engine& xEngine = *vEngines[ uiMe ];
                 for( ;; )
                 {

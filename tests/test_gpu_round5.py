@@ -374,3 +374,91 @@ def test_one_by_one_gap_fills_are_answered_by_the_enumeration(gpu_device, monkey
             assert out["1"][1] > 2000  # there ARE such jobs in this read set
     monkeypatch.delenv("MA_DP_1X1")
     idx.close()
+
+
+def test_double_buffered_io_of_a_batch_object(gpu_device):
+    """ma_batch_stage_reads / _use_staged_reads / _start_mapq_download / _finish_download: five different batches of reads go
+    through ONE batch object with the upload of the next reads and the download of the last results running beside the kernels;
+    every step's host arrays hold the bytes the serial calls (ma_batch_set_reads + ma_batch_get_mapq_alignments) return for the
+    same reads.  Misuse (two staged uploads, taking reads that were never staged, two pending downloads) fails with a message."""
+    import torch
+    import ma_amd
+    L = ma_amd.lib()
+    lens = np.array([300000, 200000, 150000], dtype=np.uint64)
+    F = int(lens.sum())
+    g = torch.empty(F, dtype=torch.uint8, device="cuda")
+    assert L.ma_synth_genome_device(C.c_uint64(7), C.c_uint64(F), C.c_int32(1), C.c_void_p(g.data_ptr())) == 0
+    idx = ma_amd.Index.build_device(lens, g.data_ptr())
+    P = ma_amd.Params.preset("default")
+    n, steps = 6000, 5
+    host = []
+    for k in range(steps):  # different read lengths and error rates per step: the buffers change size from step to step
+        rl = (150, 250, 100, 400, 150)[k]
+        codes, offs, nb = synth_reads(idx, 100 + k, n, rl, sub=0.01, ins=0.002, dele=0.002)
+        hc, ho = ma_amd.HostArray(nb + 64, np.uint8), ma_amd.HostArray(n + 1, np.uint64)
+        hc.a[:nb] = codes[:nb].cpu().numpy()
+        ho.a[:] = offs.cpu().numpy().astype(np.uint64)
+        host.append((hc, ho, nb))
+    cap = max(h[2] for h in host) + 64
+    # ---- serial reference: one object, set_reads + align + get
+    want = []
+    bt = ma_amd.Batch(idx, P, n, cap)
+    for hc, ho, nb in host:
+        bt.set_reads_flat(hc.ptr, ho.ptr, n)
+        bt.align()
+        bt.sync()
+        off, al, ops = bt.mapq_alignments()
+        na = int(off[n])
+        nops = int(al["ops_off"][na - 1] + al["n_ops"][na - 1]) if na else 0
+        want.append((off.copy(), al[:na].copy(), ops[:2 * nops].copy()))
+    bt.close()
+    # ---- double-buffered, on a stream of its own
+    st = torch.cuda.Stream()
+    bt = ma_amd.Batch(idx, P, n, cap)
+    bt.set_stream(st.cuda_stream)
+    with pytest.raises(RuntimeError, match="no reads staged"):
+        bt.use_staged_reads()
+    out = [(ma_amd.HostArray(n + 1, np.uint64), ma_amd.HostArray(4 * n, ma_amd.ALIGNMENT_DT), ma_amd.HostArray(200 * n, np.uint64))
+           for _ in range(2)]
+    bt.stage_reads_flat(host[0][0].ptr, host[0][1].ptr, n)
+    with pytest.raises(RuntimeError, match="not taken"):
+        bt.stage_reads_flat(host[1][0].ptr, host[1][1].ptr, n)
+    got = []
+    for k in range(steps):
+        bt.use_staged_reads()
+        if k + 1 < steps:
+            bt.stage_reads_flat(host[k + 1][0].ptr, host[k + 1][1].ptr, n)  # beside this step's kernels
+        bt.align()
+        bt.sync()
+        o = out[k & 1]
+        assert bt.start_mapq_download(*o) is not None
+        if k == 0:
+            with pytest.raises(RuntimeError, match="not finished"):
+                bt.start_mapq_download(*out[1])
+        if k > 0:  # the download of step k runs while step k - 1's arrays are read here
+            po = out[(k - 1) & 1]
+            got.append(tuple(x.a.copy() for x in po))
+        bt.finish_download()
+    got.append(tuple(x.a.copy() for x in out[(steps - 1) & 1]))
+    # (the arrays of step k - 1 were complete: finish_download of step k - 1 ran before they were copied)
+    for k, ((woff, wal, wops), (goff, gal, gops)) in enumerate(zip(want, got)):
+        na = int(woff[n])
+        assert np.array_equal(goff[:n + 1], woff), k
+        assert gal[:na].tobytes() == wal.tobytes(), k
+        assert np.array_equal(gops[:len(wops)], wops), k
+        assert na > 0.9 * n
+    # the serial calls still work on the same object afterwards, and wait for nothing that is not pending
+    bt.set_reads_flat(host[2][0].ptr, host[2][1].ptr, n)
+    bt.align()
+    bt.sync()
+    off, al, ops = bt.mapq_alignments()
+    assert np.array_equal(off, want[2][0]) and al[:int(off[n])].tobytes() == want[2][1].tobytes()
+    bt.finish_download()
+    bt.close()
+    for hc, ho, _ in host:
+        hc.close()
+        ho.close()
+    for o in out:
+        for x in o:
+            x.close()
+    idx.close()
