@@ -43,13 +43,8 @@ static __device__ unsigned long long g_grp_prof[ 24 ];
 #define KSW_GRP_STAGE_ROWS 32 // direction rows (128 B each) of the LDS ring: the last 17..32 diagonals of a set never leave the CU
 #define KSW_GRP_CIG_WORDS 256 // cigar words in LDS per wavefront (shared by its G groups)
 #define KSW_GRP_ROWS 516 // direction rows of a wavefront's scratch: a job leaves the regime at r > w, w <= 512
-#define KSW_GRP_LDS ( KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4 + 256 + 64 )
+#define KSW_GRP_LDS ( KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4 + 512 + 64 ) // (the target rings: 256 B per packed register of a lane)
 
-// cells of a job's group for G jobs per wavefront
-MA_HD i32 ksw_grp_cells( int G )
-{
-    return 128 / G;
-}
 // jobs per wavefront this job can share a wavefront with (0: not a job for this kernel).  Same regime as ksw_ext_slots,
 // extension jobs only (a global job's time is its set-up, and its callers read another cell).
 MA_HD int ksw_grp_size( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag )
@@ -58,7 +53,8 @@ MA_HD int ksw_grp_size( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdr
         return 0;
     if( zdrop > 16000 )
         return 0; // the z-drop threshold is kept as a packed int16
-    return qlen <= 32 ? 4 : ( qlen <= 64 ? 2 : ( qlen <= 128 && SC.grp >= 2 ? 1 : 0 ) ); // (one job per wave in this layout: MA_KSW_GRP=2, A/B)
+    // 4 / 2 jobs per wave with two rows per lane; 1 = two jobs per wave with FOUR rows per lane (MA_KSW_GRP=1 leaves those to k_ksw_ext<1>)
+    return qlen <= 32 ? 4 : ( qlen <= 64 ? 2 : ( qlen <= 128 && SC.grp >= 2 ? 1 : 0 ) );
 }
 
 template <int LANES> __device__ __forceinline__ i32 grp_max_i32( i32 v ) // maximum over the 64 / G lanes of a group, in every lane
@@ -84,56 +80,78 @@ template <int LANES> __device__ __forceinline__ i32 grp_max_i32( i32 v ) // maxi
 // half hi: row 2 l + 1): the 8 classes (t - st0) mod 8 over the chunks [st0, st0 + nS) keep their first maximum and the chunk
 // base it came from, (H[en0], en0) wins ties, max_t is the largest of the classes' positions (independent horizontal
 // maxima, sic); then the cells [st0 + nS, en0) one by one.  All values are per lane and equal within a group.
-template <int LANES>
-__device__ __forceinline__ void grp_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qlen, i32 tlen, int lane, int l, i32& mH, i32& mT )
+template <int LANES, int NR>
+__device__ __forceinline__ void grp_exact_max( const u32 ( &Hs )[ NR ], const u32 ( &Jpk )[ NR ], i32 rr, i32 qlen, i32 tlen, int lane, int l, i32& mH,
+                                               i32& mT )
 {
     const i32 st0 = max( 0, rr - qlen + 1 ), en0 = min( rr, tlen - 1 );
-    const u32 ddpk = pk_sub( pk_bcast( rr - st0 ), Jpk ); // t - st0 of the lane's two cells (mod 2^16; dead cells: >= 0x8000 or > en0 - st0)
-    const i32 j0 = rr - en0; // row of cell en0
-    const i32 hv = __builtin_amdgcn_ds_bpermute( ( ( lane - l ) + ( j0 >> 1 ) ) << 2, (i32)Hs );
+    const i32 j0 = rr - en0; // row of cell en0: half (j0 & 1) of register (j0 >> 1) % NR of lane j0 / (2 NR)
+    i32 hv = 0;
+#pragma unroll
+    for( int k = 0; k < NR; k++ )
+    {
+        const i32 v = __builtin_amdgcn_ds_bpermute( ( ( lane - l ) + j0 / ( 2 * NR ) ) << 2, (i32)Hs[ k ] );
+        hv = ( ( j0 >> 1 ) % NR ) == k ? v : hv;
+    }
     const i32 hEn0 = ( j0 & 1 ) ? ( hv >> 16 ) : ( (i32)( (u32)hv << 16 ) >> 16 );
     const i32 span = en0 - st0, nS = ( span / 8 ) * 8;
-    const u32 inv = pk_sub( 0xffffffffu, ddpk ); // 0xffff - (t - st0): earlier chunks win ties
-    const i32 lo = (i32)__builtin_amdgcn_perm( Hs, inv, 0x05040100u );
-    const i32 hi = (i32)__builtin_amdgcn_perm( Hs, inv, 0x07060302u );
-    const u32 dLo = ddpk & 0xffffu, dHi = ddpk >> 16;
     const i32 NONE = (i32)0x80000000;
-    i32 kLo = dLo < (u32)nS ? lo : NONE, kHi = dHi < (u32)nS ? hi : NONE;
-    // lanes with equal (l mod 4) hold the same two classes
-    kLo = max( kLo, dpp_ctrl<0x124>( kLo ) );
-    kHi = max( kHi, dpp_ctrl<0x124>( kHi ) );
-    kLo = max( kLo, dpp_ctrl<0x128>( kLo ) );
-    kHi = max( kHi, dpp_ctrl<0x128>( kHi ) );
-    if( LANES >= 32 )
+    // the class of a cell is (t - st0) mod 8 = (rr - st0 - j) mod 8: lanes 4 / NR apart hold the same 2 NR classes
+    i32 vh = hEn0, vt = NONE, tail = NONE; // (a class whose maximum does not beat H[en0] contributes en0 itself, below)
+#pragma unroll
+    for( int k = 0; k < NR; k++ )
     {
-        auto a16 = __builtin_amdgcn_permlane16_swap( (u32)kLo, (u32)kLo, false, false );
-        kLo = max( (i32)a16[ 0 ], (i32)a16[ 1 ] );
-        auto b16 = __builtin_amdgcn_permlane16_swap( (u32)kHi, (u32)kHi, false, false );
-        kHi = max( (i32)b16[ 0 ], (i32)b16[ 1 ] );
-    }
-    if( LANES == 64 )
-    {
-        auto a32 = __builtin_amdgcn_permlane32_swap( (u32)kLo, (u32)kLo, false, false );
-        kLo = max( (i32)a32[ 0 ], (i32)a32[ 1 ] );
-        auto b32 = __builtin_amdgcn_permlane32_swap( (u32)kHi, (u32)kHi, false, false );
-        kHi = max( (i32)b32[ 0 ], (i32)b32[ 1 ] );
-    }
-    mH = hEn0, mT = en0;
-    {
+        const u32 ddpk = pk_sub( pk_bcast( rr - st0 ), Jpk[ k ] ); // t - st0 of the two cells (mod 2^16; dead cells: >= 0x8000 or > en0 - st0)
+        const u32 inv = pk_sub( 0xffffffffu, ddpk ); // 0xffff - (t - st0): earlier chunks win ties
+        const i32 lo = (i32)__builtin_amdgcn_perm( Hs[ k ], inv, 0x05040100u );
+        const i32 hi = (i32)__builtin_amdgcn_perm( Hs[ k ], inv, 0x07060302u );
+        const u32 dLo = ddpk & 0xffffu, dHi = ddpk >> 16;
+        i32 kLo = dLo < (u32)nS ? lo : NONE, kHi = dHi < (u32)nS ? hi : NONE;
+        if( NR == 2 )
+        {
+            kLo = max( kLo, dpp_ctrl<0x122>( kLo ) );
+            kHi = max( kHi, dpp_ctrl<0x122>( kHi ) );
+        }
+        kLo = max( kLo, dpp_ctrl<0x124>( kLo ) );
+        kHi = max( kHi, dpp_ctrl<0x124>( kHi ) );
+        kLo = max( kLo, dpp_ctrl<0x128>( kLo ) );
+        kHi = max( kHi, dpp_ctrl<0x128>( kHi ) );
+        if( LANES >= 32 )
+        {
+            auto a16 = __builtin_amdgcn_permlane16_swap( (u32)kLo, (u32)kLo, false, false );
+            kLo = max( (i32)a16[ 0 ], (i32)a16[ 1 ] );
+            auto b16 = __builtin_amdgcn_permlane16_swap( (u32)kHi, (u32)kHi, false, false );
+            kHi = max( (i32)b16[ 0 ], (i32)b16[ 1 ] );
+        }
+        if( LANES == 64 )
+        {
+            auto a32 = __builtin_amdgcn_permlane32_swap( (u32)kLo, (u32)kLo, false, false );
+            kLo = max( (i32)a32[ 0 ], (i32)a32[ 1 ] );
+            auto b32 = __builtin_amdgcn_permlane32_swap( (u32)kHi, (u32)kHi, false, false );
+            kHi = max( (i32)b32[ 0 ], (i32)b32[ 1 ] );
+        }
         const i32 hl = kLo >> 16, hh = kHi >> 16;
         const i32 tl = ( kLo != NONE && hl > hEn0 ) ? st0 + ( ( 0xffff - ( kLo & 0xffff ) ) & ~7 ) : en0;
         const i32 th = ( kHi != NONE && hh > hEn0 ) ? st0 + ( ( 0xffff - ( kHi & 0xffff ) ) & ~7 ) : en0;
-        i32 vh = max( max( kLo != NONE ? hl : hEn0, kHi != NONE ? hh : hEn0 ), hEn0 ), vt = max( tl, th );
-        vh = max( vh, dpp_ctrl<0xB1>( vh ) ); // the four lanes of a quad hold the eight classes
-        vt = max( vt, dpp_ctrl<0xB1>( vt ) );
+        vh = max( vh, max( kLo != NONE ? hl : hEn0, kHi != NONE ? hh : hEn0 ) );
+        vt = max( vt, max( tl, th ) );
+        // the cells after the 8-lane part
+        const i32 tLo = ( dLo >= (u32)nS && dLo < (u32)span ) ? lo : NONE, tHi = ( dHi >= (u32)nS && dHi < (u32)span ) ? hi : NONE;
+        tail = max( tail, max( tLo, tHi ) );
+    }
+    // the 4 / NR lanes of a period hold the eight classes between them
+    vh = max( vh, dpp_ctrl<0xB1>( vh ) );
+    vt = max( vt, dpp_ctrl<0xB1>( vt ) );
+    if( NR == 1 )
+    {
         vh = max( vh, dpp_ctrl<0x4E>( vh ) );
         vt = max( vt, dpp_ctrl<0x4E>( vt ) );
-        if( nS > 0 )
-            mH = vh, mT = vt;
     }
+    mH = hEn0, mT = en0;
+    if( nS > 0 )
+        mH = vh, mT = vt;
     // the cells after the 8-lane part, in the order the reference visits them: the first of the largest wins, if it is larger
-    const i32 tLo = ( dLo >= (u32)nS && dLo < (u32)span ) ? lo : NONE, tHi = ( dHi >= (u32)nS && dHi < (u32)span ) ? hi : NONE;
-    const i32 tk = grp_max_i32<LANES>( max( tLo, tHi ) );
+    const i32 tk = grp_max_i32<LANES>( tail );
     if( tk != NONE && ( tk >> 16 ) > mH )
     {
         mH = tk >> 16;
@@ -143,8 +161,8 @@ __device__ __forceinline__ void grp_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qlen
 
 // One set of up to G jobs (queue entries [at0, min(at0 + G, n))), all of them left- (LEFT) or right-aligned extensions.
 // redo / nRedo: the hand-back list of the extension kernels.
-template <int G, bool LEFT, typename FETCH>
-__device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* list, u32 n, u32 at0, uint8_t* P /*KSW_GRP_ROWS x 128 B*/,
+template <int G, int NR, bool LEFT, typename FETCH>
+__device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* list, u32 n, u32 at0, uint8_t* P /*KSW_GRP_ROWS x 128 NR B*/,
                              uint8_t* lds, const KswOut& O, KswWaveAcc& acc, u32* redo, unsigned int* nRedo, unsigned long long* sOff
 #if defined( MA_KSW_PROF )
                              ,
@@ -152,17 +170,20 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
 #endif
 )
 {
-    constexpr int LANES = 64 / G, CJ = 128 / G;
+    // NR packed registers (2 NR rows) per lane: a group of 64 / G lanes holds CJ = 128 NR / G query rows; a direction row of the
+    // set is ROWB bytes, the LDS ring holds SR of them (4 KB whatever NR is)
+    constexpr int LANES = 64 / G, CJ = 128 * NR / G, ROWB = 128 * NR, SR = KSW_GRP_STAGE_ROWS / NR;
+    static_assert( NR == 1 || NR == 2, "two or four rows per lane" );
     const int lane = threadIdx.x & 63, g = lane / LANES, l = lane % LANES;
     GRP_PROF_T( tp0 );
     // Direction bytes: row r of the set (128 B: the G jobs' cells side by side) lives at ring slot r mod 32 in LDS.  Every 16
     // diagonals the 16 rows that the next 16 diagonals will overwrite are copied to the wave's HBM scratch (one coalesced 2 KB
     // copy), so at the end the ring holds the last 17..32 rows and HBM the older ones: the loop itself never stores to global
     // memory, and the back-trace starts on rows that never left the CU.
-    uint8_t* stage = lds; // KSW_GRP_STAGE_ROWS x 128
+    uint8_t* stage = lds; // SR x ROWB = KSW_GRP_STAGE_ROWS x 128
     u32* cigLds = (u32*)( lds + KSW_GRP_STAGE_ROWS * 128 ); // KSW_GRP_CIG_WORDS, CIGCAP per group
-    uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // G x 2 CJ bytes = 256
-    i32* gflag = (i32*)( tring + 256 ); // per group: scratch words
+    uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // G x 2 CJ bytes = 256 NR
+    i32* gflag = (i32*)( tring + 256 * NR ); // per group: scratch words
     constexpr u32 CIGCAP = KSW_GRP_CIG_WORDS / G;
     // ---- the group's job
     const bool has = at0 + (u32)g < n;
@@ -217,12 +238,17 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     const u32 V_SCHI = ( (u32)( -e2 ) & 0xffu ) | tS << 8;
     const u32 V_Q = pk_val( q, 0 ), V_Q2 = pk_val( q2, 0 ), V_QE = pk_val( q + e, 0 ), V_QE2 = pk_val( q2 + e2, 0 );
     const u32 M_LEADLO = l == 0 ? 0x0000ffffu : 0u; // the cell that takes the first-row boundary: row 0 of the group
-    // ---- static per lane: rows j = 2 l, 2 l + 1
-    const i32 j0 = 2 * l, j1 = 2 * l + 1;
-    const u32 Jpk = (u32)j0 | (u32)j1 << 16;
-    // rows of the job (cleared when it ends: a finished job's cells are dead)
-    u32 Jmask = ( has && !untouched && j0 < qlen ? 0x0000ffffu : 0u ) | ( has && !untouched && j1 < qlen ? 0xffff0000u : 0u );
-    u32 Qb = ( j0 < qlen ? (u32)qf( j0 ) & 0xffu : 4u ) | ( j1 < qlen ? (u32)qf( j1 ) & 0xffu : 4u ) << 16;
+    // ---- static per lane: rows j = 2 NR l + 2 k (low half of register k), + 1 (high half)
+    u32 Jpk[ NR ], Jmask[ NR ], Qb[ NR ];
+#pragma unroll
+    for( int k = 0; k < NR; k++ )
+    {
+        const i32 j0 = 2 * NR * l + 2 * k, j1 = j0 + 1;
+        Jpk[ k ] = (u32)j0 | (u32)j1 << 16;
+        // rows of the job (cleared when it ends: a finished job's cells are dead)
+        Jmask[ k ] = ( has && !untouched && j0 < qlen ? 0x0000ffffu : 0u ) | ( has && !untouched && j1 < qlen ? 0xffff0000u : 0u );
+        Qb[ k ] = ( j0 < qlen ? (u32)qf( j0 ) & 0xffu : 4u ) | ( j1 < qlen ? (u32)qf( j1 ) & 0xffu : 4u ) << 16;
+    }
     auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t + 1 (codes as in ksw_ext.h: an N of the target is 12)
         if( t >= tlen )
             return 0u;
@@ -234,22 +260,33 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     };
     // the group's target ring: bytes t mod 2 CJ; all of it now, CJ bytes more every CJ diagonals
     uint8_t* myRing = tring + g * ( 2 * CJ );
-    auto fillRing = [ & ]( i32 tFrom ) { // cells tFrom + 2 l, tFrom + 2 l + 1
-        const i32 t = tFrom + 2 * l;
-        const u32 ab = has ? tgt2( t ) : 0u;
-        *(uint16_t*)( myRing + ( t & ( 2 * CJ - 1 ) ) ) = (uint16_t)( ( ab & 0xffu ) | ( ab >> 8 & 0xff00u ) );
+    auto fillRing = [ & ]( i32 tFrom ) { // CJ cells from tFrom on: every lane its 2 NR
+#pragma unroll
+        for( int k = 0; k < NR; k++ )
+        {
+            const i32 t = tFrom + 2 * NR * l + 2 * k;
+            const u32 ab = has ? tgt2( t ) : 0u;
+            *(uint16_t*)( myRing + ( t & ( 2 * CJ - 1 ) ) ) = (uint16_t)( ( ab & 0xffu ) | ( ab >> 8 & 0xff00u ) );
+        }
     };
     fillRing( 0 );
     fillRing( CJ );
-    u32 V = ( ( (u32)initOf( j0 ) & 0xffu ) << 8 ) | ( ( (u32)initOf( j1 ) & 0xffu ) << 24 ); // first-column v of the rows
-    u32 X = K_X0, X2 = K_X20, U = 0, Y = K_Y0, Y2 = K_Y20, T = 0;
-    u32 H = ( (u32)hBoundary( j0 + 1 ) & 0xffffu ) | (u32)hBoundary( j1 + 1 ) << 16; // H(-1, j)
-    u32 Tpk = pk_sub( 0u, Jpk ); // t = r - j of the lane's cells
+    u32 V[ NR ], X[ NR ], X2[ NR ], U[ NR ], Y[ NR ], Y2[ NR ], T[ NR ], H[ NR ], Tpk[ NR ], snapH[ NR ];
+#pragma unroll
+    for( int k = 0; k < NR; k++ )
+    {
+        const i32 j0 = 2 * NR * l + 2 * k, j1 = j0 + 1;
+        V[ k ] = ( ( (u32)initOf( j0 ) & 0xffu ) << 8 ) | ( ( (u32)initOf( j1 ) & 0xffu ) << 24 ); // first-column v of the rows
+        X[ k ] = K_X0, X2[ k ] = K_X20, U[ k ] = 0, Y[ k ] = K_Y0, Y2[ k ] = K_Y20, T[ k ] = 0;
+        H[ k ] = ( (u32)hBoundary( j0 + 1 ) & 0xffffu ) | (u32)hBoundary( j1 + 1 ) << 16; // H(-1, j)
+        Tpk[ k ] = pk_sub( 0u, Jpk[ k ] ); // t = r - j of the lane's cells
+        snapH[ k ] = 0;
+    }
     const u32 tlenpk = pk_bcast( tlen );
     // ---- per group, equal in all lanes of the group.  Flags are 0 / -1 words, not bools: a bool that lives across the loop is
     // an exec-style mask pair in SGPRs, and the scalar file is full of the kernel's arguments.
     i32 ezmax = 0, maxT = -1, maxQ = -1, pR = 0;
-    u32 ezpk = 0, snapH = 0;
+    u32 ezpk = 0;
     i32 act = has && !untouched ? -1 : 0, handBack = 0, pend = 0, zdropped = 0;
     i32 boundPrev = 0x7fffffff, nextBound = 0;
     const i32 boundRate = max( 1, ( -sc_mis + sc_mch + 1 ) / 2 );
@@ -261,7 +298,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     // ( m - (ez.max - zdrop - 1) ) / (q + e) diagonals: a job's next test is scheduled like its next bound evaluation.
     i32 zNext = zdrop >= 0 ? 0 : 0x7fffffff;
     const i32 zStep = zdrop >= 0 ? ( zdrop + qe ) / qe : 0x3fffffff; // diagonals after a raise before the test can pass
-    const u32 laneOff = (u32)( g * CJ + 2 * l ); // the lane's two bytes of a direction row
+    const u32 laneOff = (u32)( g * CJ + 2 * NR * l ); // the lane's 2 NR bytes of a direction row
     i32 uInS = initOf( 0 ); // first-row initialisation of cell t = r (wave-uniform: the scoring is)
     i32 ringLo = 0; // rows below it have been copied to HBM (wave-uniform)
     __syncthreads( );
@@ -275,7 +312,9 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             handBack |= rEnd < nDiag ? ends : 0;
             rLast = ends ? r - 1 : rLast;
             act &= ~ends;
-            Jmask &= (u32)~ends;
+#pragma unroll
+            for( int k = 0; k < NR; k++ )
+                Jmask[ k ] &= (u32)~ends;
         }
         if( !__any( act != 0 ) ) // (wave-uniform: no lane leaves the loop before the others)
             break;
@@ -286,84 +325,115 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             fillRing( r + CJ );
             __syncthreads( );
         }
-        if( __builtin_expect( r >= KSW_GRP_STAGE_ROWS && ( r & ( KSW_GRP_STAGE_ROWS / 2 - 1 ) ) == 0, 0 ) )
+        if( __builtin_expect( r >= SR && ( r & ( SR / 2 - 1 ) ) == 0, 0 ) )
         {
-            // rows [r - 32, r - 16) -> HBM: their ring slots are the ones rows r .. r + 15 take (32 B per lane)
+            // rows [r - SR, r - SR / 2) -> HBM: their ring slots are the ones rows r .. r + SR / 2 - 1 take (2 KB: 32 B per lane)
             __syncthreads( );
-            const uint4* src = (const uint4*)( stage + ( ( r - KSW_GRP_STAGE_ROWS ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 );
-            uint4* dst = (uint4*)( P + (size_t)( r - KSW_GRP_STAGE_ROWS ) * 128 );
+            const uint4* src = (const uint4*)( stage + ( ( r - SR ) & ( SR - 1 ) ) * ROWB );
+            uint4* dst = (uint4*)( P + (size_t)( r - SR ) * ROWB );
 #pragma unroll
             for( int k = 0; k < KSW_GRP_STAGE_ROWS / 16; k++ )
                 dst[ lane + 64 * k ] = src[ lane + 64 * k ];
-            ringLo = r - KSW_GRP_STAGE_ROWS / 2;
+            ringLo = r - SR / 2;
         }
-        // ---- neighbours: u, y, y2 and the target base come from row j - 1
+        // ---- neighbours: u, y, y2 and the target base come from row j - 1: the previous lane's last register for the lane's first
+        // row, the lane's own registers for the others
         const u32 tIn = (u32)myRing[ r & ( 2 * CJ - 1 ) ];
-        u32 ut = cells_shift1( U, (u32)dpp_wave_shr1( (i32)U ) );
-        u32 yt = cells_shift1( Y, (u32)dpp_wave_shr1( (i32)Y ) );
-        u32 y2t = cells_shift1( Y2, (u32)dpp_wave_shr1( (i32)Y2 ) );
-        u32 tt = cells_shift1( T, (u32)dpp_wave_shr1( (i32)T ) );
-        ut = pk_bfi( M_LEADLO, ( (u32)uInS & 0xffu ) << 8, ut );
-        yt = pk_bfi( M_LEADLO, K_Y0, yt );
-        y2t = pk_bfi( M_LEADLO, K_Y20, y2t );
-        tt = pk_bfi( M_LEADLO, tIn, tt );
-        // ---- live cells: 0 <= t <= tlen - 1 on a row of the job
-        const u32 LM = pk_opaque( pk_nonzero15( pk_subsatu( tlenpk, Tpk ) ) & Jmask );
-        // ---- score and DP cell (kswcpp_core.h:598-766; ksw_ext.h)
-        const u32 sel = ( pk_minu( tt ^ Qb, 0x00040004u ) << 8 ) | 0x00050005u;
-        u32 z = __builtin_amdgcn_perm( V_SCHI, V_SCLO, sel );
-        u32 a = pk_add( X, V );
-        u32 b = pk_add( yt, ut );
-        u32 a2 = pk_add( X2, V );
-        u32 b2 = pk_add( y2t, ut );
-        u32 d;
-        if( LEFT )
+        u32 ut[ NR ], yt[ NR ], y2t[ NR ], tt[ NR ];
+        ut[ 0 ] = cells_shift1( U[ 0 ], (u32)dpp_wave_shr1( (i32)U[ NR - 1 ] ) );
+        yt[ 0 ] = cells_shift1( Y[ 0 ], (u32)dpp_wave_shr1( (i32)Y[ NR - 1 ] ) );
+        y2t[ 0 ] = cells_shift1( Y2[ 0 ], (u32)dpp_wave_shr1( (i32)Y2[ NR - 1 ] ) );
+        tt[ 0 ] = cells_shift1( T[ 0 ], (u32)dpp_wave_shr1( (i32)T[ NR - 1 ] ) );
+        ut[ 0 ] = pk_bfi( M_LEADLO, ( (u32)uInS & 0xffu ) << 8, ut[ 0 ] );
+        yt[ 0 ] = pk_bfi( M_LEADLO, K_Y0, yt[ 0 ] );
+        y2t[ 0 ] = pk_bfi( M_LEADLO, K_Y20, y2t[ 0 ] );
+        tt[ 0 ] = pk_bfi( M_LEADLO, tIn, tt[ 0 ] );
+#pragma unroll
+        for( int k = 1; k < NR; k++ )
         {
-            z = pk_max( pk_max( z, a ), pk_max( pk_max( b, a2 ), b2 ) );
-            d = pk_sub( 0x00040004u, z & 0x00070007u );
+            ut[ k ] = cells_shift1( U[ k ], U[ k - 1 ] );
+            yt[ k ] = cells_shift1( Y[ k ], Y[ k - 1 ] );
+            y2t[ k ] = cells_shift1( Y2[ k ], Y2[ k - 1 ] );
+            tt[ k ] = cells_shift1( T[ k ], T[ k - 1 ] );
         }
-        else
+        u32 LM[ NR ], Hm[ NR ], dirs[ NR ];
+#pragma unroll
+        for( int k = 0; k < NR; k++ )
         {
-            z = pk_max( pk_max( z, a ), pk_max( b, a2 ) );
-            d = z & 0x00070007u;
-            z = pk_max( z, b2 );
+            // ---- live cells: 0 <= t <= tlen - 1 on a row of the job
+            LM[ k ] = pk_opaque( pk_nonzero15( pk_subsatu( tlenpk, Tpk[ k ] ) ) & Jmask[ k ] );
+            // ---- score and DP cell (kswcpp_core.h:598-766; ksw_ext.h)
+            const u32 sel = ( pk_minu( tt[ k ] ^ Qb[ k ], 0x00040004u ) << 8 ) | 0x00050005u;
+            u32 z = __builtin_amdgcn_perm( V_SCHI, V_SCLO, sel );
+            u32 a = pk_add( X[ k ], V[ k ] );
+            u32 b = pk_add( yt[ k ], ut[ k ] );
+            u32 a2 = pk_add( X2[ k ], V[ k ] );
+            u32 b2 = pk_add( y2t[ k ], ut[ k ] );
+            u32 d;
+            if( LEFT )
+            {
+                z = pk_max( pk_max( z, a ), pk_max( pk_max( b, a2 ), b2 ) );
+                d = pk_sub( 0x00040004u, z & 0x00070007u );
+            }
+            else
+            {
+                z = pk_max( pk_max( z, a ), pk_max( b, a2 ) );
+                d = z & 0x00070007u;
+                z = pk_max( z, b2 );
+            }
+            const u32 zc = pk_min( z, V_CLIP ) & 0xff00ff00u;
+            const u32 nu = pk_sub( zc, V[ k ] ), nv = pk_sub( zc, ut[ k ] );
+            u32 tmp = pk_sub( zc, V_Q );
+            a = pk_sub( a, tmp );
+            b = pk_sub( b, tmp );
+            tmp = pk_sub( zc, V_Q2 );
+            a2 = pk_sub( a2, tmp );
+            b2 = pk_sub( b2, tmp );
+            const u32 nx = pk_sub( pk_max( a, K_TX ), V_QE ), ny = pk_sub( pk_max( b, K_TY ), V_QE );
+            const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), V_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), V_QE2 );
+            const u32 fa = pk_sub( K_FX, a ), fb = pk_sub( K_FY, b ), fa2 = pk_sub( K_FX2, a2 ), fb2 = pk_sub( K_FY2, b2 );
+            d = and_or( fa >> 12, 0x00080008u, and_or( fb >> 11, 0x00100010u, and_or( fa2 >> 10, 0x00200020u, and_or( fb2 >> 9, 0x00400040u, d ) ) ) );
+            dirs[ k ] = __builtin_amdgcn_perm( 0u, d, 0x0c0c0200u ); // the two direction bytes side by side
+            // ---- commit: the row's own v, x, x2 keep their first-column initialisation until the cell is born
+            U[ k ] = nu;
+            Y[ k ] = ny;
+            Y2[ k ] = ny2;
+            T[ k ] = tt[ k ];
+            V[ k ] = pk_bfi( LM[ k ], nv, V[ k ] );
+            X[ k ] = pk_bfi( LM[ k ], nx, X[ k ] );
+            X2[ k ] = pk_bfi( LM[ k ], nx2, X2[ k ] );
+            // ---- H(t, j) = H(t-1, j) + u(t, j)
+            const u32 hn = pk_add( H[ k ], pk_ashr8( nu ) );
+            H[ k ] = pk_bfi( LM[ k ], hn, H[ k ] );
+            Hm[ k ] = pk_bfi( LM[ k ], hn, K_NEG );
+            Tpk[ k ] = pk_add( Tpk[ k ], 0x00010001u );
+            if( NR > 1 )
+                __builtin_amdgcn_sched_barrier( 0 ); // one register set after the other: interleaved, their temporaries add up
         }
-        const u32 zc = pk_min( z, V_CLIP ) & 0xff00ff00u;
-        const u32 nu = pk_sub( zc, V ), nv = pk_sub( zc, ut );
-        u32 tmp = pk_sub( zc, V_Q );
-        a = pk_sub( a, tmp );
-        b = pk_sub( b, tmp );
-        tmp = pk_sub( zc, V_Q2 );
-        a2 = pk_sub( a2, tmp );
-        b2 = pk_sub( b2, tmp );
-        const u32 nx = pk_sub( pk_max( a, K_TX ), V_QE ), ny = pk_sub( pk_max( b, K_TY ), V_QE );
-        const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), V_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), V_QE2 );
-        const u32 fa = pk_sub( K_FX, a ), fb = pk_sub( K_FY, b ), fa2 = pk_sub( K_FX2, a2 ), fb2 = pk_sub( K_FY2, b2 );
-        d = and_or( fa >> 12, 0x00080008u, and_or( fb >> 11, 0x00100010u, and_or( fa2 >> 10, 0x00200020u, and_or( fb2 >> 9, 0x00400040u, d ) ) ) );
-        // ---- commit: the row's own v, x, x2 keep their first-column initialisation until the cell is born
-        U = nu;
-        Y = ny;
-        Y2 = ny2;
-        T = tt;
-        V = pk_bfi( LM, nv, V );
-        X = pk_bfi( LM, nx, X );
-        X2 = pk_bfi( LM, nx2, X2 );
-        if( LM ) // the lane's two bytes of row r of the ring
-            *(uint16_t*)( stage + ( r & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + laneOff ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
-        // ---- H(t, j) = H(t-1, j) + u(t, j)
-        const u32 hn = pk_add( H, pk_ashr8( nu ) );
-        H = pk_bfi( LM, hn, H );
-        const u32 Hm = pk_bfi( LM, hn, K_NEG );
-        Tpk = pk_add( Tpk, 0x00010001u );
+        // the lane's 2 NR bytes of row r of the ring
+        if( NR == 1 )
+        {
+            if( LM[ 0 ] )
+                *(uint16_t*)( stage + ( r & ( SR - 1 ) ) * ROWB + laneOff ) = (uint16_t)dirs[ 0 ];
+        }
+        else if( LM[ 0 ] | LM[ NR - 1 ] )
+            *(u32*)( stage + ( r & ( SR - 1 ) ) * ROWB + laneOff ) = dirs[ 0 ] | dirs[ NR - 1 ] << 16;
+        // the largest H of the lane's live cells
+        u32 HmAll = Hm[ 0 ];
+#pragma unroll
+        for( int k = 1; k < NR; k++ )
+            HmAll = pk_max( HmAll, Hm[ k ] );
         // ---- a larger maximum: the value now, its position when somebody asks (ksw_ext.h)
         i32 raise = 0;
-        if( __any( pk_max( Hm, ezpk ) != ezpk ) )
+        if( __any( pk_max( HmAll, ezpk ) != ezpk ) )
         {
-            const i32 gm = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
+            const i32 gm = grp_max_i32<LANES>( max( (i32)( HmAll << 16 ) >> 16, (i32)HmAll >> 16 ) );
             raise = gm > ezmax ? -1 : 0;
             ezmax = raise ? gm : ezmax;
             ezpk = raise ? pk_bcast( gm ) : ezpk;
-            snapH = raise ? H : snapH;
+#pragma unroll
+            for( int k = 0; k < NR; k++ )
+                snapH[ k ] = raise ? H[ k ] : snapH[ k ];
             pR = raise ? r : pR;
             pend |= raise;
             // (the diagonal's maximum IS ez.max now: no z-drop before it has fallen by zdrop + 1)
@@ -373,7 +443,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         if( __builtin_expect( __any( ( act & ~raise ) != 0 && r >= zNext ) != 0, 0 ) )
         {
             const i32 thr = ezmax - zdrop - 1; // candidates: every cell at or below it
-            const i32 gm = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
+            const i32 gm = grp_max_i32<LANES>( max( (i32)( HmAll << 16 ) >> 16, (i32)HmAll >> 16 ) );
             const bool mine = ( act & ~raise ) != 0 && r >= zNext;
             const bool cand = mine && gm <= thr;
             if( mine && !cand )
@@ -381,9 +451,9 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             if( __any( cand ) )
             {
                 i32 mH, mT;
-                grp_exact_max<LANES>( H, Jpk, r, qlen, tlen, lane, l, mH, mT );
+                grp_exact_max<LANES, NR>( H, Jpk, r, qlen, tlen, lane, l, mH, mT );
                 i32 pH, pT;
-                grp_exact_max<LANES>( snapH, Jpk, pR, qlen, tlen, lane, l, pH, pT );
+                grp_exact_max<LANES, NR>( snapH, Jpk, pR, qlen, tlen, lane, l, pH, pT );
                 if( pend && cand )
                 {
                     maxT = pT;
@@ -399,7 +469,9 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
                         zdropped = 1;
                         rLast = r;
                         act = 0;
-                        Jmask = 0;
+#pragma unroll
+                        for( int k = 0; k < NR; k++ )
+                            Jmask[ k ] = 0;
                     }
                 }
                 if( cand && act )
@@ -411,10 +483,15 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
         const bool due = ( act & ~raise ) != 0 && r >= qlen - 1 && r >= nextBound;
         if( __any( due ) )
         {
-            const u32 QLpk = pk_sub( pk_bcast( qlen - 1 ), Jpk ); // rows left below the cell
-            const u32 pot = pk_min( QLpk, pk_sub( tlenpk, Tpk ) ); // min( rows left, columns left ): Tpk is t + 1 by now
-            const u32 bnd = pk_mad( pot, K_MATCH, H );
-            const u32 bm = pk_bfi( LM, bnd, K_NEG );
+            u32 bm = K_NEG;
+#pragma unroll
+            for( int k = 0; k < NR; k++ )
+            {
+                const u32 QLpk = pk_sub( pk_bcast( qlen - 1 ), Jpk[ k ] ); // rows left below the cell
+                const u32 pot = pk_min( QLpk, pk_sub( tlenpk, Tpk[ k ] ) ); // min( rows left, columns left ): Tpk is t + 1 by now
+                const u32 bnd = pk_mad( pot, K_MATCH, H[ k ] );
+                bm = pk_max( bm, pk_bfi( LM[ k ], bnd, K_NEG ) );
+            }
             const i32 bound = grp_max_i32<LANES>( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
             const i32 top = hBoundary( r ) + sc_mch * qlen;
             if( due )
@@ -424,7 +501,9 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
                 {
                     rLast = r;
                     act = 0;
-                    Jmask = 0;
+#pragma unroll
+                    for( int k = 0; k < NR; k++ )
+                        Jmask[ k ] = 0;
                 }
                 else if( boundPrev != 0x7fffffff && r >= qlen )
                 {
@@ -444,7 +523,7 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
     // ---- position of the last raise
     {
         i32 pH, pT;
-        grp_exact_max<LANES>( snapH, Jpk, pR, qlen, tlen, lane, l, pH, pT );
+        grp_exact_max<LANES, NR>( snapH, Jpk, pR, qlen, tlen, lane, l, pH, pT );
         if( pend )
         {
             maxT = pT;
@@ -477,13 +556,13 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             curLen = len;
         }
     };
-    // rows [winLo, ...] are in the ring (slot r mod 32): first the ones the loop left there, then 32-row windows out of HBM
+    // rows [winLo, ...] are in the ring (slot r mod SR): first the ones the loop left there, then SR-row windows out of HBM
     i32 winLo = ringLo;
     while( true )
     {
         while( bi >= 0 && bj >= 0 && bi + bj >= winLo )
         {
-            const u32 tb = stage[ ( ( bi + bj ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + g * CJ + bj ];
+            const u32 tb = stage[ ( ( bi + bj ) & ( SR - 1 ) ) * ROWB + g * CJ + bj ];
             if( state != 0 && !( ( tb >> ( state + 2 ) ) & 1 ) )
                 state = 0;
             if( state == 0 )
@@ -499,12 +578,12 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
             break;
         // the highest diagonal any walker stands on (below winLo: those rows went to HBM), 32 rows down
         const i32 rhi = wave_max_i32( walking ? bi + bj : -1 );
-        winLo = max( 0, rhi - KSW_GRP_STAGE_ROWS + 1 );
+        winLo = max( 0, rhi - SR + 1 );
         __syncthreads( );
-        for( i32 k = lane; k < ( rhi - winLo + 1 ) * 8; k += 64 ) // 16 bytes each: 8 per row
+        for( i32 k = lane; k < ( rhi - winLo + 1 ) * ( ROWB / 16 ); k += 64 ) // 16 bytes each: ROWB / 16 per row
         {
-            const i32 row = winLo + ( k >> 3 );
-            *(uint4*)( stage + ( row & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + ( k & 7 ) * 16 ) = *(const uint4*)( P + (size_t)row * 128 + ( k & 7 ) * 16 );
+            const i32 row = winLo + k / ( ROWB / 16 );
+            *(uint4*)( stage + ( row & ( SR - 1 ) ) * ROWB + ( k % ( ROWB / 16 ) ) * 16 ) = *(const uint4*)( P + (size_t)row * ROWB + ( k % ( ROWB / 16 ) ) * 16 );
         }
         __syncthreads( );
     }
@@ -638,8 +717,8 @@ __device__ void ksw_grp_set( const FETCH& F, const KswScoring& SC, const u32* li
 #define KSW_GRP_LISTS 6
 // One kernel per (G, direction): a single instantiation of ksw_grp_set per kernel keeps the register allocation of each below
 // the budget (all six in one kernel: 128 VGPRs and scratch traffic inside the diagonal loop).
-template <typename FETCH, int G, bool LEFT>
-__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 5, 5 ) ) )
+template <typename FETCH, int G, int NR, bool LEFT>
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( NR == 1 ? 5 : 4, NR == 1 ? 5 : 4 ) ) )
 k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* redo, unsigned int* nRedo )
 {
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[ KSW_GRP_LDS ];
@@ -665,9 +744,9 @@ k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, u
             end = cur + 4 * G < n ? cur + 4 * G : n;
         }
 #if defined( MA_KSW_PROF )
-        ksw_grp_set<G, LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff, prof );
+        ksw_grp_set<G, NR, LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff, prof );
 #else
-        ksw_grp_set<G, LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff );
+        ksw_grp_set<G, NR, LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff );
 #endif
         cur += G;
     }
@@ -675,7 +754,7 @@ k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, u
 #if defined( MA_KSW_PROF )
     if( threadIdx.x == 0 )
         for( int i = 0; i < 8; i++ )
-            atomicAdd( g_grp_prof + 8 * ( G == 1 ? 0 : ( G == 2 ? 1 : 2 ) ) + i, prof[ i ] );
+            atomicAdd( g_grp_prof + 8 * ( NR == 2 ? 0 : ( G == 2 ? 1 : 2 ) ) + i, prof[ i ] );
 #endif
 }
 } // namespace ma

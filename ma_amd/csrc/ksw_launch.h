@@ -55,7 +55,8 @@ struct KswWaveAcc
 #define KSW_S2 3
 #define KSW_S3 5
 #define KSW_N_CLASSES 13 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots,
-                         // 7..12 the query-stationary extension kernel (ksw_grp.h): 1 (MA_KSW_GRP=2 only) / 2 / 4 jobs per wave, left / right
+                         // 7..12 the query-stationary extension kernel (ksw_grp.h): 2 jobs of up to 128 query bases (four rows per lane) / 2 of
+                         // up to 64 / 4 of up to 32 per wave, left / right
 #define KSW_CLS_GRP0 7
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
@@ -391,7 +392,10 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, KswJobs J
 inline i32 ksw_grp_env( ) // KswScoring::grp (read on every call: the tests switch it inside one process)
 {
     const char* e = getenv( "MA_KSW_GRP" );
-    return e ? std::max( 0, std::min( 2, atoi( e ) ) ) : 1; // 2: also the jobs of 65..128 query bases, one per wave (A/B)
+    // 2 (A/B): also the jobs of 65..128 query bases, two per wave with four rows per lane -- measured slower than k_ksw_ext<1> (150 bp:
+    // DP 19.1 -> 20.0 ms): a register set's recurrence is 76 of the ~91 instructions of a diagonal, so sharing the rest buys 16 % per
+    // job at best, and 128 VGPRs leave 4 waves per SIMD where k_ksw_ext runs 8
+    return e ? std::max( 0, std::min( 2, atoi( e ) ) ) : 1;
 }
 // sizes for a job population (host side)
 struct KswSizing
@@ -557,8 +561,9 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     KswLaunchPlan LG;
     if( nGrp )
     {
-        const u64 sets = SZ.cls[ 7 ] + SZ.cls[ 8 ] + ( SZ.cls[ 9 ] + 1 ) / 2 + ( SZ.cls[ 10 ] + 1 ) / 2 + ( SZ.cls[ 11 ] + 3 ) / 4 + ( SZ.cls[ 12 ] + 3 ) / 4;
-        LG = ksw_plan_launch( (u64)KSW_GRP_ROWS * 128, 0, sets, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
+        const u64 sets = ( SZ.cls[ 7 ] + 1 ) / 2 + ( SZ.cls[ 8 ] + 1 ) / 2 + ( SZ.cls[ 9 ] + 1 ) / 2 + ( SZ.cls[ 10 ] + 1 ) / 2 + ( SZ.cls[ 11 ] + 3 ) / 4 + ( SZ.cls[ 12 ] + 3 ) / 4;
+        // (direction rows of 256 B when the four-rows-per-lane lists have jobs)
+        LG = ksw_plan_launch( (u64)KSW_GRP_ROWS * ( SZ.cls[ 7 ] + SZ.cls[ 8 ] ? 256 : 128 ), 0, sets, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
     }
     for( int k = 0; k < 7; k++ )
     {
@@ -729,28 +734,28 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
             if( nk == 0 )
                 continue;
             const u32* lk = lists + (u64)( KSW_CLS_GRP0 + k ) * list_stride;
-            const u32 Gk = k < 2 ? 1u : ( k < 4 ? 2u : 4u );
+            const u32 Gk = k < 4 ? 2u : 4u;
             const u32 waves = (u32)std::max<u64>( 1, std::min<u64>( LG.waves, ( nk + Gk - 1 ) / Gk ) );
             uint8_t* sb = base + laneBase[ 0 ];
             switch( k )
             {
             case 0:
-                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 1, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 2, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
                 break;
             case 1:
-                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 1, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 2, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
                 break;
             case 2:
-                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 1, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
                 break;
             case 3:
-                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 1, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
                 break;
             case 4:
-                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 4, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 4, 1, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
                 break;
             default:
-                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 4, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 4, 1, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
             }
         }
     if( SZ.cls[ 5 ] )

@@ -220,9 +220,9 @@ int ma_dp_batch( ma_batch* b )
                 {
                     GrpSortArgs G;
                     u64 most = 0, all = 0;
-                    for( int k = 0; k < KSW_GRP_SORT_LISTS; k++ ) // (qlen <= 64 here: the lengths fit the 128 bins)
+                    for( int k = 0; k < KSW_GRP_SORT_LISTS; k++ ) // (qlen <= 128 here: 128 bins, the last one takes 127 and 128)
                     {
-                        const int cls = KSW_CLS_GRP0 + 2 + k;
+                        const int cls = KSW_CLS_GRP0 + k;
                         G.n[ k ] = (u32)S.cls[ cls ];
                         G.list[ k ] = b->clsLists.as<u32>( ) + (u64)cls * nSlots;
                         most = std::max<u64>( most, S.cls[ cls ] );

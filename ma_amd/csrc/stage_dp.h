@@ -366,7 +366,7 @@ __global__ void k_job_cost( PipeFetch F, const u32* list, u32 n, u32* key )
 // jobs need).  A counting sort over the <= 128 possible lengths, all lists in two launches (a radix sort per list was 45
 // launches per step): k_grp_hist copies every list aside and counts its lengths, k_grp_scatter puts the entries back at
 // start-of-its-length + a running index.  The order among jobs of equal length is arbitrary; no result depends on it.
-#define KSW_GRP_SORT_LISTS 4
+#define KSW_GRP_SORT_LISTS 6
 struct GrpSortArgs
 {
     u32* list[ KSW_GRP_SORT_LISTS ]; // in place
@@ -386,7 +386,7 @@ __global__ void k_grp_hist( PipeFetch F, GrpSortArgs A )
     {
         const u32 slot = A.list[ l ][ i ];
         A.tmp[ l ][ i ] = slot;
-        atomicAdd( &h[ (u32)F.view( slot ).qlen & 127u ], 1u );
+        atomicAdd( &h[ min( (u32)F.view( slot ).qlen, 127u ) ], 1u );
     }
     __syncthreads( );
     if( threadIdx.x < 128 && h[ threadIdx.x ] )
@@ -401,7 +401,7 @@ __global__ void k_grp_scatter( PipeFetch F, GrpSortArgs A )
         h[ threadIdx.x ] = 0;
     __syncthreads( );
     for( u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n[ l ]; i += gridDim.x * blockDim.x )
-        atomicAdd( &h[ (u32)F.view( A.tmp[ l ][ i ] ).qlen & 127u ], 1u );
+        atomicAdd( &h[ min( (u32)F.view( A.tmp[ l ][ i ] ).qlen, 127u ) ], 1u );
     __syncthreads( );
     if( threadIdx.x < 128 )
     {
@@ -417,7 +417,7 @@ __global__ void k_grp_scatter( PipeFetch F, GrpSortArgs A )
     for( u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n[ l ]; i += gridDim.x * blockDim.x )
     {
         const u32 slot = A.tmp[ l ][ i ];
-        const u32 len = (u32)F.view( slot ).qlen & 127u;
+        const u32 len = min( (u32)F.view( slot ).qlen, 127u );
         A.list[ l ][ start[ len ] + atomicAdd( &h[ len ], 1u ) ] = slot;
     }
 }

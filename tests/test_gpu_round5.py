@@ -267,7 +267,7 @@ def test_short_extensions_that_share_a_wavefront(gpu_device, scoring, monkeypatc
         long_cases = [(np.concatenate([q, q[::-1], q])[:int(65 + (i * 7) % 64)], t, w, zd, fl) for i, (q, t, w, zd, fl) in enumerate(cases[:400]) if len(q) >= 33]
         monkeypatch.setenv("MA_KSW_GRP", "1")
         ez, cigs = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
-        monkeypatch.setenv("MA_KSW_GRP", "2")  # the same kernel with ONE job per wavefront for queries of 65..128 bases (A/B mode)
+        monkeypatch.setenv("MA_KSW_GRP", "2")  # queries of 65..128 bases: two jobs per wavefront with four rows per lane (A/B mode)
         ez2, cigs2 = ma_amd.ksw_batch(P, cases + long_cases, pipeline_semantics=True)
         monkeypatch.setenv("MA_KSW_GRP", "0")
         ez0, cigs0 = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
@@ -284,7 +284,7 @@ def test_short_extensions_that_share_a_wavefront(gpu_device, scoring, monkeypatc
             i = len(cases) + k
             oez, ocig = or_ksw(op, q, t, w, zd, fl)
             assert all(int(ez2[f][i]) == int(oez[f]) for f in ("max", "max_q", "max_t")) and np.array_equal(cigs2[i], ocig), (
-                "one job per wave, qlen %d tlen %d flag %#x" % (len(q), len(t), fl))
+                "four rows per lane, qlen %d tlen %d flag %#x" % (len(q), len(t), fl))
     monkeypatch.delenv("MA_KSW_GRP")
 
 
