@@ -22,7 +22,13 @@ tools/_prof/valu_mix > gpurun_out/calib_$TAG/valu_mix.txt 2>&1; tools/_prof/gups
 python3 tools/calibration_json.py gpurun_out/calib_$TAG > gpurun_out/${TAG}_calibration.json
 cp gpurun_out/${TAG}_calibration.json profiles/${TAG}_calibration.json
 # the driver's line (all workloads incl. the Illumina preset and the C1 anchor); its per-workload blocks go to the detail file
-python bench.py --detail-file gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
+# (the driver's own command line)
+python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
+# where the host-to-host leg stands against the device-resident one: one direction only, serial instead of double-buffered I/O,
+# copies forced onto blit kernels, host threads on the other socket
+bash tools/h2h_experiment.sh 30 > /dev/null 2>&1; cp gpurun_out/h2h_experiment.txt gpurun_out/${TAG}_h2h_experiment.txt
+# the shapes of the kswcpp calls of the long-read workloads
+( python3 tools/dp_job_histogram.py 150 200000 0.005 0 0; python3 tools/dp_job_histogram.py 10000 4000 0.004 0.003 0.003; python3 tools/dp_job_histogram.py 50000 1000 0.03 0.03 0.04 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_dp_job_histogram.txt
 # the leg `value` comes from -- 150 bp, 3 batches in flight, host to host -- under rocprofv3 (program directly after --):
 # kernel trace -> concurrency timeline, and the same command's --stats summary
 rocprofv3 --kernel-trace --stats -d gpurun_out/tr_h2h -o tr --output-format csv -- python3 bench.py --workload 150bp --inflight 3 --host-io 1 --steps 9 --warmup 1 --cpu-sample 0 --boundary-reads 0 > gpurun_out/tr_h2h.log 2>&1
