@@ -279,6 +279,9 @@ int ma_batch_kernel_ms( ma_batch*, float out[ 8 ] );
 /* host wall time in ms of the stage calls of the last ma_align_batch: [0] seed [1] extract [2] chain [3] dp (launches,
  * stream waits and size read-backs included: what a small batch pays beside its kernels) */
 int ma_batch_host_ms( ma_batch*, float out[ 8 ] );
+/* diagnostics: extension jobs tried on the proven narrow band (ma_amd/csrc/ksw_band.h; MA_KSW_GRP=3) since the library was loaded on
+ * the current device: tried, proved, failed check 1 / 2 / 3 / 4, handed back for another reason, diagonals run */
+int ma_debug_band_stats( unsigned long long out[ 8 ] );
 /* diagnostics: the device libm the chaining stage decides with (harmonization.h:82-89, ransac.cpp:112,131-135 use
  * glibc's): op 0 tan, 1 sin, 2 atan, 3 log over n doubles (host arrays); tests compare the bits with glibc's */
 int ma_debug_libm( int op, const double* in, uint64_t n, double* out );

@@ -1,0 +1,666 @@
+// ksw_band.h -- FOUR extension jobs of up to 254 query bases per wavefront: a narrow band that is PROVEN, job by job, to give the
+// wide band's answer (round 5).
+//
+// kswcpp computes every cell of the rectangle a band of 512 leaves (kswcpp_core.h:541-879), and so do ksw_ext.h / ksw_grp.h: an
+// extension of q bases is q cells on each of ~2 q diagonals, although a good alignment stays within a few cells of the main
+// diagonal.  What the callers read -- max, max_q, max_t and the cigar traced back from there (needlemanWunsch.cpp:239-622) -- is
+// decided by those few cells, and that can be CHECKED after the fact.  This kernel computes only the cells with |t - j| <= B
+// (B = 24: 25 cells per diagonal, a ring of 32 query rows in the 16 lanes of a quarter wavefront, layout of ksw_grp.h) and hands a
+// job back to the exact kernels unless the checks below hold.
+//
+// The band.  Cell (t, j) lives in half (j & 1) of lane (j & 31) >> 1 of its group while -B <= t - j <= B; a lane whose two rows
+// have left the band takes the rows 32 further on.  A cell whose upper neighbour (t-1, j) lies outside the band takes
+// v = -(q+e), x = -(q+e), x2 = -(q2+e2) for it, one whose left neighbour (t, j-1) lies outside takes u = -(q+e), y, y2 alike:
+// the missing cell is treated as reached by opening a gap from the cell beside it, which is a path of the full matrix.  Hence
+//   (V) every value of the band matrix is the score of a real path: band H <= true H, cell by cell.
+// Let a = match, f(L) = min(q + L e, q2 + L e2) the cost of a gap of L, G = f(B + 1).  A path that visits a cell outside the band has
+// gaps of at least B + 1 in one direction more than in the other (f is concave: several gaps cost at least f of their sum), so
+//   (U) a cell (t, j) outside the band, and any cell reached THROUGH one, has true H <= a (min(t, j) + 1) - G, and on diagonal r
+//       the cells outside the band have min(t, j) <= (r - B - 1) / 2:   UB(r) = a ((r - B - 1) / 2 + 1) - G.
+//   (E) a band cell whose band H exceeds UB of its diagonal is EXACT (true H >= band H > UB: no optimal path to it leaves the
+//       band, and the band matrix holds every path that stays inside), and so is every cell on its optimal paths, with every
+//       candidate of the cell update that reaches the maximum: the direction byte of such a cell is the wide matrix's.
+// The checks (all on the job's own numbers, after its last diagonal):
+//   1. ez.max > a qlen - G: no cell outside the band, on any diagonal, reaches ez.max -- the wide run's maximum is the band's,
+//      raised on the same diagonal r*, and the early stop (ksw_reg.h) evaluated on band cells holds for the wide matrix.
+//   2. calcMaxScore's position (kswcpp_core.h:156-299) is the largest chunk base over the EIGHT classes (t - st0) mod 8 of the
+//      first maximum of each class that beats H[en0]: it depends on every class, not on the maximum alone.  With st0, en0 of
+//      the WIDE band: every class has a band cell on r*, and every class's band maximum exceeds UB(r*).  Then by (U), (E) the
+//      class maxima, the cells that hold them and their order are the wide matrix's, and H[en0] (outside the band) beats none.
+//   3. the cell the back-trace starts from, (max_t, r* - max_t), has band H > UB(r*): by (E) every direction byte on its path is
+//      the wide matrix's, and the path stays inside the band (the walk checks it anyway).
+//   4. no z-drop in the wide run: its ez.max is at most a (r / 2 + 1) on diagonal r and its diagonal maximum at least the
+//      band's, which after a raise to m0 on r0 is at least m0 - (r - r0)(q + e) (ksw_grp.h); the difference stays <= zdrop.
+// A job that fails a check, leaves the regime (r > w) or outgrows its cigar buffer goes to the hand-back list like the jobs
+// ksw_ext.h hands back.  tests/test_gpu_round5.py::test_banded_extensions_are_the_wide_bands_or_handed_back compares every
+// proved job with the oracle's kswcpp at the full band.
+#pragma once
+#include "ksw_grp.h"
+
+#if defined( __HIPCC__ )
+namespace ma
+{
+#define KSW_BAND_B 24 // cells on either side of the main diagonal
+#define KSW_BAND_QMAX 254
+#define KSW_BAND_LDS ( KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4 + 4 * 64 + 4 * 256 + 64 )
+// jobs tried, proved, failed check 1 / 2 / 3 / 4, handed back for another reason (regime, cigar buffer), diagonals (ma_debug_band_stats)
+static __device__ unsigned long long g_band_stats[ 8 ];
+
+// extension jobs this kernel may try (same regime as ksw_ext_slots; the query rows are kept in LDS: <= 254 of them)
+MA_HD int ksw_band_ok( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag, i32 qmin )
+{
+    if( !( flag & KSW_EZ_EXTZ_ONLY ) || qlen < qmin || qlen > KSW_BAND_QMAX || w > 512 || w < 2 * KSW_BAND_B + 2 )
+        return 0;
+    if( zdrop < 0 || zdrop > 16000 )
+        return 0;
+    return ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag ) != 0 ? 1 : 0;
+}
+
+// calcMaxScore over the band cells of diagonal rr (grp_exact_max of ksw_grp.h with the cells' rows per lane in Jpk and the band
+// test), plus what the checks need: the smallest of the eight class maxima (NONE when a class has no band cell) and the band H
+// of cell (mT, rr - mT).  st0 / en0 are the WIDE band's.  16 lanes per group.
+__device__ __forceinline__ void band_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qlen, i32 tlen, i32 w, int lane, int l, i32& mH, i32& mT, i32& minClass,
+                                                i32& hStart )
+{
+    const i32 NONE = (i32)0x80000000;
+    const i32 st0 = max( max( 0, rr - qlen + 1 ), ( rr - w + 1 ) >> 1 ), en0 = min( min( rr, tlen - 1 ), ( rr + w ) >> 1 );
+    const i32 span = en0 - st0, nS = ( span / 8 ) * 8;
+    // t - st0 of the lane's two cells, and whether they are cells of the band on this diagonal
+    const i32 jl = (i32)( Jpk & 0xffffu ), jh = (i32)( Jpk >> 16 );
+    const i32 tlo = rr - jl, thi = rr - jh;
+    const bool liveLo = tlo >= 0 && tlo < tlen && jl < qlen && tlo - jl >= -KSW_BAND_B && tlo - jl <= KSW_BAND_B;
+    const bool liveHi = thi >= 0 && thi < tlen && jh < qlen && thi - jh >= -KSW_BAND_B && thi - jh <= KSW_BAND_B;
+    const i32 hLo = (i32)( Hs << 16 ) >> 16, hHi = (i32)Hs >> 16;
+    // H[en0]: a band cell only on the first diagonals
+    i32 hEn0 = NONE;
+    {
+        const i32 j0 = rr - en0;
+        const i32 v = __builtin_amdgcn_ds_bpermute( ( ( lane - l ) + ( ( j0 & 31 ) >> 1 ) ) << 2, (i32)Hs );
+        const i32 jj = __builtin_amdgcn_ds_bpermute( ( ( lane - l ) + ( ( j0 & 31 ) >> 1 ) ) << 2, (i32)Jpk );
+        const i32 rowThere = ( j0 & 1 ) ? ( jj >> 16 ) & 0xffff : jj & 0xffff;
+        const bool inBand = en0 - j0 >= -KSW_BAND_B && en0 - j0 <= KSW_BAND_B && j0 >= 0 && j0 < qlen;
+        if( inBand && rowThere == j0 )
+            hEn0 = ( j0 & 1 ) ? ( v >> 16 ) : ( (i32)( (u32)v << 16 ) >> 16 );
+    }
+    // keys: H << 16 | 0xffff - (t - st0): the first maximum of a class wins
+    auto keyOf = [ & ]( bool live, i32 t, i32 h, bool part8 ) -> i32 {
+        const i32 d = t - st0;
+        if( !live || d < 0 || d >= span || ( d < nS ) != part8 )
+            return NONE;
+        return (i32)( ( (u32)h << 16 ) | (u32)( 0xffff - d ) );
+    };
+    i32 kLo = keyOf( liveLo, tlo, hLo, true ), kHi = keyOf( liveHi, thi, hHi, true );
+    // the class of a cell is (t - st0) mod 8 = (rr - st0 - j) mod 8: lanes 4 apart hold the same two classes
+    kLo = max( kLo, dpp_ctrl<0x124>( kLo ) );
+    kHi = max( kHi, dpp_ctrl<0x124>( kHi ) );
+    kLo = max( kLo, dpp_ctrl<0x128>( kLo ) );
+    kHi = max( kHi, dpp_ctrl<0x128>( kHi ) );
+    const i32 hl = kLo >> 16, hh = kHi >> 16;
+    const i32 tl = ( kLo != NONE && hl > hEn0 ) ? st0 + ( ( 0xffff - ( kLo & 0xffff ) ) & ~7 ) : en0;
+    const i32 th = ( kHi != NONE && hh > hEn0 ) ? st0 + ( ( 0xffff - ( kHi & 0xffff ) ) & ~7 ) : en0;
+    i32 vh = max( max( kLo != NONE ? hl : hEn0, kHi != NONE ? hh : hEn0 ), hEn0 ), vt = max( tl, th );
+    i32 mc = min( kLo != NONE ? hl : NONE, kHi != NONE ? hh : NONE );
+    vh = max( vh, dpp_ctrl<0xB1>( vh ) ); // the four lanes of a quad hold the eight classes
+    vt = max( vt, dpp_ctrl<0xB1>( vt ) );
+    mc = min( mc, dpp_ctrl<0xB1>( mc ) );
+    vh = max( vh, dpp_ctrl<0x4E>( vh ) );
+    vt = max( vt, dpp_ctrl<0x4E>( vt ) );
+    mc = min( mc, dpp_ctrl<0x4E>( mc ) );
+    mH = hEn0, mT = en0;
+    minClass = NONE;
+    if( nS > 0 )
+        mH = vh, mT = vt, minClass = mc;
+    // the cells after the 8-lane part, in the order the reference visits them: the first of the largest wins, if it is larger
+    const i32 tk = grp_max_i32<16>( max( keyOf( liveLo, tlo, hLo, false ), keyOf( liveHi, thi, hHi, false ) ) );
+    if( tk != NONE && ( tk >> 16 ) > mH )
+    {
+        mH = tk >> 16;
+        mT = st0 + ( 0xffff - ( tk & 0xffff ) );
+    }
+    // band H of the cell the back-trace starts from
+    {
+        const i32 js = rr - mT;
+        const i32 v = __builtin_amdgcn_ds_bpermute( ( ( lane - l ) + ( ( js & 31 ) >> 1 ) ) << 2, (i32)Hs );
+        const i32 jj = __builtin_amdgcn_ds_bpermute( ( ( lane - l ) + ( ( js & 31 ) >> 1 ) ) << 2, (i32)Jpk );
+        const i32 rowThere = ( js & 1 ) ? ( jj >> 16 ) & 0xffff : jj & 0xffff;
+        const bool inBand = js >= 0 && js < qlen && mT >= 0 && mT < tlen && mT - js >= -KSW_BAND_B && mT - js <= KSW_BAND_B;
+        hStart = inBand && rowThere == js ? ( ( js & 1 ) ? ( v >> 16 ) : ( (i32)( (u32)v << 16 ) >> 16 ) ) : NONE;
+    }
+}
+
+// One set of up to four jobs (queue entries [at0, min(at0 + 4, n))), all of them left- (LEFT) or right-aligned extensions.
+template <bool LEFT, typename FETCH>
+__device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* list, u32 n, u32 at0, uint8_t* P /*KSW_GRP_ROWS x 128 B*/, uint8_t* lds,
+                              const KswOut& O, KswWaveAcc& acc, u32* redo, unsigned int* nRedo, unsigned long long* sOff, u32* pf /*the wave's statistics*/ )
+{
+    constexpr int G = 4, LANES = 16, CJ = 32, B = KSW_BAND_B;
+    const int lane = threadIdx.x & 63, g = lane / LANES, l = lane % LANES;
+    uint8_t* stage = lds; // KSW_GRP_STAGE_ROWS x 128: direction rows (ksw_grp.h)
+    u32* cigLds = (u32*)( lds + KSW_GRP_STAGE_ROWS * 128 ); // KSW_GRP_CIG_WORDS, CIGCAP per group
+    uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // 4 x 64: two blocks of 32 target bases per job
+    uint8_t* qlds = tring + 4 * 64; // 4 x 256: the jobs' queries
+    i32* gflag = (i32*)( qlds + 4 * 256 );
+    constexpr u32 CIGCAP = KSW_GRP_CIG_WORDS / G;
+    // ---- the group's job
+    const bool has = at0 + (u32)g < n;
+    const u32 slot = list[ has ? at0 + g : at0 ];
+    i32 qlen, tlen, rEnd, nDiag, zdrop, wJob;
+    {
+        const KswJobView J = F.view( slot );
+        qlen = J.qlen, tlen = J.tlen, zdrop = J.zdrop, wJob = J.w;
+        nDiag = qlen + tlen - 1;
+        rEnd = min( nDiag, J.w + 1 ); // the job ends BEFORE diagonal rEnd: all diagonals done, or r > w (handed back)
+    }
+    auto qf = F.qfetch( slot );
+    auto tf = F.tfetch( slot );
+    typedef decltype( tf ) TF;
+    // ---- scoring (as ksw_ext_core)
+    int8_t q = (int8_t)SC.q, e = (int8_t)SC.e, q2 = (int8_t)SC.q2, e2 = (int8_t)SC.e2;
+    const i32 sc_mch = (int8_t)( SC.match < 0 ? -SC.match : SC.match );
+    const i32 sc_mis = (int8_t)( SC.mismatch > 0 ? -SC.mismatch : SC.mismatch );
+    const i32 qe0 = q + e;
+    if( q2 + e2 < q + e )
+    {
+        int8_t t = q;
+        q = q2;
+        q2 = t;
+        t = e;
+        e = e2;
+        e2 = t;
+    }
+    const bool untouched = -( sc_mis < 0 ? sc_mis : 0 ) > 2 * ( q + e ); // kswcpp returns an untouched ez (kswcpp_core.h:340-341)
+    i32 long_thres = e != e2 ? ( q2 - q ) / ( e - e2 ) - 1 : 0;
+    if( q2 + e2 + long_thres * e2 > q + e + long_thres * e )
+        ++long_thres;
+    const i32 long_diff = long_thres * ( e - e2 ) - ( q2 - q ) - e2;
+    auto initOf = [ & ]( i32 r ) -> i32 {
+        return (int8_t)( r == 0 ? -q - e : r < long_thres ? -e : r == long_thres ? long_diff : -e2 );
+    };
+    auto hBoundary = [ & ]( i32 nn ) -> i32 { // H(nn-1, -1) = H(-1, nn-1) (ksw_ext.h)
+        const i32 a = max( 0, min( nn, long_thres ) - 1 );
+        const i32 hs = long_thres >= 1 && long_thres < nn ? 1 : 0;
+        const i32 rest = ( nn - 1 ) - a - hs;
+        return ( q + e ) - qe0 + ( nn < 1 ? 0 : -( q + e ) - e * a + ( hs ? long_diff : 0 ) - e2 * rest );
+    };
+    // the cost of leaving the band, and the offset between kswcpp's H and the path score ((sic) ksw_ext.h: H[0] is seeded with the
+    // UNswapped q + e): the bounds below are on kswcpp's H
+    const i32 gapOut = min( (i32)q + ( B + 1 ) * (i32)e, (i32)q2 + ( B + 1 ) * (i32)e2 );
+    const i32 hOff = ( q + e ) - qe0;
+    auto ubOf = [ & ]( i32 r ) -> i32 { // largest H a cell outside the band can have on diagonal r
+        return r < B + 1 ? (i32)0x80000000 : sc_mch * ( ( r - B - 1 ) / 2 + 1 ) - gapOut + hOff;
+    };
+    constexpr u32 tS = LEFT ? 4 : 0, tX = LEFT ? 3 : 1, tY = 2, tX2 = LEFT ? 1 : 3, tY2 = 0;
+    const u32 K_X0 = pk_val( -q - e, tX ), K_Y0 = pk_val( -q - e, tY ), K_X20 = pk_val( -q2 - e2, tX2 ), K_Y20 = pk_val( -q2 - e2, tY2 );
+    const u32 K_TX = pk_val( 0, tX ), K_TY = pk_val( 0, tY ), K_TX2 = pk_val( 0, tX2 ), K_TY2 = pk_val( 0, tY2 );
+    const u32 K_FX = pk_sub( K_TX, LEFT ? 0u : 0x00010001u ), K_FY = pk_sub( K_TY, LEFT ? 0u : 0x00010001u ),
+              K_FX2 = pk_sub( K_TX2, LEFT ? 0u : 0x00010001u ), K_FY2 = pk_sub( K_TY2, LEFT ? 0u : 0x00010001u );
+    const u32 K_NEG = 0x80008000u, K_MATCH = pk_bcast( sc_mch );
+    const u32 V_CLIP = pk_val( sc_mch, 0xff );
+    const u32 V_SCLO = ( (u32)sc_mch & 0xffu ) | ( ( (u32)sc_mis & 0xffu ) * 0x01010100u );
+    const u32 V_SCHI = ( (u32)( -e2 ) & 0xffu ) | tS << 8;
+    const u32 V_Q = pk_val( q, 0 ), V_Q2 = pk_val( q2, 0 ), V_QE = pk_val( q + e, 0 ), V_QE2 = pk_val( q2 + e2, 0 );
+    const u32 K_GAP = pk_val( -q - e, 0 ); // u / v of a cell whose neighbour lies outside the band
+    // ---- the query in LDS (a lane takes new rows every 64 diagonals), two blocks of the target
+    uint8_t* myQ = qlds + g * 256;
+    for( i32 j = l; j < 256; j += LANES )
+        myQ[ j ] = has && j < qlen ? (uint8_t)qf( j ) : (uint8_t)4;
+    auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t + 1 (codes as in ksw_ext.h: an N of the target is 12)
+        if( t >= tlen )
+            return 0u;
+        u32 ab = tf.pair( t ) & ( t + 1 < tlen ? 0x00ff00ffu : 0x000000ffu );
+        if( TF::CLEAN )
+            return ab;
+        const u32 nn = pk_lshr( ab, 2 );
+        return pk_bfi( pk_sub( 0u, pk_minu( nn, 0x00010001u ) ), 0x000c000cu, ab );
+    };
+    uint8_t* myRing = tring + g * 64;
+    auto fillBlock = [ & ]( i32 blk ) { // target bases [32 blk, 32 blk + 32) -> ring slot blk & 1
+        const i32 t = 32 * blk + 2 * l;
+        const u32 ab = has ? tgt2( t ) : 0u;
+        *(uint16_t*)( myRing + ( t & 63 ) ) = (uint16_t)( ( ab & 0xffu ) | ( ab >> 8 & 0xff00u ) );
+    };
+    fillBlock( 0 );
+    fillBlock( 1 );
+    i32 nextBlk = 2; // the next block the ring takes: when the band's upper edge (r + B) / 2 reaches it
+    // ---- per lane: rows j = 2 l, 2 l + 1 (+ 32 per recycling)
+    u32 Jpk = (u32)( 2 * l ) | (u32)( 2 * l + 1 ) << 16;
+    auto rowState = [ & ]( u32 jpk, u32& Jmask, u32& Qb, u32& V, u32& H, u32& entOk ) {
+        const i32 j0 = (i32)( jpk & 0xffffu ), j1 = (i32)( jpk >> 16 );
+        const bool ok = has && !untouched;
+        Jmask = ( ok && j0 < qlen ? 0x0000ffffu : 0u ) | ( ok && j1 < qlen ? 0xffff0000u : 0u );
+        Qb = (u32)myQ[ j0 & 255 ] | (u32)myQ[ j1 & 255 ] << 16;
+        // rows up to B start at the first column (kswcpp_core.h:562-585); the others enter through the band's edge: their upper
+        // neighbour is a cell outside the band
+        const u32 vLo = j0 <= B ? (u32)initOf( j0 ) & 0xffu : (u32)( -q - e ) & 0xffu, vHi = j1 <= B ? (u32)initOf( j1 ) & 0xffu : (u32)( -q - e ) & 0xffu;
+        V = vLo << 8 | vHi << 24;
+        H = ( (u32)hBoundary( j0 + 1 ) & 0xffffu ) | (u32)hBoundary( j1 + 1 ) << 16; // H(-1, j): read by the rows up to B only
+        entOk = ( j0 > B ? 0x0000ffffu : 0u ) | ( j1 > B ? 0xffff0000u : 0u );
+    };
+    u32 Jmask, Qb, V, H, entOk;
+    __syncthreads( ); // the query bytes
+    rowState( Jpk, Jmask, Qb, V, H, entOk );
+    u32 X = K_X0, X2 = K_X20, U = K_GAP, Y = K_Y0, Y2 = K_Y20;
+    u32 Tpk = pk_sub( 0u, Jpk ); // t = r - j of the lane's cells
+    u32 leadLo = l == 0 ? 0x0000ffffu : 0u; // the cell that takes the first-row boundary: row 0
+    const u32 tlenpk = pk_bcast( tlen );
+    const u32 K_B = pk_bcast( B ), K_2B1 = pk_bcast( 2 * B + 1 );
+    // ---- per group, equal in all lanes of the group (0 / -1 words, ksw_grp.h)
+    i32 ezmax = 0, maxT = -1, maxQ = -1, pR = 0, pM = 0;
+    u32 ezpk = 0, snapH = 0, snapJ = Jpk;
+    i32 act = has && !untouched ? -1 : 0, handBack = 0, pend = 0;
+    i32 zBad = 0; // check 4 failed
+    i32 boundPrev = 0x7fffffff, nextBound = 0;
+    const i32 boundRate = max( 1, ( -sc_mis + sc_mch + 1 ) / 2 );
+    const i32 qe = q + e;
+    i32 rLast = -1;
+    const u32 laneOff = (u32)( g * CJ + 2 * l );
+    i32 uInS = initOf( 0 );
+    i32 ringLo = 0;
+    // the last diagonal with a band cell: row qlen - 1 leaves the band after t = qlen - 1 + B
+    const i32 rBand = min( 2 * ( qlen - 1 ) + B, 2 * ( tlen - 1 ) + B );
+    __syncthreads( );
+    i32 r = 0;
+    for( ;; ++r )
+    {
+        // ---- a job ends before this diagonal: all diagonals done, the band has left the rectangle, or it leaves the regime
+        {
+            const i32 ends = r >= rEnd || r > rBand ? act : 0;
+            handBack |= r >= rEnd && rEnd < nDiag && r <= rBand ? ends : 0;
+            rLast = ends ? r - 1 : rLast;
+            act &= ~ends;
+            Jmask &= (u32)~ends;
+        }
+        if( !__any( act != 0 ) )
+            break;
+        if( __builtin_expect( r <= long_thres + 1, 0 ) )
+            uInS = initOf( r );
+        // ---- the next 32 target bases, when the band's upper edge reaches them (wave-uniform: r and B are)
+        if( __builtin_expect( ( ( r + B ) >> 1 ) >= 32 * nextBlk - 1, 0 ) )
+        {
+            fillBlock( nextBlk );
+            nextBlk++;
+            __syncthreads( );
+        }
+        // ---- a lane whose rows have both left the band takes the rows 32 further on: lane l on diagonal 4 l + B + 3 (+ 64 k)
+        if( __builtin_expect( r >= B + 3 && ( ( r - B - 3 ) & 3 ) == 0, 0 ) )
+        {
+            if( l == ( ( ( r - B - 3 ) >> 2 ) & 15 ) )
+            {
+                Jpk = pk_add( Jpk, 0x00200020u );
+                rowState( Jpk, Jmask, Qb, V, H, entOk );
+                Jmask &= (u32)act;
+                X = K_X0, X2 = K_X20, U = K_GAP, Y = K_Y0, Y2 = K_Y20;
+                Tpk = pk_sub( pk_bcast( r ), Jpk );
+                leadLo = 0;
+            }
+        }
+        if( __builtin_expect( r >= KSW_GRP_STAGE_ROWS && ( r & ( KSW_GRP_STAGE_ROWS / 2 - 1 ) ) == 0, 0 ) )
+        {
+            // rows [r - 32, r - 16) -> HBM (ksw_grp.h)
+            __syncthreads( );
+            const uint4* src = (const uint4*)( stage + ( ( r - KSW_GRP_STAGE_ROWS ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 );
+            uint4* dst = (uint4*)( P + (size_t)( r - KSW_GRP_STAGE_ROWS ) * 128 );
+#pragma unroll
+            for( int k = 0; k < KSW_GRP_STAGE_ROWS / 16; k++ )
+                dst[ lane + 64 * k ] = src[ lane + 64 * k ];
+            ringLo = r - KSW_GRP_STAGE_ROWS / 2;
+        }
+        // ---- neighbours: u, y, y2 come from row j - 1 = the previous lane of the ring; the H of row j - 1 for a row that enters
+        const u32 ut0 = cells_shift1( U, (u32)dpp_ctrl<0x121>( (i32)U ) );
+        const u32 yt0 = cells_shift1( Y, (u32)dpp_ctrl<0x121>( (i32)Y ) );
+        const u32 y2t0 = cells_shift1( Y2, (u32)dpp_ctrl<0x121>( (i32)Y2 ) );
+        const u32 hPrev = cells_shift1( H, (u32)dpp_ctrl<0x121>( (i32)H ) );
+        const u32 ut = pk_bfi( leadLo, ( (u32)uInS & 0xffu ) << 8, ut0 );
+        const u32 yt = pk_bfi( leadLo, K_Y0, yt0 );
+        const u32 y2t = pk_bfi( leadLo, K_Y20, y2t0 );
+        // the target bases of the lane's cells: t (low half) and t - 1
+        const i32 tLo = (i32)( (u32)( Tpk << 16 ) ) >> 16;
+        const u32 tt = (u32)myRing[ tLo & 63 ] | (u32)myRing[ ( tLo - 1 ) & 63 ] << 16;
+        // ---- live cells: 0 <= t <= tlen - 1 on a row of the job, -B <= t - j <= B
+        const u32 dB = pk_add( pk_sub( Tpk, Jpk ), K_B ); // t - j + B: 0 .. 2 B inside the band
+        const u32 inBand = pk_nonzero15( pk_subsatu( K_2B1, dB ) );
+        const u32 LM = pk_opaque( pk_nonzero15( pk_subsatu( tlenpk, Tpk ) ) & Jmask & inBand );
+        const u32 ENT = LM & entOk & ~pk_nonzero15( dB ); // a cell on the band's edge t - j = -B of a row that did not start at t = 0
+        // ---- score and DP cell (kswcpp_core.h:598-766; ksw_ext.h)
+        const u32 sel = ( pk_minu( tt ^ Qb, 0x00040004u ) << 8 ) | 0x00050005u;
+        u32 z = __builtin_amdgcn_perm( V_SCHI, V_SCLO, sel );
+        u32 a = pk_add( X, V );
+        u32 b = pk_add( yt, ut );
+        u32 a2 = pk_add( X2, V );
+        u32 b2 = pk_add( y2t, ut );
+        u32 d;
+        if( LEFT )
+        {
+            z = pk_max( pk_max( z, a ), pk_max( pk_max( b, a2 ), b2 ) );
+            d = pk_sub( 0x00040004u, z & 0x00070007u );
+        }
+        else
+        {
+            z = pk_max( pk_max( z, a ), pk_max( b, a2 ) );
+            d = z & 0x00070007u;
+            z = pk_max( z, b2 );
+        }
+        const u32 zc = pk_min( z, V_CLIP ) & 0xff00ff00u;
+        const u32 nu = pk_sub( zc, V ), nv = pk_sub( zc, ut );
+        u32 tmp = pk_sub( zc, V_Q );
+        a = pk_sub( a, tmp );
+        b = pk_sub( b, tmp );
+        tmp = pk_sub( zc, V_Q2 );
+        a2 = pk_sub( a2, tmp );
+        b2 = pk_sub( b2, tmp );
+        const u32 nx = pk_sub( pk_max( a, K_TX ), V_QE ), ny = pk_sub( pk_max( b, K_TY ), V_QE );
+        const u32 nx2 = pk_sub( pk_max( a2, K_TX2 ), V_QE2 ), ny2 = pk_sub( pk_max( b2, K_TY2 ), V_QE2 );
+        const u32 fa = pk_sub( K_FX, a ), fb = pk_sub( K_FY, b ), fa2 = pk_sub( K_FX2, a2 ), fb2 = pk_sub( K_FY2, b2 );
+        d = and_or( fa >> 12, 0x00080008u, and_or( fb >> 11, 0x00100010u, and_or( fa2 >> 10, 0x00200020u, and_or( fb2 >> 9, 0x00400040u, d ) ) ) );
+        // ---- commit.  A cell that is not a cell of the band hands its right neighbour the values of a cell reached by a gap
+        // (u = -(q+e), no gap open); its own v, x, x2 keep their initialisation until the cell is born
+        U = pk_bfi( LM, nu, K_GAP );
+        Y = pk_bfi( LM, ny, K_Y0 );
+        Y2 = pk_bfi( LM, ny2, K_Y20 );
+        V = pk_bfi( LM, nv, V );
+        X = pk_bfi( LM, nx, X );
+        X2 = pk_bfi( LM, nx2, X2 );
+        if( LM ) // the lane's two bytes of row r of the ring
+            *(uint16_t*)( stage + ( r & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + laneOff ) = (uint16_t)__builtin_amdgcn_perm( 0u, d, 0x0c0c0200u );
+        // ---- H(t, j) = H(t-1, j) + u(t, j); a row that enters the band: H(t, j-1) + v(t, j)
+        const u32 hn = pk_bfi( ENT, pk_add( hPrev, pk_ashr8( nv ) ), pk_add( H, pk_ashr8( nu ) ) );
+        H = pk_bfi( LM, hn, H );
+        const u32 Hm = pk_bfi( LM, hn, K_NEG );
+        Tpk = pk_add( Tpk, 0x00010001u );
+        // ---- a larger maximum: the value now, its position when somebody asks (ksw_ext.h)
+        i32 raise = 0;
+        if( __any( pk_max( Hm, ezpk ) != ezpk ) )
+        {
+            const i32 gm = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
+            raise = gm > ezmax ? -1 : 0;
+            // check 4: between the last raise (pR, pM) and this diagonal the wide run's ez.max - diagonal maximum stayed <= zdrop
+            if( raise && pend && sc_mch * ( r / 2 + 1 ) + hOff - pM + ( r - pR ) * qe > zdrop )
+                zBad = -1;
+            ezmax = raise ? gm : ezmax;
+            ezpk = raise ? pk_bcast( gm ) : ezpk;
+            snapH = raise ? H : snapH;
+            snapJ = raise ? Jpk : snapJ;
+            pR = raise ? r : pR;
+            pM = raise ? gm : pM;
+            pend |= raise;
+        }
+        // ---- early stop (ksw_reg.h) on the band's cells, every job on its own schedule (ksw_grp.h)
+        const bool due = ( act & ~raise ) != 0 && r >= qlen - 1 && r >= nextBound;
+        if( __any( due ) )
+        {
+            const u32 QLpk = pk_sub( pk_bcast( qlen - 1 ), Jpk ); // rows left below the cell
+            const u32 pot = pk_min( QLpk, pk_sub( tlenpk, Tpk ) ); // min( rows left, columns left ): Tpk is t + 1 by now
+            const u32 bnd = pk_mad( pot, K_MATCH, H );
+            const u32 bm = pk_bfi( LM, bnd, K_NEG );
+            const i32 bound = grp_max_i32<LANES>( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
+            const i32 top = hBoundary( r ) + sc_mch * qlen;
+            if( due )
+            {
+                const i32 all = max( max( bound, boundPrev ), top );
+                if( r >= qlen && all <= ezmax )
+                {
+                    rLast = r;
+                    act = 0;
+                    Jmask = 0;
+                }
+                else if( boundPrev != 0x7fffffff && r >= qlen )
+                {
+                    nextBound = r + 1 + max( 0, ( max( bound, top ) - ezmax ) / boundRate - 1 );
+                    boundPrev = 0x7fffffff;
+                }
+                else
+                    boundPrev = bound;
+            }
+            else
+                boundPrev = 0x7fffffff;
+        }
+        else
+            boundPrev = 0x7fffffff;
+    }
+    // ---- position of the last raise, and the checks
+    i32 why = 0; // 1..4: the check that failed
+    {
+        i32 pH, pT, minClass, hStart;
+        band_exact_max( snapH, snapJ, pR, qlen, tlen, wJob, lane, l, pH, pT, minClass, hStart );
+        if( pend )
+        {
+            maxT = pT;
+            maxQ = pR - pT;
+            const i32 ub = ubOf( pR );
+            if( !( ezmax > sc_mch * qlen - gapOut + hOff ) )
+                why = 1;
+            else if( !( minClass != (i32)0x80000000 && minClass > ub ) && pR >= B + 1 )
+                why = 2;
+            else if( !( hStart != (i32)0x80000000 && hStart > ub ) )
+                why = 3;
+            else if( zBad || sc_mch * ( max( rLast, pR ) / 2 + 1 ) + hOff - pM + ( max( rLast, pR ) - pR ) * qe > zdrop )
+                why = 4;
+        }
+        else if( has && !untouched && !handBack )
+            why = 1; // no cell ever exceeded 0: nothing proves that none outside the band does
+    }
+    handBack |= why ? -1 : 0;
+    __syncthreads( ); // direction bytes (LDS, and the rows that went to HBM) visible to the back-trace
+    // ---- back-trace (ksw_grp.h); a step outside the band cannot happen after check 3 -- it hands the job back all the same
+    const bool leader = l == 0 && has && !handBack && !untouched && maxT >= 0 && maxQ >= 0;
+    const i32 revCigar = F.view( slot ).flag & KSW_EZ_REV_CIGAR;
+    u32* myCig = cigLds + g * CIGCAP;
+    u32 nCig = 0, curOp = 3, curLen = 0, steps = 0;
+    bool cigOver = false;
+    i32 bi = leader ? maxT : -1, bj = leader ? maxQ : -1, state = 0;
+    auto pushRun = [ & ]( u32 op, u32 len ) {
+        if( op == curOp )
+            curLen += len;
+        else
+        {
+            if( curLen )
+            {
+                if( nCig < CIGCAP )
+                    myCig[ nCig ] = curLen << 4 | curOp;
+                else
+                    cigOver = true;
+                nCig++;
+            }
+            curOp = op;
+            curLen = len;
+        }
+    };
+    i32 winLo = ringLo;
+    while( true )
+    {
+        while( bi >= 0 && bj >= 0 && bi + bj >= winLo )
+        {
+            if( bi - bj > B || bj - bi > B )
+            {
+                cigOver = true; // (handed back)
+                bi = bj = -1;
+                break;
+            }
+            const u32 tb = stage[ ( ( bi + bj ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + g * CJ + ( bj & 31 ) ];
+            if( state != 0 && !( ( tb >> ( state + 2 ) ) & 1 ) )
+                state = 0;
+            if( state == 0 )
+                state = tb & 7;
+            const u32 op = state == 0 ? 0u : ( ( state == 1 || state == 3 ) ? 2u : 1u );
+            steps++;
+            pushRun( op, 1 );
+            bi -= op != 1u ? 1 : 0;
+            bj -= op != 2u ? 1 : 0;
+        }
+        const bool walking = bi >= 0 && bj >= 0;
+        if( !__any( walking ) )
+            break;
+        const i32 rhi = wave_max_i32( walking ? bi + bj : -1 );
+        winLo = max( 0, rhi - KSW_GRP_STAGE_ROWS + 1 );
+        __syncthreads( );
+        for( i32 k = lane; k < ( rhi - winLo + 1 ) * 8; k += 64 ) // 16 bytes each: 8 per row
+        {
+            const i32 row = winLo + ( k >> 3 );
+            *(uint4*)( stage + ( row & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + ( k & 7 ) * 16 ) = *(const uint4*)( P + (size_t)row * 128 + ( k & 7 ) * 16 );
+        }
+        __syncthreads( );
+    }
+    if( leader && !cigOver )
+    {
+        if( bi >= 0 )
+            pushRun( 2, (u32)( bi + 1 ) );
+        if( bj >= 0 )
+            pushRun( 1, (u32)( bj + 1 ) );
+        if( curLen )
+        {
+            if( nCig < CIGCAP )
+                myCig[ nCig ] = curLen << 4 | curOp;
+            else
+                cigOver = true;
+            nCig++;
+        }
+    }
+    // ---- publish (ksw_grp.h): one pool reservation for the set, every group copies its cigar
+    gflag[ g ] = 0;
+    __syncthreads( );
+    if( l == 0 )
+        gflag[ g ] = (i32)( cigOver ? 0x40000000u : nCig );
+    __syncthreads( );
+    const u32 gw = (u32)gflag[ g ];
+    const bool over = ( gw & 0x40000000u ) != 0;
+    const u32 myN = over ? 0u : gw;
+    const bool publish = has && !handBack && !over;
+    u32 total = 0, before = 0;
+#pragma unroll
+    for( int k = 0; k < G; k++ )
+    {
+        const u32 v = (u32)gflag[ k ];
+        const u32 c = ( v & 0x40000000u ) ? 0u : v;
+        const bool pub = (u32)__builtin_amdgcn_readlane( (i32)( publish ? 1 : 0 ), k * LANES ) != 0;
+        if( k < g )
+            before += pub ? c : 0u;
+        total += pub ? c : 0u;
+    }
+    total = (u32)__builtin_amdgcn_readfirstlane( (i32)total );
+    u64 off0;
+    if( O.cig_chunk == 0 || total > O.cig_chunk )
+    {
+        if( threadIdx.x == 0 )
+            *sOff = atomicAdd( O.cig_used, (unsigned long long)total );
+        __syncthreads( );
+        off0 = *sOff;
+        __syncthreads( );
+    }
+    else
+    {
+        if( total > acc.chunk_left )
+        {
+            if( threadIdx.x == 0 )
+                *sOff = atomicAdd( O.cig_used, (unsigned long long)O.cig_chunk );
+            __syncthreads( );
+            acc.chunk_off = *sOff;
+            acc.chunk_left = O.cig_chunk;
+            __syncthreads( );
+        }
+        off0 = acc.chunk_off;
+        acc.chunk_off += total;
+        acc.chunk_left -= total;
+    }
+    const u64 off = off0 + before;
+    const bool fits = off + myN <= O.cig_pool_cap;
+    // cells the job computed: the band cells of the diagonals 0 .. rLast (the group's lanes take the diagonals in turn)
+    u64 cellsJob = 0;
+    if( has && rLast >= 0 && publish )
+    {
+        u32 c = 0;
+        for( i32 rr = l; rr <= rLast; rr += LANES )
+        {
+            const i32 lo = max( max( 0, rr - tlen + 1 ), ( rr - B + 1 ) >> 1 ), hi = min( min( qlen - 1, rr ), ( rr + B ) >> 1 );
+            c += hi >= lo ? (u32)( hi - lo + 1 ) : 0u;
+        }
+        c += (u32)dpp_ctrl<0x121>( (i32)c );
+        c += (u32)dpp_ctrl<0x122>( (i32)c );
+        c += (u32)dpp_ctrl<0x124>( (i32)c );
+        c += (u32)dpp_ctrl<0x128>( (i32)c );
+        cellsJob = c;
+    }
+    if( l == 0 && publish )
+    {
+        ma_ez rz;
+        rz.max = untouched ? 0 : ( ezmax & 0x7fffffff );
+        rz.zdropped = 0;
+        rz.max_q = maxQ;
+        rz.max_t = maxT;
+        rz.mqe = (i32)0x80000000;
+        rz.mqe_t = -1;
+        rz.mte = (i32)0x80000000;
+        rz.mte_q = -1;
+        rz.score = (i32)0x80000000;
+        rz.reach_end = 0;
+        rz.n_cigar = (i32)myN;
+        O.ez[ slot ] = rz;
+        O.cig_off[ slot ] = off;
+        if( !fits )
+            atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
+    }
+    if( l == 0 && has && ( handBack || over ) )
+        redo[ atomicAdd( nRedo, 1u ) ] = slot;
+    if( publish && fits )
+        for( u32 i = (u32)l; i < myN; i += LANES ) // the walk leaves the cigar reversed (kswcpp_core.h:146-149)
+            O.cig_pool[ off + i ] = revCigar ? myCig[ i ] : myCig[ myN - 1 - i ];
+    {
+        u64 c = l == 0 && publish ? cellsJob : 0, p = l == 0 && publish ? (u64)steps : 0, nj = l == 0 && publish ? 1 : 0, cw = l == 0 && publish ? myN : 0;
+#pragma unroll
+        for( int k = 0; k < G; k++ )
+        {
+            acc.cells += (u32)__builtin_amdgcn_readlane( (i32)(u32)c, k * LANES );
+            acc.path += (u32)__builtin_amdgcn_readlane( (i32)(u32)p, k * LANES );
+            acc.njobs += (u32)__builtin_amdgcn_readlane( (i32)(u32)nj, k * LANES );
+            acc.cig_words += (u32)__builtin_amdgcn_readlane( (i32)(u32)cw, k * LANES );
+        }
+    }
+    __syncthreads( ); // LDS and the scratch rows are free for the next set
+    if( l == 0 && has ) // (per group leader: summed over the leaders at the kernel's end)
+    {
+        pf[ 0 ] += 1;
+        pf[ 1 ] += publish ? 1 : 0;
+        pf[ 2 ] += why == 1, pf[ 3 ] += why == 2, pf[ 4 ] += why == 3, pf[ 5 ] += why == 4;
+        pf[ 6 ] += !publish && !why ? 1 : 0;
+        pf[ 7 ] += (u32)( rLast + 1 );
+    }
+}
+
+template <typename FETCH, bool LEFT>
+__global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 5, 5 ) ) )
+k_ksw_band( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* redo, unsigned int* nRedo )
+{
+    __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[ KSW_BAND_LDS ];
+    __shared__ u32 sSet;
+    __shared__ unsigned long long sOff;
+    uint8_t* P = scratch + (u64)blockIdx.x * stride;
+    KswWaveAcc acc;
+    u32 stats[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    u32 cur = 0, end = 0;
+    while( true )
+    {
+        if( cur >= end )
+        {
+            if( threadIdx.x == 0 )
+                sSet = atomicAdd( next, 16u );
+            __syncthreads( );
+            cur = sSet;
+            __syncthreads( );
+            if( cur >= n )
+                break;
+            end = cur + 16 < n ? cur + 16 : n;
+        }
+        ksw_band_set<LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff, stats );
+        cur += 4;
+    }
+    ksw_flush( O, acc );
+    for( int i = 0; i < 8; i++ )
+    {
+        u32 v = 0;
+        for( int k = 0; k < 4; k++ )
+            v += (u32)__builtin_amdgcn_readlane( (i32)stats[ i ], k * 16 );
+        if( threadIdx.x == 0 && v )
+            atomicAdd( g_band_stats + i, (unsigned long long)v );
+    }
+}
+} // namespace ma
+#endif

@@ -54,7 +54,7 @@ MA_HD int ksw_grp_size( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdr
     if( zdrop > 16000 )
         return 0; // the z-drop threshold is kept as a packed int16
     // 4 / 2 jobs per wave with two rows per lane; 1 = two jobs per wave with FOUR rows per lane (MA_KSW_GRP=1 leaves those to k_ksw_ext<1>)
-    return qlen <= 32 ? 4 : ( qlen <= 64 ? 2 : ( qlen <= 128 && SC.grp >= 2 ? 1 : 0 ) );
+    return qlen <= 32 ? 4 : ( qlen <= 64 ? 2 : ( qlen <= 128 && SC.grp == 2 ? 1 : 0 ) );
 }
 
 template <int LANES> __device__ __forceinline__ i32 grp_max_i32( i32 v ) // maximum over the 64 / G lanes of a group, in every lane

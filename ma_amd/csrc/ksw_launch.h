@@ -165,6 +165,7 @@ __device__ __forceinline__ bool ksw_next( unsigned int* nextSlot, u32 n, u32& cu
 
 } // namespace ma
 #include "ksw_grp.h"
+#include "ksw_band.h"
 namespace ma
 {
 // MA_KSW_GRP=0 (A/B and test hook) keeps the short extensions on the one-job-per-wavefront kernel.  The switch travels in
@@ -174,6 +175,8 @@ namespace ma
 MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag )
 {
     const int e = ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag );
+    if( e && SC.grp >= 1000 && ksw_band_ok( SC, qlen, tlen, w, zdrop, flag, SC.grp - 1000 ) )
+        return KSW_CLS_GRP0 + ( ( flag & KSW_EZ_RIGHT ) ? 1 : 0 ); // the proven narrow band: four jobs per wave (ksw_band.h)
     if( e == 1 && ksw_grp_enabled( ) )
         if( const int G = ksw_grp_size( SC, qlen, tlen, w, zdrop, flag ) )
             return KSW_CLS_GRP0 + ( G == 4 ? 4 : ( G == 2 ? 2 : 0 ) ) + ( ( flag & KSW_EZ_RIGHT ) ? 1 : 0 );
@@ -395,7 +398,9 @@ inline i32 ksw_grp_env( ) // KswScoring::grp (read on every call: the tests swit
     // 2 (A/B): also the jobs of 65..128 query bases, two per wave with four rows per lane -- measured slower than k_ksw_ext<1> (150 bp:
     // DP 19.1 -> 20.0 ms): a register set's recurrence is 76 of the ~91 instructions of a diagonal, so sharing the rest buys 16 % per
     // job at best, and 128 VGPRs leave 4 waves per SIMD where k_ksw_ext runs 8
-    return e ? std::max( 0, std::min( 2, atoi( e ) ) ) : 1;
+    // 3 (or 1000 + n): extensions of 65 (n) .. 254 query bases on the proven narrow band, four per wave (ksw_band.h)
+    const i32 v = e ? std::max( 0, atoi( e ) ) : 1;
+    return v == 3 ? 1065 : ( v >= 1000 ? std::min( v, 1000 + KSW_BAND_QMAX ) : std::min( v, 2 ) );
 }
 // sizes for a job population (host side)
 struct KswSizing
@@ -561,9 +566,9 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     KswLaunchPlan LG;
     if( nGrp )
     {
-        const u64 sets = ( SZ.cls[ 7 ] + 1 ) / 2 + ( SZ.cls[ 8 ] + 1 ) / 2 + ( SZ.cls[ 9 ] + 1 ) / 2 + ( SZ.cls[ 10 ] + 1 ) / 2 + ( SZ.cls[ 11 ] + 3 ) / 4 + ( SZ.cls[ 12 ] + 3 ) / 4;
+        const u64 sets = ( SZ.cls[ 7 ] + 1 ) / ( SC.grp >= 1000 ? 4 : 2 ) + ( SZ.cls[ 8 ] + 1 ) / ( SC.grp >= 1000 ? 4 : 2 ) + ( SZ.cls[ 9 ] + 1 ) / 2 + ( SZ.cls[ 10 ] + 1 ) / 2 + ( SZ.cls[ 11 ] + 3 ) / 4 + ( SZ.cls[ 12 ] + 3 ) / 4;
         // (direction rows of 256 B when the four-rows-per-lane lists have jobs)
-        LG = ksw_plan_launch( (u64)KSW_GRP_ROWS * ( SZ.cls[ 7 ] + SZ.cls[ 8 ] ? 256 : 128 ), 0, sets, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
+        LG = ksw_plan_launch( (u64)KSW_GRP_ROWS * ( SC.grp < 1000 && SZ.cls[ 7 ] + SZ.cls[ 8 ] ? 256 : 128 ), 0, sets, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
     }
     for( int k = 0; k < 7; k++ )
     {
@@ -734,15 +739,25 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
             if( nk == 0 )
                 continue;
             const u32* lk = lists + (u64)( KSW_CLS_GRP0 + k ) * list_stride;
-            const u32 Gk = k < 4 ? 2u : 4u;
+            const u32 Gk = k < 2 && SC.grp >= 1000 ? 4u : ( k < 4 ? 2u : 4u );
             const u32 waves = (u32)std::max<u64>( 1, std::min<u64>( LG.waves, ( nk + Gk - 1 ) / Gk ) );
             uint8_t* sb = base + laneBase[ 0 ];
             switch( k )
             {
             case 0:
+                if( SC.grp >= 1000 )
+                {
+                    hipLaunchKernelGGL( ( k_ksw_band<FETCH, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                    break;
+                }
                 hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 2, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
                 break;
             case 1:
+                if( SC.grp >= 1000 )
+                {
+                    hipLaunchKernelGGL( ( k_ksw_band<FETCH, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                    break;
+                }
                 hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 2, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
                 break;
             case 2:

@@ -26,7 +26,9 @@ static __device__ unsigned long long g_ksw_prof[ 16 ]; // phase cycle counters (
 struct KswScoring
 {
     i32 match, mismatch, q, e, q2, e2; // KswCppParam<5> (kswcpp.h:44-129)
-    i32 grp = 1; // not a score: short extensions may share a wavefront (ksw_grp.h; ksw_job_class_pipe); MA_KSW_GRP=0 clears it
+    // not a score: short extensions may share a wavefront (ksw_grp.h; ksw_job_class_pipe).  0 off, 1 queries up to 64 bases, 2 also
+    // 65..128 with four rows per lane (A/B), 1000 + n: extensions of n..254 query bases on the proven narrow band (ksw_band.h)
+    i32 grp = 1;
 };
 
 // Working storage of one job (flat pointers: LDS or HBM)

@@ -1061,6 +1061,16 @@ int ma_batch_get_dp_jobs( ma_batch* b, uint64_t* n_jobs, int32_t* shapes /* 8 x 
     return 0;
 }
 
+// diagnostics: what became of the extension jobs tried on the proven narrow band (ksw_band.h) since the library was loaded:
+// tried, proved, failed check 1 / 2 / 3 / 4, handed back for another reason, diagonals run
+int ma_debug_band_stats( unsigned long long out[ 8 ] )
+{
+    if( !out )
+        return fail( "ma_debug_band_stats: null argument" );
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_band_stats ), 8 * 8 ) );
+    return 0;
+}
+
 #if defined( MA_CHAIN_PROF )
 int ma_debug_chain_prof( unsigned long long* out )
 {

@@ -462,3 +462,91 @@ def test_double_buffered_io_of_a_batch_object(gpu_device):
         for x in o:
             x.close()
     idx.close()
+
+
+def band_stats():
+    import ma_amd
+    out = (C.c_ulonglong * 8)()
+    assert ma_amd.lib().ma_debug_band_stats(out) == 0
+    return np.array(list(out), dtype=np.int64)
+
+
+def band_extension_cases(n, seed, qmin=65, qmax=254):
+    """Extension jobs of qmin..qmax query bases as the pipeline emits them (band 512, z-drop 200, target = query + up to 1000 padded
+    bases): a noisy copy of the target's head that starts with a mismatch (a seed ended there), 0..12 % errors incl. indels of up
+    to 30 bases, tandem repeats and low-complexity stretches (where the alignment may wander), junk, Ns."""
+    from ma_testlib import KSW_EXTZ, KSW_REV, KSW_RIGHT
+    rng = np.random.default_rng(seed)
+    cases = []
+    for k in range(n):
+        ql = int(rng.integers(qmin, qmax + 1))
+        tl = int(rng.choice([ql + 1000, ql + 1000, ql + 300, ql + 40, ql, max(1, ql - 20), ql // 2 + 1]))
+        t = rng.integers(0, 4, size=tl + 64, dtype=np.uint8)
+        kind = rng.random()
+        if kind < 0.25:  # repeats: several alignments of about the same score
+            unit = rng.integers(0, 4, size=int(rng.integers(1, 12)), dtype=np.uint8)
+            s0, L = int(rng.integers(0, max(1, tl // 2))), int(rng.integers(10, 200))
+            t[s0:s0 + L] = np.resize(unit, L)
+        er_sub, er_indel = rng.choice([0.0, 0.005, 0.02, 0.05, 0.12]), rng.choice([0.0, 0.0, 0.003, 0.02])
+        out, i = [], 0
+        while len(out) < ql and i < len(t) - 31:
+            u = rng.random()
+            if len(out) == 0 and rng.random() < 0.7:
+                out.append((int(t[i]) + 1 + int(rng.integers(0, 3))) % 4); i += 1
+            elif u < er_sub:
+                out.append((int(t[i]) + 1 + int(rng.integers(0, 3))) % 4); i += 1
+            elif u < er_sub + er_indel:
+                g = int(rng.integers(1, 31))
+                if rng.random() < 0.5:
+                    out.extend(int(x) for x in rng.integers(0, 4, size=g))
+                else:
+                    i += g
+            else:
+                out.append(int(t[i])); i += 1
+        q = np.array((out + [0] * ql)[:ql], dtype=np.uint8)
+        if kind > 0.93:
+            q = rng.integers(0, 4, size=ql, dtype=np.uint8)  # junk
+        if rng.random() < 0.05:
+            q[rng.random(ql) < 0.1] = 4  # N
+        zd = int(rng.choice([200, 200, 200, 100, 30]))
+        fl = KSW_EXTZ if rng.random() < 0.5 else (KSW_EXTZ | KSW_RIGHT | KSW_REV)
+        cases.append((q, np.ascontiguousarray(t[:tl]), 512, zd, fl))
+    return cases
+
+
+@pytest.mark.parametrize("scoring", [None, (3, 5, 6, 3, 30, 2), (2, 4, 12, 1, 6, 3)])
+def test_banded_extensions_are_the_wide_bands_or_handed_back(gpu_device, scoring, monkeypatch):
+    """ksw_band.h (MA_KSW_GRP=3): extension jobs on a band of 24 cells, four per wavefront, each one PROVEN after the fact to be
+    the wide band's result or handed back to the exact kernel.  Every job's max, max_q, max_t and cigar against the oracle's
+    kswcpp at the full band (kswcpp_core.h:308-879); a healthy share of the jobs must be proved (else the test tests nothing)."""
+    import ma_amd
+    from ma_testlib import or_ksw
+    P = ma_amd.Params.preset("default")
+    op = or_params("default", 1)
+    if scoring is not None:
+        for prm in (P, op):
+            prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
+    monkeypatch.setenv("MA_KSW_GRP", "3")
+    for n, seed, qmin in ((6000, 21, 65), (1500, 22, 1033 - 1000), (3, 23, 65)):
+        if qmin != 65:
+            monkeypatch.setenv("MA_KSW_GRP", str(1000 + qmin))  # also the queries of 33..64 bases
+        cases = band_extension_cases(n, seed + (0 if scoring is None else 10 * scoring[0]), qmin=qmin)
+        s0 = band_stats()
+        ez, cigs = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
+        s1 = band_stats() - s0
+        bad = 0
+        for i, (q, t, w, zd, fl) in enumerate(cases):
+            oez, ocig = or_ksw(op, q, t, w, zd, fl)
+            same = all(int(ez[f][i]) == int(oez[f]) for f in ("max", "max_q", "max_t")) and np.array_equal(cigs[i], ocig)
+            if not same and bad < 5:
+                print("case %d (qlen %d tlen %d zdrop %d flag %#x): got %s %s, oracle %s %s" % (
+                    i, len(q), len(t), zd, fl, [int(ez[f][i]) for f in ("max", "max_q", "max_t")], cigs[i].tolist()[:12],
+                    [int(oez[f]) for f in ("max", "max_q", "max_t")], ocig.tolist()[:12]))
+            bad += 0 if same else 1
+        print("band: %d jobs tried, %d proved, failed checks %s, handed back otherwise %d, %.1f diagonals per job" % (
+            s1[0], s1[1], s1[2:6].tolist(), s1[6], s1[7] / max(s1[0], 1)))
+        assert bad == 0, "%d of %d jobs differ from the oracle" % (bad, len(cases))
+        assert s1[0] == len(cases)
+        if n > 100:
+            assert s1[1] > 0.4 * s1[0], s1
+    monkeypatch.delenv("MA_KSW_GRP")
