@@ -281,19 +281,6 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             nextBlk++;
             __syncthreads( );
         }
-        // ---- a lane whose rows have both left the band takes the rows 32 further on: lane l on diagonal 4 l + B + 3 (+ 64 k)
-        if( __builtin_expect( r >= B + 3 && ( ( r - B - 3 ) & 3 ) == 0, 0 ) )
-        {
-            if( l == ( ( ( r - B - 3 ) >> 2 ) & 15 ) )
-            {
-                Jpk = pk_add( Jpk, 0x00200020u );
-                rowState( Jpk, Jmask, Qb, V, H, entOk );
-                Jmask &= (u32)act;
-                X = K_X0, X2 = K_X20, U = K_GAP, Y = K_Y0, Y2 = K_Y20;
-                Tpk = pk_sub( pk_bcast( r ), Jpk );
-                leadLo = 0;
-            }
-        }
         if( __builtin_expect( r >= KSW_GRP_STAGE_ROWS && ( r & ( KSW_GRP_STAGE_ROWS / 2 - 1 ) ) == 0, 0 ) )
         {
             // rows [r - 32, r - 16) -> HBM (ksw_grp.h)
@@ -313,6 +300,20 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
         const u32 ut = pk_bfi( leadLo, ( (u32)uInS & 0xffu ) << 8, ut0 );
         const u32 yt = pk_bfi( leadLo, K_Y0, yt0 );
         const u32 y2t = pk_bfi( leadLo, K_Y20, y2t0 );
+        // ---- a lane whose rows have both left the band takes the rows 32 further on: lane l on diagonal 4 l + B + 3 (+ 64 k).
+        // AFTER the shifts above: what its last live cell computed on the diagonal before is read by the next lane on this one
+        if( __builtin_expect( r >= B + 3 && ( ( r - B - 3 ) & 3 ) == 0, 0 ) )
+        {
+            if( l == ( ( ( r - B - 3 ) >> 2 ) & 15 ) )
+            {
+                Jpk = pk_add( Jpk, 0x00200020u );
+                rowState( Jpk, Jmask, Qb, V, H, entOk );
+                Jmask &= (u32)act;
+                X = K_X0, X2 = K_X20, U = K_GAP, Y = K_Y0, Y2 = K_Y20;
+                Tpk = pk_sub( pk_bcast( r ), Jpk );
+                leadLo = 0;
+            }
+        }
         // the target bases of the lane's cells: t (low half) and t - 1
         const i32 tLo = (i32)( (u32)( Tpk << 16 ) ) >> 16;
         const u32 tt = (u32)myRing[ tLo & 63 ] | (u32)myRing[ ( tLo - 1 ) & 63 ] << 16;
