@@ -9,6 +9,7 @@ namespace ma
 {
 void set_error( const std::string& s );
 int fail( const std::string& s );
+int band_stats_of_prims( unsigned long long out[ 8 ] ); // prims.hip: its copy of ksw_band.h's statistics
 u32 sa_dense_shift( ); // index.hip: log2 of the dense SA sample's interval (0: none)
 }
 struct ma_index;

@@ -31,8 +31,8 @@
 //      the wide matrix's, and the path stays inside the band (the walk checks it anyway).
 //   4. no z-drop in the wide run: its ez.max is at most a (r / 2 + 1) on diagonal r and its diagonal maximum at least the
 //      band's, which after a raise to m0 on r0 is at least m0 - (r - r0)(q + e) (ksw_grp.h); the difference stays <= zdrop.
-// A job that fails a check, leaves the regime (r > w) or outgrows its cigar buffer goes to the hand-back list like the jobs
-// ksw_ext.h hands back.  tests/test_gpu_round5.py::test_banded_extensions_are_the_wide_bands_or_handed_back compares every
+// A job that fails a check, leaves the regime (r > w) or outgrows its cigar buffer is appended to the list of the extension
+// kernel it would have gone to without this one (k_ksw_ext<1> / <2>, which run after it).  tests/test_gpu_round5.py::test_banded_extensions_are_the_wide_bands_or_handed_back compares every
 // proved job with the oracle's kswcpp at the full band.
 #pragma once
 #include "ksw_grp.h"
@@ -54,6 +54,26 @@ MA_HD int ksw_band_ok( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdro
     if( zdrop < 0 || zdrop > 16000 )
         return 0;
     return ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag ) != 0 ? 1 : 0;
+}
+
+// Which of the eligible jobs are WORTH the attempt: the checks pass for alignments that lose less than ~44 points against a
+// perfect one, and two thirds of the extension jobs of a 150 bp batch are junk (a read end that does not continue where its seed
+// lies: profiles/r05_band_stats_150bp.txt, 64 % fail check 1).  A job is tried when the query's first min(qlen, tlen) bases differ
+// from the target's in at most KSW_BAND_MAXMIS places on the main diagonal (junk leaves the loop after a handful of bases); the
+// others go to the kernels they went to before.  qf / tf: base j of the query / t of the target in DP order.
+#define KSW_BAND_MAXMIS 5
+template <typename QF, typename TF> MA_HD bool ksw_band_likely( const QF& qf, const TF& tf, i32 qlen, i32 tlen )
+{
+    if( tlen < qlen )
+        return false;
+    int mis = 0;
+    for( i32 i = 0; i < qlen; i++ )
+    {
+        mis += (u32)qf( i ) != (u32)tf( i ) ? 1 : 0;
+        if( mis > KSW_BAND_MAXMIS )
+            return false;
+    }
+    return true;
 }
 
 // calcMaxScore over the band cells of diagonal rr (grp_exact_max of ksw_grp.h with the cells' rows per lane in Jpk and the band
@@ -131,7 +151,8 @@ __device__ __forceinline__ void band_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qle
 // One set of up to four jobs (queue entries [at0, min(at0 + 4, n))), all of them left- (LEFT) or right-aligned extensions.
 template <bool LEFT, typename FETCH>
 __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* list, u32 n, u32 at0, uint8_t* P /*KSW_GRP_ROWS x 128 B*/, uint8_t* lds,
-                              const KswOut& O, KswWaveAcc& acc, u32* redo, unsigned int* nRedo, unsigned long long* sOff, u32* pf /*the wave's statistics*/ )
+                              const KswOut& O, KswWaveAcc& acc, u32* ext1, u32 nExt1, u32* ext2, u32 nExt2, unsigned int* extMore, unsigned long long* sOff,
+                              u32* pf /*the wave's statistics*/ )
 {
     constexpr int G = 4, LANES = 16, CJ = 32, B = KSW_BAND_B;
     const int lane = threadIdx.x & 63, g = lane / LANES, l = lane % LANES;
@@ -600,7 +621,14 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             atomicOr( O.err, MA_ERR_CIGAR_OVERFLOW );
     }
     if( l == 0 && has && ( handBack || over ) )
-        redo[ atomicAdd( nRedo, 1u ) ] = slot;
+    {
+        // to the list of the extension kernel the job would have gone to (k_ksw_ext<1> / <2> run after this kernel on the same
+        // stream and read the number of appended jobs from extMore[ 0 ] / [ 1 ])
+        if( ksw_ext_slots( SC, qlen, tlen, wJob, zdrop, F.view( slot ).flag ) == 2 )
+            ext2[ nExt2 + atomicAdd( extMore + 1, 1u ) ] = slot;
+        else
+            ext1[ nExt1 + atomicAdd( extMore + 0, 1u ) ] = slot;
+    }
     if( publish && fits )
         for( u32 i = (u32)l; i < myN; i += LANES ) // the walk leaves the cigar reversed (kswcpp_core.h:146-149)
             O.cig_pool[ off + i ] = revCigar ? myCig[ i ] : myCig[ myN - 1 - i ];
@@ -628,7 +656,8 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
 
 template <typename FETCH, bool LEFT>
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 5, 5 ) ) )
-k_ksw_band( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* redo, unsigned int* nRedo )
+k_ksw_band( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* ext1, u32 nExt1, u32* ext2,
+            u32 nExt2, unsigned int* extMore )
 {
     __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[ KSW_BAND_LDS ];
     __shared__ u32 sSet;
@@ -650,7 +679,7 @@ k_ksw_band( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, 
                 break;
             end = cur + 16 < n ? cur + 16 : n;
         }
-        ksw_band_set<LEFT>( F, SC, list, n, cur, P, lds, O, acc, redo, nRedo, &sOff, stats );
+        ksw_band_set<LEFT>( F, SC, list, n, cur, P, lds, O, acc, ext1, nExt1, ext2, nExt2, extMore, &sOff, stats );
         cur += 4;
     }
     ksw_flush( O, acc );

@@ -218,9 +218,11 @@ MA_HD bool ksw_tier_takes( const KswJobs& JB, i32 qlen, i32 tlen, i32 w )
 template <typename FETCH, int R>
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( R == 1 ? 7 : 4 ) ) ) k_ksw_ext( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* nextSlot,
                                                   uint8_t* scratch, u64 stride, u64 p_cap, u32 ldsBytes, KswOut O,
-                                                  u32* redo, unsigned int* nRedo )
+                                                  u32* redo, unsigned int* nRedo, const unsigned int* nMore /*jobs k_ksw_band appended to the list, or null*/ )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) char lds[];
+    if( nMore )
+        n += *nMore;
     __shared__ u32 sSlot;
     __shared__ unsigned long long sOff;
     __shared__ uint2 sSnap[ 64 * R ]; // the lanes' H of the diagonal that raised ez.max last (ksw_ext.h)
@@ -398,8 +400,9 @@ inline i32 ksw_grp_env( ) // KswScoring::grp (read on every call: the tests swit
     // 2 (A/B): also the jobs of 65..128 query bases, two per wave with four rows per lane -- measured slower than k_ksw_ext<1> (150 bp:
     // DP 19.1 -> 20.0 ms): a register set's recurrence is 76 of the ~91 instructions of a diagonal, so sharing the rest buys 16 % per
     // job at best, and 128 VGPRs leave 4 waves per SIMD where k_ksw_ext runs 8
-    // 3 (or 1000 + n): extensions of 65 (n) .. 254 query bases on the proven narrow band, four per wave (ksw_band.h)
-    const i32 v = e ? std::max( 0, atoi( e ) ) : 1;
+    // 3 (or 1000 + n): extensions of 65 (n) .. 254 query bases on the proven narrow band, four per wave (ksw_band.h).  Default: 1033
+    // (150 bp: DP 19.0 ms with 1, 16.4 with 3, 15.7 with 1033)
+    const i32 v = e ? std::max( 0, atoi( e ) ) : 1033;
     return v == 3 ? 1065 : ( v >= 1000 ? std::min( v, 1000 + KSW_BAND_QMAX ) : std::min( v, 2 ) );
 }
 // sizes for a job population (host side)
@@ -543,6 +546,9 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( nJobs == 0 )
         return 0;
     const u64 nGrp = SZ.cls[ 7 ] + SZ.cls[ 8 ] + SZ.cls[ 9 ] + SZ.cls[ 10 ] + SZ.cls[ 11 ] + SZ.cls[ 12 ];
+    // jobs on the proven narrow band (ksw_band.h): those that fail a check are appended to the lists of k_ksw_ext<1> / <2>, which
+    // run after them (next[ 17 ], next[ 18 ] count them)
+    const u64 nBand = SC.grp >= 1000 ? SZ.cls[ 7 ] + SZ.cls[ 8 ] : 0;
     const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ] + nGrp;
     const bool conc = side && side->ready( ) && lists; // classes on their own streams
     u64 perCu = 32; // waves per CU of the persistent ksw launches (MA_KSW_WAVES_PER_CU: tuning hook)
@@ -572,11 +578,13 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     }
     for( int k = 0; k < 7; k++ )
     {
-        if( k == 4 || SZ.cls[ k ] == 0 )
+        if( k == 4 || ( SZ.cls[ k ] == 0 && !( k >= 5 && nBand ) ) )
             continue;
         const u64 pk = SZ.pc[ k ] ? SZ.pc[ k ] : ( k >= 5 ? std::max( SZ.p, ksw_ext_p_bytes( 256, 2048, k - 4 ) ) : SZ.p );
         const u64 cg = SZ.cigc[ k ] ? SZ.cigc[ k ] : SZ.cig;
-        LP[ k ] = ksw_plan_launch( pk, cg, SZ.cls[ k ], wantOf( k ), budgetOf[ k ] );
+        // (the narrow band hands on a few per cent of its jobs: the extension kernels' waves are planned for their own jobs plus a
+        // sixteenth of the band's -- more of them would only wait their turn)
+        LP[ k ] = ksw_plan_launch( pk, cg, SZ.cls[ k ] + ( k >= 5 && nBand ? nBand / 16 + 64 : 0 ), wantOf( k ), budgetOf[ k ] );
         if( k >= 5 )
         {
             LP[ k ].lds = KSW_EXT_LDS;
@@ -747,7 +755,8 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
             case 0:
                 if( SC.grp >= 1000 )
                 {
-                    hipLaunchKernelGGL( ( k_ksw_band<FETCH, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                    hipLaunchKernelGGL( ( k_ksw_band<FETCH, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O,
+                                        lists + 5 * list_stride, (u32)SZ.cls[ 5 ], lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 17 );
                     break;
                 }
                 hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 2, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
@@ -755,7 +764,8 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
             case 1:
                 if( SC.grp >= 1000 )
                 {
-                    hipLaunchKernelGGL( ( k_ksw_band<FETCH, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+                    hipLaunchKernelGGL( ( k_ksw_band<FETCH, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O,
+                                        lists + 5 * list_stride, (u32)SZ.cls[ 5 ], lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 17 );
                     break;
                 }
                 hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 2, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
@@ -773,14 +783,14 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
                 hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 4, 1, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
             }
         }
-    if( SZ.cls[ 5 ] )
+    if( SZ.cls[ 5 ] || nBand )
         hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 1> ), dim3( LP[ 5 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
                             lists + 5 * list_stride, (u32)SZ.cls[ 5 ], next + 5, base + laneBase[ 0 ], LP[ 5 ].stride, LP[ 5 ].p_cap, KSW_EXT_LDS,
-                            O, redo, nRedo );
-    if( SZ.cls[ 6 ] )
+                            O, redo, nRedo, nBand ? next + 17 : nullptr );
+    if( SZ.cls[ 6 ] || nBand )
         hipLaunchKernelGGL( ( k_ksw_ext<FETCH, 2> ), dim3( LP[ 6 ].waves ), dim3( 64 ), KSW_EXT_LDS, stream, F, SC,
                             lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 6, base + laneBase[ 0 ], LP[ 6 ].stride, LP[ 6 ].p_cap, KSW_EXT_LDS,
-                            O, redo, nRedo );
+                            O, redo, nRedo, nBand ? next + 18 : nullptr );
     if( !conc )
         for( int k = 0; k < 4; k++ )
             launchPk( 0, k );

@@ -1067,7 +1067,13 @@ int ma_debug_band_stats( unsigned long long out[ 8 ] )
 {
     if( !out )
         return fail( "ma_debug_band_stats: null argument" );
+    // (a static __device__ array per translation unit: the pipeline's kernels count here, those of ma_ksw_ext_batch in prims.hip)
+    unsigned long long other[ 8 ];
     MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_band_stats ), 8 * 8 ) );
+    if( ma::band_stats_of_prims( other ) )
+        return 1;
+    for( int i = 0; i < 8; i++ )
+        out[ i ] += other[ i ];
     return 0;
 }
 

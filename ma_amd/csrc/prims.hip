@@ -144,7 +144,20 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
             const i32 ql = jobs[ i ].qlen, tl = jobs[ i ].tlen;
             if( ql <= 0 || tl <= 0 )
                 continue;
-            const int c = ksw_job_class_pipe( SC, ql, tl, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
+            int c = ksw_job_class_pipe( SC, ql, tl, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
+            if( SC.grp >= 1000 && ( c == KSW_CLS_GRP0 || c == KSW_CLS_GRP0 + 1 ) && !getenv( "MA_KSW_BAND_ALL" ) )
+            {
+                // (k_dp_enum's pre-filter of the narrow band; MA_KSW_BAND_ALL=1: the tests try every eligible job)
+                const uint8_t *qp = q_bytes + jobs[ i ].q_off, *tp = t_bytes + jobs[ i ].t_off;
+                auto qf = [ & ]( i32 k ) -> u32 { return qp[ k ]; };
+                auto tf = [ & ]( i32 k ) -> u32 { return tp[ k ]; };
+                if( !ksw_band_likely( qf, tf, ql, tl ) )
+                {
+                    KswScoring S1 = SC;
+                    S1.grp = 1;
+                    c = ksw_job_class_pipe( S1, ql, tl, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
+                }
+            }
             lists[ (size_t)c * n + S.cls[ c ]++ ] = (u32)i;
             const u64 pk = ksw_p_bytes( ql, tl, jobs[ i ].w ), cg = (u64)ql + tl + 2;
             S.pc[ c ] = std::max( S.pc[ c ], c >= KSW_CLS_GRP0 ? 0 : ( c >= 5 ? ksw_ext_p_bytes( ql, tl, c - 4 ) : pk ) );
@@ -153,6 +166,12 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
             {
                 S.pRedo = std::max( S.pRedo, pk );
                 S.cigRedo = std::max( S.cigRedo, cg );
+            }
+            if( SC.grp >= 1000 && ( c == KSW_CLS_GRP0 || c == KSW_CLS_GRP0 + 1 ) )
+            {
+                const int e = ksw_ext_slots( SC, ql, tl, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag ); // its extension kernel, should it fail its checks
+                S.pc[ 4 + e ] = std::max( S.pc[ 4 + e ], ksw_ext_p_bytes( ql, tl, e ) );
+                S.cigc[ 4 + e ] = std::max( S.cigc[ 4 + e ], cg );
             }
         }
         if( dlists.reserve( lists.size( ) * 4 + 16 ) )
@@ -233,6 +252,15 @@ __global__ void k_libm_probe( int op, const double* in, u64 n, double* out )
     const double x = in[ i ];
     out[ i ] = op == 0 ? tan( x ) : op == 1 ? sin( x ) : op == 2 ? atan( x ) : log( x );
 }
+namespace ma
+{
+int band_stats_of_prims( unsigned long long out[ 8 ] )
+{
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_band_stats ), 8 * 8 ) );
+    return 0;
+}
+} // namespace ma
+
 extern "C" int ma_debug_libm( int op, const double* in, uint64_t n, double* out )
 {
     if( !in || !out || op < 0 || op > 3 )

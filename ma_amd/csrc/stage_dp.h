@@ -158,7 +158,20 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
             pj = cj = pk8 = 0;
             if( A.one_by_one && ql == 1 && tl == 1 && j.flag == 0 && j.zdrop < 0 )
                 return -2; // answered here (first pass)
-            const int cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
+            int cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
+            if( A.SC.grp >= 1000 && ( cls == KSW_CLS_GRP0 || cls == KSW_CLS_GRP0 + 1 ) )
+            {
+                // the proven narrow band (ksw_band.h) is tried on the jobs whose query follows the target's main diagonal
+                const uint8_t* qb = A.reads + j.read_off;
+                auto qf = [ & ]( i32 i ) -> u32 { return j.rev ? qb[ j.q_to - 1 - (u32)i ] : qb[ j.q_from + (u32)i ]; };
+                auto tf = [ & ]( i32 i ) -> u32 { return text_base( A.X, j.win_begin + ( j.rev ? j.r_to - 1 - (u32)i : j.r_from + (u32)i ) ); };
+                if( !ksw_band_likely( qf, tf, ql, tl ) )
+                {
+                    KswScoring S1 = A.SC;
+                    S1.grp = 1;
+                    cls = ksw_job_class_pipe( S1, ql, tl, j.w, j.zdrop, j.flag );
+                }
+            }
             const u64 pk = ksw_p_bytes( ql, tl, j.w );
             // 256-byte units (the query-stationary classes from KSW_CLS_GRP0 on have a fixed scratch per wave: ksw_grp.h)
             pj = cls >= KSW_CLS_GRP0 ? 0u : (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 );
@@ -179,6 +192,21 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                 {
                     pRedo = max( pRedo, pk8 );
                     cgRedo = max( cgRedo, cj );
+                }
+                if( A.SC.grp >= 1000 && ( cls == KSW_CLS_GRP0 || cls == KSW_CLS_GRP0 + 1 ) )
+                {
+                    // a job on the narrow band that fails its checks goes on to k_ksw_ext<1> / <2>: their launches are sized for it too
+                    const DpJob& jj = A.jobs[ sink.slot0 + k ];
+                    const i32 ql = (i32)( jj.q_to - jj.q_from ), tl = (i32)( jj.r_to - jj.r_from );
+                    const int e = ksw_ext_slots( A.SC, ql, tl, jj.w, jj.zdrop, jj.flag );
+                    const u32 pe = (u32)( ( ksw_ext_p_bytes( ql, tl, e ) + 255 ) >> 8 );
+#pragma unroll
+                    for( int c = 5; c < 7; c++ )
+                        if( c == 4 + e )
+                        {
+                            pcl[ c ] = max( pcl[ c ], pe );
+                            cgl[ c ] = max( cgl[ c ], cj );
+                        }
                 }
                 if( cls == -2 )
                 {
