@@ -395,6 +395,7 @@ def run_workload(E, name, wl, args):
     for ph in phases:
         ph[:] = 0
     thr0 = cfs_throttle()
+    band0 = band_stats(E)
     t0 = time.perf_counter()
     if NB == 1:
         worker(0)
@@ -471,6 +472,13 @@ def run_workload(E, name, wl, args):
         "gather_ceiling_Gblocks_s": float(E.cal["gather_ceiling_gblocks"]),
         "dp_GCUPS": round(ctr[4] / (kms[4] / 1e3) / 1e9, 3) if kms[4] > 0 else 0.0,
         "dp_band_cells_per_read_executed": round(ctr[4] / max(n_reads, 1), 1)})
+    band1 = band_stats(E)
+    if band0 is not None and band1 is not None and band1[0] > band0[0]:
+        bd = band1 - band0
+        # ksw_band.h: extension jobs computed on a band of 24 cells, four per wavefront, each PROVEN afterwards to be the wide band's
+        # result; the others go on to the extension kernels.  (The timed region plus the parity / statistics read-backs behind it.)
+        roofline["narrow_band"] = {"jobs_tried": int(bd[0]), "proved": int(bd[1]), "failed_check_1_2_3_4": [int(x) for x in bd[2:6]],
+                                   "proved_frac": round(float(bd[1]) / float(bd[0]), 4)}
 
     # ---- CPU baseline (rank 0, N = 1): the compiled reference and the oracle on this host's cores, then parity ---------
     cpu = None
@@ -668,6 +676,17 @@ def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, 
                            "what": "GPU vs oracle on the first reads of step 0: every NeedlemanWunsch alignment (positions, score, "
                                    "ops) and MappingQuality record (flags, mapq bits)"}
     return cpu
+
+
+def band_stats(E):
+    """ma_debug_band_stats: jobs tried / proved on the narrow band since the library was loaded (this process, this device)"""
+    try:
+        out = (C.c_ulonglong * 8)()
+        if E.L.ma_debug_band_stats(out) != 0:
+            return None
+        return np.array(list(out), dtype=np.int64)
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_quota_cores():

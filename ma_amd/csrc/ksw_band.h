@@ -62,7 +62,7 @@ MA_HD int ksw_band_ok( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdro
 // from the target's in at most KSW_BAND_MAXMIS places on the main diagonal (junk leaves the loop after a handful of bases); the
 // others go to the kernels they went to before.  qf / tf: base j of the query / t of the target in DP order.
 #define KSW_BAND_MAXMIS 5
-template <typename QF, typename TF> MA_HD bool ksw_band_likely( const QF& qf, const TF& tf, i32 qlen, i32 tlen )
+template <typename QF, typename TF> MA_HD bool ksw_band_likely( const QF& qf, const TF& tf, i32 qlen, i32 tlen, i32 maxMis = KSW_BAND_MAXMIS )
 {
     if( tlen < qlen )
         return false;
@@ -70,7 +70,7 @@ template <typename QF, typename TF> MA_HD bool ksw_band_likely( const QF& qf, co
     for( i32 i = 0; i < qlen; i++ )
     {
         mis += (u32)qf( i ) != (u32)tf( i ) ? 1 : 0;
-        if( mis > KSW_BAND_MAXMIS )
+        if( mis > maxMis )
             return false;
     }
     return true;

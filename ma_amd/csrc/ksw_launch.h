@@ -405,6 +405,11 @@ inline i32 ksw_grp_env( ) // KswScoring::grp (read on every call: the tests swit
     const i32 v = e ? std::max( 0, atoi( e ) ) : 1033;
     return v == 3 ? 1065 : ( v >= 1000 ? std::min( v, 1000 + KSW_BAND_QMAX ) : std::min( v, 2 ) );
 }
+inline i32 ksw_band_mis_env( )
+{
+    const char* e = getenv( "MA_KSW_BAND_MAXMIS" );
+    return e ? std::max( 0, std::min( 64, atoi( e ) ) ) : KSW_BAND_MAXMIS;
+}
 // sizes for a job population (host side)
 struct KswSizing
 {

@@ -29,6 +29,7 @@ struct KswScoring
     // not a score: short extensions may share a wavefront (ksw_grp.h; ksw_job_class_pipe).  0 off, 1 queries up to 64 bases, 2 also
     // 65..128 with four rows per lane (A/B), 1000 + n: extensions of n..254 query bases on the proven narrow band (ksw_band.h)
     i32 grp = 1;
+    i32 band_mis = 5; // mismatches on the main diagonal up to which a job is tried on the narrow band (ksw_band_likely; MA_KSW_BAND_MAXMIS: tuning hook)
 };
 
 // Working storage of one job (flat pointers: LDS or HBM)

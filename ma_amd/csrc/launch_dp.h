@@ -89,6 +89,7 @@ int ma_dp_batch( ma_batch* b )
     D.list_stride = nSlots;
     D.SC = KswScoring{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
     D.SC.grp = ksw_grp_env( );
+    D.SC.band_mis = ksw_band_mis_env( );
     D.ez = b->ez.as<ma_ez>( );
     D.cig_off = b->cigOff.as<u64>( );
     {
@@ -127,6 +128,13 @@ int ma_dp_batch( ma_batch* b )
             S.cls[ k ] = b->hctr[ CTR_CLS0 + k ];
             S.pc[ k ] = b->hctr[ CTR_MAX_PC0 + k ];
             S.cigc[ k ] = b->hctr[ CTR_MAX_CIGC0 + k ];
+        }
+        if( getenv( "MA_DP_CLASS_REPORT" ) ) // diagnostics: jobs per kernel class of this DP stage
+        {
+            fprintf( stderr, "dp classes:" );
+            for( int k = 0; k < KSW_N_CLASSES; k++ )
+                fprintf( stderr, " %llu", (unsigned long long)S.cls[ k ] );
+            fprintf( stderr, "\n" );
         }
         S.pRedo = b->hctr[ CTR_MAX_P_REDO ];
         S.cigRedo = b->hctr[ CTR_MAX_CIG_REDO ];

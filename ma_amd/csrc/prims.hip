@@ -128,6 +128,7 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
         return 0;
     KswScoring SC{ P->match, P->mismatch, P->gap, P->extend, P->gap2, P->extend2 };
     SC.grp = ksw_grp_env( );
+    SC.band_mis = ksw_band_mis_env( );
     KswSizing S;
     for( uint64_t i = 0; i < n; i++ )
         ksw_size_job( S, jobs[ i ].qlen, jobs[ i ].tlen, jobs[ i ].w );
@@ -151,7 +152,7 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
                 const uint8_t *qp = q_bytes + jobs[ i ].q_off, *tp = t_bytes + jobs[ i ].t_off;
                 auto qf = [ & ]( i32 k ) -> u32 { return qp[ k ]; };
                 auto tf = [ & ]( i32 k ) -> u32 { return tp[ k ]; };
-                if( !ksw_band_likely( qf, tf, ql, tl ) )
+                if( !ksw_band_likely( qf, tf, ql, tl, SC.band_mis ) )
                 {
                     KswScoring S1 = SC;
                     S1.grp = 1;

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                 const uint8_t* qb = A.reads + j.read_off;
                 auto qf = [ & ]( i32 i ) -> u32 { return j.rev ? qb[ j.q_to - 1 - (u32)i ] : qb[ j.q_from + (u32)i ]; };
                 auto tf = [ & ]( i32 i ) -> u32 { return text_base( A.X, j.win_begin + ( j.rev ? j.r_to - 1 - (u32)i : j.r_from + (u32)i ) ); };
-                if( !ksw_band_likely( qf, tf, ql, tl ) )
+                if( !ksw_band_likely( qf, tf, ql, tl, A.SC.band_mis ) )
                 {
                     KswScoring S1 = A.SC;
                     S1.grp = 1;

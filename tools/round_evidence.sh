@@ -27,6 +27,8 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file gpurun_out/${TAG}_b
 # where the host-to-host leg stands against the device-resident one: one direction only, serial instead of double-buffered I/O,
 # copies forced onto blit kernels, host threads on the other socket
 bash tools/h2h_experiment.sh 30 > /dev/null 2>&1; cp gpurun_out/h2h_experiment.txt gpurun_out/${TAG}_h2h_experiment.txt
+# the proven narrow band against the oracle's kswcpp at the full band: 100 000 jobs, proved or handed on
+python3 tools/band_soak.py 10 2>&1 | grep -v amdgpu.ids | tail -6 > gpurun_out/${TAG}_band_soak.txt
 # the shapes of the kswcpp calls of the long-read workloads
 ( python3 tools/dp_job_histogram.py 150 200000 0.005 0 0; python3 tools/dp_job_histogram.py 10000 4000 0.004 0.003 0.003; python3 tools/dp_job_histogram.py 50000 1000 0.03 0.03 0.04 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_dp_job_histogram.txt
 # the leg `value` comes from -- 150 bp, 3 batches in flight, host to host -- under rocprofv3 (program directly after --):
