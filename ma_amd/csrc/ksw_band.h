@@ -27,6 +27,8 @@
 //      first maximum of each class that beats H[en0]: it depends on every class, not on the maximum alone.  With st0, en0 of
 //      the WIDE band: every class has a band cell on r*, and every class's band maximum exceeds UB(r*).  Then by (U), (E) the
 //      class maxima, the cells that hold them and their order are the wide matrix's, and H[en0] (outside the band) beats none.
+//      (A diagonal with fewer than 8 cells below en0 has no classes: the position is H[en0]'s or that of the first larger cell
+//      behind it, and the winner's band H must exceed UB(r*).)
 //   3. the cell the back-trace starts from, (max_t, r* - max_t), has band H > UB(r*): by (E) every direction byte on its path is
 //      the wide matrix's, and the path stays inside the band (the walk checks it anyway).
 //   4. no z-drop in the wide run: its ez.max is at most a (r / 2 + 1) on diagonal r and its diagonal maximum at least the
@@ -127,7 +129,7 @@ __device__ __forceinline__ void band_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qle
     vt = max( vt, dpp_ctrl<0x4E>( vt ) );
     mc = min( mc, dpp_ctrl<0x4E>( mc ) );
     mH = hEn0, mT = en0;
-    minClass = NONE;
+    minClass = 0x7fffffff; // no classes on this diagonal (fewer than 8 cells below en0): the position is H[en0]'s or a tail cell's
     if( nS > 0 )
         mH = vh, mT = vt, minClass = mc;
     // the cells after the 8-lane part, in the order the reference visits them: the first of the largest wins, if it is larger
@@ -451,7 +453,7 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             const i32 ub = ubOf( pR );
             if( !( ezmax > sc_mch * qlen - gapOut + hOff ) )
                 why = 1;
-            else if( !( minClass != (i32)0x80000000 && minClass > ub ) && pR >= B + 1 )
+            else if( !( minClass != (i32)0x80000000 && minClass > ub && pH > ub ) && pR >= B + 1 )
                 why = 2;
             else if( !( hStart != (i32)0x80000000 && hStart > ub ) )
                 why = 3;

@@ -1568,6 +1568,14 @@ class BatchAligner
         {
             sFailure = rE.what( );
         }
+        // every worker's FIRST batch is handed out here, in worker order: which replica takes a batch must not depend on which
+        // thread the scheduler starts first (with few batches a late worker -- and with it a whole replica -- would get none)
+        std::vector<std::pair<size_t, size_t>> vFirst( uiWorkers, std::make_pair( uiTo, uiTo ) );
+        for( size_t k = 0; k < uiWorkers && uiNext < uiTo && sFailure.empty( ); k++ )
+        {
+            vFirst[ k ].first = uiNext;
+            vFirst[ k ].second = uiNext = std::min( uiTo, uiNext + uiBatch );
+        }
         auto worker = [ & ]( size_t uiMe ) {
             try
             {
@@ -1577,6 +1585,8 @@ class BatchAligner
                 if( uiMe != 0 && ma_index_device( vIndices[ vIndexOfWorker[ uiMe ] ], &iDevice ) == 0 )
                     ma_host_bind_thread( iDevice, 0, nullptr );
                 detail::Engine& xEngine = *vEngines[ uiMe ];
+                if( vFirst[ uiMe ].first < vFirst[ uiMe ].second )
+                    runBatch( xEngine, vIndexOfWorker[ uiMe ], vFirst[ uiMe ].first, vFirst[ uiMe ].second );
                 for( ;; )
                 {
                     size_t lo, hi;
