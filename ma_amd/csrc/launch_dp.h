@@ -90,6 +90,11 @@ int ma_dp_batch( ma_batch* b )
     D.SC = KswScoring{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
     D.SC.grp = ksw_grp_env( );
     D.SC.band_mis = ksw_band_mis_env( );
+    // The narrow band is for batches of short reads.  Long reads have millions of short extension jobs between their seeds whose
+    // query rarely follows the main diagonal (50 kb at 10 % errors: 92 k of 11 M jobs pass the pre-filter, which then costs more than
+    // the band saves: k_dp_enum 4.9 -> 20.8 ms), and their DP stage is the wide-band kernels' anyway.
+    if( D.SC.grp >= 1000 && b->max_qlen > 1000 && !getenv( "MA_KSW_BAND_LONG" ) )
+        D.SC.grp = 1;
     D.ez = b->ez.as<ma_ez>( );
     D.cig_off = b->cigOff.as<u64>( );
     {
