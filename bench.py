@@ -163,8 +163,8 @@ class Env:
                 dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.gpu))
         torch.cuda.set_device(self.gpu)
         ma_amd.set_device(self.gpu)
-        # host threads next to the GPU: on the two-socket boxes of the pool the host-to-host leg runs ~10 % slower when the
-        # scheduler happens to place this process on the other socket; MA_BENCH_BIND=none / remote: A/B hooks
+        # host threads next to the GPU: the boxes of the pool are two-socket nodes and the scheduler is free to spread this process
+        # over both, differently from run to run; MA_BENCH_BIND=none / remote: A/B hooks
         bind = os.environ.get("MA_BENCH_BIND", "local")
         self.bound_cpus = ma_amd.bind_host_thread(self.gpu, 1 if bind == "remote" else 0) if bind != "none" else 0
         self.bind = bind if self.bound_cpus else "none"

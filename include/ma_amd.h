@@ -131,9 +131,9 @@ int ma_set_device( int device );
 int ma_host_alloc( uint64_t bytes, void** out );
 int ma_host_free( void* p );
 /* Pins the CALLING host thread (and the threads it starts afterwards) to the CPUs next to GPU `device` -- the local_cpulist of
- * its PCI function in sysfs.  On a two-socket node the threads that feed a device (launches, size read-backs, stream waits,
- * the copies out of and into page-locked memory) run up to 12 % slower from the other socket, and where the scheduler puts them
- * differs from run to run.  mode 0: the GPU's CPUs; 1: the OTHER CPUs (the experiment that shows the
+ * its PCI function in sysfs.  On a two-socket node the scheduler is free to spread the threads that feed a device (launches,
+ * size read-backs, stream waits, the copies out of and into page-locked memory) over both sockets, differently from run to run;
+ * pinning takes that out of the run-to-run spread of the host-to-host rate (the effect itself is within it).  mode 0: the GPU's CPUs; 1: the OTHER CPUs (the experiment that shows the
  * cost); -1: every CPU again.  *n_cpus (optional) = CPUs of the new mask, 0 when the mask was left alone (no topology
  * information, a one-node host).  Fails only for a bad argument.  (No counterpart in the reference: its worker threads are
  * placed by the OS, module.h:303-369.) */
