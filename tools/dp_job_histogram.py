@@ -36,7 +36,8 @@ q, t, w, zd, fl = (J[:, i].astype(np.int64) for i in range(5))
 ext = (fl & 0x40) != 0
 print("%d reads of %d bp (%.1f/%.1f/%.1f %%): %d kswcpp calls" % (n, rl, 100 * sub, 100 * ins, 100 * dele, len(q)))
 edges = [0, 1, 8, 16, 32, 64, 126, 254, 1 << 30]
-for kind, m in (("global", ~ext), ("extension", ext)):
+right = (fl & 0x02) != 0
+for kind, m in (("global", ~ext), ("extension", ext), ("extension, left-aligned (read ends)", ext & ~right), ("extension, right-aligned and reversed (read starts)", ext & right)):
     print("%s jobs: %d" % (kind, int(m.sum())))
     for lo, hi in zip(edges[:-1], edges[1:]):
         s = m & (q > lo) & (q <= hi)
