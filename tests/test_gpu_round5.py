@@ -558,3 +558,39 @@ def test_banded_extensions_are_the_wide_bands_or_handed_back(gpu_device, scoring
             assert 0.05 * len(cases) < s1[0] < len(cases) and s1[1] > 0.5 * s1[0], s1  # (the filter admits up to 5 mismatches; many of the cases have an indel behind them)
     monkeypatch.delenv("MA_KSW_GRP")
     monkeypatch.delenv("MA_KSW_BAND_ALL", raising=False)
+
+
+def test_host_threads_are_pinned_next_to_the_gpu(gpu_device):
+    """ma_host_bind_thread: the calling thread's CPU mask becomes the local_cpulist of the GPU's PCI function (mode 0), its
+    complement (mode 1: the A/B experiment of DESIGN.md section 3.8) or everything again (mode -1); a thread started afterwards
+    inherits the mask; a one-node host is left alone (n_cpus = 0)."""
+    import threading
+    import ma_amd
+    before = os.sched_getaffinity(0)
+    try:
+        n = ma_amd.bind_host_thread(0, 0)
+        local = os.sched_getaffinity(0)
+        if n == 0:
+            assert local == before  # no topology information or a single node: nothing changed
+            return
+        assert n == len(local) and local <= before and len(local) < len(before)
+        seen = []
+        t = threading.Thread(target=lambda: seen.append(os.sched_getaffinity(0)))
+        t.start()
+        t.join()
+        assert seen[0] == local
+        m = ma_amd.bind_host_thread(0, 1)
+        other = os.sched_getaffinity(0)
+        assert m == len(other) and not (other & local) and (other | local) == before
+        assert ma_amd.bind_host_thread(0, -1) == len(before) and os.sched_getaffinity(0) == before
+        with pytest.raises(RuntimeError, match="mode must be"):
+            ma_amd.bind_host_thread(0, 7)
+        dev = C.c_int(-1)
+        idx_lens = np.array([5000], dtype=np.uint64)
+        import torch
+        g = torch.randint(0, 4, (5000,), dtype=torch.uint8, device="cuda")
+        idx = ma_amd.Index.build_device(idx_lens, g.data_ptr())
+        assert ma_amd.lib().ma_index_device(idx.h, C.byref(dev)) == 0 and dev.value == 0
+        idx.close()
+    finally:
+        os.sched_setaffinity(0, before)
