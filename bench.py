@@ -67,18 +67,17 @@ WORKLOADS = {
     "50kb": dict(read_len=50000, sub=0.03, ins=0.03, dele=0.04, seed=13, reads_per_step=20000, steps=4, warmup=1,
                  cpu_sample=2048, baseline_config="configs[4] (C5 shape, one GPU)"),
     # C2's reads under the Illumina preset (SMEM seeding, parameter.h:1083-1087): SURVEY 8(d) asks for this row beside every
-    # 150 bp table.  Parity sample only (the reference is timed on the Default preset's workloads)
+    # 150 bp table.
     "illumina": dict(read_len=150, sub=0.005, ins=0.0, dele=0.0, seed=11, reads_per_step=1000000, steps=10, warmup=1,
-                     cpu_sample=20000, baseline_config="configs[1] (C2), Illumina preset", preset="illumina", reference=False),
+                     cpu_sample=20000, baseline_config="configs[1] (C2), Illumina preset", preset="illumina"),
     # configs[2] / configs[4] name "PacBio-CCS-like" and "ONT-like" reads: the same reads under the reference's PacBio and
     # Nanopore parameter sets (parameter.h:1096-1104: >= 5 strips per read, up to 100 supplementary alignments; Nanopore: SMEM
-    # seeding).  One batch at a time, half a step's reads, a parity sample against the oracle; the CPU reference is timed on the
-    # Default set's workloads above.
+    # seeding).  One batch at a time, half a step's reads, a parity sample against the oracle; the compiled reference is timed on
+    # that sample under the same parameter set (cpu_baseline.kind "reference").
     "10kb_pacbio": dict(read_len=10000, sub=0.004, ins=0.003, dele=0.003, seed=12, reads_per_step=100000, steps=2, warmup=1,
-                        cpu_sample=2048, baseline_config="configs[2] (C3), PacBio preset", preset="pacbio", reference=False, single_only=True),
+                        cpu_sample=2048, baseline_config="configs[2] (C3), PacBio preset", preset="pacbio", single_only=True),
     "50kb_nanopore": dict(read_len=50000, sub=0.03, ins=0.03, dele=0.04, seed=13, reads_per_step=10000, steps=2, warmup=1,
-                          cpu_sample=512, baseline_config="configs[4] (C5 shape, one GPU), Nanopore preset", preset="nanopore", reference=False,
-                          single_only=True),
+                          cpu_sample=512, baseline_config="configs[4] (C5 shape, one GPU), Nanopore preset", preset="nanopore", single_only=True),
 }
 
 
@@ -102,8 +101,9 @@ def pmc_replay(read_len, reads_per_step, preset, genome_scale, stage):
     the pass was collected with other kernel sources than the ones libma_amd.so is built from now."""
     cur = kernel_source_hash()
     reason = "no PMC pass of this workload under profiles/"
-    for src in (os.path.join("profiles", "r05_pmc_traffic.json"), os.path.join("profiles", "r04_pmc_traffic.json"),
-                os.path.join("profiles", "r03_pmc_traffic.json"), os.path.join("profiles", "r02_pmc_traffic.json")):
+    for src in (os.path.join("profiles", "r06_pmc_traffic.json"), os.path.join("profiles", "r05_pmc_traffic.json"),
+                os.path.join("profiles", "r04_pmc_traffic.json"), os.path.join("profiles", "r03_pmc_traffic.json"),
+                os.path.join("profiles", "r02_pmc_traffic.json")):
         try:
             with open(os.path.join(ROOT, src)) as f:
                 doc = json.load(f)
@@ -118,8 +118,40 @@ def pmc_replay(read_len, reads_per_step, preset, genome_scale, stage):
                     src, have or "(unrecorded)", cur)
                 continue
             return {"traffic": pt["bytes_per_launch"].get(stage), "valu": pt.get("valu_wave_insts_per_launch", {}).get(stage),
-                    "source": src, "refused": None}
-    return {"traffic": None, "valu": None, "source": None, "refused": reason}
+                    "source": src, "refused": None, "per_kernel": pt.get("per_kernel") or {}}
+    return {"traffic": None, "valu": None, "source": None, "refused": reason, "per_kernel": {}}
+
+
+# kernel groups of tools/pmc_summarize.py -> family index of ma_debug_dp_family_stats (ksw_launch.h: g_dp_family)
+DP_FAMILIES = {"k_ksw_ext<1>": 0, "k_ksw_ext<2>": 1, "k_ksw_grp<2>": 2, "k_ksw_grp<4>": 3, "k_ksw_band": 4, "k_ksw_pk": 5, "k_ksw (LDS)": 6,
+               "k_ksw_band (long)": 7}
+
+
+def per_kernel_roofline(per_kernel, fam_cells_per_step):
+    """Every DP kernel family and k_seed on its own: duration, VALU instructions and HBM bytes per step from the committed rocprofv3 passes
+    (kernel trace + separate PMC passes of the single-stream leg: tools/collect_profiles.sh), the family's cells per step counted live in
+    this run (ma_debug_dp_family_stats).  valu_frac: against the chip's issue peak; hbm_frac: against 8 TB/s."""
+    out = {}
+    for g, o in sorted(per_kernel.items()):
+        if not (g.startswith("k_ksw") or g == "k_seed"):
+            continue
+        ms = o.get("ms_per_step")
+        if not ms:
+            continue
+        e = {"ms": round(ms, 3)}
+        if o.get("SQ_INSTS_VALU") is not None:
+            e["wave_insts"] = int(o["SQ_INSTS_VALU"])
+            e["valu_frac"] = round(o["SQ_INSTS_VALU"] / (ms / 1e3) / 1e9 / CHIP_VALU_PEAK_GINST, 3)
+        if o.get("hbm_bytes_per_step") is not None:
+            e["hbm_bytes"] = int(o["hbm_bytes_per_step"])
+            e["hbm_frac"] = round(o["hbm_bytes_per_step"] / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
+        f = DP_FAMILIES.get(g)
+        if f is not None and fam_cells_per_step is not None and fam_cells_per_step[2 * f] > 0 and "wave_insts" in e:
+            e["cells"] = int(fam_cells_per_step[2 * f])
+            e["jobs"] = int(fam_cells_per_step[2 * f + 1])
+            e["lane_insts_per_cell"] = round(e["wave_insts"] * 64.0 / e["cells"], 1)
+        out[g] = e
+    return out
 
 
 def load_calibration():
@@ -166,6 +198,7 @@ class Env:
         # host threads next to the GPU: the boxes of the pool are two-socket nodes and the scheduler is free to spread this process
         # over both, differently from run to run; MA_BENCH_BIND=none / remote: A/B hooks
         bind = os.environ.get("MA_BENCH_BIND", "local")
+        self.cpus_at_start = os.sched_getaffinity(0)  # the CPU baseline (compiled reference, oracle threads) runs on THIS mask
         self.bound_cpus = ma_amd.bind_host_thread(self.gpu, 1 if bind == "remote" else 0) if bind != "none" else 0
         self.bind = bind if self.bound_cpus else "none"
         self.dev = torch.device("cuda", self.gpu)
@@ -396,6 +429,7 @@ def run_workload(E, name, wl, args):
         ph[:] = 0
     thr0 = cfs_throttle()
     band0 = band_stats(E)
+    fam0 = dp_family_stats(E)
     t0 = time.perf_counter()
     if NB == 1:
         worker(0)
@@ -409,6 +443,7 @@ def run_workload(E, name, wl, args):
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
+    fam1 = dp_family_stats(E)
     thr1 = cfs_throttle()
     for a in acc:
         if a["err"] is not None:
@@ -472,6 +507,10 @@ def run_workload(E, name, wl, args):
         "gather_ceiling_Gblocks_s": float(E.cal["gather_ceiling_gblocks"]),
         "dp_GCUPS": round(ctr[4] / (kms[4] / 1e3) / 1e9, 3) if kms[4] > 0 else 0.0,
         "dp_band_cells_per_read_executed": round(ctr[4] / max(n_reads, 1), 1)})
+    pk = per_kernel_roofline(pmc.get("per_kernel") or {}, (fam1 - fam0) / Kd if fam0 is not None and fam1 is not None else None)
+    if pk:
+        roofline["per_kernel"] = pk
+        roofline["per_kernel_source"] = src
     band1 = band_stats(E)
     if band0 is not None and band1 is not None and band1[0] > band0[0]:
         bd = band1 - band0
@@ -483,7 +522,12 @@ def run_workload(E, name, wl, args):
     # ---- CPU baseline (rank 0, N = 1): the compiled reference and the oracle on this host's cores, then parity ---------
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample != 0 and n_reads > 0 and not host_io:
-        cpu = cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, batches, roofline)
+        pinned = os.sched_getaffinity(0)
+        try:  # the host threads were pinned next to the GPU for the GPU legs (one socket); the CPU baseline gets every CPU the process had
+            os.sched_setaffinity(0, E.cpus_at_start)
+            cpu = cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, batches, roofline)
+        finally:
+            os.sched_setaffinity(0, pinned)
 
     res = None
     if rank == 0:
@@ -685,6 +729,17 @@ def band_stats(E):
         if E.L.ma_debug_band_stats(out) != 0:
             return None
         return np.array(list(out), dtype=np.int64)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def dp_family_stats(E):
+    """ma_debug_dp_family_stats: cells / jobs per DP kernel family since the library was loaded (this process, this device)"""
+    try:
+        out = (C.c_ulonglong * 16)()
+        if E.L.ma_debug_dp_family_stats(out) != 0:
+            return None
+        return np.array(list(out), dtype=np.float64)
     except Exception:  # noqa: BLE001
         return None
 

@@ -134,8 +134,9 @@ int ma_host_free( void* p );
  * its PCI function in sysfs.  On a two-socket node the scheduler is free to spread the threads that feed a device (launches,
  * size read-backs, stream waits, the copies out of and into page-locked memory) over both sockets, differently from run to run;
  * pinning takes that out of the run-to-run spread of the host-to-host rate (the effect itself is within it).  mode 0: the GPU's CPUs; 1: the OTHER CPUs (the experiment that shows the
- * cost); -1: every CPU again.  *n_cpus (optional) = CPUs of the new mask, 0 when the mask was left alone (no topology
- * information, a one-node host).  Fails only for a bad argument.  (No counterpart in the reference: its worker threads are
+ * cost); -1: the mask the thread had when it first called this function.  Every mode stays INSIDE that first mask (a taskset /
+ * numactl / SLURM affinity of the caller is never widened).  *n_cpus (optional) = CPUs of the new mask, 0 when the mask was left
+ * alone (no topology information, a one-node host, none of the wanted CPUs in the caller's mask).  Fails only for a bad argument.  (No counterpart in the reference: its worker threads are
  * placed by the OS, module.h:303-369.) */
 int ma_host_bind_thread( int device, int mode, int* n_cpus );
 
@@ -282,6 +283,14 @@ int ma_batch_host_ms( ma_batch*, float out[ 8 ] );
 /* diagnostics: extension jobs tried on the proven narrow band (ma_amd/csrc/ksw_band.h; MA_KSW_GRP=3) since the library was loaded on
  * the current device: tried, proved, failed check 1 / 2 / 3 / 4, handed back for another reason, diagonals run */
 int ma_debug_band_stats( unsigned long long out[ 8 ] );
+/* the same for the LONG extension jobs (queries beyond 254 bases: the end extensions of long reads, needlemanWunsch.cpp:708-716,
+ * 781-782), one per wavefront on the proven band of 120 cells (ksw_band.h, G = 1; MA_KSW_BANDL=0 switches it off) */
+int ma_debug_band_long_stats( unsigned long long out[ 8 ] );
+/* diagnostics: kswcpp cells computed / calls answered per DP kernel family since the library was loaded (what bench.py divides a
+ * family's instruction count of the rocprofv3 PMC pass by): out[2f], out[2f+1] for f = 0 k_ksw_ext<1>, 1 k_ksw_ext<2>,
+ * 2 k_ksw_grp<2>, 3 k_ksw_grp<4>, 4 k_ksw_band (short jobs), 5 k_ksw_pk, 6 k_ksw (state in LDS), 7 k_ksw_band (long jobs); all of
+ * them restate kswcpp_core.h:308-879 */
+int ma_debug_dp_family_stats( unsigned long long out[ 16 ] );
 /* diagnostics: the device libm the chaining stage decides with (harmonization.h:82-89, ransac.cpp:112,131-135 use
  * glibc's): op 0 tan, 1 sin, 2 atan, 3 log over n doubles (host arrays); tests compare the bits with glibc's */
 int ma_debug_libm( int op, const double* in, uint64_t n, double* out );

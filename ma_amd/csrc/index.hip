@@ -105,6 +105,17 @@ int ma_host_bind_thread( int device, int mode, int* n_cpus )
     const long nConf = sysconf( _SC_NPROCESSORS_CONF );
     if( nConf <= 0 || nConf > CPU_SETSIZE )
         return 0;
+    // The mask the thread had when it first came here is the caller's (taskset, numactl, a SLURM task's affinity): every mode
+    // stays inside it, and mode -1 gives exactly that mask back (the kernel itself intersects with the cgroup's cpuset only).
+    static thread_local cpu_set_t tOrig;
+    static thread_local bool tHaveOrig = false;
+    if( !tHaveOrig )
+    {
+        CPU_ZERO( &tOrig );
+        if( sched_getaffinity( 0, sizeof( tOrig ), &tOrig ) != 0 )
+            return 0;
+        tHaveOrig = true;
+    }
     cpu_set_t local, want;
     CPU_ZERO( &local );
     CPU_ZERO( &want );
@@ -143,9 +154,10 @@ int ma_host_bind_thread( int device, int mode, int* n_cpus )
             return 0; // one node: nothing to choose
     }
     for( long i = 0; i < nConf; i++ )
-        if( mode < 0 || ( CPU_ISSET( (int)i, &local ) != 0 ) == ( mode == 0 ) )
+        if( CPU_ISSET( (int)i, &tOrig ) && ( mode < 0 || ( CPU_ISSET( (int)i, &local ) != 0 ) == ( mode == 0 ) ) )
             CPU_SET( (int)i, &want );
-    // only CPUs the process may use at all (a cpuset of the container): the kernel intersects, and refuses an empty set
+    if( CPU_COUNT( &want ) == 0 )
+        return 0; // none of the wanted CPUs is in the caller's mask: the thread stays where it is (n_cpus = 0)
     if( sched_setaffinity( 0, sizeof( want ), &want ) != 0 )
         return 0;
     cpu_set_t have;

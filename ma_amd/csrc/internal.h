@@ -10,6 +10,8 @@ namespace ma
 void set_error( const std::string& s );
 int fail( const std::string& s );
 int band_stats_of_prims( unsigned long long out[ 8 ] ); // prims.hip: its copy of ksw_band.h's statistics
+int band_long_stats_of_prims( unsigned long long out[ 8 ] ); // ... of the long jobs on the band of 120
+int dp_family_stats_of_prims( unsigned long long out[ 16 ] ); // prims.hip: its copy of ksw_launch.h's per-family cell counters
 u32 sa_dense_shift( ); // index.hip: log2 of the dense SA sample's interval (0: none)
 }
 struct ma_index;

@@ -17,7 +17,10 @@
 // gaps of at least B + 1 in one direction more than in the other (f is concave: several gaps cost at least f of their sum), so
 //   (U) a cell (t, j) outside the band, and any cell reached THROUGH one, has true H <= a (min(t, j) + 1) - G, and on diagonal r
 //       the cells outside the band have min(t, j) <= (r - B - 1) / 2:   UB(r) = a ((r - B - 1) / 2 + 1) - G.
-//   (E) a band cell whose band H exceeds UB of its diagonal is EXACT (true H >= band H > UB: no optimal path to it leaves the
+//   (L) the same UB(r) bounds a BAND cell of diagonal r that is reached through a cell outside the band: a path that visits offset
+//       +-(B + 1) and ends at (t, j) with t + j = r has at least B + 1 gap bases in one direction before it returns, so it matches
+//       at most (r + 2 - (B + 1)) / 2 = (r - B - 1) / 2 + 1 pairs (rounded down), and its gaps cost at least G.
+//   (E) a band cell whose band H exceeds UB of its diagonal is EXACT (true H >= band H > UB: by (L) no optimal path to it leaves the
 //       band, and the band matrix holds every path that stays inside), and so is every cell on its optimal paths, with every
 //       candidate of the cell update that reaches the maximum: the direction byte of such a cell is the wide matrix's.
 // The checks (all on the job's own numbers, after its last diagonal):
@@ -33,9 +36,35 @@
 //      the wide matrix's, and the path stays inside the band (the walk checks it anyway).
 //   4. no z-drop in the wide run: its ez.max is at most a (r / 2 + 1) on diagonal r and its diagonal maximum at least the
 //      band's, which after a raise to m0 on r0 is at least m0 - (r - r0)(q + e) (ksw_grp.h); the difference stays <= zdrop.
+//      The diagonals BEFORE the first raise count too (ez.max = 0, max_t = max_q = -1: the test of ksw_apply_zdrop is armed from
+//      diagonal 0; a first-base mismatch z-drops at r = 0 when zdrop < |mismatch|): the first raise on r1 > 0 needs
+//      (r1 + 1)(q + e) <= zdrop, the diagonal maximum being at least -(r + 2)(q + e) (round 6).
 // A job that fails a check, leaves the regime (r > w) or outgrows its cigar buffer is appended to the list of the extension
 // kernel it would have gone to without this one (k_ksw_ext<1> / <2>, which run after it).  tests/test_gpu_round5.py::test_banded_extensions_are_the_wide_bands_or_handed_back compares every
 // proved job with the oracle's kswcpp at the full band.
+//
+// Round 6: the same proof for the LONG extension jobs (G = 1: one job per wavefront, B = 120, a ring of 128 query rows in the 64
+// lanes).  A 10 kb read of the reverse strand keeps about half of its seeds in Harmonization and the rest
+// of the read -- ~2 500 bases -- is ONE extension against the 1 000 padded reference bases behind the last seed
+// (needlemanWunsch.cpp:708-716, 781-782), band 512: 99 % of the DP cells of a 10 kb batch (profiles/r05_dp_job_histogram.txt).  The
+// read does continue there: the alignment follows the main diagonal for min(qlen, tlen) bases and loses ~70 points against a perfect
+// one (tools/band_long_experiment.py: B = 120 proves 100 % of such jobs, B = 96 98 %, B = 64 78 %).  What differs from the short jobs:
+//   * the wide band CUTS the rectangle (w < qlen) and kswcpp's cells at the wide band's edge read stale values.  (U) does not need a
+//     clean matrix: H(t, j) <= H(t-1, j-1) + a holds for every cell of the wide band whatever its edge cells read (ksw_reg.h), the
+//     chain of a cell at offset d = |t - j| starts at the boundary cell of that offset, so W(t, j) <= a (min(t, j) + 1) - f(d) for
+//     the wide run's matrix W.  The cells at offsets <= B + 1 and their neighbours are interior cells of the wide band
+//     (ksw_bandl_ok: w >= 2 B + 34, the SSE blocks' garbage lanes included), their recurrences are the clean ones, so restricted to
+//     |t - j| <= B the wide matrix IS the band's DP with other inputs at offset +-(B + 1): W >= N cell by cell, and a path that
+//     enters through offset +-(B + 1) is bounded by (L).  Hence W(c) <= max(N(c), UB(r)) on the band and (E) holds as before.
+//   * every alignment has at most min(qlen, tlen) matched pairs: check 1 reads ez.max > a min(qlen, tlen) - G.
+//   * kswcpp tracks H as int32 when max(qlen, tlen) * 24 leaves int16 (kswcpp.h:101-115): calcMaxScore then has FOUR classes
+//     (t - st0) mod 4 instead of eight (band_exact_max_lds, NC).
+//   * the early stop: a band cell's diagonal chain stays in the band and starts on a diagonal <= B + 1, so from r >= B + 3 on
+//     later band H <= max(B_r, B_{r-1}) over the BAND's cells; the cells outside it stay below a min(qlen, tlen) - G < ez.max.
+//   * check 4 uses what the proof gives: up to diagonal r the wide run's ez.max is at most max(band ez.max, UB(r)); a z-drop after
+//     the LAST raise changes nothing the callers read (the back-trace starts at the same cell, kswcpp_core.h:796-835).
+//   * a job that fails goes to the list of jobs handed back to the exact kernels (k_ksw_pk<S>, second pass of ksw_run_all).
+// tests/test_gpu_round6.py::test_long_extensions_on_the_proven_band compares every job with the oracle's kswcpp at the full band.
 #pragma once
 #include "ksw_grp.h"
 
@@ -44,9 +73,12 @@ namespace ma
 {
 #define KSW_BAND_B 24 // cells on either side of the main diagonal
 #define KSW_BAND_QMAX 254
+#define KSW_BANDL_B 120 // long jobs: one per wavefront, 121 cells per diagonal in a ring of 128 query rows
+#define KSW_BANDL_NMAX 2040 // min(qlen, tlen) of a long job: bounds the diagonals (2 N + B) and keeps H + a * cells-left in 16 bits
+#define KSW_BANDL_ROWS ( 2 * KSW_BANDL_NMAX + KSW_BANDL_B + 24 ) // direction rows (128 B) of a wavefront's scratch
 #define KSW_BAND_LDS ( KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4 + 4 * 64 + 4 * 256 + 64 )
 // jobs tried, proved, failed check 1 / 2 / 3 / 4, handed back for another reason (regime, cigar buffer), diagonals (ma_debug_band_stats)
-static __device__ unsigned long long g_band_stats[ 8 ];
+static __device__ unsigned long long g_band_stats[ 16 ]; // [8..16): the same for the long jobs (one per wavefront)
 
 // extension jobs this kernel may try (same regime as ksw_ext_slots; the query rows are kept in LDS: <= 254 of them)
 MA_HD int ksw_band_ok( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag, i32 qmin )
@@ -56,6 +88,52 @@ MA_HD int ksw_band_ok( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdro
     if( zdrop < 0 || zdrop > 16000 )
         return 0;
     return ksw_ext_slots( SC, qlen, tlen, w, zdrop, flag ) != 0 ? 1 : 0;
+}
+
+// long extension jobs the one-job-per-wavefront variant may try: queries beyond the short variant's, the band well inside the wide one
+MA_HD int ksw_bandl_ok( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdrop, i32 flag )
+{
+    if( !( flag & KSW_EZ_EXTZ_ONLY ) || qlen <= KSW_BAND_QMAX || qlen > 32000 || tlen < 1 || tlen > 32000 || w > 16000 )
+        return 0;
+    if( ( qlen < tlen ? qlen : tlen ) > KSW_BANDL_NMAX || ( qlen < tlen ? qlen : tlen ) < KSW_BANDL_B + 8 || w < 2 * KSW_BANDL_B + 34 )
+        return 0;
+    if( zdrop < 0 || zdrop > 16000 )
+        return 0;
+    // the difference vectors stay inside int8 (ksw_ext_slots)
+    const i32 a = SC.q + SC.e, b = SC.q2 + SC.e2, mch = SC.match < 0 ? -SC.match : SC.match;
+    const i32 mis = SC.mismatch < 0 ? -SC.mismatch : SC.mismatch;
+    if( SC.q < 0 || SC.e < 1 || SC.q2 < 0 || SC.e2 < 1 || 2 * ( a > b ? a : b ) + mch + mis > 120 || mch < 1 || mch * ( KSW_BANDL_NMAX + 8 ) > 16000 )
+        return 0;
+    return 1;
+}
+// ... and which are worth it: a greedy walk over the first `span` query bases (a mismatch is a substitution, an inserted or a deleted
+// base, whichever lets the next three bases match) must get by with maxEdits edits -- 10 kb reads at 1 % errors pass, the noisy
+// gaps between the seeds of 50 kb reads at 10 % (which lose > 200 points and can never pass check 1) do not.  A heuristic only: every
+// tried job is proved or handed on.
+template <typename QF, typename TF> MA_HD bool ksw_bandl_likely( const QF& qf, const TF& tf, i32 qlen, i32 tlen, i32 maxEdits = 5, i32 span = 160 )
+{
+    i32 i = 0, j = 0, edits = 0;
+    const i32 n = qlen < span ? qlen : span;
+    while( i < n && j + 4 < tlen && i + 4 < qlen )
+    {
+        if( (u32)qf( i ) == (u32)tf( j ) )
+        {
+            i++, j++;
+            continue;
+        }
+        if( ++edits > maxEdits )
+            return false;
+        const u32 q1 = qf( i + 1 ), q2 = qf( i + 2 ), q3 = qf( i + 3 ), t1 = tf( j + 1 ), t2 = tf( j + 2 ), t3 = tf( j + 3 );
+        if( q1 == t1 && q2 == t2 && q3 == t3 )
+            i++, j++; // substitution
+        else if( q1 == (u32)tf( j ) && q2 == t1 && q3 == t2 )
+            i++; // the query has a base more
+        else if( (u32)qf( i ) == t1 && q1 == t2 && q2 == t3 )
+            j++; // the target has a base more
+        else
+            i++, j++;
+    }
+    return true;
 }
 
 // Which of the eligible jobs are WORTH the attempt: the checks pass for alignments that lose less than ~44 points against a
@@ -76,6 +154,92 @@ template <typename QF, typename TF> MA_HD bool ksw_band_likely( const QF& qf, co
             return false;
     }
     return true;
+}
+
+// lane i <- lane i - 1 of its group, the group's first lane <- its last (the ring of query rows is circular)
+template <int LANES> __device__ __forceinline__ u32 band_ror1( u32 x )
+{
+    return LANES == 64 ? lanes_ror1( x ) : (u32)dpp_ctrl<0x121>( (i32)x );
+}
+template <int LANES> __device__ __forceinline__ u32 band_sum_u32( u32 c ) // sum over the lanes of a group, in every lane
+{
+    c += (u32)dpp_ctrl<0x121>( (i32)c );
+    c += (u32)dpp_ctrl<0x122>( (i32)c );
+    c += (u32)dpp_ctrl<0x124>( (i32)c );
+    c += (u32)dpp_ctrl<0x128>( (i32)c );
+    if( LANES == 64 )
+    {
+        auto a = __builtin_amdgcn_permlane16_swap( c, c, false, false );
+        c = a[ 0 ] + a[ 1 ];
+        auto b = __builtin_amdgcn_permlane32_swap( c, c, false, false );
+        c = b[ 0 ] + b[ 1 ];
+    }
+    return c;
+}
+
+// The same for the one-job-per-wavefront variant (64 lanes, B = KSW_BANDL_B), through LDS and class by class -- it runs once per job.
+// NC = 8 classes when kswcpp tracks H as int16, 4 when as int32 (T_SIMD_VEC::SIZE, kswcpp_core.h:183-237).  sc: 144 words of LDS.
+__device__ __forceinline__ void band_exact_max_lds( u32 Hs, u32 Jpk, i32 rr, i32 qlen, i32 tlen, i32 w, i32 NC, int lane, i32* sc, i32& mH, i32& mT,
+                                                    i32& minClass, i32& hStart )
+{
+    constexpr i32 B = KSW_BANDL_B;
+    const i32 NONE = (i32)0x80000000;
+    const i32 st0 = max( max( 0, rr - qlen + 1 ), ( rr - w + 1 ) >> 1 ), en0 = min( min( rr, tlen - 1 ), ( rr + w ) >> 1 );
+    const i32 span = en0 - st0, nS = ( span / NC ) * NC;
+    // the band's cells of diagonal rr: t = tmin .. tmax (at most B + 1 of them)
+    const i32 tmin = max( max( 0, rr - qlen + 1 ), ( rr - B + 1 ) >> 1 ), tmax = min( min( rr, tlen - 1 ), ( rr + B ) >> 1 );
+    __syncthreads( );
+    sc[ lane ] = NONE;
+    sc[ lane + 64 ] = NONE;
+    __syncthreads( );
+    {
+        const i32 jl = (i32)( Jpk & 0xffffu ), jh = (i32)( Jpk >> 16 );
+        const i32 tlo = rr - jl, thi = rr - jh;
+        if( tlo >= tmin && tlo <= tmax && jl < qlen )
+            sc[ tlo - tmin ] = (i32)( Hs << 16 ) >> 16;
+        if( thi >= tmin && thi <= tmax && jh < qlen )
+            sc[ thi - tmin ] = (i32)Hs >> 16;
+    }
+    __syncthreads( );
+    const i32 hEn0 = en0 >= tmin && en0 <= tmax ? sc[ en0 - tmin ] : NONE;
+    // lane c < NC: the first maximum of class c over the chunks [st0, st0 + nS)
+    if( lane < NC )
+    {
+        i32 best = NONE, bestT = en0;
+        i32 t = tmin + ( ( ( lane - ( tmin - st0 ) ) % NC ) + NC ) % NC; // first band cell with (t - st0) mod NC == lane
+        for( ; t <= tmax && t - st0 < nS; t += NC )
+        {
+            const i32 h = sc[ t - tmin ];
+            if( h != NONE && h > best )
+                best = h, bestT = t;
+        }
+        sc[ 128 + 2 * lane ] = best;
+        sc[ 128 + 2 * lane + 1 ] = best != NONE && best > hEn0 ? st0 + ( ( bestT - st0 ) / NC ) * NC : en0;
+    }
+    __syncthreads( );
+    mH = hEn0, mT = en0;
+    minClass = 0x7fffffff; // no classes on this diagonal (fewer than NC cells below en0)
+    if( nS > 0 )
+    {
+        i32 vh = hEn0, vt = NONE, mc = 0x7fffffff;
+        for( i32 c = 0; c < NC; c++ )
+        {
+            const i32 b = sc[ 128 + 2 * c ];
+            vh = max( vh, b );
+            vt = max( vt, sc[ 128 + 2 * c + 1 ] );
+            mc = min( mc, b ); // NONE when a class has no band cell
+        }
+        mH = vh, mT = vt, minClass = mc;
+    }
+    // the cells after the chunks, in the order the reference visits them
+    for( i32 t = max( st0 + nS, tmin ); t < en0 && t <= tmax; t++ )
+    {
+        const i32 h = sc[ t - tmin ];
+        if( h != NONE && h > mH )
+            mH = h, mT = t;
+    }
+    hStart = mT >= tmin && mT <= tmax ? sc[ mT - tmin ] : NONE;
+    __syncthreads( );
 }
 
 // calcMaxScore over the band cells of diagonal rr (grp_exact_max of ksw_grp.h with the cells' rows per lane in Jpk and the band
@@ -150,18 +314,22 @@ __device__ __forceinline__ void band_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qle
     }
 }
 
-// One set of up to four jobs (queue entries [at0, min(at0 + 4, n))), all of them left- (LEFT) or right-aligned extensions.
-template <bool LEFT, typename FETCH>
+// One set of up to G jobs (queue entries [at0, min(at0 + G, n))), all of them left- (LEFT) or right-aligned extensions.
+// G = 4: the short jobs (B = 24, 16 lanes and 32 query rows each); G = 1: a long job (B = 120, 64 lanes, 128 query rows).
+template <int G, bool LEFT, typename FETCH>
 __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* list, u32 n, u32 at0, uint8_t* P /*KSW_GRP_ROWS x 128 B*/, uint8_t* lds,
                               const KswOut& O, KswWaveAcc& acc, u32* ext1, u32 nExt1, u32* ext2, u32 nExt2, unsigned int* extMore, unsigned long long* sOff,
                               u32* pf /*the wave's statistics*/ )
 {
-    constexpr int G = 4, LANES = 16, CJ = 32, B = KSW_BAND_B;
+    constexpr int LANES = 64 / G, CJ = 2 * LANES, B = G == 1 ? KSW_BANDL_B : KSW_BAND_B;
+    constexpr bool LONG = G == 1;
+    static_assert( G == 1 || G == 4, "two shapes" );
+    static_assert( B + 8 <= CJ, "the ring holds the band's rows and the rows being recycled" );
     const int lane = threadIdx.x & 63, g = lane / LANES, l = lane % LANES;
     uint8_t* stage = lds; // KSW_GRP_STAGE_ROWS x 128: direction rows (ksw_grp.h)
     u32* cigLds = (u32*)( lds + KSW_GRP_STAGE_ROWS * 128 ); // KSW_GRP_CIG_WORDS, CIGCAP per group
-    uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // 4 x 64: two blocks of 32 target bases per job
-    uint8_t* qlds = tring + 4 * 64; // 4 x 256: the jobs' queries
+    uint8_t* tring = lds + KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4; // G x 2 CJ = 256 bytes: two blocks of CJ target bases per job
+    uint8_t* qlds = tring + 4 * 64; // G = 4: 4 x 256, the jobs' queries; G = 1: a ring of two blocks of 128 query rows + 144 words for band_exact_max_lds
     i32* gflag = (i32*)( qlds + 4 * 256 );
     constexpr u32 CIGCAP = KSW_GRP_CIG_WORDS / G;
     // ---- the group's job
@@ -172,7 +340,7 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
         const KswJobView J = F.view( slot );
         qlen = J.qlen, tlen = J.tlen, zdrop = J.zdrop, wJob = J.w;
         nDiag = qlen + tlen - 1;
-        rEnd = min( nDiag, J.w + 1 ); // the job ends BEFORE diagonal rEnd: all diagonals done, or r > w (handed back)
+        rEnd = LONG ? nDiag : min( nDiag, J.w + 1 ); // the job ends BEFORE diagonal rEnd: all diagonals done, or (short jobs) r > w (handed back)
     }
     auto qf = F.qfetch( slot );
     auto tf = F.tfetch( slot );
@@ -225,8 +393,21 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
     const u32 K_GAP = pk_val( -q - e, 0 ); // u / v of a cell whose neighbour lies outside the band
     // ---- the query in LDS (a lane takes new rows every 64 diagonals), two blocks of the target
     uint8_t* myQ = qlds + g * 256;
-    for( i32 j = l; j < 256; j += LANES )
-        myQ[ j ] = has && j < qlen ? (uint8_t)qf( j ) : (uint8_t)4;
+    auto fillQ = [ & ]( i32 blk ) { // LONG: query rows [128 blk, 128 blk + 128) -> ring slot blk & 1
+        const i32 j = 128 * blk + 2 * l;
+        const u32 b0 = has && j < qlen ? (u32)qf( j ) : 4u, b1 = has && j + 1 < qlen ? (u32)qf( j + 1 ) : 4u;
+        *(uint16_t*)( myQ + ( j & 255 ) ) = (uint16_t)( b0 | b1 << 8 );
+    };
+    if( LONG )
+    {
+        fillQ( 0 );
+        fillQ( 1 );
+    }
+    else
+        for( i32 j = l; j < 256; j += LANES )
+            myQ[ j ] = has && j < qlen ? (uint8_t)qf( j ) : (uint8_t)4;
+    i32 nextQ = 2; // LONG: block k is written on diagonal 256 (k - 1): after the last lane took its rows of block k - 2 (diagonal
+                   // 256 (k - 2) + 4 * 63 + B + 3), before the first lane takes rows of block k (256 (k - 1) + B + 3)
     auto tgt2 = [ & ]( i32 t ) -> u32 { // target bases of cells t, t + 1 (codes as in ksw_ext.h: an N of the target is 12)
         if( t >= tlen )
             return 0u;
@@ -236,11 +417,11 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
         const u32 nn = pk_lshr( ab, 2 );
         return pk_bfi( pk_sub( 0u, pk_minu( nn, 0x00010001u ) ), 0x000c000cu, ab );
     };
-    uint8_t* myRing = tring + g * 64;
-    auto fillBlock = [ & ]( i32 blk ) { // target bases [32 blk, 32 blk + 32) -> ring slot blk & 1
-        const i32 t = 32 * blk + 2 * l;
+    uint8_t* myRing = tring + g * ( 2 * CJ );
+    auto fillBlock = [ & ]( i32 blk ) { // target bases [CJ blk, CJ blk + CJ) -> ring slot blk & 1
+        const i32 t = CJ * blk + 2 * l;
         const u32 ab = has ? tgt2( t ) : 0u;
-        *(uint16_t*)( myRing + ( t & 63 ) ) = (uint16_t)( ( ab & 0xffu ) | ( ab >> 8 & 0xff00u ) );
+        *(uint16_t*)( myRing + ( t & ( 2 * CJ - 1 ) ) ) = (uint16_t)( ( ab & 0xffu ) | ( ab >> 8 & 0xff00u ) );
     };
     fillBlock( 0 );
     fillBlock( 1 );
@@ -298,10 +479,16 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
         if( __builtin_expect( r <= long_thres + 1, 0 ) )
             uInS = initOf( r );
         // ---- the next 32 target bases, when the band's upper edge reaches them (wave-uniform: r and B are)
-        if( __builtin_expect( ( ( r + B ) >> 1 ) >= 32 * nextBlk - 1, 0 ) )
+        if( __builtin_expect( ( ( r + B ) >> 1 ) >= CJ * nextBlk - 1, 0 ) )
         {
             fillBlock( nextBlk );
             nextBlk++;
+            __syncthreads( );
+        }
+        if( LONG && __builtin_expect( r == 256 * ( nextQ - 1 ), 0 ) )
+        {
+            fillQ( nextQ );
+            nextQ++;
             __syncthreads( );
         }
         if( __builtin_expect( r >= KSW_GRP_STAGE_ROWS && ( r & ( KSW_GRP_STAGE_ROWS / 2 - 1 ) ) == 0, 0 ) )
@@ -316,20 +503,20 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             ringLo = r - KSW_GRP_STAGE_ROWS / 2;
         }
         // ---- neighbours: u, y, y2 come from row j - 1 = the previous lane of the ring; the H of row j - 1 for a row that enters
-        const u32 ut0 = cells_shift1( U, (u32)dpp_ctrl<0x121>( (i32)U ) );
-        const u32 yt0 = cells_shift1( Y, (u32)dpp_ctrl<0x121>( (i32)Y ) );
-        const u32 y2t0 = cells_shift1( Y2, (u32)dpp_ctrl<0x121>( (i32)Y2 ) );
-        const u32 hPrev = cells_shift1( H, (u32)dpp_ctrl<0x121>( (i32)H ) );
+        const u32 ut0 = cells_shift1( U, band_ror1<LANES>( U ) );
+        const u32 yt0 = cells_shift1( Y, band_ror1<LANES>( Y ) );
+        const u32 y2t0 = cells_shift1( Y2, band_ror1<LANES>( Y2 ) );
+        const u32 hPrev = cells_shift1( H, band_ror1<LANES>( H ) );
         const u32 ut = pk_bfi( leadLo, ( (u32)uInS & 0xffu ) << 8, ut0 );
         const u32 yt = pk_bfi( leadLo, K_Y0, yt0 );
         const u32 y2t = pk_bfi( leadLo, K_Y20, y2t0 );
-        // ---- a lane whose rows have both left the band takes the rows 32 further on: lane l on diagonal 4 l + B + 3 (+ 64 k).
+        // ---- a lane whose rows have both left the band takes the rows CJ further on: lane l on diagonal 4 l + B + 3 (+ 2 CJ k).
         // AFTER the shifts above: what its last live cell computed on the diagonal before is read by the next lane on this one
         if( __builtin_expect( r >= B + 3 && ( ( r - B - 3 ) & 3 ) == 0, 0 ) )
         {
-            if( l == ( ( ( r - B - 3 ) >> 2 ) & 15 ) )
+            if( l == ( ( ( r - B - 3 ) >> 2 ) & ( LANES - 1 ) ) )
             {
-                Jpk = pk_add( Jpk, 0x00200020u );
+                Jpk = pk_add( Jpk, pk_bcast( CJ ) );
                 rowState( Jpk, Jmask, Qb, V, H, entOk );
                 Jmask &= (u32)act;
                 X = K_X0, X2 = K_X20, U = K_GAP, Y = K_Y0, Y2 = K_Y20;
@@ -339,7 +526,7 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
         }
         // the target bases of the lane's cells: t (low half) and t - 1
         const i32 tLo = (i32)( (u32)( Tpk << 16 ) ) >> 16;
-        const u32 tt = (u32)myRing[ tLo & 63 ] | (u32)myRing[ ( tLo - 1 ) & 63 ] << 16;
+        const u32 tt = (u32)myRing[ tLo & ( 2 * CJ - 1 ) ] | (u32)myRing[ ( tLo - 1 ) & ( 2 * CJ - 1 ) ] << 16;
         // ---- live cells: 0 <= t <= tlen - 1 on a row of the job, -B <= t - j <= B
         const u32 dB = pk_add( pk_sub( Tpk, Jpk ), K_B ); // t - j + B: 0 .. 2 B inside the band
         const u32 inBand = pk_nonzero15( pk_subsatu( K_2B1, dB ) );
@@ -398,7 +585,14 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             const i32 gm = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
             raise = gm > ezmax ? -1 : 0;
             // check 4: between the last raise (pR, pM) and this diagonal the wide run's ez.max - diagonal maximum stayed <= zdrop
-            if( raise && pend && sc_mch * ( r / 2 + 1 ) + hOff - pM + ( r - pR ) * qe > zdrop )
+            // (LONG: by (L) the wide run's ez.max up to this diagonal is at most max(the band's ez.max so far, UB(r)))
+            if( raise && pend && ( LONG ? max( pM, ubOf( r ) ) : sc_mch * ( r / 2 + 1 ) + hOff ) - pM + ( r - pR ) * qe > zdrop )
+                zBad = -1;
+            // ... and BEFORE the first raise: ksw_apply_zdrop (kswcpp_core.h:22-44) also fires while ez.max is still 0 and max_t = max_q
+            // = -1 (every cell passes t >= max_t && q >= max_q).  The maximum of diagonal r is at least that of a cell of the first
+            // column reached by one gap from the boundary, -(2 q + (r + 2) e) >= -(r + 2)(q + e) (+ hOff in kswcpp's H); the wide run's
+            // ez.max up to diagonal r1 - 1 is 0 while no cell outside the band exists (r < B + 1), at most a (r / 2 + 1) + hOff after
+            if( raise && !pend && r > 0 && max( 0, r - 1 < B + 1 ? 0 : sc_mch * ( ( r - 1 ) / 2 + 1 ) + hOff ) + ( r + 1 ) * qe - hOff > zdrop )
                 zBad = -1;
             ezmax = raise ? gm : ezmax;
             ezpk = raise ? pk_bcast( gm ) : ezpk;
@@ -409,7 +603,10 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             pend |= raise;
         }
         // ---- early stop (ksw_reg.h) on the band's cells, every job on its own schedule (ksw_grp.h)
-        const bool due = ( act & ~raise ) != 0 && r >= qlen - 1 && r >= nextBound;
+        // (LONG: the chain of a band cell starts on a diagonal <= B + 1, so the bound over the band's cells holds from B + 3 on; it is
+        // looked at once the band has reached the last rows or columns)
+        const i32 rOk = LONG ? B + 3 : qlen;
+        const bool due = ( act & ~raise ) != 0 && r >= rOk - 1 && r >= nextBound && ( !LONG || r >= min( qlen, tlen ) - 1 );
         if( __any( due ) )
         {
             const u32 QLpk = pk_sub( pk_bcast( qlen - 1 ), Jpk ); // rows left below the cell
@@ -417,17 +614,17 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             const u32 bnd = pk_mad( pot, K_MATCH, H );
             const u32 bm = pk_bfi( LM, bnd, K_NEG );
             const i32 bound = grp_max_i32<LANES>( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
-            const i32 top = hBoundary( r ) + sc_mch * qlen;
+            const i32 top = LONG ? (i32)0x80000000 : hBoundary( r ) + sc_mch * qlen;
             if( due )
             {
                 const i32 all = max( max( bound, boundPrev ), top );
-                if( r >= qlen && all <= ezmax )
+                if( r >= rOk && all <= ezmax )
                 {
                     rLast = r;
                     act = 0;
                     Jmask = 0;
                 }
-                else if( boundPrev != 0x7fffffff && r >= qlen )
+                else if( boundPrev != 0x7fffffff && r >= rOk )
                 {
                     nextBound = r + 1 + max( 0, ( max( bound, top ) - ezmax ) / boundRate - 1 );
                     boundPrev = 0x7fffffff;
@@ -445,20 +642,23 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
     i32 why = 0; // 1..4: the check that failed
     {
         i32 pH, pT, minClass, hStart;
-        band_exact_max( snapH, snapJ, pR, qlen, tlen, wJob, lane, l, pH, pT, minClass, hStart );
+        if( LONG )
+            band_exact_max_lds( snapH, snapJ, pR, qlen, tlen, wJob, ksw_h16( SC, qlen, tlen ) ? 8 : 4, lane, (i32*)( qlds + 256 ), pH, pT, minClass, hStart );
+        else
+            band_exact_max( snapH, snapJ, pR, qlen, tlen, wJob, lane, l, pH, pT, minClass, hStart );
         if( pend )
         {
             maxT = pT;
             maxQ = pR - pT;
             const i32 ub = ubOf( pR );
-            if( !( ezmax > sc_mch * qlen - gapOut + hOff ) )
+            if( !( ezmax > sc_mch * ( LONG ? min( qlen, tlen ) : qlen ) - gapOut + hOff ) )
                 why = 1;
             else if( !( minClass != (i32)0x80000000 && minClass > ub && pH > ub ) && pR >= B + 1 )
                 why = 2;
             else if( !( hStart != (i32)0x80000000 && hStart > ub ) )
                 why = 3;
-            else if( zBad || sc_mch * ( max( rLast, pR ) / 2 + 1 ) + hOff - pM + ( max( rLast, pR ) - pR ) * qe > zdrop )
-                why = 4;
+            else if( zBad || ( !LONG && sc_mch * ( max( rLast, pR ) / 2 + 1 ) + hOff - pM + ( max( rLast, pR ) - pR ) * qe > zdrop ) )
+                why = 4; // (LONG: a z-drop behind the last raise changes nothing the callers read)
         }
         else if( has && !untouched && !handBack )
             why = 1; // no cell ever exceeded 0: nothing proves that none outside the band does
@@ -500,7 +700,7 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
                 bi = bj = -1;
                 break;
             }
-            const u32 tb = stage[ ( ( bi + bj ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + g * CJ + ( bj & 31 ) ];
+            const u32 tb = stage[ ( ( bi + bj ) & ( KSW_GRP_STAGE_ROWS - 1 ) ) * 128 + g * CJ + ( bj & ( CJ - 1 ) ) ];
             if( state != 0 && !( ( tb >> ( state + 2 ) ) & 1 ) )
                 state = 0;
             if( state == 0 )
@@ -589,19 +789,15 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
     const bool fits = off + myN <= O.cig_pool_cap;
     // cells the job computed: the band cells of the diagonals 0 .. rLast (the group's lanes take the diagonals in turn)
     u64 cellsJob = 0;
-    if( has && rLast >= 0 && publish )
+    if( __any( has && rLast >= 0 && publish ) ) // (wave-uniform for one job per wave; the sum needs all lanes of the group)
     {
         u32 c = 0;
-        for( i32 rr = l; rr <= rLast; rr += LANES )
+        for( i32 rr = l; rr <= rLast && has && publish; rr += LANES )
         {
             const i32 lo = max( max( 0, rr - tlen + 1 ), ( rr - B + 1 ) >> 1 ), hi = min( min( qlen - 1, rr ), ( rr + B ) >> 1 );
             c += hi >= lo ? (u32)( hi - lo + 1 ) : 0u;
         }
-        c += (u32)dpp_ctrl<0x121>( (i32)c );
-        c += (u32)dpp_ctrl<0x122>( (i32)c );
-        c += (u32)dpp_ctrl<0x124>( (i32)c );
-        c += (u32)dpp_ctrl<0x128>( (i32)c );
-        cellsJob = c;
+        cellsJob = band_sum_u32<LANES>( c );
     }
     if( l == 0 && publish )
     {
@@ -626,7 +822,9 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
     {
         // to the list of the extension kernel the job would have gone to (k_ksw_ext<1> / <2> run after this kernel on the same
         // stream and read the number of appended jobs from extMore[ 0 ] / [ 1 ])
-        if( ksw_ext_slots( SC, qlen, tlen, wJob, zdrop, F.view( slot ).flag ) == 2 )
+        if( LONG ) // to the jobs handed back to the exact kernels: ext1 = that list, extMore = its counter (second pass of ksw_run_all)
+            ext1[ atomicAdd( extMore, 1u ) ] = slot;
+        else if( ksw_ext_slots( SC, qlen, tlen, wJob, zdrop, F.view( slot ).flag ) == 2 )
             ext2[ nExt2 + atomicAdd( extMore + 1, 1u ) ] = slot;
         else
             ext1[ nExt1 + atomicAdd( extMore + 0, 1u ) ] = slot;
@@ -656,7 +854,7 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
     }
 }
 
-template <typename FETCH, bool LEFT>
+template <typename FETCH, bool LEFT, int G = 4>
 __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( 5, 5 ) ) )
 k_ksw_band( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, uint8_t* scratch, u64 stride, KswOut O, u32* ext1, u32 nExt1, u32* ext2,
             u32 nExt2, unsigned int* extMore )
@@ -673,25 +871,25 @@ k_ksw_band( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, 
         if( cur >= end )
         {
             if( threadIdx.x == 0 )
-                sSet = atomicAdd( next, 16u );
+                sSet = atomicAdd( next, (unsigned int)( 4 * G ) );
             __syncthreads( );
             cur = sSet;
             __syncthreads( );
             if( cur >= n )
                 break;
-            end = cur + 16 < n ? cur + 16 : n;
+            end = cur + 4 * G < n ? cur + 4 * G : n;
         }
-        ksw_band_set<LEFT>( F, SC, list, n, cur, P, lds, O, acc, ext1, nExt1, ext2, nExt2, extMore, &sOff, stats );
-        cur += 4;
+        ksw_band_set<G, LEFT>( F, SC, list, n, cur, P, lds, O, acc, ext1, nExt1, ext2, nExt2, extMore, &sOff, stats );
+        cur += G;
     }
-    ksw_flush( O, acc );
+    ksw_flush( O, acc, G == 1 ? 7 : 4 );
     for( int i = 0; i < 8; i++ )
     {
         u32 v = 0;
         for( int k = 0; k < 4; k++ )
-            v += (u32)__builtin_amdgcn_readlane( (i32)stats[ i ], k * 16 );
+            v += (u32)__builtin_amdgcn_readlane( (i32)stats[ i ], k * 16 ); // (G = 1: lanes 16, 32, 48 hold zeros)
         if( threadIdx.x == 0 && v )
-            atomicAdd( g_band_stats + i, (unsigned long long)v );
+            atomicAdd( g_band_stats + ( G == 1 ? 8 : 0 ) + i, (unsigned long long)v );
     }
 }
 } // namespace ma

@@ -750,7 +750,7 @@ k_ksw_grp( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, u
 #endif
         cur += G;
     }
-    ksw_flush( O, acc );
+    ksw_flush( O, acc, G == 2 ? 2 : 3 );
 #if defined( MA_KSW_PROF )
     if( threadIdx.x == 0 )
         for( int i = 0; i < 8; i++ )

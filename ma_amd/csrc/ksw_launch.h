@@ -54,10 +54,12 @@ struct KswWaveAcc
 #define KSW_S1 2
 #define KSW_S2 3
 #define KSW_S3 5
-#define KSW_N_CLASSES 13 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots,
-                         // 7..12 the query-stationary extension kernel (ksw_grp.h): 2 jobs of up to 128 query bases (four rows per lane) / 2 of
-                         // up to 64 / 4 of up to 32 per wave, left / right
+#define KSW_N_CLASSES 15 // 0..3 exact register kernel (ksw_pk.h), 4 LDS kernel, 5 / 6 extension kernel (ksw_ext.h) with 1 / 2 slots,
+                         // 7..12 the query-stationary extension kernel (ksw_grp.h): 4 jobs of up to 254 query bases on the proven narrow band
+                         // (ksw_band.h) / 2 of up to 64 / 4 of up to 32 per wave, left / right; 13 / 14 LONG extension jobs on the proven band
+                         // of 120, one per wave, left / right (ksw_band.h, G = 1)
 #define KSW_CLS_GRP0 7
+#define KSW_CLS_BANDL 13
 MA_HD int ksw_job_class( i32 qlen, i32 tlen, i32 w )
 {
     if( qlen > 150000 )
@@ -133,10 +135,17 @@ __device__ __forceinline__ void ksw_publish( const KswOut& O, KswWaveAcc& A, u32
             O.cig_pool[ off + i ] = cig[ i ];
     __syncthreads( ); // the scratch cigar may be overwritten by the next job
 }
-__device__ __forceinline__ void ksw_flush( const KswOut& O, const KswWaveAcc& A )
+// cells computed and jobs finished per DP kernel FAMILY since the library was loaded (ma_debug_dp_family_stats; bench.py divides a
+// family's VALU instructions of the PMC pass by ITS cells): 0 k_ksw_ext<1>, 1 k_ksw_ext<2>, 2 k_ksw_grp<2>, 3 k_ksw_grp<4>,
+// 4 k_ksw_band (four short jobs per wave), 5 k_ksw_pk, 6 k_ksw (LDS), 7 k_ksw_band (one long job per wave)
+#define KSW_N_FAMILIES 8
+static __device__ unsigned long long g_dp_family[ 2 * KSW_N_FAMILIES ];
+__device__ __forceinline__ void ksw_flush( const KswOut& O, const KswWaveAcc& A, int family )
 {
     if( threadIdx.x == 0 && A.njobs )
     {
+        atomicAdd( g_dp_family + 2 * family, (unsigned long long)A.cells );
+        atomicAdd( g_dp_family + 2 * family + 1, (unsigned long long)A.njobs );
         atomicAdd( O.cells, (unsigned long long)A.cells );
         atomicAdd( O.njobs, (unsigned long long)A.njobs );
         if( O.path )
@@ -180,6 +189,8 @@ MA_HD int ksw_job_class_pipe( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i
     if( e == 1 && ksw_grp_enabled( ) )
         if( const int G = ksw_grp_size( SC, qlen, tlen, w, zdrop, flag ) )
             return KSW_CLS_GRP0 + ( G == 4 ? 4 : ( G == 2 ? 2 : 0 ) ) + ( ( flag & KSW_EZ_RIGHT ) ? 1 : 0 );
+    if( !e && SC.band_long && ksw_bandl_ok( SC, qlen, tlen, w, zdrop, flag ) )
+        return KSW_CLS_BANDL + ( ( flag & KSW_EZ_RIGHT ) ? 1 : 0 ); // the proven band of 120, one long job per wave (ksw_band.h)
     return e ? 4 + e : ksw_job_class( qlen, tlen, w );
 }
 
@@ -289,7 +300,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( R 
         prof[ 9 ] += t3 - t0;
 #endif
     }
-    ksw_flush( O, acc );
+    ksw_flush( O, acc, R == 1 ? 0 : 1 );
 #if defined( MA_KSW_PROF )
     if( threadIdx.x == 0 )
         for( int i = 0; i < 16; i++ )
@@ -335,7 +346,7 @@ __global__ void __launch_bounds__( 64 ) __attribute__( ( amdgpu_waves_per_eu( S 
         ksw_pk_core<S, FETCH::EARLY>( SC, J, qf, tf, (uint8_t*)lds, P, cig, ez, nCig, cells, path, ldsBytes, sSnap );
         ksw_publish( O, acc, slot, ez, nCig, cells, path, cig, &sOff );
     }
-    ksw_flush( O, acc );
+    ksw_flush( O, acc, 5 );
 }
 
 template <typename FETCH>
@@ -391,19 +402,29 @@ __global__ void __launch_bounds__( 64 ) k_ksw( FETCH F, KswScoring SC, KswJobs J
             ksw_wave_core<int32_t, 4>( SC, J, qf, tf, M, ez, nCig, cells, path );
         ksw_publish( O, acc, slot, ez, nCig, cells, path, M.cig, &sOff );
     }
-    ksw_flush( O, acc );
+    ksw_flush( O, acc, 6 );
 }
 
 inline i32 ksw_grp_env( ) // KswScoring::grp (read on every call: the tests switch it inside one process)
 {
     const char* e = getenv( "MA_KSW_GRP" );
-    // 2 (A/B): also the jobs of 65..128 query bases, two per wave with four rows per lane -- measured slower than k_ksw_ext<1> (150 bp:
+    // 2 (experiment build -DMA_EXP_GRP_NR2 only): also the jobs of 65..128 query bases, two per wave with four rows per lane -- measured slower than k_ksw_ext<1> (150 bp:
     // DP 19.1 -> 20.0 ms): a register set's recurrence is 76 of the ~91 instructions of a diagonal, so sharing the rest buys 16 % per
     // job at best, and 128 VGPRs leave 4 waves per SIMD where k_ksw_ext runs 8
     // 3 (or 1000 + n): extensions of 65 (n) .. 254 query bases on the proven narrow band, four per wave (ksw_band.h).  Default: 1033
     // (150 bp: DP 19.0 ms with 1, 16.4 with 3, 15.7 with 1033)
     const i32 v = e ? std::max( 0, atoi( e ) ) : 1033;
-    return v == 3 ? 1065 : ( v >= 1000 ? std::min( v, 1000 + KSW_BAND_QMAX ) : std::min( v, 2 ) );
+#if defined( MA_EXP_GRP_NR2 )
+    const i32 top = 2;
+#else
+    const i32 top = 1; // the shipped library has no four-rows-per-lane kernels (measured slower): 2 means 1
+#endif
+    return v == 3 ? 1065 : ( v >= 1000 ? std::min( v, 1000 + KSW_BAND_QMAX ) : std::min( v, top ) );
+}
+inline i32 ksw_bandl_env( ) // KswScoring::band_long
+{
+    const char* e = getenv( "MA_KSW_BANDL" );
+    return e ? ( atoi( e ) != 0 ? 1 : 0 ) : 1;
 }
 inline i32 ksw_band_mis_env( )
 {
@@ -415,9 +436,9 @@ struct KswSizing
 {
     u64 state = 0, h = 0, p = 0, cig = 0;
     u64 qlen = 0; // longest query (LDS bytes of the register kernels)
-    u64 cls[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // jobs per class
-    u64 pc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // largest direction-byte scratch of a job, per class (0: use p)
-    u64 cigc[ KSW_N_CLASSES ] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // largest cigar scratch in words, per class (0: use cig)
+    u64 cls[ KSW_N_CLASSES ] = { }; // jobs per class
+    u64 pc[ KSW_N_CLASSES ] = { }; // largest direction-byte scratch of a job, per class (0: use p)
+    u64 cigc[ KSW_N_CLASSES ] = { }; // largest cigar scratch in words, per class (0: use cig)
     u64 pRedo = 0, cigRedo = 0; // the same for jobs the extension kernel hands back to the exact kernels (0: use p / cig)
 };
 inline void ksw_size_job( KswSizing& S, i32 qlen, i32 tlen, i32 w )
@@ -475,7 +496,8 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
     return P;
 }
 
-// Launches every class that has jobs.  `next` = 20 zeroed counters (one per launch; [11..16]: the six lists of k_ksw_grp),
+// Launches every class that has jobs.  `next` = 24 zeroed counters (one per launch; [11..16]: the six lists of k_ksw_grp, [17], [18]:
+// jobs the narrow band appended to the extension kernels' lists, [19], [20]: the two lists of long jobs on the band of 120),
 // `nextBig` = 4 more.  `lists`
 // (device, or null) holds the job slots of class k at lists + k * list_stride, SZ.cls[k] entries, and room for the jobs
 // the extension kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every
@@ -554,7 +576,8 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     // jobs on the proven narrow band (ksw_band.h): those that fail a check are appended to the lists of k_ksw_ext<1> / <2>, which
     // run after them (next[ 17 ], next[ 18 ] count them)
     const u64 nBand = SC.grp >= 1000 ? SZ.cls[ 7 ] + SZ.cls[ 8 ] : 0;
-    const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ] + nGrp;
+    const u64 nBandL = SZ.cls[ KSW_CLS_BANDL ] + SZ.cls[ KSW_CLS_BANDL + 1 ]; // long jobs on the band of 120; those that fail go to `redo`
+    const u64 nExt = SZ.cls[ 5 ] + SZ.cls[ 6 ] + nGrp + nBandL;
     const bool conc = side && side->ready( ) && lists; // classes on their own streams
     u64 perCu = 32; // waves per CU of the persistent ksw launches (MA_KSW_WAVES_PER_CU: tuning hook)
     if( const char* e = getenv( "MA_KSW_WAVES_PER_CU" ) )
@@ -581,6 +604,9 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         // (direction rows of 256 B when the four-rows-per-lane lists have jobs)
         LG = ksw_plan_launch( (u64)KSW_GRP_ROWS * ( SC.grp < 1000 && SZ.cls[ 7 ] + SZ.cls[ 8 ] ? 256 : 128 ), 0, sets, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
     }
+    KswLaunchPlan LBL; // k_ksw_band<.., 1>: KSW_BANDL_ROWS direction rows per wave, 5 waves per SIMD
+    if( nBandL )
+        LBL = ksw_plan_launch( (u64)KSW_BANDL_ROWS * 128, 0, nBandL, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
     for( int k = 0; k < 7; k++ )
     {
         if( k == 4 || ( SZ.cls[ k ] == 0 && !( k >= 5 && nBand ) ) )
@@ -636,8 +662,9 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( nExt )
         for( int k = 0; k < 4; k++ )
         {
-            LP[ 7 + k ] = ksw_plan_launch( SZ.pRedo ? SZ.pRedo : SZ.p, SZ.cigRedo ? SZ.cigRedo : SZ.cig, std::min<u64>( nExt, 256 * 4 ), wantWaves,
-                                           conc ? B / 4 : B );
+            // (the band of 120 proves nearly all of its jobs: a quarter of them as waves of the second pass is plenty)
+            LP[ 7 + k ] = ksw_plan_launch( SZ.pRedo ? SZ.pRedo : SZ.p, SZ.cigRedo ? SZ.cigRedo : SZ.cig,
+                                           std::min<u64>( nExt, 256 * 4 ) + std::min<u64>( nBandL / 4, 256 * 12 ), wantWaves, conc ? B / 4 : B );
             LP[ 7 + k ].lds = ldsOf( std::min<u64>( SZ.qlen, SZ.cigRedo ? SZ.cigRedo : SZ.qlen ) + 48 );
         }
     KswPlan plan = ksw_plan( SZ, SZ.cls[ 4 ] ? SZ.cls[ 4 ] : 1, conc ? B / 4 : B );
@@ -655,7 +682,7 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
             return 2;
         return 0;
     };
-    u64 needLane[ 4 ] = { std::max<u64>( SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0, LG.stride * LG.waves ), 0, 0, 0 };
+    u64 needLane[ 4 ] = { std::max<u64>( std::max<u64>( SZ.cls[ 4 ] ? plan.ws.stride * plan.waves : 0, LG.stride * LG.waves ), LBL.stride * LBL.waves ), 0, 0, 0 };
     for( int i = 0; i < 15; i++ )
         if( LP[ i ].waves )
             needLane[ laneOf( i ) ] = std::max<u64>( needLane[ laneOf( i ) ], LP[ i ].stride * LP[ i ].waves );
@@ -745,6 +772,22 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     if( conc )
         for( int k = 3; k >= 0; k-- )
             launchPk( 0, k );
+    if( nBandL ) // the long extensions on the band of 120 first: they are the longest jobs of lane 0
+        for( int k = 0; k < 2; k++ )
+        {
+            const u32 nk = (u32)SZ.cls[ KSW_CLS_BANDL + k ];
+            if( nk == 0 )
+                continue;
+            const u32* lk = lists + (u64)( KSW_CLS_BANDL + k ) * list_stride;
+            const u32 waves = (u32)std::max<u64>( 1, std::min<u64>( LBL.waves, nk ) );
+            uint8_t* sb = base + laneBase[ 0 ];
+            if( k == 0 )
+                hipLaunchKernelGGL( ( k_ksw_band<FETCH, true, 1> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 19 + k, sb, LBL.stride, O, redo, 0u,
+                                    (u32*)nullptr, 0u, nRedo );
+            else
+                hipLaunchKernelGGL( ( k_ksw_band<FETCH, false, 1> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 19 + k, sb, LBL.stride, O, redo, 0u,
+                                    (u32*)nullptr, 0u, nRedo );
+        }
     if( nGrp ) // the short extensions, several per wavefront (lane 0 of the streams, like the other extension kernels); longest first
         for( int k = 0; k < KSW_GRP_LISTS; k++ )
         {
@@ -764,7 +807,9 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
                                         lists + 5 * list_stride, (u32)SZ.cls[ 5 ], lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 17 );
                     break;
                 }
+#if defined( MA_EXP_GRP_NR2 ) // experiment build only (make expx X=-DMA_EXP_GRP_NR2): two jobs of 65..128 bases per wave, four rows per lane
                 hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 2, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+#endif
                 break;
             case 1:
                 if( SC.grp >= 1000 )
@@ -773,7 +818,9 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
                                         lists + 5 * list_stride, (u32)SZ.cls[ 5 ], lists + 6 * list_stride, (u32)SZ.cls[ 6 ], next + 17 );
                     break;
                 }
+#if defined( MA_EXP_GRP_NR2 )
                 hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 2, false> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );
+#endif
                 break;
             case 2:
                 hipLaunchKernelGGL( ( k_ksw_grp<FETCH, 2, 1, true> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 11 + k, sb, LG.stride, O, redo, nRedo );

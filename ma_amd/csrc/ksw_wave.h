@@ -30,6 +30,7 @@ struct KswScoring
     // 65..128 with four rows per lane (A/B), 1000 + n: extensions of n..254 query bases on the proven narrow band (ksw_band.h)
     i32 grp = 1;
     i32 band_mis = 5; // mismatches on the main diagonal up to which a job is tried on the narrow band (ksw_band_likely; MA_KSW_BAND_MAXMIS: tuning hook)
+    i32 band_long = 1; // long extension jobs (queries beyond 254 bases) one per wavefront on the proven band of 120 (ksw_band.h; MA_KSW_BANDL=0: A/B hook)
 };
 
 // Working storage of one job (flat pointers: LDS or HBM)

@@ -90,10 +90,11 @@ int ma_dp_batch( ma_batch* b )
     D.SC = KswScoring{ b->P.match, b->P.mismatch, b->P.gap, b->P.extend, b->P.gap2, b->P.extend2 };
     D.SC.grp = ksw_grp_env( );
     D.SC.band_mis = ksw_band_mis_env( );
-    // The narrow band is for batches of short reads.  Long reads have millions of short extension jobs between their seeds whose
+    D.SC.band_long = ksw_bandl_env( );
+    // The band of 24 is for batches of short reads.  Long reads have millions of short extension jobs between their seeds whose
     // query rarely follows the main diagonal (50 kb at 10 % errors: 92 k of 11 M jobs pass the pre-filter, which then costs more than
-    // the band saves: k_dp_enum 4.9 -> 20.8 ms), and their DP stage is the wide-band kernels' anyway.
-    if( D.SC.grp >= 1000 && b->max_qlen > 1000 && !getenv( "MA_KSW_BAND_LONG" ) )
+    // the band saves: k_dp_enum 4.9 -> 20.8 ms; measured in round 5).  Their LONG extension jobs go to the band of 120 (band_long).
+    if( D.SC.grp >= 1000 && b->max_qlen > 1000 )
         D.SC.grp = 1;
     D.ez = b->ez.as<ma_ez>( );
     D.cig_off = b->cigOff.as<u64>( );
@@ -177,26 +178,7 @@ int ma_dp_batch( ma_batch* b )
             O.cig_words = c + CTR_CIG_WORDS;
             {
                 EvTimer t( b, 4 );
-                // (experiment MA_CU_SPLIT: the DP kernels on the batch's second stream, masked to the other CUs)
-                hipStream_t dpStream = b->cuDp ? b->cuDp : b->stream;
-                if( dpStream != b->stream )
-                {
-                    MA_HIP( hipEventRecord( b->cuFork, b->stream ) );
-                    MA_HIP( hipStreamWaitEvent( dpStream, b->cuFork, 0 ) );
-                }
-                struct Rejoin // the batch's stream continues when the DP kernels are done, whichever way this block is left
-                {
-                    ma_batch* b;
-                    hipStream_t dp;
-                    ~Rejoin( )
-                    {
-                        if( dp != b->stream )
-                        {
-                            (void)hipEventRecord( b->cuJoin, dp );
-                            (void)hipStreamWaitEvent( b->stream, b->cuJoin, 0 );
-                        }
-                    }
-                } xRejoin{ b, dpStream };
+                hipStream_t dpStream = b->stream;
                 // long reads: every kernel class on its own stream (ksw_launch.h), longest jobs first
                 const bool longReads = b->max_qlen > 254 && !dp_one_stream( );
                 if( longReads && !b->kswSide.ready( ) )
@@ -209,7 +191,7 @@ int ma_dp_batch( ma_batch* b )
                     }
                 }
                 if( longReads )
-                    for( int k = 0; k < 4; k++ )
+                    for( int k : { 0, 1, 2, 3, KSW_CLS_BANDL, KSW_CLS_BANDL + 1 } )
                     {
                         const u64 nk = S.cls[ k ];
                         if( nk < 2048 )
@@ -233,7 +215,7 @@ int ma_dp_batch( ma_batch* b )
                 {
                     GrpSortArgs G;
                     u64 most = 0, all = 0;
-                    for( int k = 0; k < KSW_GRP_SORT_LISTS; k++ ) // (qlen <= 128 here: 128 bins, the last one takes 127 and 128)
+                    for( int k = 0; k < KSW_GRP_SORT_LISTS; k++ ) // (qlen <= 254 here: a bin per length)
                     {
                         const int cls = KSW_CLS_GRP0 + k;
                         G.n[ k ] = (u32)S.cls[ cls ];
@@ -243,7 +225,7 @@ int ma_dp_batch( ma_batch* b )
                     }
                     if( all >= 8192 )
                     {
-                        if( b->sortVal2.reserve( all * 4 + 64 ) || b->sortKey.reserve( KSW_GRP_SORT_LISTS * 2 * 128 * 4 ) )
+                        if( b->sortVal2.reserve( all * 4 + 64 ) || b->sortKey.reserve( KSW_GRP_SORT_LISTS * 2 * KSW_GRP_BINS * 4 ) )
                             return 1;
                         u64 at = 0;
                         for( int k = 0; k < KSW_GRP_SORT_LISTS; k++ )
@@ -252,7 +234,7 @@ int ma_dp_batch( ma_batch* b )
                             at += G.n[ k ];
                         }
                         G.hist = b->sortKey.as<u32>( );
-                        MA_HIP( hipMemsetAsync( G.hist, 0, KSW_GRP_SORT_LISTS * 2 * 128 * 4, dpStream ) );
+                        MA_HIP( hipMemsetAsync( G.hist, 0, KSW_GRP_SORT_LISTS * 2 * KSW_GRP_BINS * 4, dpStream ) );
                         const dim3 grid( (unsigned)std::min<u64>( 1024, ( most + 255 ) / 256 ), KSW_GRP_SORT_LISTS );
                         hipLaunchKernelGGL( k_grp_hist, grid, dim3( 256 ), 0, dpStream, F, G );
                         hipLaunchKernelGGL( k_grp_scatter, grid, dim3( 256 ), 0, dpStream, F, G );

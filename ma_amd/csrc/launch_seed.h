@@ -79,8 +79,8 @@ static int seed_mems( ma_batch* b )
     return 0;
 }
 
-// maxSpan seeding of long reads as area tasks (k_seed_tasks); returns 2 when the task arrays were too small (the caller
-// falls back to the read-per-lane kernel)
+// maxSpan / SMEM seeding of long reads as area tasks (k_seed_tasks, k_seed_tasks_smem); returns 2 when the task arrays -- or, SMEMs,
+// a lane's staging area or pending lists -- were too small (the caller falls back to the read-per-lane kernel)
 // First-attempt size of the segment pool.  Measured: 0.017 - 0.019 maxSpan segments per base (150 bp, 10 kb and 50 kb
 // reads against GRCh38-like references); the pool takes 1/16 per base + 16 per read (>3x that), 24 bytes each plus the
 // sort keys of the task kernel.  It used to be 1/2 per base: 45 GB for a 2 Gbase batch of which 0.9 GB were used, which
@@ -98,8 +98,26 @@ static int seed_tasks( ma_batch* b )
         levels++;
     if( levels >= MA_TASK_KEY_BITS / 2 )
         return 2;
+    const bool smem = b->P.seeding_technique == 1;
     const u64 taskCap = nb / 16 + 2 * n + 1024;
-    b->segPoolCap = std::max( seg_pool_heuristic( nb, n ), b->segPoolMin );
+    b->segPoolCap = std::max( ( smem ? 4 : 1 ) * seg_pool_heuristic( nb, n ), b->segPoolMin );
+    // SMEM tasks: what ONE centre needs, not what a read needs -- a centre's forward run pushes an entry per change of the interval's
+    // size (a few dozen before the match ends; a read-per-lane list is sized for the read's length) and emits a handful of segments;
+    // MA_SEED_TASK_CAPS="<segments>,<list entries>": test hook that forces the fallback
+    u32 segCapT = 96, smemCapT = 384;
+    if( const char* e = getenv( "MA_SEED_TASK_CAPS" ) )
+    {
+        int a = 0, c = 0;
+        if( sscanf( e, "%d,%d", &a, &c ) == 2 && a > 0 && c > 0 )
+            segCapT = (u32)a, smemCapT = (u32)( ( c + 1 ) & ~1 );
+    }
+    const u32 smem_compact = smem && b->max_qlen < ( 1u << MA_SMEM_QZ_BITS ) && b->idx->v.n < ( 1ull << 35 ) && !( getenv( "MA_SMEM_COMPACT" ) && atoi( getenv( "MA_SMEM_COMPACT" ) ) == 0 ) ? 1 : 0;
+    const u64 smemEntry = smem_compact ? 16 : sizeof( ma_segment );
+    const unsigned blocksT = smem ? 1024 : 2048; // (the SMEM kernel: 4 waves per SIMD)
+    const u64 lanesT = (u64)blocksT * 256;
+    if( smem && ( b->taskStage.reserve( lanesT * segCapT * sizeof( ma_segment ) ) || b->smemA.reserve( lanesT * smemCapT * smemEntry ) ||
+                  b->smemB.reserve( lanesT * smemCapT * smemEntry ) ) )
+        return 1;
     if( b->segOff.reserve( ( n + 1 ) * 8 ) || b->segCnt.reserve( ( n + 1 ) * 4 ) || b->taskA.reserve( taskCap * sizeof( SeedTask ) ) ||
         b->taskB.reserve( taskCap * sizeof( SeedTask ) ) || b->taskCnt.reserve( 64 * 8 ) ||
         b->segPool.reserve( b->segPoolCap * sizeof( ma_segment ) ) || b->segRead.reserve( b->segPoolCap * 4 ) ||
@@ -122,6 +140,22 @@ static int seed_tasks( ma_batch* b )
     A.pool_key = b->taskKey.as<u64>( );
     A.pool_cap = b->segPoolCap;
     A.ctr = b->ctr.as<unsigned long long>( );
+    A.stage = smem ? b->taskStage.as<ma_segment>( ) : nullptr;
+    A.seg_cap = segCapT;
+    A.smem_a = smem ? b->smemA.as<ma_segment>( ) : nullptr;
+    A.smem_b = smem ? b->smemB.as<ma_segment>( ) : nullptr;
+    A.smem_cap = smemCapT;
+    if( smem )
+    {
+        A.P.smem_compact = smem_compact;
+        A.P.smem_merge = A.P.min_amb == 0 ? 1 : 0;
+        if( const char* e = getenv( "MA_SMEM_MERGE" ) ) // test hook: 0 = keep every entry like the reference's lists
+            A.P.smem_merge = A.P.smem_merge && atoi( e ) != 0 ? 1 : 0;
+        A.X.kmer_k = 0; // (the K-mer table serves the maxSpan runs that start from a single base)
+        A.slow_batch = 8;
+        if( const char* e = getenv( "MA_SEED_SLOW_BATCH" ) )
+            A.slow_batch = (u32)std::max( 1, atoi( e ) );
+    }
     {
         EvTimer t( b, 0 );
         hipLaunchKernelGGL( k_task_roots, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->d_roff, (u32)n,
@@ -133,7 +167,10 @@ static int seed_tasks( ma_batch* b )
             A.nIn = cnt + lv;
             A.nOut = cnt + lv + 1;
             MA_HIP( hipMemsetAsync( A.ctr + CTR_NEXT_READ, 0, 8, b->stream ) );
-            hipLaunchKernelGGL( k_seed_tasks, dim3( 2048 ), dim3( 256 ), 0, b->stream, A );
+            if( smem )
+                hipLaunchKernelGGL( k_seed_tasks_smem, dim3( blocksT ), dim3( 256 ), 0, b->stream, A );
+            else
+                hipLaunchKernelGGL( k_seed_tasks, dim3( blocksT ), dim3( 256 ), 0, b->stream, A );
         }
     }
     MA_HIP( hipGetLastError( ) );
@@ -141,10 +178,10 @@ static int seed_tasks( ma_batch* b )
         return 1;
     const u32 err = (u32)b->hctr[ CTR_ERR ];
     const u64 ns = b->hctr[ CTR_SEG_USED ];
-    if( ( err & MA_ERR_STACK_OVERFLOW ) )
+    if( ( err & ( MA_ERR_STACK_OVERFLOW | MA_ERR_SMEM_OVERFLOW ) ) )
     {
         MA_HIP( hipMemsetAsync( b->ctr.p, 0, CTR_COUNT * 8, b->stream ) );
-        return 2; // task array too small: the classic kernel takes over
+        return 2; // task array (SMEMs: a lane's staging area or lists) too small: the classic kernel takes over
     }
     if( ( err & MA_ERR_SEG_OVERFLOW ) || ns > b->segPoolCap )
     {
@@ -195,9 +232,10 @@ int ma_seed_batch( ma_batch* b )
     // walk pays a tail per level), with 20 k reads of 50 kb the task kernel is 6.5x faster (83 vs 546 ms).
     // MA_SEED_TASKS=0 / 1 forces the choice (tests, tuning)
     {
-        bool tasks = b->P.seeding_technique == 0 && b->max_qlen > 240 && n < 131072;
+        // Round 6: SMEM seeding (Nanopore preset) as tasks too -- one read per lane left 10 k x 50 kb reads on 10 k of 262 k lanes
+        bool tasks = b->P.seeding_technique <= 1 && b->max_qlen > 240 && n < 131072;
         if( const char* e = getenv( "MA_SEED_TASKS" ) )
-            tasks = b->P.seeding_technique == 0 && atoi( e ) != 0;
+            tasks = b->P.seeding_technique <= 1 && atoi( e ) != 0;
         if( tasks )
         {
             const int rc = seed_tasks( b );

@@ -41,22 +41,22 @@ enum : int
     CTR_N_ALIGNED = 17,
     CTR_SEQ_BYTES = 18, // sum of qlen+tlen over DP jobs
     CTR_PATH_BYTES = 19, // back-trace steps (direction bytes read back)
-    CTR_CLS0 = 20, // DP jobs per kernel class (KSW_N_CLASSES = 13 consecutive words)
-    CTR_MAX_QLEN = 33,
-    CTR_NEXT_SLOTS = 34, // 20 x u32 job queues of the ksw launches (10 words)
-    CTR_N_REDO = 44, // u32: jobs the extension kernels handed back
-    CTR_CIG_WORDS = 45, // cigar words written (CTR_CIG_USED counts pool words reserved)
-    CTR_NEXT_SEED = 46, // queue of k_lf_walk
-    CTR_OPS_ALL = 47, // alignment ops of all alignments / of the MappingQuality selection (exact sizes of the downloads)
-    CTR_OPS_MQ = 48,
-    CTR_ALN_MQ = 49, // alignments MappingQuality keeps
-    CTR_MAX_PC0 = 50, // per kernel class: largest direction-byte scratch of a job (13 words) ...
-    CTR_MAX_CIGC0 = 63, // ... and largest cigar scratch in words (13 words)
-    CTR_MAX_P_REDO = 76, // the same two for the extension kernels' jobs if they are handed back to the exact kernel
-    CTR_MAX_CIG_REDO = 77,
-    CTR_NEXT_BIG = 78, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
-    CTR_N_1X1 = 80, // 1 x 1 gap fills answered by k_dp_enum itself (counted as ksw calls of one cell each)
-    CTR_COUNT = 82
+    CTR_CLS0 = 20, // DP jobs per kernel class (KSW_N_CLASSES = 15 consecutive words)
+    CTR_MAX_QLEN = 35,
+    CTR_NEXT_SLOTS = 36, // 24 x u32 job queues of the ksw launches (12 words)
+    CTR_N_REDO = 48, // u32: jobs the extension kernels (and the band of 120) handed back
+    CTR_CIG_WORDS = 49, // cigar words written (CTR_CIG_USED counts pool words reserved)
+    CTR_NEXT_SEED = 50, // queue of k_lf_walk
+    CTR_OPS_ALL = 51, // alignment ops of all alignments / of the MappingQuality selection (exact sizes of the downloads)
+    CTR_OPS_MQ = 52,
+    CTR_ALN_MQ = 53, // alignments MappingQuality keeps
+    CTR_MAX_PC0 = 54, // per kernel class: largest direction-byte scratch of a job (15 words) ...
+    CTR_MAX_CIGC0 = 69, // ... and largest cigar scratch in words (15 words)
+    CTR_MAX_P_REDO = 84, // the same two for the extension kernels' jobs if they are handed back to the exact kernel
+    CTR_MAX_CIG_REDO = 85,
+    CTR_NEXT_BIG = 86, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
+    CTR_N_1X1 = 88, // 1 x 1 gap fills answered by k_dp_enum itself (counted as ksw calls of one cell each)
+    CTR_COUNT = 90
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -90,7 +90,7 @@ struct ma_batch
     DevBuf reads, roff, ctr, seedStack, seedRow, seedSteps, seedSeg, hlocal, hdense, hseedCnt, hseedOff;
     // seeding
     DevBuf stage, smemA, smemB, segPool, segRead, segOff, segCnt, memsCnt, memsOff;
-    DevBuf taskA, taskB, taskCnt, taskKey, taskKey2, taskPerm, taskPerm2; // area tasks of long reads (seed_tasks)
+    DevBuf taskA, taskB, taskCnt, taskKey, taskKey2, taskPerm, taskPerm2, taskStage; // (taskStage: per-lane segments of an SMEM task) // area tasks of long reads (seed_tasks)
     u64 segPoolCap = 0, segPoolMin = 0;
     // extraction
     DevBuf segSeedCnt, segSeedOff, seedOff, seedCnt, seeds, cubTmp;
@@ -108,10 +108,6 @@ struct ma_batch
     DevBuf sortKey, sortKey2, sortVal2; // longest-job-first order of the DP job lists
     u64 cigPoolCap = 0, cigPoolMin = 0, nOpsCap = 0, nJobSlots = 0;
     KswSide kswSide; // created on first use
-    // MA_CU_SPLIT=<n> (experiment, tools/overlap_matrix.py): the batch's kernels run on a stream masked to CUs [0, n) -- the
-    // memory-bound front end -- and its DP kernels on one masked to CUs [n, 256)
-    hipStream_t cuFront = nullptr, cuDp = nullptr;
-    hipEvent_t cuFork = nullptr, cuJoin = nullptr;
     // double-buffered I/O (ma_batch_stage_reads / ma_batch_start_mapq_download): the next reads are uploaded into reads2 / roff2
     // and the packed results of the last step downloaded on ioStream while the batch's own stream runs kernels
     DevBuf reads2, roff2;
@@ -246,13 +242,6 @@ int ma_batch_destroy( ma_batch* b )
             if( e )
                 (void)hipEventDestroy( e );
     }
-    if( b->cuFront )
-    {
-        (void)hipStreamDestroy( b->cuFront );
-        (void)hipStreamDestroy( b->cuDp );
-        (void)hipEventDestroy( b->cuFork );
-        (void)hipEventDestroy( b->cuJoin );
-    }
     if( b->kswSide.fork )
     {
         (void)hipEventDestroy( b->kswSide.fork );
@@ -273,25 +262,6 @@ int ma_batch_set_stream( ma_batch* b, void* s )
     if( !b )
         return fail( "ma_batch_set_stream: null batch" );
     b->stream = (hipStream_t)s;
-    // The CU-partition experiment: instead of the caller's stream the batch uses two streams of its own,
-    // masked to disjoint sets of CUs (hipExtStreamCreateWithCUMask; bit i = CU i as the runtime numbers them)
-    if( const char* e = getenv( "MA_CU_SPLIT" ) )
-    {
-        const int n = atoi( e );
-        if( n > 0 && n < 256 && !b->cuFront )
-        {
-            MA_BIND_DEVICE( b->device );
-            uint32_t front[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dp[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-            for( int i = 0; i < 256; i++ )
-                ( i < n ? front : dp )[ i >> 5 ] |= 1u << ( i & 31 );
-            MA_HIP( hipExtStreamCreateWithCUMask( &b->cuFront, 8, front ) );
-            MA_HIP( hipExtStreamCreateWithCUMask( &b->cuDp, 8, dp ) );
-            MA_HIP( hipEventCreateWithFlags( &b->cuFork, hipEventDisableTiming ) );
-            MA_HIP( hipEventCreateWithFlags( &b->cuJoin, hipEventDisableTiming ) );
-        }
-        if( b->cuFront )
-            b->stream = b->cuFront;
-    }
     return 0;
 }
 
@@ -1073,6 +1043,36 @@ int ma_debug_band_stats( unsigned long long out[ 8 ] )
     if( ma::band_stats_of_prims( other ) )
         return 1;
     for( int i = 0; i < 8; i++ )
+        out[ i ] += other[ i ];
+    return 0;
+}
+
+// the same for the LONG extension jobs, one per wavefront on the band of 120 (ksw_band.h, G = 1)
+int ma_debug_band_long_stats( unsigned long long out[ 8 ] )
+{
+    if( !out )
+        return fail( "ma_debug_band_long_stats: null argument" );
+    unsigned long long other[ 8 ];
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_band_stats ), 8 * 8, 8 * 8 ) );
+    if( ma::band_long_stats_of_prims( other ) )
+        return 1;
+    for( int i = 0; i < 8; i++ )
+        out[ i ] += other[ i ];
+    return 0;
+}
+
+// diagnostics: DP cells computed and jobs finished per kernel family since the library was loaded (ksw_launch.h: g_dp_family):
+// out[ 2 f ], out[ 2 f + 1 ] for f = 0 k_ksw_ext<1>, 1 k_ksw_ext<2>, 2 k_ksw_grp<2>, 3 k_ksw_grp<4>, 4 k_ksw_band (four short jobs per wave),
+// 5 k_ksw_pk, 6 k_ksw, 7 k_ksw_band (one long job per wave)
+int ma_debug_dp_family_stats( unsigned long long out[ 16 ] )
+{
+    if( !out )
+        return fail( "ma_debug_dp_family_stats: null argument" );
+    unsigned long long other[ 2 * KSW_N_FAMILIES ];
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_dp_family ), 2 * KSW_N_FAMILIES * 8 ) );
+    if( ma::dp_family_stats_of_prims( other ) )
+        return 1;
+    for( int i = 0; i < 2 * KSW_N_FAMILIES; i++ )
         out[ i ] += other[ i ];
     return 0;
 }

@@ -129,6 +129,7 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     KswScoring SC{ P->match, P->mismatch, P->gap, P->extend, P->gap2, P->extend2 };
     SC.grp = ksw_grp_env( );
     SC.band_mis = ksw_band_mis_env( );
+    SC.band_long = ksw_bandl_env( );
     KswSizing S;
     for( uint64_t i = 0; i < n; i++ )
         ksw_size_job( S, jobs[ i ].qlen, jobs[ i ].tlen, jobs[ i ].w );
@@ -156,6 +157,18 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
                 {
                     KswScoring S1 = SC;
                     S1.grp = 1;
+                    c = ksw_job_class_pipe( S1, ql, tl, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
+                }
+            }
+            if( ( c == KSW_CLS_BANDL || c == KSW_CLS_BANDL + 1 ) && !getenv( "MA_KSW_BAND_ALL" ) )
+            {
+                const uint8_t *qp = q_bytes + jobs[ i ].q_off, *tp = t_bytes + jobs[ i ].t_off;
+                auto qf = [ & ]( i32 k ) -> u32 { return qp[ k ]; };
+                auto tf = [ & ]( i32 k ) -> u32 { return tp[ k ]; };
+                if( !ksw_bandl_likely( qf, tf, ql, tl ) )
+                {
+                    KswScoring S1 = SC;
+                    S1.band_long = 0;
                     c = ksw_job_class_pipe( S1, ql, tl, jobs[ i ].w, jobs[ i ].zdrop, jobs[ i ].flag );
                 }
             }
@@ -203,13 +216,13 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     O.path = nullptr;
     O.cig_words = nullptr;
     O.cig_chunk = 0; // dense pool: cigar_off[n] is the total
-    unsigned int* next = (unsigned int*)( ctr + 4 ); // 20 x u32 launch queues (ctr[4..13])
+    unsigned int* next = (unsigned int*)( ctr + 4 ); // 24 x u32 launch queues (ctr[4..15])
     FETCH F;
     F.jobs = dj.as<ma_ksw_job>( );
     F.qb = dq.as<uint8_t>( );
     F.tb = dt.as<uint8_t>( );
     if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0, FETCH::EARLY ? dlists.as<u32>( ) : nullptr, n,
-                     (unsigned int*)( ctr + 14 ), (unsigned int*)( ctr + 15 ) ) )
+                     (unsigned int*)( ctr + 16 ), (unsigned int*)( ctr + 17 ) ) )
         return 1;
     MA_HIP( hipDeviceSynchronize( ) );
     unsigned long long h[ 8 ];
@@ -258,6 +271,16 @@ namespace ma
 int band_stats_of_prims( unsigned long long out[ 8 ] )
 {
     MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_band_stats ), 8 * 8 ) );
+    return 0;
+}
+int band_long_stats_of_prims( unsigned long long out[ 8 ] )
+{
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_band_stats ), 8 * 8, 8 * 8 ) );
+    return 0;
+}
+int dp_family_stats_of_prims( unsigned long long out[ 2 * KSW_N_FAMILIES ] )
+{
+    MA_HIP( hipMemcpyFromSymbol( out, HIP_SYMBOL( ma::g_dp_family ), 2 * KSW_N_FAMILIES * 8 ) );
     return 0;
 }
 } // namespace ma

@@ -172,6 +172,19 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                     cls = ksw_job_class_pipe( S1, ql, tl, j.w, j.zdrop, j.flag );
                 }
             }
+            if( cls == KSW_CLS_BANDL || cls == KSW_CLS_BANDL + 1 )
+            {
+                // the band of 120 is tried on the long extensions whose first bases follow the target with few edits (ksw_bandl_likely)
+                const uint8_t* qb = A.reads + j.read_off;
+                auto qf = [ & ]( i32 i ) -> u32 { return j.rev ? qb[ j.q_to - 1 - (u32)i ] : qb[ j.q_from + (u32)i ]; };
+                auto tf = [ & ]( i32 i ) -> u32 { return text_base( A.X, j.win_begin + ( j.rev ? j.r_to - 1 - (u32)i : j.r_from + (u32)i ) ); };
+                if( !ksw_bandl_likely( qf, tf, ql, tl ) )
+                {
+                    KswScoring S1 = A.SC;
+                    S1.band_long = 0;
+                    cls = ksw_job_class_pipe( S1, ql, tl, j.w, j.zdrop, j.flag );
+                }
+            }
             const u64 pk = ksw_p_bytes( ql, tl, j.w );
             // 256-byte units (the query-stationary classes from KSW_CLS_GRP0 on have a fixed scratch per wave: ksw_grp.h)
             pj = cls >= KSW_CLS_GRP0 ? 0u : (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 );
@@ -391,61 +404,60 @@ __global__ void k_job_cost( PipeFetch F, const u32* list, u32 n, u32* key )
 
 // Jobs that share a wavefront run in lock-step until the longest of them is done (ksw_grp.h): the lists of those classes are
 // ordered by query length, longest first, so that the jobs of a set are about equally long (unsorted: 1.7x the diagonals four
-// jobs need).  A counting sort over the <= 128 possible lengths, all lists in two launches (a radix sort per list was 45
+// jobs need).  A counting sort over the <= 256 possible lengths, all lists in two launches (a radix sort per list was 45
 // launches per step): k_grp_hist copies every list aside and counts its lengths, k_grp_scatter puts the entries back at
 // start-of-its-length + a running index.  The order among jobs of equal length is arbitrary; no result depends on it.
 #define KSW_GRP_SORT_LISTS 6
+#define KSW_GRP_BINS 256 // one bin per query length: the lists of the narrow band hold queries of up to 254 bases (= the block size)
 struct GrpSortArgs
 {
     u32* list[ KSW_GRP_SORT_LISTS ]; // in place
     u32* tmp[ KSW_GRP_SORT_LISTS ];
     u32 n[ KSW_GRP_SORT_LISTS ];
-    u32* hist; // KSW_GRP_SORT_LISTS x 2 x 128 words, zeroed: [l][0][len] = jobs of that length, [l][1][len] = running index
+    u32* hist; // KSW_GRP_SORT_LISTS x 2 x 256 words, zeroed: [l][0][len] = jobs of that length, [l][1][len] = running index
 };
 // (same-address device atomics serialise in L2 at ~9 ns each: a block counts in LDS and touches every global counter once)
 __global__ void k_grp_hist( PipeFetch F, GrpSortArgs A )
 {
     const int l = blockIdx.y;
-    __shared__ u32 h[ 128 ];
-    if( threadIdx.x < 128 )
-        h[ threadIdx.x ] = 0;
+    __shared__ u32 h[ KSW_GRP_BINS ];
+    h[ threadIdx.x ] = 0; // (256 threads, KSW_GRP_BINS = 256)
     __syncthreads( );
     for( u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n[ l ]; i += gridDim.x * blockDim.x )
     {
         const u32 slot = A.list[ l ][ i ];
         A.tmp[ l ][ i ] = slot;
-        atomicAdd( &h[ min( (u32)F.view( slot ).qlen, 127u ) ], 1u );
+        atomicAdd( &h[ min( (u32)F.view( slot ).qlen, KSW_GRP_BINS - 1u ) ], 1u );
     }
     __syncthreads( );
-    if( threadIdx.x < 128 && h[ threadIdx.x ] )
-        atomicAdd( A.hist + ( l * 2 + 0 ) * 128 + threadIdx.x, h[ threadIdx.x ] );
+    if( h[ threadIdx.x ] )
+        atomicAdd( A.hist + ( l * 2 + 0 ) * KSW_GRP_BINS + threadIdx.x, h[ threadIdx.x ] );
 }
 __global__ void k_grp_scatter( PipeFetch F, GrpSortArgs A )
 {
     const int l = blockIdx.y;
-    __shared__ u32 start[ 128 ]; // where this block's entries of each length go: start of the length (longest first) + the block's reservation
-    __shared__ u32 h[ 128 ];
-    if( threadIdx.x < 128 )
-        h[ threadIdx.x ] = 0;
+    __shared__ u32 start[ KSW_GRP_BINS ]; // where this block's entries of each length go: start of the length (longest first) + the block's reservation
+    __shared__ u32 h[ KSW_GRP_BINS ];
+    __shared__ u32 tot[ KSW_GRP_BINS ];
+    h[ threadIdx.x ] = 0;
+    tot[ threadIdx.x ] = A.hist[ ( l * 2 + 0 ) * KSW_GRP_BINS + threadIdx.x ];
     __syncthreads( );
     for( u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n[ l ]; i += gridDim.x * blockDim.x )
-        atomicAdd( &h[ min( (u32)F.view( A.tmp[ l ][ i ] ).qlen, 127u ) ], 1u );
+        atomicAdd( &h[ min( (u32)F.view( A.tmp[ l ][ i ] ).qlen, KSW_GRP_BINS - 1u ) ], 1u );
     __syncthreads( );
-    if( threadIdx.x < 128 )
     {
         u32 before = 0;
-        for( u32 k = 127; k > threadIdx.x; k-- )
-            before += A.hist[ ( l * 2 + 0 ) * 128 + k ];
-        start[ threadIdx.x ] = before + ( h[ threadIdx.x ] ? atomicAdd( A.hist + ( l * 2 + 1 ) * 128 + threadIdx.x, h[ threadIdx.x ] ) : 0u );
+        for( u32 k = KSW_GRP_BINS - 1; k > threadIdx.x; k-- )
+            before += tot[ k ];
+        start[ threadIdx.x ] = before + ( h[ threadIdx.x ] ? atomicAdd( A.hist + ( l * 2 + 1 ) * KSW_GRP_BINS + threadIdx.x, h[ threadIdx.x ] ) : 0u );
     }
     __syncthreads( );
-    if( threadIdx.x < 128 )
-        h[ threadIdx.x ] = 0;
+    h[ threadIdx.x ] = 0;
     __syncthreads( );
     for( u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < A.n[ l ]; i += gridDim.x * blockDim.x )
     {
         const u32 slot = A.tmp[ l ][ i ];
-        const u32 len = min( (u32)F.view( slot ).qlen, 127u );
+        const u32 len = min( (u32)F.view( slot ).qlen, KSW_GRP_BINS - 1u );
         A.list[ l ][ start[ len ] + atomicAdd( &h[ len ], 1u ) ] = slot;
     }
 }

@@ -317,7 +317,7 @@ __global__ void k_mems_finish( IndexView X, SeedParams P, const u64* roff, u32 n
     seg_cnt[ r ] = n;
 }
 
-// ---- task-parallel maxSpan seeding for long reads --------------------------------------------------------------
+// ---- task-parallel maxSpan / SMEM seeding for long reads -----------------------------------------------------
 // procesInterval (binarySeeding.cpp:32-84) is a binary recursion: the centre of an area is extended, then the part left
 // of the covered interval and the part right of it are processed independently.  A read-per-lane walk leaves a 50 kb
 // read on ONE lane (20 k reads = 1.2 wavefronts per CU); here every AREA is a task.  The tree is walked level by level
@@ -326,6 +326,11 @@ __global__ void k_mems_finish( IndexView X, SeedParams P, const u64* roff, u32 n
 // task's PRE-ORDER key -- node before its left subtree before its right subtree, two bits per level: exactly the order in
 // which the recursion pushes segments -- and append the child areas to the next level's array.  A stable sort by
 // (read, key) then restores the reference's segment order.
+// Round 6: the same for SMEM seeding (template SM; the Nanopore preset: binarySeeding.h:261-452 under the
+// same recursion, binarySeeding.cpp:41-83).  A centre's smemExtension emits a variable number of segments -- they leave the lane's
+// staging area in emission order under ONE key, and the sort is stable -- and needs the lane's two pending lists; both are sized
+// for what reads produce (seg_cap, smem_cap), and a task that outgrows either raises MA_ERR_SMEM_OVERFLOW: the host then runs the
+// read-per-lane kernel, which sizes them for the worst case.
 struct SeedTask
 {
     u32 read, aS, aN, depth;
@@ -348,6 +353,12 @@ struct TaskKernelArgs
     u64 pool_cap;
     unsigned long long* ctr;
     u32 slow_batch;
+    // SMEM tasks: per-lane staging of a centre's segments and the two pending lists (seeding.h)
+    ma_segment* stage;
+    u32 seg_cap;
+    ma_segment* smem_a;
+    ma_segment* smem_b;
+    u32 smem_cap;
 };
 __global__ void k_task_roots( const u64* roff, u32 n_reads, SeedTask* out, unsigned long long* nOut )
 {
@@ -360,8 +371,9 @@ __global__ void k_task_roots( const u64* roff, u32 n_reads, SeedTask* out, unsig
     t.read = r, t.aS = 0, t.aN = (u32)( roff[ r + 1 ] - roff[ r ] ), t.depth = 0, t.key = 0;
     out[ r ] = t;
 }
-__global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
+template <bool SM> __device__ __forceinline__ void seed_tasks_body( const TaskKernelArgs& A )
 {
+    constexpr bool MS = !SM;
     const u32 wl = threadIdx.x & 63;
     // a level that overflowed the task array bumped *nOut past task_cap without writing those tasks: the levels queued
     // behind it must neither run on the unwritten slots nor read past the array (the host falls back to k_seed)
@@ -377,6 +389,16 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
     S.seg_cap = 2;
     S.smem_a = S.smem_b = nullptr;
     S.smem_cap = 0;
+    if( SM )
+    {
+        const u64 lane = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+        const u64 smemWords = (u64)A.smem_cap * ( A.P.smem_compact ? 2u : 5u );
+        S.stage = A.stage + lane * A.seg_cap;
+        S.seg_cap = A.seg_cap;
+        S.smem_a = (ma_segment*)( (u64*)A.smem_a + lane * smemWords );
+        S.smem_b = (ma_segment*)( (u64*)A.smem_b + lane * smemWords );
+        S.smem_cap = A.smem_cap;
+    }
     S.stack = nullptr;
     S.drop_div = 0;
     SeedTask T;
@@ -392,7 +414,9 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
         {
             // ---- finished tasks: segments to the pool, child areas to the next level (one atomic per wave and array)
             const bool flush = done && T.read != 0xffffffffu;
-            const u32 ns = flush ? ( L.nseg < 2 ? L.nseg : 2 ) : 0;
+            if( SM && flush && ( L.err & ( MA_ERR_SEG_OVERFLOW | MA_ERR_SMEM_OVERFLOW ) ) )
+                L.err = ( L.err & ~(u32)MA_ERR_SEG_OVERFLOW ) | MA_ERR_SMEM_OVERFLOW; // the task outgrew its staging area or a list
+            const u32 ns = flush ? ( L.nseg < S.seg_cap ? L.nseg : S.seg_cap ) : 0;
             const u32 nc = flush ? ( L.childN[ 0 ] ? 1 : 0 ) + ( L.childN[ 1 ] ? 1 : 0 ) : 0;
             u32 incS = ns, incC = nc;
             for( int d = 1; d < 64; d <<= 1 )
@@ -418,7 +442,7 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
                 if( so + ns <= A.pool_cap )
                     for( u32 k = 0; k < ns; k++ )
                     {
-                        A.pool[ so + k ] = mine[ k ];
+                        A.pool[ so + k ] = SM ? S.stage[ k ] : mine[ k ];
                         A.pool_key[ so + k ] = ( (u64)T.read << MA_TASK_KEY_BITS ) | T.key;
                     }
                 else
@@ -473,12 +497,12 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
             break;
         u32 c = 0;
         const bool act = alive && L.phase != PH_DONE;
-        bool ext = act && seed_try<true, false>( L, A.P, c );
+        bool ext = act && seed_try<true, SM, MS>( L, A.P, c, SM ? &S : nullptr );
         {
             const unsigned long long sm = __ballot( act && !ext );
             if( sm && ( (u32)__popcll( sm ) >= A.slow_batch || __ballot( ext ) == 0 ) )
                 if( act && !ext )
-                    ext = seed_prepare<true, true, false>( L, A.P, S, A.X, c );
+                    ext = seed_prepare<true, true, SM, MS>( L, A.P, S, A.X, c );
         }
         if( ext )
         {
@@ -488,7 +512,7 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
             extend_backward( A.X, L.ik, c, ok, nb );
             L.steps++;
             L.blocks += nb;
-            seed_apply<false>( L, A.P, S, ok );
+            seed_apply<SM, MS>( L, A.P, S, ok );
         }
     }
     steps = wave_sum_u64( steps );
@@ -498,6 +522,14 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
         atomicAdd( &A.ctr[ CTR_STEPS ], (unsigned long long)steps );
         atomicAdd( &A.ctr[ CTR_BLOCKS ], (unsigned long long)blocks );
     }
+}
+__global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
+{
+    seed_tasks_body<false>( A );
+}
+__global__ void __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( 4 ) ) ) k_seed_tasks_smem( TaskKernelArgs A )
+{
+    seed_tasks_body<true>( A );
 }
 // segments into (read, pre-order) order; read id per segment
 __global__ void k_task_permute( const ma_segment* in, const u64* sorted_key, const u32* perm, u64 n, ma_segment* out, u32* out_read )

@@ -1477,6 +1477,9 @@ class BatchAligner
     typedef libMS::ContainerVector<std::shared_ptr<AlignmentVector>> TP_RESULT;
     size_t uiBatchReads = 1u << 18;
     size_t uiInflight = 2;
+    // opt-in: the worker threads alignRangeOn starts itself are pinned to the CPUs next to their replica's GPU
+    // (ma_host_bind_thread, always inside the mask the caller runs under); off, they inherit the caller's placement
+    bool bPinWorkers = false;
     AlignerTiming xLast; // of the last execute()
     std::vector<AlignerTiming> vLastPerIndex; // the same per replica of the index (one entry without replicas)
 
@@ -1579,10 +1582,10 @@ class BatchAligner
         auto worker = [ & ]( size_t uiMe ) {
             try
             {
-                // threads this call starts itself run on the CPUs next to their replica's GPU (ma_host_bind_thread); worker 0 is
-                // the caller's thread and stays where the caller put it
+                // bPinWorkers: threads this call starts itself run on the CPUs next to their replica's GPU (ma_host_bind_thread);
+                // worker 0 is the caller's thread and stays where the caller put it
                 int iDevice = 0;
-                if( uiMe != 0 && ma_index_device( vIndices[ vIndexOfWorker[ uiMe ] ], &iDevice ) == 0 )
+                if( bPinWorkers && uiMe != 0 && ma_index_device( vIndices[ vIndexOfWorker[ uiMe ] ], &iDevice ) == 0 )
                     ma_host_bind_thread( iDevice, 0, nullptr );
                 detail::Engine& xEngine = *vEngines[ uiMe ];
                 if( vFirst[ uiMe ].first < vFirst[ uiMe ].second )

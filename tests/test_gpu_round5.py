@@ -267,7 +267,7 @@ def test_short_extensions_that_share_a_wavefront(gpu_device, scoring, monkeypatc
         long_cases = [(np.concatenate([q, q[::-1], q])[:int(65 + (i * 7) % 64)], t, w, zd, fl) for i, (q, t, w, zd, fl) in enumerate(cases[:400]) if len(q) >= 33]
         monkeypatch.setenv("MA_KSW_GRP", "1")
         ez, cigs = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
-        monkeypatch.setenv("MA_KSW_GRP", "2")  # queries of 65..128 bases: two jobs per wavefront with four rows per lane (A/B mode)
+        monkeypatch.setenv("MA_KSW_GRP", "2")  # experiment builds (-DMA_EXP_GRP_NR2): queries of 65..128 bases two per wavefront; the shipped library reads it as 1 and the 65..128-base cases run on k_ksw_ext
         ez2, cigs2 = ma_amd.ksw_batch(P, cases + long_cases, pipeline_semantics=True)
         monkeypatch.setenv("MA_KSW_GRP", "0")
         ez0, cigs0 = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
@@ -509,7 +509,9 @@ def band_extension_cases(n, seed, qmin=65, qmax=254):
             q = rng.integers(0, 4, size=ql, dtype=np.uint8)  # junk
         if rng.random() < 0.05:
             q[rng.random(ql) < 0.1] = 4  # N
-        zd = int(rng.choice([200, 200, 200, 100, 30]))
+        # small z-drops: the reference's test is armed from diagonal 0 (ez.max = 0, max_t = max_q = -1: kswcpp_core.h:22-44), so a
+        # first-base mismatch z-drops at r = 0 when zdrop < |mismatch|
+        zd = int(rng.choice([200, 200, 200, 100, 30, 10, 3, 0]))
         fl = KSW_EXTZ if rng.random() < 0.5 else (KSW_EXTZ | KSW_RIGHT | KSW_REV)
         cases.append((q, np.ascontiguousarray(t[:tl]), 512, zd, fl))
     return cases

@@ -1,0 +1,289 @@
+"""Round 6: the proven band for the LONG extension jobs (ksw_band.h, G = 1: one job per wavefront on a band of 120 cells; the end
+extensions of 10 kb reads, needlemanWunsch.cpp:708-716, 781-782), an ADVERSARIAL generator for both band kernels (an out-of-band
+path that scores within a few points of the in-band optimum; a single in-band gap near the band's edge; tiny z-drops), and SMEM
+seeding of long reads as area tasks (binarySeeding.cpp:41-83, binarySeeding.h:261-452)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ma_testlib import KSW_EXTZ, KSW_REV, KSW_RIGHT, or_ksw, or_params
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCORINGS = [None, (3, 5, 6, 3, 30, 2), (2, 4, 12, 1, 6, 3)]  # (the third: the second gap model is the cheaper one)
+
+
+@pytest.fixture(scope="module")
+def gpu_device():
+    import ma_amd
+    if ma_amd.device_count() < 1:
+        pytest.skip("no HIP device")
+    ma_amd.set_device(0)
+    return 0
+
+
+def band_stats(long_jobs):
+    import ma_amd
+    out = (C.c_ulonglong * 8)()
+    fn = ma_amd.lib().ma_debug_band_long_stats if long_jobs else ma_amd.lib().ma_debug_band_stats
+    assert fn(out) == 0
+    return np.array(list(out), dtype=np.int64)
+
+
+def scoring_of(scoring):
+    a, b, q, e, q2, e2 = scoring if scoring is not None else (2, 4, 4, 2, 24, 1)
+    return a, b, (lambda L: min(q + L * e, q2 + L * e2))
+
+
+def params_for(scoring):
+    import ma_amd
+    P = ma_amd.Params.preset("default")
+    op = or_params("default", 1)
+    if scoring is not None:
+        for prm in (P, op):
+            prm.match, prm.mismatch, prm.gap, prm.extend, prm.gap2, prm.extend2 = scoring
+    return P, op
+
+
+def noisy_copy(ref, n, sub, ins, dele, rng):
+    out, i = [], 0
+    while len(out) < n and i < len(ref):
+        u = rng.random()
+        if u < sub:
+            out.append((int(ref[i]) + 1 + int(rng.integers(0, 3))) % 4); i += 1
+        elif u < sub + ins:
+            out.append(int(rng.integers(0, 4)))
+        elif u < sub + ins + dele:
+            i += 1
+        else:
+            out.append(int(ref[i])); i += 1
+    return np.array((out + [0] * n)[:n], dtype=np.uint8)
+
+
+def adversarial_cases(n, seed, B, scoring, qlo, qhi, pad):
+    """Jobs built AGAINST the band proof, a third each:
+    A. an out-of-band competitor: the query is the target's head, except that L bases from position a on are copied from g bases further
+       down the target (g = B+1 .. B+8: the matching path leaves the band by one gap of g and comes back by another), while the path on
+       the main diagonal mismatches in x of those L places; x is chosen so that the out-of-band path scores d = -6 .. +6 more than the
+       in-band one (0: a tie);
+    B. ONE gap of B-10 .. B bases inside the band (either direction): the optimal path runs along the band's edge, where check 1 can
+       still pass and the classes / the back-trace's first cell are at the bound (checks 2 and 3);
+    C. a first-base mismatch under z-drops of 0 .. 12 (the reference's test is armed before the first raise, kswcpp_core.h:22-44)."""
+    a, b, f = scoring_of(scoring)
+    rng = np.random.default_rng(seed)
+    cases, kinds = [], []
+    for k in range(n):
+        ql = int(rng.integers(qlo, qhi + 1))
+        tl = ql + pad if rng.random() < 0.7 else int(rng.choice([ql + 40, ql, max(B + 40, ql - 30)]))
+        t = rng.integers(0, 4, size=tl + 2 * B + 64, dtype=np.uint8)
+        fam = k % 3
+        zd = 200
+        if fam == 0:
+            g = int(rng.integers(B + 1, B + 9))
+            d = int(rng.integers(-6, 7))
+            x = max(1, int(round((a * g + 2 * f(g) + d) / float(a + b))))  # in-band mismatches among the L copied bases
+            # the mismatches lie 4 .. 6 bases apart: a dense block of them would be bridged by small gaps and neither path would be the optimum
+            step = int(rng.integers(4, 7)) if B > 30 else int(rng.integers(4, 6))
+            L = max(x * step, g + int(rng.integers(0, 4)))  # (L >= g keeps the construction below sequential)
+            a0 = int(rng.integers(8, 20))
+            rest = f(g) // a + int(rng.integers(30, 50))  # (an extension may END anywhere: stopping before the second gap must cost more than the gap)
+            ql = a0 + L + g + rest
+            other = lambda c: (int(c) + 1 + int(rng.integers(0, 3))) % 4  # noqa: E731
+            same = np.ones(L, dtype=bool)
+            same[(np.arange(x) * L) // x + rng.integers(0, max(1, L // x - 2), size=x)] = False
+            q = rng.integers(0, 4, size=ql, dtype=np.uint8)
+            t = rng.integers(0, 4, size=ql + pad + 8, dtype=np.uint8)
+            t[:a0] = q[:a0]
+            for i in range(L):  # main diagonal: q[a0 + i] against t[a0 + i]; out of the band: q[a0 + i] against t[a0 + g + i]
+                if i < g:
+                    t[a0 + i] = q[a0 + i] if same[i] else other(q[a0 + i])
+                else:
+                    t[a0 + i] = q[a0 + i - g]
+                    q[a0 + i] = t[a0 + i] if same[i] else other(t[a0 + i])
+            t[a0 + g:a0 + g + L] = q[a0:a0 + L]
+            for i in range(g):  # the g bases the out-of-band path inserts: they match on the main diagonal
+                q[a0 + L + i] = t[a0 + L + i]
+            t[a0 + L + g:a0 + L + g + rest] = q[a0 + L + g:]
+            tl = ql + pad
+            if rng.random() < 0.5:  # the mirror image: the gaps the other way round
+                q, t = np.ascontiguousarray(t[:ql]), np.concatenate([q, rng.integers(0, 4, size=pad + 8, dtype=np.uint8)])
+        elif fam == 1:
+            d = int(rng.integers(max(1, B - 10), B + 1))
+            p = int(rng.integers(20, max(21, ql // 2)))
+            if rng.random() < 0.5:
+                q = np.concatenate([t[:p], t[p + d:]])[:ql]  # the target has d bases more
+            else:
+                q = np.concatenate([t[:p], rng.integers(0, 4, size=d, dtype=np.uint8), t[p:]])[:ql]  # the query has
+            if rng.random() < 0.5:
+                q = q.copy()
+                mut = rng.random(len(q)) < 0.004
+                q[mut] = (q[mut] + 1) % 4
+        else:
+            q = t[:ql].copy()
+            q[0] = (q[0] + 1) % 4
+            if rng.random() < 0.5:
+                q[1] = (q[1] + 2) % 4
+            zd = int(rng.choice([0, 1, 3, 4, 5, 8, 12]))
+        q = np.ascontiguousarray(q, dtype=np.uint8)
+        fl = KSW_EXTZ if rng.random() < 0.5 else (KSW_EXTZ | KSW_RIGHT | KSW_REV)
+        cases.append((q, np.ascontiguousarray(t[:tl]), 512, zd, fl))
+        kinds.append(fam)
+    return cases, kinds
+
+
+def compare_with_oracle(P, op, cases, what):
+    import ma_amd
+    ez, cigs = ma_amd.ksw_batch(P, cases, pipeline_semantics=True)
+    bad = 0
+    for i, (q, t, w, zd, fl) in enumerate(cases):
+        oez, ocig = or_ksw(op, q, t, w, zd, fl)
+        same = all(int(ez[f][i]) == int(oez[f]) for f in ("max", "max_q", "max_t")) and np.array_equal(cigs[i], ocig)
+        if not same and bad < 5:
+            print("%s case %d (qlen %d tlen %d zdrop %d flag %#x): got %s %s, oracle %s %s" % (
+                what, i, len(q), len(t), zd, fl, [int(ez[f][i]) for f in ("max", "max_q", "max_t")], cigs[i].tolist()[:12],
+                [int(oez[f]) for f in ("max", "max_q", "max_t")], ocig.tolist()[:12]))
+        bad += 0 if same else 1
+    return bad
+
+
+@pytest.mark.parametrize("scoring", SCORINGS)
+def test_adversarial_jobs_against_the_band_proof(gpu_device, scoring, monkeypatch):
+    """Both band kernels on jobs built against their proof (adversarial_cases): every job -- proved or handed on -- gives the oracle's
+    max, max_q, max_t and cigar at the full band; some jobs ARE proved, and some fail check 1 and some check 2 or 3 (else the generator
+    misses its target)."""
+    P, op = params_for(scoring)
+    monkeypatch.setenv("MA_KSW_GRP", "1033")
+    monkeypatch.setenv("MA_KSW_BAND_ALL", "1")
+    for long_jobs, B, qlo, qhi, n in ((False, 24, 120, 254, 3000), (True, 120, 700, 1600, 450)):
+        cases, kinds = adversarial_cases(n, 61 + (0 if scoring is None else scoring[0]) + (7 if long_jobs else 0), B, scoring, qlo, qhi, 1000)
+        s0 = band_stats(long_jobs)
+        bad = compare_with_oracle(P, op, cases, "long" if long_jobs else "short")
+        s1 = band_stats(long_jobs) - s0
+        print("%s band, adversarial: %d jobs tried, %d proved, failed checks %s, handed back otherwise %d" % (
+            "long" if long_jobs else "short", s1[0], s1[1], s1[2:6].tolist(), s1[6]))
+        assert bad == 0, "%d of %d jobs differ from the oracle" % (bad, len(cases))
+        assert s1[0] > 0.5 * len(cases), s1  # (a scoring scheme may take some shapes out of the kernels' regime)
+        assert s1[1] > 0 and s1[2] > 0 and s1[3] + s1[4] > 0, s1
+
+
+def long_extension_cases(n, seed):
+    """Extension jobs of 255 .. 3000 query bases as the pipeline emits them for long reads (band 512, z-drop 200): the rest of a read
+    against the reference behind its last seed padded by 1000 bases (10 kb reads at ~1 % errors: the band of 120 proves them), the
+    two-sided extensions into a large gap (target about as long as the query), noisy reads at 10 % (must fail check 1 and go on),
+    repeats, junk, Ns, a first-base mismatch, short targets."""
+    rng = np.random.default_rng(seed)
+    cases = []
+    for k in range(n):
+        ql = int(rng.choice([int(rng.integers(255, 400)), int(rng.integers(400, 1200)), int(rng.integers(1200, 3000))]))
+        tl = int(rng.choice([1000, 1000, 1000, ql + 1000, ql + 50, ql, max(140, ql - 100), int(rng.integers(130, 600)), 2040, 2100]))
+        ref = rng.integers(0, 4, size=max(ql, tl) + 600, dtype=np.uint8)
+        kind = rng.random()
+        if kind < 0.15:  # tandem repeats / low complexity: several paths of about the same score
+            unit = rng.integers(0, 4, size=int(rng.integers(1, 30)), dtype=np.uint8)
+            s0, L = int(rng.integers(0, max(1, min(ql, tl) - 50))), int(rng.integers(20, 400))
+            L = min(L, len(ref) - s0)
+            ref[s0:s0 + L] = np.resize(unit, L)
+        sub, ins, dele = [(0.0, 0.0, 0.0), (0.004, 0.003, 0.003), (0.004, 0.003, 0.003), (0.01, 0.005, 0.005), (0.02, 0.0, 0.0),
+                          (0.03, 0.03, 0.04)][int(rng.integers(0, 6))]
+        q = noisy_copy(ref, ql, sub, ins, dele, rng)
+        if rng.random() < 0.1:  # one long indel, inside or outside the band of 120
+            g, p = int(rng.integers(30, 200)), int(rng.integers(20, max(21, min(ql, tl) - 20)))
+            q = np.concatenate([q[:p], q[p + g:], ref[ql:ql + g]])[:ql] if rng.random() < 0.5 else np.concatenate(
+                [q[:p], rng.integers(0, 4, size=g, dtype=np.uint8), q[p:]])[:ql]
+        if rng.random() < 0.7:
+            q[0] = (q[0] + 1) % 4  # a seed ended here
+        if kind > 0.95:
+            q = rng.integers(0, 4, size=ql, dtype=np.uint8)  # junk
+        if rng.random() < 0.05:
+            q[rng.random(ql) < 0.02] = 4  # N
+        zd = int(rng.choice([200, 200, 200, 100, 30, 5]))
+        fl = KSW_EXTZ if rng.random() < 0.5 else (KSW_EXTZ | KSW_RIGHT | KSW_REV)
+        cases.append((np.ascontiguousarray(q, dtype=np.uint8), np.ascontiguousarray(ref[:tl]), 512, zd, fl))
+    return cases
+
+
+@pytest.mark.parametrize("scoring", SCORINGS)
+def test_long_extensions_on_the_proven_band(gpu_device, scoring, monkeypatch):
+    """ksw_band.h, G = 1: extension jobs of more than 254 query bases one per wavefront on a band of 120 cells, each PROVEN after the
+    fact to be the wide band's result (kswcpp at w = 512, which CUTS the rectangle of these jobs) or handed back to the exact kernels.
+    Every job's max, max_q, max_t and cigar against the oracle's kswcpp (kswcpp_core.h:308-879); with every eligible job tried
+    (MA_KSW_BAND_ALL) and behind the pre-filter; with the band switched off (MA_KSW_BANDL=0) the same answers."""
+    P, op = params_for(scoring)
+    for n, seed, every in ((900, 31, True), (600, 32, False), (3, 33, True)):
+        if every:
+            monkeypatch.setenv("MA_KSW_BAND_ALL", "1")
+        else:
+            monkeypatch.delenv("MA_KSW_BAND_ALL", raising=False)
+        cases = long_extension_cases(n, seed + (0 if scoring is None else 10 * scoring[0]))
+        s0 = band_stats(True)
+        bad = compare_with_oracle(P, op, cases, "long")
+        s1 = band_stats(True) - s0
+        print("long band: %d jobs tried, %d proved, failed checks %s, handed back otherwise %d, %.1f diagonals per job" % (
+            s1[0], s1[1], s1[2:6].tolist(), s1[6], s1[7] / max(s1[0], 1)))
+        assert bad == 0, "%d of %d jobs differ from the oracle" % (bad, len(cases))
+        if n >= 100:
+            assert s1[0] > 0.2 * len(cases) and s1[1] > 0.2 * s1[0], s1
+            if every:
+                assert s1[2] > 0, s1  # (the 10 % reads and the junk must fail check 1)
+    monkeypatch.delenv("MA_KSW_BAND_ALL", raising=False)
+    monkeypatch.setenv("MA_KSW_BANDL", "0")
+    s0 = band_stats(True)
+    assert compare_with_oracle(P, op, long_extension_cases(150, 40), "long (band off)") == 0
+    assert (band_stats(True) - s0)[0] == 0
+    monkeypatch.delenv("MA_KSW_BANDL")
+
+
+def test_smem_seeding_of_long_reads_as_area_tasks(gpu_device, monkeypatch):
+    """Nanopore preset (SMEM seeding, parameter.h:1101-1104) on batches of few long reads: one lane per AREA of procesInterval's
+    recursion (binarySeeding.cpp:41-83) instead of one per read (k_seed_tasks_smem).  The segments -- their
+    ORDER included: a centre's segments in emission order, the centres in pre-order -- are the oracle's and the read-per-lane kernel's
+    (MA_SEED_TASKS=0), with both list entry forms, uiMinAmbiguity 0 and 2, Ns, repeats; a task that outgrows its staging area or its
+    lists sends the batch to the read-per-lane kernel (MA_SEED_TASK_CAPS)."""
+    import ma_amd
+    from ma_testlib import OrIndex, rand_genome, sample_reads
+    g = rand_genome(56, [500000, 300000], repeat_unit=300, repeat_copies=80, repeat_div=0.06)
+    idx = ma_amd.Index.build(g)
+    oidx = OrIndex.from_parts(idx.download())
+    reads = (sample_reads(g, 60, 3000, 3, sub=0.03, ins=0.03, dele=0.04) + sample_reads(g, 30, 12000, 5, sub=0.03, ins=0.03, dele=0.04, n_rate=0.002)
+             + sample_reads(g, 6, 50000, 6, sub=0.01, ins=0.01, dele=0.01) + sample_reads(g, 20, 1000, 7)  # (error-free: long SMEMs)
+             + [np.zeros(700, dtype=np.uint8), np.full(500, 4, dtype=np.uint8), np.resize(np.array([0, 1, 2, 3, 3, 1], dtype=np.uint8), 4000)])
+    nb = sum(len(r) for r in reads)
+
+    def segments(P):
+        bt = ma_amd.Batch(idx, P, len(reads), nb + 64)
+        bt.set_reads(reads)
+        bt.seed()
+        bt.sync()
+        soff, segs = bt.segments()
+        steps = bt.counters()[0]
+        bt.close()
+        return soff, segs, steps
+
+    for min_amb in (0, 2):
+        op = or_params("nanopore", 1)
+        op.min_ambiguity = min_amb
+        res = oidx.align(reads, op, threads=8)
+        P = ma_amd.Params.preset("nanopore")
+        P.min_ambiguity = min_amb
+        for compact in ("1", "0"):
+            monkeypatch.setenv("MA_SMEM_COMPACT", compact)
+            monkeypatch.setenv("MA_SEED_TASKS", "1")
+            soff, segs, steps_t = segments(P)
+            assert np.array_equal(soff, res["seg_off"]), (min_amb, compact)
+            assert segs.tobytes() == res["segs"].tobytes(), (min_amb, compact)
+            monkeypatch.setenv("MA_SEED_TASKS", "0")
+            soff0, segs0, steps_r = segments(P)
+            assert np.array_equal(soff0, soff) and segs0.tobytes() == segs.tobytes()
+            assert steps_t == steps_r, (steps_t, steps_r)  # the same extension steps, shared out differently
+        monkeypatch.delenv("MA_SMEM_COMPACT")
+        # a staging area of 2 segments / lists of 4 entries: some task overflows, the read-per-lane kernel takes over
+        monkeypatch.setenv("MA_SEED_TASKS", "1")
+        monkeypatch.setenv("MA_SEED_TASK_CAPS", "2,4")
+        soff, segs, _ = segments(P)
+        assert np.array_equal(soff, res["seg_off"]) and segs.tobytes() == res["segs"].tobytes()
+        monkeypatch.delenv("MA_SEED_TASK_CAPS")
+    monkeypatch.delenv("MA_SEED_TASKS")
+    idx.close()
