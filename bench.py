@@ -378,10 +378,21 @@ def run_workload(E, name, wl, args):
         bt = batches[i][0]
         t_a = time.perf_counter()
         bt.use_staged_reads()
-        if k_next is not None:
+        # long reads: the next reads (GBs) are staged AFTER this batch's seeding stage, beside its chaining and DP stages: the library
+        # orders large uploads against the seeding kernels in flight on the device (pipeline.hip: io_gate), this batch's own included;
+        # MA_BENCH_STAGE_EARLY=1: at the start of the step, as in round 5
+        late = read_len > 1000 and k_next is not None and os.environ.get("MA_BENCH_STAGE_EARLY") != "1"
+        if k_next is not None and not late:
             stage(i, k_next)
         t_b = time.perf_counter()
-        bt.align()
+        if late:
+            bt.seed()
+            stage(i, k_next)
+            bt.extract()
+            bt.chain()
+            bt.dp()
+        else:
+            bt.align()
         bt.sync()
         t_c = time.perf_counter()
         bt.finish_download()  # of the step before (its arrays are re-used)
@@ -429,6 +440,7 @@ def run_workload(E, name, wl, args):
         ph[:] = 0
     thr0 = cfs_throttle()
     band0 = band_stats(E)
+    bandl0 = band_long_stats(E)
     fam0 = dp_family_stats(E)
     t0 = time.perf_counter()
     if NB == 1:
@@ -518,6 +530,15 @@ def run_workload(E, name, wl, args):
         # result; the others go on to the extension kernels.  (The timed region plus the parity / statistics read-backs behind it.)
         roofline["narrow_band"] = {"jobs_tried": int(bd[0]), "proved": int(bd[1]), "failed_check_1_2_3_4": [int(x) for x in bd[2:6]],
                                    "proved_frac": round(float(bd[1]) / float(bd[0]), 4)}
+
+    bandl1 = band_long_stats(E)
+    if bandl0 is not None and bandl1 is not None and bandl1[0] > bandl0[0]:
+        bd = bandl1 - bandl0
+        # ksw_band.h, G = 1: extension jobs of more than 254 query bases (the end extensions of long reads) one per wavefront on a band
+        # of 120 cells, proved afterwards or handed on to the exact kernels
+        roofline["narrow_band_long"] = {"jobs_tried": int(bd[0]), "proved": int(bd[1]), "failed_check_1_2_3_4": [int(x) for x in bd[2:6]],
+                                        "handed_on_otherwise": int(bd[6]), "proved_frac": round(float(bd[1]) / float(bd[0]), 4),
+                                        "diagonals_per_job": round(float(bd[7]) / float(bd[0]), 1)}
 
     # ---- CPU baseline (rank 0, N = 1): the compiled reference and the oracle on this host's cores, then parity ---------
     cpu = None
@@ -740,6 +761,17 @@ def dp_family_stats(E):
         if E.L.ma_debug_dp_family_stats(out) != 0:
             return None
         return np.array(list(out), dtype=np.float64)
+    except Exception:  # noqa: BLE001
+        return None
+
+
+def band_long_stats(E):
+    """ma_debug_band_long_stats: the long extension jobs, one per wavefront on the band of 120"""
+    try:
+        out = (C.c_ulonglong * 8)()
+        if E.L.ma_debug_band_long_stats(out) != 0:
+            return None
+        return np.array(list(out), dtype=np.int64)
     except Exception:  # noqa: BLE001
         return None
 

@@ -496,8 +496,9 @@ inline KswPlan ksw_plan( const KswSizing& S, u64 nJobs, u64 scratch_budget_bytes
     return P;
 }
 
-// Launches every class that has jobs.  `next` = 24 zeroed counters (one per launch; [11..16]: the six lists of k_ksw_grp, [17], [18]:
-// jobs the narrow band appended to the extension kernels' lists, [19], [20]: the two lists of long jobs on the band of 120),
+// Launches every class that has jobs.  `next` = 28 zeroed counters (one per launch; [11..16]: the six lists of k_ksw_grp, [17], [18]:
+// jobs the narrow band appended to the extension kernels' lists, [19], [20]: the two lists of long jobs on the band of 120, [21..24]:
+// the launches that take the long jobs the band handed back when they have a stream of their own, [25]: the number of those jobs),
 // `nextBig` = 4 more.  `lists`
 // (device, or null) holds the job slots of class k at lists + k * list_stride, SZ.cls[k] entries, and room for the jobs
 // the extension kernel hands back at lists + KSW_N_CLASSES * list_stride (counted in *nRedo); without lists every
@@ -552,6 +553,7 @@ struct KswSide
 {
     hipStream_t stream[ 3 ] = { nullptr, nullptr, nullptr };
     hipEvent_t fork = nullptr, join[ 3 ] = { nullptr, nullptr, nullptr };
+    hipEvent_t band = nullptr; // the long jobs' band kernels are done: their handed-back jobs start on lane 3 (ksw_run_all)
     bool ready( ) const
     {
         return stream[ 0 ] && stream[ 1 ] && stream[ 2 ];
@@ -605,8 +607,18 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
         LG = ksw_plan_launch( (u64)KSW_GRP_ROWS * ( SC.grp < 1000 && SZ.cls[ 7 ] + SZ.cls[ 8 ] ? 256 : 128 ), 0, sets, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
     }
     KswLaunchPlan LBL; // k_ksw_band<.., 1>: KSW_BANDL_ROWS direction rows per wave, 5 waves per SIMD
+    // The few long jobs the band hands back (0.1 % of a 10 kb batch, and the long ones among them: queries AND targets of thousands of
+    // bases) take tens of ms each in k_ksw_pk<5>.  Behind the extension kernels on the batch's stream they were a tail of their own
+    // (10 kb: 38 of 161 ms); with streams they get their own list and start on lane 3 the moment the band kernels are done.
+    const bool ownRedo = nBandL && conc && side->band;
+    KswLaunchPlan LPR;
     if( nBandL )
         LBL = ksw_plan_launch( (u64)KSW_BANDL_ROWS * 128, 0, nBandL, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
+    if( ownRedo )
+    {
+        LPR = ksw_plan_launch( SZ.pRedo ? SZ.pRedo : SZ.p, SZ.cigRedo ? SZ.cigRedo : SZ.cig, std::min<u64>( nBandL / 4 + 64, 256 * 8 ), wantWaves, B / 4 );
+        LPR.lds = ldsOf( std::min<u64>( SZ.qlen, SZ.cigRedo ? SZ.cigRedo : SZ.qlen ) + 48 );
+    }
     for( int k = 0; k < 7; k++ )
     {
         if( k == 4 || ( SZ.cls[ k ] == 0 && !( k >= 5 && nBand ) ) )
@@ -686,6 +698,8 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     for( int i = 0; i < 15; i++ )
         if( LP[ i ].waves )
             needLane[ laneOf( i ) ] = std::max<u64>( needLane[ laneOf( i ) ], LP[ i ].stride * LP[ i ].waves );
+    if( ownRedo )
+        needLane[ 3 ] = std::max<u64>( needLane[ 3 ], LPR.stride * LPR.waves );
     // the per-wave scratch follows the largest jobs of the batch, which vary a lot from batch to batch for long
     // reads: once it is in the GB range take the whole budget so that later batches never re-allocate mid-step
     if( !conc && needLane[ 0 ] > ( 2ull << 30 ) )
@@ -705,7 +719,7 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     }
     if( scratch.reserve( total ) )
         return 1;
-    u32 ldsMax = 0;
+    u32 ldsMax = LPR.lds;
     for( int i = 0; i < 15; i++ )
         if( i != 5 && i != 6 )
             ldsMax = std::max( ldsMax, LP[ i ].lds );
@@ -718,12 +732,15 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     }
     uint8_t* base = scratch.as<uint8_t>( );
     u32* redo = lists ? lists + (u64)KSW_N_CLASSES * list_stride : nullptr;
+    u32* redoL = lists ? lists + (u64)( KSW_N_CLASSES + 1 ) * list_stride : nullptr; // (ownRedo: the long jobs the band of 120 handed back)
     hipStream_t laneStream[ 4 ] = { stream, conc ? side->stream[ 0 ] : stream, conc ? side->stream[ 1 ] : stream,
                                     side && side->stream[ 2 ] ? side->stream[ 2 ] : stream };
     bool laneUsed[ 4 ] = { true, false, false, false };
     for( int i = 0; i < 15; i++ )
         if( LP[ i ].waves && laneStream[ laneOf( i ) ] != stream )
             laneUsed[ laneOf( i ) ] = true;
+    if( ownRedo )
+        laneUsed[ 3 ] = true;
     const bool forked = laneUsed[ 1 ] || laneUsed[ 2 ] || laneUsed[ 3 ];
     if( forked )
     {
@@ -782,12 +799,44 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
             const u32 waves = (u32)std::max<u64>( 1, std::min<u64>( LBL.waves, nk ) );
             uint8_t* sb = base + laneBase[ 0 ];
             if( k == 0 )
-                hipLaunchKernelGGL( ( k_ksw_band<FETCH, true, 1> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 19 + k, sb, LBL.stride, O, redo, 0u,
-                                    (u32*)nullptr, 0u, nRedo );
+                hipLaunchKernelGGL( ( k_ksw_band<FETCH, true, 1> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 19 + k, sb, LBL.stride, O,
+                                    ownRedo ? redoL : redo, 0u, (u32*)nullptr, 0u, ownRedo ? next + 25 : nRedo );
             else
-                hipLaunchKernelGGL( ( k_ksw_band<FETCH, false, 1> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 19 + k, sb, LBL.stride, O, redo, 0u,
-                                    (u32*)nullptr, 0u, nRedo );
+                hipLaunchKernelGGL( ( k_ksw_band<FETCH, false, 1> ), dim3( waves ), dim3( 64 ), 0, stream, F, SC, lk, nk, next + 19 + k, sb, LBL.stride, O,
+                                    ownRedo ? redoL : redo, 0u, (u32*)nullptr, 0u, ownRedo ? next + 25 : nRedo );
         }
+    if( ownRedo )
+    {
+        MA_HIP( hipEventRecord( side->band, stream ) );
+        MA_HIP( hipStreamWaitEvent( laneStream[ 3 ], side->band, 0 ) );
+        for( int k = 3; k >= 0; k-- )
+        {
+            KswJobs JB;
+            JB.list = redoL;
+            JB.n = 0;
+            JB.nDev = next + 25;
+            JB.mode = 2;
+            JB.cls = k;
+            JB.tier = 0;
+            JB.pSplit = 0;
+            JB.qSplit = KSW_Q_SPLIT;
+            uint8_t* sb = base + laneBase[ 3 ];
+            switch( k )
+            {
+            case 0:
+                hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S0> ), dim3( LPR.waves ), dim3( 64 ), LPR.lds, laneStream[ 3 ], F, SC, JB, next + 21 + k, sb, LPR.stride, LPR.p_cap, LPR.lds, O );
+                break;
+            case 1:
+                hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S1> ), dim3( LPR.waves ), dim3( 64 ), LPR.lds, laneStream[ 3 ], F, SC, JB, next + 21 + k, sb, LPR.stride, LPR.p_cap, LPR.lds, O );
+                break;
+            case 2:
+                hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S2> ), dim3( LPR.waves ), dim3( 64 ), LPR.lds, laneStream[ 3 ], F, SC, JB, next + 21 + k, sb, LPR.stride, LPR.p_cap, LPR.lds, O );
+                break;
+            default:
+                hipLaunchKernelGGL( ( k_ksw_pk<FETCH, KSW_S3> ), dim3( LPR.waves ), dim3( 64 ), LPR.lds, laneStream[ 3 ], F, SC, JB, next + 21 + k, sb, LPR.stride, LPR.p_cap, LPR.lds, O );
+            }
+        }
+    }
     if( nGrp ) // the short extensions, several per wavefront (lane 0 of the streams, like the other extension kernels); longest first
         for( int k = 0; k < KSW_GRP_LISTS; k++ )
         {

@@ -68,7 +68,7 @@ int ma_dp_batch( ma_batch* b )
     const u64 nSlots = 2 * nhs;
     b->nJobSlots = nSlots;
     if( b->jobs.reserve( ( nSlots + 2 ) * sizeof( DpJob ) ) || b->info.reserve( nh * sizeof( SetInfo ) ) ||
-        b->ez.reserve( ( nSlots + 2 ) * sizeof( ma_ez ) ) || b->clsLists.reserve( ( ( KSW_N_CLASSES + 1 ) * nSlots + 2 ) * 4 ) || b->cigOff.reserve( ( nSlots + 2 ) * 8 ) ||
+        b->ez.reserve( ( nSlots + 2 ) * sizeof( ma_ez ) ) || b->clsLists.reserve( ( ( KSW_N_CLASSES + 2 ) * nSlots + 2 ) * 4 ) || b->cigOff.reserve( ( nSlots + 2 ) * 8 ) ||
         b->opsCap.reserve( ( nh + 1 ) * 8 ) || b->opsOff.reserve( ( nh + 2 ) * 8 ) ||
         b->hdr.reserve( nh * sizeof( AlnHeader ) ) || b->order.reserve( nh * 4 ) || b->mqOrder.reserve( nh * 4 ) )
         return 1;
@@ -184,6 +184,7 @@ int ma_dp_batch( ma_batch* b )
                 if( longReads && !b->kswSide.ready( ) )
                 {
                     MA_HIP( hipEventCreateWithFlags( &b->kswSide.fork, hipEventDisableTiming ) );
+                    MA_HIP( hipEventCreateWithFlags( &b->kswSide.band, hipEventDisableTiming ) );
                     for( int l = 0; l < 3; l++ )
                     {
                         MA_HIP( hipStreamCreateWithFlags( &b->kswSide.stream[ l ], hipStreamNonBlocking ) );

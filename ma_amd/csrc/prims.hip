@@ -140,7 +140,7 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     {
         for( int k = 0; k < KSW_N_CLASSES; k++ )
             S.cls[ k ] = S.pc[ k ] = S.cigc[ k ] = 0;
-        lists.assign( (size_t)( KSW_N_CLASSES + 1 ) * n, 0u );
+        lists.assign( (size_t)( KSW_N_CLASSES + 2 ) * n, 0u );
         for( uint64_t i = 0; i < n; i++ )
         {
             const i32 ql = jobs[ i ].qlen, tl = jobs[ i ].tlen;
@@ -216,13 +216,13 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
     O.path = nullptr;
     O.cig_words = nullptr;
     O.cig_chunk = 0; // dense pool: cigar_off[n] is the total
-    unsigned int* next = (unsigned int*)( ctr + 4 ); // 24 x u32 launch queues (ctr[4..15])
+    unsigned int* next = (unsigned int*)( ctr + 4 ); // 28 x u32 launch queues (ctr[4..17])
     FETCH F;
     F.jobs = dj.as<ma_ksw_job>( );
     F.qb = dq.as<uint8_t>( );
     F.tb = dt.as<uint8_t>( );
     if( ksw_run_all( F, SC, (u32)n, S, dscr, next, O, 0, FETCH::EARLY ? dlists.as<u32>( ) : nullptr, n,
-                     (unsigned int*)( ctr + 16 ), (unsigned int*)( ctr + 17 ) ) )
+                     (unsigned int*)( ctr + 18 ), (unsigned int*)( ctr + 19 ) ) )
         return 1;
     MA_HIP( hipDeviceSynchronize( ) );
     unsigned long long h[ 8 ];

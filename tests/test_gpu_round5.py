@@ -557,7 +557,7 @@ def test_banded_extensions_are_the_wide_bands_or_handed_back(gpu_device, scoring
             assert s1[0] <= len(cases) and ( n < 100 or s1[0] > 0.5 * len(cases) )  # (a scoring scheme may take some shapes out of the extension kernels' regime)
             assert n < 100 or s1[1] > 0.1 * s1[0], s1  # (the cases are hard on purpose: most of them must FAIL a check)
         else:
-            assert 0.05 * len(cases) < s1[0] < len(cases) and s1[1] > 0.5 * s1[0], s1  # (the filter admits up to 5 mismatches; many of the cases have an indel behind them)
+            assert 0.05 * len(cases) < s1[0] < len(cases) and s1[1] > 0.3 * s1[0], s1  # (the filter admits up to 5 mismatches; many of the cases have an indel behind them; three eighths run under a z-drop of 10 or less, which check 4 refuses)
     monkeypatch.delenv("MA_KSW_GRP")
     monkeypatch.delenv("MA_KSW_BAND_ALL", raising=False)
 
