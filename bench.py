@@ -62,8 +62,10 @@ WORKLOADS = {
     # name: read_len, sub, ins, dele, reads seed, reads/step, default steps, warm-up, CPU sample (reads)
     "150bp": dict(read_len=150, sub=0.005, ins=0.0, dele=0.0, seed=11, reads_per_step=1000000, steps=None, warmup=None,
                   cpu_sample=None, baseline_config="configs[1] (C2)"),
+    # (h2h_inflight 1: one batch object, its next upload and last download beside its own kernels -- 545 k reads/s against 459 k with two
+    # batches in flight, whose seeding kernels crawl beside each other's persistent DP waves: profiles/r06_h2h_inflight.txt)
     "10kb": dict(read_len=10000, sub=0.004, ins=0.003, dele=0.003, seed=12, reads_per_step=200000, steps=5, warmup=1,
-                 cpu_sample=15360, baseline_config="configs[2] (C3)"),
+                 cpu_sample=15360, baseline_config="configs[2] (C3)", h2h_inflight=1),
     "50kb": dict(read_len=50000, sub=0.03, ins=0.03, dele=0.04, seed=13, reads_per_step=20000, steps=4, warmup=1,
                  cpu_sample=2048, baseline_config="configs[4] (C5 shape, one GPU)"),
     # C2's reads under the Illumina preset (SMEM seeding, parameter.h:1083-1087): SURVEY 8(d) asks for this row beside every
@@ -378,9 +380,10 @@ def run_workload(E, name, wl, args):
         bt = batches[i][0]
         t_a = time.perf_counter()
         bt.use_staged_reads()
-        # long reads: the next reads (GBs) are staged AFTER this batch's seeding stage, beside its chaining and DP stages: the library
-        # orders large uploads against the seeding kernels in flight on the device (pipeline.hip: io_gate), this batch's own included;
-        # MA_BENCH_STAGE_EARLY=1: at the start of the step, as in round 5
+        # long reads: the next reads (GBs) are staged AFTER this batch's seeding stage, beside its chaining and DP stages (k_seed_long
+        # lives on random gathers and is the kernel a concurrent 2 GB copy disturbs most); MA_BENCH_STAGE_EARLY=1: at the start of the
+        # step, as in round 5.  (Ordering uploads against the seeding kernels of OTHER batches by events was built and measured in
+        # round 6 -- no gain, profiles/r06_h2h_inflight.txt -- and taken out again.)
         late = read_len > 1000 and k_next is not None and os.environ.get("MA_BENCH_STAGE_EARLY") != "1"
         if k_next is not None and not late:
             stage(i, k_next)
@@ -980,12 +983,17 @@ def run_legs(E, name, wl, args):
     a1.inflight, a1.host_io = 1, 0
     r = run_workload(E, name, wl, a1)
     nfl = args.overlap if wl["read_len"] <= 1000 else min(args.overlap, args.overlap_long)
+    # batches in flight of the host-to-host leg: a workload may ask for its own number (WORKLOADS[..]["h2h_inflight"]: 10 kb reads run
+    # best with ONE batch object whose uploads and downloads run beside its own kernels -- a second batch's seeding crawls beside the
+    # first one's persistent DP waves, profiles/r06_h2h_inflight.txt); --overlap 0 / 1 still means: single-stream leg only
+    nfl_h2h = min(nfl, wl.get("h2h_inflight", nfl)) if nfl > 1 else nfl
     if nfl > 1 and not wl.get("single_only"):
-        wl2 = dict(wl)
-        wl2["steps"] = max(wl["steps"], 2 * nfl)  # every batch object gets at least two timed steps
         for key, hio in (("overlapped", 0), ("host_to_host", 1)):
+            nfl_leg = nfl_h2h if hio else nfl
+            wl2 = dict(wl)
+            wl2["steps"] = max(wl["steps"], 2 * nfl_leg)  # every batch object gets at least two timed steps
             a2 = copy.copy(args)
-            a2.inflight, a2.cpu_sample, a2.host_io = nfl, 0, hio
+            a2.inflight, a2.cpu_sample, a2.host_io = nfl_leg, 0, hio
             try:
                 r2, err = run_workload(E, name, wl2, a2), None
             except RuntimeError as e:  # e.g. not enough HBM for that many long-read batches
@@ -1000,12 +1008,12 @@ def run_legs(E, name, wl, args):
             if r is None:
                 continue
             if r2 is None:
-                r[key] = {"batches_in_flight": nfl, "error": err}
+                r[key] = {"batches_in_flight": nfl_leg, "error": err}
                 continue
             rf2 = dict(r2["roofline"])
             rf2["leg"] = ("%d batches in flight, %s: a kernel's launch time includes the share of the chip the other batches' kernels "
-                          "took meanwhile" % (nfl, r2["io"]))
-            r[key] = {"batches_in_flight": nfl, "io": r2["io"], "value": r2["value"], "unit": r2["unit"], "steps": r2["steps"],
+                          "took meanwhile" % (nfl_leg, r2["io"]))
+            r[key] = {"batches_in_flight": nfl_leg, "io": r2["io"], "value": r2["value"], "unit": r2["unit"], "steps": r2["steps"],
                       "ms_per_step": r2["ms_per_step"], "step_ms_min": r2["step_ms_min"], "step_ms_max": r2["step_ms_max"],
                       "gbases_per_s": r2["gbases_per_s"], "aligned_reads": r2["aligned_reads"],
                       "kernel_ms_per_step_under_overlap": r2["roofline"]["kernel_ms_per_step"], "roofline": rf2,
@@ -1125,11 +1133,14 @@ def compose_line(E, args, results, boundary, anchor):
         v, ms, nb = leg_of(r, "host_to_host")
         if v is not None:
             out["value_%s" % n], out["ms_per_step_%s" % n], out["batches_in_flight_%s" % n] = v, ms, nb
-        v2, ms2, _ = leg_of(r, "overlapped")
+        v2, ms2, nb2 = leg_of(r, "overlapped")
         if v2 is not None:
             out["value_%s_device_resident" % n], out["ms_per_step_%s_device_resident" % n] = v2, ms2
-        if v is not None and v2:
-            out["h2h_over_device_resident_%s" % n] = round(v / v2, 3)
+        # what the host-to-host leg loses to its copies: against the device-resident leg with the SAME batches in flight (one batch at a
+        # time when the workload's host-to-host leg runs one batch object with its I/O beside its own kernels)
+        vd = r.get("value") if nb == 1 and r.get("batches_in_flight", 1) == 1 else (v2 if nb == nb2 else None)
+        if v is not None and vd:
+            out["h2h_over_device_resident_%s" % n] = round(v / vd, 3)
         for key2, tag in (("host_to_host", "h2h"), ("overlapped", "overlapped")):
             xp = (r.get(key2) or {}).get("cross_leg_parity")
             if xp:

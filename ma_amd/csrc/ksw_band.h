@@ -56,7 +56,11 @@
 //     (ksw_bandl_ok: w >= 2 B + 34, the SSE blocks' garbage lanes included), their recurrences are the clean ones, so restricted to
 //     |t - j| <= B the wide matrix IS the band's DP with other inputs at offset +-(B + 1): W >= N cell by cell, and a path that
 //     enters through offset +-(B + 1) is bounded by (L).  Hence W(c) <= max(N(c), UB(r)) on the band and (E) holds as before.
-//   * every alignment has at most min(qlen, tlen) matched pairs: check 1 reads ez.max > a min(qlen, tlen) - G.
+//   * check 1 asks less than "a perfect alignment minus G": a cell outside the band with t - j >= B + 1 has j <= tlen - B - 2, one with
+//     j - t >= B + 1 has t <= qlen - B - 2, so by (U) none of them exceeds a NB - G with
+//     NB = max( min(tlen - B - 1, qlen), min(qlen - B - 1, tlen) ).  For an end extension (qlen >> tlen) that is a tlen - G as
+//     before; for the two extensions into a large gap between two seeds (ksw_dual_ext, needlemanWunsch.cpp:239-260: qlen ~ tlen ~
+//     thousands) it is a (N - B - 1) - G: an alignment of 4 000 bases may lose 387 points instead of 145 and still be proved.
 //   * kswcpp tracks H as int32 when max(qlen, tlen) * 24 leaves int16 (kswcpp.h:101-115): calcMaxScore then has FOUR classes
 //     (t - st0) mod 4 instead of eight (band_exact_max_lds, NC).
 //   * the early stop: a band cell's diagonal chain stays in the band and starts on a diagonal <= B + 1, so from r >= B + 3 on
@@ -74,8 +78,8 @@ namespace ma
 #define KSW_BAND_B 24 // cells on either side of the main diagonal
 #define KSW_BAND_QMAX 254
 #define KSW_BANDL_B 120 // long jobs: one per wavefront, 121 cells per diagonal in a ring of 128 query rows
-#define KSW_BANDL_NMAX 2040 // min(qlen, tlen) of a long job: bounds the diagonals (2 N + B) and keeps H + a * cells-left in 16 bits
-#define KSW_BANDL_ROWS ( 2 * KSW_BANDL_NMAX + KSW_BANDL_B + 24 ) // direction rows (128 B) of a wavefront's scratch
+#define KSW_BANDL_NMAX 7900 // min(qlen, tlen) of a long job: bounds the diagonals (2 N + B) and keeps H + a * cells-left in 16 bits
+#define KSW_BANDL_ROWS( N ) ( 2 * ( N ) + KSW_BANDL_B + 24 ) // direction rows (128 B) of a wavefront's scratch, N = the largest min(qlen, tlen) of the launch
 #define KSW_BAND_LDS ( KSW_GRP_STAGE_ROWS * 128 + KSW_GRP_CIG_WORDS * 4 + 4 * 64 + 4 * 256 + 64 )
 // jobs tried, proved, failed check 1 / 2 / 3 / 4, handed back for another reason (regime, cigar buffer), diagonals (ma_debug_band_stats)
 static __device__ unsigned long long g_band_stats[ 16 ]; // [8..16): the same for the long jobs (one per wavefront)
@@ -102,7 +106,8 @@ MA_HD int ksw_bandl_ok( const KswScoring& SC, i32 qlen, i32 tlen, i32 w, i32 zdr
     // the difference vectors stay inside int8 (ksw_ext_slots)
     const i32 a = SC.q + SC.e, b = SC.q2 + SC.e2, mch = SC.match < 0 ? -SC.match : SC.match;
     const i32 mis = SC.mismatch < 0 ? -SC.mismatch : SC.mismatch;
-    if( SC.q < 0 || SC.e < 1 || SC.q2 < 0 || SC.e2 < 1 || 2 * ( a > b ? a : b ) + mch + mis > 120 || mch < 1 || mch * ( KSW_BANDL_NMAX + 8 ) > 16000 )
+    if( SC.q < 0 || SC.e < 1 || SC.q2 < 0 || SC.e2 < 1 || 2 * ( a > b ? a : b ) + mch + mis > 120 || mch < 1 ||
+        mch * ( ( qlen < tlen ? qlen : tlen ) + 8 ) > 16000 ) // (H and H + a * cells-left are packed 16-bit values)
         return 0;
     return 1;
 }
@@ -319,7 +324,7 @@ __device__ __forceinline__ void band_exact_max( u32 Hs, u32 Jpk, i32 rr, i32 qle
 template <int G, bool LEFT, typename FETCH>
 __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* list, u32 n, u32 at0, uint8_t* P /*KSW_GRP_ROWS x 128 B*/, uint8_t* lds,
                               const KswOut& O, KswWaveAcc& acc, u32* ext1, u32 nExt1, u32* ext2, u32 nExt2, unsigned int* extMore, unsigned long long* sOff,
-                              u32* pf /*the wave's statistics*/ )
+                              u32* pf /*the wave's statistics*/, u32 rowsCap /*direction rows of P (LONG)*/ )
 {
     constexpr int LANES = 64 / G, CJ = 2 * LANES, B = G == 1 ? KSW_BANDL_B : KSW_BAND_B;
     constexpr bool LONG = G == 1;
@@ -451,7 +456,9 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
     // ---- per group, equal in all lanes of the group (0 / -1 words, ksw_grp.h)
     i32 ezmax = 0, maxT = -1, maxQ = -1, pR = 0, pM = 0;
     u32 ezpk = 0, snapH = 0, snapJ = Jpk;
-    i32 act = has && !untouched ? -1 : 0, handBack = 0, pend = 0;
+    // (LONG: the launch's scratch is planned for a full set of waves; a job that needs more direction rows goes on to the exact kernels)
+    const bool tooBig = LONG && has && (u32)KSW_BANDL_ROWS( min( qlen, tlen ) ) > rowsCap;
+    i32 act = has && !untouched && !tooBig ? -1 : 0, handBack = tooBig ? -1 : 0, pend = 0;
     i32 zBad = 0; // check 4 failed
     i32 boundPrev = 0x7fffffff, nextBound = 0;
     const i32 boundRate = max( 1, ( -sc_mis + sc_mch + 1 ) / 2 );
@@ -651,7 +658,7 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             maxT = pT;
             maxQ = pR - pT;
             const i32 ub = ubOf( pR );
-            if( !( ezmax > sc_mch * ( LONG ? min( qlen, tlen ) : qlen ) - gapOut + hOff ) )
+            if( !( ezmax > sc_mch * ( LONG ? max( min( tlen - B - 1, qlen ), min( qlen - B - 1, tlen ) ) : qlen ) - gapOut + hOff ) )
                 why = 1;
             else if( !( minClass != (i32)0x80000000 && minClass > ub && pH > ub ) && pR >= B + 1 )
                 why = 2;
@@ -879,7 +886,7 @@ k_ksw_band( FETCH F, KswScoring SC, const u32* list, u32 n, unsigned int* next, 
                 break;
             end = cur + 4 * G < n ? cur + 4 * G : n;
         }
-        ksw_band_set<G, LEFT>( F, SC, list, n, cur, P, lds, O, acc, ext1, nExt1, ext2, nExt2, extMore, &sOff, stats );
+        ksw_band_set<G, LEFT>( F, SC, list, n, cur, P, lds, O, acc, ext1, nExt1, ext2, nExt2, extMore, &sOff, stats, (u32)( stride / 128 ) );
         cur += G;
     }
     ksw_flush( O, acc, G == 1 ? 7 : 4 );

@@ -440,6 +440,7 @@ struct KswSizing
     u64 pc[ KSW_N_CLASSES ] = { }; // largest direction-byte scratch of a job, per class (0: use p)
     u64 cigc[ KSW_N_CLASSES ] = { }; // largest cigar scratch in words, per class (0: use cig)
     u64 pRedo = 0, cigRedo = 0; // the same for jobs the extension kernel hands back to the exact kernels (0: use p / cig)
+    u64 bandlN = 0; // largest min(qlen, tlen) of the long jobs on the band of 120 (their scratch: KSW_BANDL_ROWS( N ) direction rows per wave)
 };
 inline void ksw_size_job( KswSizing& S, i32 qlen, i32 tlen, i32 w )
 {
@@ -613,7 +614,15 @@ int ksw_run_all( const FETCH& F, const KswScoring& SC, u32 nSlots, const KswSizi
     const bool ownRedo = nBandL && conc && side->band;
     KswLaunchPlan LPR;
     if( nBandL )
-        LBL = ksw_plan_launch( (u64)KSW_BANDL_ROWS * 128, 0, nBandL, std::min<u64>( wantWaves, 256 * 20 ), conc ? B / 4 : B );
+    {
+        // rows for the largest job of the batch, but no more than leave a full set of waves their scratch: the few larger jobs are handed
+        // on by the kernel (a 7 900 x 7 900 job needs 2 MB of direction rows; sized for it, a launch of 10^5 jobs of 2 500 x 1 000 would
+        // run on half its waves)
+        const u64 wavesL = std::min<u64>( std::min<u64>( wantWaves, 256 * 20 ), nBandL );
+        const u64 rowsFull = std::max<u64>( KSW_BANDL_ROWS( 2048 ), ( ( conc ? B / 4 : B ) / std::max<u64>( wavesL, 1 ) ) / 128 );
+        const u64 rows = std::min<u64>( KSW_BANDL_ROWS( SZ.bandlN ? std::min<u64>( SZ.bandlN, KSW_BANDL_NMAX ) : KSW_BANDL_NMAX ), rowsFull );
+        LBL = ksw_plan_launch( rows * 128, 0, nBandL, wavesL, conc ? B / 4 : B );
+    }
     if( ownRedo )
     {
         LPR = ksw_plan_launch( SZ.pRedo ? SZ.pRedo : SZ.p, SZ.cigRedo ? SZ.cigRedo : SZ.cig, std::min<u64>( nBandL / 4 + 64, 256 * 8 ), wantWaves, B / 4 );

@@ -142,6 +142,7 @@ int ma_dp_batch( ma_batch* b )
                 fprintf( stderr, " %llu", (unsigned long long)S.cls[ k ] );
             fprintf( stderr, "\n" );
         }
+        S.bandlN = b->hctr[ CTR_MAX_BANDL ];
         S.pRedo = b->hctr[ CTR_MAX_P_REDO ];
         S.cigRedo = b->hctr[ CTR_MAX_CIG_REDO ];
         // every wave of the ksw launches may leave one partly used 4096-word reservation per class launch

@@ -195,7 +195,7 @@ static int seed_tasks( ma_batch* b )
         }
     }
     MA_HIP( hipGetLastError( ) );
-    if( gate_seed_launched( b, true ) || read_ctr( b ) || gate_seed_launched( b, false ) )
+    if( read_ctr( b ) )
         return 1;
     const u32 err = (u32)b->hctr[ CTR_ERR ];
     const u64 ns = b->hctr[ CTR_SEG_USED ];
@@ -248,8 +248,6 @@ int ma_seed_batch( ma_batch* b )
     }
     if( b->P.seeding_technique == 2 )
         return seed_mems( b );
-    if( gate_before_seed( b ) ) // long reads: after the large uploads in flight on this device (pipeline.hip: io_gate)
-        return 1;
     // few long reads: one lane per AREA of the recursion instead of one per read.  With >= 128 k reads in the batch the
     // read-per-lane kernel already fills the machine and is faster (10 kb x 200 k reads: 157 vs 184 ms; the level-by-level
     // walk pays a tail per level), with 20 k reads of 50 kb the task kernel is 6.5x faster (83 vs 546 ms).
@@ -354,7 +352,7 @@ int ma_seed_batch( ma_batch* b )
         }
         MA_HIP( hipGetLastError( ) );
         // did every read fit its staging area, and all segments the pool?
-        if( gate_seed_launched( b, true ) || read_ctr( b ) || gate_seed_launched( b, false ) )
+        if( read_ctr( b ) )
             return 1;
         if( !( (u32)b->hctr[ CTR_ERR ] & MA_ERR_SEG_OVERFLOW ) )
             break;

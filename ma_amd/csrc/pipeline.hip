@@ -56,6 +56,7 @@ enum : int
     CTR_MAX_CIG_REDO = 87,
     CTR_NEXT_BIG = 88, // 4 x u32 job queues of the second (few waves, large scratch) launch of a class (2 words)
     CTR_N_1X1 = 90, // 1 x 1 gap fills answered by k_dp_enum itself (counted as ksw calls of one cell each)
+    CTR_MAX_BANDL = 91, // largest min(qlen, tlen) of the long jobs on the band of 120 (scratch rows of their launch)
     CTR_COUNT = 92
 };
 
@@ -114,9 +115,6 @@ struct ma_batch
     hipStream_t ioStream = nullptr;
     hipEvent_t evReadsFree = nullptr, evStaged = nullptr, evPacked = nullptr, evDown = nullptr;
     bool stagedPending = false, downPending = false;
-    // the gate between large uploads and the seeding kernels of long-read batches on one device (io_gate below)
-    hipEvent_t evSeedDone = nullptr;
-    bool seedActive = false, uploadActive = false;
     u64 stN = 0, stBases = 0;
     u32 stMaxQ = 0;
     int stage_done = 0; // 0 none, 1 seeded, 2 extracted, 3 chained, 4 dp
@@ -129,75 +127,6 @@ struct ma_batch
     float hostMs[ 8 ] = { 0, 0, 0, 0, 0, 0, 0, 0 }; // wall time of the last stage calls on the host: seed, extract, chain, dp
     unsigned long long hctr[ CTR_COUNT ];
 };
-
-// ---- uploads beside seeding (round 6) ----------------------------------------------------------------
-// k_seed_long lives on random 64-byte gathers over the 12 GB index; while the 2 GB of a long-read batch are copied from host memory
-// the seeding stage of ANOTHER batch on the device takes ~300 instead of 128 ms (the upload walks host pages
-// through the same translation path) -- host to host fell to 0.84 of device resident at 10 kb.  So the two are ordered on the device,
-// by events, without a host thread waiting: a large staged upload (ma_batch_stage_reads) starts after the seeding kernels that are
-// in flight on the device, and the seeding stage of a long-read batch starts after the staged uploads that are in flight (its own
-// included: a caller that wants both to overlap with something stages the next reads AFTER ma_seed_batch, beside the DP stage).
-// MA_IO_GATE=0: off (A/B hook).
-#define MA_GATE_MIN_BYTES ( 256ull << 20 )
-struct IoGate
-{
-    std::mutex mx;
-    std::vector<ma_batch*> live;
-};
-static IoGate& io_gate( int device )
-{
-    static IoGate gates[ 64 ];
-    return gates[ device & 63 ];
-}
-static bool io_gate_on( )
-{
-    const char* e = getenv( "MA_IO_GATE" );
-    return !e || atoi( e ) != 0;
-}
-// a large upload is about to be enqueued on b->ioStream
-static int gate_before_upload( ma_batch* b )
-{
-    if( !io_gate_on( ) )
-        return 0;
-    IoGate& G = io_gate( b->device );
-    std::lock_guard<std::mutex> xGuard( G.mx );
-    for( ma_batch* o : G.live )
-        if( o != b && o->seedActive && o->evSeedDone )
-            MA_HIP( hipStreamWaitEvent( b->ioStream, o->evSeedDone, 0 ) );
-    return 0;
-}
-static void gate_set_upload( ma_batch* b, bool on )
-{
-    IoGate& G = io_gate( b->device );
-    std::lock_guard<std::mutex> xGuard( G.mx );
-    b->uploadActive = on;
-}
-// the seeding kernels of a long-read batch are about to be enqueued on b->stream
-static int gate_before_seed( ma_batch* b )
-{
-    if( !io_gate_on( ) || b->n_bases < MA_GATE_MIN_BYTES || b->max_qlen <= 240 )
-        return 0;
-    IoGate& G = io_gate( b->device );
-    std::lock_guard<std::mutex> xGuard( G.mx );
-    for( ma_batch* o : G.live )
-        if( o->uploadActive && o->evStaged )
-            MA_HIP( hipStreamWaitEvent( b->stream, o->evStaged, 0 ) );
-    return 0;
-}
-// ... have been enqueued (on = true) / are done (false)
-static int gate_seed_launched( ma_batch* b, bool on )
-{
-    if( !io_gate_on( ) || b->n_bases < MA_GATE_MIN_BYTES || b->max_qlen <= 240 )
-        return 0;
-    if( on && !b->evSeedDone )
-        MA_HIP( hipEventCreateWithFlags( &b->evSeedDone, hipEventDisableTiming ) );
-    if( on )
-        MA_HIP( hipEventRecord( b->evSeedDone, b->stream ) );
-    IoGate& G = io_gate( b->device );
-    std::lock_guard<std::mutex> xGuard( G.mx );
-    b->seedActive = on;
-    return 0;
-}
 
 // Waits for the batch's stream.  Default: hipStreamSynchronize (the runtime spins: lowest latency, one host core busy).
 // With blocking waits (ma_batch_set_blocking_sync) the host thread sleeps on an interrupt-driven event instead: the mode for
@@ -292,11 +221,6 @@ int ma_batch_create( const ma_index* idx, const ma_params* P, uint64_t max_reads
     b->max_bases = max_bases;
     if( b->ctr.reserve( CTR_COUNT * 8 ) || b->reads.reserve( max_bases + 64 ) || b->roff.reserve( ( max_reads + 1 ) * 8 ) )
         return 1;
-    {
-        IoGate& G = io_gate( b->device );
-        std::lock_guard<std::mutex> xGuard( G.mx );
-        G.live.push_back( b.get( ) );
-    }
     *out = b.release( );
     return 0;
 }
@@ -306,13 +230,6 @@ int ma_batch_destroy( ma_batch* b )
     if( !b )
         return 0;
     MA_BIND_DEVICE( b->device );
-    {
-        IoGate& G = io_gate( b->device );
-        std::lock_guard<std::mutex> xGuard( G.mx );
-        G.live.erase( std::remove( G.live.begin( ), G.live.end( ), b ), G.live.end( ) );
-    }
-    if( b->evSeedDone )
-        (void)hipEventDestroy( b->evSeedDone );
     if( b->evInit )
         for( int i = 0; i < 16; i++ )
             (void)hipEventDestroy( b->ev[ i ] );
@@ -407,15 +324,10 @@ int ma_batch_stage_reads( ma_batch* b, const uint8_t* codes, const uint64_t* off
     // up to the last swap may still read it
     if( b->evReadsFree )
         MA_HIP( hipStreamWaitEvent( b->ioStream, b->evReadsFree, 0 ) );
-    const bool gated = b->stBases >= MA_GATE_MIN_BYTES;
-    if( gated && gate_before_upload( b ) )
-        return 1;
     if( b->stBases )
         MA_HIP( hipMemcpyAsync( b->reads2.p, codes, b->stBases, hipMemcpyHostToDevice, b->ioStream ) );
     MA_HIP( hipMemcpyAsync( b->roff2.p, offsets, ( n + 1 ) * 8, hipMemcpyHostToDevice, b->ioStream ) );
     MA_HIP( hipEventRecord( b->evStaged, b->ioStream ) );
-    if( gated )
-        gate_set_upload( b, true );
     b->stagedPending = true;
     return 0;
 }
@@ -428,8 +340,6 @@ int ma_batch_use_staged_reads( ma_batch* b )
         return fail( "ma_batch_use_staged_reads: no reads staged (ma_batch_stage_reads)" );
     MA_BIND_DEVICE( b->device );
     MA_HIP( hipEventSynchronize( b->evStaged ) );
-    if( b->uploadActive )
-        gate_set_upload( b, false );
     MA_HIP( hipEventRecord( b->evReadsFree, b->stream ) ); // what runs on the stream now is the last reader of the old buffer
     std::swap( b->reads, b->reads2 );
     std::swap( b->roff, b->roff2 );

@@ -176,6 +176,8 @@ static int ksw_batch_impl( const ma_params* P, const ma_ksw_job* jobs, uint64_t 
             const u64 pk = ksw_p_bytes( ql, tl, jobs[ i ].w ), cg = (u64)ql + tl + 2;
             S.pc[ c ] = std::max( S.pc[ c ], c >= KSW_CLS_GRP0 ? 0 : ( c >= 5 ? ksw_ext_p_bytes( ql, tl, c - 4 ) : pk ) );
             S.cigc[ c ] = std::max( S.cigc[ c ], cg );
+            if( c == KSW_CLS_BANDL || c == KSW_CLS_BANDL + 1 )
+                S.bandlN = std::max<u64>( S.bandlN, (u64)std::min( ql, tl ) );
             if( c >= 5 )
             {
                 S.pRedo = std::max( S.pRedo, pk );

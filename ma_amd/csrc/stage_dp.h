@@ -137,7 +137,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
         dp_enum_one( A, s, sink );
     // per-class scratch sizes: only the classes whose launches are sized by their jobs (the query-stationary classes from
     // KSW_CLS_GRP0 on have a fixed scratch per wave)
-    u32 pcl[ KSW_CLS_GRP0 ], cgl[ KSW_CLS_GRP0 ], pRedo = 0, cgRedo = 0;
+    u32 pcl[ KSW_CLS_GRP0 ], cgl[ KSW_CLS_GRP0 ], pRedo = 0, cgRedo = 0, bandlN = 0;
     // Append the jobs to the per-class lists with ONE round trip to the list counters per wave: a first pass over the lanes'
     // jobs counts the wave's jobs per class (lane c holds class c's count), lane c reserves class c's list space, a second
     // pass writes the entries.  (A reservation per class and round -- each waiting for its atomic's return -- made the kernel
@@ -205,6 +205,11 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                 {
                     pRedo = max( pRedo, pk8 );
                     cgRedo = max( cgRedo, cj );
+                }
+                if( cls == KSW_CLS_BANDL || cls == KSW_CLS_BANDL + 1 )
+                {
+                    const DpJob& jj = A.jobs[ sink.slot0 + k ];
+                    bandlN = max( bandlN, min( jj.q_to - jj.q_from, jj.r_to - jj.r_from ) );
                 }
                 if( A.SC.grp >= 1000 && ( cls == KSW_CLS_GRP0 || cls == KSW_CLS_GRP0 + 1 ) )
                 {
@@ -290,7 +295,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
         pcW[ c ] = wave_max_u64( pcl[ c ] );
         cgW[ c ] = wave_max_u64( cgl[ c ] );
     }
-    const u64 pRedoW = wave_max_u64( pRedo ), cgRedoW = wave_max_u64( cgRedo );
+    const u64 pRedoW = wave_max_u64( pRedo ), cgRedoW = wave_max_u64( cgRedo ), bandlW = wave_max_u64( bandlN );
     if( ( threadIdx.x & 63 ) == 0 && nj )
     {
         atomicMax( &A.ctr[ CTR_MAX_STATE ], (unsigned long long)st );
@@ -306,6 +311,8 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
             if( cgW[ c ] )
                 atomicMax( &A.ctr[ CTR_MAX_CIGC0 + c ], (unsigned long long)cgW[ c ] );
         }
+        if( bandlW )
+            atomicMax( &A.ctr[ CTR_MAX_BANDL ], (unsigned long long)bandlW );
         if( pRedoW )
         {
             atomicMax( &A.ctr[ CTR_MAX_P_REDO ], (unsigned long long)pRedoW << 8 );

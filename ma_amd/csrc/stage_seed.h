@@ -543,8 +543,10 @@ __global__ void __launch_bounds__( 256 ) k_seed_tasks( TaskKernelArgs A )
 {
     seed_tasks_body<false>( A );
 }
+// 3 waves per SIMD: at 4 (128 VGPRs) the kernel spills 51 VGPRs inside the step loop -- 50 kb x 10 k reads: 439-469 ms against 368 ms
+// with 168 VGPRs and no spill (profiles/r06_smem_tasks_tuning.txt)
 #if !defined( MA_TASKS_SMEM_WAVES )
-#define MA_TASKS_SMEM_WAVES 4
+#define MA_TASKS_SMEM_WAVES 3
 #endif
 __global__ void __launch_bounds__( 256 ) __attribute__( ( amdgpu_waves_per_eu( MA_TASKS_SMEM_WAVES ) ) ) k_seed_tasks_smem( TaskKernelArgs A )
 {

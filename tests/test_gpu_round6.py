@@ -177,15 +177,15 @@ def test_adversarial_jobs_against_the_band_proof(gpu_device, scoring, monkeypatc
 
 
 def long_extension_cases(n, seed):
-    """Extension jobs of 255 .. 3000 query bases as the pipeline emits them for long reads (band 512, z-drop 200): the rest of a read
+    """Extension jobs of 255 .. 8200 query bases as the pipeline emits them for long reads (band 512, z-drop 200): the rest of a read
     against the reference behind its last seed padded by 1000 bases (10 kb reads at ~1 % errors: the band of 120 proves them), the
-    two-sided extensions into a large gap (target about as long as the query), noisy reads at 10 % (must fail check 1 and go on),
-    repeats, junk, Ns, a first-base mismatch, short targets."""
+    two-sided extensions into a large gap (target about as long as the query, thousands of bases: check 1 in its near-square form),
+    noisy reads at 10 % (must fail check 1 and go on), repeats, junk, Ns, a first-base mismatch, short targets, jobs beyond 7 900."""
     rng = np.random.default_rng(seed)
     cases = []
     for k in range(n):
-        ql = int(rng.choice([int(rng.integers(255, 400)), int(rng.integers(400, 1200)), int(rng.integers(1200, 3000))]))
-        tl = int(rng.choice([1000, 1000, 1000, ql + 1000, ql + 50, ql, max(140, ql - 100), int(rng.integers(130, 600)), 2040, 2100]))
+        ql = int(rng.choice([int(rng.integers(255, 400)), int(rng.integers(400, 1200)), int(rng.integers(1200, 3000)), int(rng.integers(3000, 8200))]))
+        tl = int(rng.choice([1000, 1000, 1000, ql + 1000, ql + 50, ql, ql, max(140, ql - 100), int(rng.integers(130, 600)), 2040, 2100]))
         ref = rng.integers(0, 4, size=max(ql, tl) + 600, dtype=np.uint8)
         kind = rng.random()
         if kind < 0.15:  # tandem repeats / low complexity: several paths of about the same score
@@ -219,7 +219,7 @@ def test_long_extensions_on_the_proven_band(gpu_device, scoring, monkeypatch):
     Every job's max, max_q, max_t and cigar against the oracle's kswcpp (kswcpp_core.h:308-879); with every eligible job tried
     (MA_KSW_BAND_ALL) and behind the pre-filter; with the band switched off (MA_KSW_BANDL=0) the same answers."""
     P, op = params_for(scoring)
-    for n, seed, every in ((900, 31, True), (600, 32, False), (3, 33, True)):
+    for n, seed, every in ((700, 31, True), (500, 32, False), (3, 33, True)):
         if every:
             monkeypatch.setenv("MA_KSW_BAND_ALL", "1")
         else:
@@ -235,6 +235,14 @@ def test_long_extensions_on_the_proven_band(gpu_device, scoring, monkeypatch):
             assert s1[0] > 0.2 * len(cases) and s1[1] > 0.2 * s1[0], s1
             if every:
                 assert s1[2] > 0, s1  # (the 10 % reads and the junk must fail check 1)
+    # a scratch budget that leaves the launch rows for jobs of ~2 000 bases: the larger ones are handed on by the kernel
+    monkeypatch.setenv("MA_KSW_BAND_ALL", "1")
+    monkeypatch.setenv("MA_KSW_SCRATCH_MB", "64")
+    s0 = band_stats(True)
+    assert compare_with_oracle(P, op, long_extension_cases(300, 41), "long (small scratch)") == 0
+    s1 = band_stats(True) - s0
+    assert s1[0] > 0 and s1[6] > 0, s1  # (handed back for another reason than a failed check)
+    monkeypatch.delenv("MA_KSW_SCRATCH_MB")
     monkeypatch.delenv("MA_KSW_BAND_ALL", raising=False)
     monkeypatch.setenv("MA_KSW_BANDL", "0")
     s0 = band_stats(True)

@@ -48,3 +48,16 @@ for kind, m in (("global", ~ext), ("extension", ext), ("extension, left-aligned 
         cells = np.where(ext[s], q[s] * np.minimum(t[s], q[s] + 16), q[s] * t[s])
         print("  qlen %4d..%-10d %9d jobs  mean q %6.1f t %7.1f w %6.1f  diagonals %12d  cells %14d" % (
             lo + 1, hi, int(s.sum()), q[s].mean(), t[s].mean(), w[s].mean(), int(cut.sum()), int(cells.sum())))
+
+# the long extension jobs (queries beyond 254 bases) by shape: which of them is an end extension (target = the padding) and which a
+# two-sided extension into a gap (target about as long as the query) -- what the band of 120 (ksw_band.h, G = 1) is planned for
+lg = ext & (q > 254)
+if lg.any():
+    mn = np.minimum(q[lg], t[lg])
+    print("long extension jobs: %d; min(qlen, tlen) quantiles 50 / 90 / 99 / 100 %%: %s" % (int(lg.sum()), np.percentile(mn, [50, 90, 99, 100]).astype(int).tolist()))
+    for lo, hi in ((0, 1100), (1100, 2048), (2048, 4096), (4096, 7900), (7900, 1 << 30)):
+        s2 = (mn > lo) & (mn <= hi)
+        if s2.any():
+            ql, tl = q[lg][s2], t[lg][s2]
+            print("  min(qlen, tlen) %5d..%-10d %8d jobs  mean q %7.1f t %7.1f  |q - t| < 120: %5.1f %%  diagonals (2 min + 120) %12d" % (
+                lo + 1, hi, int(s2.sum()), ql.mean(), tl.mean(), 100.0 * float((np.abs(ql - tl) < 120).mean()), int((2 * mn[s2] + 120).sum())))
