@@ -98,6 +98,9 @@ int ma_dp_batch( ma_batch* b )
         D.SC.grp = 1;
     D.ez = b->ez.as<ma_ez>( );
     D.cig_off = b->cigOff.as<u64>( );
+    if( b->sortKey2.reserve( nSlots + 64 ) ) // (free until the job lists are sorted)
+        return 1;
+    D.cls_cache = b->sortKey2.as<uint8_t>( );
     {
         // 1 x 1 gap fills are answered by the enumeration when the worst score cannot lose to a gap (stage_dp.h); MA_DP_1X1=0: A/B hook
         int8_t q = (int8_t)b->P.gap, e = (int8_t)b->P.extend, q2 = (int8_t)b->P.gap2, e2 = (int8_t)b->P.extend2;
@@ -180,6 +183,31 @@ int ma_dp_batch( ma_batch* b )
             {
                 EvTimer t( b, 4 );
                 hipStream_t dpStream = b->stream;
+#if defined( MA_EXP_DP_PRIO )
+                // Experiment (round 6): with several batches in flight the persistent DP waves of one batch keep another batch's seeding
+                // kernel out of the SIMDs.  On a stream of the lowest priority the dispatcher should prefer the other batches' kernels
+                // whenever a DP launch ends and wave slots come free.
+                if( !b->dpLow )
+                {
+                    int lo = 0, hi = 0;
+                    MA_HIP( hipDeviceGetStreamPriorityRange( &lo, &hi ) );
+                    MA_HIP( hipStreamCreateWithPriority( &b->dpLow, hipStreamNonBlocking, lo ) );
+                    MA_HIP( hipEventCreateWithFlags( &b->dpFork, hipEventDisableTiming ) );
+                    MA_HIP( hipEventCreateWithFlags( &b->dpJoin, hipEventDisableTiming ) );
+                }
+                dpStream = b->dpLow;
+                MA_HIP( hipEventRecord( b->dpFork, b->stream ) );
+                MA_HIP( hipStreamWaitEvent( dpStream, b->dpFork, 0 ) );
+                struct Rejoin
+                {
+                    ma_batch* b;
+                    ~Rejoin( )
+                    {
+                        (void)hipEventRecord( b->dpJoin, b->dpLow );
+                        (void)hipStreamWaitEvent( b->stream, b->dpJoin, 0 );
+                    }
+                } xRejoin{ b };
+#endif
                 // long reads: every kernel class on its own stream (ksw_launch.h), longest jobs first
                 const bool longReads = b->max_qlen > 254 && !dp_one_stream( );
                 if( longReads && !b->kswSide.ready( ) )

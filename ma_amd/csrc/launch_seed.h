@@ -104,14 +104,7 @@ static int seed_tasks( ma_batch* b )
     // SMEM tasks: what ONE centre needs, not what a read needs -- a centre's forward run pushes an entry per change of the interval's
     // size (a few dozen before the match ends; a read-per-lane list is sized for the read's length) and emits a handful of segments;
     // MA_SEED_TASK_CAPS="<segments>,<list entries>": test hook that forces the fallback
-    // areas of up to `leaf` bases are walked by one lane (stage_seed.h); MA_SEED_TASK_LEAF: tuning / A-B hook (0: every centre a task)
-    // Measured (profiles/r06_seed_task_leaf.txt): slower for every size tried -- 50 kb x 10 k reads, SMEMs: 465 ms without, 453 / 470 /
-    // 1 207 ms with subtrees of 64 / 256 / 1 024 bases; 50 kb x 20 k reads, maxSpan: 80 ms without, 89 ms at 512 -- a lane that walks a
-    // subtree is a long chain of dependent memory round trips again, which is what the tasks were introduced against.  Default: off.
-    u32 leaf = 0;
-    if( const char* e = getenv( "MA_SEED_TASK_LEAF" ) )
-        leaf = (u32)std::max( 0, atoi( e ) );
-    u32 segCapT = smem ? ( leaf ? 320 : 96 ) : 128, smemCapT = 384;
+    u32 segCapT = 96, smemCapT = 384;
     if( const char* e = getenv( "MA_SEED_TASK_CAPS" ) )
     {
         int a = 0, c = 0;
@@ -124,9 +117,8 @@ static int seed_tasks( ma_batch* b )
     if( const char* e = getenv( "MA_SEED_TASK_BLOCKS" ) ) // tuning hook
         blocksT = (unsigned)std::max( 64, std::min( 4096, atoi( e ) ) );
     const u64 lanesT = (u64)blocksT * 256;
-    if( ( ( smem || leaf ) && b->taskStage.reserve( lanesT * segCapT * sizeof( ma_segment ) ) ) ||
-        ( smem && ( b->smemA.reserve( lanesT * smemCapT * smemEntry ) || b->smemB.reserve( lanesT * smemCapT * smemEntry ) ) ) ||
-        ( leaf && b->seedStack.reserve( lanesT * 2 * MA_SEED_STACK * 4 ) ) )
+    if( smem && ( b->taskStage.reserve( lanesT * segCapT * sizeof( ma_segment ) ) || b->smemA.reserve( lanesT * smemCapT * smemEntry ) ||
+                  b->smemB.reserve( lanesT * smemCapT * smemEntry ) ) )
         return 1;
     if( b->segOff.reserve( ( n + 1 ) * 8 ) || b->segCnt.reserve( ( n + 1 ) * 4 ) || b->taskA.reserve( taskCap * sizeof( SeedTask ) ) ||
         b->taskB.reserve( taskCap * sizeof( SeedTask ) ) || b->taskCnt.reserve( 64 * 8 ) ||
@@ -150,10 +142,8 @@ static int seed_tasks( ma_batch* b )
     A.pool_key = b->taskKey.as<u64>( );
     A.pool_cap = b->segPoolCap;
     A.ctr = b->ctr.as<unsigned long long>( );
-    A.stage = smem || leaf ? b->taskStage.as<ma_segment>( ) : nullptr;
+    A.stage = smem ? b->taskStage.as<ma_segment>( ) : nullptr;
     A.seg_cap = segCapT;
-    A.leaf = leaf;
-    A.stack = leaf ? b->seedStack.as<u32>( ) : nullptr;
     A.smem_a = smem ? b->smemA.as<ma_segment>( ) : nullptr;
     A.smem_b = smem ? b->smemB.as<ma_segment>( ) : nullptr;
     A.smem_cap = smemCapT;
@@ -172,16 +162,7 @@ static int seed_tasks( ma_batch* b )
         EvTimer t( b, 0 );
         hipLaunchKernelGGL( k_task_roots, dim3( (unsigned)( ( n + 255 ) / 256 ) ), dim3( 256 ), 0, b->stream, b->d_roff, (u32)n,
                             b->taskA.as<SeedTask>( ), cnt );
-        // an area halves from level to level and areas of up to `leaf` bases are not split: the levels beyond that are empty
-        int levelsRun = levels;
-        if( leaf > 1 )
-        {
-            levelsRun = 3;
-            for( u64 q = b->max_qlen; q > leaf; q >>= 1 )
-                levelsRun++;
-            levelsRun = std::min( levelsRun, levels );
-        }
-        for( int lv = 0; lv < levelsRun; lv++ )
+        for( int lv = 0; lv < levels; lv++ )
         {
             A.in = ( lv & 1 ) ? b->taskB.as<SeedTask>( ) : b->taskA.as<SeedTask>( );
             A.out = ( lv & 1 ) ? b->taskA.as<SeedTask>( ) : b->taskB.as<SeedTask>( );

@@ -109,6 +109,10 @@ struct ma_batch
     DevBuf sortKey, sortKey2, sortVal2; // longest-job-first order of the DP job lists
     u64 cigPoolCap = 0, cigPoolMin = 0, nOpsCap = 0, nJobSlots = 0;
     KswSide kswSide; // created on first use
+#if defined( MA_EXP_DP_PRIO ) // experiment build: the DP kernels of a batch on a stream of the lowest priority (launch_dp.h)
+    hipStream_t dpLow = nullptr;
+    hipEvent_t dpFork = nullptr, dpJoin = nullptr;
+#endif
     // double-buffered I/O (ma_batch_stage_reads / ma_batch_start_mapq_download): the next reads are uploaded into reads2 / roff2
     // and the packed results of the last step downloaded on ioStream while the batch's own stream runs kernels
     DevBuf reads2, roff2;

@@ -265,18 +265,6 @@ MA_HD void seed_begin_area( SeedLane& L, const uint8_t* q, u32 qlen, u32 aS, u32
     L.phase = aN == 0 ? PH_DONE : PH_NEW_CENTER;
 }
 
-// leaf mode (round 6): the lane walks the WHOLE recursion below [aS, aS + aN) of the read itself -- the classic walk with its stack,
-// started inside the read -- and emits the subtree's segments in the recursion's order
-MA_HD void seed_begin_subtree( SeedLane& L, const uint8_t* q, u32 qlen, u32 aS, u32 aN )
-{
-    seed_begin_read( L, q, qlen );
-    L.aS = aS;
-    L.aN = aN;
-    L.childN[ 0 ] = L.childN[ 1 ] = 0;
-    L.childS[ 0 ] = L.childS[ 1 ] = 0;
-    L.phase = aN == 0 ? PH_DONE : PH_NEW_CENTER;
-}
-
 // After an extension around `center` covered [cS, cS+cN] (reference convention), split the area
 // (binarySeeding.cpp:58-82): recurse left first, continue right afterwards.
 MA_HD void seed_after_center( SeedLane& L, const SeedScratch& S, u32 cS, u32 cN )

@@ -77,6 +77,9 @@ struct DpKernelArgs
     u32 one_by_one;
     ma_ez* ez;
     u64* cig_off;
+    // class of every job slot as the first pass over a wave's jobs decided it (the pre-filters of the band kernels walk the job's first
+    // bases: once, not once per pass -- 50 kb: k_dp_enum 26 -> RESULT_ENUM_50KB ms)
+    uint8_t* cls_cache;
 };
 
 #if defined( __HIPCC__ )
@@ -152,14 +155,14 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
 #pragma unroll
         for( int c = 0; c < KSW_CLS_GRP0; c++ )
             pcl[ c ] = cgl[ c ] = 0;
-        auto classOf = [ & ]( u32 k, u32& pj, u32& cj, u32& pk8 ) -> int {
+        auto classOf = [ & ]( u32 k, u32& pj, u32& cj, u32& pk8, bool second ) -> int {
             const DpJob& j = A.jobs[ sink.slot0 + k ];
             const i32 ql = (i32)( j.q_to - j.q_from ), tl = (i32)( j.r_to - j.r_from );
             pj = cj = pk8 = 0;
             if( A.one_by_one && ql == 1 && tl == 1 && j.flag == 0 && j.zdrop < 0 )
                 return -2; // answered here (first pass)
-            int cls = ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
-            if( A.SC.grp >= 1000 && ( cls == KSW_CLS_GRP0 || cls == KSW_CLS_GRP0 + 1 ) )
+            int cls = second ? (int)A.cls_cache[ sink.slot0 + k ] : ksw_job_class_pipe( A.SC, ql, tl, j.w, j.zdrop, j.flag );
+            if( !second && A.SC.grp >= 1000 && ( cls == KSW_CLS_GRP0 || cls == KSW_CLS_GRP0 + 1 ) )
             {
                 // the proven narrow band (ksw_band.h) is tried on the jobs whose query follows the target's main diagonal
                 const uint8_t* qb = A.reads + j.read_off;
@@ -172,7 +175,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                     cls = ksw_job_class_pipe( S1, ql, tl, j.w, j.zdrop, j.flag );
                 }
             }
-            if( cls == KSW_CLS_BANDL || cls == KSW_CLS_BANDL + 1 )
+            if( !second && ( cls == KSW_CLS_BANDL || cls == KSW_CLS_BANDL + 1 ) )
             {
                 // the band of 120 is tried on the long extensions whose first bases follow the target with few edits (ksw_bandl_likely)
                 const uint8_t* qb = A.reads + j.read_off;
@@ -185,6 +188,8 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
                     cls = ksw_job_class_pipe( S1, ql, tl, j.w, j.zdrop, j.flag );
                 }
             }
+            if( !second )
+                A.cls_cache[ sink.slot0 + k ] = (uint8_t)cls;
             const u64 pk = ksw_p_bytes( ql, tl, j.w );
             // 256-byte units (the query-stationary classes from KSW_CLS_GRP0 on have a fixed scratch per wave: ksw_grp.h)
             pj = cls >= KSW_CLS_GRP0 ? 0u : (u32)( ( ( cls >= 5 ? ksw_ext_p_bytes( ql, tl, cls - 4 ) : pk ) + 255 ) >> 8 );
@@ -200,7 +205,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
             u32 pj = 0, cj = 0, pk8 = 0;
             if( k < mine )
             {
-                cls = classOf( k, pj, cj, pk8 );
+                cls = classOf( k, pj, cj, pk8, false );
                 if( cls >= 5 )
                 {
                     pRedo = max( pRedo, pk8 );
@@ -268,7 +273,7 @@ __global__ void __launch_bounds__( 64 ) k_dp_enum( DpKernelArgs A )
             int cls = -1;
             u32 pj, cj, pk8;
             if( k < mine )
-                cls = classOf( k, pj, cj, pk8 );
+                cls = classOf( k, pj, cj, pk8, true );
             unsigned long long todo = __ballot( cls >= 0 );
             while( todo )
             {

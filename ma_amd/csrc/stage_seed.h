@@ -353,14 +353,8 @@ struct TaskKernelArgs
     u64 pool_cap;
     unsigned long long* ctr;
     u32 slow_batch;
-    // An area of up to `leaf` bases is not split any further: the lane that takes it walks the whole subtree below it (the classic
-    // walk with its stack: `stack`, 2 * MA_SEED_STACK words per lane) and the subtree's segments leave under the area's key, in the
-    // recursion's order.  The last levels of the tree hold most of its nodes and their areas are a few dozen bases long: as tasks
-    // of their own they cost a task record, two offsets, a key and a share of four atomics for ~15 (maxSpan) / ~50 (SMEMs) extension
-    // steps each, and every level a launch with its tail (50 kb x 10 k reads, SMEMs: the last three of 12 levels were 368 of 465 ms).
-    u32 leaf;
-    u32* stack;
-    // per-lane staging of a task's segments (SMEMs, and maxSpan with leaf > 0) and the two pending lists of SMEM tasks (seeding.h)
+    // SMEM tasks: per-lane staging of a centre's segments and the two pending lists (seeding.h).  (Round 6 also built and measured
+    // "areas of up to L bases walked as whole subtrees by one lane" -- slower for every L, DESIGN.md section 3.1, commit 6600a6f.)
     ma_segment* stage;
     u32 seg_cap;
     ma_segment* smem_a;
@@ -396,23 +390,17 @@ template <bool SM> __device__ __forceinline__ void seed_tasks_body( const TaskKe
     S.seg_cap = 2;
     S.smem_a = S.smem_b = nullptr;
     S.smem_cap = 0;
-    const bool staged = SM || A.leaf != 0; // (wave-uniform)
+    if( SM )
     {
         const u64 lane = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-        if( staged )
-        {
-            S.stage = A.stage + lane * A.seg_cap;
-            S.seg_cap = A.seg_cap;
-        }
-        if( SM )
-        {
-            const u64 smemWords = (u64)A.smem_cap * ( A.P.smem_compact ? 2u : 5u );
-            S.smem_a = (ma_segment*)( (u64*)A.smem_a + lane * smemWords );
-            S.smem_b = (ma_segment*)( (u64*)A.smem_b + lane * smemWords );
-            S.smem_cap = A.smem_cap;
-        }
-        S.stack = A.leaf ? A.stack + lane * ( 2 * MA_SEED_STACK ) : nullptr;
+        const u64 smemWords = (u64)A.smem_cap * ( A.P.smem_compact ? 2u : 5u );
+        S.stage = A.stage + lane * A.seg_cap;
+        S.seg_cap = A.seg_cap;
+        S.smem_a = (ma_segment*)( (u64*)A.smem_a + lane * smemWords );
+        S.smem_b = (ma_segment*)( (u64*)A.smem_b + lane * smemWords );
+        S.smem_cap = A.smem_cap;
     }
+    S.stack = nullptr;
     S.drop_div = 0;
     SeedTask T;
     T.read = 0xffffffffu;
@@ -427,7 +415,7 @@ template <bool SM> __device__ __forceinline__ void seed_tasks_body( const TaskKe
         {
             // ---- finished tasks: segments to the pool, child areas to the next level (one atomic per wave and array)
             const bool flush = done && T.read != 0xffffffffu;
-            if( staged && flush && ( L.err & ( MA_ERR_SEG_OVERFLOW | MA_ERR_SMEM_OVERFLOW ) ) )
+            if( SM && flush && ( L.err & ( MA_ERR_SEG_OVERFLOW | MA_ERR_SMEM_OVERFLOW ) ) )
                 L.err = ( L.err & ~(u32)MA_ERR_SEG_OVERFLOW ) | MA_ERR_SMEM_OVERFLOW; // the task outgrew its staging area or a list
             const u32 ns = flush ? ( L.nseg < S.seg_cap ? L.nseg : S.seg_cap ) : 0;
             const u32 nc = flush ? ( L.childN[ 0 ] ? 1 : 0 ) + ( L.childN[ 1 ] ? 1 : 0 ) : 0;
@@ -455,7 +443,7 @@ template <bool SM> __device__ __forceinline__ void seed_tasks_body( const TaskKe
                 if( so + ns <= A.pool_cap )
                     for( u32 k = 0; k < ns; k++ )
                     {
-                        A.pool[ so + k ] = staged ? S.stage[ k ] : mine[ k ];
+                        A.pool[ so + k ] = SM ? S.stage[ k ] : mine[ k ];
                         A.pool_key[ so + k ] = ( (u64)T.read << MA_TASK_KEY_BITS ) | T.key;
                     }
                 else
@@ -498,10 +486,7 @@ template <bool SM> __device__ __forceinline__ void seed_tasks_body( const TaskKe
                 {
                     T = A.in[ qCur + rank ];
                     const u64 r0 = A.roff[ T.read ];
-                    if( A.leaf && T.aN <= A.leaf )
-                        seed_begin_subtree( L, A.reads + r0, (u32)( A.roff[ T.read + 1 ] - r0 ), T.aS, T.aN );
-                    else
-                        seed_begin_area( L, A.reads + r0, (u32)( A.roff[ T.read + 1 ] - r0 ), T.aS, T.aN );
+                    seed_begin_area( L, A.reads + r0, (u32)( A.roff[ T.read + 1 ] - r0 ), T.aS, T.aN );
                 }
                 else if( qEnd == nIn )
                     alive = false;

@@ -255,9 +255,8 @@ def test_smem_seeding_of_long_reads_as_area_tasks(gpu_device, monkeypatch):
     """Nanopore preset (SMEM seeding, parameter.h:1101-1104) on batches of few long reads: one lane per AREA of procesInterval's
     recursion (binarySeeding.cpp:41-83) instead of one per read (k_seed_tasks_smem).  The segments -- their
     ORDER included: a centre's segments in emission order, the centres in pre-order -- are the oracle's and the read-per-lane kernel's
-    (MA_SEED_TASKS=0), with both list entry forms, uiMinAmbiguity 0 and 2, Ns, repeats, with and without the small areas walked as
-    whole subtrees (MA_SEED_TASK_LEAF); a task that outgrows its staging area or its lists sends the batch to the read-per-lane
-    kernel (MA_SEED_TASK_CAPS).  The maxSpan tasks with subtrees: test_maxspan_area_tasks_with_subtrees."""
+    (MA_SEED_TASKS=0), with both list entry forms, uiMinAmbiguity 0 and 2, Ns, repeats; a task that outgrows its staging area or its
+    lists sends the batch to the read-per-lane kernel (MA_SEED_TASK_CAPS)."""
     import ma_amd
     from ma_testlib import OrIndex, rand_genome, sample_reads
     g = rand_genome(56, [500000, 300000], repeat_unit=300, repeat_copies=80, repeat_div=0.06)
@@ -287,14 +286,9 @@ def test_smem_seeding_of_long_reads_as_area_tasks(gpu_device, monkeypatch):
         for compact in ("1", "0"):
             monkeypatch.setenv("MA_SMEM_COMPACT", compact)
             monkeypatch.setenv("MA_SEED_TASKS", "1")
-            for leaf in ("0", "64", None):  # every centre a task / areas of up to 64 bases walked by one lane / the default (256)
-                if leaf is None:
-                    monkeypatch.delenv("MA_SEED_TASK_LEAF", raising=False)
-                else:
-                    monkeypatch.setenv("MA_SEED_TASK_LEAF", leaf)
-                soff, segs, steps_t = segments(P)
-                assert np.array_equal(soff, res["seg_off"]), (min_amb, compact, leaf)
-                assert segs.tobytes() == res["segs"].tobytes(), (min_amb, compact, leaf)
+            soff, segs, steps_t = segments(P)
+            assert np.array_equal(soff, res["seg_off"]), (min_amb, compact)
+            assert segs.tobytes() == res["segs"].tobytes(), (min_amb, compact)
             monkeypatch.setenv("MA_SEED_TASKS", "0")
             soff0, segs0, steps_r = segments(P)
             assert np.array_equal(soff0, soff) and segs0.tobytes() == segs.tobytes()
@@ -307,37 +301,4 @@ def test_smem_seeding_of_long_reads_as_area_tasks(gpu_device, monkeypatch):
         assert np.array_equal(soff, res["seg_off"]) and segs.tobytes() == res["segs"].tobytes()
         monkeypatch.delenv("MA_SEED_TASK_CAPS")
     monkeypatch.delenv("MA_SEED_TASKS")
-    idx.close()
-
-
-def test_maxspan_area_tasks_with_subtrees(gpu_device, monkeypatch):
-    """k_seed_tasks with areas of up to MA_SEED_TASK_LEAF bases walked as whole subtrees by one lane (round 6): the segments and their
-    order are the read-per-lane kernel's and the oracle's for every leaf size, incl. a staging area that is too small (fallback)."""
-    import ma_amd
-    from ma_testlib import OrIndex, rand_genome, sample_reads
-    g = rand_genome(57, [400000, 200000], repeat_unit=200, repeat_copies=50, repeat_div=0.05)
-    idx = ma_amd.Index.build(g)
-    oidx = OrIndex.from_parts(idx.download())
-    reads = (sample_reads(g, 50, 5000, 3, sub=0.02, ins=0.02, dele=0.02) + sample_reads(g, 10, 40000, 5, sub=0.03, ins=0.03, dele=0.04, n_rate=0.001)
-             + sample_reads(g, 30, 700, 7) + [np.zeros(900, dtype=np.uint8), np.full(300, 4, dtype=np.uint8)])
-    nb = sum(len(r) for r in reads)
-    res = oidx.align(reads, or_params("default", 1), threads=8)
-    P = ma_amd.Params.preset("default")
-    for tasks, leaf, caps in (("1", "0", None), ("1", "32", None), ("1", "512", None), ("1", "100000", None), ("1", "512", "3,4"), ("0", None, None)):
-        monkeypatch.setenv("MA_SEED_TASKS", tasks)
-        for key, val in (("MA_SEED_TASK_LEAF", leaf), ("MA_SEED_TASK_CAPS", caps)):
-            if val is None:
-                monkeypatch.delenv(key, raising=False)
-            else:
-                monkeypatch.setenv(key, val)
-        bt = ma_amd.Batch(idx, P, len(reads), nb + 64)
-        bt.set_reads(reads)
-        bt.seed()
-        bt.sync()
-        soff, segs = bt.segments()
-        bt.close()
-        assert np.array_equal(soff, res["seg_off"]), (tasks, leaf, caps)
-        assert segs.tobytes() == res["segs"].tobytes(), (tasks, leaf, caps)
-    for key in ("MA_SEED_TASKS", "MA_SEED_TASK_LEAF", "MA_SEED_TASK_CAPS"):
-        monkeypatch.delenv(key, raising=False)
     idx.close()

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Everything the round's committed numbers come from, in one GPU call (≈20 min of box time in round 5): parity tests, rocprofv3
+# Everything the round's committed numbers come from, in one GPU call (≈35 min of box time in round 6): parity tests, rocprofv3
 # kernel stats + PMC passes of the four workloads, the bench line (all workloads, three legs each, C1 anchor, boundary), the
 # kernel trace of the leg `value` comes from and its concurrency timeline, the overlap matrix, the phase profile of
 # k_ksw_pk<5>, SQ counters of the 10 kb DP stage, launch timelines.  tools/evidence_to_profiles.sh copies what is to be judged
 # from gpurun_out/ into profiles/ (profiles/README.md).
-#   usage: bash tools/round_evidence.sh [tag=r04]
-TAG=${1:-r05}
+#   usage: bash tools/round_evidence.sh [tag=r06]
+TAG=${1:-r06}
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > gpurun_out/${TAG}_gpu_tests.txt
@@ -14,6 +14,9 @@ cat gpurun_out/${TAG}_gpu_tests.txt
 # when they were collected with the kernel sources the library is built from (kernel_source_hash)
 for wl in 150bp 10kb 50kb; do bash tools/collect_profiles.sh $TAG $wl > gpurun_out/collect_$wl.log 2>&1; done
 bash tools/collect_profiles.sh $TAG 150bp illumina > gpurun_out/collect_illumina.log 2>&1
+# (round 6) the legs under the reference's PacBio and Nanopore parameter sets
+for wl in 10kb_pacbio 50kb_nanopore; do bash tools/collect_profiles.sh $TAG $wl > gpurun_out/collect_$wl.log 2>&1; done
+for wl in 150bp 10kb 50kb 150bp_illumina 10kb_pacbio 50kb_nanopore; do cp gpurun_out/prof_${TAG}_$wl/summary.txt gpurun_out/${TAG}_pmc_summary_$wl.txt 2>/dev/null; cp gpurun_out/prof_${TAG}_$wl/kernel_stats.csv gpurun_out/${TAG}_kernel_stats_$wl.csv 2>/dev/null; done
 cp gpurun_out/prof_${TAG}_pmc_traffic.json profiles/${TAG}_pmc_traffic.json
 # the ceilings the roofline fractions are quoted against, re-measured beside this build (tools/calibrate.sh without its PMC passes)
 mkdir -p gpurun_out/calib_$TAG tools/_prof
@@ -29,7 +32,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file gpurun_out/${TAG}_b
 # copies forced onto blit kernels, host threads on the other socket
 bash tools/h2h_experiment.sh 30 > /dev/null 2>&1; cp gpurun_out/h2h_experiment.txt gpurun_out/${TAG}_h2h_experiment.txt
 # the proven narrow band against the oracle's kswcpp at the full band: 100 000 jobs, proved or handed on
-python3 tools/band_soak.py 10 2>&1 | grep -v amdgpu.ids | tail -6 > gpurun_out/${TAG}_band_soak.txt
+python3 tools/band_soak.py 10 2>&1 | grep -v amdgpu.ids | tail -12 > gpurun_out/${TAG}_band_soak.txt
 # the shapes of the kswcpp calls of the long-read workloads
 ( python3 tools/dp_job_histogram.py 150 200000 0.005 0 0; python3 tools/dp_job_histogram.py 10000 4000 0.004 0.003 0.003; python3 tools/dp_job_histogram.py 50000 1000 0.03 0.03 0.04 ) 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_dp_job_histogram.txt
 # the leg `value` comes from -- 150 bp, 3 batches in flight, host to host -- under rocprofv3 (program directly after --):
@@ -38,7 +41,6 @@ rocprofv3 --kernel-trace --stats -d gpurun_out/tr_h2h -o tr --output-format csv 
 python3 tools/overlap_timeline.py $(find gpurun_out/tr_h2h -name "*kernel_trace.csv" | head -1) 3 1 > gpurun_out/${TAG}_overlap_timeline_150bp_h2h.txt
 find gpurun_out/tr_h2h -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_150bp_h2h_inflight3.csv \;
 grep "^{" gpurun_out/tr_h2h.log | tail -1 > gpurun_out/${TAG}_bench_150bp_h2h_inflight3_under_rocprof.json; rm -rf gpurun_out/tr_h2h
-python3 tools/overlap_matrix.py --workload 150bp --steps 12 --inflight 1,3 --waves 0 --exclusive 0 --cu-split 0,64,96,128,160 > gpurun_out/${TAG}_overlap_matrix_150bp_cu_split.txt 2>/dev/null
 # the single-stream step launch by launch, and the phase profile of the kernel that runs several short extensions per wavefront
 rocprofv3 --kernel-trace -d gpurun_out/tr150 -o tr --output-format csv -- python3 bench.py --workload 150bp --steps 3 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/tr150.log 2>&1
 python3 tools/step_timeline.py gpurun_out/tr150 > gpurun_out/${TAG}_step_timeline_150bp.txt; rm -rf gpurun_out/tr150
@@ -48,9 +50,9 @@ python3 tools/pk_prof.py --workload 10kb 2>&1 | grep -v "^{" | grep -v "^bench d
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_SALU \
   -d gpurun_out/sq10 -o pmc --output-format csv -- python3 bench.py --workload 10kb --steps 1 --warmup 0 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/sq10.log 2>&1
 python3 tools/pmc_sq.py gpurun_out/sq10 k_ksw > gpurun_out/${TAG}_sq_counters_10kb_dp.txt; rm -rf gpurun_out/sq10
-for wl in 50kb 10kb; do
+for wl in 50kb 10kb 50kb_nanopore; do
 rocprofv3 --kernel-trace -d gpurun_out/tr_$wl -o tr --output-format csv -- python3 bench.py --workload $wl --steps 1 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/tr_$wl.log 2>&1
-python3 tools/launch_list.py gpurun_out/tr_$wl k_ksw k_job_cost k_chain k_sort_seeds k_soc_windows k_stitch > gpurun_out/${TAG}_launch_timeline_$wl.txt; rm -rf gpurun_out/tr_$wl
+python3 tools/launch_list.py gpurun_out/tr_$wl k_ksw k_job_cost k_chain k_sort_seeds k_soc_windows k_stitch k_seed k_task k_dp_enum > gpurun_out/${TAG}_launch_timeline_$wl.txt; rm -rf gpurun_out/tr_$wl
 done
 python3 tools/ksw_prof.py --workload 150bp --boundary-reads 0 --overlap 0 2>&1 | grep -v "^{" | grep -v "^bench detail:" | grep -v amdgpu.ids > gpurun_out/${TAG}_ext_pairing_bound.txt
 python3 - <<PY
