@@ -691,16 +691,19 @@ def cpu_baseline_and_parity(E, name, wl, args, codes, offs_h, B, n_reads, step, 
             quota = cpu_quota_cores()
             cand = sorted(set([ncores] + ([max(1, ncores // 4)] if args.cpu_threads_sweep else [])
                               + ([max(1, int(quota))] if quota and quota < ncores else [])))  # as many threads as the quota grants cores
+            light = bool(wl.get("preset"))  # the legs under another parameter set: ONE run, with the threads the quota grants (every run
+            if light:                       # of ref_dump loads the GRCh38-size index again: the default bench line stays within minutes)
+                cand = [max(1, int(quota))] if quota and quota < ncores else [ncores]
             for t in cand:
                 runs[t] = timed("reads.case", t)
             best = max(runs, key=lambda t: runs[t][0])
-            one = timed("reads1.case", 1)
+            one = (None, None) if light else timed("reads1.case", 1)
             cpu = dict(cpu, value=round(runs[best][0], 1), cores=best, kind="reference",
                        sample="first %d reads of the same workload, the reference's own modules (BinarySeeding .. "
                               "MappingQuality), %.1f s on %d threads; index written by the GPU builder and loaded by the "
                               "reference's loaders (%.0f s to write, not counted)" % (S, runs[best][1], best, t_store),
                        by_threads={str(t): round(v[0], 1) for t, v in runs.items()},
-                       one_thread={"value": round(one[0], 1), "sample": "first %d reads, %.1f s" % (S1, one[1])},
+                       one_thread=None if one[0] is None else {"value": round(one[0], 1), "sample": "first %d reads, %.1f s" % (S1, one[1])},
                        port={"value": cpu["value"], "sample": cpu["sample"]})
         except Exception as e:  # the oracle's number stays
             cpu["reference_error"] = repr(e)[:300]
@@ -1052,6 +1055,11 @@ def build_parser():
 
 
 def main():
+    # A batch of long reads runs its DP classes on up to four streams beside its I/O stream, and the runtime maps streams onto
+    # GPU_MAX_HW_QUEUES hardware queues (default 4): streams that share a queue run one after the other.  After the 150 bp legs of this
+    # process had created and dropped a dozen streams, the 10 kb batch's main stream and its k_ksw_pk<5> stream landed on ONE queue and
+    # the DP stage took 196 instead of 148 ms (profiles/r06_hw_queues.txt).  Must be set before the first HIP call of the process.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     args = build_parser().parse_args()
     self_launch_or_check(args, sys.argv[1:])
     if os.environ.get("MA_BENCH_DRY_RUN") == "1":
@@ -1066,7 +1074,10 @@ def main():
                                    reads_per_step=B, steps=args.steps, warmup=args.warmup, cpu_sample=None,
                                    baseline_config=None)))
     else:
-        for name in (["150bp", "10kb", "50kb", "illumina", "10kb_pacbio", "50kb_nanopore"] if args.workload == "all" else [args.workload]):
+        names = ["150bp", "10kb", "50kb", "illumina", "10kb_pacbio", "50kb_nanopore"]
+        if os.environ.get("MA_BENCH_ONLY"):  # diagnostics: a subset of the default run's workloads, in its order and with its step counts
+            names = [n for n in names if n in os.environ["MA_BENCH_ONLY"].split(",")]
+        for name in (names if args.workload == "all" else [args.workload]):
             wl = dict(WORKLOADS[name])
             if wl["steps"] is None or args.workload != "all":
                 wl["steps"], wl["warmup"] = args.steps, args.warmup
@@ -1195,6 +1206,7 @@ def compose_line(E, args, results, boundary, anchor):
             E.world, args.scaling, top.get("batches_in_flight", 1)),
         "detail_file": os.path.relpath(dpath, ROOT) if os.path.isabs(dpath) else dpath,
         "kernel_source_hash": kernel_source_hash(),
+        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
     }
     # The top-level roofline is the SINGLE-STREAM leg's (one batch at a time: a launch's duration is the kernel's own, and
     # avg_launch_ms <= that leg's ms_per_step); under overlap a kernel's launch time includes the share of the chip the other

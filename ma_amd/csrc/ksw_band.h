@@ -589,7 +589,10 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
         i32 raise = 0;
         if( __any( pk_max( Hm, ezpk ) != ezpk ) )
         {
-            const i32 gm = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
+            // (LONG: one job per wave -- the maximum and everything derived from it, ez.max, the last raise, the schedule of the early
+            // stop, is wave-uniform: read into a scalar register, the bookkeeping below runs on the scalar unit)
+            const i32 gmV = grp_max_i32<LANES>( max( (i32)( Hm << 16 ) >> 16, (i32)Hm >> 16 ) );
+            const i32 gm = LONG ? __builtin_amdgcn_readfirstlane( gmV ) : gmV;
             raise = gm > ezmax ? -1 : 0;
             // check 4: between the last raise (pR, pM) and this diagonal the wide run's ez.max - diagonal maximum stayed <= zdrop
             // (LONG: by (L) the wide run's ez.max up to this diagonal is at most max(the band's ez.max so far, UB(r)))
@@ -620,7 +623,8 @@ __device__ void ksw_band_set( const FETCH& F, const KswScoring& SC, const u32* l
             const u32 pot = pk_min( QLpk, pk_sub( tlenpk, Tpk ) ); // min( rows left, columns left ): Tpk is t + 1 by now
             const u32 bnd = pk_mad( pot, K_MATCH, H );
             const u32 bm = pk_bfi( LM, bnd, K_NEG );
-            const i32 bound = grp_max_i32<LANES>( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
+            const i32 boundV = grp_max_i32<LANES>( max( (i32)( bm << 16 ) >> 16, (i32)bm >> 16 ) );
+            const i32 bound = LONG ? __builtin_amdgcn_readfirstlane( boundV ) : boundV;
             const i32 top = LONG ? (i32)0x80000000 : hBoundary( r ) + sc_mch * qlen;
             if( due )
             {

@@ -47,6 +47,13 @@ struct KswWaveAcc
     u32 chunk_left = 0;
 };
 #define KSW_JOBS_PER_FETCH 8u // queue entries a wave takes per atomic
+// ... when the launch has jobs in plenty.  With few jobs per wave -- the long junk extensions of a 10 kb batch on k_ksw_pk<5> (8.5 k jobs
+// of ~8 ms on 4 096 waves), the handful of jobs the band of 120 hands back -- eight at a time leaves most waves without work and
+// makes the launch as long as eight jobs in a row (10 kb: the 150 handed-back jobs were a tail of 40 ms on 19 waves): one at a time.
+__device__ __forceinline__ u32 ksw_fetch_size( u32 n )
+{
+    return n / gridDim.x >= 32u ? KSW_JOBS_PER_FETCH : 1u;
+}
 
 // job classes by the number of 128-cell ring slots they need (ksw_pk_slots): 1, 2, 3, <=5, else LDS kernel (class 3
 // shares the launch slot of the widest ring; class 4 = ksw_wave.h)
@@ -159,12 +166,13 @@ __device__ __forceinline__ bool ksw_next( unsigned int* nextSlot, u32 n, u32& cu
 {
     if( cur == end )
     {
+        const u32 fetch = ksw_fetch_size( n );
         if( threadIdx.x == 0 )
-            *sSlot = atomicAdd( nextSlot, KSW_JOBS_PER_FETCH );
+            *sSlot = atomicAdd( nextSlot, fetch );
         __syncthreads( );
         cur = *sSlot;
         __syncthreads( );
-        end = cur + KSW_JOBS_PER_FETCH < n ? cur + KSW_JOBS_PER_FETCH : n;
+        end = cur + fetch < n ? cur + fetch : n;
         if( cur >= n )
             return false;
     }

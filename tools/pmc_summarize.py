@@ -29,6 +29,9 @@ def group_of(name):
     m = re.search(r"k_ksw_ext<.*?, (\d)>\(", name)
     if m:
         return "k_ksw_ext<%s>" % m.group(1)
+    m = re.search(r"k_ksw_band<.*?, (true|false), (\d)>\(", name)
+    if m:
+        return "k_ksw_band" if m.group(2) == "4" else "k_ksw_band (long)"  # four short jobs per wave / one long job per wave (ksw_band.h)
     m = re.search(r"k_ksw_grp<.*?, (\d), (\d), (true|false)>\(", name)
     if m:
         return "k_ksw_grp<%s>" % m.group(1)  # (several short extension jobs per wavefront: ksw_grp.h)

@@ -28,6 +28,7 @@ cp gpurun_out/${TAG}_calibration.json profiles/${TAG}_calibration.json
 # (the driver's own command line)
 python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
 [ -n "$QUICK" ] && exit 0   # QUICK=1: only what depends on the kernel sources' hash (tests, PMC passes, calibration, the bench line)
+make -s -C ma_amd/csrc prof > /dev/null 2>&1   # the diagnostics build of THESE sources (phase profiles below)
 # where the host-to-host leg stands against the device-resident one: one direction only, serial instead of double-buffered I/O,
 # copies forced onto blit kernels, host threads on the other socket
 bash tools/h2h_experiment.sh 30 > /dev/null 2>&1; cp gpurun_out/h2h_experiment.txt gpurun_out/${TAG}_h2h_experiment.txt
