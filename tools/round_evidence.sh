@@ -26,7 +26,9 @@ python3 tools/calibration_json.py gpurun_out/calib_$TAG > gpurun_out/${TAG}_cali
 cp gpurun_out/${TAG}_calibration.json profiles/${TAG}_calibration.json
 # the driver's line (all workloads incl. the Illumina preset and the C1 anchor); its per-workload blocks go to the detail file
 # (the driver's own command line)
+T0=$(date +%s)
 python bench.py --gpus 1 --steps 20 --warmup 5 --detail-file gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench_default.json 2> gpurun_out/${TAG}_bench_default.err
+echo "python bench.py --gpus 1 --steps 20 --warmup 5: $(( $(date +%s) - T0 )) s wall" > gpurun_out/${TAG}_bench_default_wall.txt
 [ -n "$QUICK" ] && exit 0   # QUICK=1: only what depends on the kernel sources' hash (tests, PMC passes, calibration, the bench line)
 make -s -C ma_amd/csrc prof > /dev/null 2>&1   # the diagnostics build of THESE sources (phase profiles below)
 # where the host-to-host leg stands against the device-resident one: one direction only, serial instead of double-buffered I/O,
