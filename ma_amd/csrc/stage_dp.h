@@ -78,7 +78,7 @@ struct DpKernelArgs
     ma_ez* ez;
     u64* cig_off;
     // class of every job slot as the first pass over a wave's jobs decided it (the pre-filters of the band kernels walk the job's first
-    // bases: once, not once per pass -- 50 kb: k_dp_enum 26 -> RESULT_ENUM_50KB ms)
+    // bases: once, not once per pass -- 50 kb: k_dp_enum 26 -> 15 ms)
     uint8_t* cls_cache;
 };
 
