@@ -33,6 +33,13 @@ struct SeedScratch
     u32 drop_div; // SeedParams::min_seed_size_drop (seed_emit keeps the running sum seed_finish needs)
     u32* stack; // 2 * MA_SEED_STACK words: interval stack of procesInterval (kept out of SeedLane so that the lane
                 // state stays in registers; a dynamically indexed member would put the whole struct in scratch memory)
+    // Round 6: the HEADS of the two SMEM lists in LDS (16-byte entries only; kernels whose reads stay in HBM).  A backward list holds one
+    // to three entries once equal intervals are merged, the forward list about a dozen: with the first lds_n entries of each list in
+    // LDS a backward step neither reads nor writes a list entry in HBM (50 kb x 10 k reads, SMEM tasks: 1.42 TB of fabric traffic per
+    // step for 0.35 TB of occ blocks before).  Entry e of list w (0 = smem_a, 1 = smem_b) of this lane: lds[ 2 (w lds_n + e) lds_stride ].
+    // lds_n <= smem_cap: an entry past the capacity is never written (the batch goes to the fallback), so none may be read from LDS.
+    u64* lds = nullptr;
+    u32 lds_n = 0, lds_stride = 0;
 };
 
 enum SeedPhase : u32
@@ -207,6 +214,37 @@ MA_HD ma_segment smem_get( const SeedParams& P, const ma_segment* list, u32 idx,
 
 // request entry idx of a list of 16-byte entries into the lane's prefetch registers
 MA_HD void smem_prefetch( SeedLane& L, const ma_segment* list, u32 idx );
+// the same three by list NUMBER (0 = smem_a, 1 = smem_b): the first S.lds_n entries of a list live in LDS (SeedScratch::lds)
+MA_HD void smem_put_w( const SeedParams& P, const SeedScratch& S, u32 w, u32 idx, u32 qs, u32 qz, i64 a, i64 b, i64 c )
+{
+    if( P.smem_compact && idx < S.lds_n )
+    {
+        u64 w0, w1;
+        smem_pack( qz, a, b, c, w0, w1 );
+        u64* p = S.lds + 2 * (u64)( ( w * S.lds_n + idx ) * S.lds_stride );
+#if defined( __HIP_DEVICE_COMPILE__ )
+        *(ulonglong2*)p = make_ulonglong2( w0, w1 );
+#else
+        p[ 0 ] = w0, p[ 1 ] = w1;
+#endif
+        return;
+    }
+    smem_put( P, w ? S.smem_b : S.smem_a, idx, qs, qz, a, b, c );
+}
+MA_HD ma_segment smem_get_w( const SeedParams& P, const SeedScratch& S, u32 w, u32 idx, u32 qs )
+{
+    if( P.smem_compact && idx < S.lds_n )
+    {
+        const u64* p = S.lds + 2 * (u64)( ( w * S.lds_n + idx ) * S.lds_stride );
+#if defined( __HIP_DEVICE_COMPILE__ )
+        const ulonglong2 v = *(const ulonglong2*)p;
+        return smem_unpack( v.x, v.y, qs );
+#else
+        return smem_unpack( p[ 0 ], p[ 1 ], qs );
+#endif
+    }
+    return smem_get( P, w ? S.smem_b : S.smem_a, idx, qs );
+}
 MA_HD void seed_emit( SeedLane& L, const SeedScratch& S, u32 start, u32 size, i64 a, i64 b, i64 c )
 {
     if( L.nseg < S.seg_cap )
@@ -236,6 +274,22 @@ MA_HD void smem_prefetch( SeedLane& L, const ma_segment* list, u32 idx )
     L.nxt0 = w[ 0 ], L.nxt1 = w[ 1 ];
 #endif
     L.nxtOk = 1;
+}
+MA_HD void smem_prefetch_w( SeedLane& L, const SeedScratch& S, u32 w, u32 idx ) // (16-byte entries only, like smem_prefetch)
+{
+    if( idx < S.lds_n )
+    {
+        const u64* p = S.lds + 2 * (u64)( ( w * S.lds_n + idx ) * S.lds_stride );
+#if defined( __HIP_DEVICE_COMPILE__ )
+        const ulonglong2 v = *(const ulonglong2*)p;
+        L.nxt0 = v.x, L.nxt1 = v.y;
+#else
+        L.nxt0 = p[ 0 ], L.nxt1 = p[ 1 ];
+#endif
+        L.nxtOk = 1;
+        return;
+    }
+    smem_prefetch( L, w ? S.smem_b : S.smem_a, idx );
 }
 MA_HD void seed_begin_read( SeedLane& L, const uint8_t* q, u32 qlen )
 {
@@ -489,7 +543,7 @@ template <bool WIN = false, bool SM = true, bool MS = true> MA_HD bool seed_try(
             L.ik[ 0 ] = s.sa_start, L.ik[ 1 ] = s.sa_start_rc, L.ik[ 2 ] = s.sa_size;
             L.curQStart = (u32)s.q_start, L.curQSize = (u32)s.q_size;
             if( L.jPrev + 1 < L.nPrev )
-                smem_prefetch( L, L.flip ? S->smem_b : S->smem_a, L.jPrev + 1 );
+                smem_prefetch_w( L, *S, L.flip, L.jPrev + 1 );
             else
                 L.nxtOk = 0;
             c = seed_qbyte<WIN>( L, P, L.i );
@@ -511,7 +565,7 @@ template <bool WIN = false, bool SM = true, bool MS = true> MA_HD bool seed_try(
             L.ik[ 0 ] = s.sa_start, L.ik[ 1 ] = s.sa_start_rc, L.ik[ 2 ] = s.sa_size;
             L.curQStart = (u32)s.q_start, L.curQSize = (u32)s.q_size;
             if( L.nPrev > 1 )
-                smem_prefetch( L, L.flip ? S->smem_b : S->smem_a, 1 );
+                smem_prefetch_w( L, *S, L.flip, 1 );
             else
                 L.nxtOk = 0;
             L.i--;
@@ -686,12 +740,11 @@ template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> M
                 }
                 // forward phase over: reverse the list (binarySeeding.h:343) and go backwards
                 {
-                    ma_segment* cur = S.smem_a;
                     for( u32 a = 0, b = L.nCurr; a + 1 < b; a++, b-- )
                     {
-                        const ma_segment t = smem_get( P, cur, a, L.center ), u = smem_get( P, cur, b - 1, L.center );
-                        smem_put( P, cur, a, (u32)u.q_start, (u32)u.q_size, u.sa_start, u.sa_start_rc, u.sa_size );
-                        smem_put( P, cur, b - 1, (u32)t.q_start, (u32)t.q_size, t.sa_start, t.sa_start_rc, t.sa_size );
+                        const ma_segment t = smem_get_w( P, S, 0, a, L.center ), u = smem_get_w( P, S, 0, b - 1, L.center );
+                        smem_put_w( P, S, 0, a, (u32)u.q_start, (u32)u.q_size, u.sa_start, u.sa_start_rc, u.sa_size );
+                        smem_put_w( P, S, 0, b - 1, (u32)t.q_start, (u32)t.q_size, t.sa_start, t.sa_start_rc, t.sa_size );
                     }
                     L.nPrev = L.nCurr;
                     L.nCurr = 0;
@@ -709,7 +762,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> M
                         // cannot extend backwards at all (binarySeeding.h:354, 437-448)
                         if( L.nPrev > 0 )
                         {
-                            const ma_segment f = smem_get( P, S.smem_a, 0, L.center );
+                            const ma_segment f = smem_get_w( P, S, 0, 0, L.center );
                             seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
                         }
                         seed_after_center( L, S, L.retS, L.retE - L.retS );
@@ -720,12 +773,11 @@ template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> M
             {
                 if( !SM )
                     return false;
-                ma_segment* prev = L.flip ? S.smem_b : S.smem_a;
                 if( L.jPrev < L.nPrev )
                 {
-                    const ma_segment s = L.nxtOk ? smem_unpack( L.nxt0, L.nxt1, L.i + 1 ) : smem_get( P, prev, L.jPrev, L.i + 1 );
+                    const ma_segment s = L.nxtOk ? smem_unpack( L.nxt0, L.nxt1, L.i + 1 ) : smem_get_w( P, S, L.flip, L.jPrev, L.i + 1 );
                     if( P.smem_compact && L.jPrev + 1 < L.nPrev )
-                        smem_prefetch( L, prev, L.jPrev + 1 );
+                        smem_prefetch_w( L, S, L.flip, L.jPrev + 1 );
                     else
                         L.nxtOk = 0;
                     L.ik[ 0 ] = s.sa_start;
@@ -758,7 +810,7 @@ template <bool WIN = false, bool JUMP = false, bool SM = true, bool MS = true> M
                 {
                     if( L.nPrev > 0 )
                     {
-                        const ma_segment f = smem_get( P, L.flip ? S.smem_b : S.smem_a, 0, L.i );
+                        const ma_segment f = smem_get_w( P, S, L.flip, 0, L.i );
                         seed_emit( L, S, (u32)f.q_start, (u32)f.q_size, f.sa_start, f.sa_start_rc, f.sa_size );
                     }
                     seed_after_center( L, S, L.retS, L.retE - L.retS );
@@ -806,10 +858,9 @@ template <bool SM = true, bool MS = true> MA_HD void seed_apply( SeedLane& L, co
         { // binarySeeding.h:296-337
             if( !SM )
                 break;
-            ma_segment* cur = S.smem_a;
             auto push = [ & ]( u32 st, u32 sz, i64 a, i64 b, i64 c ) {
                 if( L.nCurr < S.smem_cap )
-                    smem_put( P, cur, L.nCurr, st, sz, a, b, c );
+                    smem_put_w( P, S, 0, L.nCurr, st, sz, a, b, c );
                 else
                     L.err |= MA_ERR_SMEM_OVERFLOW;
                 L.nCurr++;
@@ -832,7 +883,6 @@ template <bool SM = true, bool MS = true> MA_HD void seed_apply( SeedLane& L, co
         { // binarySeeding.h:380-413
             if( !SM )
                 break;
-            ma_segment* curr = L.flip ? S.smem_a : S.smem_b;
             ma_segment s; // = prev[ L.jPrev ], kept in the lane state by seed_prepare (saves a memory round trip per step)
             s.q_start = L.curQStart, s.q_size = L.curQSize, s.sa_start = L.ik[ 0 ], s.sa_start_rc = L.ik[ 1 ], s.sa_size = L.ik[ 2 ];
             if( ok[ 2 ] <= (i64)P.min_amb && !L.bHaveOne )
@@ -855,7 +905,7 @@ template <bool SM = true, bool MS = true> MA_HD void seed_apply( SeedLane& L, co
                 if( !twin )
                 {
                     if( L.nCurr < S.smem_cap )
-                        smem_put( P, curr, L.nCurr, L.i, (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ] );
+                        smem_put_w( P, S, L.flip ^ 1u, L.nCurr, L.i, (u32)s.q_size + 1, ok[ 0 ], ok[ 1 ], ok[ 2 ] );
                     else
                         L.err |= MA_ERR_SMEM_OVERFLOW;
                     if( L.nCurr == 0 )

@@ -27,6 +27,9 @@ struct SeedKernelArgs
 #if defined( MA_KSW_PROF )
 static __device__ unsigned long long g_seed_prof[ 8 ];
 #endif
+// entries of each SMEM list a lane of k_seed_tasks_smem keeps in LDS: 3 waves per SIMD = 3 workgroups per CU x 48 KB.  (The read-per-lane
+// kernel k_seed_long<true> keeps its lists in HBM: with 4 heads in LDS it spilled 8 registers and ran 2140 ms for 1848 on 50 kb x 10 k reads.)
+#define MA_SMEM_LDS_HEADS_TASK 6
 // One read per lane at a time; lanes refill from a global queue, so a wavefront keeps stepping 64
 // reads in lockstep through extend_backward until the batch is exhausted.
 // LONG: the reads stay in HBM (longer than 240 bases) and are read through the register window of seed_qbyte.
@@ -399,6 +402,13 @@ template <bool SM> __device__ __forceinline__ void seed_tasks_body( const TaskKe
         S.smem_a = (ma_segment*)( (u64*)A.smem_a + lane * smemWords );
         S.smem_b = (ma_segment*)( (u64*)A.smem_b + lane * smemWords );
         S.smem_cap = A.smem_cap;
+    }
+    __shared__ ulonglong2 sHeads[ SM ? 2 * MA_SMEM_LDS_HEADS_TASK * 256 : 1 ]; // the heads of the two SMEM lists (seeding.h: SeedScratch::lds)
+    if( SM && A.P.smem_compact )
+    {
+        S.lds = (u64*)sHeads + 2 * threadIdx.x;
+        S.lds_n = A.smem_cap < MA_SMEM_LDS_HEADS_TASK ? A.smem_cap : MA_SMEM_LDS_HEADS_TASK;
+        S.lds_stride = 256;
     }
     S.stack = nullptr;
     S.drop_div = 0;
