@@ -99,7 +99,7 @@ struct SeedLane
     // byte load per step is one 64-byte fabric request per step once the line has left L2 -- a third of the requests
     // k_seed issued on 10 kb reads (431 GB of fetches for 299 GB of occ blocks)
     u32 qwinLo;
-    u32 qw[ 4 ];
+    u32 qw0, qw1, qw2, qw3;
 };
 
 // base i of the lane's read.  P.window_begin / window_end (wave-uniform; null = off: the read is in LDS, or host code)
@@ -122,7 +122,7 @@ MA_HD void seed_qwin_load( SeedLane& L, const SeedParams& P, u32 i )
     }
     else
         v = *(const uint4*)base; // one global_load_dwordx4
-    L.qw[ 0 ] = v.x, L.qw[ 1 ] = v.y, L.qw[ 2 ] = v.z, L.qw[ 3 ] = v.w;
+    L.qw0 = v.x, L.qw1 = v.y, L.qw2 = v.z, L.qw3 = v.w;
     L.qwinLo = i - (u32)( a - base );
 #endif
 }
@@ -134,7 +134,11 @@ template <bool WIN> MA_HD u32 seed_qbyte( SeedLane& L, const SeedParams& P, u32 
         if( i - L.qwinLo >= 16u )
             seed_qwin_load( L, P, i );
         const u32 d = i - L.qwinLo;
-        const u32 lo = d & 8u ? L.qw[ 2 ] : L.qw[ 0 ], hi = d & 8u ? L.qw[ 3 ] : L.qw[ 1 ]; // selects, not a register index
+        // selects of VALUES: without the empty asm the compiler folds them into one load through a selected address, and that address
+        // keeps the whole lane state of k_seed_tasks* in scratch memory (90 scratch stores in its loop, 0.76 TB of writes per step)
+        u32 w0 = L.qw0, w1 = L.qw1, w2 = L.qw2, w3 = L.qw3;
+        asm( "" : "+v"( w0 ), "+v"( w1 ), "+v"( w2 ), "+v"( w3 ) );
+        const u32 lo = d & 8u ? w2 : w0, hi = d & 8u ? w3 : w1;
         return ( ( d & 4u ? hi : lo ) >> ( 8u * ( d & 3u ) ) ) & 0xffu;
     }
 #endif
