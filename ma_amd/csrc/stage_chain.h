@@ -95,7 +95,7 @@ struct PackedKeyLess
 // sort has many large ranges to partition (10 kb reads, ~250 seeds: 28 ms of wave sorts vs 17 ms inside the lane kernels)
 #define MA_WSORT_MIN 768u
 #define MA_WSORT_SMALL 2688u // reads with up to this many seeds: 37 KB of LDS per wavefront
-#define MA_WSORT_LARGE 8192u // up to this many: 100 KB; more -> the lane-serial sort of chain.h
+#define MA_WSORT_LARGE 12288u // up to this many: 158 KB, the whole LDS of a CU (13 n + 1.9 KB); more -> the lane-serial sort of chain.h
 // One wavefront per read.  mode 0: work = seeds sorted by delta (reads outside [nMin, nMax] of this launch are left alone,
 // reads it owns but cannot sort are copied unsorted); mode 1: work re-sorted by reference position in place (via tmp).
 __global__ void __launch_bounds__( 64 ) k_sort_seeds_wave( u32 n_reads, const u64* seed_off, const u32* seed_cnt, const ma_seed* seeds,
