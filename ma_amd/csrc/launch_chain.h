@@ -116,15 +116,15 @@ int ma_chain_batch( ma_batch* b )
             // test hooks: MA_WSORT_MIN / MA_WSORT_SMALL move the thresholds so that small test reads take both launches
             const u32 wsMin = []( ) { const char* e = getenv( "MA_WSORT_MIN" ); return e ? (u32)std::max( 17, atoi( e ) ) : MA_WSORT_MIN; }( );
             const u32 wsSmall = []( ) { const char* e = getenv( "MA_WSORT_SMALL" ); return e ? (u32)std::min<int>( std::max( 17, atoi( e ) ), MA_WSORT_SMALL ) : MA_WSORT_SMALL; }( );
-            const u32 ldsSmall = (u32)ws::scratch_bytes( wsSmall ), ldsLarge = (u32)ws::scratch_bytes( MA_WSORT_LARGE );
-            MA_HIP( hipFuncSetAttribute( (const void*)k_sort_seeds_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsLarge ) );
+            const u32 ldsSmall = (u32)ws::scratch_bytes( wsSmall );
             for( int mode = 0; mode < 2; mode++ )
             {
-                // reads of up to MA_WSORT_SMALL seeds (several wavefronts per CU), then the larger ones (one per CU)
+                // reads of up to MA_WSORT_SMALL seeds with their arrays in LDS, then the larger ones with their arrays in global memory
+                // (setB: free until k_chain); reads of more than MA_WSORT_HUGE seeds are copied by that launch and sorted by their lane
                 hipLaunchKernelGGL( k_sort_seeds_wave, dim3( (unsigned)n ), dim3( 64 ), ldsSmall, b->stream, (u32)n, A.seed_off, A.seed_cnt, A.seeds,
-                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, 0u, wsSmall, wsMin, wsSmall );
-                hipLaunchKernelGGL( k_sort_seeds_wave, dim3( (unsigned)n ), dim3( 64 ), ldsLarge, b->stream, (u32)n, A.seed_off, A.seed_cnt, A.seeds,
-                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, wsSmall + 1, 0xffffffffu, std::max( wsSmall + 1, wsMin ), MA_WSORT_LARGE );
+                                    A.work, A.setA, b->preSorted.as<u32>( ), mode, 0u, wsSmall, wsMin, wsSmall, (ma_seed*)nullptr );
+                hipLaunchKernelGGL( k_sort_seeds_wave, dim3( (unsigned)n ), dim3( 64 ), 0, b->stream, (u32)n, A.seed_off, A.seed_cnt, A.seeds, A.work,
+                                    A.setA, b->preSorted.as<u32>( ), mode, wsSmall + 1, 0xffffffffu, std::max( wsSmall + 1, wsMin ), MA_WSORT_HUGE, A.setB );
                 if( mode == 0 )
                     hipLaunchKernelGGL( k_soc_windows, dim3( (unsigned)( ( n + A.lanes - 1 ) / A.lanes ) ), dim3( 64 ), 0, b->stream, A.X, A.P, (u32)n,
                                         A.lanes, A.roff, A.seed_off, A.seed_cnt, A.work, A.maxima, A.mm, A.setA, b->preSorted.as<u32>( ),

@@ -231,11 +231,12 @@ int ma_seed_batch( ma_batch* b )
         return seed_mems( b );
     // few long reads: one lane per AREA of the recursion instead of one per read.  With >= 128 k reads in the batch the
     // read-per-lane kernel already fills the machine and is faster (10 kb x 200 k reads: 157 vs 184 ms; the level-by-level
-    // walk pays a tail per level), with 20 k reads of 50 kb the task kernel is 6.5x faster (83 vs 546 ms).
+    // walk pays a tail per level), with 20 k reads of 50 kb the task kernel is 6.5x faster (83 vs 546 ms).  100 k reads of 10 kb
+    // (`pacbio` parameter set) are past the crossover as well: 87 ms per lane, 98 ms as tasks -- the limit is 64 k reads.
     // MA_SEED_TASKS=0 / 1 forces the choice (tests, tuning)
     {
         // Round 6: SMEM seeding (Nanopore preset) as tasks too -- one read per lane left 10 k x 50 kb reads on 10 k of 262 k lanes
-        bool tasks = b->P.seeding_technique <= 1 && b->max_qlen > 240 && n < 131072;
+        bool tasks = b->P.seeding_technique <= 1 && b->max_qlen > 240 && n < 65536;
         if( const char* e = getenv( "MA_SEED_TASKS" ) )
             tasks = b->P.seeding_technique <= 1 && atoi( e ) != 0;
         if( tasks )

@@ -94,13 +94,20 @@ struct PackedKeyLess
 // reads with fewer seeds are sorted by their lane in k_soc_windows / k_chain as before: a wavefront per read pays off when the
 // sort has many large ranges to partition (10 kb reads, ~250 seeds: 28 ms of wave sorts vs 17 ms inside the lane kernels)
 #define MA_WSORT_MIN 768u
-#define MA_WSORT_SMALL 2688u // reads with up to this many seeds: 37 KB of LDS per wavefront
-#define MA_WSORT_LARGE 12288u // up to this many: 158 KB, the whole LDS of a CU (13 n + 1.9 KB); more -> the lane-serial sort of chain.h
+#define MA_WSORT_SMALL 1024u // reads with up to this many seeds: arrays in LDS, 15 KB per wavefront (13 n + 1.9 KB)
+// More seeds, up to the 16-bit positions of wave_sort.h: the same sort on arrays in GLOBAL memory (the read's part of a scratch buffer
+// the stage uses later).  Round 6: the LDS form of the large reads (up to 8192 seeds in 100 KB) ran one wavefront per CU, and half of
+// the Nanopore preset's 50 kb reads (8400 seeds on average) fell to the lane-serial sort behind it; the global form runs as many
+// wavefronts per CU as registers allow and is faster from about 1000 seeds on (chain stage: Nanopore preset 379 -> 141 ms,
+// 50 kb reads under the default preset 113 -> 92 ms); reads of more seeds than MA_WSORT_HUGE -> the lane-serial sort of chain.h.
+#define MA_WSORT_HUGE 65535u
 // One wavefront per read.  mode 0: work = seeds sorted by delta (reads outside [nMin, nMax] of this launch are left alone,
 // reads it owns but cannot sort are copied unsorted); mode 1: work re-sorted by reference position in place (via tmp).
+// gscratch (or null): 40 n bytes per read carved by seed offset -- the arrays of a read that does not fit the LDS (13 n + 1.9 KB of it;
+// the barriers of wave_sort.h order a wavefront's accesses to global memory as they order those to LDS)
 __global__ void __launch_bounds__( 64 ) k_sort_seeds_wave( u32 n_reads, const u64* seed_off, const u32* seed_cnt, const ma_seed* seeds,
                                                           ma_seed* work, ma_seed* tmp, u32* sorted, int mode, u32 nMin, u32 nMax,
-                                                          u32 nSortMin, u32 nSortMax )
+                                                          u32 nSortMin, u32 nSortMax, ma_seed* gscratch )
 {
     extern __shared__ __attribute__( ( aligned( 16 ) ) ) uint8_t lds[];
     const u32 r = blockIdx.x;
@@ -113,7 +120,7 @@ __global__ void __launch_bounds__( 64 ) k_sort_seeds_wave( u32 n_reads, const u6
     const u64 off = seed_off[ r ];
     bool doSort = n >= nSortMin && n <= nSortMax;
     const ma_seed* src = mode == 0 ? seeds + off : work + off;
-    ws::Scratch S = ws::carve( lds, doSort ? n : 1 );
+    ws::Scratch S = gscratch != nullptr ? ws::carve( (uint8_t*)( gscratch + off ), n ) : ws::carve( lds, doSort ? n : 1 );
     if( doSort )
     {
         bool wide = false;
