@@ -126,9 +126,18 @@ int ma_chain_batch( ma_batch* b )
                 hipLaunchKernelGGL( k_sort_seeds_wave, dim3( (unsigned)n ), dim3( 64 ), 0, b->stream, (u32)n, A.seed_off, A.seed_cnt, A.seeds, A.work,
                                     A.setA, b->preSorted.as<u32>( ), mode, wsSmall + 1, 0xffffffffu, std::max( wsSmall + 1, wsMin ), MA_WSORT_HUGE, A.setB );
                 if( mode == 0 )
+                {
+                    // the sweep: one wavefront per read the kernels above sorted, one lane per read for the others
+                    // (MA_SOC_WAVE=0: all by their lane; 2: the wave kernel's fallback to the lane form on every read -- tests)
+                    const int waveSweep = []( ) { const char* e = getenv( "MA_SOC_WAVE" ); return e ? atoi( e ) : 1; }( );
+                    if( waveSweep )
+                        hipLaunchKernelGGL( k_soc_windows_wave, dim3( (unsigned)n ), dim3( 64 ), 0, b->stream, A.X, A.P, (u32)n, A.roff, A.seed_off,
+                                            A.seed_cnt, A.work, A.maxima, A.mm, A.setA, A.setB, b->preSorted.as<u32>( ), b->preNmx.as<u32>( ),
+                                            waveSweep == 2 ? 1 : 0 );
                     hipLaunchKernelGGL( k_soc_windows, dim3( (unsigned)( ( n + A.lanes - 1 ) / A.lanes ) ), dim3( 64 ), 0, b->stream, A.X, A.P, (u32)n,
                                         A.lanes, A.roff, A.seed_off, A.seed_cnt, A.work, A.maxima, A.mm, A.setA, b->preSorted.as<u32>( ),
-                                        b->preNmx.as<u32>( ) );
+                                        b->preNmx.as<u32>( ), waveSweep );
+                }
             }
             A.pre_nmx = b->preNmx.as<u32>( );
             A.pre_sorted = b->preSorted.as<u32>( );

@@ -184,13 +184,15 @@ def test_bench_four_ranks_long_reads_both_scaling_modes(gpu_device):
 
 
 @pytest.mark.parametrize("env", [{"MA_CHAIN_WAVE_SORT": "0"}, {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "60"}, {"MA_WSORT_MIN": "100"},
-                                 {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "100"},
+                                 {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "100"}, {"MA_WSORT_MIN": "20", "MA_SOC_WAVE": "0"},
+                                 {"MA_WSORT_MIN": "20", "MA_SOC_WAVE": "2"}, {"MA_WSORT_MIN": "20"},
                                  {"MA_DP_ONE_STREAM": "1"}, {"MA_KSW_SCRATCH_MB": "64"}, {"MA_STITCH_WAVE": "0"}])
 def test_long_read_stage_variants_give_identical_results(gpu_device, monkeypatch, env):
     """Round-3 variants of the long-read stages forced through their hooks on one read set with repeats (many equal deltas
     and reference positions = ties in the sweep's sorts): the sweep's sorts inside the lane kernels / as wave-cooperative
     kernels with both launch sizes -- and (round 6) the launch whose arrays stay in global memory -- exercised (thresholds moved down to
-    test-sized reads), the DP classes on one stream / on
+    test-sized reads), the window sweep by one wavefront per read (round 6; with MA_WSORT_MIN=20 on every read of more than 20 seeds), by
+    lanes only (MA_SOC_WAVE=0) and through the wave kernel's fallback (2), the DP classes on one stream / on
     their own streams, a tiny DP scratch budget (every class split into tiers), the walk of the long alignments by one lane
     each instead of one wavefront each.  Every stage record equals the default's."""
     import ma_amd
