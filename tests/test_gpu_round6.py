@@ -302,3 +302,60 @@ def test_smem_seeding_of_long_reads_as_area_tasks(gpu_device, monkeypatch):
         monkeypatch.delenv("MA_SEED_TASK_CAPS")
     monkeypatch.delenv("MA_SEED_TASKS")
     idx.close()
+
+
+@pytest.mark.gpu
+def test_window_sweep_and_sorts_of_long_reads_by_one_wavefront(gpu_device, monkeypatch):
+    """The SoC sweep of long reads (stripOfConsideration.cpp:12-161, soc.h:362-404) one wavefront per read: the sorts on arrays in LDS
+    / in global memory (wave_sort.h), the window ends by binary search and the strip stack wave-uniformly (k_soc_windows_wave; VERDICT
+    round 5 item 5).  Reads on two large contigs with repeats (ties in delta and reference position) and CHIMERIC reads across the
+    borders of small adjacent contigs -- their seeds have equal deltas on both sides of a border, so the window must end where the
+    contig changes, and contig ids that do not rise along the deltas send the read to the kernel's lane form.  The harmonized seed
+    sets of every read (they depend on every strip of the sweep, on its order in the heap and on its reference rectangle) are the
+    oracle's and equal those of the lane kernels (MA_SOC_WAVE=0, MA_CHAIN_WAVE_SORT=0) and of the forced fallback (MA_SOC_WAVE=2),
+    with the thresholds at their defaults and moved down so that reads of 21 seeds and more take the wave kernels."""
+    import ma_amd
+    from ma_testlib import OrIndex, rand_genome, revcomp, sample_reads
+    g = rand_genome(61, [400000, 250000] + [6000] * 24, repeat_unit=400, repeat_copies=150, repeat_div=0.03)
+    idx = ma_amd.Index.build(g)
+    oidx = OrIndex.from_parts(idx.download())
+    rng = np.random.default_rng(62)
+    chim = []
+    for k in range(2, 24):
+        a, b = g[k], g[k + 1]
+        cut = int(rng.integers(1500, 4500))
+        rd = np.concatenate([a[-cut:], b[:6000 - cut]]).copy()
+        mut = rng.random(len(rd)) < 0.02
+        rd[mut] = (rd[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) % 4
+        chim.append(rd if k % 2 else revcomp(rd))
+    reads = (sample_reads(g[:2], 24, 30000, 63, sub=0.03, ins=0.03, dele=0.04) + sample_reads(g[:2], 30, 8000, 64, sub=0.01, ins=0.005, dele=0.005)
+             + chim + sample_reads(g, 40, 3000, 65, sub=0.02) + sample_reads(g, 60, 150, 66))
+    nb = sum(len(r) for r in reads)
+    for preset in ("default", "nanopore"):
+        res = oidx.align(reads, or_params(preset, 1), threads=8)
+        P = ma_amd.Params.preset(preset)
+        P.srand_seed = 1
+
+        def hsets():
+            bt = ma_amd.Batch(idx, P, len(reads), nb + 64)
+            bt.set_reads(reads)
+            bt.seed(), bt.extract(), bt.chain()
+            bt.sync()
+            out = bt.hsets()
+            n_seeds = np.diff(bt.seeds()[0].astype(np.int64))
+            bt.close()
+            return out, n_seeds
+
+        for env in ({}, {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "200"}, {"MA_WSORT_MIN": "20", "MA_SOC_WAVE": "2"}, {"MA_SOC_WAVE": "0"},
+                    {"MA_CHAIN_WAVE_SORT": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            (hoff, hsoff, hsoc, hseeds), n_seeds = hsets()
+            for k in env:
+                monkeypatch.delenv(k)
+            assert (n_seeds > 1024).sum() >= 10 and (n_seeds > 768).sum() >= 20, "the read set must reach the thresholds of the wave kernels"
+            assert np.array_equal(hoff, res["hset_off"]), (preset, env)
+            assert np.array_equal(hsoff, res["hseed_off"]), (preset, env)
+            assert np.array_equal(hsoc, res["hset_soc"]), (preset, env)
+            assert hseeds.tobytes() == res["hseeds"].tobytes(), (preset, env)
+    idx.close()
