@@ -91,3 +91,123 @@ def test_stage_logic_vs_oracle_long_reads(emul, tmp_path):
         run_oracle("pipe", case, preset, 5, str(tmp_path / "or.pipe"))
         subprocess.check_call([emul, case, preset, "5", str(tmp_path / "em.pipe"), "all"])
         assert first_diff(str(tmp_path / "or.pipe"), str(tmp_path / "em.pipe")) is None
+
+
+def test_window_sweep_restated_for_one_wavefront_is_the_references_loop():
+    """k_soc_windows_wave (stage_chain.h) restates the SoC sweep (stripOfConsideration.cpp:77-113 with push_back_no_overlap,
+    soc.h:362-404) as prefix sums + window ends by binary search + a strip stack whose top two entries carry the prefix sums at
+    their ends.  Both forms in plain Python on random seed lists with heavy ties in delta, several contigs and every strip
+    width: the same strips in the same order.  The binary search needs contig ids that do not fall along the deltas; lists
+    where they do are the ones the kernel hands to its lane form (and the restatement must then NOT be trusted: counted)."""
+    import numpy as np
+    rng = np.random.default_rng(17)
+
+    def less(a, b):  # SoCOrder::operator< (soc.h:71-76)
+        return a[1] > b[1] if a[0] == b[0] else a[0] < b[0]
+
+    def push(mx, cur, itS, itE, minScore, resum):
+        cur = list(cur)
+        while mx and mx[-1][3] > itS:
+            back = mx[-1]
+            if less(back, cur):
+                bb = back[2]
+                back[0], back[1] = resum(bb, itS)
+                back[3] = itS
+                if back[0] < minScore or back[0] == 0:
+                    mx.pop()
+            else:
+                be = back[3]
+                cur[0], cur[1] = resum(be, itE)
+                itS = be
+                if cur[0] < minScore or cur[0] == 0:
+                    return
+        mx.append([cur[0], cur[1], itS, itE])
+
+    def reference_form(delta, cid, ln, amb, strip, fmin):
+        n = len(delta)
+        resum = lambda b, e: (int(ln[b:e].sum()), int(amb[b:e].sum())) if e >= b else (0, 0)
+        mx, S, E, acc, am = [], 0, 0, 0, 0
+        while E != n and S != n:
+            while E != n and delta[S] + strip >= delta[E] and cid[S] == cid[E]:
+                acc += int(ln[E]); am += int(amb[E]); E += 1
+            if acc >= fmin:
+                push(mx, (acc, am), S, E, int(fmin), resum)
+            acc -= int(ln[S]); am -= int(amb[S]); S += 1
+        return mx
+
+    def wave_form(delta, cid, ln, amb, strip, fmin):
+        n = len(delta)
+        pl = np.concatenate([[0], np.cumsum(ln)]).astype(np.int64)
+        pa = np.concatenate([[0], np.cumsum(amb)]).astype(np.int64)
+        winE = np.zeros(n, dtype=np.int64)
+        for S in range(n):
+            lo, hi = S + 1, n
+            while lo < hi:
+                mid = lo + (hi - lo) // 2
+                if delta[mid] > delta[S] + strip or cid[mid] != cid[S]:
+                    hi = mid
+                else:
+                    lo = mid + 1
+            winE[S] = lo
+        # the stack as the kernel keeps it: the array in memory (written whenever an entry changes and stays), the top two entries
+        # in registers with the prefix sums at their ends -- [accLen, amb, b, e, plb, pab, ple, pae]
+        mem, nmx, top, second = {}, 0, None, None
+        minScore = int(fmin)
+        for S in range(n):
+            E = int(winE[S])
+            plS, paS, plE, paE = int(pl[S]), int(pa[S]), int(pl[E]), int(pa[E])
+            cur = [plE - plS, paE - paS]
+            if cur[0] >= fmin:
+                itS, plI, paI, drop = S, plS, paS, False
+                while nmx > 0 and top[3] > itS:
+                    if less(top, cur):
+                        top[0], top[1] = (0, 0) if itS < top[2] else (plI - top[4], paI - top[5])
+                        top[3], top[6], top[7] = itS, plI, paI
+                        if top[0] < minScore or top[0] == 0:
+                            nmx -= 1
+                            if nmx > 0:
+                                if second is not None:
+                                    top, second = second, None
+                                else:
+                                    m = mem[nmx - 1]
+                                    top = m + [int(pl[m[2]]), int(pa[m[2]]), int(pl[m[3]]), int(pa[m[3]])]
+                        else:
+                            mem[nmx - 1] = top[:4]
+                    else:
+                        be = top[3]
+                        cur = [0, 0] if E < be else [plE - top[6], paE - top[7]]
+                        itS, plI, paI = be, top[6], top[7]
+                        if cur[0] < minScore or cur[0] == 0:
+                            drop = True
+                            break
+                if not drop:
+                    if nmx > 0:
+                        second = list(top)
+                    top = [cur[0], cur[1], itS, E, plI, paI, plE, paE]
+                    mem[nmx] = top[:4]
+                    nmx += 1
+            if E == n:
+                break
+        return [mem[k] for k in range(nmx)]
+
+    falling = 0
+    for case in range(1500):
+        n = int(rng.integers(1, 120))
+        n_contigs = int(rng.integers(1, 4))
+        cid = np.sort(rng.integers(0, n_contigs, size=n))
+        delta = np.sort(rng.integers(0, int(rng.choice([8, 60, 2000])), size=n)).astype(np.int64)
+        if case % 5 == 4 and n > 3:  # contig ids that fall along the deltas somewhere
+            i = int(rng.integers(0, n - 1))
+            cid[i], cid[i + 1] = max(cid[i], cid[i + 1]) + 1, min(cid[i], cid[i + 1])
+        ln = rng.integers(1, 40, size=n).astype(np.int64)
+        amb = rng.integers(1, 4, size=n).astype(np.int64)
+        strip = int(rng.choice([0, 3, 25, 500]))
+        fmin = float(rng.choice([0.0, 16.0, 60.5, 300.0]))
+        monotone = bool(np.all(np.diff(cid) >= 0))
+        a = reference_form(delta, cid, ln, amb, strip, fmin)
+        if not monotone:
+            falling += 1
+            continue
+        b = wave_form(delta, cid, ln, amb, strip, fmin)
+        assert a == b, (case, n, strip, fmin)
+    assert 100 < falling < 400
