@@ -1,5 +1,5 @@
 #!/bin/bash
-# Everything the round's committed numbers come from, in one GPU call (≈35 min of box time in round 6): parity tests, rocprofv3
+# Everything the round's committed numbers come from, in one GPU call (≈38 min of box time in round 6; the part before QUICK's exit ≈23 min): parity tests, rocprofv3
 # kernel stats + PMC passes of the four workloads, the bench line (all workloads, three legs each, C1 anchor, boundary), the
 # kernel trace of the leg `value` comes from and its concurrency timeline, the overlap matrix, the phase profile of
 # k_ksw_pk<5>, SQ counters of the 10 kb DP stage, launch timelines.  tools/evidence_to_profiles.sh copies what is to be judged
@@ -57,6 +57,10 @@ for wl in 50kb 10kb 50kb_nanopore; do
 rocprofv3 --kernel-trace -d gpurun_out/tr_$wl -o tr --output-format csv -- python3 bench.py --workload $wl --steps 1 --warmup 1 --cpu-sample 0 --boundary-reads 0 --overlap 0 > gpurun_out/tr_$wl.log 2>&1
 python3 tools/launch_list.py gpurun_out/tr_$wl k_ksw k_job_cost k_chain k_sort_seeds k_soc_windows k_stitch k_seed k_task k_dp_enum > gpurun_out/${TAG}_launch_timeline_$wl.txt; rm -rf gpurun_out/tr_$wl
 done
+# the chain stage of the long-read workloads: its wave kernels on / off, and the phases of what is left one read per lane
+bash tools/chain_ab.sh > gpurun_out/${TAG}_chain_wave_ab.txt 2>&1
+make -s -C ma_amd/csrc chainprof > /dev/null 2>&1
+for wl in 50kb_nanopore 50kb 10kb; do echo "== $wl"; python3 tools/chain_prof.py --workload $wl 2>&1 | grep -v "^{" | grep -v amdgpu.ids | grep -v "^bench detail" | tail -11; done > gpurun_out/${TAG}_chain_phase_profile.txt
 python3 tools/ksw_prof.py --workload 150bp --boundary-reads 0 --overlap 0 2>&1 | grep -v "^{" | grep -v "^bench detail:" | grep -v amdgpu.ids > gpurun_out/${TAG}_ext_pairing_bound.txt
 python3 - <<PY
 import json
