@@ -302,6 +302,17 @@ int main( int argc, char** argv )
         std::vector<ma_segment> stage( seg_cap ), sa( qlen + 2 ), sb( qlen + 2 );
         std::vector<u32> seedStack( 2 * MA_SEED_STACK );
         SeedScratch SS{ stage.data( ), seg_cap, sa.data( ), sb.data( ), qlen + 2, SP.min_seed_size_drop, seedStack.data( ) };
+        // round 6: the first n entries of each list in a separate array, as k_seed_tasks_smem keeps them in LDS (SeedScratch::lds).  The
+        // array starts out as garbage: an entry that is read before it was written shows up in the dump
+        std::vector<u64> heads;
+        if( const char* e = getenv( "MA_EMUL_SMEM_LDS_HEADS" ) )
+        {
+            const u32 nh = std::min<u32>( (u32)std::max( 0, atoi( e ) ), qlen + 2 );
+            heads.assign( (size_t)4 * nh + 2, ~0ull );
+            SS.lds = heads.data( );
+            SS.lds_n = nh;
+            SS.lds_stride = 1;
+        }
         SeedLane L;
         u32 nseg = 0;
         if( SP.technique == 2 )

@@ -61,7 +61,8 @@ def test_smem_compact_entries_vs_reference_golden_and_long_reads(emul, tmp_path)
     """The 16-byte SMEM list entries (seeding.h smem_pack: three 35-bit interval fields + ONE 22-bit length; the start of the
     match is shared by all entries of a list and named by the reader) give the compiled reference's Illumina dump and, for reads
     of 2047 / 2048 / 20 000 bases (round 4's two 11-bit fields ended at 2047), the oracle's.  The 40-byte form of the same run
-    aborts if an entry's own start ever differs from the shared one (smem_get, host build)."""
+    aborts if an entry's own start ever differs from the shared one (smem_get, host build).  Round 6: the same with the heads of the
+    two lists in a separate array that starts out as garbage (SeedScratch::lds -- LDS in k_seed_tasks_smem)."""
     case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
     ref = gunzip_to(os.path.join(G, "small_ref.illumina.pipe.gz"), str(tmp_path / "ref.pipe"))
     out = str(tmp_path / "emul.pipe")
@@ -69,16 +70,21 @@ def test_smem_compact_entries_vs_reference_golden_and_long_reads(emul, tmp_path)
         subprocess.check_call([emul, case, "illumina", "1", out, "all"],
                               env=dict(os.environ, MA_EMUL_SMEM_MERGE=merge, MA_EMUL_SMEM_COMPACT="1"))
         assert first_diff(ref, out) is None
+        # round 6: the first 1 / 3 / 6 entries of each list in their own array (k_seed_tasks_smem keeps them in LDS)
+        for heads in ("1", "3", "6"):
+            subprocess.check_call([emul, case, "illumina", "1", out, "all"],
+                                  env=dict(os.environ, MA_EMUL_SMEM_MERGE=merge, MA_EMUL_SMEM_COMPACT="1", MA_EMUL_SMEM_LDS_HEADS=heads))
+            assert first_diff(ref, out) is None, (merge, heads)
     g = rand_genome(78, [300000, 200000], repeat_unit=250, repeat_copies=60, repeat_div=0.05)
     reads = (sample_reads(g, 4, 2047, 1, sub=0.03, ins=0.02, dele=0.02) + sample_reads(g, 4, 2048, 2, sub=0.03, ins=0.02, dele=0.02)
              + sample_reads(g, 1, 20000, 3, sub=0.03, ins=0.03, dele=0.03, n_rate=0.001))
     c2 = str(tmp_path / "c.case")
     write_case(c2, g, reads)
     run_oracle("pipe", c2, "illumina", 5, str(tmp_path / "or.pipe"))
-    for compact in ("0", "1"):
+    for compact, heads in (("0", "0"), ("1", "0"), ("1", "6"), ("1", "2")):
         subprocess.check_call([emul, c2, "illumina", "5", str(tmp_path / "em.pipe"), "all"],
-                              env=dict(os.environ, MA_EMUL_SMEM_MERGE="1", MA_EMUL_SMEM_COMPACT=compact))
-        assert first_diff(str(tmp_path / "or.pipe"), str(tmp_path / "em.pipe")) is None
+                              env=dict(os.environ, MA_EMUL_SMEM_MERGE="1", MA_EMUL_SMEM_COMPACT=compact, MA_EMUL_SMEM_LDS_HEADS=heads))
+        assert first_diff(str(tmp_path / "or.pipe"), str(tmp_path / "em.pipe")) is None, (compact, heads)
 
 
 def test_stage_logic_vs_oracle_long_reads(emul, tmp_path):
