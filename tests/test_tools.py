@@ -66,3 +66,35 @@ def test_per_kernel_roofline_is_the_rows_arithmetic():
     assert e["lane_insts_per_cell"] == pytest.approx(3.5e9 * 64 / 4.0e9, abs=0.1)
     assert pk["k_ksw_band (long)"]["lane_insts_per_cell"] == pytest.approx(2.0e10 * 64 / 1.0e10, abs=0.1)
     assert "valu_frac" not in pk["k_seed"] and pk["k_seed"]["hbm_frac"] == pytest.approx(1.6e10 / 8e-3 / 1e9 / 8000.0, abs=1e-4)
+
+
+def test_seeding_task_kernels_keep_their_lane_state_out_of_scratch_memory(tmp_path):
+    """Round 6: the two selects of seed_qbyte (seeding.h) had been folded into one load through a selected address, which kept the whole
+    SeedLane of k_seed_tasks / k_seed_tasks_smem in scratch memory -- 83 / 90 scratch stores in their loops, 0.76 TB of writes per
+    Nanopore step, invisible in the spill counts.  The gfx950 assembly of the shipped sources (hipcc cross-compiles without a GPU) must
+    have no scratch traffic in those kernels beyond the handful of SGPR-spill slots, and no VGPR spills in any seeding kernel."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    asm = str(tmp_path / "pipeline.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "pipeline.hip", "-o", asm],
+                          cwd=os.path.join(ROOT, "ma_amd", "csrc"), stderr=subprocess.DEVNULL)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "kernel_regs.py"), asm, "k_seed"], text=True)
+    rows = {}
+    for line in out.splitlines():
+        t = line.split()
+        rows[t[0]] = dict(vgpr=int(t[2]), vspill=int(t[4]), scratch=int(t[10]), lds=int(t[12]))
+    tasks = [k for k in rows if "k_seed_tasks" in k]
+    assert len(tasks) == 2, rows.keys()
+    for k, r in rows.items():
+        if "k_seed_rows" in k or "k_seed_final" in k:
+            continue
+        assert r["vspill"] == 0, (k, r)
+    text = open(asm).read()
+    for k in tasks:
+        body = text[text.index("\n" + k + ":"):]
+        body = body[:body.index("s_endpgm")]
+        assert body.count("scratch_store") <= 8 and body.count("scratch_load") <= 8, (k, body.count("scratch_store"), body.count("scratch_load"))
+        assert rows[k]["scratch"] <= 96, (k, rows[k])
+    smem = [k for k in tasks if "smem" in k][0]
+    assert rows[smem]["scratch"] == 0 and rows[smem]["lds"] == 49152, rows[smem]  # no scratch at all; six heads of two lists per lane in LDS
