@@ -183,7 +183,7 @@ def test_bench_four_ranks_long_reads_both_scaling_modes(gpu_device):
     assert ww["value"] > 0 and ws["value"] > 0
 
 
-@pytest.mark.parametrize("env", [{"MA_CHAIN_WAVE_SORT": "0"}, {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "60"}, {"MA_WSORT_MIN": "100"},
+@pytest.mark.parametrize("env", [{"MA_CHAIN_WAVE_SORT": "0"}, {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "80"}, {"MA_WSORT_MIN": "100"},
                                  {"MA_WSORT_MIN": "20", "MA_WSORT_SMALL": "100"}, {"MA_WSORT_MIN": "20", "MA_SOC_WAVE": "0"},
                                  {"MA_WSORT_MIN": "20", "MA_SOC_WAVE": "2"}, {"MA_WSORT_MIN": "20"},
                                  {"MA_DP_ONE_STREAM": "1"}, {"MA_KSW_SCRATCH_MB": "64"}, {"MA_STITCH_WAVE": "0"}])
