@@ -217,3 +217,44 @@ def test_window_sweep_restated_for_one_wavefront_is_the_references_loop():
         b = wave_form(delta, cid, ln, amb, strip, fmin)
         assert a == b, (case, n, strip, fmin)
     assert 100 < falling < 400
+
+
+def test_stage_logic_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """GPU AddressSanitizer is not available on the pool: the sanitizers run on the CPU build of the SAME stage logic
+    (tests/emul/host_emul.cpp over ma_amd/csrc/{seeding,chain,nw,stdsort,fm_device}.h), compiled with clang's
+    -fsanitize=address,undefined.  The reference's golden dumps (Default and Illumina presets; SMEM lists with their heads in a
+    separate array) and long reads against the oracle: no sanitizer report, the same bytes.  (g++'s -fsanitize=shift is not
+    used: it miscomputes the index of `(c ? a : b)[k >> s]` in fm_device.h's sa_sample -- the shift exponent it checks is a
+    pointer's low word -- and changes the program's results without any report.)"""
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang")
+    build_oracle()
+    exe = str(tmp_path / "host_emul_san")
+    subprocess.check_call([clang, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off", "-w",
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "emul", "host_emul.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "oracle"), "-lma_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")])
+
+    def run(case, preset, seed, out, **env):
+        p = subprocess.run([exe, case, preset, str(seed), out, "all"], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", **env),
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert "runtime error" not in p.stderr and "Sanitizer" not in p.stderr, p.stderr[-2000:]
+
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    out = str(tmp_path / "emul.pipe")
+    run(case, "default", 1, out)
+    assert first_diff(gunzip_to(os.path.join(G, "small_ref.default.pipe.gz"), str(tmp_path / "ref_d.pipe")), out) is None
+    ref = gunzip_to(os.path.join(G, "small_ref.illumina.pipe.gz"), str(tmp_path / "ref_i.pipe"))
+    for env in (dict(), dict(MA_EMUL_SMEM_MERGE="1", MA_EMUL_SMEM_COMPACT="1", MA_EMUL_SMEM_LDS_HEADS="6")):
+        run(case, "illumina", 1, out, **env)
+        assert first_diff(ref, out) is None, env
+    g = rand_genome(78, [300000, 200000], repeat_unit=250, repeat_copies=60, repeat_div=0.05)
+    reads = (sample_reads(g, 4, 2047, 1, sub=0.03, ins=0.02, dele=0.02) + sample_reads(g, 2, 20000, 3, sub=0.03, ins=0.03, dele=0.03, n_rate=0.001)
+             + sample_reads(g, 30, 150, 4) + sample_reads(g, 6, 6000, 5, sub=0.01, ins=0.005, dele=0.005))
+    c2 = str(tmp_path / "long.case")
+    write_case(c2, g, reads)
+    for preset, env in (("default", dict()), ("illumina", dict(MA_EMUL_SMEM_MERGE="1", MA_EMUL_SMEM_COMPACT="1", MA_EMUL_SMEM_LDS_HEADS="4"))):
+        run_oracle("pipe", c2, preset, 5, str(tmp_path / "or.pipe"))
+        run(c2, preset, 5, out, **env)
+        assert first_diff(str(tmp_path / "or.pipe"), out) is None, preset
