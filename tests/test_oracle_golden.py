@@ -111,3 +111,34 @@ def test_f4_golden(tmp_path, cfg):
     run_oracle("f4", case, preset, 1, str(tmp_path / "or.f4"), inv, paired, zd)
     ref = gunzip_to(os.path.join(G, nm + ".f4.gz"), str(tmp_path / "ref.f4"))
     assert first_diff(ref, str(tmp_path / "or.f4")) is None
+
+
+def test_oracle_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The checker itself under clang's -fsanitize=address,undefined: the index files, the extend_backward traces, the pipeline dumps of
+    three parameter sets and the kswcpp cases of the compiled reference come out byte for byte, with no sanitizer report -- an
+    oracle that agrees with the reference through undefined behaviour would be no oracle."""
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        pytest.skip("no clang")
+    exe = str(tmp_path / "oracle_dump_san")
+    subprocess.check_call([clang, "-std=c++17", "-O1", "-g", "-msse4.1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off", "-w",
+                           os.path.join(ROOT, "oracle", "ma_oracle.cpp"), os.path.join(ROOT, "oracle", "oracle_dump.cpp"), "-o", exe, "-lpthread"])
+
+    def run(*args):
+        p = subprocess.run([exe] + [str(a) for a in args], env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert "runtime error" not in p.stderr and "Sanitizer" not in p.stderr, p.stderr[-2000:]
+
+    case = gunzip_to(os.path.join(G, "small.case.gz"), str(tmp_path / "small.case"))
+    run("index", case, str(tmp_path / "or"))
+    for ext in ("bwt", "sa", "pac"):
+        assert filecmp.cmp(gunzip_to(os.path.join(G, "small_ref.%s.gz" % ext), str(tmp_path / ("ref." + ext))), str(tmp_path / ("or." + ext)), shallow=False), ext
+    run("ext", case, str(tmp_path / "or.ext"))
+    assert first_diff(gunzip_to(os.path.join(G, "small_ref.ext.gz"), str(tmp_path / "ref.ext")), str(tmp_path / "or.ext")) is None
+    for preset, seed, name in (("default", 1, "small_ref.default.pipe"), ("illumina", 1, "small_ref.illumina.pipe"), ("default+mems", 1, "small_ref.mems.pipe")):
+        run("pipe", case, preset, seed, str(tmp_path / "or.pipe"))
+        assert first_diff(gunzip_to(os.path.join(G, name + ".gz"), str(tmp_path / name)), str(tmp_path / "or.pipe")) is None, name
+    kcase = gunzip_to(os.path.join(G, "ksw.case.gz"), str(tmp_path / "ksw.case"))
+    run("ksw", kcase, str(tmp_path / "or.out"))
+    assert first_diff(gunzip_to(os.path.join(G, "ksw_ref.out.gz"), str(tmp_path / "ref.out")), str(tmp_path / "or.out")) is None
